@@ -1,0 +1,178 @@
+"""Pins the CPU oracle against golden vectors produced by importing the
+reference (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import torch
+
+from oracle import hand_ref as H
+from oracle import image_ref as I
+
+
+def T(a):
+    return torch.tensor(np.asarray(a))
+
+
+def close(a, b, atol=1e-5, rtol=1e-5):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    np.testing.assert_allclose(a, b, atol=atol, rtol=rtol)
+
+
+def test_model_buffers(golden, oracle_hand):
+    hm = oracle_hand
+    assert np.array_equal(hm.faces.numpy(), golden["mano_faces"])
+    assert np.array_equal(np.array([f.shape[0] for f in hm.joint_faces]), golden["mano_joint_faces_len"])
+    assert np.array_equal(torch.cat(hm.joint_faces).numpy(), golden["mano_joint_faces_cat"])
+    assert np.array_equal(np.array([f.shape[0] for f in hm.finger_faces]), golden["mano_finger_faces_len"])
+    assert np.array_equal(torch.cat(hm.finger_faces).numpy(), golden["mano_finger_faces_cat"])
+    assert np.array_equal(hm.coll_mask.numpy().astype(np.uint8), golden["mano_coll_mask"])
+    assert np.array_equal(hm.parents, golden["mano_parents"])
+
+
+def test_rodrigues_quat(golden):
+    close(H.rodrigues(T(golden["rod_in"])), golden["rod_out"], atol=1e-6)
+    close(H.quat_to_mat(T(golden["quat_in"])), golden["quat_out"], atol=1e-6)
+
+
+def test_mano_forward_and_grad(golden, oracle_hand):
+    P = T(golden["mano_params"]).requires_grad_(True)
+    v, j, Rs = H.mano_forward(oracle_hand, P[:, 48:58], P[:, 3:48], P[:, :3])
+    close(v, golden["mano_fwd_verts"], atol=2e-6)
+    close(j, golden["mano_fwd_joints"], atol=2e-6)
+    close(Rs, golden["mano_fwd_Rs"], atol=2e-6)
+    v2, j2 = H.mano_vertices(oracle_hand, P[:, :3], P[:, 3:48], P[:, 48:58], P[:, 58:62], global_scale=1 / 125)
+    close(v2, golden["mano_gmv_verts"], atol=1e-5)
+    close(j2, golden["mano_gmv_joints"], atol=1e-5)
+    loss = (v2 * T(golden["mano_gw_verts"])).sum() + (j2 * T(golden["mano_gw_joints"])).sum()
+    g, = torch.autograd.grad(loss, P)
+    ref = golden["mano_grad_params"]
+    assert np.abs(g.numpy() - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_mano_quaternion_root(golden, oracle_hand):
+    P = T(golden["mano_quat_params"])
+    v, j = H.mano_vertices(oracle_hand, P[:, :4], P[:, 4:49], P[:, 49:59], P[:, 59:63])
+    close(v, golden["mano_quat_verts"], atol=2e-3, rtol=1e-5)      # mm units
+    close(j, golden["mano_quat_joints"], atol=2e-3, rtol=1e-5)
+
+
+def test_spheres_collision_seg(golden, oracle_hand):
+    j = T(golden["mano_gmv_joints"]).requires_grad_(True)
+    v = T(golden["mano_gmv_verts"]).requires_grad_(True)
+    c, r = H.sphere_set(oracle_hand, j, v)
+    close(c, golden["sph_c"], atol=1e-6)
+    close(r, golden["sph_r"], atol=1e-6)
+    val = H.collision_loss(oracle_hand, j, v)
+    close(val, golden["coll_val"], atol=1e-7)
+    gj, gv = torch.autograd.grad(val, (j, v))
+    close(gj, golden["coll_grad_j"], atol=1e-6)
+    close(gv, golden["coll_grad_v"], atol=1e-6)
+    j2 = T(golden["coll2_j"]).requires_grad_(True)
+    v2 = T(golden["coll2_v"]).requires_grad_(True)
+    val2 = H.collision_loss(oracle_hand, j2, v2)
+    close(val2, golden["coll2_val"], atol=1e-7)
+    gj2, gv2 = torch.autograd.grad(val2, (j2, v2))
+    close(gj2, golden["coll2_grad_j"], atol=1e-6)
+    close(gv2, golden["coll2_grad_v"], atol=1e-6)
+    seg = H.segment_points(oracle_hand, T(golden["seg_joints_pix"]), T(golden["mano_gmv_joints"]),
+                           T(golden["mano_gmv_verts"]), T(golden["seg_pcl_in"]))
+    assert np.array_equal(seg.numpy().astype(np.int32), golden["seg_out"])
+
+
+def test_crop_matrix_chain(golden):
+    c3, cube = golden["crop_center3d"], golden["crop_cube"]
+    c2 = I.project_points(c3)
+    assert np.array_equal(c2, golden["crop_center2d"])
+    xs, xe, ys, ye, zs, ze = I.crop_bounds(c2, cube)
+    assert np.array_equal(np.stack([xs, xe, ys, ye], 1), golden["crop_bounds"])
+    assert np.array_equal(np.stack([zs, ze], 1), golden["crop_zbounds"])
+    M = I.crop_matrix(xs, xe, ys, ye)
+    assert np.array_equal(M, golden["crop_M"])
+
+
+def test_warp_index_map_bit_exact(golden):
+    idx = I.warp_source_index(golden["crop_Minv"])
+    assert np.array_equal(idx, golden["warp_srcidx"])
+
+
+def test_resize_rowmap_matches_torch(golden):
+    # the 640->480 row table is *derived from torch's own ops* (SURVEY H3); the
+    # committed golden is the canonical table.
+    import torch.nn.functional as Fn
+    idx = torch.arange(640, dtype=torch.float32).view(1, 1, 640, 1).expand(1, 1, 640, 640).contiguous()
+    theta = torch.tensor([[[1.0, 0, 0], [0, 1.0, 0]]])
+    grid = Fn.affine_grid(theta, (1, 1, 480, 640), align_corners=False)
+    rows = Fn.grid_sample(idx, grid, mode="nearest", align_corners=False)[0, 0, :, 0].numpy().astype(np.int16)
+    assert np.array_equal(rows, golden["resize_rowmap"])
+
+
+def test_normalize_jointtrans(golden):
+    out = I.normalize_depth(golden["norm_in"], golden["crop_center2d"][:, 2], golden["crop_cube"][:, 2])
+    assert np.array_equal(out, golden["norm_out"])
+    jt = I.joint_trans(golden["jt_in"], golden["crop_M"], golden["crop_center2d"], golden["crop_cube"])
+    close(jt, golden["jt_out"], atol=1e-6)
+    close(I.project_points(golden["jt_in"]), golden["p3d2img_out"], atol=1e-4)
+
+
+def test_loader_utils(golden):
+    c3, cube, M, Minv = golden["crop_center3d"], golden["crop_cube"], golden["crop_M"], golden["crop_Minv"]
+    xyz = I.uvd_to_xyz(golden["ld_uvd"], c3, Minv, cube)
+    close(xyz, golden["ld_uvd2xyznl"], atol=2e-6)
+    close(I.uvd_to_xyz(golden["ld_uvd"], c3, Minv, cube, normalise=False), golden["ld_uvd2xyz"], atol=2e-4)
+    close(I.xyz_to_uvd(golden["ld_uvd2xyznl"], c3, M, cube), golden["ld_xyznl2uvd"], atol=2e-6)
+    full_in, full_out = golden["ld_crop_hand_full_in"], golden["ld_crop_hand_full_out"]
+    ch = I.crop_hand(full_in, golden["ld_crop_joints"][:2], c3[:2], Minv[:2], cube[:2])
+    assert (ch != full_out).mean() < 1e-4          # boundary pixels may flip on 1-ulp differences
+    a, b = I.depth_image_to_xyz(full_in, c3[:2], Minv[:2], cube[:2])
+    close(a[:, :, ::4, ::4], golden["ld_xyzimg"][:2], atol=2e-4)
+    close(b[:, :, ::4, ::4], golden["ld_xyzimg_n"][:2], atol=2e-6)
+
+
+def test_img2pcl_deterministic_branches(golden):
+    img = np.ones((3, 1, 128, 128), dtype=np.float32)
+    img[:, :, :16] = golden["i2p_img"]
+    c3, cube, Minv = golden["crop_center3d"][:3], golden["crop_cube"][:3], golden["crop_Minv"][:3]
+    cand = I.image_to_points_candidates(img, c3, Minv, cube)
+    out = golden["i2p_out"]
+    assert cand[0].shape[0] == 2048 and cand[1].shape[0] == 1024 and cand[2].shape[0] == 0
+    # exactly sample_num valid points: the reference still draws a multinomial permutation -> same SET
+    srt = lambda a: a[np.lexsort(a.T[::-1])]
+    close(srt(cand[0]), srt(out[0]), atol=2e-6)
+    close(np.concatenate([cand[1], cand[1]]), out[1], atol=2e-6)   # exact multiple: tiled, no RNG
+    assert not out[2].any()
+
+
+def test_img2pcl_random_branch_is_a_valid_sample(golden):
+    img = golden["i2p_rand_img"]
+    c3, cube, Minv = golden["crop_center3d"][:2], golden["crop_cube"][:2], golden["crop_Minv"][:2]
+    cand = I.image_to_points_candidates(img, c3, Minv, cube)
+    out = golden["i2p_rand_out"]
+    for b in range(2):
+        rows = {tuple(np.round(r, 5)) for r in cand[b]}
+        assert all(tuple(np.round(r, 5)) in rows for r in out[b])
+    n1 = cand[1].shape[0]                                   # 900 -> 2 full copies + 248 w/o replacement
+    close(out[1][:2 * n1], np.concatenate([cand[1], cand[1]]), atol=2e-6)
+    tail = [tuple(np.round(r, 5)) for r in out[1][2 * n1:]]
+    assert len(set(tail)) == len(tail) == 2048 - 2 * n1
+
+
+def test_gfm_and_losses(golden):
+    j = T(golden["gfm_joints"]).requires_grad_(True)
+    dep = T(golden["gfm_depth"])
+    feat = I.joints_to_offset_maps(j, dep)
+    close(feat[:, :, ::4, ::4], golden["gfm_feat_sub"], atol=2e-6)
+    close(feat.double().sum((2, 3)), golden["gfm_feat_sum"], atol=1e-3)
+    gw = np.random.default_rng(77).normal(size=tuple(feat.shape)).astype(np.float32)
+    gj, = torch.autograd.grad((feat * T(gw)).sum(), j)
+    close(gj, golden["gfm_grad_joints"], atol=2e-3, rtol=1e-4)
+    offs = T((feat.detach().numpy() + np.random.default_rng(78).normal(size=tuple(feat.shape)) * 0.05)
+             .astype(np.float32)).requires_grad_(True)
+    dec = I.offset_maps_to_joints(offs, dep)
+    close(dec, golden["gfm_dec_joints"], atol=2e-6)
+    gwj = np.random.default_rng(79).normal(size=(2, 21, 3)).astype(np.float32)
+    go, = torch.autograd.grad((dec * T(gwj)).sum(), offs)
+    close(go[:, :, ::4, ::4], golden["gfm_dec_grad_sub"], atol=1e-7, rtol=1e-4)
+    a = T(golden["sl1_a"]).requires_grad_(True)
+    val = I.huber(a, T(golden["sl1_b"]))
+    close(val, golden["sl1_val"], atol=1e-8, rtol=1e-5)
+    ga, = torch.autograd.grad(val, a)
+    close(ga, golden["sl1_grad"], atol=1e-9, rtol=1e-5)
+    close(I.masked_depth_l1(T(golden["dl_a"]), T(golden["dl_b"])), golden["dl_val"], atol=1e-7)
