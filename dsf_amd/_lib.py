@@ -1,0 +1,99 @@
+"""ctypes binding of libdsf_hip.so (the C ABI declared in include/dsf_hip.h).
+
+There is NO CPU fallback: if the shared library is missing, or an op is handed a
+non-GPU tensor, the call raises.  The library is built in-tree by
+``dsf_amd/csrc/build.sh`` (``__graft_entry__.build()``).
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdsf_hip.so")
+
+c_float_p = ctypes.c_void_p
+_lib = None
+
+
+class MissingNativeLibrary(RuntimeError):
+    pass
+
+
+class dsf_mano_model(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in (
+        "v_template", "shapedirs", "posedirs", "j_regressor", "j_template", "j_shapedirs", "hands_comp",
+        "hands_mean", "weights", "parents", "wrist_ring", "jreg_rowptr", "jreg_col", "jreg_val")]
+
+
+class dsf_camera(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_float) for n in ("fx", "fy", "px", "py", "img_w", "img_h")]
+
+
+class dsf_sphere_model(ctypes.Structure):
+    _fields_ = [("jreg_mask", ctypes.c_void_p), ("coll_mask", ctypes.c_void_p),
+                ("t_finger", ctypes.c_float * 3), ("t_palm", ctypes.c_float * 4)]
+
+
+# every symbol include/dsf_hip.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "dsf_abi_version", "dsf_status_string", "dsf_mano_forward", "dsf_mano_backward", "dsf_project_face_verts",
+    "dsf_rasterize_meshes", "dsf_rasterize_meshes_backward", "dsf_crop_setup", "dsf_render_crop_forward",
+    "dsf_render_crop_backward", "dsf_point_face_dist_forward", "dsf_point_face_dist_backward",
+    "dsf_mesh_point_dist_forward", "dsf_mesh_point_dist_backward", "dsf_sphere_set", "dsf_collision_forward",
+    "dsf_collision_backward", "dsf_seg_pcl", "dsf_uvd_to_xyz", "dsf_xyz_to_uvd", "dsf_uvd_to_xyz_backward",
+    "dsf_xyz_to_uvd_backward", "dsf_crop_hand", "dsf_img2pcl", "dsf_joint2offset_forward",
+    "dsf_joint2offset_backward", "dsf_offset2joint_forward", "dsf_offset2joint_backward",
+]
+
+
+def lib():
+    """Loads the native library or raises MissingNativeLibrary (never falls back)."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise MissingNativeLibrary(
+                "libdsf_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(dsf_amd has no CPU fallback)" % LIB_PATH)
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.dsf_status_string.restype = ctypes.c_char_p
+        for s in SYMBOLS:
+            getattr(_lib, s)
+    return _lib
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a contiguous GPU tensor (None -> NULL)."""
+    if t is None:
+        return ctypes.c_void_p(0)
+    if not t.is_cuda:
+        raise RuntimeError("dsf_amd ops run on the GPU only (got a %s tensor); there is no CPU path" % t.device)
+    if not t.is_contiguous():
+        raise RuntimeError("dsf_amd ops need contiguous tensors")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def f32(t):
+    """Contiguous fp32 view/copy of a GPU tensor (plumbing)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def check(status, what):
+    if status != 0:
+        raise RuntimeError("%s failed: %s" % (what, lib().dsf_status_string(status).decode()))
+
+
+def camera(paras, image_size):
+    fx, fy, px, py = paras
+    return dsf_camera(float(fx), float(fy), float(px), float(py), float(image_size[0]), float(image_size[1]))
+
+
+F = ctypes.c_float
+I = ctypes.c_int
+I64 = ctypes.c_int64

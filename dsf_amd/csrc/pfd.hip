@@ -1,0 +1,341 @@
+// K3/K4: point -> triangle squared distance (pytorch3d==0.4.0 semantics, SURVEY.md
+// Appendix A.4) for gfx950.
+//
+// One lane owns one point; the triangles of the point's mesh are staged through LDS in
+// chunks of 256 records (one record built per lane: vertices, unit normal and the
+// Gram-matrix invariants, computed once per workgroup instead of once per pair) and read
+// back as wave-uniform broadcasts.  The kernel is VALU-bound (about 120 flops and five
+// IEEE divisions per pair), not HBM-bound.
+//
+// Argmin ties (ubiquitous: a point nearest to a shared edge sees the same distance from
+// both triangles) resolve to the lowest triangle index, as in the oracle; for that the
+// per-pair arithmetic below is the oracle's, operation for operation (-ffp-contract=off).
+//
+// The fused batched form used by ICPLoss / JointICPLoss tests each point only against the
+// triangles of its own part: the point list of a (sample, part) workgroup is compacted in
+// LDS first, so all lanes stay busy (the reference replicates the cloud 15x and throws
+// 14/15 of the results away, metric/meshLoss.py:377-395).
+#include "common.h"
+
+namespace {
+
+constexpr float kEps = 1e-8f;
+constexpr int CHUNK = 256;
+
+struct TriRec {                 // 80 B
+    float v0x, v0y, v0z, v1x, v1y, v1z, v2x, v2y, v2z;
+    float nx, ny, nz;           // normal / (|normal| + eps)
+    float nn;                   // |normal|
+    float d00, d01, d11, denom; // Gram invariants of (v1-v0, v2-v0)
+    float l12;                  // |v2-v1|^2
+    int id;
+    int pad;
+};
+
+__device__ __forceinline__ TriRec make_tri(f3 v0, f3 v1, f3 v2, int id) {
+    TriRec r;
+    r.v0x = v0.x; r.v0y = v0.y; r.v0z = v0.z; r.v1x = v1.x; r.v1y = v1.y; r.v1z = v1.z;
+    r.v2x = v2.x; r.v2y = v2.y; r.v2z = v2.z;
+    const f3 q0 = v1 - v0, q1 = v2 - v0;
+    const f3 n = cross(q1, q0);
+    r.nn = sqrtf(dot(n, n));
+    const float den = r.nn + kEps;
+    r.nx = n.x / den; r.ny = n.y / den; r.nz = n.z / den;
+    r.d00 = dot(q0, q0); r.d01 = dot(q0, q1); r.d11 = dot(q1, q1);
+    r.denom = r.d00 * r.d11 - r.d01 * r.d01 + kEps;
+    const f3 e12 = v2 - v1;
+    r.l12 = dot(e12, e12);
+    r.id = id; r.pad = 0;
+    return r;
+}
+
+__device__ __forceinline__ float seg_dist2(f3 p, f3 a, f3 b, f3 ba, float l2) {
+    if (l2 <= kEps) { const f3 d = p - b; return dot(d, d); }
+    const float t = dot(ba, p - a) / l2;
+    const float tt = fminf(fmaxf(t, 0.0f), 1.0f);
+    const f3 d = p - (a + tt * ba);
+    return dot(d, d);
+}
+
+__device__ __forceinline__ float point_tri_dist2(f3 p, const TriRec& r) {
+    const f3 v0 = mk3(r.v0x, r.v0y, r.v0z), v1 = mk3(r.v1x, r.v1y, r.v1z), v2 = mk3(r.v2x, r.v2y, r.v2z);
+    const f3 n = mk3(r.nx, r.ny, r.nz);
+    const float t = dot(v0 - p, n);
+    const f3 p0 = p + t * n;
+    const f3 q0 = v1 - v0, q1 = v2 - v0, q2 = p0 - v0;
+    const float d20 = dot(q2, q0), d21 = dot(q2, q1);
+    const float w1 = (r.d11 * d20 - r.d01 * d21) / r.denom;
+    const float w2 = (r.d00 * d21 - r.d01 * d20) / r.denom;
+    const float w0 = 1.0f - w1 - w2;
+    const bool inside = (0.0f <= w0 && w0 <= 1.0f) && (0.0f <= w1 && w1 <= 1.0f) && (0.0f <= w2 && w2 <= 1.0f);
+    if (inside && r.nn > kEps) return t * t;
+    const float e01 = seg_dist2(p, v0, v1, q0, r.d00);
+    const float e02 = seg_dist2(p, v0, v2, q1, r.d11);
+    const float e12 = seg_dist2(p, v1, v2, v2 - v1, r.l12);
+    float d = (e01 > e02) ? e02 : e01;
+    d = (d > e12) ? e12 : d;
+    return d;
+}
+
+__device__ __forceinline__ f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+
+// ---- packed (pytorch3d._C) form ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void pfd_packed_fwd_kernel(const float* __restrict__ points,
+                                                             const int64_t* __restrict__ pfirst,
+                                                             const float* __restrict__ tris,
+                                                             const int64_t* __restrict__ tfirst, int N, int64_t P,
+                                                             int64_t T, float* __restrict__ dists,
+                                                             int64_t* __restrict__ idxs) {
+    __shared__ TriRec s_tri[CHUNK];
+    const int n = blockIdx.y, t = threadIdx.x;
+    const int64_t p0 = pfirst[n], p1 = (n + 1 < N) ? pfirst[n + 1] : P;
+    const int64_t t0 = tfirst[n], t1 = (n + 1 < N) ? tfirst[n + 1] : T;
+    const int64_t p = p0 + (int64_t)blockIdx.x * 256 + t;
+    if (p0 + (int64_t)blockIdx.x * 256 >= p1) return;          // whole workgroup past the cloud
+    const bool live = p < p1;
+    const f3 pt = live ? ld3(points + p * 3) : mk3(0.f, 0.f, 0.f);
+    float best = INFINITY;
+    int64_t bi = -1;
+    for (int64_t base = t0; base < t1; base += CHUNK) {
+        __syncthreads();
+        if (base + t < t1) {
+            const float* v = tris + (base + t) * 9;
+            s_tri[t] = make_tri(ld3(v), ld3(v + 3), ld3(v + 6), t);
+        }
+        __syncthreads();
+        const int cnt = (int)((t1 - base < CHUNK) ? (t1 - base) : CHUNK);
+        if (live) {
+            for (int q = 0; q < cnt; ++q) {
+                const float d = point_tri_dist2(pt, s_tri[q]);
+                if (d < best || bi < 0) { best = d; bi = base + q; }
+            }
+        }
+    }
+    if (live) { dists[p] = (bi < 0) ? 0.f : best; idxs[p] = bi; }
+}
+
+// gradient of the selected branch (Appendix A.4 / oracle p3d_ref.c:orc_point_face_dist_backward)
+__device__ __forceinline__ void seg_backward(f3 p, f3 a, f3 b, float g, f3& gp, f3& ga, f3& gb) {
+    const f3 ba = b - a;
+    const float l2 = dot(ba, ba);
+    if (l2 <= kEps) { const f3 d = (2.0f * g) * (p - b); gp = gp + d; gb = gb - d; return; }
+    const float t = dot(ba, p - a) / l2;
+    if (t < 0.0f) { const f3 d = (2.0f * g) * (p - a); gp = gp + d; ga = ga - d; }
+    else if (t > 1.0f) { const f3 d = (2.0f * g) * (p - b); gp = gp + d; gb = gb - d; }
+    else {
+        const f3 d = (2.0f * g) * (p - (a + t * ba));
+        gp = gp + d; ga = ga - (1.0f - t) * d; gb = gb - t * d;
+    }
+}
+
+__device__ __forceinline__ void point_tri_backward(f3 p, f3 v0, f3 v1, f3 v2, float g, f3& gp, f3& g0, f3& g1, f3& g2) {
+    gp = mk3(0.f, 0.f, 0.f); g0 = gp; g1 = gp; g2 = gp;
+    const TriRec r = make_tri(v0, v1, v2, 0);
+    const f3 n = mk3(r.nx, r.ny, r.nz);
+    const float t = dot(v0 - p, n);
+    const f3 p0 = p + t * n;
+    const f3 q0 = v1 - v0, q1 = v2 - v0, q2 = p0 - v0;
+    const float d20 = dot(q2, q0), d21 = dot(q2, q1);
+    const float w1 = (r.d11 * d20 - r.d01 * d21) / r.denom;
+    const float w2 = (r.d00 * d21 - r.d01 * d20) / r.denom;
+    const float w0 = 1.0f - w1 - w2;
+    const bool inside = (0.0f <= w0 && w0 <= 1.0f) && (0.0f <= w1 && w1 <= 1.0f) && (0.0f <= w2 && w2 <= 1.0f);
+    if (inside && r.nn > kEps) {
+        const float gt = 2.0f * g * t;
+        gp = (-gt) * n;
+        g0 = gt * n;
+        const f3 gn = gt * (v0 - p);
+        const f3 raw = cross(q1, q0);
+        const float den = r.nn + kEps;
+        const float s = dot(gn, raw) / (den * den * r.nn);
+        const f3 graw = (1.0f / den) * gn - s * raw;
+        const f3 ge2 = cross(q0, graw), ge1 = cross(graw, q1);     // raw = q1 x q0
+        g2 = g2 + ge2; g1 = g1 + ge1; g0 = (g0 - ge2) - ge1;
+    } else {
+        const float e01 = seg_dist2(p, v0, v1, q0, r.d00);
+        const float e02 = seg_dist2(p, v0, v2, q1, r.d11);
+        const float e12 = seg_dist2(p, v1, v2, v2 - v1, r.l12);
+        if (e01 <= e02 && e01 <= e12) seg_backward(p, v0, v1, g, gp, g0, g1);
+        else if (e02 <= e01 && e02 <= e12) seg_backward(p, v0, v2, g, gp, g0, g2);
+        else seg_backward(p, v1, v2, g, gp, g1, g2);
+    }
+}
+
+__global__ void pfd_packed_bwd_kernel(const float* __restrict__ points, const float* __restrict__ tris,
+                                      const int64_t* __restrict__ idxs, const float* __restrict__ gd, int64_t P,
+                                      float* __restrict__ gpoints, float* __restrict__ gtris) {
+    const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const int64_t ti = idxs[p];
+    if (ti < 0) return;
+    f3 gp, g0, g1, g2;
+    const float* v = tris + ti * 9;
+    point_tri_backward(ld3(points + p * 3), ld3(v), ld3(v + 3), ld3(v + 6), gd[p], gp, g0, g1, g2);
+    gpoints[p * 3] = gp.x; gpoints[p * 3 + 1] = gp.y; gpoints[p * 3 + 2] = gp.z;
+    float* o = gtris + ti * 9;
+    atomicAdd(o, g0.x); atomicAdd(o + 1, g0.y); atomicAdd(o + 2, g0.z);
+    atomicAdd(o + 3, g1.x); atomicAdd(o + 4, g1.y); atomicAdd(o + 5, g1.z);
+    atomicAdd(o + 6, g2.x); atomicAdd(o + 7, g2.y); atomicAdd(o + 8, g2.z);
+}
+
+// ---- fused batched (sample, part) form --------------------------------------------------------
+constexpr int LIST_CAP = 4096;      // points per workgroup range
+
+__global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __restrict__ verts,
+                                                             const float* __restrict__ points,
+                                                             const int32_t* __restrict__ faces,
+                                                             const int32_t* __restrict__ part_first,
+                                                             const int64_t* __restrict__ seg, int V, int P, int n_parts,
+                                                             int splits, float* __restrict__ dists,
+                                                             int32_t* __restrict__ idxs) {
+    __shared__ TriRec s_tri[CHUNK];
+    __shared__ uint16_t s_list[LIST_CAP];
+    __shared__ int s_n;
+    const int t = threadIdx.x;
+    int w = blockIdx.x;
+    const int split = w % splits; w /= splits;
+    const int part = w % n_parts;
+    const int b = w / n_parts;
+    const int per = (P + splits - 1) / splits;
+    const int pbeg = split * per, pend = min(P, pbeg + per);
+    const float* vb = verts + (int64_t)b * V * 3;
+    const float* pb = points + (int64_t)b * P * 3;
+
+    if (t == 0) s_n = 0;
+    __syncthreads();
+    for (int p = pbeg + t; p < pend; p += 256) {
+        bool mine = true;
+        if (seg) {
+            const int64_t lab = seg[(int64_t)b * P + p];
+            mine = (lab == part + 1);
+            if (part == 0 && (lab < 1 || lab > n_parts)) {          // no part: the reference's masked-out zeros
+                dists[(int64_t)b * P + p] = 0.f;
+                idxs[(int64_t)b * P + p] = -1;
+            }
+        }
+        if (mine) s_list[atomicAdd(&s_n, 1)] = (uint16_t)(p - pbeg);
+    }
+    __syncthreads();
+    const int n_mine = s_n;
+    const int f0 = part_first[part], f1 = part_first[part + 1];
+    for (int g = 0; g < n_mine; g += 256) {
+        const bool live = g + t < n_mine;
+        const int p = live ? pbeg + s_list[g + t] : 0;
+        const f3 pt = live ? ld3(pb + p * 3) : mk3(0.f, 0.f, 0.f);
+        float best = INFINITY;
+        int bi = -1;
+        for (int base = f0; base < f1; base += CHUNK) {
+            __syncthreads();
+            if (base + t < f1) {
+                const int32_t* fc = faces + (base + t) * 3;
+                s_tri[t] = make_tri(ld3(vb + fc[0] * 3), ld3(vb + fc[1] * 3), ld3(vb + fc[2] * 3), t);
+            }
+            __syncthreads();
+            const int cnt = min(CHUNK, f1 - base);
+            if (live) {
+                for (int q = 0; q < cnt; ++q) {
+                    const float d = point_tri_dist2(pt, s_tri[q]);
+                    if (d < best || bi < 0) { best = d; bi = base + q; }
+                }
+            }
+        }
+        if (live) {
+            dists[(int64_t)b * P + p] = (bi < 0) ? 0.f : best;
+            idxs[(int64_t)b * P + p] = bi;
+        }
+    }
+}
+
+constexpr int BWD_MAX_V = 1024;
+
+__global__ __launch_bounds__(256) void mesh_point_bwd_kernel(const float* __restrict__ verts,
+                                                             const float* __restrict__ points,
+                                                             const int32_t* __restrict__ faces,
+                                                             const int32_t* __restrict__ idxs,
+                                                             const float* __restrict__ gd, int V, int P, int per_wg,
+                                                             float* __restrict__ gverts, float* __restrict__ gpoints) {
+    __shared__ float s_g[BWD_MAX_V * 3];
+    const int t = threadIdx.x;
+    const int wgs = (P + per_wg - 1) / per_wg;
+    const int b = blockIdx.x / wgs, chunk = blockIdx.x % wgs;
+    for (int e = t; e < V * 3; e += 256) s_g[e] = 0.f;
+    __syncthreads();
+    const float* vb = verts + (int64_t)b * V * 3;
+    const int pend = min(P, (chunk + 1) * per_wg);
+    for (int p = chunk * per_wg + t; p < pend; p += 256) {
+        const int64_t o = (int64_t)b * P + p;
+        const int fi = idxs[o];
+        f3 gp = mk3(0.f, 0.f, 0.f);
+        const float g = gd[o];
+        if (fi >= 0 && g != 0.f) {
+            const int32_t* fc = faces + fi * 3;
+            f3 g0, g1, g2;
+            point_tri_backward(ld3(points + o * 3), ld3(vb + fc[0] * 3), ld3(vb + fc[1] * 3), ld3(vb + fc[2] * 3), g, gp,
+                               g0, g1, g2);
+            atomicAdd(&s_g[fc[0] * 3], g0.x); atomicAdd(&s_g[fc[0] * 3 + 1], g0.y); atomicAdd(&s_g[fc[0] * 3 + 2], g0.z);
+            atomicAdd(&s_g[fc[1] * 3], g1.x); atomicAdd(&s_g[fc[1] * 3 + 1], g1.y); atomicAdd(&s_g[fc[1] * 3 + 2], g1.z);
+            atomicAdd(&s_g[fc[2] * 3], g2.x); atomicAdd(&s_g[fc[2] * 3 + 1], g2.y); atomicAdd(&s_g[fc[2] * 3 + 2], g2.z);
+        }
+        if (gpoints) { gpoints[o * 3] = gp.x; gpoints[o * 3 + 1] = gp.y; gpoints[o * 3 + 2] = gp.z; }
+    }
+    __syncthreads();
+    for (int e = t; e < V * 3; e += 256) {
+        const float v = s_g[e];
+        if (v != 0.f) atomicAdd(gverts + (int64_t)b * V * 3 + e, v);
+    }
+}
+
+}  // namespace
+
+extern "C" int dsf_point_face_dist_forward(const float* points, const int64_t* points_first_idx, const float* tris,
+                                           const int64_t* tris_first_idx, int N, int64_t P, int64_t T,
+                                           int64_t max_points, float* dists, int64_t* idxs, dsf_stream_t stream) {
+    DSF_CHECK_ARG(points_first_idx && tris_first_idx && dists && idxs && N >= 0 && P >= 0 && T >= 0);
+    if (N == 0 || P == 0) return DSF_OK;
+    DSF_CHECK_ARG(points && (tris || T == 0) && max_points > 0);
+    hipLaunchKernelGGL(pfd_packed_fwd_kernel, dim3((unsigned)((max_points + 255) / 256), N), dim3(256), 0,
+                       (hipStream_t)stream, points, points_first_idx, tris, tris_first_idx, N, P, T, dists, idxs);
+    return dsf_launch_status();
+}
+
+extern "C" int dsf_point_face_dist_backward(const float* points, const float* tris, const int64_t* idxs,
+                                            const float* grad_dists, int64_t P, int64_t T, float* grad_points,
+                                            float* grad_tris, dsf_stream_t stream) {
+    DSF_CHECK_ARG(idxs && grad_dists && grad_points && grad_tris && P >= 0 && T >= 0);
+    if (hipMemsetAsync(grad_points, 0, sizeof(float) * 3 * P, (hipStream_t)stream) != hipSuccess ||
+        hipMemsetAsync(grad_tris, 0, sizeof(float) * 9 * T, (hipStream_t)stream) != hipSuccess)
+        return DSF_ERR_LAUNCH;
+    if (P == 0) return DSF_OK;
+    hipLaunchKernelGGL(pfd_packed_bwd_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       points, tris, idxs, grad_dists, P, grad_points, grad_tris);
+    return dsf_launch_status();
+}
+
+extern "C" int dsf_mesh_point_dist_forward(const float* verts, const float* points, const int32_t* faces,
+                                           const int32_t* part_first, const int64_t* seg, int B, int V, int P,
+                                           int n_parts, float* dists, int32_t* idxs, dsf_stream_t stream) {
+    DSF_CHECK_ARG(verts && points && faces && part_first && dists && idxs);
+    DSF_CHECK_ARG(B >= 0 && V > 0 && P >= 0 && n_parts >= 1 && (seg || n_parts == 1));
+    if (B == 0 || P == 0) return DSF_OK;
+    // seg == NULL: every point meets every triangle -> 256 points per workgroup; with labels one
+    // workgroup per (sample, part) scans the cloud (<= LIST_CAP points per range).
+    int splits = seg ? (P + LIST_CAP - 1) / LIST_CAP : (P + 255) / 256;
+    if (splits < 1) splits = 1;
+    hipLaunchKernelGGL(mesh_point_fwd_kernel, dim3((unsigned)(B * n_parts * splits)), dim3(256), 0, (hipStream_t)stream,
+                       verts, points, faces, part_first, seg, V, P, n_parts, splits, dists, idxs);
+    return dsf_launch_status();
+}
+
+extern "C" int dsf_mesh_point_dist_backward(const float* verts, const float* points, const int32_t* faces,
+                                            const int32_t* idxs, const float* grad_dists, int B, int V, int P,
+                                            float* grad_verts, float* grad_points, dsf_stream_t stream) {
+    DSF_CHECK_ARG(verts && points && faces && idxs && grad_dists && grad_verts && B >= 0 && V > 0 && V <= BWD_MAX_V);
+    if (hipMemsetAsync(grad_verts, 0, sizeof(float) * 3 * (size_t)B * V, (hipStream_t)stream) != hipSuccess)
+        return DSF_ERR_LAUNCH;
+    if (B == 0 || P == 0) return DSF_OK;
+    const int per_wg = 1024;
+    const int wgs = (P + per_wg - 1) / per_wg;
+    hipLaunchKernelGGL(mesh_point_bwd_kernel, dim3((unsigned)(B * wgs)), dim3(256), 0, (hipStream_t)stream, verts, points,
+                       faces, idxs, grad_dists, V, P, per_wg, grad_verts, grad_points);
+    return dsf_launch_status();
+}

@@ -1,0 +1,131 @@
+"""Dual-branch backbone (counterpart of the reference's ``model/backbone.py``): a ResNet trunk
+regressing 62 MANO parameters plus a 3x-deconv pixel branch producing 84 offset/heat channels at
+64x64; with ``refine=True`` a second trunk consumes the stage-1 features fused with the re-encoded
+render of the stage-1 MANO estimate.  Convolutions run on PyTorch-ROCm (MIOpen MFMA kernels); the
+stage-2 bridge (``render.render`` + ``joint2offset``) runs on the HIP kernels of this package.
+Module / parameter names equal the reference's (``MANO_OCR_stage``, model/backbone.py:188-343) so
+its ``latest.pth`` / ``best.pth`` load unchanged."""
+import math
+
+import torch
+import torch.nn as nn
+
+from .resnet import BasicBlock, Bottleneck
+from ..util.generateFeature import joint2offset, offset2joint_softmax
+
+BN_MOMENTUM = 0.1
+resnet = {18: (BasicBlock, [2, 2, 2, 2]), 50: (Bottleneck, [3, 4, 6, 3]), 101: (Bottleneck, [3, 4, 23, 3]),
+          152: (Bottleneck, [3, 8, 36, 3])}
+N_MANO = 3 + 45 + 10 + 4
+
+
+def convtranspose_bn_relu(cin, cout, kernel):
+    return nn.Sequential(nn.ConvTranspose2d(cin, cout, kernel, stride=2, padding=1, output_padding=0, bias=False),
+                         nn.BatchNorm2d(cout, momentum=0.1), nn.ReLU(inplace=True))
+
+
+class _TwoBranchNet(nn.Module):
+    """Trunk builder shared by the 1-stage and 2-stage nets; ``suffix`` = '' or '_s2'."""
+
+    def _stem(self):
+        self.pre = nn.Sequential(nn.Conv2d(1, 64, kernel_size=5, stride=1, padding=2, bias=False),
+                                 nn.BatchNorm2d(64, momentum=BN_MOMENTUM), nn.ReLU(inplace=True),
+                                 nn.MaxPool2d(kernel_size=3, stride=2, padding=1))
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        down = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            down = nn.Sequential(nn.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
+                                 nn.BatchNorm2d(planes * block.expansion, momentum=BN_MOMENTUM))
+        layers = [block(self.inplanes, planes, stride, down)]
+        self.inplanes = planes * block.expansion
+        layers += [block(self.inplanes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    def _trunk(self, block, layers, suffix):
+        for i, (planes, stride) in enumerate(zip((64, 128, 256, 512), (1, 2, 2, 2))):
+            setattr(self, 'layer%d%s' % (i + 1, suffix), self._make_layer(block, planes, layers[i], stride))
+        setattr(self, 'mano_regress' + suffix,
+                nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(self.inplanes, N_MANO)))
+        setattr(self, 'deconv_layer4' + suffix, convtranspose_bn_relu(self.inplanes, 256, 4))
+        setattr(self, 'deconv_layer3' + suffix, convtranspose_bn_relu(256, 256, 4))
+        setattr(self, 'deconv_layer2' + suffix, convtranspose_bn_relu(256, 256, 4))
+        heads = nn.ModuleList([nn.Conv2d(256, self.joint_num * 3, kernel_size=1, stride=1),
+                               nn.Conv2d(256, self.joint_num, kernel_size=1, stride=1)])
+        setattr(self, 'finals' + suffix, heads)
+
+    def _run_trunk(self, x, suffix):
+        g = lambda n: getattr(self, n + suffix)
+        c4 = g('layer4')(g('layer3')(g('layer2')(g('layer1')(x))))
+        mano = g('mano_regress')(c4)
+        feat = g('deconv_layer2')(g('deconv_layer3')(g('deconv_layer4')(c4)))
+        pix = torch.cat([head(feat) for head in g('finals')], dim=1)
+        return c4, feat, pix, mano
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                m.weight.data.normal_(0, math.sqrt(2. / (m.kernel_size[0] * m.kernel_size[1] * m.out_channels)))
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+            elif isinstance(m, nn.Linear):
+                m.weight.data.normal_(0, 0.001)
+            elif isinstance(m, nn.ConvTranspose2d):
+                nn.init.normal_(m.weight, std=0.001)
+        for name in ('finals', 'finals_s2'):
+            for m in getattr(self, name, nn.ModuleList()).modules():
+                if isinstance(m, nn.Conv2d):
+                    nn.init.normal_(m.weight, std=0.001)
+                    nn.init.constant_(m.bias, 0)
+
+
+class MANO_OCR(_TwoBranchNet):
+    def __init__(self, backbone, joint_num):
+        super().__init__()
+        self.joint_num = joint_num
+        self.feature_dim = [joint_num * 3, joint_num]
+        block, layers = resnet[int(backbone.split('_')[-1])]
+        self._stem()
+        self.inplanes = 64
+        self._trunk(block, layers, '')
+        self.init_weights()
+
+    def forward(self, img):
+        _, _, pix, mano = self._run_trunk(self.pre(img), '')
+        return [[pix, mano]]
+
+
+class MANO_OCR_stage(_TwoBranchNet):
+    def __init__(self, backbone, joint_num, refine=False, coord='xyz'):
+        super().__init__()
+        self.joint_num = joint_num
+        self.feature_dim = [joint_num * 3, joint_num]
+        self.refine = refine
+        self.coord_type = coord
+        self.pool = nn.AdaptiveAvgPool2d(1)
+        block, layers = resnet[int(backbone.split('_')[-1])]
+        self._stem()
+        self.inplanes = 64
+        self._trunk(block, layers, '')
+        if refine:
+            self.fusion = nn.Sequential(nn.Conv2d(256 + joint_num * 4 * 2 + 64, 256, 3, 1, 1), nn.BatchNorm2d(256), nn.ReLU())
+            self.inplanes = 256
+            self._trunk(block, layers, '_s2')
+        self.init_weights()
+
+    def forward(self, img, render=None, center=None, cube=None, M=None):
+        c0 = self.pre(img)
+        _, feat, pix, mano = self._run_trunk(c0, '')
+        if not self.refine:
+            return [[pix, mano]]
+        # stage-2 bridge: render the stage-1 MANO estimate, re-encode it as an offset map (HIP kernels)
+        mano_img, mano_uvd, _, _ = render.render(mano, center, cube)
+        remap = joint2offset(mano_uvd, mano_img, 0.8, 64)
+        _, _, pix2, mano2 = self._run_trunk(self.fusion(torch.cat((c0, feat, pix, remap), dim=1)), '_s2')
+        return [[pix, mano], [pix2, mano2]]
+
+    def encoder(self, img):
+        c0 = self.pre(img)
+        c4, _, pix, _ = self._run_trunk(c0, '')
+        return self.pool(c4).squeeze(), offset2joint_softmax(pix, img, 0.8)

@@ -1,0 +1,133 @@
+"""Stacked-hourglass pixel network (counterpart of the reference's ``model/hourglass.py:62-259``).
+Pure dense convolutions -> PyTorch-ROCm / MIOpen.  ``PoseNetMANO`` adds the 62-d MANO head that
+BASELINE config 3 needs (the reference's PoseNet has none and is not used by its trainer)."""
+import math
+
+import torch
+from torch import nn
+
+
+class Conv(nn.Module):
+    def __init__(self, inp_dim, out_dim, kernel_size=3, stride=1, bn=False, relu=True):
+        super().__init__()
+        self.inp_dim = inp_dim
+        self.conv = nn.Conv2d(inp_dim, out_dim, kernel_size, stride, padding=(kernel_size - 1) // 2, bias=True)
+        self.relu = nn.ReLU() if relu else None
+        self.bn = nn.BatchNorm2d(out_dim) if bn else None
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.bn is not None:
+            x = self.bn(x)
+        return self.relu(x) if self.relu is not None else x
+
+
+class Residual(nn.Module):
+    """pre-activation bottleneck: BN-ReLU-1x1, BN-ReLU-3x3, BN-ReLU-1x1 (+1x1 skip when widths differ)."""
+
+    def __init__(self, inp_dim, out_dim):
+        super().__init__()
+        mid = int(out_dim / 2)
+        self.bn1 = nn.BatchNorm2d(inp_dim)
+        self.relu1 = nn.ReLU()
+        self.conv1 = Conv(inp_dim, mid, 1, relu=False)
+        self.bn2 = nn.BatchNorm2d(mid)
+        self.relu2 = nn.ReLU()
+        self.conv2 = Conv(mid, mid, 3, relu=False)
+        self.bn3 = nn.BatchNorm2d(mid)
+        self.relu3 = nn.ReLU()
+        self.conv3 = Conv(mid, out_dim, 1, relu=False)
+        self.skip_layer = Conv(inp_dim, out_dim, 1, relu=False)
+        self.need_skip = inp_dim != out_dim
+
+    def forward(self, x):
+        y = self.conv1(self.relu1(self.bn1(x)))
+        y = self.conv2(self.relu2(self.bn2(y)))
+        y = self.conv3(self.relu3(self.bn3(y)))
+        return y + (self.skip_layer(x) if self.need_skip else x)
+
+
+class Hourglass(nn.Module):
+    def __init__(self, n, f, bn=None, increase=0):
+        super().__init__()
+        nf = f + increase
+        self.up1 = Residual(f, f)
+        self.pool1 = nn.MaxPool2d(2, 2)
+        self.low1 = Residual(f, nf)
+        self.n = n
+        self.low2 = Hourglass(n - 1, nf, bn=bn) if n > 1 else Residual(nf, nf)
+        self.low3 = Residual(nf, f)
+        self.up2 = nn.Upsample(scale_factor=2, mode='nearest')
+
+    def forward(self, x):
+        return self.up1(x) + self.up2(self.low3(self.low2(self.low1(self.pool1(x)))))
+
+
+class Merge(nn.Module):
+    def __init__(self, x_dim, y_dim):
+        super().__init__()
+        self.conv = Conv(x_dim, y_dim, 1, relu=False, bn=False)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class PoseNet(nn.Module):
+    def __init__(self, nstack, joint_num, inp_dim=256, bn=False, increase=0, **kwargs):
+        super().__init__()
+        self.nstack = nstack
+        self.joint_num = joint_num
+        self.pre = nn.Sequential(Conv(1, 64, 7, 2, bn=True, relu=True), Residual(64, 128), nn.MaxPool2d(2, 2),
+                                 Residual(128, 256), Residual(256, inp_dim))
+        self.hgs = nn.ModuleList([Hourglass(4, inp_dim, bn, increase) for _ in range(nstack)])
+        self.features = nn.ModuleList([nn.Sequential(Residual(inp_dim, inp_dim), Conv(inp_dim, inp_dim, 1, bn=True, relu=True))
+                                       for _ in range(nstack)])
+        head = lambda c: nn.ModuleList([nn.Conv2d(inp_dim, c, kernel_size=1, stride=1, padding=0) for _ in range(nstack)])
+        self.outs_1 = head(joint_num * 3)
+        self.outs_2 = head(joint_num)
+        self.outs_3 = head(joint_num)
+        self.merge_features = nn.ModuleList([Merge(inp_dim, inp_dim) for _ in range(nstack - 1)])
+        self.merge_preds = nn.ModuleList([Merge(joint_num * 5, inp_dim) for _ in range(nstack - 1)])
+        self.merge_all = nn.ModuleList([Merge(inp_dim * 2, inp_dim) for _ in range(nstack - 1)])
+        self.init_weights()
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                m.weight.data.normal_(0, math.sqrt(2. / (m.kernel_size[0] * m.kernel_size[1] * m.out_channels)))
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+            elif isinstance(m, nn.Linear):
+                m.weight.data.normal_(0, 0.001)
+        for heads in (self.outs_1, self.outs_2):
+            for m in heads:
+                nn.init.normal_(m.weight, std=0.001)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, imgs):
+        x = self.pre(imgs)
+        preds_all, hg = [], None
+        for i in range(self.nstack):
+            hg = self.hgs[i](x)
+            feature = self.features[i](hg)
+            preds = torch.cat((self.outs_1[i](feature), self.outs_2[i](feature), self.outs_3[i](feature)), dim=1)
+            preds_all.append(preds)
+            if i < self.nstack - 1:
+                x = x + self.merge_preds[i](preds) + self.merge_features[i](feature)
+        return preds_all, hg
+
+
+class PoseNetMANO(nn.Module):
+    """PoseNet + a pooled linear head regressing the 62 MANO parameters (BASELINE config 3)."""
+
+    def __init__(self, nstack=2, joint_num=21):
+        super().__init__()
+        self.body = PoseNet(nstack, joint_num)
+        self.mano_regress = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(256, 62))
+        nn.init.normal_(self.mano_regress[2].weight, std=0.001)
+        nn.init.zeros_(self.mano_regress[2].bias)
+
+    def forward(self, img):
+        preds, hg = self.body(img)
+        return preds, self.mano_regress(hg)

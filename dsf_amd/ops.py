@@ -1,0 +1,425 @@
+"""torch-facing wrappers of the C ABI (include/dsf_hip.h): allocation of outputs,
+raw-pointer hand-off on the current HIP stream, and autograd registration.
+PyTorch is plumbing here (device memory, streams, autograd graph); all
+arithmetic happens in the HIP kernels.  No CPU path exists: CPU tensors raise.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib as L
+from ._lib import F, I, I64, ptr, f32, check, stream_ptr
+
+SAVE_FLOATS = 5248
+
+
+def _empty(shape, ref, dtype=torch.float32):
+    return torch.empty(shape, device=ref.device, dtype=dtype)
+
+
+# --------------------------------------------------------------------------------------------
+# K5 MANO
+# --------------------------------------------------------------------------------------------
+class ManoFunction(Function):
+    """MANO_SMPL.forward / get_mano_vertices (render_model/mano_layer.py:573-693)."""
+
+    @staticmethod
+    def forward(ctx, model, beta, theta, rot, cam, k1, k2):
+        beta, theta, rot = f32(beta), f32(theta), f32(rot)
+        cam = f32(cam) if cam is not None else None
+        B, ncomp, rot_dim = beta.shape[0], theta.shape[1], rot.shape[1]
+        verts = _empty((B, 779, 3), beta)
+        joints = _empty((B, 21, 3), beta)
+        Rs = _empty((B, 15, 3, 3), beta)
+        need_grad = any(ctx.needs_input_grad[1:5])
+        save = _empty((B, SAVE_FLOATS), beta) if need_grad else None
+        check(L.lib().dsf_mano_forward(ctypes.byref(model.c_struct), ptr(beta), ptr(theta), ptr(rot), ptr(cam), I(B),
+                                       I(ncomp), I(rot_dim), F(k1), F(k2), ptr(verts), ptr(joints), ptr(Rs),
+                                       ptr(save), stream_ptr()), "dsf_mano_forward")
+        ctx.model, ctx.k = model, (k1, k2)
+        ctx.has_cam = cam is not None
+        ctx.save_for_backward(theta, rot, cam, save)
+        ctx.mark_non_differentiable(Rs)
+        return verts, joints, Rs
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_verts, g_joints, _g_rs):
+        theta, rot, cam, save = ctx.saved_tensors
+        B, ncomp, rot_dim = theta.shape[0], theta.shape[1], rot.shape[1]
+        g_verts = f32(g_verts) if g_verts is not None else None
+        g_joints = f32(g_joints) if g_joints is not None else None
+        g_beta = _empty((B, 10), theta)
+        g_theta = _empty((B, ncomp), theta)
+        g_rot = _empty((B, rot_dim), theta)
+        g_cam = _empty((B, 4), theta) if ctx.has_cam else None
+        k1, k2 = ctx.k
+        check(L.lib().dsf_mano_backward(ctypes.byref(ctx.model.c_struct), ptr(theta), ptr(rot), ptr(cam), ptr(save),
+                                        ptr(g_verts), ptr(g_joints), I(B), I(ncomp), I(rot_dim), F(k1), F(k2),
+                                        ptr(g_beta), ptr(g_theta), ptr(g_rot), ptr(g_cam), stream_ptr()),
+              "dsf_mano_backward")
+        return None, g_beta, g_theta, g_rot, g_cam, None, None
+
+
+# --------------------------------------------------------------------------------------------
+# K1/K2 rasteriser (pytorch3d._C contract) and the fused crop renderer
+# --------------------------------------------------------------------------------------------
+def project_face_verts(verts, faces_i32, cam):
+    verts = f32(verts)
+    N, V, _ = verts.shape
+    Fn = faces_i32.shape[0]
+    out = _empty((N * Fn, 3, 3), verts)
+    check(L.lib().dsf_project_face_verts(ptr(verts), ptr(faces_i32), ctypes.byref(cam), I(N), I(V), I(Fn), ptr(out),
+                                         stream_ptr()), "dsf_project_face_verts")
+    return out
+
+
+class RasterizeMeshesFunction(Function):
+    """pytorch3d._C.rasterize_meshes(+_backward) for the reference's settings (mano_layer.py:946-951)."""
+
+    @staticmethod
+    def forward(ctx, face_verts, mesh_to_face_first_idx, num_faces_per_mesh, image_size, blur_radius=0.0,
+                faces_per_pixel=1, bin_size=None, max_faces_per_bin=None, perspective_correct=False,
+                clip_barycentric_coords=False, cull_backfaces=False):
+        face_verts = f32(face_verts)
+        N = mesh_to_face_first_idx.shape[0]
+        S = int(image_size)
+        p2f = _empty((N, S, S, 1), face_verts, torch.int64)
+        zbuf = _empty((N, S, S, 1), face_verts)
+        bary = _empty((N, S, S, 1, 3), face_verts)
+        dists = _empty((N, S, S, 1), face_verts)
+        ws = _empty((max(N, 1), 4), face_verts)
+        check(L.lib().dsf_rasterize_meshes(ptr(face_verts), ptr(mesh_to_face_first_idx.contiguous()),
+                                           ptr(num_faces_per_mesh.contiguous()), I(N), I64(face_verts.shape[0]), I(S),
+                                           F(blur_radius), I(faces_per_pixel), I(int(perspective_correct)),
+                                           I(int(clip_barycentric_coords)), I(int(cull_backfaces)), ptr(p2f),
+                                           ptr(zbuf), ptr(bary), ptr(dists), ptr(ws), stream_ptr()),
+              "dsf_rasterize_meshes")
+        ctx.save_for_backward(face_verts, p2f)
+        ctx.S = S
+        ctx.mark_non_differentiable(p2f)
+        return p2f, zbuf, bary, dists
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, _g_p2f, g_zbuf, g_bary, g_dists):
+        face_verts, p2f = ctx.saved_tensors
+        # only zbuf is consumed by the reference (mano_layer.py:1023); bary/dists grads must be zero
+        g = _empty(face_verts.shape, face_verts)
+        check(L.lib().dsf_rasterize_meshes_backward(ptr(face_verts), ptr(p2f), ptr(f32(g_zbuf)), ptr(None), ptr(None),
+                                                    I(p2f.shape[0]), I64(face_verts.shape[0]), I(ctx.S), ptr(g),
+                                                    stream_ptr()), "dsf_rasterize_meshes_backward")
+        return (g,) + (None,) * 10
+
+
+def crop_setup(center3d, cube, cam, crop=128, want_closed_inverse=False):
+    center3d, cube = f32(center3d), f32(cube)
+    B = center3d.shape[0]
+    c2 = _empty((B, 3), center3d)
+    M = _empty((B, 3, 3), center3d)
+    bounds = _empty((B, 4), center3d, torch.int32)
+    minv = _empty((B, 3, 3), center3d) if want_closed_inverse else None
+    check(L.lib().dsf_crop_setup(ptr(center3d), ptr(cube), ctypes.byref(cam), I(B), I(crop), ptr(c2), ptr(M),
+                                 ptr(bounds), ptr(minv), stream_ptr()), "dsf_crop_setup")
+    return c2, M, bounds, minv
+
+
+class RenderCropFunction(Function):
+    """verts (B,V,3) world mm -> normalised 128x128 depth crop (Render.render leaf, mano_layer.py:1082-1092)."""
+
+    @staticmethod
+    def forward(ctx, verts, faces_i32, minv, rowmap, center_z, cube_z, cam, raster_size, crop):
+        verts, minv = f32(verts), f32(minv)
+        center_z = f32(center_z) if center_z is not None else None
+        cube_z = f32(cube_z) if cube_z is not None else None
+        B, V, _ = verts.shape
+        img = _empty((B, 1, crop, crop), verts)
+        p2f = _empty((B, crop, crop), verts, torch.int32)
+        check(L.lib().dsf_render_crop_forward(ptr(verts), ptr(faces_i32), ptr(minv), ptr(rowmap), ptr(center_z),
+                                              ptr(cube_z), ctypes.byref(cam), I(B), I(V), I(faces_i32.shape[0]),
+                                              I(raster_size), I(crop), ptr(img), ptr(p2f), stream_ptr()),
+              "dsf_render_crop_forward")
+        ctx.save_for_backward(verts, faces_i32, minv, rowmap, center_z, cube_z, p2f)
+        ctx.cam, ctx.dims = cam, (raster_size, crop)
+        ctx.mark_non_differentiable(p2f)
+        return img, p2f
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_img, _g_p2f):
+        verts, faces_i32, minv, rowmap, center_z, cube_z, p2f = ctx.saved_tensors
+        B, V, _ = verts.shape
+        raster_size, crop = ctx.dims
+        g = _empty(verts.shape, verts)
+        check(L.lib().dsf_render_crop_backward(ptr(verts), ptr(faces_i32), ptr(minv), ptr(rowmap), ptr(center_z),
+                                               ptr(cube_z), ctypes.byref(ctx.cam), ptr(p2f), ptr(f32(g_img)), I(B),
+                                               I(V), I(faces_i32.shape[0]), I(raster_size), I(crop), ptr(g),
+                                               stream_ptr()), "dsf_render_crop_backward")
+        return (g,) + (None,) * 8
+
+
+# --------------------------------------------------------------------------------------------
+# K3/K4 point-face distance
+# --------------------------------------------------------------------------------------------
+class PointFaceDistance(Function):
+    """pytorch3d._C.point_face_dist_forward/backward (metric/meshLoss.py:21-70)."""
+
+    @staticmethod
+    def forward(ctx, points, points_first_idx, tris, tris_first_idx, max_points):
+        points, tris = f32(points), f32(tris)
+        P, T, N = points.shape[0], tris.shape[0], points_first_idx.shape[0]
+        dists = _empty((P,), points)
+        idxs = _empty((P,), points, torch.int64)
+        check(L.lib().dsf_point_face_dist_forward(ptr(points), ptr(points_first_idx.contiguous()), ptr(tris),
+                                                  ptr(tris_first_idx.contiguous()), I(N), I64(P), I64(T),
+                                                  I64(int(max_points)), ptr(dists), ptr(idxs), stream_ptr()),
+              "dsf_point_face_dist_forward")
+        ctx.save_for_backward(points, tris, idxs)
+        return dists
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_dists):
+        points, tris, idxs = ctx.saved_tensors
+        gp = _empty(points.shape, points)
+        gt = _empty(tris.shape, tris)
+        check(L.lib().dsf_point_face_dist_backward(ptr(points), ptr(tris), ptr(idxs), ptr(f32(g_dists)),
+                                                   I64(points.shape[0]), I64(tris.shape[0]), ptr(gp), ptr(gt),
+                                                   stream_ptr()), "dsf_point_face_dist_backward")
+        return gp, None, gt, None, None
+
+
+class MeshPointDistance(Function):
+    """Fused batched point->mesh(-part) distance behind ICPLoss/JointICPLoss (metric/meshLoss.py:347-395)."""
+
+    @staticmethod
+    def forward(ctx, verts, points, faces_cat, part_first, seg, n_parts):
+        verts, points = f32(verts), f32(points)
+        B, V, _ = verts.shape
+        P = points.shape[1]
+        dists = _empty((B, P), verts)
+        idxs = _empty((B, P), verts, torch.int32)
+        seg_c = seg.contiguous() if seg is not None else None
+        if seg_c is not None and seg_c.dtype != torch.int64:
+            seg_c = seg_c.long()
+        check(L.lib().dsf_mesh_point_dist_forward(ptr(verts), ptr(points), ptr(faces_cat), ptr(part_first), ptr(seg_c),
+                                                  I(B), I(V), I(P), I(n_parts), ptr(dists), ptr(idxs), stream_ptr()),
+              "dsf_mesh_point_dist_forward")
+        ctx.save_for_backward(verts, points, faces_cat, idxs)
+        ctx.need_points = ctx.needs_input_grad[1]
+        ctx.mark_non_differentiable(idxs)
+        return dists, idxs
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_dists, _g_idx):
+        verts, points, faces_cat, idxs = ctx.saved_tensors
+        B, V, _ = verts.shape
+        gv = _empty(verts.shape, verts)
+        gp = _empty(points.shape, points) if ctx.need_points else None
+        check(L.lib().dsf_mesh_point_dist_backward(ptr(verts), ptr(points), ptr(faces_cat), ptr(idxs),
+                                                   ptr(f32(g_dists)), I(B), I(V), I(points.shape[1]), ptr(gv), ptr(gp),
+                                                   stream_ptr()), "dsf_mesh_point_dist_backward")
+        return gv, gp, None, None, None, None
+
+
+# --------------------------------------------------------------------------------------------
+# K6/K7 spheres, collision, segmentation
+# --------------------------------------------------------------------------------------------
+def sphere_set(sphere_model, joints, mesh):
+    joints, mesh = f32(joints), f32(mesh)
+    B, V = joints.shape[0], mesh.shape[1]
+    c = _empty((B, 66, 3), joints)
+    r = _empty((B, 66), joints)
+    check(L.lib().dsf_sphere_set(ctypes.byref(sphere_model), ptr(joints), ptr(mesh), I(B), I(V), ptr(c), ptr(r),
+                                 ptr(None), stream_ptr()), "dsf_sphere_set")
+    return c, r
+
+
+class CollisionRows(Function):
+    """Gated per-sphere row sums of calculate_coll (mano_layer.py:373-386)."""
+
+    @staticmethod
+    def forward(ctx, sphere_model, joints, mesh):
+        joints, mesh = f32(joints), f32(mesh)
+        B, V = joints.shape[0], mesh.shape[1]
+        rows = _empty((B, 66), joints)
+        c = _empty((B, 66, 3), joints)
+        r = _empty((B, 66), joints)
+        topk = _empty((B, 16, 10), joints, torch.int32)
+        check(L.lib().dsf_collision_forward(ctypes.byref(sphere_model), ptr(joints), ptr(mesh), I(B), I(V), ptr(rows),
+                                            ptr(c), ptr(r), ptr(topk), stream_ptr()), "dsf_collision_forward")
+        ctx.sm = sphere_model
+        ctx.save_for_backward(joints, mesh, c, r, topk)
+        return rows
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_rows):
+        joints, mesh, c, r, topk = ctx.saved_tensors
+        B, V = joints.shape[0], mesh.shape[1]
+        gj = _empty(joints.shape, joints)
+        gm = _empty(mesh.shape, mesh)
+        check(L.lib().dsf_collision_backward(ctypes.byref(ctx.sm), ptr(joints), ptr(mesh), ptr(c), ptr(r), ptr(topk),
+                                             ptr(f32(g_rows)), I(B), I(V), ptr(gj), ptr(gm), stream_ptr()),
+              "dsf_collision_backward")
+        return None, gj, gm
+
+
+def seg_pcl(centres, radii, pcl):
+    centres, radii, pcl = f32(centres), f32(radii), f32(pcl)
+    B, P = pcl.shape[0], pcl.shape[1]
+    labels = _empty((B, P), pcl, torch.int64)
+    check(L.lib().dsf_seg_pcl(ptr(centres), ptr(radii), ptr(pcl), I(B), I(P), ptr(labels), stream_ptr()), "dsf_seg_pcl")
+    return labels
+
+
+# --------------------------------------------------------------------------------------------
+# K8/K9/K10 image-side ops
+# --------------------------------------------------------------------------------------------
+class UvdToXyz(Function):
+    @staticmethod
+    def forward(ctx, uvd, center, minv, cube, cam, img_size, normalise):
+        uvd, center, minv, cube = f32(uvd), f32(center), f32(minv), f32(cube)
+        B, N, _ = uvd.shape
+        out = _empty(uvd.shape, uvd)
+        check(L.lib().dsf_uvd_to_xyz(ptr(uvd), ptr(center), ptr(minv), ptr(cube), ctypes.byref(cam), I(B), I(N),
+                                     I(img_size), I(int(normalise)), ptr(out), stream_ptr()), "dsf_uvd_to_xyz")
+        ctx.save_for_backward(uvd, center, minv, cube)
+        ctx.args = (cam, img_size, int(normalise))
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        uvd, center, minv, cube = ctx.saved_tensors
+        cam, img_size, normalise = ctx.args
+        B, N, _ = uvd.shape
+        out = _empty(uvd.shape, uvd)
+        check(L.lib().dsf_uvd_to_xyz_backward(ptr(uvd), ptr(center), ptr(minv), ptr(cube), ctypes.byref(cam),
+                                              ptr(f32(g)), I(B), I(N), I(img_size), I(normalise), ptr(out),
+                                              stream_ptr()), "dsf_uvd_to_xyz_backward")
+        return out, None, None, None, None, None, None
+
+
+class XyzToUvd(Function):
+    @staticmethod
+    def forward(ctx, xyz, center, M, cube, cam, img_size, world):
+        xyz, center, M, cube = f32(xyz), f32(center), f32(M), f32(cube)
+        B, N, _ = xyz.shape
+        out = _empty(xyz.shape, xyz)
+        check(L.lib().dsf_xyz_to_uvd(ptr(xyz), ptr(center), ptr(M), ptr(cube), ctypes.byref(cam), I(B), I(N),
+                                     I(img_size), I(int(world)), ptr(out), stream_ptr()), "dsf_xyz_to_uvd")
+        ctx.save_for_backward(xyz, center, M, cube)
+        ctx.args = (cam, img_size, int(world))
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        xyz, center, M, cube = ctx.saved_tensors
+        cam, img_size, world = ctx.args
+        B, N, _ = xyz.shape
+        out = _empty(xyz.shape, xyz)
+        check(L.lib().dsf_xyz_to_uvd_backward(ptr(xyz), ptr(center), ptr(M), ptr(cube), ctypes.byref(cam), ptr(f32(g)),
+                                              I(B), I(N), I(img_size), I(world), ptr(out), stream_ptr()),
+              "dsf_xyz_to_uvd_backward")
+        return out, None, None, None, None, None, None
+
+
+class CropHand(Function):
+    """crop_hand (data/render_loader.py:1209-1227); also returns the normalised point image."""
+
+    @staticmethod
+    def forward(ctx, img, joints_nl, center, minv, cube, cam, offsetxy, offsetz, thickness):
+        img, joints_nl, center, minv, cube = f32(img), f32(joints_nl), f32(center), f32(minv), f32(cube)
+        B, _, S, _ = img.shape
+        out = _empty(img.shape, img)
+        xyz = _empty((B, S * S, 3), img)
+        keep = _empty((B, 1, S, S), img, torch.uint8)
+        check(L.lib().dsf_crop_hand(ptr(img), ptr(joints_nl), ptr(center), ptr(minv), ptr(cube), ctypes.byref(cam),
+                                    I(B), I(joints_nl.shape[1]), I(S), F(offsetxy), F(offsetz), F(thickness), ptr(out),
+                                    ptr(xyz), ptr(keep), stream_ptr()), "dsf_crop_hand")
+        ctx.save_for_backward(keep)
+        ctx.mark_non_differentiable(xyz, keep)
+        return out, xyz, keep
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g, _gx, _gk):
+        keep, = ctx.saved_tensors
+        return (g * keep.to(g.dtype),) + (None,) * 8
+
+
+def img2pcl(img, center, minv, cube, cam, n_sample, rand_keys=None):
+    """Img2pcl (data/render_loader.py:1121-1156) with the random draw as an explicit input."""
+    img, center, minv, cube = f32(img), f32(center), f32(minv), f32(cube)
+    B, _, S, _ = img.shape
+    if rand_keys is None:
+        rand_keys = torch.randint(0, 2 ** 31 - 1, (B, S * S), device=img.device, dtype=torch.int32)
+    rand_keys = rand_keys.contiguous()
+    pcl = _empty((B, n_sample, 3), img)
+    counts = _empty((B,), img, torch.int32)
+    ws = _empty((B, 2 * S * S), img, torch.int32)
+    check(L.lib().dsf_img2pcl(ptr(img), ptr(center), ptr(minv), ptr(cube), ctypes.byref(cam), ptr(rand_keys), I(B), I(S),
+                              I(n_sample), ptr(pcl), ptr(counts), ptr(ws), stream_ptr()), "dsf_img2pcl")
+    return pcl, counts
+
+
+class Joint2Offset(Function):
+    """GFM.joint2offset (util/generateFeature.py:14-37)."""
+
+    @staticmethod
+    def forward(ctx, joints, img, kernel_size, S):
+        joints, img = f32(joints), f32(img)
+        B = img.shape[0]
+        joints = joints.reshape(B, -1, 3)
+        J, H = joints.shape[1], img.shape[-1]
+        maps = _empty((B, 4 * J, S, S), img)
+        check(L.lib().dsf_joint2offset_forward(ptr(joints), ptr(img), I(B), I(J), I(H), I(S), F(kernel_size), ptr(maps),
+                                               stream_ptr()), "dsf_joint2offset_forward")
+        ctx.save_for_backward(joints, img)
+        ctx.args = (kernel_size, S)
+        return maps
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        joints, img = ctx.saved_tensors
+        ks, S = ctx.args
+        B, J, _ = joints.shape
+        gj = _empty(joints.shape, joints)
+        check(L.lib().dsf_joint2offset_backward(ptr(joints), ptr(img), ptr(f32(g)), I(B), I(J), I(img.shape[-1]), I(S),
+                                                F(ks), ptr(gj), stream_ptr()), "dsf_joint2offset_backward")
+        return gj, None, None, None
+
+
+class Offset2Joint(Function):
+    """GFM.offset2joint_softmax (util/generateFeature.py:39-59)."""
+
+    @staticmethod
+    def forward(ctx, maps, depth, kernel_size, scale):
+        maps, depth = f32(maps), f32(depth)
+        B, C, S, _ = maps.shape
+        J, H = C // 4, depth.shape[-1]
+        joints = _empty((B, J, 3), maps)
+        stats = _empty((B, J, 2), maps)
+        check(L.lib().dsf_offset2joint_forward(ptr(maps), ptr(depth), I(B), I(J), I(H), I(S), F(kernel_size), F(scale),
+                                               ptr(joints), ptr(stats), stream_ptr()), "dsf_offset2joint_forward")
+        ctx.save_for_backward(maps, depth, joints, stats)
+        ctx.args = (kernel_size, scale)
+        return joints
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        maps, depth, joints, stats = ctx.saved_tensors
+        ks, scale = ctx.args
+        B, C, S, _ = maps.shape
+        gm = _empty(maps.shape, maps)
+        check(L.lib().dsf_offset2joint_backward(ptr(maps), ptr(depth), ptr(joints), ptr(stats), ptr(f32(g)), I(B),
+                                                I(C // 4), I(depth.shape[-1]), I(S), F(ks), F(scale), ptr(gm),
+                                                stream_ptr()), "dsf_offset2joint_backward")
+        return gm, None, None, None

@@ -1,0 +1,271 @@
+/*
+ * dsf_hip.h -- C ABI of libdsf_hip.so, the MI355X (gfx950) native layer of the
+ * DSF training hot path.  This is the drop-in boundary: plain pointers (device
+ * memory unless stated), sizes and a HIP stream; no torch types.  Every entry
+ * point returns an int status (DSF_OK = 0); kernels never allocate, free or
+ * synchronise, so every call is safe under HIP-graph capture.  All tensors are
+ * contiguous row-major, fp32 unless noted.
+ *
+ * Each entry point cites the reference interface it replaces
+ * (paths relative to the reference repository root).
+ */
+#ifndef DSF_HIP_H
+#define DSF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSF_OK 0
+#define DSF_ERR_INVALID_ARG 1
+#define DSF_ERR_UNSUPPORTED 2
+#define DSF_ERR_LAUNCH 3
+
+#define DSF_MANO_VERTS 779      /* 778 + wrist cap vertex (render_model/mano_layer.py:636-637) */
+#define DSF_MANO_JOINTS 21
+#define DSF_MANO_FACES 1554
+#define DSF_MANO_SAVE_FLOATS 5248   /* per-sample forward state kept for the backward kernel */
+#define DSF_N_SPHERES 66
+
+typedef void* dsf_stream_t;     /* hipStream_t */
+
+int dsf_abi_version(void);
+const char* dsf_status_string(int status);
+
+/* ------------------------------------------------------------------------------------
+ * K5  MANO layer: shape/pose blendshapes, Rodrigues, kinematic chain, LBS, joint
+ * regression, wrist cap, output affine.
+ * Replaces MANO_SMPL.forward (render_model/mano_layer.py:573-641) and
+ * MANO_SMPL.get_mano_vertices (:643-693) -- ~40 torch kernels + a 15-step Python loop.
+ * ---------------------------------------------------------------------------------- */
+typedef struct dsf_mano_model {
+    const float* v_template;    /* (778,3)                                   mano_layer.py:112-113 */
+    const float* shapedirs;     /* (10, 2334)                                :116-120 */
+    const float* posedirs;      /* (135, 2334)                               :142-145 */
+    const float* j_regressor;   /* (778, 21) dense, 16 regressed + 5 tips    :123-132 */
+    const float* j_template;    /* (16,3)   = J_regressor[:, :16]^T v_template   (host precompute) */
+    const float* j_shapedirs;   /* (10, 48) = J_regressor[:, :16]^T shapedirs_k  (host precompute) */
+    const float* hands_comp;    /* (45,45)                                   :135-136 */
+    const float* hands_mean;    /* (45)                                      :138-139 */
+    const float* weights;       /* (778,16)                                  :149-154 */
+    const int32_t* parents;     /* (16), parents[0] = -1                     :147 */
+    const int32_t* wrist_ring;  /* (16) vertex ids averaged into vertex 778  :636 */
+    const int32_t* jreg_rowptr; /* (22) CSR of j_regressor^T (joint-major) */
+    const int32_t* jreg_col;    /* (nnz) vertex ids */
+    const float* jreg_val;      /* (nnz) */
+} dsf_mano_model;
+
+/* rot: (B,rot_dim) rot_dim 3 = axis-angle, 4 = quaternion(w,x,y,z); theta: (B,ncomp) PCA
+ * coefficients, ncomp <= 45; beta: (B,10); cam: (B,4) = scale|trans or NULL.
+ * out = ((raw * k1) * k2) * cam[0] + cam[1:4]   (k1 = 1000, k2 = global_scale in get_mano_vertices;
+ * k1 = k2 = 1 and cam = NULL reproduce MANO_SMPL.forward).
+ * verts (B,779,3), joints (B,21,3), Rs (B,15,3,3) (may be NULL), save (B,DSF_MANO_SAVE_FLOATS)
+ * (may be NULL when no backward is needed). */
+int dsf_mano_forward(const dsf_mano_model* m, const float* beta, const float* theta, const float* rot,
+                     const float* cam, int B, int ncomp, int rot_dim, float k1, float k2,
+                     float* verts, float* joints, float* Rs, float* save, dsf_stream_t stream);
+
+/* grad_verts (B,779,3) / grad_joints (B,21,3): either may be NULL (= zeros).
+ * Outputs (all written, not accumulated): grad_beta (B,10), grad_theta (B,ncomp),
+ * grad_rot (B,rot_dim), grad_cam (B,4) or NULL. */
+int dsf_mano_backward(const dsf_mano_model* m, const float* theta, const float* rot, const float* cam,
+                      const float* save, const float* grad_verts, const float* grad_joints,
+                      int B, int ncomp, int rot_dim, float k1, float k2,
+                      float* grad_beta, float* grad_theta, float* grad_rot, float* grad_cam,
+                      dsf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K1/K2  Mesh rasteriser (pytorch3d==0.4.0 semantics).
+ * Replaces pytorch3d._C.rasterize_meshes / rasterize_meshes_backward as driven by
+ * MeshRasterizer (render_model/mano_layer.py:946-952, call sites :1022,1054,1083,1117,
+ * 1194,1211) for blur_radius=0, faces_per_pixel=1, perspective_correct=False,
+ * clip_barycentric_coords=False, cull_backfaces=False (anything else: DSF_ERR_UNSUPPORTED).
+ * ---------------------------------------------------------------------------------- */
+typedef struct dsf_camera {
+    float fx, fy, px, py;       /* screen-space intrinsics (mano_layer.py:939-945) */
+    float img_w, img_h;         /* PerspectiveCameras image_size = (640, 480) */
+} dsf_camera;
+
+/* World verts (N,V,3) -> face_verts (N*F,3,3) of (x_ndc, y_ndc, z_view): camera R=diag(-1,-1,1),
+ * T=0, then Meshes packing verts_packed[faces_packed] (faces (F,3) int32 shared by all meshes). */
+int dsf_project_face_verts(const float* verts, const int32_t* faces, const dsf_camera* cam,
+                           int N, int V, int F, float* face_verts, dsf_stream_t stream);
+
+/* face_verts (F_total,3,3); mesh_to_face_first_idx / num_faces_per_mesh (N) int64 (device).
+ * Outputs (N,S,S[,3]): pix_to_face int64 (packed face index or -1), zbuf, bary (may be NULL),
+ * dists (may be NULL).  Exact-z ties resolve to the lowest face index (= the naive path).
+ * workspace: (N,4) floats of scratch for the per-mesh screen bbox (tiles outside it skip the
+ * face scan), or NULL to disable that culling. */
+int dsf_rasterize_meshes(const float* face_verts, const int64_t* mesh_to_face_first_idx,
+                         const int64_t* num_faces_per_mesh, int N, int64_t F_total, int image_size,
+                         float blur_radius, int faces_per_pixel, int perspective_correct,
+                         int clip_barycentric_coords, int cull_backfaces,
+                         int64_t* pix_to_face, float* zbuf, float* bary, float* dists,
+                         float* workspace, dsf_stream_t stream);
+
+/* grad_bary / grad_dists may be NULL (= zeros; the reference only consumes zbuf).
+ * grad_face_verts (F_total,3,3) is zeroed by this call, then accumulated with float atomics. */
+int dsf_rasterize_meshes_backward(const float* face_verts, const int64_t* pix_to_face,
+                                  const float* grad_zbuf, const float* grad_bary, const float* grad_dists,
+                                  int N, int64_t F_total, int image_size, float* grad_face_verts,
+                                  dsf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K1+K8 fused "crop mode": the whole leaf of Render.render / normal_render / mesh2img /
+ * getDepth (render_model/mano_layer.py:1078-1092, 1190-1218):
+ *   world verts -> raster (640x640, Appendix A) -> background -> 0 (:1085) -> resize to
+ *   480x640 (:1233-1242) -> nearest crop warp with torch.inverse(M) (:1244-1260) ->
+ *   normalize_img (:1289-1299),
+ * evaluated only at the <=128*128 raster pixels the crop reads (bit-identical to the full
+ * chain, ~25x less work, no 11.5 MB/mesh fragment traffic).
+ * ---------------------------------------------------------------------------------- */
+/* center3d (B,3) mm, cube (B,3) mm -> center2d (B,3) (points3DToImg :1318-1324), M (B,3,3)
+ * (comToBounds :1133-1141 + Offset2Trans :1143-1169), bounds (B,4) int32 xs,xe,ys,ye (may be NULL),
+ * minv_closed (B,3,3) closed-form inverse of the affine M (may be NULL). */
+int dsf_crop_setup(const float* center3d, const float* cube, const dsf_camera* cam, int B, int crop,
+                   float* center2d, float* M, int32_t* bounds, float* minv_closed, dsf_stream_t stream);
+
+/* verts (B,V,3) world mm; faces (F,3) int32; minv (B,3,3) = the reference's torch.inverse(M);
+ * resize_rowmap (img_h) int32: source raster row for each row of the resized image (derived
+ * from torch's own affine_grid+grid_sample at init); center_z, cube_z (B) for
+ * normalize_img (pass NULL for both to get metric depth with 0 background).
+ * Outputs: img (B,1,crop,crop); pix_to_face (B,crop,crop) int32 local face id or -1 (may be NULL). */
+int dsf_render_crop_forward(const float* verts, const int32_t* faces, const float* minv,
+                            const int32_t* resize_rowmap, const float* center_z, const float* cube_z,
+                            const dsf_camera* cam, int B, int V, int F, int raster_size, int crop,
+                            float* img, int32_t* pix_to_face, dsf_stream_t stream);
+
+/* grad_img (B,1,crop,crop) -> grad_verts (B,V,3) world (zeroed, then accumulated).
+ * Gradient flows only through zbuf of covered, un-clamped pixels (Appendix A.3). */
+int dsf_render_crop_backward(const float* verts, const int32_t* faces, const float* minv,
+                             const int32_t* resize_rowmap, const float* center_z, const float* cube_z,
+                             const dsf_camera* cam, const int32_t* pix_to_face,
+                             const float* grad_img, int B, int V, int F, int raster_size, int crop,
+                             float* grad_verts, dsf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K3/K4  Point -> triangle squared distance.
+ * Replaces pytorch3d._C.point_face_dist_forward / _backward (metric/meshLoss.py:52, 63).
+ * ---------------------------------------------------------------------------------- */
+/* points (P,3); tris (T,3,3); *_first_idx (N) int64 CSR starts; dists (P), idxs (P) int64
+ * (packed triangle index, ties -> lowest). max_points is accepted for signature parity. */
+int dsf_point_face_dist_forward(const float* points, const int64_t* points_first_idx, const float* tris,
+                                const int64_t* tris_first_idx, int N, int64_t P, int64_t T,
+                                int64_t max_points, float* dists, int64_t* idxs, dsf_stream_t stream);
+
+/* grad_points (P,3) and grad_tris (T,3,3) are zeroed by this call. */
+int dsf_point_face_dist_backward(const float* points, const float* tris, const int64_t* idxs,
+                                 const float* grad_dists, int64_t P, int64_t T, float* grad_points,
+                                 float* grad_tris, dsf_stream_t stream);
+
+/* Fused batched variant used by ICPLoss / JointICPLoss / FingerICPLoss (metric/meshLoss.py:347-395):
+ * verts (B,V,3), points (B,P,3), faces (Fcat,3) int32 = concatenation of n_parts face lists with
+ * part_first (n_parts+1) int32 offsets; seg (B,P) int64 labels or NULL.
+ *   seg == NULL (ICPLoss, n_parts = 1): every point is tested against part 0.
+ *   seg != NULL: point p is tested against part seg[p]-1 only (label 0 -> no part, dist 0);
+ *   this is exactly the subset the reference keeps after its 15x replicated launch.
+ * Outputs: dists (B,P), idxs (B,P) int32 = index into the concatenated face list (or -1). */
+int dsf_mesh_point_dist_forward(const float* verts, const float* points, const int32_t* faces,
+                                const int32_t* part_first, const int64_t* seg, int B, int V, int P,
+                                int n_parts, float* dists, int32_t* idxs, dsf_stream_t stream);
+
+/* grad_verts (B,V,3) zeroed then accumulated; grad_points (B,P,3) written (may be NULL). */
+int dsf_mesh_point_dist_backward(const float* verts, const float* points, const int32_t* faces,
+                                 const int32_t* idxs, const float* grad_dists, int B, int V, int P,
+                                 float* grad_verts, float* grad_points, dsf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K6/K7  Sphere hand model: radii/centres, collision loss, point-cloud part labels.
+ * Replaces MANO_SMPL.get_sphere_radius (:271-317), calculate_coll (:373-386), seg_pcl (:404-426).
+ * ---------------------------------------------------------------------------------- */
+typedef struct dsf_sphere_model {
+    const uint8_t* jreg_mask;   /* (21,778) 1 where J_regressor[v][j] > 0   (:275) */
+    const float* coll_mask;     /* (66,66)                                   (:240-269) */
+    float t_finger[3];          /* linspace(0,1,4)[:-1]                      (:231) */
+    float t_palm[4];            /* linspace(0,1,6)[1:-1]                     (:236) */
+} dsf_sphere_model;
+
+/* joints (B,21,3), mesh (B,V>=778,3) -> centres (B,66,3), radii (B,66); topk_idx (B,21,10) int32
+ * (the 10 nearest owned vertices per joint, needed by the backward; may be NULL). */
+int dsf_sphere_set(const dsf_sphere_model* sm, const float* joints, const float* mesh, int B, int V,
+                   float* centres, float* radii, int32_t* topk_idx, dsf_stream_t stream);
+
+/* loss_rows (B,66): gated row sums sum_j err_ij (the caller takes the mean, = calculate_coll).
+ * Also writes centres/radii/topk_idx for the backward. */
+int dsf_collision_forward(const dsf_sphere_model* sm, const float* joints, const float* mesh, int B, int V,
+                          float* loss_rows, float* centres, float* radii, int32_t* topk_idx,
+                          dsf_stream_t stream);
+
+/* grad_rows (B,66) -> grad_joints (B,21,3), grad_mesh (B,V,3) (both written). */
+int dsf_collision_backward(const dsf_sphere_model* sm, const float* joints, const float* mesh,
+                           const float* centres, const float* radii, const int32_t* topk_idx,
+                           const float* grad_rows, int B, int V, float* grad_joints, float* grad_mesh,
+                           dsf_stream_t stream);
+
+/* centres (B,66,3) from the pixel-branch joints, radii (B,66) from the MANO joints (:407-408);
+ * pcl (B,P,3) -> labels (B,P) int64 in 0..15. */
+int dsf_seg_pcl(const float* centres, const float* radii, const float* pcl, int B, int P,
+                int64_t* labels, dsf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K8/K9/K10  image-side elementwise kernels.
+ * ---------------------------------------------------------------------------------- */
+/* uvd (B,N,3) crop-normalised -> xyz (B,N,3); mat (B,3,3) = torch.inverse(M).
+ * normalise=1: uvd_nl2xyznl_tensor, 0: uvd_nl2xyz_tensor (data/render_loader.py:1044-1073). */
+int dsf_uvd_to_xyz(const float* uvd, const float* center, const float* minv, const float* cube,
+                   const dsf_camera* cam, int B, int N, int img_size, int normalise, float* xyz,
+                   dsf_stream_t stream);
+/* xyz_nl2uvdnl_tensor (data/render_loader.py:1075-1088) == Render.JointTrans for world input
+ * (render_model/mano_layer.py:1301-1309) when world=1 (xyz already in mm). */
+int dsf_xyz_to_uvd(const float* xyz, const float* center, const float* M, const float* cube,
+                   const dsf_camera* cam, int B, int N, int img_size, int world, float* uvd,
+                   dsf_stream_t stream);
+/* backward of the two transforms w.r.t. their point input */
+int dsf_uvd_to_xyz_backward(const float* uvd, const float* center, const float* minv, const float* cube,
+                            const dsf_camera* cam, const float* grad_xyz, int B, int N, int img_size,
+                            int normalise, float* grad_uvd, dsf_stream_t stream);
+int dsf_xyz_to_uvd_backward(const float* xyz, const float* center, const float* M, const float* cube,
+                            const dsf_camera* cam, const float* grad_uvd, int B, int N, int img_size,
+                            int world, float* grad_xyz, dsf_stream_t stream);
+
+/* crop_hand (data/render_loader.py:1209-1227) fused with uvdImg2xyzImg (:1190-1201):
+ * img (B,1,S,S), joints_nl (B,J,3) -> img_hand (B,1,S,S); xyz_nl (B,S*S,3) normalised point
+ * image (may be NULL); keep (B,S*S) uint8 inside-box mask (may be NULL; d img_hand/d img). */
+int dsf_crop_hand(const float* img, const float* joints_nl, const float* center, const float* minv,
+                  const float* cube, const dsf_camera* cam, int B, int J, int S, float offset_xy,
+                  float offset_z, float thickness, float* img_hand, float* xyz_nl, uint8_t* keep,
+                  dsf_stream_t stream);
+
+/* Img2pcl (data/render_loader.py:1121-1156): valid = img <= 0.99 in scan order, converted with
+ * uvd_nl2xyznl; resampled to exactly n_sample points: floor(n_sample/count) whole copies followed
+ * by (n_sample mod count) distinct points (count >= n_sample: n_sample distinct points), zeros if
+ * empty.  The reference draws with torch.multinomial; here the draw is the explicit input
+ * rand_keys (B,S*S) uint32 (the distinct points are the valid pixels with the smallest keys --
+ * ties by scan order -- emitted in scan order), so tests can inject the same draw.
+ * workspace: (B, 2*S*S) uint32.  counts (B) int32 out. */
+int dsf_img2pcl(const float* img, const float* center, const float* minv, const float* cube,
+                const dsf_camera* cam, const uint32_t* rand_keys, int B, int S, int n_sample,
+                float* pcl, int32_t* counts, uint32_t* workspace, dsf_stream_t stream);
+
+/* GFM.joint2offset (util/generateFeature.py:14-37 == model/backbone.py:68-91):
+ * joints (B,J,3), img (B,1,H,H) -> maps (B,4J,S,S). */
+int dsf_joint2offset_forward(const float* joints, const float* img, int B, int J, int H, int S,
+                             float kernel_size, float* maps, dsf_stream_t stream);
+int dsf_joint2offset_backward(const float* joints, const float* img, const float* grad_maps, int B, int J,
+                              int H, int S, float kernel_size, float* grad_joints, dsf_stream_t stream);
+/* GFM.offset2joint_softmax (util/generateFeature.py:39-59 == model/backbone.py:45-65):
+ * maps (B,4J,S,S), depth (B,1,H,H) -> joints (B,J,3); stats (B,J,2) = softmax max / denominator
+ * kept for the backward. */
+int dsf_offset2joint_forward(const float* maps, const float* depth, int B, int J, int H, int S,
+                             float kernel_size, float scale, float* joints, float* stats,
+                             dsf_stream_t stream);
+int dsf_offset2joint_backward(const float* maps, const float* depth, const float* joints,
+                              const float* stats, const float* grad_joints, int B, int J, int H, int S,
+                              float kernel_size, float scale, float* grad_maps, dsf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSF_HIP_H */

@@ -1,0 +1,70 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/dsf_hip.h declares; the product path refuses to run without a GPU (no fallback)."""
+import os
+import re
+
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    src = open(os.path.join(REPO, "include", "dsf_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dsf_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+    from dsf_amd import _lib
+    if not os.path.isfile(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    declared = _header_symbols()
+    assert len(declared) >= 28
+    for s in declared:
+        assert hasattr(lib, s), "libdsf_hip.so lacks %s" % s
+    assert sorted(_lib.SYMBOLS) == declared
+    lib.dsf_abi_version.restype = ctypes.c_int
+    assert lib.dsf_abi_version() == 1
+    lib.dsf_status_string.restype = ctypes.c_char_p
+    assert lib.dsf_status_string(2) == b"unsupported configuration"
+
+
+def test_product_path_has_no_cpu_fallback():
+    from dsf_amd.render_model.mano_layer import MANO_SMPL
+    from dsf_amd.metric.meshLoss import ICPLoss
+    from dsf_amd.util.generateFeature import GFM
+    m = MANO_SMPL("synthetic", "nyu")
+    with pytest.raises(RuntimeError):
+        m.get_mano_vertices(torch.zeros(1, 3), torch.zeros(1, 45), torch.zeros(1, 10), torch.ones(1, 4))
+    with pytest.raises(RuntimeError):
+        ICPLoss(torch.zeros(1, 779, 3), torch.zeros(1, 8, 3), m.faces)
+    with pytest.raises(RuntimeError):
+        GFM().joint2offset(torch.zeros(1, 21, 3), torch.zeros(1, 1, 128, 128), 0.8, 64)
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for root, _, files in os.walk(os.path.join(REPO, "dsf_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".sh")):
+                txt = open(os.path.join(root, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "oracle/" in txt and f.endswith(".sh"):
+                    bad.append(f)
+    assert not bad, bad
+
+
+def test_model_buffers_match_reference(golden):
+    import numpy as np
+    from dsf_amd.render_model.mano_layer import MANO_SMPL
+    m = MANO_SMPL("synthetic", "nyu")
+    assert np.array_equal(m.faces.numpy().astype(np.int32), golden["mano_faces"])
+    assert [f.shape[0] for f in m.joint_faces] == golden["mano_joint_faces_len"].tolist()
+    assert np.array_equal(torch.cat(m.joint_faces).numpy().astype(np.int32), golden["mano_joint_faces_cat"])
+    assert np.array_equal(torch.cat(m.finger_faces).numpy().astype(np.int32), golden["mano_finger_faces_cat"])
+    assert np.array_equal(m.mask.numpy().astype(np.uint8), golden["mano_coll_mask"])
+    assert np.array_equal(m.parents, golden["mano_parents"])
+    assert m.transfer == [18, 8, 19, 11, 17, 5, 16, 2, 20, 15, 14, 0]
