@@ -104,7 +104,7 @@ class MANO_SMPL(nn.Module):
         self.scale = scale
         model = load_mano_dict(mano_pkl_path)
 
-        t32 = lambda a: torch.from_numpy(np.array(a, dtype=np.float64)).float()
+        t32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).float().contiguous()
         faces = np.array(model['f'], dtype=np.int64)
         cap = np.array([[_WRIST_RING[i], _WRIST_RING[(i + 1) % 16], 778] for i in range(16)], dtype=np.int64)
         faces = np.concatenate([faces, cap], 0)                       # 1538 + 16 wrist-cap faces
@@ -210,7 +210,9 @@ class MANO_SMPL(nn.Module):
             if not self.v_template.is_cuda:
                 raise RuntimeError("MANO_SMPL buffers are on %s; dsf_amd runs on the GPU only -- call .cuda()"
                                    % self.v_template.device)
-            p = lambda t: t.data_ptr()
+            def p(t):
+                assert t.is_contiguous(), "model buffers handed to the kernels must be contiguous"
+                return t.data_ptr()
             self.c_struct = L.dsf_mano_model(p(self.v_template), p(self.shapedirs), p(self.posedirs),
                                              p(self.J_regressor), p(self.j_template), p(self.j_shapedirs),
                                              p(self.hands_comp), p(self.hands_mean), p(self.weight),

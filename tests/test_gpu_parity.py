@@ -267,7 +267,9 @@ def test_render_api_and_backward_vs_oracle(oracle_hand, mano, render):
     faces = N(mano.faces_i32)
     exp_img, exp_f, fv, p2f_full = _oracle_crop(vw.detach().numpy(), faces, Minv_gpu, N(render.resize_rowmap).astype(np.int64),
                                                 c2[:, 2], cube[:, 2])
-    assert (N(img) != exp_img).mean() < 2e-3
+    # (verts come from two MANO implementations here -> depths agree to 1e-4, not bitwise; only
+    #  silhouette pixels may flip)
+    assert (np.abs(N(img) - exp_img) > 1e-4).mean() < 2e-3
     # backward: oracle raster backward on the 640 grid, scattered from the crop gradient
     src = I.warp_source_index(Minv_gpu)
     half = cube[:, 2] / 2
@@ -396,14 +398,14 @@ def test_spheres_collision_seg_vs_golden(golden, mano):
     assert np.abs(N(c) - golden["sph_c"]).max() < 1e-5
     assert np.abs(N(r) - golden["sph_r"]).max() < 1e-5
     val = mano.calculate_coll(j, v)
-    assert abs(float(val) - float(golden["coll_val"])) < 1e-6
+    assert abs(float(val.detach()) - float(golden["coll_val"])) < 1e-6
     gj, gv = torch.autograd.grad(val, (j, v))
     assert np.abs(N(gj) - golden["coll_grad_j"]).max() < 1e-5
     assert np.abs(N(gv) - golden["coll_grad_v"]).max() < 1e-5
     j2 = T(golden["coll2_j"]).requires_grad_(True)
     v2 = T(golden["coll2_v"]).requires_grad_(True)
     val2 = mano.calculate_coll(j2, v2)
-    assert abs(float(val2) - float(golden["coll2_val"])) < 1e-6
+    assert abs(float(val2.detach()) - float(golden["coll2_val"])) < 1e-6
     gj2, gv2 = torch.autograd.grad(val2, (j2, v2))
     assert np.abs(N(gj2) - golden["coll2_grad_j"]).max() < 1e-5
     assert np.abs(N(gv2) - golden["coll2_grad_v"]).max() < 1e-5
@@ -516,7 +518,7 @@ def test_losses_vs_golden(golden):
     from dsf_amd.render_model.render_loss import depth_loss
     a = T(golden["sl1_a"]).requires_grad_(True)
     val = SmoothL1Loss()(a, T(golden["sl1_b"]))
-    assert abs(float(val) - float(golden["sl1_val"])) < 1e-8
+    assert abs(float(val.detach()) - float(golden["sl1_val"])) < 1e-8
     g, = torch.autograd.grad(val, a)
     assert np.abs(N(g) - golden["sl1_grad"]).max() < 1e-9
     assert abs(float(depth_loss()(T(golden["dl_a"]), T(golden["dl_b"]))) - float(golden["dl_val"])) < 1e-6
