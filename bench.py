@@ -1,0 +1,147 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/sec (fwd+bwd+optimizer) of the DSF training hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1]): per-GPU batch 32, ResNet-18 two-stage backbone
+(``MANO_OCR_stage('ResNet_stage_18', 21, refine=True)``, reference config.py:38,80,93) + MANO layer +
+fused crop rasteriser + GFM offset maps + SmoothL1 / m2d losses, backward, AdamW -- synthetic
+NYU-shape inputs, random-init weights, fp32 (the reference's precision).
+Weak scaling: every rank processes its own 32 images, gradients are averaged with a bucketed,
+backward-overlapped RCCL all-reduce.  One JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP32_MATRIX_PEAK_TFLOPS = 157.3
+
+
+def crop_kernel_roofline(render, B, launches=200):
+    """Live timing of the dominant hand-written kernel (dsf_render_crop_forward) with HIP events on
+    the stream it is launched on.  Algorithmic bytes per image (SURVEY 8d, K1 crop mode):
+    read verts 779*12 = 9,348 B, write depth crop 128*128*4 = 65,536 B + face index 65,536 B."""
+    from dsf_amd import ops
+    from dsf_amd.train_step import synthetic_batch
+    p, c, cube = synthetic_batch(B, "cuda", seed=123)
+    mano = render.mano_layer
+    with torch.no_grad():
+        v, _ = mano.get_mano_vertices(p[:, :3], p[:, 3:48], p[:, 48:58], p[:, 58:62], 1 / 125)
+        verts = (v * cube.unsqueeze(1) / 2 + c.unsqueeze(1)).contiguous()
+        c2, M, _, _ = ops.crop_setup(c, cube, render.cam, 128)
+        minv = torch.linalg.inv_ex(M)[0].contiguous()
+        cz, cbz = c2[:, 2].contiguous(), cube[:, 2].contiguous()
+        run = lambda: ops.RenderCropFunction.apply(verts, mano.faces_i32, minv, render.resize_rowmap, cz, cbz,
+                                                   render.cam, 640, 128)
+        for _ in range(10):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(launches):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / launches
+    bytes_per_launch = B * (779 * 12 + 128 * 128 * 4 + 128 * 128 * 4)
+    achieved = bytes_per_launch / (us * 1e-6) / 1e9
+    return {"kernel": "render_crop_fwd_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "avg_launch_us": round(us, 2), "bytes_per_launch": bytes_per_launch,
+            "note": "crop-mode raster is latency/VALU-bound at B=32 (4.5 MB per launch); HBM frac is its honest roofline"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--backbone", default="ResNet_stage_18")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=6)
+    args = ap.parse_args()
+
+    from dsf_amd.parallel import init_distributed, GradAllReducer
+    rank, local, world = init_distributed()
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    torch.backends.cudnn.benchmark = True           # as the reference (train_render.py:87): MIOpen find mode
+
+    from dsf_amd.render_model.mano_layer import Render
+    from dsf_amd.model.backbone import MANO_OCR_stage
+    from dsf_amd.train_step import RenderSupervisedStep, synthetic_batch, Config
+
+    torch.manual_seed(0)                              # identical initial weights on every rank
+    net = MANO_OCR_stage(args.backbone, 21, True).to(dev)
+    render = Render("synthetic", "nyu", (588.03, 587.07, 320.0, 240.0), (640, 480)).to(dev)
+    sync = GradAllReducer(net.parameters()) if world > 1 else None
+    step = RenderSupervisedStep(net, render, Config, grad_sync=sync)
+    p, c, cube = synthetic_batch(args.batch, dev, seed=0 + rank)           # per-rank shard of the global batch
+    tgt = step.make_targets(p, c, cube, seed=1 + rank)
+
+    for _ in range(args.warmup):
+        step(tgt)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = step(tgt)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    loss_val = float(loss)
+
+    if rank == 0:
+        images = args.batch * world * args.steps
+        out = {
+            "metric": "images/sec (fwd+bwd, 128x128 depth, MANO+render loss)",
+            "value": round(images / dt, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: batch=%d/GPU %s 2-stage + MANO + depth rasteriser, single view"
+                                   % (args.batch, args.backbone),
+                       "global_batch": args.batch * world, "crop": 128, "raster": 640, "parallelism": "dp%d" % world,
+                       "mano_asset": "synthetic MANO-shaped hand (real MANO_RIGHT.pkl is license-gated)"},
+            "final_loss": round(loss_val, 5),
+        }
+        out["roofline"] = crop_kernel_roofline(render, args.batch)
+        # the backbone (MIOpen convs) dominates the step: report its aggregate MFMA fraction too
+        flops_per_img = 3 * 25.42e9 if args.backbone.endswith("18") else 3 * 37.84e9     # fwd+bwd ~ 3x fwd
+        tf = flops_per_img * images / dt / 1e12
+        out["backbone_mfma"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": round(tf / FP32_MATRIX_PEAK_TFLOPS, 4),
+                                "note": "whole-step FLOP rate of the fp32 conv GEMMs (library kernels, not hand-written)"}
+        if world == 1 and not args.no_cpu_baseline:
+            from dsf_amd.assets import build_synthetic_mano
+            from oracle import step_ref                       # CPU oracle: the reported baseline leg only
+            torch.set_num_threads(os.cpu_count())
+            ips, secs, n = step_ref.timed_steps(build_synthetic_mano(0), B=2, steps=args.cpu_steps, warmup=1,
+                                                backbone=args.backbone)
+            out["cpu_baseline"] = {"value": round(ips, 3), "unit": "images/s", "cores": os.cpu_count(), "kind": "port",
+                                   "sample": "%d images: the same step (same net, losses, AdamW) at B=2 x %d steps through "
+                                             "the CPU oracle (torch-CPU trunk, C rasteriser, numpy crop chain), %.1f s"
+                                             % (n, args.cpu_steps, secs)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
