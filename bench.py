@@ -76,7 +76,7 @@ def main():
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    torch.backends.cudnn.benchmark = True           # as the reference (train_render.py:87): MIOpen find mode
+    torch.backends.cudnn.benchmark = os.environ.get("DSF_MIOPEN_FIND", "0") == "1"   # reference :87 uses find mode; gfx950 ships no MIOpen find-db, find mode JIT-compiles every solver (hours)
 
     from dsf_amd.render_model.mano_layer import Render
     from dsf_amd.model.backbone import MANO_OCR_stage

@@ -1,0 +1,350 @@
+// K11: fp32 implicit-GEMM convolution on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact f32
+// in / f32 accumulate, 157 TFLOP/s peak) for the backbone's dense layers.
+//
+// Why hand-written: ROCm 7.2's MIOpen ships no gfx950 find-db / perf-db / kernel-db.  In find mode
+// (the reference's cudnn.benchmark=True) every solver is JIT-compiled for every layer (hours on a
+// fresh box); in immediate mode it falls back to `naive_conv_*` kernels (45 ms per launch, 3.3 s per
+// step measured: profiles/r01_step_miopen_immediate_stats.csv).  These two kernels replace all
+// Conv2d / ConvTranspose2d forward, backward-data and backward-weight passes of ResNet-18/50,
+// the hourglass and the CycleGAN generator.
+//
+// Layout: NHWC activations (torch channels_last), weights as a [KH*KW*Ci][Co] row-major GEMM
+// operand.  GEMM view: M = B*Ho*Wo output pixels, N = Co, K = KH*KW*Ci; the A operand is gathered
+// on the fly (no im2col buffer in HBM).  Block tile 128(M) x BN(N: 128 or 64) x 32(K), 256 threads =
+// 4 waves, each wave a 64x64 (or 32x64) sub-tile of 32x32 MFMA tiles.  Operands are staged k-major in
+// LDS so that the MFMA fragment read (lane l -> row l&31, k = l>>5) is a conflict-free ds_read_b32;
+// the next K-chunk's global loads are issued before the MFMA block and written to LDS after it.
+// The fp32 MFMA takes 64 cycles per 32x32x2, so per 32-deep chunk a wave spends 4096 MFMA cycles
+// against 16 dwords of global traffic per lane: the kernel is MFMA-bound by construction.
+//
+// `dil` generalises the gather to transposed convolutions (virtual input = X upsampled by `dil`
+// with zeros): forward conv (stride s, dil 1), backward-data of a stride-1 conv (flipped weights),
+// backward-data of a stride-2 conv and ConvTranspose2d forward (dil 2) all run the same kernel.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvP {
+    int B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, dil, pad_h, pad_w;
+};
+
+constexpr int BM = 128, BK = 32;
+
+// ------------------------------------------------------------------------------------------------
+// forward-type kernel: Y[m][n] = sum_k A[m][k] W[k][n] (+ bias[n])
+// ------------------------------------------------------------------------------------------------
+template <int BN>
+__global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                        const float* __restrict__ bias, float* __restrict__ Y, ConvP p,
+                                                        int m_tiles) {
+    constexpr int LDA = BM + 4, LDB = BN + 4;
+    constexpr int WM = (BN == 128) ? 64 : 32;       // wave tile rows
+    constexpr int TM = WM / 32, TN = 2;
+    constexpr int B4 = BN / 4;                       // float4 per weight row of the tile
+    constexpr int BROWS = 256 / B4;                  // weight rows loaded per pass
+    constexpr int BPASS = BK / BROWS;
+    __shared__ float As[BK * LDA];
+    __shared__ float Bs[BK * LDB];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = (BN == 128) ? (wave >> 1) : wave, wn = (BN == 128) ? (wave & 1) : 0;
+    const int m_tile = blockIdx.x % m_tiles, n_tile = blockIdx.x / m_tiles;
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+    const int M = p.B * p.Ho * p.Wo;
+    const bool vec_a = (p.Ci & 3) == 0, vec_b = (p.Co & 3) == 0;
+
+    // A-load coordinates: 4 rows per thread, one float4 (4 consecutive k) each
+    const int a_k4 = (t & 7) * 4;
+    int a_b[4], a_oy[4], a_ox[4];
+    bool a_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + (t >> 3) + 32 * i;
+        a_ok[i] = m < M;
+        const int mm = a_ok[i] ? m : 0;
+        a_ox[i] = mm % p.Wo;
+        const int q = mm / p.Wo;
+        a_oy[i] = q % p.Ho;
+        a_b[i] = q / p.Ho;
+    }
+    const int b_n4 = (t % B4) * 4, b_row = t / B4;
+    const int vH = (p.Hi - 1) * p.dil + 1, vW = (p.Wi - 1) * p.dil + 1;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[4], rb[BPASS];
+    const int chunks_per_tap = (p.Ci + BK - 1) / BK;
+    const int n_chunks = p.KH * p.KW * chunks_per_tap;
+
+    auto load_chunk = [&](int chunk) {
+        const int tap = chunk / chunks_per_tap, c0 = (chunk % chunks_per_tap) * BK;
+        const int kh = tap / p.KW, kw = tap % p.KW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int vy = a_oy[i] * p.stride + kh - p.pad_h, vx = a_ox[i] * p.stride + kw - p.pad_w;
+            bool ok = a_ok[i] && vy >= 0 && vy < vH && vx >= 0 && vx < vW;
+            int iy = vy, ix = vx;
+            if (p.dil > 1) {
+                ok = ok && (vy % p.dil == 0) && (vx % p.dil == 0);
+                iy = vy / p.dil; ix = vx / p.dil;
+            }
+            const int c = c0 + a_k4;
+            if (ok && c < p.Ci) {
+                const float* src = X + (((int64_t)a_b[i] * p.Hi + iy) * p.Wi + ix) * p.Ci + c;
+                if (vec_a) {
+                    v = *reinterpret_cast<const float4*>(src);
+                } else {
+                    v.x = src[0];
+                    if (c + 1 < p.Ci) v.y = src[1];
+                    if (c + 2 < p.Ci) v.z = src[2];
+                    if (c + 3 < p.Ci) v.w = src[3];
+                }
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int kk = b_row + BROWS * i;
+            const int c = c0 + kk, n = n0 + b_n4;
+            if (c < p.Ci && n < p.Co) {
+                const float* src = W + ((int64_t)tap * p.Ci + c) * p.Co + n;
+                if (vec_b) {
+                    v = *reinterpret_cast<const float4*>(src);
+                } else {
+                    v.x = src[0];
+                    if (n + 1 < p.Co) v.y = src[1];
+                    if (n + 2 < p.Co) v.z = src[2];
+                    if (n + 3 < p.Co) v.w = src[3];
+                }
+            }
+            rb[i] = v;
+        }
+    };
+
+    load_chunk(0);
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = (t >> 3) + 32 * i;
+            As[(a_k4 + 0) * LDA + r] = ra[i].x; As[(a_k4 + 1) * LDA + r] = ra[i].y;
+            As[(a_k4 + 2) * LDA + r] = ra[i].z; As[(a_k4 + 3) * LDA + r] = ra[i].w;
+        }
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i)
+            *reinterpret_cast<float4*>(&Bs[(b_row + BROWS * i) * LDB + b_n4]) = rb[i];
+        __syncthreads();
+        if (chunk + 1 < n_chunks) load_chunk(chunk + 1);       // in flight during the MFMA block
+#pragma unroll 4
+        for (int kk = 0; kk < BK; kk += 2) {
+            const int k = kk + (lane >> 5);
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[k * LDA + wm * WM + i * 32 + (lane & 31)];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[k * LDB + wn * 64 + j * 32 + (lane & 31)];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (n >= p.Co) continue;
+            const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < M) Y[(int64_t)m * p.Co + n] = acc[i][j][r] + bv;
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward-weights: dW[k][n] += sum_m A[m][k] dY[m][n], reduction over pixels split across blocks
+// ------------------------------------------------------------------------------------------------
+template <int BN>
+__global__ __launch_bounds__(256) void igemm_wrw_kernel(const float* __restrict__ X, const float* __restrict__ dY,
+                                                        float* __restrict__ dW, ConvP p, int k_tiles, int n_tiles,
+                                                        int m_per_split) {
+    constexpr int BKT = 128;                         // k rows of the output tile
+    constexpr int LDA = BKT + 4, LDB = BN + 4;
+    constexpr int WM = (BN == 128) ? 64 : 32;
+    constexpr int TM = WM / 32, TN = 2;
+    constexpr int B4 = BN / 4, BROWS = 256 / B4, BPASS = BK / BROWS;
+    __shared__ float As[BK * LDA];                   // [pixel][k]
+    __shared__ float Bs[BK * LDB];                   // [pixel][n]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = (BN == 128) ? (wave >> 1) : wave, wn = (BN == 128) ? (wave & 1) : 0;
+    int bid = blockIdx.x;
+    const int k_tile = bid % k_tiles; bid /= k_tiles;
+    const int n_tile = bid % n_tiles; const int split = bid / n_tiles;
+    const int k0 = k_tile * BKT, n0 = n_tile * BN;
+    const int M = p.B * p.Ho * p.Wo, K = p.KH * p.KW * p.Ci;
+    const int m_begin = split * m_per_split, m_end = min(M, m_begin + m_per_split);
+    const bool vec_a = (p.Ci & 3) == 0, vec_b = (p.Co & 3) == 0;
+
+    // A loader: thread -> 4 consecutive k (same tap when Ci%4==0), 4 pixel rows per chunk
+    const int a_k = k0 + (t & 31) * 4;
+    int a_kh[4], a_kw[4], a_c[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = min(a_k + j, K - 1);
+        const int tap = k / p.Ci;
+        a_c[j] = k % p.Ci; a_kh[j] = tap / p.KW; a_kw[j] = tap % p.KW;
+    }
+    const int b_n4 = (t % B4) * 4, b_row = t / B4;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[4], rb[BPASS];
+    auto load_chunk = [&](int mc) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int m = mc + (t >> 5) + 8 * i;
+            if (m < m_end && a_k < K) {
+                const int ox = m % p.Wo, q = m / p.Wo, oy = q % p.Ho, b = q / p.Ho;
+                if (vec_a) {
+                    const int iy = oy * p.stride + a_kh[0] - p.pad_h, ix = ox * p.stride + a_kw[0] - p.pad_w;
+                    if (iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi)
+                        v = *reinterpret_cast<const float4*>(X + (((int64_t)b * p.Hi + iy) * p.Wi + ix) * p.Ci + a_c[0]);
+                } else {
+                    float e[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int iy = oy * p.stride + a_kh[j] - p.pad_h, ix = ox * p.stride + a_kw[j] - p.pad_w;
+                        if (a_k + j < K && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi)
+                            e[j] = X[(((int64_t)b * p.Hi + iy) * p.Wi + ix) * p.Ci + a_c[j]];
+                    }
+                    v = make_float4(e[0], e[1], e[2], e[3]);
+                }
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int m = mc + b_row + BROWS * i, n = n0 + b_n4;
+            if (m < m_end && n < p.Co) {
+                const float* src = dY + (int64_t)m * p.Co + n;
+                if (vec_b) {
+                    v = *reinterpret_cast<const float4*>(src);
+                } else {
+                    v.x = src[0];
+                    if (n + 1 < p.Co) v.y = src[1];
+                    if (n + 2 < p.Co) v.z = src[2];
+                    if (n + 3 < p.Co) v.w = src[3];
+                }
+            }
+            rb[i] = v;
+        }
+    };
+
+    if (m_begin < m_end) load_chunk(m_begin);
+    for (int mc = m_begin; mc < m_end; mc += BK) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&As[((t >> 5) + 8 * i) * LDA + (t & 31) * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i) *reinterpret_cast<float4*>(&Bs[(b_row + BROWS * i) * LDB + b_n4]) = rb[i];
+        __syncthreads();
+        if (mc + BK < m_end) load_chunk(mc + BK);
+#pragma unroll 4
+        for (int kk = 0; kk < BK; kk += 2) {
+            const int r = kk + (lane >> 5);
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[r * LDA + wm * WM + i * 32 + (lane & 31)];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[r * LDB + wn * 64 + j * 32 + (lane & 31)];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (n >= p.Co) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = k0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (k < K) atomicAdd(dW + (int64_t)k * p.Co + n, acc[i][j][r]);
+            }
+        }
+}
+
+}  // namespace
+
+extern "C" int dsf_conv_igemm_forward(const float* X, const float* W, const float* bias, float* Y, int B, int Hi, int Wi,
+                                      int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int dil, int pad_h,
+                                      int pad_w, dsf_stream_t stream) {
+    DSF_CHECK_ARG(X && W && Y && B >= 0 && Hi > 0 && Wi > 0 && Ci > 0 && Ho > 0 && Wo > 0 && Co > 0 && KH > 0 && KW > 0);
+    DSF_CHECK_ARG(stride >= 1 && dil >= 1 && (stride == 1 || dil == 1));
+    if (B == 0) return DSF_OK;
+    ConvP p = {B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, dil, pad_h, pad_w};
+    const int64_t M = (int64_t)B * Ho * Wo;
+    DSF_CHECK_ARG(M < (1ll << 31));
+    const int m_tiles = (int)((M + BM - 1) / BM);
+    if (Co > 64) {
+        const int n_tiles = (Co + 127) / 128;
+        hipLaunchKernelGGL(igemm_fwd_kernel<128>, dim3(m_tiles * n_tiles), dim3(256), 0, (hipStream_t)stream, X, W, bias,
+                           Y, p, m_tiles);
+    } else {
+        hipLaunchKernelGGL(igemm_fwd_kernel<64>, dim3(m_tiles), dim3(256), 0, (hipStream_t)stream, X, W, bias, Y, p, m_tiles);
+    }
+    return dsf_launch_status();
+}
+
+extern "C" int dsf_conv_igemm_wrw(const float* X, const float* dY, float* dW, int B, int Hi, int Wi, int Ci, int Ho, int Wo,
+                                  int Co, int KH, int KW, int stride, int pad_h, int pad_w, dsf_stream_t stream) {
+    DSF_CHECK_ARG(X && dY && dW && B >= 0 && Hi > 0 && Wi > 0 && Ci > 0 && Ho > 0 && Wo > 0 && Co > 0 && KH > 0 && KW > 0);
+    const int K = KH * KW * Ci;
+    if (hipMemsetAsync(dW, 0, sizeof(float) * (size_t)K * Co, (hipStream_t)stream) != hipSuccess) return DSF_ERR_LAUNCH;
+    if (B == 0) return DSF_OK;
+    ConvP p = {B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, 1, pad_h, pad_w};
+    const int64_t M = (int64_t)B * Ho * Wo;
+    DSF_CHECK_ARG(M < (1ll << 31));
+    const int k_tiles = (K + 127) / 128;
+    const int bn = (Co > 64) ? 128 : 64;
+    const int n_tiles = (Co + bn - 1) / bn;
+    // split the pixel reduction so that ~1024 workgroups are in flight; at least 4 chunks per split
+    int splits = 1024 / (k_tiles * n_tiles);
+    if (splits < 1) splits = 1;
+    int64_t per = (M + splits - 1) / splits;
+    per = ((per + BK - 1) / BK) * BK;
+    if (per < 4 * BK) per = 4 * BK;
+    splits = (int)((M + per - 1) / per);
+    if (bn == 128)
+        hipLaunchKernelGGL(igemm_wrw_kernel<128>, dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream, X, dY,
+                           dW, p, k_tiles, n_tiles, (int)per);
+    else
+        hipLaunchKernelGGL(igemm_wrw_kernel<64>, dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream, X, dY,
+                           dW, p, k_tiles, n_tiles, (int)per);
+    return dsf_launch_status();
+}

@@ -10,7 +10,9 @@ import math
 import torch
 import torch.nn as nn
 
+from . import resnet as _resnet
 from .resnet import BasicBlock, Bottleneck
+from .. import nn_conv
 from ..util.generateFeature import joint2offset, offset2joint_softmax
 
 BN_MOMENTUM = 0.1
@@ -19,8 +21,25 @@ resnet = {18: (BasicBlock, [2, 2, 2, 2]), 50: (Bottleneck, [3, 4, 6, 3]), 101: (
 N_MANO = 3 + 45 + 10 + 4
 
 
-def convtranspose_bn_relu(cin, cout, kernel):
-    return nn.Sequential(nn.ConvTranspose2d(cin, cout, kernel, stride=2, padding=1, output_padding=0, bias=False),
+class _Layers:
+    """Layer factories: the HIP implicit-GEMM convolutions (native=True, GPU only) or plain torch.nn
+    (native=False: the CPU twin the oracle / cpu_baseline builds; same parameters and keys)."""
+
+    def __init__(self, native):
+        self.Conv2d = nn_conv.Conv2d if native else nn.Conv2d
+        self.ConvTranspose2d = nn_conv.ConvTranspose2d if native else nn.ConvTranspose2d
+
+    def __enter__(self):
+        self._saved = _resnet._CONV[0]
+        _resnet._CONV[0] = self.Conv2d
+        return self
+
+    def __exit__(self, *a):
+        _resnet._CONV[0] = self._saved
+
+
+def convtranspose_bn_relu(cin, cout, kernel, L):
+    return nn.Sequential(L.ConvTranspose2d(cin, cout, kernel, stride=2, padding=1, output_padding=0, bias=False),
                          nn.BatchNorm2d(cout, momentum=0.1), nn.ReLU(inplace=True))
 
 
@@ -28,14 +47,15 @@ class _TwoBranchNet(nn.Module):
     """Trunk builder shared by the 1-stage and 2-stage nets; ``suffix`` = '' or '_s2'."""
 
     def _stem(self):
-        self.pre = nn.Sequential(nn.Conv2d(1, 64, kernel_size=5, stride=1, padding=2, bias=False),
+        L = self._L
+        self.pre = nn.Sequential(L.Conv2d(1, 64, kernel_size=5, stride=1, padding=2, bias=False),
                                  nn.BatchNorm2d(64, momentum=BN_MOMENTUM), nn.ReLU(inplace=True),
                                  nn.MaxPool2d(kernel_size=3, stride=2, padding=1))
 
     def _make_layer(self, block, planes, blocks, stride=1):
         down = None
         if stride != 1 or self.inplanes != planes * block.expansion:
-            down = nn.Sequential(nn.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
+            down = nn.Sequential(self._L.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
                                  nn.BatchNorm2d(planes * block.expansion, momentum=BN_MOMENTUM))
         layers = [block(self.inplanes, planes, stride, down)]
         self.inplanes = planes * block.expansion
@@ -47,11 +67,12 @@ class _TwoBranchNet(nn.Module):
             setattr(self, 'layer%d%s' % (i + 1, suffix), self._make_layer(block, planes, layers[i], stride))
         setattr(self, 'mano_regress' + suffix,
                 nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(self.inplanes, N_MANO)))
-        setattr(self, 'deconv_layer4' + suffix, convtranspose_bn_relu(self.inplanes, 256, 4))
-        setattr(self, 'deconv_layer3' + suffix, convtranspose_bn_relu(256, 256, 4))
-        setattr(self, 'deconv_layer2' + suffix, convtranspose_bn_relu(256, 256, 4))
-        heads = nn.ModuleList([nn.Conv2d(256, self.joint_num * 3, kernel_size=1, stride=1),
-                               nn.Conv2d(256, self.joint_num, kernel_size=1, stride=1)])
+        L = self._L
+        setattr(self, 'deconv_layer4' + suffix, convtranspose_bn_relu(self.inplanes, 256, 4, L))
+        setattr(self, 'deconv_layer3' + suffix, convtranspose_bn_relu(256, 256, 4, L))
+        setattr(self, 'deconv_layer2' + suffix, convtranspose_bn_relu(256, 256, 4, L))
+        heads = nn.ModuleList([L.Conv2d(256, self.joint_num * 3, kernel_size=1, stride=1),
+                               L.Conv2d(256, self.joint_num, kernel_size=1, stride=1)])
         setattr(self, 'finals' + suffix, heads)
 
     def _run_trunk(self, x, suffix):
@@ -81,14 +102,16 @@ class _TwoBranchNet(nn.Module):
 
 
 class MANO_OCR(_TwoBranchNet):
-    def __init__(self, backbone, joint_num):
+    def __init__(self, backbone, joint_num, native=True):
         super().__init__()
+        self._L = _Layers(native)
         self.joint_num = joint_num
         self.feature_dim = [joint_num * 3, joint_num]
         block, layers = resnet[int(backbone.split('_')[-1])]
-        self._stem()
-        self.inplanes = 64
-        self._trunk(block, layers, '')
+        with self._L:
+            self._stem()
+            self.inplanes = 64
+            self._trunk(block, layers, '')
         self.init_weights()
 
     def forward(self, img):
@@ -97,21 +120,23 @@ class MANO_OCR(_TwoBranchNet):
 
 
 class MANO_OCR_stage(_TwoBranchNet):
-    def __init__(self, backbone, joint_num, refine=False, coord='xyz'):
+    def __init__(self, backbone, joint_num, refine=False, coord='xyz', native=True):
         super().__init__()
+        self._L = _Layers(native)
         self.joint_num = joint_num
         self.feature_dim = [joint_num * 3, joint_num]
         self.refine = refine
         self.coord_type = coord
         self.pool = nn.AdaptiveAvgPool2d(1)
         block, layers = resnet[int(backbone.split('_')[-1])]
-        self._stem()
-        self.inplanes = 64
-        self._trunk(block, layers, '')
-        if refine:
-            self.fusion = nn.Sequential(nn.Conv2d(256 + joint_num * 4 * 2 + 64, 256, 3, 1, 1), nn.BatchNorm2d(256), nn.ReLU())
-            self.inplanes = 256
-            self._trunk(block, layers, '_s2')
+        with self._L:
+            self._stem()
+            self.inplanes = 64
+            self._trunk(block, layers, '')
+            if refine:
+                self.fusion = nn.Sequential(self._L.Conv2d(256 + joint_num * 4 * 2 + 64, 256, 3, 1, 1), nn.BatchNorm2d(256), nn.ReLU())
+                self.inplanes = 256
+                self._trunk(block, layers, '_s2')
         self.init_weights()
 
     def forward(self, img, render=None, center=None, cube=None, M=None):

@@ -4,9 +4,13 @@ MFMA for the backbone's conv GEMMs only.  Attribute names follow the reference s
 checkpoints (state-dict keys) load unchanged."""
 import torch.nn as nn
 
+from ..nn_conv import Conv2d as _HipConv2d
+
+_CONV = [_HipConv2d]      # layer factory switch: [nn.Conv2d] builds the plain-torch CPU twin (oracle / tests)
+
 
 def _conv(cin, cout, k, stride=1):
-    return nn.Conv2d(cin, cout, kernel_size=k, stride=stride, padding=k // 2, bias=False)
+    return _CONV[0](cin, cout, kernel_size=k, stride=stride, padding=k // 2, bias=False)
 
 
 class BasicBlock(nn.Module):

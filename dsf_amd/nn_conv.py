@@ -1,0 +1,139 @@
+"""Conv2d / ConvTranspose2d on the hand-written fp32 MFMA implicit-GEMM kernels
+(dsf_amd/csrc/conv.hip).  Drop-in subclasses of the torch modules: same parameters, state-dict
+keys and initialisation; only ``forward`` differs.  Activations are kept channels_last (NHWC in
+memory), which is what the kernels read and write.  GPU only: a CPU tensor raises (the CPU oracle
+builds the same architecture from plain ``torch.nn`` layers instead, ``native=False``).
+"""
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib as L
+from ._lib import I, ptr, check, stream_ptr
+
+CL = torch.channels_last
+
+
+def _nhwc(x):
+    if x.dtype != torch.float32:
+        x = x.float()
+    return x.contiguous(memory_format=CL)
+
+
+def _fwd(x, wk, bias, out_hw, Co, KH, KW, stride, dil, pad):
+    """x: (B,Ci,Hi,Wi) channels_last; wk: [KH][KW][Ci][Co] contiguous -> (B,Co,Ho,Wo) channels_last."""
+    B, Ci, Hi, Wi = x.shape
+    Ho, Wo = out_hw
+    y = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=CL)
+    check(L.lib().dsf_conv_igemm_forward(ptr_nhwc(x), ptr(wk), ptr(bias), ptr_nhwc(y), I(B), I(Hi), I(Wi), I(Ci), I(Ho),
+                                         I(Wo), I(Co), I(KH), I(KW), I(stride), I(dil), I(pad[0]), I(pad[1]),
+                                         stream_ptr()), "dsf_conv_igemm_forward")
+    return y
+
+
+def _wrw(x, gy, KH, KW, stride, pad):
+    """-> dW [KH][KW][Ci][Co] for x (B,Ci,Hi,Wi), gy (B,Co,Ho,Wo), both channels_last."""
+    B, Ci, Hi, Wi = x.shape
+    _, Co, Ho, Wo = gy.shape
+    dw = torch.empty((KH, KW, Ci, Co), device=x.device, dtype=torch.float32)
+    check(L.lib().dsf_conv_igemm_wrw(ptr_nhwc(x), ptr_nhwc(gy), ptr(dw), I(B), I(Hi), I(Wi), I(Ci), I(Ho), I(Wo), I(Co),
+                                     I(KH), I(KW), I(stride), I(pad[0]), I(pad[1]), stream_ptr()), "dsf_conv_igemm_wrw")
+    return dw
+
+
+def ptr_nhwc(t):
+    if not t.is_cuda:
+        raise RuntimeError("dsf_amd convolution runs on the GPU only (got %s); build the net with native=False for "
+                           "a plain torch.nn CPU twin" % t.device)
+    assert t.is_contiguous(memory_format=CL) or t.is_contiguous()
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class Conv2dFunction(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding):
+        x = _nhwc(x)
+        Co, Ci, KH, KW = weight.shape
+        B, _, Hi, Wi = x.shape
+        Ho = (Hi + 2 * padding[0] - KH) // stride + 1
+        Wo = (Wi + 2 * padding[1] - KW) // stride + 1
+        wk = weight.detach().float().permute(2, 3, 1, 0).contiguous()
+        y = _fwd(x, wk, bias.detach().float().contiguous() if bias is not None else None, (Ho, Wo), Co, KH, KW, stride, 1,
+                 padding)
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, padding, bias is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        stride, padding, has_bias = ctx.cfg
+        Co, Ci, KH, KW = weight.shape
+        gy = _nhwc(gy)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            wd = weight.detach().float().flip(2, 3).permute(2, 3, 0, 1).contiguous()          # [kh'][kw'][Co][Ci]
+            gx = _fwd(gy, wd, None, (x.shape[2], x.shape[3]), Ci, KH, KW, 1, stride, (KH - 1 - padding[0], KW - 1 - padding[1]))
+        if ctx.needs_input_grad[1]:
+            gw = _wrw(x, gy, KH, KW, stride, padding).permute(3, 2, 0, 1)
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum(dim=(0, 2, 3))
+        return gx, gw, gb, None, None
+
+
+class ConvTranspose2dFunction(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, output_padding):
+        x = _nhwc(x)
+        Cin, Cout, KH, KW = weight.shape
+        B, _, Hi, Wi = x.shape
+        Ho = (Hi - 1) * stride - 2 * padding[0] + KH + output_padding[0]
+        Wo = (Wi - 1) * stride - 2 * padding[1] + KW + output_padding[1]
+        wk = weight.detach().float().flip(2, 3).permute(2, 3, 0, 1).contiguous()             # [kh'][kw'][Cin][Cout]
+        y = _fwd(x, wk, bias.detach().float().contiguous() if bias is not None else None, (Ho, Wo), Cout, KH, KW, 1, stride,
+                 (KH - 1 - padding[0], KW - 1 - padding[1]))
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, padding, bias is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        stride, padding, has_bias = ctx.cfg
+        Cin, Cout, KH, KW = weight.shape
+        gy = _nhwc(gy)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            wd = weight.detach().float().permute(2, 3, 1, 0).contiguous()                     # [kh][kw][Cout][Cin]
+            gx = _fwd(gy, wd, None, (x.shape[2], x.shape[3]), Cin, KH, KW, stride, 1, padding)
+        if ctx.needs_input_grad[1]:
+            gw = _wrw(gy, x, KH, KW, stride, padding).permute(3, 2, 0, 1)                      # [kh][kw][Cout][Cin] -> (Cin,Cout,kh,kw)
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum(dim=(0, 2, 3))
+        return gx, gw, gb, None, None, None
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d whose forward runs dsf_conv_igemm_* (groups=1, dilation=1, zero padding, square stride)."""
+
+    def forward(self, x):
+        assert self.groups == 1 and _pair(self.dilation) == (1, 1) and self.padding_mode == 'zeros'
+        s = _pair(self.stride)
+        assert s[0] == s[1]
+        return Conv2dFunction.apply(x, self.weight, self.bias, s[0], _pair(self.padding))
+
+
+class ConvTranspose2d(nn.ConvTranspose2d):
+    def forward(self, x, output_size=None):
+        assert self.groups == 1 and _pair(self.dilation) == (1, 1) and output_size is None
+        s = _pair(self.stride)
+        assert s[0] == s[1]
+        return ConvTranspose2dFunction.apply(x, self.weight, self.bias, s[0], _pair(self.padding), _pair(self.output_padding))

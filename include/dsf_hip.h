@@ -265,6 +265,24 @@ int dsf_offset2joint_backward(const float* maps, const float* depth, const float
                               const float* stats, const float* grad_joints, int B, int J, int H, int S,
                               float kernel_size, float scale, float* grad_maps, dsf_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * K11  fp32 implicit-GEMM convolution on the matrix cores (v_mfma_f32_32x32x2_f32).
+ * Replaces the cuDNN/MIOpen convolutions behind nn.Conv2d / nn.ConvTranspose2d of
+ * model/resnet.py, model/backbone.py, model/hourglass.py, render_model/transfer.py (MIOpen has
+ * no gfx950 database in ROCm 7.2: find mode compiles for hours, immediate mode runs naive kernels).
+ * NHWC activations; W is the [KH*KW*Ci][Co] row-major GEMM operand.
+ *   Y[b,oy,ox,n] = bias[n] + sum_{kh,kw,c} Xv[b, oy*stride+kh-pad_h, ox*stride+kw-pad_w, c] * W[(kh*KW+kw)*Ci+c][n]
+ * where Xv is X upsampled by `dil` with zeros (dil = 1: ordinary convolution; dil > 1 with
+ * stride = 1: transposed convolution / backward-data of a strided convolution).
+ * ---------------------------------------------------------------------------------- */
+int dsf_conv_igemm_forward(const float* X, const float* W, const float* bias, float* Y, int B, int Hi, int Wi,
+                           int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int dil, int pad_h,
+                           int pad_w, dsf_stream_t stream);
+/* dW[(kh*KW+kw)*Ci+c][n] = sum_{b,oy,ox} X[b, oy*stride+kh-pad_h, ox*stride+kw-pad_w, c] * dY[b,oy,ox,n]
+ * (zeroed by the call, accumulated with float atomics across the pixel splits). */
+int dsf_conv_igemm_wrw(const float* X, const float* dY, float* dW, int B, int Hi, int Wi, int Ci, int Ho, int Wo,
+                       int Co, int KH, int KW, int stride, int pad_h, int pad_w, dsf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

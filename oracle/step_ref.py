@@ -145,7 +145,7 @@ def timed_steps(mano_dict, B=2, steps=3, warmup=1, backbone="ResNet_stage_18", s
     from dsf_amd.model.backbone import MANO_OCR_stage          # plain torch.nn trunk (no HIP inside its modules)
     from dsf_amd.train_step import synthetic_batch
     torch.manual_seed(seed)
-    net = MANO_OCR_stage(backbone, 21, True)
+    net = MANO_OCR_stage(backbone, 21, True, native=False)       # plain torch.nn twin of the product net
     opt = torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=0.01)
     render = OracleRender(mano_dict)
     p, c, cube = synthetic_batch(B, "cpu", seed)
