@@ -35,10 +35,15 @@ constexpr int BM = 128, BK = 32;
 // ------------------------------------------------------------------------------------------------
 // forward-type kernel: Y[m][n] = sum_k A[m][k] W[k][n] (+ bias[n])
 // ------------------------------------------------------------------------------------------------
-template <int BN>
+// FLAT: K is walked as one flat (tap, channel) index in 32-wide chunks (small Ci, e.g. the 1-channel
+// stem) instead of per-tap channel chunks.  k_splits > 1: the K range is split across workgroups and
+// the partial tiles are combined with float atomics (small-M layers: 512ch @ 8x8 has only 64 tiles).
+// perm: with dil > 1 output pixels are ordered parity-class-major, so all rows of a tile share
+// (oy % dil, ox % dil) and the taps that only ever hit inserted zeros are skipped tile-wide.
+template <int BN, bool FLAT>
 __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                         const float* __restrict__ bias, float* __restrict__ Y, ConvP p,
-                                                        int m_tiles) {
+                                                        int m_tiles, int n_tiles, int k_splits, int perm) {
     constexpr int LDA = BM + 4, LDB = BN + 4;
     constexpr int WM = (BN == 128) ? 64 : 32;       // wave tile rows
     constexpr int TM = WM / 32, TN = 2;
@@ -49,10 +54,28 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
     __shared__ float Bs[BK * LDB];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = (BN == 128) ? (wave >> 1) : wave, wn = (BN == 128) ? (wave & 1) : 0;
-    const int m_tile = blockIdx.x % m_tiles, n_tile = blockIdx.x / m_tiles;
+    int bid = blockIdx.x;
+    const int m_tile = bid % m_tiles; bid /= m_tiles;
+    const int n_tile = bid % n_tiles; const int ks = bid / n_tiles;
     const int m0 = m_tile * BM, n0 = n_tile * BN;
     const int M = p.B * p.Ho * p.Wo;
     const bool vec_a = (p.Ci & 3) == 0, vec_b = (p.Co & 3) == 0;
+    const int Hq = p.Ho / p.dil, Wq = p.Wo / p.dil, Mc = p.B * Hq * Wq;      // perm only
+    auto decode = [&](int m, int& b, int& oy, int& ox) {
+        if (perm) {
+            const int cls = m / Mc, r = m % Mc;
+            const int qx = r % Wq, q = r / Wq;
+            ox = qx * p.dil + cls % p.dil; oy = (q % Hq) * p.dil + cls / p.dil; b = q / Hq;
+        } else {
+            ox = m % p.Wo; const int q = m / p.Wo; oy = q % p.Ho; b = q / p.Ho;
+        }
+    };
+    // tile-uniform parity class (-1: mixed / not applicable)
+    int tile_py = -1, tile_px = -1;
+    if (perm) {
+        const int c0 = m0 / Mc, c1 = min(m0 + BM - 1, M - 1) / Mc;
+        if (c0 == c1) { tile_py = c0 / p.dil; tile_px = c0 % p.dil; }
+    }
 
     // A-load coordinates: 4 rows per thread, one float4 (4 consecutive k) each
     const int a_k4 = (t & 7) * 4;
@@ -62,11 +85,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + (t >> 3) + 32 * i;
         a_ok[i] = m < M;
-        const int mm = a_ok[i] ? m : 0;
-        a_ox[i] = mm % p.Wo;
-        const int q = mm / p.Wo;
-        a_oy[i] = q % p.Ho;
-        a_b[i] = q / p.Ho;
+        decode(a_ok[i] ? m : 0, a_b[i], a_oy[i], a_ox[i]);
     }
     const int b_n4 = (t % B4) * 4, b_row = t / B4;
     const int vH = (p.Hi - 1) * p.dil + 1, vW = (p.Wi - 1) * p.dil + 1;
@@ -80,10 +99,57 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[4], rb[BPASS];
+    const int Ktot = p.KH * p.KW * p.Ci;
     const int chunks_per_tap = (p.Ci + BK - 1) / BK;
-    const int n_chunks = p.KH * p.KW * chunks_per_tap;
+    const int n_chunks = FLAT ? (Ktot + BK - 1) / BK : p.KH * p.KW * chunks_per_tap;
+    const int per_split = (n_chunks + k_splits - 1) / k_splits;
+    const int chunk_lo = ks * per_split, chunk_hi = min(n_chunks, chunk_lo + per_split);
+
+    auto tap_live = [&](int chunk) -> bool {          // false: every row of this tile reads inserted zeros
+        if (FLAT || tile_py < 0) return true;
+        const int tap = chunk / chunks_per_tap;
+        const int kh = tap / p.KW, kw = tap % p.KW;
+        return ((tile_py + kh - p.pad_h) % p.dil == 0) && ((tile_px + kw - p.pad_w) % p.dil == 0);
+    };
+    auto next_live = [&](int chunk) { while (chunk < chunk_hi && !tap_live(chunk)) ++chunk; return chunk; };
 
     auto load_chunk = [&](int chunk) {
+        if (FLAT) {
+            const int kbase = chunk * BK;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float e[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = kbase + a_k4 + j;
+                    if (k < Ktot && a_ok[i]) {
+                        const int tap = k / p.Ci, c = k % p.Ci;
+                        const int vy = a_oy[i] * p.stride + tap / p.KW - p.pad_h, vx = a_ox[i] * p.stride + tap % p.KW - p.pad_w;
+                        if (vy >= 0 && vy < p.Hi && vx >= 0 && vx < p.Wi)
+                            e[j] = X[(((int64_t)a_b[i] * p.Hi + vy) * p.Wi + vx) * p.Ci + c];
+                    }
+                }
+                ra[i] = make_float4(e[0], e[1], e[2], e[3]);
+            }
+#pragma unroll
+            for (int i = 0; i < BPASS; ++i) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int k = kbase + b_row + BROWS * i, n = n0 + b_n4;
+                if (k < Ktot && n < p.Co) {
+                    const float* src = W + (int64_t)k * p.Co + n;
+                    if (vec_b) {
+                        v = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        v.x = src[0];
+                        if (n + 1 < p.Co) v.y = src[1];
+                        if (n + 2 < p.Co) v.z = src[2];
+                        if (n + 3 < p.Co) v.w = src[3];
+                    }
+                }
+                rb[i] = v;
+            }
+            return;
+        }
         const int tap = chunk / chunks_per_tap, c0 = (chunk % chunks_per_tap) * BK;
         const int kh = tap / p.KW, kw = tap % p.KW;
 #pragma unroll
@@ -130,8 +196,10 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
         }
     };
 
-    load_chunk(0);
-    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+    int chunk = next_live(chunk_lo);
+    if (chunk < chunk_hi) load_chunk(chunk);
+    while (chunk < chunk_hi) {
+        const int nxt = next_live(chunk + 1);
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -143,7 +211,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
         for (int i = 0; i < BPASS; ++i)
             *reinterpret_cast<float4*>(&Bs[(b_row + BROWS * i) * LDB + b_n4]) = rb[i];
         __syncthreads();
-        if (chunk + 1 < n_chunks) load_chunk(chunk + 1);       // in flight during the MFMA block
+        if (nxt < chunk_hi) load_chunk(nxt);                   // in flight during the MFMA block
 #pragma unroll 4
         for (int kk = 0; kk < BK; kk += 2) {
             const int k = kk + (lane >> 5);
@@ -157,22 +225,28 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        chunk = nxt;
     }
 
     // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * 64 + j * 32 + (lane & 31);
-            if (n >= p.Co) continue;
-            const float bv = bias ? bias[n] : 0.f;
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m >= M) continue;
+            int64_t row = m;
+            if (perm) { int b, oy, ox; decode(m, b, oy, ox); row = ((int64_t)b * p.Ho + oy) * p.Wo + ox; }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < M) Y[(int64_t)m * p.Co + n] = acc[i][j][r] + bv;
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+                if (n >= p.Co) continue;
+                const float bv = (bias && ks == 0) ? bias[n] : 0.f;
+                if (k_splits > 1) atomicAdd(Y + row * p.Co + n, acc[i][j][r] + bv);
+                else Y[row * p.Co + n] = acc[i][j][r] + bv;
             }
         }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -311,13 +385,26 @@ extern "C" int dsf_conv_igemm_forward(const float* X, const float* W, const floa
     const int64_t M = (int64_t)B * Ho * Wo;
     DSF_CHECK_ARG(M < (1ll << 31));
     const int m_tiles = (int)((M + BM - 1) / BM);
-    if (Co > 64) {
-        const int n_tiles = (Co + 127) / 128;
-        hipLaunchKernelGGL(igemm_fwd_kernel<128>, dim3(m_tiles * n_tiles), dim3(256), 0, (hipStream_t)stream, X, W, bias,
-                           Y, p, m_tiles);
-    } else {
-        hipLaunchKernelGGL(igemm_fwd_kernel<64>, dim3(m_tiles), dim3(256), 0, (hipStream_t)stream, X, W, bias, Y, p, m_tiles);
+    const int bn = (Co > 64) ? 128 : 64;
+    const int n_tiles = (Co + bn - 1) / bn;
+    const bool flat = Ci < BK && dil == 1;
+    const int perm = (dil > 1 && Ho % dil == 0 && Wo % dil == 0) ? 1 : 0;
+    const int n_chunks = flat ? (KH * KW * Ci + BK - 1) / BK : KH * KW * ((Ci + BK - 1) / BK);
+    const int live_chunks = perm ? n_chunks / (dil * dil) : n_chunks;
+    int k_splits = 1;
+    if (m_tiles * n_tiles < 384) {                      // fewer tiles than ~1.5 per CU: split K to fill the chip
+        k_splits = (768 + m_tiles * n_tiles - 1) / (m_tiles * n_tiles);
+        if (k_splits > live_chunks / 4) k_splits = live_chunks / 4;
+        if (k_splits < 1) k_splits = 1;
     }
+    if (k_splits > 1 &&
+        hipMemsetAsync(Y, 0, sizeof(float) * (size_t)M * Co, (hipStream_t)stream) != hipSuccess) return DSF_ERR_LAUNCH;
+    const dim3 grid(m_tiles * n_tiles * k_splits);
+#define DSF_LAUNCH_FWD(BNv, FL) hipLaunchKernelGGL((igemm_fwd_kernel<BNv, FL>), grid, dim3(256), 0, (hipStream_t)stream, X, W, \
+                                                   bias, Y, p, m_tiles, n_tiles, k_splits, perm)
+    if (bn == 128) { if (flat) DSF_LAUNCH_FWD(128, true); else DSF_LAUNCH_FWD(128, false); }
+    else { if (flat) DSF_LAUNCH_FWD(64, true); else DSF_LAUNCH_FWD(64, false); }
+#undef DSF_LAUNCH_FWD
     return dsf_launch_status();
 }
 

@@ -326,8 +326,16 @@ __device__ __forceinline__ bool crop_to_raster(const float* mi, const int32_t* _
     return ry >= 0;
 }
 
-struct CropFace { float x0, y0, z0, x1, y1, z1, x2, y2, z2; };
+constexpr int CROP_MAX_ROWS = 1024;
 
+// One wave per 8x8 crop tile, one lane per crop pixel.  LDS per workgroup: projected vertices
+// (<=10 KB), packed 16-bit face indices (13 KB), per-face raster-pixel bboxes (13 KB) and the
+// resize row table (2 KB) -> ~38 KB, four workgroups per CU.  A wave ballots the bbox-vs-tile test
+// over 64 faces at a time and walks the set bits (ascending face index, so a strict `<` on z keeps
+// the lowest face on exact ties, as the naive pytorch3d path does).  Lanes whose edge functions do
+// not all share the sign of the face area cannot be covered (w_i > 0 is a sign statement), so the
+// three IEEE divisions are only executed for the surviving lanes -- the accepted arithmetic is
+// still the oracle's, operation for operation.
 __global__ __launch_bounds__(256) void render_crop_fwd_kernel(const float* __restrict__ verts,
                                                               const int32_t* __restrict__ faces,
                                                               const float* __restrict__ minv,
@@ -336,15 +344,18 @@ __global__ __launch_bounds__(256) void render_crop_fwd_kernel(const float* __res
                                                               const float* __restrict__ cube_z, dsf_camera cam, int V,
                                                               int F, int S, int crop, int wg_per_sample,
                                                               float* __restrict__ img, int32_t* __restrict__ p2f) {
-    __shared__ float s_pv[CROP_MAX_V * 3];          // projected verts
-    __shared__ CropFace s_face[CROP_MAX_F];
-    __shared__ uint32_t s_box[CROP_MAX_F];           // tile-space bbox: x0 | x1<<8 | y0<<16 | y1<<24, 0xFFFFFFFF = never
+    __shared__ float s_pv[CROP_MAX_V * 3];          // projected verts (x_ndc, y_ndc, z_view)
+    __shared__ uint2 s_fidx[CROP_MAX_F];             // x = v0 | v1<<16, y = v2
+    __shared__ uint2 s_box[CROP_MAX_F];              // x = lo_x | hi_x<<16, y = lo_y | hi_y<<16 (raster pixels); lo>hi = never
+    __shared__ uint16_t s_rows[CROP_MAX_ROWS];
     __shared__ float s_mi[6];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int b = blockIdx.x / wg_per_sample, part = blockIdx.x % wg_per_sample;
     const CamN k = cam_ndc(cam);
+    const int n_rows = (int)cam.img_h;
 
     if (t < 6) s_mi[t] = minv[b * 9 + t];
+    for (int r = t; r < n_rows && r < CROP_MAX_ROWS; r += 256) s_rows[r] = (uint16_t)max(rowmap[r], 0);
     for (int v = t; v < V; v += 256) {
         const float* p = verts + ((int64_t)b * V + v) * 3;
         float xn, yn, zv;
@@ -353,37 +364,27 @@ __global__ __launch_bounds__(256) void render_crop_fwd_kernel(const float* __res
     }
     __syncthreads();
 
-    // conservative map NDC -> crop pixel coordinates (for binning only).  Raster continuous
-    // X = S(1-x_ndc)/2; src = raster in x, raster*img_h/S in y; crop = (src - minv[.][2]) / minv[.][.]
-    const float inv_sx = 1.0f / s_mi[0], inv_sy = 1.0f / s_mi[4];
-    const float yscale = cam.img_h / (float)S;
-    const int tiles_axis = crop >> 3;
+    // per-face conservative bbox in raster pixel indices: column rx has x_ndc = 1 - (2rx+1)/S
     for (int f = t; f < F; f += 256) {
         const int a = faces[f * 3], c1 = faces[f * 3 + 1], c2 = faces[f * 3 + 2];
-        CropFace r;
-        r.x0 = s_pv[a * 3]; r.y0 = s_pv[a * 3 + 1]; r.z0 = s_pv[a * 3 + 2];
-        r.x1 = s_pv[c1 * 3]; r.y1 = s_pv[c1 * 3 + 1]; r.z1 = s_pv[c1 * 3 + 2];
-        r.x2 = s_pv[c2 * 3]; r.y2 = s_pv[c2 * 3 + 1]; r.z2 = s_pv[c2 * 3 + 2];
-        s_face[f] = r;
-        const float zmax = max3(r.z0, r.z1, r.z2);
-        const float face_area = edge_fn(r.x0, r.y0, r.x1, r.y1, r.x2, r.y2);
+        s_fidx[f] = make_uint2((uint32_t)a | ((uint32_t)c1 << 16), (uint32_t)c2);
+        const float x0 = s_pv[a * 3], y0 = s_pv[a * 3 + 1], z0 = s_pv[a * 3 + 2];
+        const float x1 = s_pv[c1 * 3], y1 = s_pv[c1 * 3 + 1], z1 = s_pv[c1 * 3 + 2];
+        const float x2 = s_pv[c2 * 3], y2 = s_pv[c2 * 3 + 1], z2 = s_pv[c2 * 3 + 2];
+        const float zmax = max3(z0, z1, z2);
+        const float face_area = edge_fn(x0, y0, x1, y1, x2, y2);
         const bool degenerate = (face_area <= kEps && face_area >= -kEps);
-        uint32_t box = 0xFFFFFFFFu;
+        uint2 box = make_uint2(1u, 1u);                        // lo = 1 > hi = 0
         if (!(zmax < 0.0f) && !degenerate) {
-            const float xmin = min3(r.x0, r.x1, r.x2), xmax = max3(r.x0, r.x1, r.x2);
-            const float ymin = min3(r.y0, r.y1, r.y2), ymax = max3(r.y0, r.y1, r.y2);
-            // raster continuous coords (reversed axes), 2 px safety margin
-            const float Xlo = 0.5f * S * (1.0f - xmax) - 2.0f, Xhi = 0.5f * S * (1.0f - xmin) + 2.0f;
-            const float Ylo = (0.5f * S * (1.0f - ymax) - 2.0f) * yscale - 1.0f;
-            const float Yhi = (0.5f * S * (1.0f - ymin) + 2.0f) * yscale + 1.0f;
-            float j0 = (Xlo - s_mi[2]) * inv_sx - 1.0f, j1 = (Xhi - s_mi[2]) * inv_sx + 1.0f;
-            float i0 = (Ylo - s_mi[5]) * inv_sy - 1.0f, i1 = (Yhi - s_mi[5]) * inv_sy + 1.0f;
-            if (j0 > j1) { const float tmp = j0; j0 = j1; j1 = tmp; }
-            if (i0 > i1) { const float tmp = i0; i0 = i1; i1 = tmp; }
-            if (j1 >= 0.0f && i1 >= 0.0f && j0 < (float)crop && i0 < (float)crop) {
-                const int tx0 = max(0, (int)floorf(j0) >> 3), tx1 = min(tiles_axis - 1, (int)floorf(j1) >> 3);
-                const int ty0 = max(0, (int)floorf(i0) >> 3), ty1 = min(tiles_axis - 1, (int)floorf(i1) >> 3);
-                box = (uint32_t)tx0 | ((uint32_t)tx1 << 8) | ((uint32_t)ty0 << 16) | ((uint32_t)ty1 << 24);
+            const float xmin = min3(x0, x1, x2), xmax = max3(x0, x1, x2);
+            const float ymin = min3(y0, y1, y2), ymax = max3(y0, y1, y2);
+            const float fxlo = 0.5f * ((float)S * (1.0f - xmax) - 1.0f), fxhi = 0.5f * ((float)S * (1.0f - xmin) - 1.0f);
+            const float fylo = 0.5f * ((float)S * (1.0f - ymax) - 1.0f), fyhi = 0.5f * ((float)S * (1.0f - ymin) - 1.0f);
+            if (fxhi > -2.0f && fyhi > -2.0f && fxlo < (float)S + 1.0f && fylo < (float)S + 1.0f) {
+                const int xlo = max(0, (int)ceilf(fmaxf(fxlo, -4.0f)) - 1), xhi = min(S - 1, (int)floorf(fminf(fxhi, (float)S + 4.0f)) + 1);
+                const int ylo = max(0, (int)ceilf(fmaxf(fylo, -4.0f)) - 1), yhi = min(S - 1, (int)floorf(fminf(fyhi, (float)S + 4.0f)) + 1);
+                if (xlo <= xhi && ylo <= yhi)
+                    box = make_uint2((uint32_t)xlo | ((uint32_t)xhi << 16), (uint32_t)ylo | ((uint32_t)yhi << 16));
             }
         }
         s_box[f] = box;
@@ -394,38 +395,70 @@ __global__ __launch_bounds__(256) void render_crop_fwd_kernel(const float* __res
     const float cz = normalise ? center_z[b] : 0.f;
     const float half = normalise ? cube_z[b] / 2.0f : 1.f;
     const float zmin_c = cz - half, zmax_c = cz + half;
+    const int tiles_axis = crop >> 3;
     const int n_tiles = tiles_axis * tiles_axis;
     const int waves_total = wg_per_sample * 4;
     for (int tile = part * 4 + wave; tile < n_tiles; tile += waves_total) {
         const int ty = tile / tiles_axis, tx = tile % tiles_axis;
         const int i = ty * 8 + (lane >> 3), j = tx * 8 + (lane & 7);
+        // crop pixel -> source pixel of the resized image -> raster pixel (zero padding outside)
         int ry = 0, rx = 0;
-        const bool valid = crop_to_raster(s_mi, rowmap, cam.img_w, cam.img_h, i, j, ry, rx);
+        bool valid;
+        {
+            const float x = (float)j, y = (float)i;
+            const float sx = (s_mi[0] * x + s_mi[1] * y) + s_mi[2];       // torch CPU matmul order: mul, mul, add, add
+            const float sy = (s_mi[3] * x + s_mi[4] * y) + s_mi[5];
+            const float gx = (sx / cam.img_w) * 2.0f - 1.0f;
+            const float gy = (sy / cam.img_h) * 2.0f - 1.0f;
+            const float fx = rintf((gx + 1.0f) * (cam.img_w / 2.0f) - 0.5f);   // grid_sample unnormalize + nearbyint
+            const float fy = rintf((gy + 1.0f) * (cam.img_h / 2.0f) - 0.5f);
+            valid = fx >= 0.0f && fx < cam.img_w && fy >= 0.0f && fy < cam.img_h;
+            if (valid) {
+                rx = (int)fx;
+                const int sy_i = (int)fy;
+                ry = (sy_i < CROP_MAX_ROWS) ? (int)s_rows[sy_i] : rowmap[sy_i];
+            }
+        }
         const float xf = pix_to_ndc(S - 1 - rx, S), yf = pix_to_ndc(S - 1 - ry, S);
         float bz = INFINITY;
         int bf = -1;
-        for (int base = 0; base < F; base += 64) {
+        // raster-pixel bbox of the 64 sample points of this tile (wave reduction)
+        int t_x0 = valid ? rx : 0x7fffffff, t_x1 = valid ? rx : -1, t_y0 = valid ? ry : 0x7fffffff, t_y1 = valid ? ry : -1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            t_x0 = min(t_x0, __shfl_xor(t_x0, o, 64)); t_x1 = max(t_x1, __shfl_xor(t_x1, o, 64));
+            t_y0 = min(t_y0, __shfl_xor(t_y0, o, 64)); t_y1 = max(t_y1, __shfl_xor(t_y1, o, 64));
+        }
+        const int f_end = (t_x1 < 0) ? 0 : F;                    // whole tile reads the zero padding
+        for (int base = 0; base < f_end; base += 64) {
             const int fme = base + lane;
             bool hit = false;
             if (fme < F) {
-                const uint32_t box = s_box[fme];
-                hit = (box != 0xFFFFFFFFu) && (uint32_t)tx >= (box & 0xFF) && (uint32_t)tx <= ((box >> 8) & 0xFF) &&
-                      (uint32_t)ty >= ((box >> 16) & 0xFF) && (uint32_t)ty <= (box >> 24);
+                const uint2 box = s_box[fme];
+                const int xlo = (int)(box.x & 0xFFFF), xhi = (int)(box.x >> 16), ylo = (int)(box.y & 0xFFFF), yhi = (int)(box.y >> 16);
+                hit = xlo <= xhi && xlo <= t_x1 && xhi >= t_x0 && ylo <= t_y1 && yhi >= t_y0;
             }
             unsigned long long mask = __ballot(hit);
             while (mask) {
                 const int bit = __ffsll((long long)mask) - 1;
                 mask &= mask - 1;
                 const int f = base + bit;
-                const CropFace r = s_face[f];                   // wave-uniform address: LDS broadcast
-                const float xmin = min3(r.x0, r.x1, r.x2), xmax = max3(r.x0, r.x1, r.x2);
-                const float ymin = min3(r.y0, r.y1, r.y2), ymax = max3(r.y0, r.y1, r.y2);
+                const uint2 fi = s_fidx[f];                       // wave-uniform address: LDS broadcast
+                const int a = (int)(fi.x & 0xFFFF) * 3, c1 = (int)(fi.x >> 16) * 3, c2 = (int)fi.y * 3;
+                const float x0 = s_pv[a], y0 = s_pv[a + 1], x1 = s_pv[c1], y1 = s_pv[c1 + 1], x2 = s_pv[c2], y2 = s_pv[c2 + 1];
+                const float xmin = min3(x0, x1, x2), xmax = max3(x0, x1, x2);
+                const float ymin = min3(y0, y1, y2), ymax = max3(y0, y1, y2);
                 if (!valid || xf > xmax || xf < xmin || yf > ymax || yf < ymin) continue;
-                const float area = edge_fn(r.x2, r.y2, r.x0, r.y0, r.x1, r.y1) + kEps;
-                const float w0 = edge_fn(xf, yf, r.x1, r.y1, r.x2, r.y2) / area;
-                const float w1 = edge_fn(xf, yf, r.x2, r.y2, r.x0, r.y0) / area;
-                const float w2 = edge_fn(xf, yf, r.x0, r.y0, r.x1, r.y1) / area;
-                const float pz = w0 * r.z0 + w1 * r.z1 + w2 * r.z2;
+                const float area = edge_fn(x2, y2, x0, y0, x1, y1) + kEps;
+                const float e0 = edge_fn(xf, yf, x1, y1, x2, y2);
+                const float e1 = edge_fn(xf, yf, x2, y2, x0, y0);
+                const float e2 = edge_fn(xf, yf, x0, y0, x1, y1);
+                // exact pre-test: e/area > 0 needs equal, non-zero signs (area == 0: leave it to the division)
+                if (area > 0.0f) { if (!(e0 > 0.0f && e1 > 0.0f && e2 > 0.0f)) continue; }
+                else if (area < 0.0f) { if (!(e0 < 0.0f && e1 < 0.0f && e2 < 0.0f)) continue; }
+                const float w0 = e0 / area, w1 = e1 / area, w2 = e2 / area;
+                const float z0 = s_pv[a + 2], z1 = s_pv[c1 + 2], z2 = s_pv[c2 + 2];
+                const float pz = w0 * z0 + w1 * z1 + w2 * z2;
                 if (pz < 0.0f) continue;
                 if (!(w0 > 0.0f && w1 > 0.0f && w2 > 0.0f)) continue;
                 if (bf < 0 || pz < bz) { bz = pz; bf = f; }      // faces visited in ascending order: ties keep the lowest
@@ -524,9 +557,10 @@ __global__ __launch_bounds__(256) void render_crop_bwd_kernel(const float* __res
 }
 
 inline int crop_wg_per_sample(int B, int tiles) {
-    // aim for >= 1024 workgroups on the 256-CU chip while keeping >= 1 tile per wave
+    // ~2 workgroups per CU on the 256-CU chip (each re-stages the sample's vertices / face boxes),
+    // at least one tile per wave
     int g = 1;
-    while (g < tiles / 4 && B * g < 1024) g *= 2;
+    while (g < tiles / 4 && B * g < 512) g *= 2;
     return g;
 }
 
@@ -594,7 +628,7 @@ extern "C" int dsf_render_crop_forward(const float* verts, const int32_t* faces,
                                        const dsf_camera* cam, int B, int V, int F, int raster_size, int crop, float* img,
                                        int32_t* pix_to_face, dsf_stream_t stream) {
     DSF_CHECK_ARG(verts && faces && minv && resize_rowmap && cam && img);
-    DSF_CHECK_ARG(B >= 0 && V > 0 && V <= CROP_MAX_V && F >= 0 && F <= CROP_MAX_F);
+    DSF_CHECK_ARG(B >= 0 && V > 0 && V <= CROP_MAX_V && F >= 0 && F <= CROP_MAX_F && raster_size <= 65535);
     DSF_CHECK_ARG(crop > 0 && (crop & 7) == 0 && crop <= 2048 && (center_z == nullptr) == (cube_z == nullptr));
     if ((int)cam->img_w != raster_size) return DSF_ERR_UNSUPPORTED;   // resize keeps columns (mano_layer.py:1233-1242)
     if (B == 0) return DSF_OK;

@@ -8,13 +8,17 @@ import functools
 import torch.nn as nn
 from torch.nn import init
 
+from .. import nn_conv
+
+_L = {"conv": nn_conv.Conv2d, "convT": nn_conv.ConvTranspose2d}
+
 
 class ResnetBlock(nn.Module):
     def __init__(self, dim, norm_layer, use_bias):
         super().__init__()
         self.conv_block = nn.Sequential(
-            nn.ReflectionPad2d(1), nn.Conv2d(dim, dim, kernel_size=3, padding=0, bias=use_bias), norm_layer(dim), nn.ReLU(True),
-            nn.ReflectionPad2d(1), nn.Conv2d(dim, dim, kernel_size=3, padding=0, bias=use_bias), norm_layer(dim))
+            nn.ReflectionPad2d(1), _L["conv"](dim, dim, kernel_size=3, padding=0, bias=use_bias), norm_layer(dim), nn.ReLU(True),
+            nn.ReflectionPad2d(1), _L["conv"](dim, dim, kernel_size=3, padding=0, bias=use_bias), norm_layer(dim))
 
     def forward(self, x):
         return x + self.conv_block(x)
@@ -27,24 +31,26 @@ class ResnetGenerator(nn.Module):
         assert padding_type == 'reflect' and not use_dropout
         fn = norm_layer.func if isinstance(norm_layer, functools.partial) else norm_layer
         bias = fn == nn.InstanceNorm2d
-        seq = [nn.ReflectionPad2d(3), nn.Conv2d(input_nc, ngf, kernel_size=7, padding=0, bias=bias), norm_layer(ngf), nn.ReLU(True)]
+        seq = [nn.ReflectionPad2d(3), _L["conv"](input_nc, ngf, kernel_size=7, padding=0, bias=bias), norm_layer(ngf), nn.ReLU(True)]
         ch = ngf
         for _ in range(2):
-            seq += [nn.Conv2d(ch, ch * 2, kernel_size=3, stride=2, padding=1, bias=bias), norm_layer(ch * 2), nn.ReLU(True)]
+            seq += [_L["conv"](ch, ch * 2, kernel_size=3, stride=2, padding=1, bias=bias), norm_layer(ch * 2), nn.ReLU(True)]
             ch *= 2
         seq += [ResnetBlock(ch, norm_layer, bias) for _ in range(n_blocks)]
         for _ in range(2):
-            seq += [nn.ConvTranspose2d(ch, ch // 2, kernel_size=3, stride=2, padding=1, output_padding=1, bias=bias),
+            seq += [_L["convT"](ch, ch // 2, kernel_size=3, stride=2, padding=1, output_padding=1, bias=bias),
                     norm_layer(ch // 2), nn.ReLU(True)]
             ch //= 2
-        seq += [nn.ReflectionPad2d(3), nn.Conv2d(ngf, output_nc, kernel_size=7, padding=0), nn.Tanh()]
+        seq += [nn.ReflectionPad2d(3), _L["conv"](ngf, output_nc, kernel_size=7, padding=0), nn.Tanh()]
         self.model = nn.Sequential(*seq)
 
     def forward(self, x):
         return self.model(x)
 
 
-def define_G(input_nc, output_nc, ngf, netG, norm='batch', use_dropout=False, init_type='normal', init_gain=0.02, gpu_ids=[]):
+def define_G(input_nc, output_nc, ngf, netG, norm='batch', use_dropout=False, init_type='normal', init_gain=0.02, gpu_ids=[],
+             native=True):
+    _L["conv"], _L["convT"] = (nn_conv.Conv2d, nn_conv.ConvTranspose2d) if native else (nn.Conv2d, nn.ConvTranspose2d)
     if norm == 'instance':
         norm_layer = functools.partial(nn.InstanceNorm2d, affine=False, track_running_stats=False)
     elif norm == 'batch':

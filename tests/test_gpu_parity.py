@@ -530,3 +530,63 @@ def test_no_cpu_fallback(mano):
     cpu = MANO_SMPL("synthetic", "nyu")
     with pytest.raises(RuntimeError):
         cpu.forward(torch.zeros(1, 10), torch.zeros(1, 45), torch.zeros(1, 3), get_skin=True)
+
+
+# ------------------------------------------------------------------------------------------------
+# whole step (BASELINE config 2 at the reference's CPU-runnable size, B=2): HIP path vs CPU oracle
+# ------------------------------------------------------------------------------------------------
+def test_whole_step_loss_and_grads_vs_oracle_step(mano_dict, render):
+    from oracle import step_ref
+    from dsf_amd.model.backbone import MANO_OCR_stage
+    from dsf_amd.train_step import RenderSupervisedStep, synthetic_batch, Config
+    torch.manual_seed(3)
+    net_cpu = MANO_OCR_stage("ResNet_stage_18", 21, True, native=False)
+    # make the MANO heads produce non-degenerate hands
+    with torch.no_grad():
+        for head in (net_cpu.mano_regress[2], net_cpu.mano_regress_s2[2]):
+            head.bias[58] = 1.0
+            head.bias[3:48] = 0.2 * torch.randn(45)
+            head.bias[:3] = torch.tensor([0.3, -0.2, 0.1])
+    net_gpu = MANO_OCR_stage("ResNet_stage_18", 21, True).cuda()
+    net_gpu.load_state_dict(net_cpu.state_dict())
+    B = 2
+    p, c, cube = synthetic_batch(B, "cpu", seed=5)
+    orender = step_ref.OracleRender(mano_dict)
+    tgt_c = step_ref.make_targets(orender, p, c, cube)
+    loss_c = step_ref.step_loss(net_cpu, orender, tgt_c)
+    loss_c.backward()
+    tgt_g = {k: v.cuda() for k, v in tgt_c.items()}
+    step = RenderSupervisedStep(net_gpu, render, Config)
+    loss_g, terms = step.loss(tgt_g)
+    loss_g.backward()
+    assert abs(float(loss_g.detach()) - float(loss_c.detach())) <= 2e-3 * abs(float(loss_c.detach()))
+    # gradients: batch-norm at B=2 amplifies fp32 summation-order noise through ~40 layers, so compare
+    # the whole gradient vector (relative L2 error, cosine) and bound the worst single tensor loosely
+    num = den = dot = ng = 0.0
+    worst = 0.0
+    for (n, pc), (_, pg) in zip(net_cpu.named_parameters(), net_gpu.named_parameters()):
+        if pc.grad is None:
+            continue
+        ref, got = pc.grad.double(), pg.grad.cpu().double()
+        num += float(((got - ref) ** 2).sum()); den += float((ref ** 2).sum())
+        dot += float((got * ref).sum()); ng += float((got ** 2).sum())
+        worst = max(worst, (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6))
+    assert (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5
+    assert dot / (den * ng) ** 0.5 > 0.9995
+    assert worst < 0.25, worst
+
+
+def test_mesh_loss_step_runs_and_decreases(render):
+    """BASELINE config 3 slice: hourglass + MANO head + ICP / part-ICP / collision / m2d terms."""
+    from dsf_amd.model.hourglass import PoseNetMANO
+    from dsf_amd.train_step import MeshLossStep, synthetic_batch, Config
+    torch.manual_seed(0)
+    net = PoseNetMANO(2, 21).cuda()
+    step = MeshLossStep(net, render, Config)
+    p, c, cube = synthetic_batch(4, "cuda", seed=9)
+    tgt = step.make_targets(p, c, cube)
+    assert tgt["joint_pcl"].shape == (4, 2048, 3) and int(tgt["seg"].max()) <= 15
+    l0, terms = step(tgt)
+    hist = [float(step(tgt)[0]) for _ in range(40)]
+    assert all(np.isfinite(hist)) and min(hist[-10:]) < float(l0)      # AdamW from random init: noisy first steps
+    assert all(torch.isfinite(v) for v in terms.values())

@@ -1,0 +1,143 @@
+"""Known-answer tests that anchor the plain-C restatement of pytorch3d==0.4.0's rasteriser and
+point-face distance (oracle/p3d_ref.c).  The wheel cannot be imported here, so these hand-checkable
+cases are what pins the oracle: "parity unpinned" against the real wheel.  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import p3d
+
+S = 16
+ndc = lambda i: -1 + (2 * i + 1) / S
+
+
+def _run(fv):
+    fv = np.asarray(fv, dtype=np.float32).reshape(-1, 3, 3)
+    p2f, z, b, d = p3d.rasterize_meshes(fv, np.zeros(1, dtype=np.int64), np.array([fv.shape[0]]), S)
+    return p2f[0], z[0], b[0], d[0]
+
+
+TRI = [[-1.0, -1.0, 5.0], [1.0, -1.0, 5.0], [-1.0, 1.0, 5.0]]
+
+
+def test_axis_aligned_triangle_coverage_and_axes():
+    p2f, z, b, d = _run([TRI])
+    exp = np.zeros((S, S), dtype=bool)
+    for yo in range(S):
+        for xo in range(S):
+            # output (yo, xo) samples NDC of index S-1-o: +x is left, +y is up (A.1)
+            exp[yo, xo] = ndc(S - 1 - xo) + ndc(S - 1 - yo) < 0
+    assert np.array_equal(p2f >= 0, exp)
+    assert np.all(z[exp] == 5.0) and np.all(z[~exp] == -1.0)
+    assert np.allclose(b[exp].sum(-1), 1.0, atol=1e-6) and np.all(b[~exp] == -1)
+    assert np.all(d[exp] <= 0) and np.all(d[~exp] == -1)
+    # the top-left output pixel is NDC (+,+): outside this triangle; bottom-right is inside
+    assert p2f[0, 0] == -1 and p2f[S - 1, S - 1] == 0
+
+
+def test_depth_order_ties_backface_and_behind_camera():
+    far = [[-1, -1, 9.0], [1, -1, 9.0], [-1, 1, 9.0]]
+    near = [[-1, -1, 3.0], [1, -1, 3.0], [-1, 1, 3.0]]
+    assert set(np.unique(_run([far, near])[0])) == {-1, 1}
+    assert set(np.unique(_run([near, far])[0])) == {-1, 0}
+    assert set(np.unique(_run([TRI, TRI])[0])) == {-1, 0}                 # exact tie -> lowest face index
+    back = [TRI[0], TRI[2], TRI[1]]
+    assert (_run([back])[0] >= 0).sum() == (_run([TRI])[0] >= 0).sum()     # no back-face culling
+    behind = [[-1, -1, -5.0], [1, -1, -5.0], [-1, 1, -5.0]]
+    assert (_run([behind])[0] >= 0).sum() == 0
+
+
+def test_pixel_centre_on_edge_is_not_covered():
+    xk = ndc(5)
+    half = [[xk, -1.0, 2.0], [xk, 1.0, 2.0], [-1.0, 0.0, 2.0]]
+    p2f = _run([half])[0]
+    assert not (p2f[:, S - 1 - 5] >= 0).any()          # strict w > 0
+    assert (p2f >= 0).any()
+
+
+def test_zbuf_is_screen_space_linear_interpolation():
+    t = [[-1.0, -1.0, 2.0], [1.0, -1.0, 4.0], [-1.0, 1.0, 6.0]]
+    p2f, z, b, _ = _run([t])
+    m = p2f >= 0
+    assert np.allclose(z[m], (b[m] * np.array([2.0, 4.0, 6.0])).sum(-1), atol=1e-6)
+
+
+def test_raster_backward_matches_finite_differences():
+    rng = np.random.default_rng(0)
+    fv = np.array([[[-0.8, -0.7, 3.0], [0.9, -0.6, 4.0], [-0.5, 0.85, 5.0]]], dtype=np.float32)
+    p2f, z, _, _ = p3d.rasterize_meshes(fv, np.zeros(1, dtype=np.int64), np.array([1]), S)
+    gz = (rng.normal(size=z.shape) * (p2f >= 0)).astype(np.float32)
+    g = p3d.rasterize_backward_zbuf(fv, p2f, gz)
+    eps = 1e-3
+    for idx in [(0, 0, 0), (0, 1, 1), (0, 2, 2), (0, 0, 2), (0, 2, 0)]:
+        fp, fm = fv.copy(), fv.copy()
+        fp[idx] += eps
+        fm[idx] -= eps
+        pp, zp, _, _ = p3d.rasterize_meshes(fp, np.zeros(1, dtype=np.int64), np.array([1]), S)
+        pm, zm, _, _ = p3d.rasterize_meshes(fm, np.zeros(1, dtype=np.int64), np.array([1]), S)
+        same = (pp >= 0) & (pm >= 0) & (p2f >= 0)        # coverage is piecewise constant; compare where it did not flip
+        fd = ((zp - zm) * gz * same).sum() / (2 * eps)
+        an_mask_corr = g[idx]
+        assert abs(fd - an_mask_corr) < 5e-2 * max(1.0, abs(fd)), (idx, fd, an_mask_corr)
+
+
+def test_project_verts_matches_pinhole():
+    v = np.array([[10.0, -20.0, 800.0], [0.0, 0.0, 500.0]], dtype=np.float32)
+    out = p3d.project_verts(v)
+    u = v[:, 0] * 588.03 / v[:, 2] + 320
+    w = v[:, 1] * 587.07 / v[:, 2] + 240
+    assert np.allclose(out[:, 0], -(u - 320) / 320, atol=1e-6)          # A.1: x_ndc = -(u-320)/320
+    assert np.allclose(out[:, 1], -(w - 240) / 240, atol=1e-6)
+    assert np.array_equal(out[:, 2], v[:, 2])                            # z is view-space depth in mm
+
+
+# ---- point-face distance (A.4) ----
+T0 = np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0]]], dtype=np.float32)
+
+
+def _pfd(pts, tris=T0, pf=(0,), tf=(0,)):
+    return p3d.point_face_dist_forward(np.asarray(pts, dtype=np.float32), np.array(pf), tris, np.array(tf))
+
+
+def test_point_above_interior_edge_vertex():
+    d, i = _pfd([[0.25, 0.25, 2.0], [0.5, -1.0, 0.0], [-3.0, -4.0, 0.0], [2.0, 2.0, 1.0]])
+    assert np.allclose(d, [4.0, 1.0, 25.0, (2 - 0.5) ** 2 * 2 + 1.0], atol=1e-6)
+    assert np.all(i == 0)
+
+
+def test_argmin_ties_take_lowest_index_and_ragged_batches():
+    tris = np.concatenate([T0, T0, T0 + np.float32(5)]).astype(np.float32)
+    d, i = _pfd([[0.2, 0.2, 1.0]], tris[:2])
+    assert i[0] == 0 and d[0] == 1.0
+    # batch element 0: 2 points vs tris[0:2]; element 1: EMPTY cloud; element 2: 1 point vs tris[2:3]
+    pts = [[0.2, 0.2, 1.0], [0.1, 0.1, 0.5], [5.2, 5.2, 7.0]]
+    d, i = _pfd(pts, tris, pf=(0, 2, 2), tf=(0, 2, 2))
+    assert np.allclose(d, [1.0, 0.25, 4.0], atol=1e-6) and i.tolist() == [0, 0, 2]
+
+
+def test_degenerate_triangle_falls_back_to_segments():
+    tri = np.array([[[0, 0, 0], [1, 0, 0], [2, 0, 0]]], dtype=np.float32)       # zero area
+    d, _ = _pfd([[0.5, 1.0, 0.0]], tri)
+    assert np.allclose(d, [1.0], atol=1e-6)
+
+
+def test_pfd_backward_matches_finite_differences():
+    rng = np.random.default_rng(1)
+    tris = rng.normal(size=(6, 3, 3)).astype(np.float32)
+    pts = rng.normal(size=(40, 3)).astype(np.float32)
+    d, idx = _pfd(pts, tris)
+    gw = rng.normal(size=d.shape).astype(np.float32)
+    gp, gt = p3d.point_face_dist_backward(pts, tris, idx, gw)
+    eps = 1e-3
+    for trial in range(12):
+        if trial % 2 == 0:
+            k = tuple(rng.integers(0, s) for s in pts.shape)
+            a, b = pts.copy(), pts.copy()
+            a[k] += eps; b[k] -= eps
+            fd = ((_pfd(a, tris)[0] - _pfd(b, tris)[0]) * gw).sum() / (2 * eps)
+            assert abs(fd - gp[k]) < 2e-2 * max(1.0, abs(fd))
+        else:
+            k = tuple(rng.integers(0, s) for s in tris.shape)
+            a, b = tris.copy(), tris.copy()
+            a[k] += eps; b[k] -= eps
+            fd = ((_pfd(pts, a)[0] - _pfd(pts, b)[0]) * gw).sum() / (2 * eps)
+            assert abs(fd - gt[k]) < 2e-2 * max(1.0, abs(fd))
