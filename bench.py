@@ -22,14 +22,65 @@ sys.path.insert(0, ROOT)
 import torch
 import torch.distributed as dist
 
+def usable_cpus():
+    """Cores this process may really use: min(affinity mask, cgroup quota).  os.cpu_count() reports the
+    host's cores even inside a CPU-limited container; oversubscribing the OpenMP pools stalls for minutes."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, n)
+
+
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP32_MATRIX_PEAK_TFLOPS = 157.3
 
 
+def conv_kernel_roofline(step, tgt):
+    """Roofline of the dominant kernel, igemm_fwd_kernel<128,false> (fp32 MFMA implicit-GEMM
+    convolution: forward, backward-data and transposed-conv passes of every layer with Co > 64).
+    One step is traced at the Python level, then every launch of that kernel is re-issued on the
+    stream it runs on and timed with HIP events; `achieved` = algorithmic FLOPs of those launches
+    (2*M*N*K of each implicit GEMM) / their summed duration."""
+    from dsf_amd import nn_conv
+    nn_conv.RECORD = []
+    step(tgt)
+    torch.cuda.synchronize()
+    recs, nn_conv.RECORD = nn_conv.RECORD, None
+    per_kernel = {}
+    for r in recs:
+        us, fl = nn_conv.replay(r)
+        k = per_kernel.setdefault(nn_conv.kernel_name(r), [0, 0.0, 0.0])
+        k[0] += 1; k[1] += us; k[2] += fl
+    dom = max(per_kernel, key=lambda n: per_kernel[n][1])
+    n, us, fl = per_kernel[dom]
+    tf = fl / (us * 1e-6) / 1e12
+    table = {name: {"launches_per_step": v[0], "avg_launch_us": round(v[1] / v[0], 1), "TFLOP/s": round(v[2] / (v[1] * 1e-6) / 1e12, 1),
+                    "ms_per_step": round(v[1] / 1e3, 2)} for name, v in per_kernel.items()}
+    return {"kernel": dom, "bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": None, "launches_per_step": n,
+            "avg_launch_us": round(us / n, 1), "flops_per_launch": fl / n,
+            "note": "fp32-in/fp32-acc MFMA (v_mfma_f32_32x32x2_f32) dense peak 157.3 TFLOP/s; HBM traffic is not the bound"}, table
+
+
 def crop_kernel_roofline(render, B, launches=200):
-    """Live timing of the dominant hand-written kernel (dsf_render_crop_forward) with HIP events on
-    the stream it is launched on.  Algorithmic bytes per image (SURVEY 8d, K1 crop mode):
-    read verts 779*12 = 9,348 B, write depth crop 128*128*4 = 65,536 B + face index 65,536 B."""
+    """Live timing of the fused crop rasteriser (dsf_render_crop_forward) with HIP events on the stream
+    it is launched on.  Algorithmic bytes per image (SURVEY 8d, K1 crop mode): read verts 779*12 = 9,348 B,
+    write depth crop 128*128*4 = 65,536 B + face index 65,536 B."""
     from dsf_amd import ops
     from dsf_amd.train_step import synthetic_batch
     p, c, cube = synthetic_batch(B, "cuda", seed=123)
@@ -57,7 +108,7 @@ def crop_kernel_roofline(render, B, launches=200):
     return {"kernel": "render_crop_fwd_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
             "avg_launch_us": round(us, 2), "bytes_per_launch": bytes_per_launch,
-            "note": "crop-mode raster is latency/VALU-bound at B=32 (4.5 MB per launch); HBM frac is its honest roofline"}
+            "note": "VALU/latency-bound at this size (4.5 MB of algorithmic traffic per launch); 2 launches per step"}
 
 
 def main():
@@ -68,7 +119,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
     ap.add_argument("--backbone", default="ResNet_stage_18")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--cpu-steps", type=int, default=60)
     args = ap.parse_args()
 
     from dsf_amd.parallel import init_distributed, GradAllReducer
@@ -121,20 +172,22 @@ def main():
                        "mano_asset": "synthetic MANO-shaped hand (real MANO_RIGHT.pkl is license-gated)"},
             "final_loss": round(loss_val, 5),
         }
-        out["roofline"] = crop_kernel_roofline(render, args.batch)
-        # the backbone (MIOpen convs) dominates the step: report its aggregate MFMA fraction too
+        out["roofline"], out["conv_kernels"] = conv_kernel_roofline(step, tgt)
+        out["roofline_raster"] = crop_kernel_roofline(render, args.batch)
         flops_per_img = 3 * 25.42e9 if args.backbone.endswith("18") else 3 * 37.84e9     # fwd+bwd ~ 3x fwd
         tf = flops_per_img * images / dt / 1e12
-        out["backbone_mfma"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": round(tf / FP32_MATRIX_PEAK_TFLOPS, 4),
-                                "note": "whole-step FLOP rate of the fp32 conv GEMMs (library kernels, not hand-written)"}
+        out["whole_step_mfma"] = {"achieved": round(tf, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": round(tf / FP32_MATRIX_PEAK_TFLOPS, 4),
+                                  "note": "backbone FLOPs (3 x 25.42 GFLOP/img) / whole step time, all kernels included"}
         if world == 1 and not args.no_cpu_baseline:
             from dsf_amd.assets import build_synthetic_mano
             from oracle import step_ref                       # CPU oracle: the reported baseline leg only
-            torch.set_num_threads(os.cpu_count())
+            cores = min(usable_cpus(), 32)
+            torch.set_num_threads(cores)
+            os.environ["OMP_NUM_THREADS"] = str(cores)
             ips, secs, n = step_ref.timed_steps(build_synthetic_mano(0), B=2, steps=args.cpu_steps, warmup=1,
                                                 backbone=args.backbone)
-            out["cpu_baseline"] = {"value": round(ips, 3), "unit": "images/s", "cores": os.cpu_count(), "kind": "port",
+            out["cpu_baseline"] = {"value": round(ips, 3), "unit": "images/s", "cores": cores, "kind": "port",
                                    "sample": "%d images: the same step (same net, losses, AdamW) at B=2 x %d steps through "
                                              "the CPU oracle (torch-CPU trunk, C rasteriser, numpy crop chain), %.1f s"
                                              % (n, args.cpu_steps, secs)}

@@ -13,6 +13,7 @@ from . import _lib as L
 from ._lib import I, ptr, check, stream_ptr
 
 CL = torch.channels_last
+RECORD = None        # set to a list to log every igemm launch (bench.py replays them for the roofline)
 
 
 def _nhwc(x):
@@ -25,6 +26,8 @@ def _fwd(x, wk, bias, out_hw, Co, KH, KW, stride, dil, pad):
     """x: (B,Ci,Hi,Wi) channels_last; wk: [KH][KW][Ci][Co] contiguous -> (B,Co,Ho,Wo) channels_last."""
     B, Ci, Hi, Wi = x.shape
     Ho, Wo = out_hw
+    if RECORD is not None:
+        RECORD.append(("fwd", B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, dil, pad[0], pad[1]))
     y = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=CL)
     check(L.lib().dsf_conv_igemm_forward(ptr_nhwc(x), ptr(wk), ptr(bias), ptr_nhwc(y), I(B), I(Hi), I(Wi), I(Ci), I(Ho),
                                          I(Wo), I(Co), I(KH), I(KW), I(stride), I(dil), I(pad[0]), I(pad[1]),
@@ -36,6 +39,8 @@ def _wrw(x, gy, KH, KW, stride, pad):
     """-> dW [KH][KW][Ci][Co] for x (B,Ci,Hi,Wi), gy (B,Co,Ho,Wo), both channels_last."""
     B, Ci, Hi, Wi = x.shape
     _, Co, Ho, Wo = gy.shape
+    if RECORD is not None:
+        RECORD.append(("wrw", B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, 1, pad[0], pad[1]))
     dw = torch.empty((KH, KW, Ci, Co), device=x.device, dtype=torch.float32)
     check(L.lib().dsf_conv_igemm_wrw(ptr_nhwc(x), ptr_nhwc(gy), ptr(dw), I(B), I(Hi), I(Wi), I(Ci), I(Ho), I(Wo), I(Co),
                                      I(KH), I(KW), I(stride), I(pad[0]), I(pad[1]), stream_ptr()), "dsf_conv_igemm_wrw")
@@ -137,3 +142,41 @@ class ConvTranspose2d(nn.ConvTranspose2d):
         s = _pair(self.stride)
         assert s[0] == s[1]
         return ConvTranspose2dFunction.apply(x, self.weight, self.bias, s[0], _pair(self.padding), _pair(self.output_padding))
+
+
+def replay(rec, iters=3):
+    """Re-issues one recorded igemm launch on fresh buffers and returns (avg microseconds, flops).
+    flops = 2*M*N*K of the implicit GEMM, counting only taps that can hit data when dil > 1."""
+    kind, B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, dil, ph, pw = rec
+    dev = torch.device("cuda")
+    x = torch.randn(B, Ci, Hi, Wi, device=dev).contiguous(memory_format=CL)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if kind == "fwd":
+        wk = torch.randn(KH, KW, Ci, Co, device=dev)
+        run = lambda: _fwd(x, wk, None, (Ho, Wo), Co, KH, KW, stride, dil, (ph, pw))
+    else:
+        gy = torch.randn(B, Co, Ho, Wo, device=dev).contiguous(memory_format=CL)
+        run = lambda: _wrw(x, gy, KH, KW, stride, (ph, pw))
+    global RECORD
+    saved, RECORD = RECORD, None
+    try:
+        run()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(iters):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+    finally:
+        RECORD = saved
+    taps = KH * KW / float(dil * dil)
+    return e0.elapsed_time(e1) * 1e3 / iters, 2.0 * B * Ho * Wo * Co * Ci * taps
+
+
+def kernel_name(rec):
+    kind, B, Hi, Wi, Ci, Ho, Wo, Co = rec[:8]
+    dil = rec[11]
+    bn = 128 if Co > 64 else 64
+    if kind == "fwd":
+        return "igemm_fwd_kernel<%d, %s>" % (bn, "true" if (Ci < 32 and dil == 1) else "false")
+    return "igemm_wrw_kernel<%d>" % bn

@@ -172,3 +172,139 @@ class MeshLossStep:
             self.grad_sync.finish()
         self.opt.step()
         return loss.detach(), terms
+
+
+class FinetuneStageStep:
+    """Counterpart of ``Trainer.FinetuneStage`` (train_render.py:622-823), the reference's default
+    self-boosting step (config.py:36-38): a synthetic supervised pass through the frozen transfer
+    generator + a real-image pass where the detached stage-2 outputs teach stage 1 and the geometry
+    terms (m2d, ICP, part-aware ICP, collision, P2M, M2P) close the self-supervised loop.
+
+    Differences from the reference, all forced by "no host sync inside the step":
+      * random draws are explicit (a ``torch.Generator`` per step instead of global RNG state);
+      * the M2P term (:784-801) selects rows with ``nonzero()`` + ``index_select`` and branches on
+        ``joint_mano_mask.sum() == 0`` on the host; here it is the algebraically identical masked mean
+        (same rows, same divisor, same "sum of selected indices == 0 -> 0" rule), evaluated on device;
+      * ``xyz2error`` / TensorBoard / colour LUT host round trips (:654-667, :703, :713-721) are dropped.
+    """
+
+    def __init__(self, net, render, transfer_net, config=Config, optimizer=None, grad_sync=None, mask=True):
+        self.net, self.render, self.transfer, self.cfg, self.mask = net, render, transfer_net, config, mask
+        self.L1 = SmoothL1Loss()
+        self.gfm = GFM()
+        self.opt = optimizer if optimizer is not None else torch.optim.AdamW(net.parameters(), lr=config.lr,
+                                                                             weight_decay=config.weight_decay)
+        self.grad_sync = grad_sync
+        self.utils = TensorUtils(img_size=config.input_size)
+        if transfer_net is not None:
+            for p in transfer_net.parameters():
+                p.requires_grad_(False)
+            transfer_net.eval()
+
+    def _keys(self, B, g, dev):
+        return torch.randint(0, 2 ** 31 - 1, (B, 128 * 128), device=dev, dtype=torch.int32, generator=g)
+
+    def _masked_huber(self, a, b, row_mask):
+        """L1Loss(index_select(a, rows), index_select(b, rows)) with the reference's empty rule (:796-801)."""
+        z = (a - b).float()
+        az = z.abs()
+        per_row = torch.where(az < 0.01, 0.5 * z * z, 0.01 * (az - 0.005)).mean(-1)          # (rows,)
+        m = row_mask.to(per_row.dtype)
+        n = m.sum()
+        idx_sum = (torch.arange(m.numel(), device=m.device, dtype=per_row.dtype) * m).sum()
+        val = (per_row * m).sum() / torch.clamp(n, min=1.0)
+        return torch.where(idx_sum == 0, torch.zeros_like(val), val)
+
+    def loss(self, model_para, cube, img_r, center_r, cube_r, M_r, generator=None):
+        cfg, R, u, gfm, L1 = self.cfg, self.render, self.utils, self.gfm, self.L1
+        mano_layer = R.mano_layer
+        dev = model_para.device
+        B = model_para.size(0)
+        g = generator if generator is not None else torch.Generator(device=dev)
+        rnd = lambda *s: torch.rand(*s, device=dev, generator=g)
+        # ---- synthetic branch (:628-667) ----
+        aug_shape = torch.randn(B, 10, device=dev, generator=g) * 3
+        aug_center = (rnd(B, 3) - 0.5) * 40
+        aug_size = 1 + (rnd(B, 1) - 0.5) * 0.4
+        aug_view = rnd(B, 3) * math.pi * 2
+        depth = rnd(B, 1) * (R.depth_range[1] - R.depth_range[0]) + R.depth_range[0]
+        center0 = torch.cat((torch.zeros(B, 2, device=dev), depth), dim=-1)
+        with torch.no_grad():
+            draws = None
+            if self.mask:
+                k = 6                                   # reference: 3..9 occluders drawn on the host (:1328); fixed count keeps the step sync-free
+                jid = torch.randperm(21, device=dev, generator=g)[:k]
+                draws = (jid, (rnd(B, k, 3) - 0.5) * 0.15 * 2, rnd(B, k) * 0.3)
+            img, juvd_gt, _, jxyz_gt, mesh_gt, center_s, cube_s, M_s = R(model_para, center0, cube, augmentView=aug_view,
+                                                                        augmentShape=aug_shape, augmentCenter=aug_center,
+                                                                        augmentSize=aug_size, mask=False)
+            if draws is not None:
+                img = R.mask_img(img, juvd_gt, 0.15, 0.3, draws=draws)
+            img_t = self.transfer(img) if self.transfer is not None else img
+        outputs = self.net(img_t, R, center=center_s, cube=cube_s)
+        total = 0
+        for pixel_pd, mano_pd in outputs:
+            S = pixel_pd.size(-1)
+            pixel_gt = gfm.joint2feature(juvd_gt, img, cfg.feature_para, S, cfg.feature_type)
+            juvd = gfm.feature2joint(img, pixel_pd, cfg.feature_type, cfg.feature_para)
+            total = total + L1(pixel_pd, pixel_gt) * cfg.deconv_weight + L1(juvd, juvd_gt) * cfg.coord_weight
+            jx, mx = R.get_mesh_xyz(mano_pd)
+            total = total + L1(jx, jxyz_gt) * cfg.coord_weight + L1(mx, mesh_gt) * cfg.coord_weight \
+                + mano_layer.calculate_coll(jx, mx.detach()) * cfg.coll_weight
+        # ---- real branch: teacher from the detached stage-2 outputs (:671-703) ----
+        outputs = self.net(img_r, R, center=center_r, cube=cube_r)
+        pix_t, mano_t = outputs[1][0].detach(), outputs[1][1].detach()
+        with torch.no_grad():
+            juvd_t = gfm.feature2joint(img_r, pix_t, cfg.feature_type, cfg.feature_para)
+            jxyz_t = u.uvd_nl2xyznl_tensor(juvd_t, center_r, M_r, cube_r)
+            mj_t, mm_t = R.get_mesh_xyz(mano_t)
+            crop_r, pts = u.crop_hand(img_r, mj_t, center_r, M_r, cube_r, return_points=True)
+            _, pts = u.crop_hand(crop_r, mj_t, center_r, M_r, cube_r, return_points=True)
+            seg_img = mano_layer.seg_pcl(jxyz_t, mj_t, mm_t, pts)
+            seg_img = torch.where(crop_r.lt(0.99).reshape(B, -1), seg_img, torch.zeros_like(seg_img)).reshape(B, 1, 128, 128)
+            joint_img = torch.where(seg_img.gt(0), crop_r, torch.ones_like(img_r))
+            joint_pcl = u.Img2pcl(joint_img, 128, center_r, M_r, cube_r, 2048, rand_keys=self._keys(B, g, dev))
+            segment = mano_layer.seg_pcl(jxyz_t, mj_t, mm_t, joint_pcl)
+            pcl = u.Img2pcl(crop_r, 128, center_r, M_r, cube_r, 2048, rand_keys=self._keys(B, g, dev))
+        # ---- stage 1 student (:706-749) ----
+        pix1, mano1 = outputs[0]
+        juvd1 = gfm.feature2joint(img_r, pix1, cfg.feature_type, cfg.feature_para)
+        total = total + L1(pix1, pix_t) * cfg.deconv_weight + L1(juvd1, juvd_t) * cfg.coord_weight
+        img1, mjuvd1, mjxyz1, mesh1 = R.render(mano1, center_r, cube_r)
+        total = total + L1(mjxyz1, jxyz_t) * cfg.coord_weight + L1(mesh1, mm_t) * cfg.coord_weight
+        total = total + mano_layer.calculate_coll(mjxyz1, mesh1.detach()) * cfg.coll_weight
+        crop1 = u.crop_hand(img1, mj_t, center_r, M_r, cube_r)
+        total = total + m2d_loss(crop_r, crop1) * cfg.model_weight
+        total = total + ICPLoss(mesh1, pcl, mano_layer.faces).mean(-1) * cfg.model_weight
+        total = total + JointICPLoss(mesh1, joint_pcl, mano_layer.joint_faces, segment).mean(-1).mean(-1) * cfg.partICP_weight
+        # ---- stage 2 (:752-808) ----
+        pix2, mano2 = outputs[1]
+        juvd2 = gfm.feature2joint(img_r, pix2, cfg.feature_type, cfg.feature_para)
+        img2, mjuvd2, mjxyz2, mesh2 = R.render(mano2, center_r, cube_r)
+        p2m = L1(mjuvd2, juvd_t) * cfg.coord_weight
+        coll2 = mano_layer.calculate_coll(mjxyz2, mesh2.detach())
+        crop2 = u.crop_hand(img2, mj_t, center_r, M_r, cube_r)
+        union = (crop_r.lt(0.99) | crop2.lt(0.99)).float()
+        m2d2 = m2d_loss(crop_r, crop2)
+        pd2m_j = JointICPLoss(mesh2, joint_pcl, mano_layer.joint_faces, segment)
+        d2m_b = ICPLoss(mesh2, pcl, mano_layer.faces)
+        both = (crop_r.lt(0.99) & crop2.lt(0.99)).float()
+        depth_b = ((crop_r - crop2).abs() * both).sum(-1).sum(-1) / (union.sum(-1).sum(-1) + 1e-8)
+        mano_ok = depth_b.lt(0.04).squeeze(-1) & d2m_b.lt(1e-3)                              # (:787-789)
+        jm = pd2m_j.lt(1e-3)
+        jm = torch.cat((torch.ones(B, 1, device=dev, dtype=torch.bool), jm, jm[:, [2, 5, 8, 11, 14]]), dim=-1)
+        rows = (mano_ok.unsqueeze(-1) & jm).detach().reshape(-1)
+        m2p = self._masked_huber(juvd2.reshape(-1, 3), mjuvd2.detach().reshape(-1, 3), rows) * cfg.coord_weight
+        total = total + p2m + coll2 * cfg.coll_weight + m2d2 * cfg.model_weight + d2m_b.mean(-1) * cfg.model_weight \
+            + pd2m_j.mean(-1).mean(-1) * cfg.partICP_weight + m2p * cfg.M2P_weight
+        terms = {"P2M": p2m, "m2d": m2d2, "d2m": d2m_b.mean(-1), "pd2m": pd2m_j.mean(-1).mean(-1), "M2P": m2p, "coll": coll2}
+        return total, terms
+
+    def __call__(self, model_para, cube, img_r, center_r, cube_r, M_r, generator=None):
+        self.opt.zero_grad(set_to_none=False)
+        loss, terms = self.loss(model_para, cube, img_r, center_r, cube_r, M_r, generator)
+        loss.backward()
+        if self.grad_sync is not None:
+            self.grad_sync.finish()
+        self.opt.step()
+        return loss.detach(), terms
