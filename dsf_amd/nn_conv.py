@@ -47,6 +47,14 @@ def _wrw(x, gy, KH, KW, stride, pad):
     return dw
 
 
+def _bias_grad(gy):
+    """sum over (B,H,W) of an NHWC tensor as a skinny GEMM (hipBLASLt) -- torch's strided reduce kernel
+    needs ~250 us for a 33 MB channels_last tensor."""
+    B, Co, H, W = gy.shape
+    flat = gy.permute(0, 2, 3, 1).reshape(B * H * W, Co)           # a view: NHWC memory is already (M, Co)
+    return torch.mm(torch.ones(1, flat.shape[0], device=gy.device, dtype=gy.dtype), flat).reshape(Co)
+
+
 def ptr_nhwc(t):
     if not t.is_cuda:
         raise RuntimeError("dsf_amd convolution runs on the GPU only (got %s); build the net with native=False for "
@@ -85,7 +93,7 @@ class Conv2dFunction(Function):
         if ctx.needs_input_grad[1]:
             gw = _wrw(x, gy, KH, KW, stride, padding).permute(3, 2, 0, 1)
         if has_bias and ctx.needs_input_grad[2]:
-            gb = gy.sum(dim=(0, 2, 3))
+            gb = _bias_grad(gy)
         return gx, gw, gb, None, None
 
 
@@ -118,7 +126,7 @@ class ConvTranspose2dFunction(Function):
         if ctx.needs_input_grad[1]:
             gw = _wrw(gy, x, KH, KW, stride, padding).permute(3, 2, 0, 1)                      # [kh][kw][Cout][Cin] -> (Cin,Cout,kh,kw)
         if has_bias and ctx.needs_input_grad[2]:
-            gb = gy.sum(dim=(0, 2, 3))
+            gb = _bias_grad(gy)
         return gx, gw, gb, None, None, None
 
 
