@@ -186,5 +186,7 @@ def kernel_name(rec):
     dil = rec[11]
     bn = 128 if Co > 64 else 64
     if kind == "fwd":
+        if dil == 1 and Ci >= 32 and Ci % 4 == 0 and Co % 4 == 0:
+            return "igemm_fwd_fast_kernel<%d>" % bn
         return "igemm_fwd_kernel<%d, %s>" % (bn, "true" if (Ci < 32 and dil == 1) else "false")
     return "igemm_wrw_kernel<%d>" % bn
