@@ -6,6 +6,7 @@ stage-2 bridge (``render.render`` + ``joint2offset``) runs on the HIP kernels of
 Module / parameter names equal the reference's (``MANO_OCR_stage``, model/backbone.py:188-343) so
 its ``latest.pth`` / ``best.pth`` load unchanged."""
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -13,6 +14,7 @@ import torch.nn as nn
 from . import resnet as _resnet
 from .resnet import BasicBlock, Bottleneck
 from .. import nn_conv
+from ..nn_norm import FusedBatchNorm2d
 from ..util.generateFeature import joint2offset, offset2joint_softmax
 
 BN_MOMENTUM = 0.1
@@ -26,21 +28,38 @@ class _Layers:
     (native=False: the CPU twin the oracle / cpu_baseline builds; same parameters and keys)."""
 
     def __init__(self, native):
+        self.native = native
+        # fused BN(+add+ReLU) kernels exist (csrc/norm.hip, parity-tested) but measure slower than torch's
+        # BN + add + ReLU at these sizes: activations (<= 134 MB) sit in the 256 MiB Infinity Cache, so the
+        # passes saved are nearly free and the extra stats->combine->finalize->apply launches dominate
+        # (fwd 82 vs 50 us at 64ch 64x64 B=32).  Opt in with DSF_FUSED_BN=1.
+        self.fused_bn = native and os.environ.get("DSF_FUSED_BN", "0") == "1"
         self.Conv2d = nn_conv.Conv2d if native else nn.Conv2d
         self.ConvTranspose2d = nn_conv.ConvTranspose2d if native else nn.ConvTranspose2d
 
+    def bn_relu(self, c, **kw):
+        """[BatchNorm, ReLU] pair of an nn.Sequential: fused into one module (the ReLU slot becomes an
+        Identity so indices and state-dict keys do not move)."""
+        if self.fused_bn:
+            return [FusedBatchNorm2d(c, fuse_relu=True, **kw), nn.Identity()]
+        return [nn.BatchNorm2d(c, **kw), nn.ReLU(inplace=True)]
+
+    def bn(self, c, **kw):
+        return FusedBatchNorm2d(c, **kw) if self.fused_bn else nn.BatchNorm2d(c, **kw)
+
     def __enter__(self):
-        self._saved = _resnet._CONV[0]
+        self._saved = (_resnet._CONV[0], _resnet._FUSED_BN[0])
         _resnet._CONV[0] = self.Conv2d
+        _resnet._FUSED_BN[0] = self.fused_bn
         return self
 
     def __exit__(self, *a):
-        _resnet._CONV[0] = self._saved
+        _resnet._CONV[0], _resnet._FUSED_BN[0] = self._saved
 
 
 def convtranspose_bn_relu(cin, cout, kernel, L):
     return nn.Sequential(L.ConvTranspose2d(cin, cout, kernel, stride=2, padding=1, output_padding=0, bias=False),
-                         nn.BatchNorm2d(cout, momentum=0.1), nn.ReLU(inplace=True))
+                         *L.bn_relu(cout, momentum=0.1))
 
 
 class _TwoBranchNet(nn.Module):
@@ -49,14 +68,14 @@ class _TwoBranchNet(nn.Module):
     def _stem(self):
         L = self._L
         self.pre = nn.Sequential(L.Conv2d(1, 64, kernel_size=5, stride=1, padding=2, bias=False),
-                                 nn.BatchNorm2d(64, momentum=BN_MOMENTUM), nn.ReLU(inplace=True),
+                                 *L.bn_relu(64, momentum=BN_MOMENTUM),
                                  nn.MaxPool2d(kernel_size=3, stride=2, padding=1))
 
     def _make_layer(self, block, planes, blocks, stride=1):
         down = None
         if stride != 1 or self.inplanes != planes * block.expansion:
             down = nn.Sequential(self._L.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
-                                 nn.BatchNorm2d(planes * block.expansion, momentum=BN_MOMENTUM))
+                                 self._L.bn(planes * block.expansion, momentum=BN_MOMENTUM))
         layers = [block(self.inplanes, planes, stride, down)]
         self.inplanes = planes * block.expansion
         layers += [block(self.inplanes, planes) for _ in range(1, blocks)]
@@ -134,7 +153,7 @@ class MANO_OCR_stage(_TwoBranchNet):
             self.inplanes = 64
             self._trunk(block, layers, '')
             if refine:
-                self.fusion = nn.Sequential(self._L.Conv2d(256 + joint_num * 4 * 2 + 64, 256, 3, 1, 1), nn.BatchNorm2d(256), nn.ReLU())
+                self.fusion = nn.Sequential(self._L.Conv2d(256 + joint_num * 4 * 2 + 64, 256, 3, 1, 1), *self._L.bn_relu(256))
                 self.inplanes = 256
                 self._trunk(block, layers, '_s2')
         self.init_weights()

@@ -5,8 +5,14 @@ checkpoints (state-dict keys) load unchanged."""
 import torch.nn as nn
 
 from ..nn_conv import Conv2d as _HipConv2d
+from ..nn_norm import FusedBatchNorm2d, bn_act
 
 _CONV = [_HipConv2d]      # layer factory switch: [nn.Conv2d] builds the plain-torch CPU twin (oracle / tests)
+_FUSED_BN = [False]       # fused BN+add+ReLU kernels (opt-in, see model/backbone.py::_Layers)
+
+
+def _norm(c, **kw):
+    return FusedBatchNorm2d(c, **kw) if _FUSED_BN[0] else nn.BatchNorm2d(c, **kw)
 
 
 def _conv(cin, cout, k, stride=1):
@@ -19,18 +25,17 @@ class BasicBlock(nn.Module):
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
         self.conv1 = _conv(inplanes, planes, 3, stride)
-        self.bn1 = nn.BatchNorm2d(planes)
+        self.bn1 = _norm(planes)
         self.relu = nn.ReLU(inplace=True)
         self.conv2 = _conv(planes, planes, 3)
-        self.bn2 = nn.BatchNorm2d(planes)
+        self.bn2 = _norm(planes)
         self.downsample = downsample
         self.stride = stride
 
     def forward(self, x):
-        y = self.relu(self.bn1(self.conv1(x)))
-        y = self.bn2(self.conv2(y))
-        y += x if self.downsample is None else self.downsample(x)
-        return self.relu(y)
+        y = bn_act(self.bn1, self.conv1(x), relu=True)
+        identity = x if self.downsample is None else self.downsample(x)
+        return bn_act(self.bn2, self.conv2(y), residual=identity, relu=True)      # bn + skip + relu in one pass
 
 
 class Bottleneck(nn.Module):
@@ -39,18 +44,17 @@ class Bottleneck(nn.Module):
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
         self.conv1 = _conv(inplanes, planes, 1)
-        self.bn1 = nn.BatchNorm2d(planes)
+        self.bn1 = _norm(planes)
         self.conv2 = _conv(planes, planes, 3, stride)
-        self.bn2 = nn.BatchNorm2d(planes)
+        self.bn2 = _norm(planes)
         self.conv3 = _conv(planes, planes * self.expansion, 1)
-        self.bn3 = nn.BatchNorm2d(planes * self.expansion)
+        self.bn3 = _norm(planes * self.expansion)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
         self.stride = stride
 
     def forward(self, x):
-        y = self.relu(self.bn1(self.conv1(x)))
-        y = self.relu(self.bn2(self.conv2(y)))
-        y = self.bn3(self.conv3(y))
-        y += x if self.downsample is None else self.downsample(x)
-        return self.relu(y)
+        y = bn_act(self.bn1, self.conv1(x), relu=True)
+        y = bn_act(self.bn2, self.conv2(y), relu=True)
+        identity = x if self.downsample is None else self.downsample(x)
+        return bn_act(self.bn3, self.conv3(y), residual=identity, relu=True)

@@ -1,0 +1,114 @@
+"""BatchNorm2d fused with the residual add and ReLU that follow it, on the HIP kernels of
+dsf_amd/csrc/norm.hip (NHWC).  Drop-in subclass of nn.BatchNorm2d: same parameters / buffers /
+state-dict keys; ``forward(x, residual=None, relu=False)``.  GPU only."""
+import ctypes
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib as L
+from ._lib import I, I64, F as CF, ptr, check, stream_ptr
+
+CL = torch.channels_last
+
+
+def supported(C):
+    c4 = C >> 2
+    return C >= 4 and C % 4 == 0 and c4 <= 256 and 256 % c4 == 0
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+class _BNFunction(Function):
+    @staticmethod
+    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, eps, momentum, relu):
+        x = x.contiguous(memory_format=CL)
+        if residual is not None:
+            residual = residual.contiguous(memory_format=CL)
+        B, C, H, W = x.shape
+        M = B * H * W
+        y = torch.empty_like(x, memory_format=CL)
+        mean = torch.empty(C, device=x.device, dtype=torch.float32)
+        invstd = torch.empty(C, device=x.device, dtype=torch.float32)
+        ws = torch.empty(514 * C, device=x.device, dtype=torch.float64)
+        check(L.lib().dsf_bn_forward(_p(x), _p(residual), _p(gamma), _p(beta), I64(M), I(C), CF(eps), CF(momentum),
+                                     I(int(relu)), _p(running_mean), _p(running_var), _p(y), _p(mean), _p(invstd), _p(ws),
+                                     stream_ptr()), "dsf_bn_forward")
+        ctx.save_for_backward(x, y if relu else None, gamma, mean, invstd)
+        ctx.cfg = (relu, residual is not None, gamma is not None, beta is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, y, gamma, mean, invstd = ctx.saved_tensors
+        relu, has_res, has_g, has_b = ctx.cfg
+        gy = gy.contiguous(memory_format=CL)
+        B, C, H, W = x.shape
+        M = B * H * W
+        gx = torch.empty_like(x, memory_format=CL)
+        gres = torch.empty_like(x, memory_format=CL) if has_res else None
+        gg = torch.empty(C, device=x.device, dtype=torch.float32) if has_g else None
+        gb = torch.empty(C, device=x.device, dtype=torch.float32) if has_b else None
+        ws = torch.empty(514 * C, device=x.device, dtype=torch.float64)
+        check(L.lib().dsf_bn_backward(_p(x), _p(gy), _p(y), _p(gamma), _p(mean), _p(invstd), I64(M), I(C), I(int(relu)), _p(gx),
+                                      _p(gres), _p(gg), _p(gb), _p(ws), stream_ptr()), "dsf_bn_backward")
+        return gx, gres, gg, gb, None, None, None, None, None
+
+
+class FusedBatchNorm2d(nn.BatchNorm2d):
+    """``fuse_relu=True`` makes plain ``bn(x)`` apply the ReLU too (used inside nn.Sequential stacks,
+    where the following nn.ReLU slot is replaced by nn.Identity so module indices / keys stay put)."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True, fuse_relu=False):
+        super().__init__(num_features, eps=eps, momentum=momentum, affine=affine, track_running_stats=track_running_stats)
+        self.fuse_relu = fuse_relu
+
+    def forward(self, x, residual=None, relu=None):
+        relu = self.fuse_relu if relu is None else relu
+        if not x.is_cuda:
+            raise RuntimeError("dsf_amd FusedBatchNorm2d runs on the GPU only (got %s)" % x.device)
+        C = x.shape[1]
+        use_batch_stats = self.training or not self.track_running_stats
+        if supported(C) and x.dtype == torch.float32:
+            if use_batch_stats:
+                if self.training and self.track_running_stats and self.num_batches_tracked is not None:
+                    self.num_batches_tracked.add_(1)
+                mom = 0.0 if self.momentum is None else self.momentum
+                rm = self.running_mean if (self.training and self.track_running_stats) else None
+                rv = self.running_var if (self.training and self.track_running_stats) else None
+                return _BNFunction.apply(x, residual, self.weight, self.bias, rm, rv, self.eps, mom, relu)
+            if torch.is_grad_enabled() and (x.requires_grad or (residual is not None and residual.requires_grad)):
+                y = super().forward(x)                      # frozen-statistics BN inside a differentiated graph: torch's kernels
+                if residual is not None:
+                    y = y + residual
+                return F.relu(y) if relu else y
+            # eval: frozen statistics, one streaming pass
+            xc = x.contiguous(memory_format=CL)
+            res = residual.contiguous(memory_format=CL) if residual is not None else None
+            y = torch.empty_like(xc, memory_format=CL)
+            invstd = torch.rsqrt(self.running_var + self.eps)
+            B, _, H, W = xc.shape
+            check(L.lib().dsf_bn_apply(_p(xc), _p(res), _p(self.weight), _p(self.bias), _p(self.running_mean), _p(invstd),
+                                       I64(B * H * W), I(C), I(int(relu)), _p(y), stream_ptr()), "dsf_bn_apply")
+            return y
+        # channel counts the kernels do not cover (e.g. 2048 in ResNet-50 layer4): torch's own kernels
+        y = super().forward(x)
+        if residual is not None:
+            y = y + residual
+        return F.relu(y) if relu else y
+
+
+def bn_act(bn, x, residual=None, relu=False):
+    """bn(x) (+ residual) (relu) for either the fused module or a plain nn.BatchNorm2d (CPU twin)."""
+    if isinstance(bn, FusedBatchNorm2d):
+        return bn(x, residual, relu)
+    y = bn(x)
+    if residual is not None:
+        y = y + residual
+    return F.relu(y) if relu else y

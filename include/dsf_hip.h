@@ -283,6 +283,27 @@ int dsf_conv_igemm_forward(const float* X, const float* W, const float* bias, fl
 int dsf_conv_igemm_wrw(const float* X, const float* dY, float* dW, int B, int Hi, int Wi, int Ci, int Ho, int Wo,
                        int Co, int KH, int KW, int stride, int pad_h, int pad_w, dsf_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Fused training-mode BatchNorm2d (+ residual add) (+ ReLU) on NHWC activations, x viewed as (M, C).
+ * Replaces nn.BatchNorm2d + `out += identity` + nn.ReLU of model/resnet.py:38-55, 82-98 and the
+ * conv-bn-relu sequences of model/backbone.py:16-42 (3 + 1 + 1 forward and 3 + 1 backward kernels in
+ * PyTorch) by two HBM passes each way.  C must be a power of two in [4, 1024] (else
+ * DSF_ERR_UNSUPPORTED and the caller keeps torch's kernels).  workspace: 2*C doubles (channel sums)
+ * followed by 512*2*C floats (per-workgroup partials), i.e. 514*C doubles.
+ * running_mean / running_var (may be NULL) are updated in place with `momentum` (unbiased variance).
+ * ---------------------------------------------------------------------------------- */
+int dsf_bn_forward(const float* x, const float* residual, const float* gamma, const float* beta, int64_t M,
+                   int C, float eps, float momentum, int relu, float* running_mean, float* running_var,
+                   float* y, float* save_mean, float* save_invstd, double* workspace, dsf_stream_t stream);
+int dsf_bn_apply(const float* x, const float* residual, const float* gamma, const float* beta,
+                 const float* mean, const float* invstd, int64_t M, int C, int relu, float* y,
+                 dsf_stream_t stream);
+/* grad_x (M,C) written; grad_residual (M,C) = relu-masked grad_y, may be NULL; grad_gamma / grad_beta (C). */
+int dsf_bn_backward(const float* x, const float* grad_y, const float* y, const float* gamma,
+                    const float* save_mean, const float* save_invstd, int64_t M, int C, int relu,
+                    float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta,
+                    double* workspace, dsf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,3 +66,43 @@ def test_conv_transpose2d_matches_torch_cpu(Ci, Co, K, s, p, op, H):
     assert _rel(yg.cpu(), y.detach()) < 1e-4
     for a, r in zip(torch.autograd.grad((yg * gy.cuda()).sum(), [xg, wg, bg]), grads):
         assert _rel(a.cpu(), r) < 1e-4
+
+
+@pytest.mark.parametrize("C,H,res,relu", [(64, 16, True, True), (256, 8, False, True), (512, 4, True, False), (8, 5, False, False),
+                                          (1024, 3, True, True)])
+def test_fused_batchnorm_matches_torch_cpu(C, H, res, relu):
+    """bn(x) (+ residual) (relu) in training mode vs torch CPU: output, running stats, all gradients."""
+    from dsf_amd.nn_norm import FusedBatchNorm2d
+    g = torch.Generator().manual_seed(C + H)
+    B = 6
+    x = (torch.randn(B, C, H, H, generator=g) * 2 + 0.5).requires_grad_(True)
+    r = torch.randn(B, C, H, H, generator=g).requires_grad_(True) if res else None
+    ref = torch.nn.BatchNorm2d(C, momentum=0.1)
+    with torch.no_grad():
+        ref.weight.copy_(torch.randn(C, generator=g)); ref.bias.copy_(torch.randn(C, generator=g))
+    fused = FusedBatchNorm2d(C, momentum=0.1).cuda()
+    fused.load_state_dict(ref.state_dict())
+    y = ref(x)
+    if res:
+        y = y + r
+    if relu:
+        y = F.relu(y)
+    gy = torch.randn(y.shape, generator=g)
+    inputs = [x, ref.weight, ref.bias] + ([r] if res else [])
+    grads = torch.autograd.grad((y * gy).sum(), inputs)
+    xg = x.detach().cuda().requires_grad_(True)
+    rg = r.detach().cuda().requires_grad_(True) if res else None
+    yg = fused(xg, rg, relu)
+    assert _rel(yg.cpu(), y.detach()) < 1e-5
+    gin = [xg, fused.weight, fused.bias] + ([rg] if res else [])
+    gg = torch.autograd.grad((yg * gy.cuda()).sum(), gin)
+    for a, b_ in zip(gg, grads):
+        assert _rel(a.cpu(), b_) < 1e-4
+    assert _rel(fused.running_mean.cpu(), ref.running_mean) < 1e-5
+    assert _rel(fused.running_var.cpu(), ref.running_var) < 1e-5
+    assert int(fused.num_batches_tracked) == 1
+    # eval mode: frozen statistics
+    ref.eval(); fused.eval()
+    with torch.no_grad():
+        ye = ref(x)
+        assert _rel(fused(xg.detach()).cpu(), ye) < 1e-5
