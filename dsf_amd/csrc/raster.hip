@@ -11,16 +11,18 @@
 //
 //  * crop mode  -- the fused leaf of Render.render: only the <=128x128 raster pixels
 //    that survive resize(640->480 rows) + nearest crop warp are evaluated.  One wave per
-//    8x8 crop tile, one lane per crop pixel; the projected faces of the sample are staged
-//    once per workgroup in LDS with a 16-bit tile-space bbox; a wave ballots the bbox test
-//    over 64 faces at a time and walks the set bits, broadcasting the face record from
-//    LDS and z-testing with a lexicographic (z, face) key, which reproduces the naive
-//    path's "lowest face index wins exact ties".
+//    8x8 crop tile; the projected vertices, packed face indices and per-face raster-pixel
+//    bboxes of the sample are staged once per workgroup in LDS.  A wave ballots the
+//    bbox-vs-tile test over 64 faces at a time and compacts the candidates; then one LANE
+//    per candidate face walks only the tile pixels inside its bbox and merges
+//    (z bits << 32 | face) keys with 64-bit LDS atomic-min, which is exactly the naive
+//    path's "strict < on z, lowest face index wins exact ties".
 //
 // Every float expression that decides coverage / index selection is written as separate
 // IEEE binary32 operations in the oracle's order (file is compiled with -ffp-contract=off;
 // hipcc's fp32 division and sqrt are correctly rounded by default).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -327,6 +329,7 @@ __device__ __forceinline__ bool crop_to_raster(const float* mi, const int32_t* _
 }
 
 constexpr int CROP_MAX_ROWS = 1024;
+constexpr int CAND_CAP = 512;                   // candidate faces per tile handled by the face-parallel path
 
 // One wave per 8x8 crop tile, one lane per crop pixel.  LDS per workgroup: projected vertices
 // (<=10 KB), packed 16-bit face indices (13 KB), per-face raster-pixel bboxes (13 KB) and the
@@ -349,6 +352,11 @@ __global__ __launch_bounds__(256) void render_crop_fwd_kernel(const float* __res
     __shared__ uint2 s_box[CROP_MAX_F];              // x = lo_x | hi_x<<16, y = lo_y | hi_y<<16 (raster pixels); lo>hi = never
     __shared__ uint16_t s_rows[CROP_MAX_ROWS];
     __shared__ float s_mi[6];
+    // per-wave scratch of the face-parallel tile path
+    __shared__ unsigned long long s_key[4][64];     // (z bits << 32 | face) per tile pixel
+    __shared__ unsigned short s_cand[4][CAND_CAP];   // compacted candidate faces of the tile
+    __shared__ short s_colrx[4][8], s_rowry[4][8];  // raster column of tile column j / raster row of tile row i (-1: padding)
+    __shared__ float s_colx[4][8], s_rowy[4][8];    // their NDC coordinates
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int b = blockIdx.x / wg_per_sample, part = blockIdx.x % wg_per_sample;
     const CamN k = cam_ndc(cam);
@@ -430,6 +438,99 @@ __global__ __launch_bounds__(256) void render_crop_fwd_kernel(const float* __res
             t_y0 = min(t_y0, __shfl_xor(t_y0, o, 64)); t_y1 = max(t_y1, __shfl_xor(t_y1, o, 64));
         }
         const int f_end = (t_x1 < 0) ? 0 : F;                    // whole tile reads the zero padding
+
+        // Is the tile a separable grid (raster column depends on j only, raster row on i only)?  It is
+        // unless the ~1e-7 off-diagonal LAPACK noise of M^-1 flips a rounding; then fall back below.
+        const int col_rx = __shfl(valid ? rx : -1, lane & 7, 64), col_ok = __shfl((int)valid, lane & 7, 64);
+        const int row_ry = __shfl(valid ? ry : -1, lane & 56, 64), row_ok = __shfl((int)valid, lane & 56, 64);
+        const bool sep_lane = valid ? (rx == col_rx && ry == row_ry && col_ok && row_ok) : !(col_ok && row_ok);
+        bool separable = __all(sep_lane);
+        // candidate count first (tiles with more than CAND_CAP candidates take the pixel-parallel path)
+        int n_total = 0;
+        if (separable) {
+            for (int base = 0; base < f_end; base += 64) {
+                const int fme = base + lane;
+                bool hit = false;
+                if (fme < F) {
+                    const uint2 box = s_box[fme];
+                    const int xlo = (int)(box.x & 0xFFFF), xhi = (int)(box.x >> 16), ylo = (int)(box.y & 0xFFFF), yhi = (int)(box.y >> 16);
+                    hit = xlo <= xhi && xlo <= t_x1 && xhi >= t_x0 && ylo <= t_y1 && yhi >= t_y0;
+                }
+                const unsigned long long mask = __ballot(hit);
+                if (hit && n_total + __popcll(mask & ((1ull << lane) - 1ull)) < CAND_CAP)
+                    s_cand[wave][n_total + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)fme;
+                n_total += __popcll(mask);
+            }
+            if (n_total > CAND_CAP) separable = false;
+        }
+
+        if (separable && n_total > 0) {
+            // ---- face-parallel path: one lane per candidate face, each lane walks only the tile pixels inside
+            //      its face's raster bbox and merges (z, face) keys with 64-bit LDS atomic min ----
+            unsigned long long* keys = s_key[wave];
+            keys[lane] = ~0ull;
+            if (lane < 8) {
+                s_colrx[wave][lane] = (short)(col_ok ? rx : -1);                         // lane j: row 0, column j
+                s_colx[wave][lane] = xf;
+            }
+            if ((lane & 7) == 0) {
+                s_rowry[wave][lane >> 3] = (short)(row_ok ? ry : -1);                    // lane 8i: row i, column 0
+                s_rowy[wave][lane >> 3] = yf;
+            }
+            const int n_cand = n_total;
+            __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): the wave's own LDS writes have landed
+            __builtin_amdgcn_wave_barrier();
+            for (int c0 = 0; c0 < n_cand; c0 += 64) {
+                if (c0 + lane < n_cand) {
+                    const int f = s_cand[wave][c0 + lane];
+                    const uint2 box = s_box[f];
+                    const int xlo = (int)(box.x & 0xFFFF), xhi = (int)(box.x >> 16), ylo = (int)(box.y & 0xFFFF), yhi = (int)(box.y >> 16);
+                    // pixel sub-rectangle [i0,i1] x [j0,j1] of the tile inside the face's raster bbox
+                    int j0 = 8, j1 = -1, i0 = 8, i1 = -1;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int cx = s_colrx[wave][q], cy = s_rowry[wave][q];
+                        if (cx >= xlo && cx <= xhi) { j0 = min(j0, q); j1 = max(j1, q); }
+                        if (cy >= ylo && cy <= yhi) { i0 = min(i0, q); i1 = max(i1, q); }
+                    }
+                    if (j0 <= j1 && i0 <= i1) {
+                        const uint2 fi = s_fidx[f];
+                        const int a = (int)(fi.x & 0xFFFF) * 3, c1 = (int)(fi.x >> 16) * 3, c2 = (int)fi.y * 3;
+                        const float x0 = s_pv[a], y0 = s_pv[a + 1], z0 = s_pv[a + 2];
+                        const float x1 = s_pv[c1], y1 = s_pv[c1 + 1], z1 = s_pv[c1 + 2];
+                        const float x2 = s_pv[c2], y2 = s_pv[c2 + 1], z2 = s_pv[c2 + 2];
+                        const float xmin = min3(x0, x1, x2), xmax = max3(x0, x1, x2);
+                        const float ymin = min3(y0, y1, y2), ymax = max3(y0, y1, y2);
+                        const float area = edge_fn(x2, y2, x0, y0, x1, y1) + kEps;
+                        for (int pi = i0; pi <= i1; ++pi) {
+                            const float py = s_rowy[wave][pi];
+                            if (s_rowry[wave][pi] < 0 || py > ymax || py < ymin) continue;
+                            for (int pj = j0; pj <= j1; ++pj) {
+                                const float px = s_colx[wave][pj];
+                                if (s_colrx[wave][pj] < 0 || px > xmax || px < xmin) continue;
+                                const float e0 = edge_fn(px, py, x1, y1, x2, y2);
+                                const float e1 = edge_fn(px, py, x2, y2, x0, y0);
+                                const float e2 = edge_fn(px, py, x0, y0, x1, y1);
+                                if (area > 0.0f) { if (!(e0 > 0.0f && e1 > 0.0f && e2 > 0.0f)) continue; }
+                                else if (area < 0.0f) { if (!(e0 < 0.0f && e1 < 0.0f && e2 < 0.0f)) continue; }
+                                const float w0 = e0 / area, w1 = e1 / area, w2 = e2 / area;
+                                const float pz = w0 * z0 + w1 * z1 + w2 * z2;
+                                if (pz < 0.0f) continue;
+                                if (!(w0 > 0.0f && w1 > 0.0f && w2 > 0.0f)) continue;
+                                // (z bits, face) ordered lexicographically == strict < on z with lowest-face ties
+                                const unsigned long long key = ((unsigned long long)__float_as_uint(pz + 0.0f) << 32) | (unsigned)f;
+                                atomicMin(&keys[pi * 8 + pj], key);
+                            }
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            const unsigned long long k = keys[lane];
+            if (k != ~0ull) { bz = __uint_as_float((unsigned)(k >> 32)); bf = (int)(k & 0xFFFFFFFFu); }
+        } else if (!separable) {
+        // ---- pixel-parallel path (non-separable tile): every lane z-tests its own pixel against each candidate ----
         for (int base = 0; base < f_end; base += 64) {
             const int fme = base + lane;
             bool hit = false;
@@ -463,6 +564,7 @@ __global__ __launch_bounds__(256) void render_crop_fwd_kernel(const float* __res
                 if (!(w0 > 0.0f && w1 > 0.0f && w2 > 0.0f)) continue;
                 if (bf < 0 || pz < bz) { bz = pz; bf = f; }      // faces visited in ascending order: ties keep the lowest
             }
+        }
         }
         // zbuf -> background 0 (:1085) -> zero-padded nearest crop -> normalize_img (:1289-1299)
         float d = (bf >= 0) ? bz : -1.0f;
@@ -560,7 +662,9 @@ inline int crop_wg_per_sample(int B, int tiles) {
     // ~2 workgroups per CU on the 256-CU chip (each re-stages the sample's vertices / face boxes),
     // at least one tile per wave
     int g = 1;
-    while (g < tiles / 4 && B * g < 512) g *= 2;
+    int target = 1024;
+    if (const char* e = getenv("DSF_CROP_WG_TARGET")) target = atoi(e);
+    while (g < tiles / 4 && B * g < target) g *= 2;
     return g;
 }
 
