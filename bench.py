@@ -127,6 +127,8 @@ def main():
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # MIOpen is still used for BatchNorm (faster than torch's native channels-last BN here: 41.5 vs 47.6 ms/step);
+    # convolutions never reach it (dsf_conv_igemm_*)
     torch.backends.cudnn.benchmark = os.environ.get("DSF_MIOPEN_FIND", "0") == "1"   # reference :87 uses find mode; gfx950 ships no MIOpen find-db, find mode JIT-compiles every solver (hours)
 
     from dsf_amd.render_model.mano_layer import Render

@@ -504,6 +504,109 @@ __global__ __launch_bounds__(256) void igemm_wrw_kernel(const float* __restrict_
         }
 }
 
+// fast path of backward-weights: Ci % 4 == 0, Co % 4 == 0, < 2^31 elements.  Pixel decode by
+// multiply-shift (magic = ceil(2^40 / d), exact for n*d < 2^40), clamped-address loads + select instead of
+// branches; otherwise identical to igemm_wrw_kernel.
+__device__ __forceinline__ uint32_t fast_div(uint32_t n, uint64_t magic) { return (uint32_t)(((uint64_t)n * magic) >> 40); }
+
+template <int BN>
+__global__ __launch_bounds__(256) void igemm_wrw_fast_kernel(const float* __restrict__ X, const float* __restrict__ dY,
+                                                             float* __restrict__ dW, ConvP p, int k_tiles, int n_tiles,
+                                                             int m_per_split, uint64_t magic_wo, uint64_t magic_ho) {
+    constexpr int BKT = 128;
+    constexpr int LDA = BKT + 4, LDB = BN + 4;
+    constexpr int WM = (BN == 128) ? 64 : 32;
+    constexpr int TM = WM / 32, TN = 2;
+    constexpr int B4 = BN / 4, BROWS = 256 / B4, BPASS = BK / BROWS;
+    __shared__ float As[BK * LDA];
+    __shared__ float Bs[BK * LDB];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = (BN == 128) ? (wave >> 1) : wave, wn = (BN == 128) ? (wave & 1) : 0;
+    int bid = blockIdx.x;
+    const int k_tile = bid % k_tiles; bid /= k_tiles;
+    const int n_tile = bid % n_tiles; const int split = bid / n_tiles;
+    const int k0 = k_tile * BKT, n0 = n_tile * BN;
+    const int M = p.B * p.Ho * p.Wo, K = p.KH * p.KW * p.Ci;
+    const int m_begin = split * m_per_split, m_end = min(M, m_begin + m_per_split);
+
+    const int a_k = k0 + (t & 31) * 4;
+    const bool a_kok = a_k < K;
+    const int a_tap = min(a_k, K - 1) / p.Ci;
+    const int a_c = min(a_k, K - 1) % p.Ci, a_kh = a_tap / p.KW, a_kw = a_tap % p.KW;
+    const int b_n4 = (t % B4) * 4, b_row = t / B4;
+    const bool b_nok = n0 + b_n4 < p.Co;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[4], rb[BPASS];
+    auto load_chunk = [&](int mc) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = mc + (t >> 5) + 8 * i;
+            const uint32_t mm = (uint32_t)min(m, M - 1);
+            const uint32_t q = fast_div(mm, magic_wo);
+            const int ox = (int)(mm - q * (uint32_t)p.Wo);
+            const uint32_t b = fast_div(q, magic_ho);
+            const int oy = (int)(q - b * (uint32_t)p.Ho);
+            const int iy = oy * p.stride + a_kh - p.pad_h, ix = ox * p.stride + a_kw - p.pad_w;
+            const bool ok = a_kok && m < m_end && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            const int off = ok ? (((int)b * p.Hi + iy) * p.Wi + ix) * p.Ci + a_c : 0;
+            const float4 v = *reinterpret_cast<const float4*>(X + off);
+            ra[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i) {
+            const int m = mc + b_row + BROWS * i;
+            const bool ok = b_nok && m < m_end;
+            const int off = ok ? m * p.Co + n0 + b_n4 : 0;
+            const float4 v = *reinterpret_cast<const float4*>(dY + off);
+            rb[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+        }
+    };
+
+    if (m_begin < m_end) load_chunk(m_begin);
+    for (int mc = m_begin; mc < m_end; mc += BK) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&As[((t >> 5) + 8 * i) * LDA + (t & 31) * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i) *reinterpret_cast<float4*>(&Bs[(b_row + BROWS * i) * LDB + b_n4]) = rb[i];
+        __syncthreads();
+        if (mc + BK < m_end) load_chunk(mc + BK);
+#pragma unroll 4
+        for (int kk = 0; kk < BK; kk += 2) {
+            const int r = kk + (lane >> 5);
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[r * LDA + wm * WM + i * 32 + (lane & 31)];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[r * LDB + wn * 64 + j * 32 + (lane & 31)];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (n >= p.Co) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = k0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (k < K) atomicAdd(dW + (int64_t)k * p.Co + n, acc[i][j][r]);
+            }
+        }
+}
+
 }  // namespace
 
 extern "C" int dsf_conv_igemm_forward(const float* X, const float* W, const float* bias, float* Y, int B, int Hi, int Wi,
@@ -569,6 +672,17 @@ extern "C" int dsf_conv_igemm_wrw(const float* X, const float* dY, float* dW, in
     per = ((per + BK - 1) / BK) * BK;
     if (per < 4 * BK) per = 4 * BK;
     splits = (int)((M + per - 1) / per);
+    const bool fast = (Ci & 3) == 0 && (Co & 3) == 0 && (int64_t)B * Hi * Wi * Ci < (1ll << 31) && M * Co < (1ll << 31);
+    if (fast) {
+        const uint64_t mwo = ((1ull << 40) + Wo - 1) / Wo, mho = ((1ull << 40) + Ho - 1) / Ho;
+        if (bn == 128)
+            hipLaunchKernelGGL(igemm_wrw_fast_kernel<128>, dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream,
+                               X, dY, dW, p, k_tiles, n_tiles, (int)per, mwo, mho);
+        else
+            hipLaunchKernelGGL(igemm_wrw_fast_kernel<64>, dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream,
+                               X, dY, dW, p, k_tiles, n_tiles, (int)per, mwo, mho);
+        return dsf_launch_status();
+    }
     if (bn == 128)
         hipLaunchKernelGGL(igemm_wrw_kernel<128>, dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream, X, dY,
                            dW, p, k_tiles, n_tiles, (int)per);

@@ -189,4 +189,6 @@ def kernel_name(rec):
         if dil == 1 and Ci >= 32 and Ci % 4 == 0 and Co % 4 == 0:
             return "igemm_fwd_fast_kernel<%d>" % bn
         return "igemm_fwd_kernel<%d, %s>" % (bn, "true" if (Ci < 32 and dil == 1) else "false")
+    if Ci % 4 == 0 and Co % 4 == 0:
+        return "igemm_wrw_fast_kernel<%d>" % bn
     return "igemm_wrw_kernel<%d>" % bn

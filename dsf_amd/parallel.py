@@ -46,17 +46,20 @@ def shard_batch(tensors, rank, world):
 class GradAllReducer:
     """Bucketed, backward-overlapped gradient averaging.
 
-    Parameters' ``.grad`` tensors are made views of flat per-bucket buffers (reverse registration
-    order ~ the order backward produces them).  ``post_accumulate_grad`` hooks count arrivals; the
-    last arrival of a bucket pre-scales it by 1/world and launches ``all_reduce(async_op=True)``.
+    Parameters are grouped (reverse registration order ~ the order backward produces their grads) into
+    ~32 MiB buckets.  ``post_accumulate_grad`` hooks count arrivals; when the last gradient of a bucket
+    has been produced the bucket is packed with ONE ``torch.cat`` launch, pre-scaled by 1/world and
+    all-reduced asynchronously, overlapping with the rest of backward.  ``finish()`` waits and rebinds
+    every ``p.grad`` to its slice of the reduced bucket (a view, no copy), so steps can run with
+    ``zero_grad(set_to_none=True)``: no per-parameter fill or accumulate kernels (~500 launches per step
+    for ResNet-18 two-stage).
     """
 
     def __init__(self, params, bucket_bytes=32 << 20, group=None):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.group = group
         self.params = [p for p in params if p.requires_grad]
-        self.buckets = []            # list of (flat tensor, [params])
-        self._pending = []
+        self.buckets = []            # lists of params
         self._bucket_of = {}
         cur, cur_bytes = [], 0
         for p in reversed(self.params):
@@ -68,52 +71,49 @@ class GradAllReducer:
             cur_bytes += nbytes
         if cur:
             self._seal(cur)
-        self._arrived = [0] * len(self.buckets)
-        self._launched = [False] * len(self.buckets)
+        self._reset()
         self._hooks = []
         if self.world > 1:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
     def _seal(self, plist):
-        total = sum(p.numel() for p in plist)
-        flat = torch.zeros(total, dtype=plist[0].dtype, device=plist[0].device)
-        off = 0
         for p in plist:
-            n = p.numel()
-            p.grad = flat[off:off + n].view_as(p)       # grads accumulate in place inside the bucket
             self._bucket_of[p] = len(self.buckets)
-            off += n
-        self.buckets.append((flat, plist))
+        self.buckets.append(list(plist))
+
+    def _reset(self):
+        self._arrived = [0] * len(self.buckets)
+        self._flat = [None] * len(self.buckets)
+        self._work = [None] * len(self.buckets)
 
     def _on_grad(self, p):
         b = self._bucket_of[p]
         self._arrived[b] += 1
-        if self._arrived[b] == len(self.buckets[b][1]) and not self._launched[b]:
+        if self._arrived[b] == len(self.buckets[b]) and self._flat[b] is None:
             self._launch(b)
 
     def _launch(self, b):
-        flat = self.buckets[b][0]
+        parts = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.buckets[b]]
+        flat = torch.cat(parts)
         flat.div_(self.world)
-        self._pending.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        self._launched[b] = True
+        self._flat[b] = flat
+        self._work[b] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self):
         """Call after backward, before optimizer.step()."""
         if self.world > 1:
             for b in range(len(self.buckets)):
-                if not self._launched[b]:               # parameters that received no gradient this step
+                if self._flat[b] is None:                # some parameter of the bucket got no gradient this step
                     self._launch(b)
-            for w in self._pending:
-                w.wait()
-        self._pending = []
-        self._arrived = [0] * len(self.buckets)
-        self._launched = [False] * len(self.buckets)
-
-    def grads_are_views(self):
-        """zero_grad(set_to_none=True) would detach the views; steps use set_to_none=False."""
-        return all(p.grad is not None and p.grad.data_ptr() >= self.buckets[self._bucket_of[p]][0].data_ptr()
-                   for p in self.params)
+            for b, plist in enumerate(self.buckets):
+                self._work[b].wait()
+                off = 0
+                for p in plist:
+                    n = p.numel()
+                    p.grad = self._flat[b][off:off + n].view_as(p)
+                    off += n
+        self._reset()
 
 
 def all_reduce_mean_pair(total, count, group=None):

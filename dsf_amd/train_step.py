@@ -107,7 +107,7 @@ class RenderSupervisedStep:
         return total + l_m2d, terms
 
     def __call__(self, tgt):
-        self.opt.zero_grad(set_to_none=False)
+        self.opt.zero_grad(set_to_none=True)
         loss, terms = self.loss(tgt)
         loss.backward()
         if self.grad_sync is not None:
@@ -165,7 +165,7 @@ class MeshLossStep:
         return l_m2d + l_part + l_icp + l_coll + l_sup, terms
 
     def __call__(self, tgt):
-        self.opt.zero_grad(set_to_none=False)
+        self.opt.zero_grad(set_to_none=True)
         loss, terms = self.loss(tgt)
         loss.backward()
         if self.grad_sync is not None:
@@ -301,7 +301,7 @@ class FinetuneStageStep:
         return total, terms
 
     def __call__(self, model_para, cube, img_r, center_r, cube_r, M_r, generator=None):
-        self.opt.zero_grad(set_to_none=False)
+        self.opt.zero_grad(set_to_none=True)
         loss, terms = self.loss(model_para, cube, img_r, center_r, cube_r, M_r, generator)
         loss.backward()
         if self.grad_sync is not None:
