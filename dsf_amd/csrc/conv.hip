@@ -380,6 +380,162 @@ __global__ __launch_bounds__(256) void igemm_fwd_fast_kernel(const float* __rest
         }
 }
 
+// dil == 2 twin of the fast path (ConvTranspose2d forward, backward-data of stride-2 convolutions)
+template <int BN>
+__global__ __launch_bounds__(256) void igemm_fwd_dil2_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                             const float* __restrict__ bias, float* __restrict__ Y,
+                                                             ConvP p, int m_tiles, int n_tiles, int k_splits) {
+    constexpr int LDA = BM + 4, LDB = BN + 4;
+    constexpr int WM = (BN == 128) ? 64 : 32;
+    constexpr int TM = WM / 32, TN = 2;
+    constexpr int B4 = BN / 4, BROWS = 256 / B4, BPASS = BK / BROWS;
+    __shared__ float As[BK * LDA];
+    __shared__ float Bs[BK * LDB];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = (BN == 128) ? (wave >> 1) : wave, wn = (BN == 128) ? (wave & 1) : 0;
+    int bid = blockIdx.x;
+    const int m_tile = bid % m_tiles; bid /= m_tiles;
+    const int n_tile = bid % n_tiles; const int ks = bid / n_tiles;
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+    const int M = p.B * p.Ho * p.Wo;
+
+    // transposed-convolution gather (virtual input = X upsampled by 2 with zeros, stride 1): output pixels are
+    // ordered parity-class-major, so a tile shares (oy & 1, ox & 1) and only KH*KW/4 taps can meet data
+    const int Hq = p.Ho >> 1, Wq = p.Wo >> 1, Mc = p.B * Hq * Wq;
+    auto decode = [&](int m, int& b, int& oy, int& ox) {
+        const int cls = m / Mc, r = m % Mc;
+        const int qx = r % Wq, q = r / Wq;
+        ox = qx * 2 + (cls & 1); oy = (q % Hq) * 2 + (cls >> 1); b = q / Hq;
+    };
+    int tile_py = -1, tile_px = -1;
+    {
+        const int c0 = m0 / Mc, c1 = min(m0 + BM - 1, M - 1) / Mc;
+        if (c0 == c1) { tile_py = c0 >> 1; tile_px = c0 & 1; }
+    }
+    const int a_k4 = (t & 7) * 4;
+    int a_base[4], a_iy[4], a_ix[4];               // a_base = b * Hi (row base), a_iy / a_ix = virtual coords of tap (0,0)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + (t >> 3) + 32 * i;
+        const bool ok = m < M;
+        int b, oy, ox;
+        decode(ok ? m : 0, b, oy, ox);
+        a_iy[i] = ok ? oy - p.pad_h : -0x40000000;
+        a_ix[i] = ox - p.pad_w;
+        a_base[i] = b * p.Hi;
+    }
+    const int b_n4 = (t % B4) * 4, b_row = t / B4;
+    const bool b_nok = n0 + b_n4 < p.Co;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int chunks_per_tap = (p.Ci + BK - 1) / BK;
+    const int n_chunks = p.KH * p.KW * chunks_per_tap;
+    const int per_split = (n_chunks + k_splits - 1) / k_splits;
+    const int chunk_lo = ks * per_split, chunk_hi = min(n_chunks, chunk_lo + per_split);
+
+    float4 ra[4], rb[BPASS];
+    // wave-uniform walk state of the chunk being loaded
+    int l_tap = chunk_lo / chunks_per_tap, l_c0 = (chunk_lo % chunks_per_tap) * BK;
+    int l_kh = l_tap / p.KW, l_kw = l_tap % p.KW;
+    auto tap_dead = [&]() -> bool {                   // every row of this tile reads inserted zeros for this tap
+        return tile_py >= 0 && ((((tile_py + l_kh - p.pad_h) & 1) != 0) || (((tile_px + l_kw - p.pad_w) & 1) != 0));
+    };
+    int l_chunk = chunk_lo;                           // chunk index of the walk state
+    auto skip_dead = [&]() {
+        while (l_chunk < chunk_hi && tap_dead()) {    // jump to the first chunk of the next tap
+            l_chunk += chunks_per_tap - l_c0 / BK;
+            l_c0 = 0; ++l_tap; ++l_kw;
+            if (l_kw == p.KW) { l_kw = 0; ++l_kh; }
+        }
+    };
+    const int vH = (p.Hi - 1) * 2 + 1, vW = (p.Wi - 1) * 2 + 1;
+    auto load_next = [&]() {
+        const bool c_ok = l_c0 + a_k4 < p.Ci;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int vy = a_iy[i] + l_kh, vx = a_ix[i] + l_kw;
+            const bool ok = c_ok && (unsigned)vy < (unsigned)vH && (unsigned)vx < (unsigned)vW && ((vy | vx) & 1) == 0;
+            const int off = ok ? ((a_base[i] + (vy >> 1)) * p.Wi + (vx >> 1)) * p.Ci + l_c0 + a_k4 : 0;
+            const float4 v = *reinterpret_cast<const float4*>(X + off);
+            ra[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+        }
+        const int wrow = l_tap * p.Ci + l_c0;
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i) {
+            const int kk = b_row + BROWS * i;
+            const bool ok = b_nok && (l_c0 + kk < p.Ci);
+            const int off = ok ? (wrow + kk) * p.Co + n0 + b_n4 : 0;
+            const float4 v = *reinterpret_cast<const float4*>(W + off);
+            rb[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+        }
+        // advance (scalar)
+        l_c0 += BK; ++l_chunk;
+        if (l_c0 >= p.Ci) {
+            l_c0 = 0; ++l_tap; ++l_kw;
+            if (l_kw == p.KW) { l_kw = 0; ++l_kh; }
+        }
+        skip_dead();
+    };
+
+    skip_dead();
+    bool have = l_chunk < chunk_hi;
+    if (have) load_next();
+    while (have) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = (t >> 3) + 32 * i;
+            As[(a_k4 + 0) * LDA + r] = ra[i].x; As[(a_k4 + 1) * LDA + r] = ra[i].y;
+            As[(a_k4 + 2) * LDA + r] = ra[i].z; As[(a_k4 + 3) * LDA + r] = ra[i].w;
+        }
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i)
+            *reinterpret_cast<float4*>(&Bs[(b_row + BROWS * i) * LDB + b_n4]) = rb[i];
+        __syncthreads();
+        have = l_chunk < chunk_hi;
+        if (have) load_next();
+#pragma unroll 4
+        for (int kk = 0; kk < BK; kk += 2) {
+            const int k = kk + (lane >> 5);
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[k * LDA + wm * WM + i * 32 + (lane & 31)];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[k * LDB + wn * 64 + j * 32 + (lane & 31)];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (n >= p.Co) continue;
+            const float bv = (bias && ks == 0) ? bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= M) continue;
+                int b, oy, ox;
+                decode(m, b, oy, ox);
+                const int64_t row = ((int64_t)b * p.Ho + oy) * p.Wo + ox;
+                if (k_splits > 1) atomicAdd(Y + row * p.Co + n, acc[i][j][r] + bv);
+                else Y[row * p.Co + n] = acc[i][j][r] + bv;
+            }
+        }
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward-weights: dW[k][n] += sum_m A[m][k] dY[m][n], reduction over pixels split across blocks
 // ------------------------------------------------------------------------------------------------
@@ -636,6 +792,17 @@ extern "C" int dsf_conv_igemm_forward(const float* X, const float* W, const floa
     const dim3 grid(m_tiles * n_tiles * k_splits);
     const bool fast = dil == 1 && !flat && (Ci & 3) == 0 && (Co & 3) == 0 && (int64_t)B * Hi * Wi * Ci < (1ll << 31) &&
                       (int64_t)KH * KW * Ci * Co < (1ll << 31);
+    const bool fast2 = dil == 2 && stride == 1 && perm && (Ci & 3) == 0 && (Co & 3) == 0 && Ci >= BK &&
+                       (int64_t)B * Hi * Wi * Ci < (1ll << 31) && (int64_t)KH * KW * Ci * Co < (1ll << 31);
+    if (fast2) {
+        if (bn == 128)
+            hipLaunchKernelGGL(igemm_fwd_dil2_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, X, W, bias, Y, p, m_tiles,
+                               n_tiles, k_splits);
+        else
+            hipLaunchKernelGGL(igemm_fwd_dil2_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, X, W, bias, Y, p, m_tiles,
+                               n_tiles, k_splits);
+        return dsf_launch_status();
+    }
     if (fast) {
         if (bn == 128)
             hipLaunchKernelGGL(igemm_fwd_fast_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, X, W, bias, Y, p, m_tiles,

@@ -188,6 +188,8 @@ def kernel_name(rec):
     if kind == "fwd":
         if dil == 1 and Ci >= 32 and Ci % 4 == 0 and Co % 4 == 0:
             return "igemm_fwd_fast_kernel<%d>" % bn
+        if dil == 2 and Ci >= 32 and Ci % 4 == 0 and Co % 4 == 0 and Ho % 2 == 0 and Wo % 2 == 0:
+            return "igemm_fwd_dil2_kernel<%d>" % bn
         return "igemm_fwd_kernel<%d, %s>" % (bn, "true" if (Ci < 32 and dil == 1) else "false")
     if Ci % 4 == 0 and Co % 4 == 0:
         return "igemm_wrw_fast_kernel<%d>" % bn
