@@ -257,7 +257,9 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
 // zero instead of branching, so the VALU stream per 32-deep chunk is ~5x shorter and no longer competes
 // with the 4096 MFMA cycles of the chunk.
 // ------------------------------------------------------------------------------------------------
-template <int BN>
+// WT = true: W is the FORWARD operand [KH][KW][N][Kc] of the same layer (i.e. this launch is the backward-data pass of
+// a stride-1 convolution): taps are read flipped and the B tile transposed, so no re-laid copy of the weights is needed.
+template <int BN, bool WT>
 __global__ __launch_bounds__(256) void igemm_fwd_fast_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                              const float* __restrict__ bias, float* __restrict__ Y,
                                                              ConvP p, int m_tiles, int n_tiles, int k_splits) {
@@ -289,6 +291,8 @@ __global__ __launch_bounds__(256) void igemm_fwd_fast_kernel(const float* __rest
     }
     const int b_n4 = (t % B4) * 4, b_row = t / B4;
     const bool b_nok = n0 + b_n4 < p.Co;
+    constexpr int WTPASS = BN / 32;                  // WT: thread -> column (t>>3) + 32 i, 4 consecutive k
+    float4 rbt[WTPASS];
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -317,14 +321,26 @@ __global__ __launch_bounds__(256) void igemm_fwd_fast_kernel(const float* __rest
             const float4 v = *reinterpret_cast<const float4*>(X + off);
             ra[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
         }
-        const int wrow = l_tap * p.Ci + l_c0;
+        if (WT) {
+            const int tapf = (p.KH - 1 - l_kh) * p.KW + (p.KW - 1 - l_kw);
 #pragma unroll
-        for (int i = 0; i < BPASS; ++i) {
-            const int kk = b_row + BROWS * i;
-            const bool ok = b_nok && (l_c0 + kk < p.Ci);
-            const int off = ok ? (wrow + kk) * p.Co + n0 + b_n4 : 0;
-            const float4 v = *reinterpret_cast<const float4*>(W + off);
-            rb[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+            for (int i = 0; i < WTPASS; ++i) {
+                const int n = n0 + (t >> 3) + 32 * i;
+                const bool ok = c_ok && n < p.Co;
+                const int off = ok ? (tapf * p.Co + n) * p.Ci + l_c0 + a_k4 : 0;
+                const float4 v = *reinterpret_cast<const float4*>(W + off);
+                rbt[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+            }
+        } else {
+            const int wrow = l_tap * p.Ci + l_c0;
+#pragma unroll
+            for (int i = 0; i < BPASS; ++i) {
+                const int kk = b_row + BROWS * i;
+                const bool ok = b_nok && (l_c0 + kk < p.Ci);
+                const int off = ok ? (wrow + kk) * p.Co + n0 + b_n4 : 0;
+                const float4 v = *reinterpret_cast<const float4*>(W + off);
+                rb[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+            }
         }
         // advance (scalar)
         l_c0 += BK;
@@ -343,9 +359,18 @@ __global__ __launch_bounds__(256) void igemm_fwd_fast_kernel(const float* __rest
             As[(a_k4 + 0) * LDA + r] = ra[i].x; As[(a_k4 + 1) * LDA + r] = ra[i].y;
             As[(a_k4 + 2) * LDA + r] = ra[i].z; As[(a_k4 + 3) * LDA + r] = ra[i].w;
         }
+        if (WT) {
 #pragma unroll
-        for (int i = 0; i < BPASS; ++i)
-            *reinterpret_cast<float4*>(&Bs[(b_row + BROWS * i) * LDB + b_n4]) = rb[i];
+            for (int i = 0; i < WTPASS; ++i) {
+                const int c = (t >> 3) + 32 * i;
+                Bs[(a_k4 + 0) * LDB + c] = rbt[i].x; Bs[(a_k4 + 1) * LDB + c] = rbt[i].y;
+                Bs[(a_k4 + 2) * LDB + c] = rbt[i].z; Bs[(a_k4 + 3) * LDB + c] = rbt[i].w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < BPASS; ++i)
+                *reinterpret_cast<float4*>(&Bs[(b_row + BROWS * i) * LDB + b_n4]) = rb[i];
+        }
         __syncthreads();
         if (chunk + 1 < chunk_hi) load_next();
 #pragma unroll 4
@@ -765,9 +790,9 @@ __global__ __launch_bounds__(256) void igemm_wrw_fast_kernel(const float* __rest
 
 }  // namespace
 
-extern "C" int dsf_conv_igemm_forward(const float* X, const float* W, const float* bias, float* Y, int B, int Hi, int Wi,
-                                      int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int dil, int pad_h,
-                                      int pad_w, dsf_stream_t stream) {
+static int conv_forward_impl(const float* X, const float* W, const float* bias, float* Y, int B, int Hi, int Wi, int Ci, int Ho,
+                             int Wo, int Co, int KH, int KW, int stride, int dil, int pad_h, int pad_w, int w_fwd_layout,
+                             dsf_stream_t stream) {
     DSF_CHECK_ARG(X && W && Y && B >= 0 && Hi > 0 && Wi > 0 && Ci > 0 && Ho > 0 && Wo > 0 && Co > 0 && KH > 0 && KW > 0);
     DSF_CHECK_ARG(stride >= 1 && dil >= 1 && (stride == 1 || dil == 1));
     if (B == 0) return DSF_OK;
@@ -803,13 +828,13 @@ extern "C" int dsf_conv_igemm_forward(const float* X, const float* W, const floa
                                n_tiles, k_splits);
         return dsf_launch_status();
     }
+    if (w_fwd_layout && !fast) return DSF_ERR_UNSUPPORTED;
     if (fast) {
-        if (bn == 128)
-            hipLaunchKernelGGL(igemm_fwd_fast_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, X, W, bias, Y, p, m_tiles,
-                               n_tiles, k_splits);
-        else
-            hipLaunchKernelGGL(igemm_fwd_fast_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, X, W, bias, Y, p, m_tiles,
-                               n_tiles, k_splits);
+#define DSF_LAUNCH_FAST(BNv, WTv) hipLaunchKernelGGL((igemm_fwd_fast_kernel<BNv, WTv>), grid, dim3(256), 0, (hipStream_t)stream, X, W, \
+                                                    bias, Y, p, m_tiles, n_tiles, k_splits)
+        if (bn == 128) { if (w_fwd_layout) DSF_LAUNCH_FAST(128, true); else DSF_LAUNCH_FAST(128, false); }
+        else { if (w_fwd_layout) DSF_LAUNCH_FAST(64, true); else DSF_LAUNCH_FAST(64, false); }
+#undef DSF_LAUNCH_FAST
         return dsf_launch_status();
     }
 #define DSF_LAUNCH_FWD(BNv, FL) hipLaunchKernelGGL((igemm_fwd_kernel<BNv, FL>), grid, dim3(256), 0, (hipStream_t)stream, X, W, \
@@ -818,6 +843,21 @@ extern "C" int dsf_conv_igemm_forward(const float* X, const float* W, const floa
     else { if (flat) DSF_LAUNCH_FWD(64, true); else DSF_LAUNCH_FWD(64, false); }
 #undef DSF_LAUNCH_FWD
     return dsf_launch_status();
+}
+
+extern "C" int dsf_conv_igemm_forward(const float* X, const float* W, const float* bias, float* Y, int B, int Hi, int Wi,
+                                      int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int dil, int pad_h,
+                                      int pad_w, dsf_stream_t stream) {
+    return conv_forward_impl(X, W, bias, Y, B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, dil, pad_h, pad_w, 0, stream);
+}
+
+// Backward-data of a stride-1 convolution straight from the layer's FORWARD weight operand W_fwd [KH][KW][Cin][Cout]:
+// dX[b,y,x,ci] = sum_{kh,kw,co} dY[b, y+pad-kh, x+pad-kw, co] * W_fwd[kh][kw][ci][co].  (Ci = Cout, Co = Cin here.)
+extern "C" int dsf_conv_igemm_bwd_data_s1(const float* dY, const float* W_fwd, float* dX, int B, int H, int Wd, int Cout,
+                                          int Cin, int KH, int KW, int pad_h, int pad_w, dsf_stream_t stream) {
+    const int Ho = H + 2 * pad_h - KH + 1, Wo = Wd + 2 * pad_w - KW + 1;          // dY spatial size
+    return conv_forward_impl(dY, W_fwd, nullptr, dX, B, Ho, Wo, Cout, H, Wd, Cin, KH, KW, 1, 1, KH - 1 - pad_h, KW - 1 - pad_w, 1,
+                             stream);
 }
 
 extern "C" int dsf_conv_igemm_wrw(const float* X, const float* dY, float* dW, int B, int Hi, int Wi, int Ci, int Ho, int Wo,

@@ -64,6 +64,27 @@ def ptr_nhwc(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def kernel_layout_(param, perm):
+    """Re-strides ``param`` in place so that its MEMORY order is ``param.permute(perm)`` (the kernels' GEMM operand)
+    while the logical shape -- state-dict compatibility -- is unchanged.  With it the forward operand is a free view,
+    the backward-weights output is already in the parameter's layout (autograd adopts it without a copy) and
+    optimizer state created with preserve_format matches."""
+    inv = [perm.index(i) for i in range(len(perm))]
+    param.data = param.data.permute(*perm).contiguous().permute(*inv)
+
+
+def _bwd_data_s1(gy, wk, out_hw, Cin, KH, KW, pad):
+    """stride-1 backward-data straight from the forward operand wk [KH][KW][Cin][Cout] (no flipped copy)."""
+    B, Cout, Ho, Wo = gy.shape
+    H, W = out_hw
+    if RECORD is not None:
+        RECORD.append(("fwd", B, Ho, Wo, Cout, H, W, Cin, KH, KW, 1, 1, KH - 1 - pad[0], KW - 1 - pad[1]))
+    gx = torch.empty((B, Cin, H, W), device=gy.device, dtype=torch.float32, memory_format=CL)
+    check(L.lib().dsf_conv_igemm_bwd_data_s1(ptr_nhwc(gy), ptr(wk), ptr_nhwc(gx), I(B), I(H), I(W), I(Cout), I(Cin), I(KH), I(KW),
+                                             I(pad[0]), I(pad[1]), stream_ptr()), "dsf_conv_igemm_bwd_data_s1")
+    return gx
+
+
 class Conv2dFunction(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding):
@@ -72,22 +93,24 @@ class Conv2dFunction(Function):
         B, _, Hi, Wi = x.shape
         Ho = (Hi + 2 * padding[0] - KH) // stride + 1
         Wo = (Wi + 2 * padding[1] - KW) // stride + 1
-        wk = weight.detach().float().permute(2, 3, 1, 0).contiguous()
+        wk = weight.detach().float().permute(2, 3, 1, 0).contiguous()          # a free view when the weight has kernel layout
         y = _fwd(x, wk, bias.detach().float().contiguous() if bias is not None else None, (Ho, Wo), Co, KH, KW, stride, 1,
                  padding)
-        ctx.save_for_backward(x, weight)
+        ctx.save_for_backward(x, weight, wk)
         ctx.cfg = (stride, padding, bias is not None)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        x, weight = ctx.saved_tensors
+        x, weight, wk = ctx.saved_tensors
         stride, padding, has_bias = ctx.cfg
         Co, Ci, KH, KW = weight.shape
         gy = _nhwc(gy)
         gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and stride == 1 and Co >= 32 and Co % 4 == 0 and Ci % 4 == 0:
+            gx = _bwd_data_s1(gy, wk, (x.shape[2], x.shape[3]), Ci, KH, KW, padding)
+        elif ctx.needs_input_grad[0]:
             wd = weight.detach().float().flip(2, 3).permute(2, 3, 0, 1).contiguous()          # [kh'][kw'][Co][Ci]
             gx = _fwd(gy, wd, None, (x.shape[2], x.shape[3]), Ci, KH, KW, 1, stride, (KH - 1 - padding[0], KW - 1 - padding[1]))
         if ctx.needs_input_grad[1]:
@@ -141,6 +164,8 @@ class Conv2d(nn.Conv2d):
         assert self.groups == 1 and _pair(self.dilation) == (1, 1) and self.padding_mode == 'zeros'
         s = _pair(self.stride)
         assert s[0] == s[1]
+        if x.is_cuda and not self.weight.permute(2, 3, 1, 0).is_contiguous():
+            kernel_layout_(self.weight, (2, 3, 1, 0))             # once: memory order [KH][KW][Ci][Co]
         return Conv2dFunction.apply(x, self.weight, self.bias, s[0], _pair(self.padding))
 
 
@@ -149,6 +174,8 @@ class ConvTranspose2d(nn.ConvTranspose2d):
         assert self.groups == 1 and _pair(self.dilation) == (1, 1) and output_size is None
         s = _pair(self.stride)
         assert s[0] == s[1]
+        if x.is_cuda and not self.weight.permute(2, 3, 1, 0).is_contiguous():
+            kernel_layout_(self.weight, (2, 3, 1, 0))             # once: memory order [KH][KW][Cout][Cin] (bwd-data / wrw operand)
         return ConvTranspose2dFunction.apply(x, self.weight, self.bias, s[0], _pair(self.padding), _pair(self.output_padding))
 
 

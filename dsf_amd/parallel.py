@@ -32,6 +32,17 @@ def init_distributed(backend=None):
     return rank, local, world
 
 
+def _flat(t):
+    """1-D view of a dense tensor in MEMORY order (conv weights keep a kernel layout: logical (Co,Ci,KH,KW),
+    memory [KH][KW][Ci][Co]); falls back to a logical-order copy for non-dense tensors."""
+    if t.is_contiguous():
+        return t.view(-1)
+    order = sorted(range(t.dim()), key=lambda d: -t.stride(d))
+    if t.permute(*order).is_contiguous():
+        return t.as_strided((t.numel(),), (1,), t.storage_offset())
+    return t.reshape(-1)
+
+
 def shard_batch(tensors, rank, world):
     """Per-image sharding: rank r takes rows [r*B/world, (r+1)*B/world)."""
     out = []
@@ -94,7 +105,8 @@ class GradAllReducer:
             self._launch(b)
 
     def _launch(self, b):
-        parts = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.buckets[b]]
+        parts = [_flat(p.grad if p.grad is not None and p.grad.stride() == p.stride() else
+                       (torch.zeros_like(p) if p.grad is None else torch.empty_like(p).copy_(p.grad))) for p in self.buckets[b]]
         flat = torch.cat(parts)
         flat.div_(self.world)
         self._flat[b] = flat
@@ -111,7 +123,7 @@ class GradAllReducer:
                 off = 0
                 for p in plist:
                     n = p.numel()
-                    p.grad = self._flat[b][off:off + n].view_as(p)
+                    p.grad = self._flat[b][off:off + n].as_strided(p.shape, p.stride())      # same (possibly kernel) layout as p
                     off += n
         self._reset()
 

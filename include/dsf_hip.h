@@ -278,6 +278,13 @@ int dsf_offset2joint_backward(const float* maps, const float* depth, const float
 int dsf_conv_igemm_forward(const float* X, const float* W, const float* bias, float* Y, int B, int Hi, int Wi,
                            int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int dil, int pad_h,
                            int pad_w, dsf_stream_t stream);
+/* Backward-data of a stride-1 convolution read straight from the layer's forward operand W_fwd
+ * [KH][KW][Cin][Cout] (taps flipped and the tile transposed in the loader; no re-laid weight copy):
+ * dX[b,y,x,ci] = sum_{kh,kw,co} dY[b, y+pad_h-kh, x+pad_w-kw, co] * W_fwd[kh][kw][ci][co];
+ * dY is (B, H+2pad-KH+1, W+2pad-KW+1, Cout), dX (B,H,W,Cin).  Needs Cin%4 == Cout%4 == 0, Cout >= 32
+ * (else DSF_ERR_UNSUPPORTED: use dsf_conv_igemm_forward with flipped weights). */
+int dsf_conv_igemm_bwd_data_s1(const float* dY, const float* W_fwd, float* dX, int B, int H, int W, int Cout,
+                               int Cin, int KH, int KW, int pad_h, int pad_w, dsf_stream_t stream);
 /* dW[(kh*KW+kw)*Ci+c][n] = sum_{b,oy,ox} X[b, oy*stride+kh-pad_h, ox*stride+kw-pad_w, c] * dY[b,oy,ox,n]
  * (zeroed by the call, accumulated with float atomics across the pixel splits). */
 int dsf_conv_igemm_wrw(const float* X, const float* dY, float* dW, int B, int Hi, int Wi, int Ci, int Ho, int Wo,
