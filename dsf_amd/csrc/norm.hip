@@ -169,6 +169,30 @@ __global__ void bn_param_grads_kernel(const double* __restrict__ acc, int C, flo
     if (dgamma) dgamma[c] = (float)acc[C + c];
 }
 
+// per-column sums of a row-major (M, C) matrix, any C <= 1024 (bias gradients of NHWC conv outputs).
+// `out` must be zeroed; one float atomic per column per workgroup (<= 256 workgroups).
+__global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ x, int64_t M, int C, int cpad,
+                                                      int rows_per_wg, float* __restrict__ out) {
+    __shared__ float s[256];
+    const int t = threadIdx.x;
+    const int c = t % cpad, rl = t / cpad, rlanes = 256 / cpad;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+    const int64_t r1 = (r0 + rows_per_wg < M) ? r0 + rows_per_wg : M;
+    for (int cb = 0; cb < C; cb += cpad) {
+        float acc = 0.f;
+        if (cb + c < C)
+            for (int64_t r = r0 + rl; r < r1; r += rlanes) acc += x[r * C + cb + c];
+        s[t] = acc;
+        __syncthreads();
+        if (rl == 0 && cb + c < C) {
+            float tot = 0.f;
+            for (int q = 0; q < rlanes; ++q) tot += s[q * cpad + c];
+            atomicAdd(out + cb + c, tot);
+        }
+        __syncthreads();
+    }
+}
+
 inline bool bn_shape_ok(int C) { return C >= 4 && (C & 3) == 0 && (C >> 2) <= 256 && 256 % (C >> 2) == 0; }
 
 constexpr int BN_MAX_WGS = 512;
@@ -234,5 +258,18 @@ extern "C" int dsf_bn_backward(const float* x, const float* grad_y, const float*
                        workspace, M, n4, C, relu, grad_x, grad_residual);
     if (grad_gamma || grad_beta)
         hipLaunchKernelGGL(bn_param_grads_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, C, grad_gamma, grad_beta);
+    return dsf_launch_status();
+}
+
+extern "C" int dsf_col_sum(const float* x, int64_t M, int C, float* out, dsf_stream_t stream) {
+    DSF_CHECK_ARG(x && out && M > 0 && C > 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(out, 0, sizeof(float) * C, st) != hipSuccess) return DSF_ERR_LAUNCH;
+    int cpad = 1;
+    while (cpad < C && cpad < 256) cpad <<= 1;         // columns handled per pass (power of two <= 256)
+    int64_t rows = (M + 255) / 256;
+    if (rows < 64) rows = 64;
+    const int wgs = (int)((M + rows - 1) / rows);
+    hipLaunchKernelGGL(col_sum_kernel, dim3(wgs), dim3(256), 0, st, x, M, C, cpad, (int)rows, out);
     return dsf_launch_status();
 }

@@ -311,6 +311,10 @@ int dsf_bn_backward(const float* x, const float* grad_y, const float* y, const f
                     float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta,
                     double* workspace, dsf_stream_t stream);
 
+/* out[c] = sum_m x[m][c] of a row-major (M, C) matrix (bias gradient of an NHWC convolution output:
+ * the `gy.sum((0,2,3))` of nn.Conv2d's backward). */
+int dsf_col_sum(const float* x, int64_t M, int C, float* out, dsf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
