@@ -58,7 +58,11 @@ def conv_kernel_roofline(step, tgt):
     (2*M*N*K of each implicit GEMM) / their summed duration."""
     from dsf_amd import nn_conv
     nn_conv.RECORD = []
+    if step.grad_sync is not None:
+        step.grad_sync.enabled = False          # rank-0-only diagnostic step: no collectives
     step(tgt)
+    if step.grad_sync is not None:
+        step.grad_sync.enabled = True
     torch.cuda.synchronize()
     recs, nn_conv.RECORD = nn_conv.RECORD, None
     per_kernel = {}

@@ -83,6 +83,7 @@ class GradAllReducer:
         if cur:
             self._seal(cur)
         self._reset()
+        self.enabled = True          # False: hooks and finish() do nothing (single-rank diagnostic steps)
         self._hooks = []
         if self.world > 1:
             for p in self.params:
@@ -99,6 +100,8 @@ class GradAllReducer:
         self._work = [None] * len(self.buckets)
 
     def _on_grad(self, p):
+        if not self.enabled:
+            return
         b = self._bucket_of[p]
         self._arrived[b] += 1
         if self._arrived[b] == len(self.buckets[b]) and self._flat[b] is None:
@@ -114,7 +117,7 @@ class GradAllReducer:
 
     def finish(self):
         """Call after backward, before optimizer.step()."""
-        if self.world > 1:
+        if self.world > 1 and self.enabled:
             for b in range(len(self.buckets)):
                 if self._flat[b] is None:                # some parameter of the bucket got no gradient this step
                     self._launch(b)
