@@ -50,6 +50,20 @@ HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP32_MATRIX_PEAK_TFLOPS = 157.3
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed PMC passes (profiles/r01_pmc_traffic.json, made by
+    scratch/pmc_summary.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this script;
+    FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md).  A profiler cannot run inside the timed
+    process, so the figure is read back from the profile of the same command; null when the file has no entry."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            e = json.load(f)["kernels"][kernel]
+        return {"traffic": e["hbm_bytes_per_launch"], "traffic_source": "profiles/r01_pmc_traffic.json (fetch x2 + write)"}
+    except (OSError, KeyError, ValueError):
+        return {"traffic": None}
+
+
 def conv_kernel_roofline(step, tgt):
     """Roofline of the dominant kernel, igemm_fwd_kernel<128,false> (fp32 MFMA implicit-GEMM
     convolution: forward, backward-data and transposed-conv passes of every layer with Co > 64).
@@ -67,17 +81,18 @@ def conv_kernel_roofline(step, tgt):
     recs, nn_conv.RECORD = nn_conv.RECORD, None
     per_kernel = {}
     for r in recs:
-        us, fl = nn_conv.replay(r)
-        k = per_kernel.setdefault(nn_conv.kernel_name(r), [0, 0.0, 0.0])
-        k[0] += 1; k[1] += us; k[2] += fl
+        us, fl, nb = nn_conv.replay(r)
+        k = per_kernel.setdefault(nn_conv.kernel_name(r), [0, 0.0, 0.0, 0.0])
+        k[0] += 1; k[1] += us; k[2] += fl; k[3] += nb
     dom = max(per_kernel, key=lambda n: per_kernel[n][1])
-    n, us, fl = per_kernel[dom]
+    n, us, fl, nb = per_kernel[dom]
     tf = fl / (us * 1e-6) / 1e12
     table = {name: {"launches_per_step": v[0], "avg_launch_us": round(v[1] / v[0], 1), "TFLOP/s": round(v[2] / (v[1] * 1e-6) / 1e12, 1),
-                    "ms_per_step": round(v[1] / 1e3, 2)} for name, v in per_kernel.items()}
+                    "ms_per_step": round(v[1] / 1e3, 2), "algorithmic_MB_per_launch": round(v[3] / v[0] / 1e6, 2)} for name, v in per_kernel.items()}
     return {"kernel": dom, "bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(tf / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": None, "launches_per_step": n,
-            "avg_launch_us": round(us / n, 1), "flops_per_launch": fl / n,
+            "frac": round(tf / FP32_MATRIX_PEAK_TFLOPS, 4), "launches_per_step": n,
+            "avg_launch_us": round(us / n, 1), "flops_per_launch": fl / n, "algorithmic_bytes_per_launch": nb / n,
+            **pmc_traffic(dom),
             "note": "fp32-in/fp32-acc MFMA (v_mfma_f32_32x32x2_f32) dense peak 157.3 TFLOP/s; HBM traffic is not the bound"}, table
 
 
@@ -110,7 +125,7 @@ def crop_kernel_roofline(render, B, launches=200):
     bytes_per_launch = B * (779 * 12 + 128 * 128 * 4 + 128 * 128 * 4)
     achieved = bytes_per_launch / (us * 1e-6) / 1e9
     return {"kernel": "render_crop_fwd_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), **pmc_traffic("render_crop_fwd_kernel"),
             "avg_launch_us": round(us, 2), "bytes_per_launch": bytes_per_launch,
             "note": "VALU/latency-bound at this size (4.5 MB of algorithmic traffic per launch); 2 launches per step"}
 

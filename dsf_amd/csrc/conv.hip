@@ -250,38 +250,92 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-// fast path of the forward-type kernel: dil == 1, Ci % 4 == 0, Co % 4 == 0, < 2^31 elements.
-// Same tiling and arithmetic as igemm_fwd_kernel; the gather is reduced to one add + one unsigned
-// compare pair per row and tap (row bases / validity are hoisted out of the K loop, the (tap, c0)
-// walk is wave-uniform scalar state) and out-of-range lanes load from a clamped address and select
-// zero instead of branching, so the VALU stream per 32-deep chunk is ~5x shorter and no longer competes
-// with the 4096 MFMA cycles of the chunk.
+// fast path of the forward-type kernel: dil == 1, Ci % 4 == 0, Co % 4 == 0, operands < 4 GiB.
+// Same tiling and arithmetic as igemm_fwd_kernel, software-pipelined for the 64-cycle fp32 MFMA:
+//  * gather through buffer_load_dwordx4 with a raw buffer descriptor: padding taps / ragged rows get the
+//    offset 0xFFFFFFFF, which the hardware range check turns into zeros -- no select on the loaded
+//    data, so nothing consumes the loads until the LDS store after the MFMA block (the compiler had put
+//    `s_waitcnt vmcnt(0)` + 32 v_cndmask in front of the MFMAs of every chunk);
+//  * two LDS stages, one barrier per 32-deep chunk: loads of chunk c+1 are in flight during the 64
+//    MFMAs of chunk c and are stored to the other stage afterwards;
+//  * MFMA fragments are double-buffered in registers (reads of k-step s+1 issued before the MFMAs of s);
+//  * LDS tiles are k-major [32][128] with the column XOR-swizzled by (k & 28): the transposing
+//    ds_write_b32 of the A tile (lanes = 8 k-quads x 4 rows) and the 32-wide fragment ds_read_b32 are both
+//    bank-conflict-free without padding, so two stages are exactly 64 KiB and two workgroups share a CU;
+//  * workgroup -> tile map is XCD-contiguous (the 8 XCDs take blockIdx round-robin; each XCD walks its
+//    own range of tiles with the n tiles of one pixel tile adjacent, so they share the A rows in its L2).
 // ------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dsf_buffer(const void* ptr, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 dsf_buffer_load4(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
+    const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0);
+    const f32x4 f = __builtin_bit_cast(f32x4, raw);
+    return make_float4(f[0], f[1], f[2], f[3]);
+}
+constexpr uint32_t OOB = 0xFFFFFFFFu;
+
+// blockIdx -> tile number such that every XCD (blockIdx % 8) owns one contiguous range of tiles
+__device__ __forceinline__ int xcd_contiguous(int bid, int total) {
+    const int q = total >> 3, rem = total & 7, xcd = bid & 7, local = bid >> 3;
+    return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
+}
+
+// One 32-deep chunk of the block GEMM from one LDS stage: 16 k-steps x (TM x TN) MFMAs per wave.
+template <int BN, int TM, int TN>
+__device__ __forceinline__ void mma_chunk(const float* __restrict__ Asb, const float* __restrict__ Bsb, int arow, int bcol,
+                                          int lane, f32x16 (&acc)[TM][TN]) {
+    const int h = lane >> 5, l31 = lane & 31;
+    float af[2][TM], bf[2][TN];
+    auto frag = [&](int kk, float* a, float* b) {
+        const int k = kk + h, sw = l31 ^ (kk & 28);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = Asb[k * BM + arow + i * 32 + sw];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = Bsb[k * BN + bcol + j * 32 + sw];
+    };
+    frag(0, af[0], bf[0]);
+#pragma unroll
+    for (int s = 0; s < BK / 2; ++s) {
+        if (s + 1 < BK / 2) frag(2 * (s + 1), af[(s + 1) & 1], bf[(s + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);           // keep the next step's LDS reads ahead of this step's MFMAs
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][i], bf[s & 1][j], acc[i][j], 0, 0, 0);
+    }
+}
+
 // WT = true: W is the FORWARD operand [KH][KW][N][Kc] of the same layer (i.e. this launch is the backward-data pass of
 // a stride-1 convolution): taps are read flipped and the B tile transposed, so no re-laid copy of the weights is needed.
 template <int BN, bool WT>
 __global__ __launch_bounds__(256) void igemm_fwd_fast_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                              const float* __restrict__ bias, float* __restrict__ Y,
-                                                             ConvP p, int m_tiles, int n_tiles, int k_splits) {
-    constexpr int LDA = BM + 4, LDB = BN + 4;
+                                                             ConvP p, int m_tiles, int n_tiles, int k_splits,
+                                                             uint32_t x_bytes, uint32_t w_bytes) {
     constexpr int WM = (BN == 128) ? 64 : 32;
     constexpr int TM = WM / 32, TN = 2;
     constexpr int B4 = BN / 4, BROWS = 256 / B4, BPASS = BK / BROWS;
-    __shared__ float As[BK * LDA];
-    __shared__ float Bs[BK * LDB];
+    constexpr int WTPASS = BN / 32;                  // WT: thread -> column (t>>3) + 32 i, 4 consecutive k
+    __shared__ float As[2][BK * BM];
+    __shared__ float Bs[2][BK * BN];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = (BN == 128) ? (wave >> 1) : wave, wn = (BN == 128) ? (wave & 1) : 0;
-    int bid = blockIdx.x;
-    const int m_tile = bid % m_tiles; bid /= m_tiles;
-    const int n_tile = bid % n_tiles; const int ks = bid / n_tiles;
+    int tile = xcd_contiguous(blockIdx.x, m_tiles * n_tiles * k_splits);
+    const int n_tile = tile % n_tiles; tile /= n_tiles;
+    const int m_tile = tile % m_tiles; const int ks = tile / m_tiles;
     const int m0 = m_tile * BM, n0 = n_tile * BN;
     const int M = p.B * p.Ho * p.Wo;
+    const __amdgpu_buffer_rsrc_t xbuf = dsf_buffer(X, x_bytes), wbuf = dsf_buffer(W, w_bytes);
 
-    const int a_k4 = (t & 7) * 4;
+    const int a_k4 = (t & 7) * 4, a_r = t >> 3;
     int a_base[4], a_iy[4], a_ix[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int m = m0 + (t >> 3) + 32 * i;
+        const int m = m0 + a_r + 32 * i;
         const bool ok = m < M;
         const int mm = ok ? m : 0;
         const int ox = mm % p.Wo, q = mm / p.Wo, oy = q % p.Ho, b = q / p.Ho;
@@ -291,8 +345,6 @@ __global__ __launch_bounds__(256) void igemm_fwd_fast_kernel(const float* __rest
     }
     const int b_n4 = (t % B4) * 4, b_row = t / B4;
     const bool b_nok = n0 + b_n4 < p.Co;
-    constexpr int WTPASS = BN / 32;                  // WT: thread -> column (t>>3) + 32 i, 4 consecutive k
-    float4 rbt[WTPASS];
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -307,7 +359,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_fast_kernel(const float* __rest
     const int per_split = (n_chunks + k_splits - 1) / k_splits;
     const int chunk_lo = ks * per_split, chunk_hi = min(n_chunks, chunk_lo + per_split);
 
-    float4 ra[4], rb[BPASS];
+    float4 ra[4], rb[WT ? WTPASS : BPASS];
     // wave-uniform walk state of the chunk being loaded
     int l_tap = chunk_lo / chunks_per_tap, l_c0 = (chunk_lo % chunks_per_tap) * BK;
     int l_kh = l_tap / p.KW, l_kw = l_tap % p.KW;
@@ -317,19 +369,15 @@ __global__ __launch_bounds__(256) void igemm_fwd_fast_kernel(const float* __rest
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool ok = c_ok && (unsigned)(a_iy[i] + l_kh) < (unsigned)p.Hi && (unsigned)(a_ix[i] + l_kw) < (unsigned)p.Wi;
-            const int off = ok ? a_base[i] + tap_off : 0;
-            const float4 v = *reinterpret_cast<const float4*>(X + off);
-            ra[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+            ra[i] = dsf_buffer_load4(xbuf, ok ? (uint32_t)(a_base[i] + tap_off) * 4u : OOB);
         }
         if (WT) {
             const int tapf = (p.KH - 1 - l_kh) * p.KW + (p.KW - 1 - l_kw);
 #pragma unroll
             for (int i = 0; i < WTPASS; ++i) {
-                const int n = n0 + (t >> 3) + 32 * i;
+                const int n = n0 + a_r + 32 * i;
                 const bool ok = c_ok && n < p.Co;
-                const int off = ok ? (tapf * p.Co + n) * p.Ci + l_c0 + a_k4 : 0;
-                const float4 v = *reinterpret_cast<const float4*>(W + off);
-                rbt[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+                rb[i] = dsf_buffer_load4(wbuf, ok ? (uint32_t)((tapf * p.Co + n) * p.Ci + l_c0 + a_k4) * 4u : OOB);
             }
         } else {
             const int wrow = l_tap * p.Ci + l_c0;
@@ -337,9 +385,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_fast_kernel(const float* __rest
             for (int i = 0; i < BPASS; ++i) {
                 const int kk = b_row + BROWS * i;
                 const bool ok = b_nok && (l_c0 + kk < p.Ci);
-                const int off = ok ? (wrow + kk) * p.Co + n0 + b_n4 : 0;
-                const float4 v = *reinterpret_cast<const float4*>(W + off);
-                rb[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+                rb[i] = dsf_buffer_load4(wbuf, ok ? (uint32_t)((wrow + kk) * p.Co + n0 + b_n4) * 4u : OOB);
             }
         }
         // advance (scalar)
@@ -349,43 +395,43 @@ __global__ __launch_bounds__(256) void igemm_fwd_fast_kernel(const float* __rest
             if (l_kw == p.KW) { l_kw = 0; ++l_kh; }
         }
     };
-
-    if (chunk_lo < chunk_hi) load_next();
-    for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
-        __syncthreads();
+    auto stage = [&](int buf) {                                     // registers -> LDS stage `buf` (k-major, swizzled)
+        float* Asb = As[buf];
+        float* Bsb = Bs[buf];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int r = (t >> 3) + 32 * i;
-            As[(a_k4 + 0) * LDA + r] = ra[i].x; As[(a_k4 + 1) * LDA + r] = ra[i].y;
-            As[(a_k4 + 2) * LDA + r] = ra[i].z; As[(a_k4 + 3) * LDA + r] = ra[i].w;
+            const int r = (a_r + 32 * i) ^ a_k4;                    // (a_k4 + j) & 28 == a_k4
+            Asb[(a_k4 + 0) * BM + r] = ra[i].x; Asb[(a_k4 + 1) * BM + r] = ra[i].y;
+            Asb[(a_k4 + 2) * BM + r] = ra[i].z; Asb[(a_k4 + 3) * BM + r] = ra[i].w;
         }
         if (WT) {
 #pragma unroll
             for (int i = 0; i < WTPASS; ++i) {
-                const int c = (t >> 3) + 32 * i;
-                Bs[(a_k4 + 0) * LDB + c] = rbt[i].x; Bs[(a_k4 + 1) * LDB + c] = rbt[i].y;
-                Bs[(a_k4 + 2) * LDB + c] = rbt[i].z; Bs[(a_k4 + 3) * LDB + c] = rbt[i].w;
+                const int c = (a_r + 32 * i) ^ a_k4;
+                Bsb[(a_k4 + 0) * BN + c] = rb[i].x; Bsb[(a_k4 + 1) * BN + c] = rb[i].y;
+                Bsb[(a_k4 + 2) * BN + c] = rb[i].z; Bsb[(a_k4 + 3) * BN + c] = rb[i].w;
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < BPASS; ++i)
-                *reinterpret_cast<float4*>(&Bs[(b_row + BROWS * i) * LDB + b_n4]) = rb[i];
+            for (int i = 0; i < BPASS; ++i) {
+                const int kk = b_row + BROWS * i;
+                *reinterpret_cast<float4*>(&Bsb[kk * BN + (b_n4 ^ (kk & 28))]) = rb[i];
+            }
         }
+    };
+
+    if (chunk_lo < chunk_hi) {
+        load_next();
+        stage(0);
+    }
+    __syncthreads();
+    for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
+        const int buf = (chunk - chunk_lo) & 1;
+        const bool more = chunk + 1 < chunk_hi;
+        if (more) load_next();
+        mma_chunk<BN, TM, TN>(As[buf], Bs[buf], wm * WM, wn * 64, lane, acc);
+        if (more) stage(buf ^ 1);
         __syncthreads();
-        if (chunk + 1 < chunk_hi) load_next();
-#pragma unroll 4
-        for (int kk = 0; kk < BK; kk += 2) {
-            const int k = kk + (lane >> 5);
-            float a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[k * LDA + wm * WM + i * 32 + (lane & 31)];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[k * LDB + wn * 64 + j * 32 + (lane & 31)];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
     }
 
 #pragma unroll
@@ -808,15 +854,17 @@ static int conv_forward_impl(const float* X, const float* W, const float* bias, 
     const int live_chunks = perm ? n_chunks / (dil * dil) : n_chunks;
     int k_splits = 1;
     if (m_tiles * n_tiles < 384) {                      // fewer tiles than ~1.5 per CU: split K to fill the chip
-        k_splits = (768 + m_tiles * n_tiles - 1) / (m_tiles * n_tiles);
+        // the pipelined kernels hold 2 workgroups per CU (64 KiB of LDS each): aim at one full round of 512
+        const int slots = 512;
+        k_splits = (slots + m_tiles * n_tiles / 2) / (m_tiles * n_tiles);
         if (k_splits > live_chunks / 4) k_splits = live_chunks / 4;
         if (k_splits < 1) k_splits = 1;
     }
     if (k_splits > 1 &&
         hipMemsetAsync(Y, 0, sizeof(float) * (size_t)M * Co, (hipStream_t)stream) != hipSuccess) return DSF_ERR_LAUNCH;
     const dim3 grid(m_tiles * n_tiles * k_splits);
-    const bool fast = dil == 1 && !flat && (Ci & 3) == 0 && (Co & 3) == 0 && (int64_t)B * Hi * Wi * Ci < (1ll << 31) &&
-                      (int64_t)KH * KW * Ci * Co < (1ll << 31);
+    const int64_t x_bytes = (int64_t)B * Hi * Wi * Ci * 4, w_bytes = (int64_t)KH * KW * Ci * Co * 4;
+    const bool fast = dil == 1 && !flat && (Ci & 3) == 0 && (Co & 3) == 0 && x_bytes < 0xFFFFFFF0ll && w_bytes < 0xFFFFFFF0ll;
     const bool fast2 = dil == 2 && stride == 1 && perm && (Ci & 3) == 0 && (Co & 3) == 0 && Ci >= BK &&
                        (int64_t)B * Hi * Wi * Ci < (1ll << 31) && (int64_t)KH * KW * Ci * Co < (1ll << 31);
     if (fast2) {
@@ -831,7 +879,7 @@ static int conv_forward_impl(const float* X, const float* W, const float* bias, 
     if (w_fwd_layout && !fast) return DSF_ERR_UNSUPPORTED;
     if (fast) {
 #define DSF_LAUNCH_FAST(BNv, WTv) hipLaunchKernelGGL((igemm_fwd_fast_kernel<BNv, WTv>), grid, dim3(256), 0, (hipStream_t)stream, X, W, \
-                                                    bias, Y, p, m_tiles, n_tiles, k_splits)
+                                                    bias, Y, p, m_tiles, n_tiles, k_splits, (uint32_t)x_bytes, (uint32_t)w_bytes)
         if (bn == 128) { if (w_fwd_layout) DSF_LAUNCH_FAST(128, true); else DSF_LAUNCH_FAST(128, false); }
         else { if (w_fwd_layout) DSF_LAUNCH_FAST(64, true); else DSF_LAUNCH_FAST(64, false); }
 #undef DSF_LAUNCH_FAST

@@ -250,7 +250,8 @@ __global__ __launch_bounds__(256) void img2pcl_kernel(const float* __restrict__ 
 // ---- GFM ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void joint2offset_fwd_kernel(const float* __restrict__ joints,
                                                                const float* __restrict__ img, int J, int H, int S,
-                                                               float ks, float* __restrict__ maps) {
+                                                               float ks, float* __restrict__ maps, int64_t sb,
+                                                               int64_t sc, int64_t sq) {
     extern __shared__ float s_j[];
     const int b = blockIdx.y, t = threadIdx.x;
     for (int e = t; e < J * 3; e += 256) s_j[e] = joints[b * J * 3 + e];
@@ -261,8 +262,8 @@ __global__ __launch_bounds__(256) void joint2offset_fwd_kernel(const float* __re
     const float dep = img[((int64_t)b * H + y * step) * H + x * step];       // F.interpolate nearest
     const float cu = grid_centre(x, S), cv = grid_centre(y, S);
     const bool fg = dep < 0.99f;
-    float* mb = maps + (int64_t)b * 4 * J * S * S + q;
-    const int64_t plane = (int64_t)S * S;
+    float* mb = maps + (int64_t)b * sb + q * sq;
+    const int64_t plane = sc;
     for (int j = 0; j < J; ++j) {
         const float ox = s_j[j * 3] - cu, oy = s_j[j * 3 + 1] - cv, oz = s_j[j * 3 + 2] - dep;
         const float dist = sqrtf(ox * ox + oy * oy + oz * oz + 1e-8f);
@@ -278,12 +279,13 @@ __global__ __launch_bounds__(256) void joint2offset_fwd_kernel(const float* __re
 __global__ __launch_bounds__(256) void joint2offset_bwd_kernel(const float* __restrict__ joints,
                                                                const float* __restrict__ img,
                                                                const float* __restrict__ gmaps, int J, int H, int S,
-                                                               float ks, float* __restrict__ gj) {
+                                                               float ks, float* __restrict__ gj, int64_t sb, int64_t sc,
+                                                               int64_t sq) {
     __shared__ float s_red[4][3];
     const int j = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const float jx = joints[(b * J + j) * 3], jy = joints[(b * J + j) * 3 + 1], jz = joints[(b * J + j) * 3 + 2];
-    const int64_t plane = (int64_t)S * S;
-    const float* gb = gmaps + (int64_t)b * 4 * J * plane;
+    const int64_t plane = sc;
+    const float* gb = gmaps + (int64_t)b * sb;
     const int step = H / S;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     for (int q = t; q < S * S; q += 256) {
@@ -294,8 +296,9 @@ __global__ __launch_bounds__(256) void joint2offset_bwd_kernel(const float* __re
         const float heat = (ks - dist) / ks;
         if (!(heat >= 0.f && dep < 0.99f)) continue;
         const float ux = ox / dist, uy = oy / dist, uz = oz / dist;
-        const float g0 = gb[(j * 3) * plane + q], g1 = gb[(j * 3 + 1) * plane + q], g2 = gb[(j * 3 + 2) * plane + q];
-        const float gh = gb[(3 * J + j) * plane + q];
+        const float* gq = gb + q * sq;
+        const float g0 = gq[(j * 3) * plane], g1 = gq[(j * 3 + 1) * plane], g2 = gq[(j * 3 + 2) * plane];
+        const float gh = gq[(3 * J + j) * plane];
         // d(unit)/d(off) = (I - u u^T)/dist ; d(heat)/d(off) = -u/ks ; dist = sqrt(|off|^2 + eps)
         const float gu = g0 * ux + g1 * uy + g2 * uz;
         const float k = gu + gh * dist / ks;
@@ -470,20 +473,26 @@ extern "C" int dsf_img2pcl(const float* img, const float* center, const float* m
 }
 
 extern "C" int dsf_joint2offset_forward(const float* joints, const float* img, int B, int J, int H, int S,
-                                        float kernel_size, float* maps, dsf_stream_t stream) {
+                                        float kernel_size, float* maps, const int64_t* map_strides,
+                                        dsf_stream_t stream) {
     DSF_CHECK_ARG(joints && img && maps && B >= 0 && J > 0 && J <= 64 && S > 0 && H >= S && H % S == 0);
     if (B == 0) return DSF_OK;
+    const int64_t sb = map_strides ? map_strides[0] : (int64_t)4 * J * S * S, sc = map_strides ? map_strides[1] : (int64_t)S * S,
+                  sq = map_strides ? map_strides[2] : 1;
     hipLaunchKernelGGL(joint2offset_fwd_kernel, dim3((S * S + 255) / 256, B), dim3(256), J * 3 * sizeof(float),
-                       (hipStream_t)stream, joints, img, J, H, S, kernel_size, maps);
+                       (hipStream_t)stream, joints, img, J, H, S, kernel_size, maps, sb, sc, sq);
     return dsf_launch_status();
 }
 
 extern "C" int dsf_joint2offset_backward(const float* joints, const float* img, const float* grad_maps, int B, int J,
-                                         int H, int S, float kernel_size, float* grad_joints, dsf_stream_t stream) {
+                                         int H, int S, float kernel_size, float* grad_joints, const int64_t* map_strides,
+                                         dsf_stream_t stream) {
     DSF_CHECK_ARG(joints && img && grad_maps && grad_joints && B >= 0 && J > 0 && S > 0 && H >= S && H % S == 0);
     if (B == 0) return DSF_OK;
+    const int64_t sb = map_strides ? map_strides[0] : (int64_t)4 * J * S * S, sc = map_strides ? map_strides[1] : (int64_t)S * S,
+                  sq = map_strides ? map_strides[2] : 1;
     hipLaunchKernelGGL(joint2offset_bwd_kernel, dim3(J, B), dim3(256), 0, (hipStream_t)stream, joints, img, grad_maps, J,
-                       H, S, kernel_size, grad_joints);
+                       H, S, kernel_size, grad_joints, sb, sc, sq);
     return dsf_launch_status();
 }
 

@@ -12,6 +12,11 @@ class SmoothL1Loss(torch.nn.Module):
 
     def forward(self, x, y):
         assert x.shape == y.shape
+        if x.is_cuda:
+            from .. import ops
+            fused = ops.huber_mean(x, y, 0.01, self.size_average)       # one reduction + one backward kernel
+            if fused is not None:
+                return fused
         z = (x - y).float()
         a = z.abs()
         per = torch.where(a < 0.01, 0.5 * z * z, 0.01 * (a - 0.005)).mean(dim=-1)

@@ -99,7 +99,8 @@ class _TwoBranchNet(nn.Module):
         c4 = g('layer4')(g('layer3')(g('layer2')(g('layer1')(x))))
         mano = g('mano_regress')(c4)
         feat = g('deconv_layer2')(g('deconv_layer3')(g('deconv_layer4')(c4)))
-        pix = torch.cat([head(feat) for head in g('finals')], dim=1)
+        heads = g('finals')
+        pix = nn_conv.fused_heads(feat, heads) if self._L.native else torch.cat([head(feat) for head in heads], dim=1)
         return c4, feat, pix, mano
 
     def init_weights(self):

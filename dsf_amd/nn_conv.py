@@ -80,7 +80,7 @@ def _bwd_data_s1(gy, wk, out_hw, Cin, KH, KW, pad):
     B, Cout, Ho, Wo = gy.shape
     H, W = out_hw
     if RECORD is not None:
-        RECORD.append(("fwd", B, Ho, Wo, Cout, H, W, Cin, KH, KW, 1, 1, KH - 1 - pad[0], KW - 1 - pad[1]))
+        RECORD.append(("bwd_s1", B, Ho, Wo, Cout, H, W, Cin, KH, KW, 1, 1, pad[0], pad[1]))
     gx = torch.empty((B, Cin, H, W), device=gy.device, dtype=torch.float32, memory_format=CL)
     check(L.lib().dsf_conv_igemm_bwd_data_s1(ptr_nhwc(gy), ptr(wk), ptr_nhwc(gx), I(B), I(H), I(W), I(Cout), I(Cin), I(KH), I(KW),
                                              I(pad[0]), I(pad[1]), stream_ptr()), "dsf_conv_igemm_bwd_data_s1")
@@ -181,9 +181,26 @@ class ConvTranspose2d(nn.ConvTranspose2d):
         return ConvTranspose2dFunction.apply(x, self.weight, self.bias, s[0], _pair(self.padding), _pair(self.output_padding))
 
 
+def fused_heads(x, heads):
+    """cat([h(x) for h in heads], dim=1) for parallel Conv2d heads of one geometry as ONE convolution over the
+    concatenated output channels (the 63 + 21 channel 1x1 heads of the reference's ``finals`` become one 84-channel
+    launch on the vectorised path instead of two odd-width ones plus a concatenation).  Parameters stay separate
+    modules; the merged operand is rebuilt per call (a few KB) and autograd splits its gradient."""
+    h0 = heads[0]
+    same = all(isinstance(h, Conv2d) and h.kernel_size == h0.kernel_size and h.stride == h0.stride and
+               h.padding == h0.padding and h.in_channels == h0.in_channels and (h.bias is None) == (h0.bias is None)
+               for h in heads)
+    if not (same and x.is_cuda):
+        return torch.cat([h(x) for h in heads], dim=1)
+    w = torch.cat([h.weight for h in heads], dim=0)
+    b = torch.cat([h.bias for h in heads], dim=0) if h0.bias is not None else None
+    return Conv2dFunction.apply(x, w, b, _pair(h0.stride)[0], _pair(h0.padding))
+
+
 def replay(rec, iters=3):
-    """Re-issues one recorded igemm launch on fresh buffers and returns (avg microseconds, flops).
-    flops = 2*M*N*K of the implicit GEMM, counting only taps that can hit data when dil > 1."""
+    """Re-issues one recorded igemm launch on fresh buffers and returns (avg microseconds, flops, bytes).
+    flops = 2*M*N*K of the implicit GEMM, counting only taps that can hit data when dil > 1;
+    bytes = the algorithmic traffic of the launch: each operand read once, the result written once."""
     kind, B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, dil, ph, pw = rec
     dev = torch.device("cuda")
     x = torch.randn(B, Ci, Hi, Wi, device=dev).contiguous(memory_format=CL)
@@ -191,6 +208,9 @@ def replay(rec, iters=3):
     if kind == "fwd":
         wk = torch.randn(KH, KW, Ci, Co, device=dev)
         run = lambda: _fwd(x, wk, None, (Ho, Wo), Co, KH, KW, stride, dil, (ph, pw))
+    elif kind == "bwd_s1":                                   # x plays grad_out (B,Cout=Ci,..), result is grad_in (B,Cin=Co,..)
+        wk = torch.randn(KH, KW, Co, Ci, device=dev)
+        run = lambda: _bwd_data_s1(x, wk, (Ho, Wo), Co, KH, KW, (ph, pw))
     else:
         gy = torch.randn(B, Co, Ho, Wo, device=dev).contiguous(memory_format=CL)
         run = lambda: _wrw(x, gy, KH, KW, stride, (ph, pw))
@@ -207,16 +227,19 @@ def replay(rec, iters=3):
     finally:
         RECORD = saved
     taps = KH * KW / float(dil * dil)
-    return e0.elapsed_time(e1) * 1e3 / iters, 2.0 * B * Ho * Wo * Co * Ci * taps
+    nbytes = 4.0 * (B * Hi * Wi * Ci + KH * KW * Ci * Co + B * Ho * Wo * Co)
+    return e0.elapsed_time(e1) * 1e3 / iters, 2.0 * B * Ho * Wo * Co * Ci * taps, nbytes
 
 
 def kernel_name(rec):
     kind, B, Hi, Wi, Ci, Ho, Wo, Co = rec[:8]
     dil = rec[11]
     bn = 128 if Co > 64 else 64
+    if kind == "bwd_s1":
+        return "igemm_fwd_fast_kernel<%d, true>" % bn
     if kind == "fwd":
         if dil == 1 and Ci >= 32 and Ci % 4 == 0 and Co % 4 == 0:
-            return "igemm_fwd_fast_kernel<%d>" % bn
+            return "igemm_fwd_fast_kernel<%d, false>" % bn
         if dil == 2 and Ci >= 32 and Ci % 4 == 0 and Co % 4 == 0 and Ho % 2 == 0 and Wo % 2 == 0:
             return "igemm_fwd_dil2_kernel<%d>" % bn
         return "igemm_fwd_kernel<%d, %s>" % (bn, "true" if (Ci < 32 and dil == 1) else "false")

@@ -368,18 +368,30 @@ def img2pcl(img, center, minv, cube, cam, n_sample, rand_keys=None):
     return pcl, counts
 
 
+def _map_strides(t):
+    """(batch, channel, pixel) strides of a (B,C,S,S) tensor whose pixels are uniformly strided (NCHW, channels-last,
+    or a channel slice of either) as a ctypes int64[3]; None if the layout is anything else."""
+    sb, sc, sy, sx = t.stride()
+    if sy != t.shape[-1] * sx:
+        return None
+    return (ctypes.c_int64 * 3)(sb, sc, sx)
+
+
 class Joint2Offset(Function):
-    """GFM.joint2offset (util/generateFeature.py:14-37)."""
+    """GFM.joint2offset (util/generateFeature.py:14-37).  ``channels_last``: the (B,4J,S,S) result is written
+    with channels-last strides (same values; it then concatenates / compares with convolution outputs copy-free)."""
 
     @staticmethod
-    def forward(ctx, joints, img, kernel_size, S):
+    def forward(ctx, joints, img, kernel_size, S, channels_last=False):
         joints, img = f32(joints), f32(img)
         B = img.shape[0]
         joints = joints.reshape(B, -1, 3)
         J, H = joints.shape[1], img.shape[-1]
-        maps = _empty((B, 4 * J, S, S), img)
-        check(L.lib().dsf_joint2offset_forward(ptr(joints), ptr(img), I(B), I(J), I(H), I(S), F(kernel_size), ptr(maps),
-                                               stream_ptr()), "dsf_joint2offset_forward")
+        maps = torch.empty((B, 4 * J, S, S), device=img.device, dtype=torch.float32,
+                           memory_format=torch.channels_last if channels_last else torch.contiguous_format)
+        check(L.lib().dsf_joint2offset_forward(ptr(joints), ptr(img), I(B), I(J), I(H), I(S), F(kernel_size),
+                                               ctypes.c_void_p(maps.data_ptr()), _map_strides(maps), stream_ptr()),
+              "dsf_joint2offset_forward")
         ctx.save_for_backward(joints, img)
         ctx.args = (kernel_size, S)
         return maps
@@ -391,9 +403,66 @@ class Joint2Offset(Function):
         ks, S = ctx.args
         B, J, _ = joints.shape
         gj = _empty(joints.shape, joints)
-        check(L.lib().dsf_joint2offset_backward(ptr(joints), ptr(img), ptr(f32(g)), I(B), I(J), I(img.shape[-1]), I(S),
-                                                F(ks), ptr(gj), stream_ptr()), "dsf_joint2offset_backward")
-        return gj, None, None, None
+        if g.dtype != torch.float32:
+            g = g.float()
+        st = _map_strides(g)
+        if st is None:
+            g = g.contiguous()
+            st = _map_strides(g)
+        check(L.lib().dsf_joint2offset_backward(ptr(joints), ptr(img), ctypes.c_void_p(g.data_ptr()), I(B), I(J),
+                                                I(img.shape[-1]), I(S), F(ks), ptr(gj), st, stream_ptr()),
+              "dsf_joint2offset_backward")
+        return gj, None, None, None, None
+
+
+class HuberMean(Function):
+    """SmoothL1Loss with delta (metric/losses.py:6-30) as one fused reduction + one fused backward; gradient w.r.t.
+    ``x`` only.  x and y are walked in memory order, so they must share one dense layout (arranged by the caller)."""
+
+    @staticmethod
+    def forward(ctx, x, y, delta, scale):
+        assert x.shape == y.shape and x.stride() == y.stride()
+        n = x.numel()
+        loss = torch.empty((), device=x.device, dtype=torch.float32)
+        ws = torch.empty(1024, device=x.device, dtype=torch.float32) if n > 4096 else None
+        check(L.lib().dsf_huber_mean_forward(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), I64(n), F(delta),
+                                             F(scale), ptr(loss), ptr(ws), stream_ptr()), "dsf_huber_mean_forward")
+        ctx.save_for_backward(x, y)
+        ctx.args = (delta, scale)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        delta, scale = ctx.args
+        gx = torch.empty_like(x)                      # preserve_format: same dense strides as x
+        assert gx.stride() == x.stride()
+        check(L.lib().dsf_huber_mean_backward(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()),
+                                              ptr(f32(g)), I64(x.numel()), F(delta), F(scale),
+                                              ctypes.c_void_p(gx.data_ptr()), stream_ptr()), "dsf_huber_mean_backward")
+        return gx, None, None, None
+
+
+def _dense(t):
+    return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+
+
+def huber_mean(x, y, delta=0.01, size_average=True):
+    """mean_{rows}(mean_{last dim} h(x - y)) (or the sum over rows) on the fused kernels; falls back to None when the
+    inputs are not plain fp32 GPU tensors or y needs a gradient (caller then uses the composite formula)."""
+    if not (x.is_cuda and y.is_cuda and x.dtype == torch.float32 and y.dtype == torch.float32) or y.requires_grad:
+        return None
+    if x.numel() == 0:
+        return None
+    if not _dense(x):
+        x = x.contiguous()
+    if y.stride() != x.stride():
+        y = y.contiguous(memory_format=torch.channels_last) if (x.dim() == 4 and not x.is_contiguous()) else y.contiguous()
+        if y.stride() != x.stride():              # size-1 dims can make strides ambiguous: settle on plain contiguous
+            x, y = x.contiguous(), y.contiguous()
+    scale = 1.0 / x.numel() if size_average else 1.0 / x.shape[-1]
+    return HuberMean.apply(x, y, float(delta), float(scale))
 
 
 class Offset2Joint(Function):

@@ -4,10 +4,12 @@ from .. import ops
 
 
 class GFM:
+    channels_last = True      # maps come out with channels-last strides (same values), matching the convolution outputs
+
     def joint2offset(self, joint, img, kernel_size, feature_size):
         """joint (B,J,3) crop-normalised uvd, img (B,1,H,H) -> (B,4J,S,S) unit offsets + heat
         (/root/reference/util/generateFeature.py:14-37)."""
-        return ops.Joint2Offset.apply(joint, img, float(kernel_size), int(feature_size))
+        return ops.Joint2Offset.apply(joint, img, float(kernel_size), int(feature_size), self.channels_last)
 
     def offset2joint_softmax(self, offset, depth, kernel_size, scale=30):
         """(B,4J,S,S) maps + depth -> (B,J,3) by softmax(scale*heat)-weighted voting (reference :39-59)."""
@@ -30,7 +32,7 @@ class GFM:
 
 def joint2offset(joint, img, kernel_size, feature_size):
     """module-level twin used by the backbone's stage-2 remap (/root/reference/model/backbone.py:68-91)."""
-    return ops.Joint2Offset.apply(joint, img, float(kernel_size), int(feature_size))
+    return ops.Joint2Offset.apply(joint, img, float(kernel_size), int(feature_size), True)
 
 
 def offset2joint_softmax(offset, depth, kernel_size, scale=30):

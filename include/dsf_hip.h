@@ -249,12 +249,26 @@ int dsf_img2pcl(const float* img, const float* center, const float* minv, const 
                 const dsf_camera* cam, const uint32_t* rand_keys, int B, int S, int n_sample,
                 float* pcl, int32_t* counts, uint32_t* workspace, dsf_stream_t stream);
 
+/* SmoothL1Loss with delta (metric/losses.py:6-30): loss[0] = scale * sum_i h(x_i - y_i),
+ * h(z) = 0.5 z^2 if |z| < delta else delta (|z| - delta/2); scale = 1/n for size_average (mean over the last
+ * dim, then mean over the rest), 1/last_dim for the sum variant.  x, y: n floats walked in memory order (any two
+ * tensors with identical dense strides).  workspace: >= 1024 floats (may be NULL when n <= 4096).
+ * Deterministic (fixed partials, fixed order).  backward: grad_x = grad_loss[0] * scale * h'(x - y). */
+int dsf_huber_mean_forward(const float* x, const float* y, int64_t n, float delta, float scale, float* loss,
+                           float* workspace, dsf_stream_t stream);
+int dsf_huber_mean_backward(const float* x, const float* y, const float* grad_loss, int64_t n, float delta,
+                            float scale, float* grad_x, dsf_stream_t stream);
+
 /* GFM.joint2offset (util/generateFeature.py:14-37 == model/backbone.py:68-91):
- * joints (B,J,3), img (B,1,H,H) -> maps (B,4J,S,S). */
+ * joints (B,J,3), img (B,1,H,H) -> maps (B,4J,S,S).
+ * map_strides: host array {batch, channel, pixel} strides in floats of maps / grad_maps (element (b,c,y,x) at
+ * b*s0 + c*s1 + (y*S + x)*s2), NULL = contiguous NCHW {4J*S*S, S*S, 1}; channels-last is {4J*S*S, 1, 4J}, a
+ * channel slice of a wider channels-last tensor keeps that tensor's batch / pixel strides. */
 int dsf_joint2offset_forward(const float* joints, const float* img, int B, int J, int H, int S,
-                             float kernel_size, float* maps, dsf_stream_t stream);
+                             float kernel_size, float* maps, const int64_t* map_strides, dsf_stream_t stream);
 int dsf_joint2offset_backward(const float* joints, const float* img, const float* grad_maps, int B, int J,
-                              int H, int S, float kernel_size, float* grad_joints, dsf_stream_t stream);
+                              int H, int S, float kernel_size, float* grad_joints, const int64_t* map_strides,
+                              dsf_stream_t stream);
 /* GFM.offset2joint_softmax (util/generateFeature.py:39-59 == model/backbone.py:45-65):
  * maps (B,4J,S,S), depth (B,1,H,H) -> joints (B,J,3); stats (B,J,2) = softmax max / denominator
  * kept for the backward. */

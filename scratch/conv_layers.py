@@ -17,7 +17,7 @@ for r in recs:
     agg.setdefault(r,0); agg[r]+=1
 rows=[]
 for r,n in agg.items():
-    us,fl=nn_conv.replay(r,iters=5)
+    us,fl,_=nn_conv.replay(r,iters=5)
     rows.append((us*n,n,us,fl/us/1e6,r))
 rows.sort(reverse=True)
 tot=sum(x[0] for x in rows)

@@ -1,0 +1,86 @@
+"""Fused / layout-aware variants must give the results of the plain formulations they replace."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _composite_huber(x, y, size_average=True):
+    z = (x - y).float()
+    a = z.abs()
+    per = torch.where(a < 0.01, 0.5 * z * z, 0.01 * (a - 0.005)).mean(dim=-1)
+    return per.mean() if size_average else per.sum()
+
+
+@pytest.mark.parametrize("shape,cl", [((32, 84, 16, 16), True), ((32, 84, 16, 16), False), ((7, 21, 3), False),
+                                      ((5, 779, 3), False), ((3, 1, 1, 5), True), ((2, 5000, 3), False)])
+@pytest.mark.parametrize("size_average", [True, False])
+def test_fused_huber_matches_composite_and_oracle(shape, cl, size_average):
+    from dsf_amd.metric.losses import SmoothL1Loss
+    from oracle import image_ref
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = (torch.randn(shape, device="cuda", generator=g) * 0.02)
+    y = (torch.randn(shape, device="cuda", generator=g) * 0.02)
+    if cl:
+        x = x.contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(True)
+    loss = SmoothL1Loss(size_average)(x, y)
+    (loss * 3.0).backward()
+    xr = x.detach().clone().requires_grad_(True)
+    ref = _composite_huber(xr, y, size_average)
+    (ref * 3.0).backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 2e-6 * abs(float(ref.detach())) + 1e-12
+    assert torch.allclose(x.grad, xr.grad, rtol=1e-5, atol=1e-12)
+    assert x.grad.stride() == x.stride()
+    if size_average:
+        want = float(image_ref.huber(x.detach().cpu(), y.cpu()))
+        assert abs(float(loss) - want) <= 2e-6 * abs(want) + 1e-12
+
+
+def test_fused_huber_is_deterministic_and_falls_back_when_target_needs_grad():
+    from dsf_amd.metric.losses import SmoothL1Loss
+    x = torch.randn(32, 84, 64, 64, device="cuda") * 0.02
+    y = torch.randn(32, 84, 64, 64, device="cuda") * 0.02
+    a, b = SmoothL1Loss()(x, y), SmoothL1Loss()(x, y)
+    assert torch.equal(a, b)
+    yg = y.clone().requires_grad_(True)
+    l = SmoothL1Loss()(x, yg)
+    l.backward()
+    assert yg.grad is not None and torch.isfinite(yg.grad).all()
+
+
+def test_joint2offset_channels_last_output_and_strided_gradient():
+    from dsf_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(9)
+    B, J, S = 6, 21, 64
+    joints = (torch.rand(B, J, 3, device="cuda", generator=g) * 1.6 - 0.8).requires_grad_(True)
+    img = torch.rand(B, 1, 128, 128, device="cuda", generator=g) * 2 - 1
+    img = torch.where(img > 0.3, torch.ones_like(img), img)
+    a = ops.Joint2Offset.apply(joints, img, 0.8, S, False)
+    b = ops.Joint2Offset.apply(joints, img, 0.8, S, True)
+    assert a.is_contiguous() and b.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(a, b)
+    # gradient arriving as a channel slice of a wider channels-last tensor (the stage-2 fusion input)
+    wide = torch.randn(B, 40 + 4 * J, S, S, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    gslice = wide[:, 40:]
+    ga, = torch.autograd.grad(a, joints, gslice.contiguous(), retain_graph=True)
+    gb, = torch.autograd.grad(b, joints, gslice)
+    assert torch.equal(ga, gb)
+
+
+def test_fused_heads_equal_separate_heads():
+    from dsf_amd import nn_conv
+    torch.manual_seed(3)
+    heads = torch.nn.ModuleList([nn_conv.Conv2d(256, 63, 1), nn_conv.Conv2d(256, 21, 1)]).cuda()
+    x = torch.randn(4, 256, 32, 32, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = nn_conv.fused_heads(x, heads)
+    y2 = torch.cat([h(x) for h in heads], dim=1)
+    assert y.shape == (4, 84, 32, 32)
+    assert torch.allclose(y, y2, rtol=1e-5, atol=1e-5)
+    gy = torch.randn_like(y)
+    params = [heads[0].weight, heads[0].bias, heads[1].weight, heads[1].bias]
+    g1 = torch.autograd.grad(y, [x] + params, gy)
+    g2 = torch.autograd.grad(y2, [x] + params, gy)
+    for a, b in zip(g1, g2):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))
