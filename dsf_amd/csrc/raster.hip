@@ -445,28 +445,11 @@ __global__ __launch_bounds__(256) void render_crop_fwd_kernel(const float* __res
         const int row_ry = __shfl(valid ? ry : -1, lane & 56, 64), row_ok = __shfl((int)valid, lane & 56, 64);
         const bool sep_lane = valid ? (rx == col_rx && ry == row_ry && col_ok && row_ok) : !(col_ok && row_ok);
         bool separable = __all(sep_lane);
-        // candidate count first (tiles with more than CAND_CAP candidates take the pixel-parallel path)
-        int n_total = 0;
-        if (separable) {
-            for (int base = 0; base < f_end; base += 64) {
-                const int fme = base + lane;
-                bool hit = false;
-                if (fme < F) {
-                    const uint2 box = s_box[fme];
-                    const int xlo = (int)(box.x & 0xFFFF), xhi = (int)(box.x >> 16), ylo = (int)(box.y & 0xFFFF), yhi = (int)(box.y >> 16);
-                    hit = xlo <= xhi && xlo <= t_x1 && xhi >= t_x0 && ylo <= t_y1 && yhi >= t_y0;
-                }
-                const unsigned long long mask = __ballot(hit);
-                if (hit && n_total + __popcll(mask & ((1ull << lane) - 1ull)) < CAND_CAP)
-                    s_cand[wave][n_total + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)fme;
-                n_total += __popcll(mask);
-            }
-            if (n_total > CAND_CAP) separable = false;
-        }
-
-        if (separable && n_total > 0) {
-            // ---- face-parallel path: one lane per candidate face, each lane walks only the tile pixels inside
-            //      its face's raster bbox and merges (z, face) keys with 64-bit LDS atomic min ----
+        if (separable && f_end > 0) {
+            // ---- face-parallel path: candidates (face bbox meets the tile's raster bbox) are compacted CAND_CAP at a
+            //      time; one lane per candidate face walks only the tile pixels inside its face's raster bbox and merges
+            //      (z, face) keys with 64-bit LDS atomic min.  Any number of candidates is handled in rounds, so a mesh
+            //      that collapses into one tile (early training: a hand a few pixels wide) stays on this path. ----
             unsigned long long* keys = s_key[wave];
             keys[lane] = ~0ull;
             if (lane < 8) {
@@ -477,56 +460,71 @@ __global__ __launch_bounds__(256) void render_crop_fwd_kernel(const float* __res
                 s_rowry[wave][lane >> 3] = (short)(row_ok ? ry : -1);                    // lane 8i: row i, column 0
                 s_rowy[wave][lane >> 3] = yf;
             }
-            const int n_cand = n_total;
-            __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): the wave's own LDS writes have landed
-            __builtin_amdgcn_wave_barrier();
-            for (int c0 = 0; c0 < n_cand; c0 += 64) {
-                if (c0 + lane < n_cand) {
-                    const int f = s_cand[wave][c0 + lane];
-                    const uint2 box = s_box[f];
-                    const int xlo = (int)(box.x & 0xFFFF), xhi = (int)(box.x >> 16), ylo = (int)(box.y & 0xFFFF), yhi = (int)(box.y >> 16);
-                    // pixel sub-rectangle [i0,i1] x [j0,j1] of the tile inside the face's raster bbox
-                    int j0 = 8, j1 = -1, i0 = 8, i1 = -1;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int cx = s_colrx[wave][q], cy = s_rowry[wave][q];
-                        if (cx >= xlo && cx <= xhi) { j0 = min(j0, q); j1 = max(j1, q); }
-                        if (cy >= ylo && cy <= yhi) { i0 = min(i0, q); i1 = max(i1, q); }
+            int base = 0;
+            while (base < f_end) {
+                int n_cand = 0;
+                for (; base < f_end && n_cand <= CAND_CAP - 64; base += 64) {
+                    const int fme = base + lane;
+                    bool hit = false;
+                    if (fme < F) {
+                        const uint2 box = s_box[fme];
+                        const int xlo = (int)(box.x & 0xFFFF), xhi = (int)(box.x >> 16), ylo = (int)(box.y & 0xFFFF), yhi = (int)(box.y >> 16);
+                        hit = xlo <= xhi && xlo <= t_x1 && xhi >= t_x0 && ylo <= t_y1 && yhi >= t_y0;
                     }
-                    if (j0 <= j1 && i0 <= i1) {
-                        const uint2 fi = s_fidx[f];
-                        const int a = (int)(fi.x & 0xFFFF) * 3, c1 = (int)(fi.x >> 16) * 3, c2 = (int)fi.y * 3;
-                        const float x0 = s_pv[a], y0 = s_pv[a + 1], z0 = s_pv[a + 2];
-                        const float x1 = s_pv[c1], y1 = s_pv[c1 + 1], z1 = s_pv[c1 + 2];
-                        const float x2 = s_pv[c2], y2 = s_pv[c2 + 1], z2 = s_pv[c2 + 2];
-                        const float xmin = min3(x0, x1, x2), xmax = max3(x0, x1, x2);
-                        const float ymin = min3(y0, y1, y2), ymax = max3(y0, y1, y2);
-                        const float area = edge_fn(x2, y2, x0, y0, x1, y1) + kEps;
-                        for (int pi = i0; pi <= i1; ++pi) {
-                            const float py = s_rowy[wave][pi];
-                            if (s_rowry[wave][pi] < 0 || py > ymax || py < ymin) continue;
-                            for (int pj = j0; pj <= j1; ++pj) {
-                                const float px = s_colx[wave][pj];
-                                if (s_colrx[wave][pj] < 0 || px > xmax || px < xmin) continue;
-                                const float e0 = edge_fn(px, py, x1, y1, x2, y2);
-                                const float e1 = edge_fn(px, py, x2, y2, x0, y0);
-                                const float e2 = edge_fn(px, py, x0, y0, x1, y1);
-                                if (area > 0.0f) { if (!(e0 > 0.0f && e1 > 0.0f && e2 > 0.0f)) continue; }
-                                else if (area < 0.0f) { if (!(e0 < 0.0f && e1 < 0.0f && e2 < 0.0f)) continue; }
-                                const float w0 = e0 / area, w1 = e1 / area, w2 = e2 / area;
-                                const float pz = w0 * z0 + w1 * z1 + w2 * z2;
-                                if (pz < 0.0f) continue;
-                                if (!(w0 > 0.0f && w1 > 0.0f && w2 > 0.0f)) continue;
-                                // (z bits, face) ordered lexicographically == strict < on z with lowest-face ties
-                                const unsigned long long key = ((unsigned long long)__float_as_uint(pz + 0.0f) << 32) | (unsigned)f;
-                                atomicMin(&keys[pi * 8 + pj], key);
+                    const unsigned long long mask = __ballot(hit);
+                    if (hit) s_cand[wave][n_cand + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)fme;
+                    n_cand += __popcll(mask);
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): the wave's own LDS writes have landed
+                __builtin_amdgcn_wave_barrier();
+                for (int c0 = 0; c0 < n_cand; c0 += 64) {
+                    if (c0 + lane < n_cand) {
+                        const int f = s_cand[wave][c0 + lane];
+                        const uint2 box = s_box[f];
+                        const int xlo = (int)(box.x & 0xFFFF), xhi = (int)(box.x >> 16), ylo = (int)(box.y & 0xFFFF), yhi = (int)(box.y >> 16);
+                        // pixel sub-rectangle [i0,i1] x [j0,j1] of the tile inside the face's raster bbox
+                        int j0 = 8, j1 = -1, i0 = 8, i1 = -1;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int cx = s_colrx[wave][q], cy = s_rowry[wave][q];
+                            if (cx >= xlo && cx <= xhi) { j0 = min(j0, q); j1 = max(j1, q); }
+                            if (cy >= ylo && cy <= yhi) { i0 = min(i0, q); i1 = max(i1, q); }
+                        }
+                        if (j0 <= j1 && i0 <= i1) {
+                            const uint2 fi = s_fidx[f];
+                            const int a = (int)(fi.x & 0xFFFF) * 3, c1 = (int)(fi.x >> 16) * 3, c2 = (int)fi.y * 3;
+                            const float x0 = s_pv[a], y0 = s_pv[a + 1], z0 = s_pv[a + 2];
+                            const float x1 = s_pv[c1], y1 = s_pv[c1 + 1], z1 = s_pv[c1 + 2];
+                            const float x2 = s_pv[c2], y2 = s_pv[c2 + 1], z2 = s_pv[c2 + 2];
+                            const float xmin = min3(x0, x1, x2), xmax = max3(x0, x1, x2);
+                            const float ymin = min3(y0, y1, y2), ymax = max3(y0, y1, y2);
+                            const float area = edge_fn(x2, y2, x0, y0, x1, y1) + kEps;
+                            for (int pi = i0; pi <= i1; ++pi) {
+                                const float py = s_rowy[wave][pi];
+                                if (s_rowry[wave][pi] < 0 || py > ymax || py < ymin) continue;
+                                for (int pj = j0; pj <= j1; ++pj) {
+                                    const float px = s_colx[wave][pj];
+                                    if (s_colrx[wave][pj] < 0 || px > xmax || px < xmin) continue;
+                                    const float e0 = edge_fn(px, py, x1, y1, x2, y2);
+                                    const float e1 = edge_fn(px, py, x2, y2, x0, y0);
+                                    const float e2 = edge_fn(px, py, x0, y0, x1, y1);
+                                    if (area > 0.0f) { if (!(e0 > 0.0f && e1 > 0.0f && e2 > 0.0f)) continue; }
+                                    else if (area < 0.0f) { if (!(e0 < 0.0f && e1 < 0.0f && e2 < 0.0f)) continue; }
+                                    const float w0 = e0 / area, w1 = e1 / area, w2 = e2 / area;
+                                    const float pz = w0 * z0 + w1 * z1 + w2 * z2;
+                                    if (pz < 0.0f) continue;
+                                    if (!(w0 > 0.0f && w1 > 0.0f && w2 > 0.0f)) continue;
+                                    // (z bits, face) ordered lexicographically == strict < on z with lowest-face ties
+                                    const unsigned long long key = ((unsigned long long)__float_as_uint(pz + 0.0f) << 32) | (unsigned)f;
+                                    atomicMin(&keys[pi * 8 + pj], key);
+                                }
                             }
                         }
                     }
                 }
+                __builtin_amdgcn_s_waitcnt(0xc07f);               // this round's reads of s_cand are done before it is refilled
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
             const unsigned long long k = keys[lane];
             if (k != ~0ull) { bz = __uint_as_float((unsigned)(k >> 32)); bf = (int)(k & 0xFFFFFFFFu); }
         } else if (!separable) {

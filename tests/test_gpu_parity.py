@@ -221,6 +221,28 @@ def test_crop_render_bit_exact_vs_oracle_chain(golden, mano, render):
     assert np.array_equal(N(img), exp_img)         # same pixels selected, same depth bits
 
 
+def test_crop_render_collapsed_and_oversized_meshes_bit_exact(golden, mano, render):
+    """Early-training predictions: a hand a few pixels wide (every face in one or two tiles -> thousands of
+    candidates per tile, handled in rounds) and a hand larger than the crop."""
+    from dsf_amd import ops
+    B = 6
+    _, c, cube = _world_verts(mano, B, 61)
+    P = T(_params(B, 61))
+    v, _ = mano.get_mano_vertices(P[:, :3], P[:, 3:48], P[:, 48:58], P[:, 58:62], 1 / 125)
+    scale = T(np.array([0.02, 0.05, 0.004, 0.3, 2.5, 4.0], dtype=np.float32)).view(B, 1, 1)
+    v = (v - v.mean(1, keepdim=True)) * scale
+    verts = (v * T(cube).unsqueeze(1) / 2 + T(c).unsqueeze(1)).contiguous()
+    c2, M, _, _ = ops.crop_setup(T(c), T(cube), render.cam, 128)
+    Minv = torch.inverse(M.cpu())
+    img, p2f = ops.RenderCropFunction.apply(verts, mano.faces_i32, Minv.cuda(), render.resize_rowmap, c2[:, 2].contiguous(),
+                                            T(cube)[:, 2].contiguous(), render.cam, 640, 128)
+    rowmap = golden["resize_rowmap"].astype(np.int64)
+    exp_img, exp_f, _, _ = _oracle_crop(N(verts), N(mano.faces_i32), Minv.numpy(), rowmap, N(c2)[:, 2], cube[:, 2])
+    assert (exp_f[:3] >= 0).sum() > 0 and (exp_f[4:] >= 0).mean() > 0.3
+    assert np.array_equal(N(p2f), exp_f)
+    assert np.array_equal(N(img), exp_img)
+
+
 def test_crop_render_matches_golden_warp_maps(golden, mano, render):
     """Feed the reference's own torch.inverse(M) (golden) and check that the pixels the kernel reads
     are the ones the reference's warpPerspective read (golden warp_srcidx)."""
