@@ -283,14 +283,18 @@ __device__ __forceinline__ int xcd_contiguous(int bid, int total) {
     return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
 }
 
-// One 32-deep chunk of the block GEMM from one LDS stage: 16 k-steps x (TM x TN) MFMAs per wave.
-template <int BN, int TM, int TN>
+// LDS column swizzle of k-row k: spreads the k-quads a 32-lane store group touches over the 32 banks
+template <int BKT>
+__device__ __forceinline__ int lds_swz(int k) { return BKT == 32 ? (k & 28) : ((k & 12) << 1); }
+
+// One BKT-deep chunk of the block GEMM from one LDS stage: BKT/2 k-steps x (TM x TN) MFMAs per wave.
+template <int BN, int TM, int TN, int BKT, bool SWZ = true>
 __device__ __forceinline__ void mma_chunk(const float* __restrict__ Asb, const float* __restrict__ Bsb, int arow, int bcol,
                                           int lane, f32x16 (&acc)[TM][TN]) {
     const int h = lane >> 5, l31 = lane & 31;
     float af[2][TM], bf[2][TN];
     auto frag = [&](int kk, float* a, float* b) {
-        const int k = kk + h, sw = l31 ^ (kk & 28);
+        const int k = kk + h, sw = SWZ ? (l31 ^ lds_swz<BKT>(kk)) : l31;       // kk is even: swz(kk + h) == swz(kk)
 #pragma unroll
         for (int i = 0; i < TM; ++i) a[i] = Asb[k * BM + arow + i * 32 + sw];
 #pragma unroll
@@ -298,8 +302,8 @@ __device__ __forceinline__ void mma_chunk(const float* __restrict__ Asb, const f
     };
     frag(0, af[0], bf[0]);
 #pragma unroll
-    for (int s = 0; s < BK / 2; ++s) {
-        if (s + 1 < BK / 2) frag(2 * (s + 1), af[(s + 1) & 1], bf[(s + 1) & 1]);
+    for (int s = 0; s < BKT / 2; ++s) {
+        if (s + 1 < BKT / 2) frag(2 * (s + 1), af[(s + 1) & 1], bf[(s + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);           // keep the next step's LDS reads ahead of this step's MFMAs
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -311,17 +315,22 @@ __device__ __forceinline__ void mma_chunk(const float* __restrict__ Asb, const f
 
 // WT = true: W is the FORWARD operand [KH][KW][N][Kc] of the same layer (i.e. this launch is the backward-data pass of
 // a stride-1 convolution): taps are read flipped and the B tile transposed, so no re-laid copy of the weights is needed.
-template <int BN, bool WT>
+// BKT: K depth of one pipeline stage.  32: two 32 KiB stages (BN = 128), 2 workgroups per CU.  16: two 16 KiB stages,
+// 4-5 workgroups per CU -- twice the barriers per FLOP but twice the waves to cover them.
+template <int BN, bool WT, int BKT>
 __global__ __launch_bounds__(256) void igemm_fwd_fast_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                              const float* __restrict__ bias, float* __restrict__ Y,
                                                              ConvP p, int m_tiles, int n_tiles, int k_splits,
                                                              uint32_t x_bytes, uint32_t w_bytes) {
     constexpr int WM = (BN == 128) ? 64 : 32;
     constexpr int TM = WM / 32, TN = 2;
-    constexpr int B4 = BN / 4, BROWS = 256 / B4, BPASS = BK / BROWS;
-    constexpr int WTPASS = BN / 32;                  // WT: thread -> column (t>>3) + 32 i, 4 consecutive k
-    __shared__ float As[2][BK * BM];
-    __shared__ float Bs[2][BK * BN];
+    constexpr int KQ = BKT / 4;                      // k-quads per tile row
+    constexpr int AROWS = 256 / KQ, APASS = BM / AROWS;          // transposing loader: thread -> (row, k-quad)
+    constexpr int B4 = BN / 4, BROWS = 256 / B4, BPASS = BKT / BROWS;
+    constexpr int WTPASS = BN / AROWS;               // WT: thread -> (column, k-quad)
+    static_assert(APASS >= 1 && BPASS >= 1 && WTPASS >= 1, "tile / thread mapping");
+    __shared__ float As[2][BKT * BM];
+    __shared__ float Bs[2][BKT * BN];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = (BN == 128) ? (wave >> 1) : wave, wn = (BN == 128) ? (wave & 1) : 0;
     int tile = xcd_contiguous(blockIdx.x, m_tiles * n_tiles * k_splits);
@@ -331,11 +340,11 @@ __global__ __launch_bounds__(256) void igemm_fwd_fast_kernel(const float* __rest
     const int M = p.B * p.Ho * p.Wo;
     const __amdgpu_buffer_rsrc_t xbuf = dsf_buffer(X, x_bytes), wbuf = dsf_buffer(W, w_bytes);
 
-    const int a_k4 = (t & 7) * 4, a_r = t >> 3;
-    int a_base[4], a_iy[4], a_ix[4];
+    const int a_k4 = (t % KQ) * 4, a_r = t / KQ;
+    int a_base[APASS], a_iy[APASS], a_ix[APASS];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + a_r + 32 * i;
+    for (int i = 0; i < APASS; ++i) {
+        const int m = m0 + a_r + AROWS * i;
         const bool ok = m < M;
         const int mm = ok ? m : 0;
         const int ox = mm % p.Wo, q = mm / p.Wo, oy = q % p.Ho, b = q / p.Ho;
@@ -354,20 +363,20 @@ __global__ __launch_bounds__(256) void igemm_fwd_fast_kernel(const float* __rest
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int chunks_per_tap = (p.Ci + BK - 1) / BK;
+    const int chunks_per_tap = (p.Ci + BKT - 1) / BKT;
     const int n_chunks = p.KH * p.KW * chunks_per_tap;
     const int per_split = (n_chunks + k_splits - 1) / k_splits;
     const int chunk_lo = ks * per_split, chunk_hi = min(n_chunks, chunk_lo + per_split);
 
-    float4 ra[4], rb[WT ? WTPASS : BPASS];
+    float4 ra[APASS], rb[WT ? WTPASS : BPASS];
     // wave-uniform walk state of the chunk being loaded
-    int l_tap = chunk_lo / chunks_per_tap, l_c0 = (chunk_lo % chunks_per_tap) * BK;
+    int l_tap = chunk_lo / chunks_per_tap, l_c0 = (chunk_lo % chunks_per_tap) * BKT;
     int l_kh = l_tap / p.KW, l_kw = l_tap % p.KW;
     auto load_next = [&]() {
         const int tap_off = (l_kh * p.Wi + l_kw) * p.Ci + l_c0;
         const bool c_ok = l_c0 + a_k4 < p.Ci;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < APASS; ++i) {
             const bool ok = c_ok && (unsigned)(a_iy[i] + l_kh) < (unsigned)p.Hi && (unsigned)(a_ix[i] + l_kw) < (unsigned)p.Wi;
             ra[i] = dsf_buffer_load4(xbuf, ok ? (uint32_t)(a_base[i] + tap_off) * 4u : OOB);
         }
@@ -375,7 +384,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_fast_kernel(const float* __rest
             const int tapf = (p.KH - 1 - l_kh) * p.KW + (p.KW - 1 - l_kw);
 #pragma unroll
             for (int i = 0; i < WTPASS; ++i) {
-                const int n = n0 + a_r + 32 * i;
+                const int n = n0 + a_r + AROWS * i;
                 const bool ok = c_ok && n < p.Co;
                 rb[i] = dsf_buffer_load4(wbuf, ok ? (uint32_t)((tapf * p.Co + n) * p.Ci + l_c0 + a_k4) * 4u : OOB);
             }
@@ -389,7 +398,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_fast_kernel(const float* __rest
             }
         }
         // advance (scalar)
-        l_c0 += BK;
+        l_c0 += BKT;
         if (l_c0 >= p.Ci) {
             l_c0 = 0; ++l_tap; ++l_kw;
             if (l_kw == p.KW) { l_kw = 0; ++l_kh; }
@@ -398,16 +407,17 @@ __global__ __launch_bounds__(256) void igemm_fwd_fast_kernel(const float* __rest
     auto stage = [&](int buf) {                                     // registers -> LDS stage `buf` (k-major, swizzled)
         float* Asb = As[buf];
         float* Bsb = Bs[buf];
+        const int swz = lds_swz<BKT>(a_k4);                         // same for the 4 k-rows of the quad
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = (a_r + 32 * i) ^ a_k4;                    // (a_k4 + j) & 28 == a_k4
+        for (int i = 0; i < APASS; ++i) {
+            const int r = (a_r + AROWS * i) ^ swz;
             Asb[(a_k4 + 0) * BM + r] = ra[i].x; Asb[(a_k4 + 1) * BM + r] = ra[i].y;
             Asb[(a_k4 + 2) * BM + r] = ra[i].z; Asb[(a_k4 + 3) * BM + r] = ra[i].w;
         }
         if (WT) {
 #pragma unroll
             for (int i = 0; i < WTPASS; ++i) {
-                const int c = (a_r + 32 * i) ^ a_k4;
+                const int c = (a_r + AROWS * i) ^ swz;
                 Bsb[(a_k4 + 0) * BN + c] = rb[i].x; Bsb[(a_k4 + 1) * BN + c] = rb[i].y;
                 Bsb[(a_k4 + 2) * BN + c] = rb[i].z; Bsb[(a_k4 + 3) * BN + c] = rb[i].w;
             }
@@ -415,7 +425,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_fast_kernel(const float* __rest
 #pragma unroll
             for (int i = 0; i < BPASS; ++i) {
                 const int kk = b_row + BROWS * i;
-                *reinterpret_cast<float4*>(&Bsb[kk * BN + (b_n4 ^ (kk & 28))]) = rb[i];
+                *reinterpret_cast<float4*>(&Bsb[kk * BN + (b_n4 ^ lds_swz<BKT>(kk))]) = rb[i];
             }
         }
     };
@@ -429,7 +439,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_fast_kernel(const float* __rest
         const int buf = (chunk - chunk_lo) & 1;
         const bool more = chunk + 1 < chunk_hi;
         if (more) load_next();
-        mma_chunk<BN, TM, TN>(As[buf], Bs[buf], wm * WM, wn * 64, lane, acc);
+        mma_chunk<BN, TM, TN, BKT>(As[buf], Bs[buf], wm * WM, wn * 64, lane, acc);
         if (more) stage(buf ^ 1);
         __syncthreads();
     }
@@ -736,25 +746,31 @@ __global__ __launch_bounds__(256) void igemm_wrw_kernel(const float* __restrict_
 // branches; otherwise identical to igemm_wrw_kernel.
 __device__ __forceinline__ uint32_t fast_div(uint32_t n, uint64_t magic) { return (uint32_t)(((uint64_t)n * magic) >> 40); }
 
-template <int BN>
+// Pipelined like igemm_fwd_fast_kernel (buffer loads with hardware zero fill, two LDS stages and one barrier per
+// BKT-pixel chunk, register-double-buffered MFMA fragments); both tiles are stored as loaded (pixel-major rows of 128
+// k / BN n values), so the float4 LDS stores and the 32-wide fragment reads are conflict-free without a swizzle.
+template <int BN, int BKT>
 __global__ __launch_bounds__(256) void igemm_wrw_fast_kernel(const float* __restrict__ X, const float* __restrict__ dY,
                                                              float* __restrict__ dW, ConvP p, int k_tiles, int n_tiles,
-                                                             int m_per_split, uint64_t magic_wo, uint64_t magic_ho) {
-    constexpr int BKT = 128;
-    constexpr int LDA = BKT + 4, LDB = BN + 4;
+                                                             int n_splits, int m_per_split, uint64_t magic_wo,
+                                                             uint64_t magic_ho, uint32_t x_bytes, uint32_t dy_bytes) {
+    constexpr int KT = 128;                          // k values (tap, channel) per tile = BM of the block GEMM
     constexpr int WM = (BN == 128) ? 64 : 32;
     constexpr int TM = WM / 32, TN = 2;
-    constexpr int B4 = BN / 4, BROWS = 256 / B4, BPASS = BK / BROWS;
-    __shared__ float As[BK * LDA];
-    __shared__ float Bs[BK * LDB];
+    constexpr int APASS = BKT / 8;                   // thread -> (pixel row t >> 5 (+ 8 i), k-quad t & 31)
+    constexpr int B4 = BN / 4, BROWS = 256 / B4, BPASS = BKT / BROWS;
+    static_assert(KT == BM && APASS >= 1 && BPASS >= 1, "tile / thread mapping");
+    __shared__ float As[2][BKT * KT];
+    __shared__ float Bs[2][BKT * BN];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = (BN == 128) ? (wave >> 1) : wave, wn = (BN == 128) ? (wave & 1) : 0;
-    int bid = blockIdx.x;
-    const int k_tile = bid % k_tiles; bid /= k_tiles;
-    const int n_tile = bid % n_tiles; const int split = bid / n_tiles;
-    const int k0 = k_tile * BKT, n0 = n_tile * BN;
+    int tile = xcd_contiguous(blockIdx.x, k_tiles * n_tiles * n_splits);
+    const int k_tile = tile % k_tiles; tile /= k_tiles;
+    const int n_tile = tile % n_tiles; const int split = tile / n_tiles;
+    const int k0 = k_tile * KT, n0 = n_tile * BN;
     const int M = p.B * p.Ho * p.Wo, K = p.KH * p.KW * p.Ci;
     const int m_begin = split * m_per_split, m_end = min(M, m_begin + m_per_split);
+    const __amdgpu_buffer_rsrc_t xbuf = dsf_buffer(X, x_bytes), ybuf = dsf_buffer(dY, dy_bytes);
 
     const int a_k = k0 + (t & 31) * 4;
     const bool a_kok = a_k < K;
@@ -771,10 +787,10 @@ __global__ __launch_bounds__(256) void igemm_wrw_fast_kernel(const float* __rest
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[4], rb[BPASS];
+    float4 ra[APASS], rb[BPASS];
     auto load_chunk = [&](int mc) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < APASS; ++i) {
             const int m = mc + (t >> 5) + 8 * i;
             const uint32_t mm = (uint32_t)min(m, M - 1);
             const uint32_t q = fast_div(mm, magic_wo);
@@ -783,42 +799,34 @@ __global__ __launch_bounds__(256) void igemm_wrw_fast_kernel(const float* __rest
             const int oy = (int)(q - b * (uint32_t)p.Ho);
             const int iy = oy * p.stride + a_kh - p.pad_h, ix = ox * p.stride + a_kw - p.pad_w;
             const bool ok = a_kok && m < m_end && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-            const int off = ok ? (((int)b * p.Hi + iy) * p.Wi + ix) * p.Ci + a_c : 0;
-            const float4 v = *reinterpret_cast<const float4*>(X + off);
-            ra[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+            ra[i] = dsf_buffer_load4(xbuf, ok ? (uint32_t)((((int)b * p.Hi + iy) * p.Wi + ix) * p.Ci + a_c) * 4u : OOB);
         }
 #pragma unroll
         for (int i = 0; i < BPASS; ++i) {
             const int m = mc + b_row + BROWS * i;
             const bool ok = b_nok && m < m_end;
-            const int off = ok ? m * p.Co + n0 + b_n4 : 0;
-            const float4 v = *reinterpret_cast<const float4*>(dY + off);
-            rb[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+            rb[i] = dsf_buffer_load4(ybuf, ok ? (uint32_t)(m * p.Co + n0 + b_n4) * 4u : OOB);
         }
     };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) *reinterpret_cast<float4*>(&As[buf][((t >> 5) + 8 * i) * KT + (t & 31) * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i) *reinterpret_cast<float4*>(&Bs[buf][(b_row + BROWS * i) * BN + b_n4]) = rb[i];
+    };
 
-    if (m_begin < m_end) load_chunk(m_begin);
-    for (int mc = m_begin; mc < m_end; mc += BK) {
+    if (m_begin < m_end) {
+        load_chunk(m_begin);
+        stage(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int mc = m_begin; mc < m_end; mc += BKT, buf ^= 1) {
+        const bool more = mc + BKT < m_end;
+        if (more) load_chunk(mc + BKT);
+        mma_chunk<BN, TM, TN, BKT, false>(As[buf], Bs[buf], wm * WM, wn * 64, lane, acc);
+        if (more) stage(buf ^ 1);
         __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&As[((t >> 5) + 8 * i) * LDA + (t & 31) * 4]) = ra[i];
-#pragma unroll
-        for (int i = 0; i < BPASS; ++i) *reinterpret_cast<float4*>(&Bs[(b_row + BROWS * i) * LDB + b_n4]) = rb[i];
-        __syncthreads();
-        if (mc + BK < m_end) load_chunk(mc + BK);
-#pragma unroll 4
-        for (int kk = 0; kk < BK; kk += 2) {
-            const int r = kk + (lane >> 5);
-            float a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[r * LDA + wm * WM + i * 32 + (lane & 31)];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[r * LDB + wn * 64 + j * 32 + (lane & 31)];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -852,10 +860,17 @@ static int conv_forward_impl(const float* X, const float* W, const float* bias, 
     const int perm = (dil > 1 && Ho % dil == 0 && Wo % dil == 0) ? 1 : 0;
     const int n_chunks = flat ? (KH * KW * Ci + BK - 1) / BK : KH * KW * ((Ci + BK - 1) / BK);
     const int live_chunks = perm ? n_chunks / (dil * dil) : n_chunks;
+    const int64_t x_bytes = (int64_t)B * Hi * Wi * Ci * 4, w_bytes = (int64_t)KH * KW * Ci * Co * 4;
+    const bool fast = dil == 1 && !flat && (Ci & 3) == 0 && (Co & 3) == 0 && x_bytes < 0xFFFFFFF0ll && w_bytes < 0xFFFFFFF0ll;
+    static const int bk_env = [] { const char* e = getenv("DSF_CONV_BK"); return e ? atoi(e) : 0; }();
+    // pipeline stage depth of the fast kernel: 16 (4-5 workgroups per CU) once there are >= 4 tiles per CU, 32 (2 per
+    // CU, half the barriers, and half the split-K partials for small-M layers) below that.  Measured per layer on
+    // MI355X (B=32 ResNet-18 shapes): 64x64 maps 124 vs 116 TFLOP/s with 16; 8x8..32x32 maps 85 vs 62 with 32.
+    const int bkt = !fast ? 32 : (bk_env == 16 || bk_env == 32) ? bk_env : (m_tiles * n_tiles >= 1024 ? 16 : 32);
     int k_splits = 1;
     if (m_tiles * n_tiles < 384) {                      // fewer tiles than ~1.5 per CU: split K to fill the chip
-        // the pipelined kernels hold 2 workgroups per CU (64 KiB of LDS each): aim at one full round of 512
-        const int slots = 512;
+        // resident workgroups per CU: 2 with 32-deep stages (64 KiB of LDS each), 4 with 16-deep ones
+        const int slots = (fast && bkt == 16) ? 1024 : 512;
         k_splits = (slots + m_tiles * n_tiles / 2) / (m_tiles * n_tiles);
         if (k_splits > live_chunks / 4) k_splits = live_chunks / 4;
         if (k_splits < 1) k_splits = 1;
@@ -863,8 +878,6 @@ static int conv_forward_impl(const float* X, const float* W, const float* bias, 
     if (k_splits > 1 &&
         hipMemsetAsync(Y, 0, sizeof(float) * (size_t)M * Co, (hipStream_t)stream) != hipSuccess) return DSF_ERR_LAUNCH;
     const dim3 grid(m_tiles * n_tiles * k_splits);
-    const int64_t x_bytes = (int64_t)B * Hi * Wi * Ci * 4, w_bytes = (int64_t)KH * KW * Ci * Co * 4;
-    const bool fast = dil == 1 && !flat && (Ci & 3) == 0 && (Co & 3) == 0 && x_bytes < 0xFFFFFFF0ll && w_bytes < 0xFFFFFFF0ll;
     const bool fast2 = dil == 2 && stride == 1 && perm && (Ci & 3) == 0 && (Co & 3) == 0 && Ci >= BK &&
                        (int64_t)B * Hi * Wi * Ci < (1ll << 31) && (int64_t)KH * KW * Ci * Co < (1ll << 31);
     if (fast2) {
@@ -878,10 +891,12 @@ static int conv_forward_impl(const float* X, const float* W, const float* bias, 
     }
     if (w_fwd_layout && !fast) return DSF_ERR_UNSUPPORTED;
     if (fast) {
-#define DSF_LAUNCH_FAST(BNv, WTv) hipLaunchKernelGGL((igemm_fwd_fast_kernel<BNv, WTv>), grid, dim3(256), 0, (hipStream_t)stream, X, W, \
-                                                    bias, Y, p, m_tiles, n_tiles, k_splits, (uint32_t)x_bytes, (uint32_t)w_bytes)
-        if (bn == 128) { if (w_fwd_layout) DSF_LAUNCH_FAST(128, true); else DSF_LAUNCH_FAST(128, false); }
-        else { if (w_fwd_layout) DSF_LAUNCH_FAST(64, true); else DSF_LAUNCH_FAST(64, false); }
+#define DSF_LAUNCH_FAST(BNv, WTv, BKv) hipLaunchKernelGGL((igemm_fwd_fast_kernel<BNv, WTv, BKv>), grid, dim3(256), 0, (hipStream_t)stream, \
+                                                         X, W, bias, Y, p, m_tiles, n_tiles, k_splits, (uint32_t)x_bytes, (uint32_t)w_bytes)
+#define DSF_LAUNCH_FAST_BK(BNv, WTv) do { if (bkt == 16) DSF_LAUNCH_FAST(BNv, WTv, 16); else DSF_LAUNCH_FAST(BNv, WTv, 32); } while (0)
+        if (bn == 128) { if (w_fwd_layout) DSF_LAUNCH_FAST_BK(128, true); else DSF_LAUNCH_FAST_BK(128, false); }
+        else { if (w_fwd_layout) DSF_LAUNCH_FAST_BK(64, true); else DSF_LAUNCH_FAST_BK(64, false); }
+#undef DSF_LAUNCH_FAST_BK
 #undef DSF_LAUNCH_FAST
         return dsf_launch_status();
     }
@@ -920,22 +935,27 @@ extern "C" int dsf_conv_igemm_wrw(const float* X, const float* dY, float* dW, in
     const int k_tiles = (K + 127) / 128;
     const int bn = (Co > 64) ? 128 : 64;
     const int n_tiles = (Co + bn - 1) / bn;
-    // split the pixel reduction so that ~1024 workgroups are in flight; at least 4 chunks per split
-    int splits = 1024 / (k_tiles * n_tiles);
+    const int64_t x_bytes = (int64_t)B * Hi * Wi * Ci * 4, dy_bytes = M * Co * 4;
+    const bool fast = (Ci & 3) == 0 && (Co & 3) == 0 && x_bytes < 0xFFFFFFF0ll && dy_bytes < 0xFFFFFFF0ll;
+    static const int bk_env = [] { const char* e = getenv("DSF_WRW_BK"); return e ? atoi(e) : 0; }();
+    // 16-pixel stages (4-5 workgroups per CU) pay off on long reductions; short ones (8x8, 16x16 maps) keep 32
+    const int bkt = !fast ? 32 : (bk_env == 16 || bk_env == 32) ? bk_env : (M >= 32768 ? 16 : 32);
+    // split the pixel reduction so that one round of resident workgroups covers the chip (4 per CU with 16-pixel
+    // stages, 2 per CU with 32-pixel ones); at least 4 chunks per split
+    int splits = (bkt == 16 ? 1024 : 512) / (k_tiles * n_tiles);
     if (splits < 1) splits = 1;
     int64_t per = (M + splits - 1) / splits;
     per = ((per + BK - 1) / BK) * BK;
     if (per < 4 * BK) per = 4 * BK;
     splits = (int)((M + per - 1) / per);
-    const bool fast = (Ci & 3) == 0 && (Co & 3) == 0 && (int64_t)B * Hi * Wi * Ci < (1ll << 31) && M * Co < (1ll << 31);
     if (fast) {
         const uint64_t mwo = ((1ull << 40) + Wo - 1) / Wo, mho = ((1ull << 40) + Ho - 1) / Ho;
-        if (bn == 128)
-            hipLaunchKernelGGL(igemm_wrw_fast_kernel<128>, dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream,
-                               X, dY, dW, p, k_tiles, n_tiles, (int)per, mwo, mho);
-        else
-            hipLaunchKernelGGL(igemm_wrw_fast_kernel<64>, dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream,
-                               X, dY, dW, p, k_tiles, n_tiles, (int)per, mwo, mho);
+#define DSF_LAUNCH_WRW(BNv, BKv) hipLaunchKernelGGL((igemm_wrw_fast_kernel<BNv, BKv>), dim3(k_tiles * n_tiles * splits), dim3(256), 0, \
+                                                   (hipStream_t)stream, X, dY, dW, p, k_tiles, n_tiles, splits, (int)per, mwo, mho,     \
+                                                   (uint32_t)x_bytes, (uint32_t)dy_bytes)
+        if (bn == 128) { if (bkt == 16) DSF_LAUNCH_WRW(128, 16); else DSF_LAUNCH_WRW(128, 32); }
+        else { if (bkt == 16) DSF_LAUNCH_WRW(64, 16); else DSF_LAUNCH_WRW(64, 32); }
+#undef DSF_LAUNCH_WRW
         return dsf_launch_status();
     }
     if (bn == 128)
