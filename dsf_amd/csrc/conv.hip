@@ -461,27 +461,31 @@ __global__ __launch_bounds__(256) void igemm_fwd_fast_kernel(const float* __rest
         }
 }
 
-// dil == 2 twin of the fast path (ConvTranspose2d forward, backward-data of stride-2 convolutions)
-template <int BN>
+// dil == 2 twin of the fast path (ConvTranspose2d forward, backward-data of stride-2 convolutions); same pipeline.
+// Transposed-convolution gather (virtual input = X upsampled by 2 with zeros, stride 1): output pixels are ordered
+// parity-class-major, so a tile shares (oy & 1, ox & 1), only KH*KW/4 taps can meet data and the others are skipped
+// tile-wide without touching memory.
+template <int BN, int BKT>
 __global__ __launch_bounds__(256) void igemm_fwd_dil2_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                              const float* __restrict__ bias, float* __restrict__ Y,
-                                                             ConvP p, int m_tiles, int n_tiles, int k_splits) {
-    constexpr int LDA = BM + 4, LDB = BN + 4;
+                                                             ConvP p, int m_tiles, int n_tiles, int k_splits,
+                                                             uint32_t x_bytes, uint32_t w_bytes) {
     constexpr int WM = (BN == 128) ? 64 : 32;
     constexpr int TM = WM / 32, TN = 2;
-    constexpr int B4 = BN / 4, BROWS = 256 / B4, BPASS = BK / BROWS;
-    __shared__ float As[BK * LDA];
-    __shared__ float Bs[BK * LDB];
+    constexpr int KQ = BKT / 4, AROWS = 256 / KQ, APASS = BM / AROWS;
+    constexpr int B4 = BN / 4, BROWS = 256 / B4, BPASS = BKT / BROWS;
+    static_assert(APASS >= 1 && BPASS >= 1, "tile / thread mapping");
+    __shared__ float As[2][BKT * BM];
+    __shared__ float Bs[2][BKT * BN];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = (BN == 128) ? (wave >> 1) : wave, wn = (BN == 128) ? (wave & 1) : 0;
-    int bid = blockIdx.x;
-    const int m_tile = bid % m_tiles; bid /= m_tiles;
-    const int n_tile = bid % n_tiles; const int ks = bid / n_tiles;
+    int tile = xcd_contiguous(blockIdx.x, m_tiles * n_tiles * k_splits);
+    const int n_tile = tile % n_tiles; tile /= n_tiles;
+    const int m_tile = tile % m_tiles; const int ks = tile / m_tiles;
     const int m0 = m_tile * BM, n0 = n_tile * BN;
     const int M = p.B * p.Ho * p.Wo;
+    const __amdgpu_buffer_rsrc_t xbuf = dsf_buffer(X, x_bytes), wbuf = dsf_buffer(W, w_bytes);
 
-    // transposed-convolution gather (virtual input = X upsampled by 2 with zeros, stride 1): output pixels are
-    // ordered parity-class-major, so a tile shares (oy & 1, ox & 1) and only KH*KW/4 taps can meet data
     const int Hq = p.Ho >> 1, Wq = p.Wo >> 1, Mc = p.B * Hq * Wq;
     auto decode = [&](int m, int& b, int& oy, int& ox) {
         const int cls = m / Mc, r = m % Mc;
@@ -493,11 +497,11 @@ __global__ __launch_bounds__(256) void igemm_fwd_dil2_kernel(const float* __rest
         const int c0 = m0 / Mc, c1 = min(m0 + BM - 1, M - 1) / Mc;
         if (c0 == c1) { tile_py = c0 >> 1; tile_px = c0 & 1; }
     }
-    const int a_k4 = (t & 7) * 4;
-    int a_base[4], a_iy[4], a_ix[4];               // a_base = b * Hi (row base), a_iy / a_ix = virtual coords of tap (0,0)
+    const int a_k4 = (t % KQ) * 4, a_r = t / KQ;
+    int a_base[APASS], a_iy[APASS], a_ix[APASS];   // a_base = b * Hi (row base), a_iy / a_ix = virtual coords of tap (0,0)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + (t >> 3) + 32 * i;
+    for (int i = 0; i < APASS; ++i) {
+        const int m = m0 + a_r + AROWS * i;
         const bool ok = m < M;
         int b, oy, ox;
         decode(ok ? m : 0, b, oy, ox);
@@ -516,14 +520,14 @@ __global__ __launch_bounds__(256) void igemm_fwd_dil2_kernel(const float* __rest
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int chunks_per_tap = (p.Ci + BK - 1) / BK;
+    const int chunks_per_tap = (p.Ci + BKT - 1) / BKT;
     const int n_chunks = p.KH * p.KW * chunks_per_tap;
     const int per_split = (n_chunks + k_splits - 1) / k_splits;
     const int chunk_lo = ks * per_split, chunk_hi = min(n_chunks, chunk_lo + per_split);
 
-    float4 ra[4], rb[BPASS];
+    float4 ra[APASS], rb[BPASS];
     // wave-uniform walk state of the chunk being loaded
-    int l_tap = chunk_lo / chunks_per_tap, l_c0 = (chunk_lo % chunks_per_tap) * BK;
+    int l_tap = chunk_lo / chunks_per_tap, l_c0 = (chunk_lo % chunks_per_tap) * BKT;
     int l_kh = l_tap / p.KW, l_kw = l_tap % p.KW;
     auto tap_dead = [&]() -> bool {                   // every row of this tile reads inserted zeros for this tap
         return tile_py >= 0 && ((((tile_py + l_kh - p.pad_h) & 1) != 0) || (((tile_px + l_kw - p.pad_w) & 1) != 0));
@@ -531,7 +535,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_dil2_kernel(const float* __rest
     int l_chunk = chunk_lo;                           // chunk index of the walk state
     auto skip_dead = [&]() {
         while (l_chunk < chunk_hi && tap_dead()) {    // jump to the first chunk of the next tap
-            l_chunk += chunks_per_tap - l_c0 / BK;
+            l_chunk += chunks_per_tap - l_c0 / BKT;
             l_c0 = 0; ++l_tap; ++l_kw;
             if (l_kw == p.KW) { l_kw = 0; ++l_kh; }
         }
@@ -540,61 +544,58 @@ __global__ __launch_bounds__(256) void igemm_fwd_dil2_kernel(const float* __rest
     auto load_next = [&]() {
         const bool c_ok = l_c0 + a_k4 < p.Ci;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < APASS; ++i) {
             const int vy = a_iy[i] + l_kh, vx = a_ix[i] + l_kw;
             const bool ok = c_ok && (unsigned)vy < (unsigned)vH && (unsigned)vx < (unsigned)vW && ((vy | vx) & 1) == 0;
-            const int off = ok ? ((a_base[i] + (vy >> 1)) * p.Wi + (vx >> 1)) * p.Ci + l_c0 + a_k4 : 0;
-            const float4 v = *reinterpret_cast<const float4*>(X + off);
-            ra[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+            ra[i] = dsf_buffer_load4(xbuf, ok ? (uint32_t)(((a_base[i] + (vy >> 1)) * p.Wi + (vx >> 1)) * p.Ci + l_c0 + a_k4) * 4u : OOB);
         }
         const int wrow = l_tap * p.Ci + l_c0;
 #pragma unroll
         for (int i = 0; i < BPASS; ++i) {
             const int kk = b_row + BROWS * i;
             const bool ok = b_nok && (l_c0 + kk < p.Ci);
-            const int off = ok ? (wrow + kk) * p.Co + n0 + b_n4 : 0;
-            const float4 v = *reinterpret_cast<const float4*>(W + off);
-            rb[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+            rb[i] = dsf_buffer_load4(wbuf, ok ? (uint32_t)((wrow + kk) * p.Co + n0 + b_n4) * 4u : OOB);
         }
         // advance (scalar)
-        l_c0 += BK; ++l_chunk;
+        l_c0 += BKT; ++l_chunk;
         if (l_c0 >= p.Ci) {
             l_c0 = 0; ++l_tap; ++l_kw;
             if (l_kw == p.KW) { l_kw = 0; ++l_kh; }
         }
         skip_dead();
     };
+    auto stage = [&](int buf) {
+        float* Asb = As[buf];
+        float* Bsb = Bs[buf];
+        const int swz = lds_swz<BKT>(a_k4);
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) {
+            const int r = (a_r + AROWS * i) ^ swz;
+            Asb[(a_k4 + 0) * BM + r] = ra[i].x; Asb[(a_k4 + 1) * BM + r] = ra[i].y;
+            Asb[(a_k4 + 2) * BM + r] = ra[i].z; Asb[(a_k4 + 3) * BM + r] = ra[i].w;
+        }
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i) {
+            const int kk = b_row + BROWS * i;
+            *reinterpret_cast<float4*>(&Bsb[kk * BN + (b_n4 ^ lds_swz<BKT>(kk))]) = rb[i];
+        }
+    };
 
     skip_dead();
     bool have = l_chunk < chunk_hi;
-    if (have) load_next();
+    if (have) {
+        load_next();
+        stage(0);
+    }
+    __syncthreads();
+    int buf = 0;
     while (have) {
+        const bool more = l_chunk < chunk_hi;
+        if (more) load_next();
+        mma_chunk<BN, TM, TN, BKT>(As[buf], Bs[buf], wm * WM, wn * 64, lane, acc);
+        if (more) stage(buf ^ 1);
         __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = (t >> 3) + 32 * i;
-            As[(a_k4 + 0) * LDA + r] = ra[i].x; As[(a_k4 + 1) * LDA + r] = ra[i].y;
-            As[(a_k4 + 2) * LDA + r] = ra[i].z; As[(a_k4 + 3) * LDA + r] = ra[i].w;
-        }
-#pragma unroll
-        for (int i = 0; i < BPASS; ++i)
-            *reinterpret_cast<float4*>(&Bs[(b_row + BROWS * i) * LDB + b_n4]) = rb[i];
-        __syncthreads();
-        have = l_chunk < chunk_hi;
-        if (have) load_next();
-#pragma unroll 4
-        for (int kk = 0; kk < BK; kk += 2) {
-            const int k = kk + (lane >> 5);
-            float a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[k * LDA + wm * WM + i * 32 + (lane & 31)];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[k * LDB + wn * 64 + j * 32 + (lane & 31)];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
+        have = more; buf ^= 1;
     }
 
 #pragma unroll
@@ -862,15 +863,18 @@ static int conv_forward_impl(const float* X, const float* W, const float* bias, 
     const int live_chunks = perm ? n_chunks / (dil * dil) : n_chunks;
     const int64_t x_bytes = (int64_t)B * Hi * Wi * Ci * 4, w_bytes = (int64_t)KH * KW * Ci * Co * 4;
     const bool fast = dil == 1 && !flat && (Ci & 3) == 0 && (Co & 3) == 0 && x_bytes < 0xFFFFFFF0ll && w_bytes < 0xFFFFFFF0ll;
+    const bool fast2 = dil == 2 && stride == 1 && perm && (Ci & 3) == 0 && (Co & 3) == 0 && Ci >= BK &&
+                       x_bytes < 0xFFFFFFF0ll && w_bytes < 0xFFFFFFF0ll;
     static const int bk_env = [] { const char* e = getenv("DSF_CONV_BK"); return e ? atoi(e) : 0; }();
     // pipeline stage depth of the fast kernel: 16 (4-5 workgroups per CU) once there are >= 4 tiles per CU, 32 (2 per
     // CU, half the barriers, and half the split-K partials for small-M layers) below that.  Measured per layer on
     // MI355X (B=32 ResNet-18 shapes): 64x64 maps 124 vs 116 TFLOP/s with 16; 8x8..32x32 maps 85 vs 62 with 32.
-    const int bkt = !fast ? 32 : (bk_env == 16 || bk_env == 32) ? bk_env : (m_tiles * n_tiles >= 1024 ? 16 : 32);
+    const int bkt = !(fast || fast2) ? 32 : (bk_env == 16 || bk_env == 32) ? bk_env
+                    : (m_tiles * n_tiles >= 1024 && !(fast2 && bn == 64) ? 16 : 32);   // (dil2, BN 64: 75 vs 102 us with 32)
     int k_splits = 1;
     if (m_tiles * n_tiles < 384) {                      // fewer tiles than ~1.5 per CU: split K to fill the chip
         // resident workgroups per CU: 2 with 32-deep stages (64 KiB of LDS each), 4 with 16-deep ones
-        const int slots = (fast && bkt == 16) ? 1024 : 512;
+        const int slots = ((fast || fast2) && bkt == 16) ? 1024 : 512;
         k_splits = (slots + m_tiles * n_tiles / 2) / (m_tiles * n_tiles);
         if (k_splits > live_chunks / 4) k_splits = live_chunks / 4;
         if (k_splits < 1) k_splits = 1;
@@ -878,15 +882,12 @@ static int conv_forward_impl(const float* X, const float* W, const float* bias, 
     if (k_splits > 1 &&
         hipMemsetAsync(Y, 0, sizeof(float) * (size_t)M * Co, (hipStream_t)stream) != hipSuccess) return DSF_ERR_LAUNCH;
     const dim3 grid(m_tiles * n_tiles * k_splits);
-    const bool fast2 = dil == 2 && stride == 1 && perm && (Ci & 3) == 0 && (Co & 3) == 0 && Ci >= BK &&
-                       (int64_t)B * Hi * Wi * Ci < (1ll << 31) && (int64_t)KH * KW * Ci * Co < (1ll << 31);
     if (fast2) {
-        if (bn == 128)
-            hipLaunchKernelGGL(igemm_fwd_dil2_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, X, W, bias, Y, p, m_tiles,
-                               n_tiles, k_splits);
-        else
-            hipLaunchKernelGGL(igemm_fwd_dil2_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, X, W, bias, Y, p, m_tiles,
-                               n_tiles, k_splits);
+#define DSF_LAUNCH_DIL2(BNv, BKv) hipLaunchKernelGGL((igemm_fwd_dil2_kernel<BNv, BKv>), grid, dim3(256), 0, (hipStream_t)stream, X, W, \
+                                                    bias, Y, p, m_tiles, n_tiles, k_splits, (uint32_t)x_bytes, (uint32_t)w_bytes)
+        if (bn == 128) { if (bkt == 16) DSF_LAUNCH_DIL2(128, 16); else DSF_LAUNCH_DIL2(128, 32); }
+        else { if (bkt == 16) DSF_LAUNCH_DIL2(64, 16); else DSF_LAUNCH_DIL2(64, 32); }
+#undef DSF_LAUNCH_DIL2
         return dsf_launch_status();
     }
     if (w_fwd_layout && !fast) return DSF_ERR_UNSUPPORTED;
