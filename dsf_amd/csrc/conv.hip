@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_fast_kernel(const float* __rest
 // Transposed-convolution gather (virtual input = X upsampled by 2 with zeros, stride 1): output pixels are ordered
 // parity-class-major, so a tile shares (oy & 1, ox & 1), only KH*KW/4 taps can meet data and the others are skipped
 // tile-wide without touching memory.
-template <int BN, int BKT>
+template <int BN, int BKT, bool WT>
 __global__ __launch_bounds__(256) void igemm_fwd_dil2_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                              const float* __restrict__ bias, float* __restrict__ Y,
                                                              ConvP p, int m_tiles, int n_tiles, int k_splits,
@@ -474,7 +474,8 @@ __global__ __launch_bounds__(256) void igemm_fwd_dil2_kernel(const float* __rest
     constexpr int TM = WM / 32, TN = 2;
     constexpr int KQ = BKT / 4, AROWS = 256 / KQ, APASS = BM / AROWS;
     constexpr int B4 = BN / 4, BROWS = 256 / B4, BPASS = BKT / BROWS;
-    static_assert(APASS >= 1 && BPASS >= 1, "tile / thread mapping");
+    constexpr int WTPASS = BN / AROWS;               // WT: thread -> (column, k-quad), as in igemm_fwd_fast_kernel
+    static_assert(APASS >= 1 && BPASS >= 1 && WTPASS >= 1, "tile / thread mapping");
     __shared__ float As[2][BKT * BM];
     __shared__ float Bs[2][BKT * BN];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -525,7 +526,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_dil2_kernel(const float* __rest
     const int per_split = (n_chunks + k_splits - 1) / k_splits;
     const int chunk_lo = ks * per_split, chunk_hi = min(n_chunks, chunk_lo + per_split);
 
-    float4 ra[APASS], rb[BPASS];
+    float4 ra[APASS], rb[WT ? WTPASS : BPASS];
     // wave-uniform walk state of the chunk being loaded
     int l_tap = chunk_lo / chunks_per_tap, l_c0 = (chunk_lo % chunks_per_tap) * BKT;
     int l_kh = l_tap / p.KW, l_kw = l_tap % p.KW;
@@ -549,12 +550,22 @@ __global__ __launch_bounds__(256) void igemm_fwd_dil2_kernel(const float* __rest
             const bool ok = c_ok && (unsigned)vy < (unsigned)vH && (unsigned)vx < (unsigned)vW && ((vy | vx) & 1) == 0;
             ra[i] = dsf_buffer_load4(xbuf, ok ? (uint32_t)(((a_base[i] + (vy >> 1)) * p.Wi + (vx >> 1)) * p.Ci + l_c0 + a_k4) * 4u : OOB);
         }
-        const int wrow = l_tap * p.Ci + l_c0;
+        if (WT) {
+            const int tapf = (p.KH - 1 - l_kh) * p.KW + (p.KW - 1 - l_kw);
 #pragma unroll
-        for (int i = 0; i < BPASS; ++i) {
-            const int kk = b_row + BROWS * i;
-            const bool ok = b_nok && (l_c0 + kk < p.Ci);
-            rb[i] = dsf_buffer_load4(wbuf, ok ? (uint32_t)((wrow + kk) * p.Co + n0 + b_n4) * 4u : OOB);
+            for (int i = 0; i < WTPASS; ++i) {
+                const int n = n0 + a_r + AROWS * i;
+                const bool ok = c_ok && n < p.Co;
+                rb[i] = dsf_buffer_load4(wbuf, ok ? (uint32_t)((tapf * p.Co + n) * p.Ci + l_c0 + a_k4) * 4u : OOB);
+            }
+        } else {
+            const int wrow = l_tap * p.Ci + l_c0;
+#pragma unroll
+            for (int i = 0; i < BPASS; ++i) {
+                const int kk = b_row + BROWS * i;
+                const bool ok = b_nok && (l_c0 + kk < p.Ci);
+                rb[i] = dsf_buffer_load4(wbuf, ok ? (uint32_t)((wrow + kk) * p.Co + n0 + b_n4) * 4u : OOB);
+            }
         }
         // advance (scalar)
         l_c0 += BKT; ++l_chunk;
@@ -574,10 +585,19 @@ __global__ __launch_bounds__(256) void igemm_fwd_dil2_kernel(const float* __rest
             Asb[(a_k4 + 0) * BM + r] = ra[i].x; Asb[(a_k4 + 1) * BM + r] = ra[i].y;
             Asb[(a_k4 + 2) * BM + r] = ra[i].z; Asb[(a_k4 + 3) * BM + r] = ra[i].w;
         }
+        if (WT) {
 #pragma unroll
-        for (int i = 0; i < BPASS; ++i) {
-            const int kk = b_row + BROWS * i;
-            *reinterpret_cast<float4*>(&Bsb[kk * BN + (b_n4 ^ lds_swz<BKT>(kk))]) = rb[i];
+            for (int i = 0; i < WTPASS; ++i) {
+                const int c = (a_r + AROWS * i) ^ swz;
+                Bsb[(a_k4 + 0) * BN + c] = rb[i].x; Bsb[(a_k4 + 1) * BN + c] = rb[i].y;
+                Bsb[(a_k4 + 2) * BN + c] = rb[i].z; Bsb[(a_k4 + 3) * BN + c] = rb[i].w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < BPASS; ++i) {
+                const int kk = b_row + BROWS * i;
+                *reinterpret_cast<float4*>(&Bsb[kk * BN + (b_n4 ^ lds_swz<BKT>(kk))]) = rb[i];
+            }
         }
     };
 
@@ -883,10 +903,12 @@ static int conv_forward_impl(const float* X, const float* W, const float* bias, 
         hipMemsetAsync(Y, 0, sizeof(float) * (size_t)M * Co, (hipStream_t)stream) != hipSuccess) return DSF_ERR_LAUNCH;
     const dim3 grid(m_tiles * n_tiles * k_splits);
     if (fast2) {
-#define DSF_LAUNCH_DIL2(BNv, BKv) hipLaunchKernelGGL((igemm_fwd_dil2_kernel<BNv, BKv>), grid, dim3(256), 0, (hipStream_t)stream, X, W, \
-                                                    bias, Y, p, m_tiles, n_tiles, k_splits, (uint32_t)x_bytes, (uint32_t)w_bytes)
-        if (bn == 128) { if (bkt == 16) DSF_LAUNCH_DIL2(128, 16); else DSF_LAUNCH_DIL2(128, 32); }
-        else { if (bkt == 16) DSF_LAUNCH_DIL2(64, 16); else DSF_LAUNCH_DIL2(64, 32); }
+#define DSF_LAUNCH_DIL2(BNv, BKv, WTv) hipLaunchKernelGGL((igemm_fwd_dil2_kernel<BNv, BKv, WTv>), grid, dim3(256), 0, (hipStream_t)stream, \
+                                                         X, W, bias, Y, p, m_tiles, n_tiles, k_splits, (uint32_t)x_bytes, (uint32_t)w_bytes)
+#define DSF_LAUNCH_DIL2_WT(BNv, BKv) do { if (w_fwd_layout) DSF_LAUNCH_DIL2(BNv, BKv, true); else DSF_LAUNCH_DIL2(BNv, BKv, false); } while (0)
+        if (bn == 128) { if (bkt == 16) DSF_LAUNCH_DIL2_WT(128, 16); else DSF_LAUNCH_DIL2_WT(128, 32); }
+        else { if (bkt == 16) DSF_LAUNCH_DIL2_WT(64, 16); else DSF_LAUNCH_DIL2_WT(64, 32); }
+#undef DSF_LAUNCH_DIL2_WT
 #undef DSF_LAUNCH_DIL2
         return dsf_launch_status();
     }
@@ -922,6 +944,16 @@ extern "C" int dsf_conv_igemm_bwd_data_s1(const float* dY, const float* W_fwd, f
     const int Ho = H + 2 * pad_h - KH + 1, Wo = Wd + 2 * pad_w - KW + 1;          // dY spatial size
     return conv_forward_impl(dY, W_fwd, nullptr, dX, B, Ho, Wo, Cout, H, Wd, Cin, KH, KW, 1, 1, KH - 1 - pad_h, KW - 1 - pad_w, 1,
                              stream);
+}
+
+// Same GEMM with the weights given TRANSPOSED AND TAP-FLIPPED, Wt[KH][KW][Co][Ci] with tap (kh, kw) stored at
+// (KH-1-kh, KW-1-kw): that is what a layer's own parameter memory looks like from its other direction, so
+// ConvTranspose2d forward and the backward-data of strided convolutions need no re-laid weight copy.
+// Only the vectorised paths implement it (DSF_ERR_UNSUPPORTED otherwise; callers then re-lay the weights).
+extern "C" int dsf_conv_igemm_forward_wt(const float* X, const float* Wt, const float* bias, float* Y, int B, int Hi, int Wi,
+                                         int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int dil, int pad_h,
+                                         int pad_w, dsf_stream_t stream) {
+    return conv_forward_impl(X, Wt, bias, Y, B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, dil, pad_h, pad_w, 1, stream);
 }
 
 extern "C" int dsf_conv_igemm_wrw(const float* X, const float* dY, float* dW, int B, int Hi, int Wi, int Ci, int Ho, int Wo,

@@ -169,10 +169,51 @@ __global__ void bn_param_grads_kernel(const double* __restrict__ acc, int C, flo
     if (dgamma) dgamma[c] = (float)acc[C + c];
 }
 
-// per-column sums of a row-major (M, C) matrix, any C <= 1024 (bias gradients of NHWC conv outputs).
-// `out` must be zeroed; one float atomic per column per workgroup (<= 256 workgroups).
-__global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ x, int64_t M, int C, int cpad,
+// Per-channel sums of an (M rows, C channels) row-major matrix (bias gradients of NHWC activations).
+// Each lane owns one float4 column group, the 256 / (C/4) row-lanes of a workgroup walk rows_per_wg rows with 8
+// independent 16-byte loads in flight per lane; row-lanes fold through LDS and one float atomic per channel per
+// workgroup lands in `out` (zeroed by the caller).  ~2048 workgroups keep every CU's memory pipeline full.
+__global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ x, int64_t M, int C, int c4n,
                                                       int rows_per_wg, float* __restrict__ out) {
+    __shared__ float4 s[256];
+    const int t = threadIdx.x;
+    const int rlanes = 256 / c4n;                  // c4n <= 256 column groups per pass
+    const int col = t % c4n, rl = t / c4n;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+    const int64_t r1 = (r0 + rows_per_wg < M) ? r0 + rows_per_wg : M;
+    const int C4 = C >> 2;
+    for (int cb = 0; cb < C4; cb += c4n) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rl < rlanes && cb + col < C4) {
+            const float4* base = reinterpret_cast<const float4*>(x) + cb + col;
+            int64_t r = r0 + rl;
+            for (; r + 7 * rlanes < r1; r += 8 * rlanes) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = base[(r + u * rlanes) * C4];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+            }
+            for (; r < r1; r += rlanes) {
+                const float4 v = base[r * C4];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        }
+        s[t] = acc;
+        __syncthreads();
+        if (rl == 0 && cb + col < C4) {
+            float4 tot = s[col];
+            for (int q = 1; q < rlanes; ++q) { const float4 v = s[q * c4n + col]; tot.x += v.x; tot.y += v.y; tot.z += v.z; tot.w += v.w; }
+            float* o = out + (cb + col) * 4;
+            atomicAdd(o, tot.x); atomicAdd(o + 1, tot.y); atomicAdd(o + 2, tot.z); atomicAdd(o + 3, tot.w);
+        }
+        __syncthreads();
+    }
+}
+
+// scalar-column variant for channel counts that are not a multiple of 4
+__global__ __launch_bounds__(256) void col_sum_scalar_kernel(const float* __restrict__ x, int64_t M, int C, int cpad,
+                                                             int rows_per_wg, float* __restrict__ out) {
     __shared__ float s[256];
     const int t = threadIdx.x;
     const int c = t % cpad, rl = t / cpad, rlanes = 256 / cpad;
@@ -265,11 +306,22 @@ extern "C" int dsf_col_sum(const float* x, int64_t M, int C, float* out, dsf_str
     DSF_CHECK_ARG(x && out && M > 0 && C > 0);
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(out, 0, sizeof(float) * C, st) != hipSuccess) return DSF_ERR_LAUNCH;
+    if ((C & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        int c4n = 1;
+        while (c4n < (C >> 2) && c4n < 256) c4n <<= 1;        // float4 column groups per pass (power of two <= 256)
+        const int rlanes = 256 / c4n;
+        int64_t rows = (M + 2047) / 2048;                      // ~2048 workgroups
+        const int64_t min_rows = (int64_t)rlanes * 8;          // at least one unrolled trip per lane
+        if (rows < min_rows) rows = min_rows;
+        const int wgs = (int)((M + rows - 1) / rows);
+        hipLaunchKernelGGL(col_sum_kernel, dim3(wgs), dim3(256), 0, st, x, M, C, c4n, (int)rows, out);
+        return dsf_launch_status();
+    }
     int cpad = 1;
     while (cpad < C && cpad < 256) cpad <<= 1;         // columns handled per pass (power of two <= 256)
     int64_t rows = (M + 255) / 256;
     if (rows < 64) rows = 64;
     const int wgs = (int)((M + rows - 1) / rows);
-    hipLaunchKernelGGL(col_sum_kernel, dim3(wgs), dim3(256), 0, st, x, M, C, cpad, (int)rows, out);
+    hipLaunchKernelGGL(col_sum_scalar_kernel, dim3(wgs), dim3(256), 0, st, x, M, C, cpad, (int)rows, out);
     return dsf_launch_status();
 }

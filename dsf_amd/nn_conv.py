@@ -75,6 +75,25 @@ def kernel_layout_(param, perm):
     param.data = param.data.permute(*perm).contiguous().permute(*inv)
 
 
+def _wt_ok(Ci, Co, Ho, Wo, dil):
+    """shapes the transposed-weight kernels implement (dsf_conv_igemm_forward_wt)"""
+    return Ci >= 32 and Ci % 4 == 0 and Co % 4 == 0 and (dil == 1 or (dil == 2 and Ho % 2 == 0 and Wo % 2 == 0))
+
+
+def _fwd_wt(x, wt, bias, out_hw, Co, KH, KW, stride, dil, pad):
+    """_fwd with the weight operand transposed and tap-flipped, wt [KH][KW][Co][Ci] (a layer's own parameter memory
+    seen from its other direction): no re-laid copy of the weights."""
+    B, Ci, Hi, Wi = x.shape
+    Ho, Wo = out_hw
+    if RECORD is not None:
+        RECORD.append(("fwd_wt", B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, dil, pad[0], pad[1]))
+    y = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=CL)
+    check(L.lib().dsf_conv_igemm_forward_wt(ptr_nhwc(x), ptr(wt), ptr(bias), ptr_nhwc(y), I(B), I(Hi), I(Wi), I(Ci), I(Ho),
+                                            I(Wo), I(Co), I(KH), I(KW), I(stride), I(dil), I(pad[0]), I(pad[1]),
+                                            stream_ptr()), "dsf_conv_igemm_forward_wt")
+    return y
+
+
 def _bwd_data_s1(gy, wk, out_hw, Cin, KH, KW, pad):
     """stride-1 backward-data straight from the forward operand wk [KH][KW][Cin][Cout] (no flipped copy)."""
     B, Cout, Ho, Wo = gy.shape
@@ -112,6 +131,9 @@ class Conv2dFunction(Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0] and stride == 1 and Co >= 32 and Co % 4 == 0 and Ci % 4 == 0:
             gx = _bwd_data_s1(gy, wk, (x.shape[2], x.shape[3]), Ci, KH, KW, padding)
+        elif ctx.needs_input_grad[0] and _wt_ok(Co, Ci, x.shape[2], x.shape[3], stride):
+            # backward-data as a dilated convolution over gy; wk (the forward operand) is its transposed, flipped weight
+            gx = _fwd_wt(gy, wk, None, (x.shape[2], x.shape[3]), Ci, KH, KW, 1, stride, (KH - 1 - padding[0], KW - 1 - padding[1]))
         elif ctx.needs_input_grad[0]:
             wd = weight.detach().float().flip(2, 3).permute(2, 3, 0, 1).contiguous()          # [kh'][kw'][Co][Ci]
             gx = _fwd(gy, wd, None, (x.shape[2], x.shape[3]), Ci, KH, KW, 1, stride, (KH - 1 - padding[0], KW - 1 - padding[1]))
@@ -130,9 +152,13 @@ class ConvTranspose2dFunction(Function):
         B, _, Hi, Wi = x.shape
         Ho = (Hi - 1) * stride - 2 * padding[0] + KH + output_padding[0]
         Wo = (Wi - 1) * stride - 2 * padding[1] + KW + output_padding[1]
-        wk = weight.detach().float().flip(2, 3).permute(2, 3, 0, 1).contiguous()             # [kh'][kw'][Cin][Cout]
-        y = _fwd(x, wk, bias.detach().float().contiguous() if bias is not None else None, (Ho, Wo), Cout, KH, KW, 1, stride,
-                 (KH - 1 - padding[0], KW - 1 - padding[1]))
+        b = bias.detach().float().contiguous() if bias is not None else None
+        if _wt_ok(Cin, Cout, Ho, Wo, stride):
+            wt = weight.detach().float().permute(2, 3, 1, 0).contiguous()                     # [kh][kw][Cout][Cin]: a free view in kernel layout
+            y = _fwd_wt(x, wt, b, (Ho, Wo), Cout, KH, KW, 1, stride, (KH - 1 - padding[0], KW - 1 - padding[1]))
+        else:
+            wk = weight.detach().float().flip(2, 3).permute(2, 3, 0, 1).contiguous()         # [kh'][kw'][Cin][Cout]
+            y = _fwd(x, wk, b, (Ho, Wo), Cout, KH, KW, 1, stride, (KH - 1 - padding[0], KW - 1 - padding[1]))
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, padding, bias is not None)
         return y
@@ -208,6 +234,9 @@ def replay(rec, iters=3):
     if kind == "fwd":
         wk = torch.randn(KH, KW, Ci, Co, device=dev)
         run = lambda: _fwd(x, wk, None, (Ho, Wo), Co, KH, KW, stride, dil, (ph, pw))
+    elif kind == "fwd_wt":
+        wt = torch.randn(KH, KW, Co, Ci, device=dev)
+        run = lambda: _fwd_wt(x, wt, None, (Ho, Wo), Co, KH, KW, stride, dil, (ph, pw))
     elif kind == "bwd_s1":                                   # x plays grad_out (B,Cout=Ci,..), result is grad_in (B,Cin=Co,..)
         wk = torch.randn(KH, KW, Co, Ci, device=dev)
         run = lambda: _bwd_data_s1(x, wk, (Ho, Wo), Co, KH, KW, (ph, pw))
@@ -232,17 +261,20 @@ def replay(rec, iters=3):
 
 
 def kernel_name(rec):
+    """Name of the kernel conv.hip launches for a recorded call, as rocprofv3 prints it (mirrors the host heuristics)."""
     kind, B, Hi, Wi, Ci, Ho, Wo, Co = rec[:8]
     dil = rec[11]
     bn = 128 if Co > 64 else 64
-    if kind == "bwd_s1":
-        return "igemm_fwd_fast_kernel<%d, true>" % bn
-    if kind == "fwd":
-        if dil == 1 and Ci >= 32 and Ci % 4 == 0 and Co % 4 == 0:
-            return "igemm_fwd_fast_kernel<%d, false>" % bn
-        if dil == 2 and Ci >= 32 and Ci % 4 == 0 and Co % 4 == 0 and Ho % 2 == 0 and Wo % 2 == 0:
-            return "igemm_fwd_dil2_kernel<%d>" % bn
+    M = B * Ho * Wo
+    tiles = ((M + 127) // 128) * ((Co + bn - 1) // bn)
+    vec = Ci % 4 == 0 and Co % 4 == 0
+    if kind in ("fwd", "fwd_wt", "bwd_s1"):
+        wt = "false" if kind == "fwd" else "true"
+        if dil == 1 and Ci >= 32 and vec:
+            return "igemm_fwd_fast_kernel<%d, %s, %d>" % (bn, wt, 16 if tiles >= 1024 else 32)
+        if dil == 2 and Ci >= 32 and vec and Ho % 2 == 0 and Wo % 2 == 0:
+            return "igemm_fwd_dil2_kernel<%d, %d, %s>" % (bn, 16 if (tiles >= 1024 and bn == 128) else 32, wt)
         return "igemm_fwd_kernel<%d, %s>" % (bn, "true" if (Ci < 32 and dil == 1) else "false")
-    if Ci % 4 == 0 and Co % 4 == 0:
-        return "igemm_wrw_fast_kernel<%d>" % bn
+    if vec:
+        return "igemm_wrw_fast_kernel<%d, %d>" % (bn, 16 if M >= 32768 else 32)
     return "igemm_wrw_kernel<%d>" % bn

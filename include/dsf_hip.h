@@ -299,6 +299,14 @@ int dsf_conv_igemm_forward(const float* X, const float* W, const float* bias, fl
  * (else DSF_ERR_UNSUPPORTED: use dsf_conv_igemm_forward with flipped weights). */
 int dsf_conv_igemm_bwd_data_s1(const float* dY, const float* W_fwd, float* dX, int B, int H, int W, int Cout,
                                int Cin, int KH, int KW, int pad_h, int pad_w, dsf_stream_t stream);
+/* dsf_conv_igemm_forward with the weight operand given transposed and tap-flipped, Wt[KH][KW][Co][Ci] holding tap
+ * (kh, kw) at (KH-1-kh, KW-1-kw): the memory of a layer's own parameter seen from its other direction
+ * (ConvTranspose2d forward, backward-data of strided Conv2d).  Implemented by the vectorised kernels only
+ * (Ci, Co multiples of 4, Ci >= 32; dil 2 needs even Ho, Wo); returns DSF_ERR_UNSUPPORTED otherwise. */
+int dsf_conv_igemm_forward_wt(const float* X, const float* Wt, const float* bias, float* Y, int B, int Hi, int Wi,
+                              int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int dil, int pad_h,
+                              int pad_w, dsf_stream_t stream);
+
 /* dW[(kh*KW+kw)*Ci+c][n] = sum_{b,oy,ox} X[b, oy*stride+kh-pad_h, ox*stride+kw-pad_w, c] * dY[b,oy,ox,n]
  * (zeroed by the call, accumulated with float atomics across the pixel splits). */
 int dsf_conv_igemm_wrw(const float* X, const float* dY, float* dW, int B, int Hi, int Wi, int Ci, int Ho, int Wo,
