@@ -11,9 +11,23 @@
 
 namespace {
 
-// ---- pass 1: per-channel sums of a (M, C) matrix: sum(a*m), sum(a*m*b_hat) style reductions --------
-// MODE 0: stats of x:          s0 = sum x,            s1 = sum x^2
-// MODE 1: backward reductions: s0 = sum g,            s1 = sum g * xhat      (g = gy * (y > 0 if relu))
+// ---- pass 1: per-channel reductions of a (M, C) matrix + finalisation by the last workgroup ---------------
+// MODE 0: stats of x:          s0 = sum x,            s1 = sum x^2          -> mean, invstd, running stats
+// MODE 1: backward reductions: s0 = sum g,            s1 = sum g * xhat     -> sums (for pass 2), dbeta, dgamma
+//                              (g = gy * (y > 0) when the ReLU is fused)
+// Each lane owns 4 consecutive channels (16-byte loads, 4 rows in flight), the row-lanes of a workgroup fold through
+// LDS and the workgroup writes ONE float partial per channel (no atomics on the 2C sums: hundreds of workgroups on
+// 2C addresses serialise at the memory side).  bn_finalize_kernel adds the partials in double, in a fixed order.
+// (An in-launch finalisation by the last-arriving workgroup was measured: its serial walk over up to 256 KB of
+// partials costs 60+ us, a second tiny launch ~4 us.)
+struct BnFinal {
+    // MODE 0
+    float eps, momentum;
+    float* mean; float* invstd; float* running_mean; float* running_var;
+    // MODE 1
+    double* sums; float* dgamma; float* dbeta;
+};
+
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                         const float* __restrict__ y, const float* __restrict__ mean,
@@ -21,8 +35,8 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
                                                         int rows_per_wg, float* __restrict__ part) {
     __shared__ float s_part[2][256 * 4];
     const int t = threadIdx.x;
-    const int c4n = C >> 2;                       // float4 columns
-    const int col = t % c4n, rl = t / c4n;        // requires c4n <= 256 and 256 % c4n == 0
+    const int c4n = C >> 2;                       // float4 columns; c4n <= 256 and 256 % c4n == 0
+    const int col = t % c4n, rl = t / c4n;
     const int rlanes = 256 / c4n;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
     const int64_t r1 = (r0 + rows_per_wg < M) ? r0 + rows_per_wg : M;
@@ -32,17 +46,14 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
 #pragma unroll
         for (int k = 0; k < 4; ++k) { mu[k] = mean[col * 4 + k]; is[k] = invstd[col * 4 + k]; }
     }
-    for (int64_t r = r0 + rl; r < r1; r += rlanes) {
-        const float4 xv = *reinterpret_cast<const float4*>(x + r * C + col * 4);
+    auto accumulate = [&](const float4& xv, const float4& gv, const float4& yv) {
         const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
         if (MODE == 0) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) { a0[k] += xe[k]; a1[k] = fmaf(xe[k], xe[k], a1[k]); }
         } else {
-            const float4 gv = *reinterpret_cast<const float4*>(gy + r * C + col * 4);
             float ge[4] = {gv.x, gv.y, gv.z, gv.w};
             if (relu) {
-                const float4 yv = *reinterpret_cast<const float4*>(y + r * C + col * 4);
                 const float ye[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) ge[k] = (ye[k] > 0.f) ? ge[k] : 0.f;
@@ -50,13 +61,33 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
 #pragma unroll
             for (int k = 0; k < 4; ++k) { a0[k] += ge[k]; a1[k] = fmaf(ge[k], (xe[k] - mu[k]) * is[k], a1[k]); }
         }
+    };
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    int64_t r = r0 + rl;
+    for (; r + 3 * rlanes < r1; r += 4 * rlanes) {
+        float4 xv[4], gv[4], yv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t o = (r + u * rlanes) * C + col * 4;
+            xv[u] = *reinterpret_cast<const float4*>(x + o);
+            gv[u] = (MODE == 1) ? *reinterpret_cast<const float4*>(gy + o) : z4;
+            yv[u] = (MODE == 1 && relu) ? *reinterpret_cast<const float4*>(y + o) : z4;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) accumulate(xv[u], gv[u], yv[u]);
+    }
+    for (; r < r1; r += rlanes) {
+        const int64_t o = r * C + col * 4;
+        const float4 xv = *reinterpret_cast<const float4*>(x + o);
+        const float4 gv = (MODE == 1) ? *reinterpret_cast<const float4*>(gy + o) : z4;
+        const float4 yv = (MODE == 1 && relu) ? *reinterpret_cast<const float4*>(y + o) : z4;
+        accumulate(xv, gv, yv);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) { s_part[0][t * 4 + k] = a0[k]; s_part[1][t * 4 + k] = a1[k]; }
     __syncthreads();
-    // fold the row-lanes; one partial row per workgroup (no atomics: 1000 workgroups on 2C addresses
-    // serialise at the memory side), combined in double by bn_combine_kernel
-    float* out = part + (int64_t)blockIdx.x * 2 * C;
+    const int nv = 2 * C;
+    float* out = part + (int64_t)blockIdx.x * nv;
     for (int ch = t; ch < C; ch += 256) {
         const int cc = ch >> 2, kk = ch & 3;
         float d0 = 0.f, d1 = 0.f;
@@ -66,57 +97,74 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
     }
 }
 
-// sums[2][C] (double accumulate) over the per-workgroup partials; 64 channels x 4 partial-lanes per block
-__global__ __launch_bounds__(256) void bn_combine_kernel(const float* __restrict__ part, int wgs, int C,
-                                                         double* __restrict__ sums) {
-    __shared__ double s[2][256];
-    const int t = threadIdx.x, cl = t & 63, pl = t >> 6;
-    const int c = blockIdx.x * 64 + cl;
-    double d0 = 0.0, d1 = 0.0;
-    if (c < C)
-        for (int w = pl; w < wgs; w += 4) { d0 += part[(int64_t)w * 2 * C + c]; d1 += part[(int64_t)w * 2 * C + C + c]; }
-    s[0][t] = d0; s[1][t] = d1;
-    __syncthreads();
-    if (pl == 0 && c < C) {
-        sums[c] = s[0][cl] + s[0][64 + cl] + s[0][128 + cl] + s[0][192 + cl];
-        sums[C + c] = s[1][cl] + s[1][64 + cl] + s[1][128 + cl] + s[1][192 + cl];
+// ---- pass 1b: combine the per-workgroup partials (double, fixed order: deterministic) and finalise ----------------
+// One workgroup per 16 channels (32 values): 8 partial-lanes per value walk the `wgs` partial rows, fold through LDS.
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int wgs, int64_t M, int C,
+                                                          BnFinal fin) {
+    __shared__ double s_fold[256];
+    const int t = threadIdx.x, vl = t & 31, pl = t >> 5;           // value-lane (16 channels x {s0, s1}), partial-lane
+    const int cl = vl & 15, which = vl >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    const int nv = 2 * C;
+    double d = 0.0;
+    if (c < C) {
+        const float* p = part + which * C + c;
+        int w = pl;
+        for (; w + 24 < wgs; w += 32) {
+            const float p0 = p[(int64_t)w * nv], p1 = p[(int64_t)(w + 8) * nv], p2 = p[(int64_t)(w + 16) * nv], p3 = p[(int64_t)(w + 24) * nv];
+            d += ((double)p0 + (double)p1) + ((double)p2 + (double)p3);
+        }
+        for (; w < wgs; w += 8) d += (double)p[(int64_t)w * nv];
     }
-}
-
-// finalize forward statistics: mean, invstd; running stats with momentum (unbiased variance)
-__global__ void bn_finalize_kernel(const double* __restrict__ acc, int64_t M, int C, float eps, float momentum,
-                                   float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const double mu = acc[c] / (double)M;
-    double var = acc[C + c] / (double)M - mu * mu;
-    if (var < 0.0) var = 0.0;
-    mean[c] = (float)mu;
-    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (running_mean) {
-        const double unbiased = (M > 1) ? var * (double)M / (double)(M - 1) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    s_fold[t] = d;
+    __syncthreads();
+    if (t < 16 && c < C) {
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { s0 += s_fold[q * 32 + cl]; s1 += s_fold[q * 32 + 16 + cl]; }
+        if (MODE == 0) {
+            const double m = s0 / (double)M;
+            double var = s1 / (double)M - m * m;
+            if (var < 0.0) var = 0.0;
+            fin.mean[c] = (float)m;
+            fin.invstd[c] = (float)(1.0 / sqrt(var + (double)fin.eps));
+            if (fin.running_mean) {
+                const double unbiased = (M > 1) ? var * (double)M / (double)(M - 1) : var;
+                fin.running_mean[c] = (1.f - fin.momentum) * fin.running_mean[c] + fin.momentum * (float)m;
+                fin.running_var[c] = (1.f - fin.momentum) * fin.running_var[c] + fin.momentum * (float)unbiased;
+            }
+        } else {
+            fin.sums[c] = s0;
+            fin.sums[C + c] = s1;
+            if (fin.dbeta) fin.dbeta[c] = (float)s0;
+            if (fin.dgamma) fin.dgamma[c] = (float)s1;
+        }
     }
 }
 
 // ---- pass 2 forward: y = (x - mean) * invstd * gamma + beta (+ residual) (relu) ---------------------
+// The grid stride is a multiple of the float4 column count, so a thread's channel quad is loop-invariant.
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        int64_t n4, int C, int relu, float* __restrict__ y) {
     const int c4n = C >> 2;
-    for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        const int c = (int)(i % c4n) * 4;
+    const int64_t i0 = blockIdx.x * (int64_t)256 + threadIdx.x;
+    const int c = (int)(i0 % c4n) * 4;
+    float sc[4], sh[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        sc[k] = invstd[c + k] * (gamma ? gamma[c + k] : 1.f);
+        sh[k] = beta ? beta[c + k] : 0.f;
+    }
+    const float mu[4] = {mean[c], mean[c + 1], mean[c + 2], mean[c + 3]};
+    for (int64_t i = i0; i < n4; i += (int64_t)gridDim.x * 256) {
         const float4 xv = reinterpret_cast<const float4*>(x)[i];
         const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
         float o[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float sc = invstd[c + k] * (gamma ? gamma[c + k] : 1.f);
-            o[k] = (xe[k] - mean[c + k]) * sc + (beta ? beta[c + k] : 0.f);
-        }
+        for (int k = 0; k < 4; ++k) o[k] = (xe[k] - mu[k]) * sc[k] + sh[k];
         if (res) {
             const float4 rv = reinterpret_cast<const float4*>(res)[i];
             o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w;
@@ -137,8 +185,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            int relu, float* __restrict__ dx, float* __restrict__ dres) {
     const int c4n = C >> 2;
     const float invM = 1.0f / (float)M;
-    for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        const int c = (int)(i % c4n) * 4;
+    const int64_t i0 = blockIdx.x * (int64_t)256 + threadIdx.x;
+    const int c = (int)(i0 % c4n) * 4;
+    float mu[4], is[4], sg[4], sgx[4], gi[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        mu[k] = mean[c + k]; is[k] = invstd[c + k];
+        sg[k] = (float)acc[c + k] * invM; sgx[k] = (float)acc[C + c + k] * invM;
+        gi[k] = (gamma ? gamma[c + k] : 1.f) * is[k];
+    }
+    for (int64_t i = i0; i < n4; i += (int64_t)gridDim.x * 256) {
         const float4 xv = reinterpret_cast<const float4*>(x)[i];
         const float4 gv = reinterpret_cast<const float4*>(gy)[i];
         const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
@@ -152,21 +208,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         float o[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float xh = (xe[k] - mean[c + k]) * invstd[c + k];
-            const float sg = (float)acc[c + k] * invM, sgx = (float)acc[C + c + k] * invM;
-            o[k] = (gamma ? gamma[c + k] : 1.f) * invstd[c + k] * (ge[k] - sg - xh * sgx);
+            const float xh = (xe[k] - mu[k]) * is[k];
+            o[k] = gi[k] * (ge[k] - sg[k] - xh * sgx[k]);
         }
         reinterpret_cast<float4*>(dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
         if (dres) reinterpret_cast<float4*>(dres)[i] = make_float4(ge[0], ge[1], ge[2], ge[3]);
     }
-}
-
-__global__ void bn_param_grads_kernel(const double* __restrict__ acc, int C, float* __restrict__ dgamma,
-                                      float* __restrict__ dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    if (dbeta) dbeta[c] = (float)acc[c];
-    if (dgamma) dgamma[c] = (float)acc[C + c];
 }
 
 // Per-channel sums of an (M rows, C channels) row-major matrix (bias gradients of NHWC activations).
@@ -236,15 +283,28 @@ __global__ __launch_bounds__(256) void col_sum_scalar_kernel(const float* __rest
 
 inline bool bn_shape_ok(int C) { return C >= 4 && (C & 3) == 0 && (C >> 2) <= 256 && 256 % (C >> 2) == 0; }
 
-constexpr int BN_MAX_WGS = 512;
-inline int bn_rows_per_wg(int64_t M) {
+constexpr int BN_MAX_WGS = 256;
+inline int bn_rows_per_wg(int64_t M, int C) {
+    const int rlanes = 256 / (C >> 2);
     int64_t r = (M + BN_MAX_WGS - 1) / BN_MAX_WGS;
-    if (r < 32) r = 32;
+    if (r < (int64_t)rlanes * 4) r = (int64_t)rlanes * 4;      // at least one unrolled trip per row-lane
     return (int)r;
 }
-// workspace layout (doubles): [0, 2C) channel sums; then BN_MAX_WGS * 2C floats of per-workgroup partials
+inline int bn_apply_grid(int64_t n4) {
+    int64_t g = (n4 + 1023) / 1024;                             // >= 4 float4 per thread
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+// workspace layout: [0, 2C) doubles = channel sums of the backward pass; then BN_MAX_WGS * 2C floats of per-workgroup
+// partials.  No state survives a call.
+inline float* bn_ws_part(double* ws, int C) { return reinterpret_cast<float*>(ws + 2 * C); }
 
 }  // namespace
+
+extern "C" int64_t dsf_bn_workspace_bytes(int C) {
+    return (int64_t)(2 * C) * 8 + (int64_t)BN_MAX_WGS * 2 * C * 4 + 16;
+}
 
 extern "C" int dsf_bn_forward(const float* x, const float* residual, const float* gamma, const float* beta, int64_t M,
                               int C, float eps, float momentum, int relu, float* running_mean, float* running_var,
@@ -252,18 +312,15 @@ extern "C" int dsf_bn_forward(const float* x, const float* residual, const float
     DSF_CHECK_ARG(x && y && save_mean && save_invstd && workspace && M > 0);
     if (!bn_shape_ok(C)) return DSF_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    const int rows = bn_rows_per_wg(M);
+    const int rows = bn_rows_per_wg(M, C);
     const int wgs = (int)((M + rows - 1) / rows);
-    float* part = reinterpret_cast<float*>(workspace + 2 * C);
+    BnFinal fin = {eps, momentum, save_mean, save_invstd, running_mean, running_var, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(wgs), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, M, C, 0, rows,
-                       part);
-    hipLaunchKernelGGL(bn_combine_kernel, dim3((C + 63) / 64), dim3(256), 0, st, part, wgs, C, workspace);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, M, C, eps, momentum, save_mean,
-                       save_invstd, running_mean, running_var);
+                       bn_ws_part(workspace, C));
+    hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3((C + 15) / 16), dim3(256), 0, st, bn_ws_part(workspace, C), wgs, M, C, fin);
     const int64_t n4 = M * (C >> 2);
-    const int grid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), 0, st, x, residual, save_mean, save_invstd, gamma, beta, n4, C,
-                       relu, y);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_apply_grid(n4)), dim3(256), 0, st, x, residual, save_mean, save_invstd, gamma,
+                       beta, n4, C, relu, y);
     return dsf_launch_status();
 }
 
@@ -272,11 +329,10 @@ extern "C" int dsf_bn_apply(const float* x, const float* residual, const float* 
                             const float* mean, const float* invstd, int64_t M, int C, int relu, float* y,
                             dsf_stream_t stream) {
     DSF_CHECK_ARG(x && y && mean && invstd && M > 0);
-    if (C < 4 || (C & 3)) return DSF_ERR_UNSUPPORTED;
+    if (!bn_shape_ok(C)) return DSF_ERR_UNSUPPORTED;
     const int64_t n4 = M * (C >> 2);
-    const int grid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, residual, mean, invstd, gamma, beta,
-                       n4, C, relu, y);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_apply_grid(n4)), dim3(256), 0, (hipStream_t)stream, x, residual, mean, invstd,
+                       gamma, beta, n4, C, relu, y);
     return dsf_launch_status();
 }
 
@@ -287,18 +343,15 @@ extern "C" int dsf_bn_backward(const float* x, const float* grad_y, const float*
     DSF_CHECK_ARG(x && grad_y && save_mean && save_invstd && grad_x && workspace && M > 0 && (!relu || y));
     if (!bn_shape_ok(C)) return DSF_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    const int rows = bn_rows_per_wg(M);
+    const int rows = bn_rows_per_wg(M, C);
     const int wgs = (int)((M + rows - 1) / rows);
-    float* part = reinterpret_cast<float*>(workspace + 2 * C);
+    BnFinal fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, workspace, grad_gamma, grad_beta};
     hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(wgs), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd, M, C, relu,
-                       rows, part);
-    hipLaunchKernelGGL(bn_combine_kernel, dim3((C + 63) / 64), dim3(256), 0, st, part, wgs, C, workspace);
+                       rows, bn_ws_part(workspace, C));
+    hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(256), 0, st, bn_ws_part(workspace, C), wgs, M, C, fin);
     const int64_t n4 = M * (C >> 2);
-    const int grid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd, gamma,
-                       workspace, M, n4, C, relu, grad_x, grad_residual);
-    if (grad_gamma || grad_beta)
-        hipLaunchKernelGGL(bn_param_grads_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, C, grad_gamma, grad_beta);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_apply_grid(n4)), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd,
+                       gamma, workspace, M, n4, C, relu, grad_x, grad_residual);
     return dsf_launch_status();
 }
 

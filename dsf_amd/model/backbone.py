@@ -29,11 +29,9 @@ class _Layers:
 
     def __init__(self, native):
         self.native = native
-        # fused BN(+add+ReLU) kernels exist (csrc/norm.hip, parity-tested) but measure slower than torch's
-        # BN + add + ReLU at these sizes: activations (<= 134 MB) sit in the 256 MiB Infinity Cache, so the
-        # passes saved are nearly free and the extra stats->combine->finalize->apply launches dominate
-        # (fwd 82 vs 50 us at 64ch 64x64 B=32).  Opt in with DSF_FUSED_BN=1.
-        self.fused_bn = native and os.environ.get("DSF_FUSED_BN", "0") == "1"
+        # fused BN(+add+ReLU) kernels (csrc/norm.hip): 3 launches each way instead of MIOpen's 3 + add + ReLU
+        # (B=32 ResNet-18 step: 32.6 vs 33.0 ms).  DSF_FUSED_BN=0 keeps torch's BatchNorm2d / ReLU modules.
+        self.fused_bn = native and os.environ.get("DSF_FUSED_BN", "1") == "1"
         self.Conv2d = nn_conv.Conv2d if native else nn.Conv2d
         self.ConvTranspose2d = nn_conv.ConvTranspose2d if native else nn.ConvTranspose2d
 

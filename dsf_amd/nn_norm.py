@@ -24,6 +24,22 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+_WS = {}
+
+
+def _workspace(device, C):
+    """Zero-initialised scratch (partials + workgroup ticket) per (device, stream, C), shared by every BN call with
+    that channel count issued on that stream: calls are stream-ordered and each leaves the ticket at zero."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, C)
+    ws = _WS.get(key)
+    if ws is None:
+        fn = L.lib().dsf_bn_workspace_bytes
+        fn.restype = ctypes.c_int64
+        ws = torch.zeros((int(fn(I(C))) + 7) // 8, device=device, dtype=torch.float64)
+        _WS[key] = ws
+    return ws
+
+
 class _BNFunction(Function):
     @staticmethod
     def forward(ctx, x, residual, gamma, beta, running_mean, running_var, eps, momentum, relu):
@@ -35,7 +51,7 @@ class _BNFunction(Function):
         y = torch.empty_like(x, memory_format=CL)
         mean = torch.empty(C, device=x.device, dtype=torch.float32)
         invstd = torch.empty(C, device=x.device, dtype=torch.float32)
-        ws = torch.empty(514 * C, device=x.device, dtype=torch.float64)
+        ws = _workspace(x.device, C)
         check(L.lib().dsf_bn_forward(_p(x), _p(residual), _p(gamma), _p(beta), I64(M), I(C), CF(eps), CF(momentum),
                                      I(int(relu)), _p(running_mean), _p(running_var), _p(y), _p(mean), _p(invstd), _p(ws),
                                      stream_ptr()), "dsf_bn_forward")
@@ -55,7 +71,7 @@ class _BNFunction(Function):
         gres = torch.empty_like(x, memory_format=CL) if has_res else None
         gg = torch.empty(C, device=x.device, dtype=torch.float32) if has_g else None
         gb = torch.empty(C, device=x.device, dtype=torch.float32) if has_b else None
-        ws = torch.empty(514 * C, device=x.device, dtype=torch.float64)
+        ws = _workspace(x.device, C)
         check(L.lib().dsf_bn_backward(_p(x), _p(gy), _p(y), _p(gamma), _p(mean), _p(invstd), I64(M), I(C), I(int(relu)), _p(gx),
                                       _p(gres), _p(gg), _p(gb), _p(ws), stream_ptr()), "dsf_bn_backward")
         return gx, gres, gg, gb, None, None, None, None, None
@@ -68,6 +84,22 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
     def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True, fuse_relu=False):
         super().__init__(num_features, eps=eps, momentum=momentum, affine=affine, track_running_stats=track_running_stats)
         self.fuse_relu = fuse_relu
+        self._pending_batches = 0      # training steps not yet added to num_batches_tracked (flushed when it is read out)
+
+    def flush_batch_counter(self):
+        """num_batches_tracked is only an output when momentum is set (the running statistics do not depend on it), so
+        the per-step `add_(1)` launch is deferred and folded in when the state dict is taken."""
+        if self._pending_batches and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(self._pending_batches)
+        self._pending_batches = 0
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        self.flush_batch_counter()
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._pending_batches = 0
+        super()._load_from_state_dict(*args, **kwargs)
 
     def forward(self, x, residual=None, relu=None):
         relu = self.fuse_relu if relu is None else relu
@@ -77,9 +109,12 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
         use_batch_stats = self.training or not self.track_running_stats
         if supported(C) and x.dtype == torch.float32:
             if use_batch_stats:
+                if self.momentum is None:
+                    raise NotImplementedError("FusedBatchNorm2d: cumulative moving average (momentum=None) is not used by "
+                                              "the reference and not implemented")
                 if self.training and self.track_running_stats and self.num_batches_tracked is not None:
-                    self.num_batches_tracked.add_(1)
-                mom = 0.0 if self.momentum is None else self.momentum
+                    self._pending_batches += 1
+                mom = self.momentum
                 rm = self.running_mean if (self.training and self.track_running_stats) else None
                 rv = self.running_var if (self.training and self.track_running_stats) else None
                 return _BNFunction.apply(x, residual, self.weight, self.bias, rm, rv, self.eps, mom, relu)

@@ -140,6 +140,33 @@ def all_reduce_mean_pair(total, count, group=None):
     return total / (count + 1e-8)
 
 
+class _SyncBNAct(torch.nn.SyncBatchNorm):
+    """SyncBatchNorm standing in for a FusedBatchNorm2d: keeps the fused module's call signature
+    (``forward(x, residual=None, relu=None)``) so blocks that pass the skip connection / ReLU flag keep working."""
+    fuse_relu = False
+
+    def forward(self, x, residual=None, relu=None):
+        y = super().forward(x)
+        if residual is not None:
+            y = y + residual
+        return torch.relu(y) if (self.fuse_relu if relu is None else relu) else y
+
+
 def convert_sync_batchnorm(net):
-    """Optional: global-batch BN statistics (per-replica statistics are the default)."""
-    return torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)
+    """Optional: global-batch BN statistics (per-replica statistics are the default).  Fused BN(+add+ReLU)
+    modules become a SyncBatchNorm that still applies their residual add / ReLU; parameters, buffers and keys carry over."""
+    from .nn_norm import FusedBatchNorm2d
+    fused = {name: m for name, m in net.named_modules() if isinstance(m, FusedBatchNorm2d)}
+    for m in fused.values():
+        m.flush_batch_counter()
+    net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)
+    for name, old in fused.items():
+        parent = net
+        *path, leaf = name.split(".")
+        for p in path:
+            parent = getattr(parent, p)
+        new = getattr(parent, leaf)
+        if isinstance(new, torch.nn.SyncBatchNorm):
+            new.__class__ = _SyncBNAct
+            new.fuse_relu = old.fuse_relu
+    return net

@@ -316,11 +316,13 @@ int dsf_conv_igemm_wrw(const float* X, const float* dY, float* dW, int B, int Hi
  * Fused training-mode BatchNorm2d (+ residual add) (+ ReLU) on NHWC activations, x viewed as (M, C).
  * Replaces nn.BatchNorm2d + `out += identity` + nn.ReLU of model/resnet.py:38-55, 82-98 and the
  * conv-bn-relu sequences of model/backbone.py:16-42 (3 + 1 + 1 forward and 3 + 1 backward kernels in
- * PyTorch) by two HBM passes each way.  C must be a power of two in [4, 1024] (else
- * DSF_ERR_UNSUPPORTED and the caller keeps torch's kernels).  workspace: 2*C doubles (channel sums)
- * followed by 512*2*C floats (per-workgroup partials), i.e. 514*C doubles.
+ * PyTorch) by three launches each way (per-workgroup partial sums, combine + finalise, one streaming pass).
+ * C must be a power of two in [4, 1024] (else DSF_ERR_UNSUPPORTED and the caller keeps torch's kernels).
+ * workspace: dsf_bn_workspace_bytes(C) bytes, 8-byte aligned scratch; one buffer can serve every layer of a stream
+ * because calls on a stream are ordered.  The reduction is deterministic (fixed partials, fixed order, double combine).
  * running_mean / running_var (may be NULL) are updated in place with `momentum` (unbiased variance).
  * ---------------------------------------------------------------------------------- */
+int64_t dsf_bn_workspace_bytes(int C);
 int dsf_bn_forward(const float* x, const float* residual, const float* gamma, const float* beta, int64_t M,
                    int C, float eps, float momentum, int relu, float* running_mean, float* running_var,
                    float* y, float* save_mean, float* save_invstd, double* workspace, dsf_stream_t stream);

@@ -35,7 +35,7 @@ def test_fused_huber_matches_composite_and_oracle(shape, cl, size_average):
     assert x.grad.stride() == x.stride()
     if size_average:
         want = float(image_ref.huber(x.detach().cpu(), y.cpu()))
-        assert abs(float(loss) - want) <= 2e-6 * abs(want) + 1e-12
+        assert abs(float(loss.detach()) - want) <= 2e-6 * abs(want) + 1e-12
 
 
 def test_fused_huber_is_deterministic_and_falls_back_when_target_needs_grad():
