@@ -31,8 +31,11 @@ struct BnFinal {
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                         const float* __restrict__ y, const float* __restrict__ mean,
-                                                        const float* __restrict__ invstd, int64_t M, int C, int relu,
+                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int64_t M, int C, int relu,
                                                         int rows_per_wg, float* __restrict__ part) {
+    // relu: 0 none, 1 mask from the saved output y (y > 0), 2 mask recomputed from x with the forward's own expression
+    // (x - mean) * (invstd * gamma) + beta > 0 -- bit-identical to the forward, and y is not read (nor kept) at all
     __shared__ float s_part[2][256 * 4];
     const int t = threadIdx.x;
     const int c4n = C >> 2;                       // float4 columns; c4n <= 256 and 256 % c4n == 0
@@ -41,10 +44,14 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
     const int64_t r1 = (r0 + rows_per_wg < M) ? r0 + rows_per_wg : M;
     float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
-    float mu[4] = {0.f, 0.f, 0.f, 0.f}, is[4] = {1.f, 1.f, 1.f, 1.f};
+    float mu[4] = {0.f, 0.f, 0.f, 0.f}, is[4] = {1.f, 1.f, 1.f, 1.f}, sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
     if (MODE == 1) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { mu[k] = mean[col * 4 + k]; is[k] = invstd[col * 4 + k]; }
+        for (int k = 0; k < 4; ++k) {
+            mu[k] = mean[col * 4 + k]; is[k] = invstd[col * 4 + k];
+            sc[k] = is[k] * (gamma ? gamma[col * 4 + k] : 1.f);
+            sh[k] = beta ? beta[col * 4 + k] : 0.f;
+        }
     }
     auto accumulate = [&](const float4& xv, const float4& gv, const float4& yv) {
         const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
@@ -53,10 +60,13 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
             for (int k = 0; k < 4; ++k) { a0[k] += xe[k]; a1[k] = fmaf(xe[k], xe[k], a1[k]); }
         } else {
             float ge[4] = {gv.x, gv.y, gv.z, gv.w};
-            if (relu) {
+            if (relu == 1) {
                 const float ye[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) ge[k] = (ye[k] > 0.f) ? ge[k] : 0.f;
+            } else if (relu == 2) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ge[k] = ((xe[k] - mu[k]) * sc[k] + sh[k] > 0.f) ? ge[k] : 0.f;
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) { a0[k] += ge[k]; a1[k] = fmaf(ge[k], (xe[k] - mu[k]) * is[k], a1[k]); }
@@ -71,7 +81,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
             const int64_t o = (r + u * rlanes) * C + col * 4;
             xv[u] = *reinterpret_cast<const float4*>(x + o);
             gv[u] = (MODE == 1) ? *reinterpret_cast<const float4*>(gy + o) : z4;
-            yv[u] = (MODE == 1 && relu) ? *reinterpret_cast<const float4*>(y + o) : z4;
+            yv[u] = (MODE == 1 && relu == 1) ? *reinterpret_cast<const float4*>(y + o) : z4;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) accumulate(xv[u], gv[u], yv[u]);
@@ -80,7 +90,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
         const int64_t o = r * C + col * 4;
         const float4 xv = *reinterpret_cast<const float4*>(x + o);
         const float4 gv = (MODE == 1) ? *reinterpret_cast<const float4*>(gy + o) : z4;
-        const float4 yv = (MODE == 1 && relu) ? *reinterpret_cast<const float4*>(y + o) : z4;
+        const float4 yv = (MODE == 1 && relu == 1) ? *reinterpret_cast<const float4*>(y + o) : z4;
         accumulate(xv, gv, yv);
     }
 #pragma unroll
@@ -181,29 +191,35 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                            const float* __restrict__ y, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                           const double* __restrict__ acc, int64_t M, int64_t n4, int C,
-                                                           int relu, float* __restrict__ dx, float* __restrict__ dres) {
+                                                           const float* __restrict__ beta, const double* __restrict__ acc,
+                                                           int64_t M, int64_t n4, int C, int relu, float* __restrict__ dx,
+                                                           float* __restrict__ dres) {
     const int c4n = C >> 2;
     const float invM = 1.0f / (float)M;
     const int64_t i0 = blockIdx.x * (int64_t)256 + threadIdx.x;
     const int c = (int)(i0 % c4n) * 4;
-    float mu[4], is[4], sg[4], sgx[4], gi[4];
+    float mu[4], is[4], sg[4], sgx[4], gi[4], sc[4], sh[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         mu[k] = mean[c + k]; is[k] = invstd[c + k];
         sg[k] = (float)acc[c + k] * invM; sgx[k] = (float)acc[C + c + k] * invM;
         gi[k] = (gamma ? gamma[c + k] : 1.f) * is[k];
+        sc[k] = is[k] * (gamma ? gamma[c + k] : 1.f);
+        sh[k] = beta ? beta[c + k] : 0.f;
     }
     for (int64_t i = i0; i < n4; i += (int64_t)gridDim.x * 256) {
         const float4 xv = reinterpret_cast<const float4*>(x)[i];
         const float4 gv = reinterpret_cast<const float4*>(gy)[i];
         const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
         float ge[4] = {gv.x, gv.y, gv.z, gv.w};
-        if (relu) {
+        if (relu == 1) {
             const float4 yv = reinterpret_cast<const float4*>(y)[i];
             const float ye[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) ge[k] = (ye[k] > 0.f) ? ge[k] : 0.f;
+        } else if (relu == 2) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ge[k] = ((xe[k] - mu[k]) * sc[k] + sh[k] > 0.f) ? ge[k] : 0.f;
         }
         float o[4];
 #pragma unroll
@@ -218,10 +234,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 
 // Per-channel sums of an (M rows, C channels) row-major matrix (bias gradients of NHWC activations).
 // Each lane owns one float4 column group, the 256 / (C/4) row-lanes of a workgroup walk rows_per_wg rows with 8
-// independent 16-byte loads in flight per lane; row-lanes fold through LDS and one float atomic per channel per
-// workgroup lands in `out` (zeroed by the caller).  ~2048 workgroups keep every CU's memory pipeline full.
+// independent 16-byte loads in flight per lane; row-lanes fold through LDS and the workgroup writes one partial row
+// (float atomics from ~2000 workgroups onto C addresses serialise at the memory side: measured 200 us for a 134 MB
+// tensor); col_sum_combine_kernel adds the <= 256 partial rows.
 __global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ x, int64_t M, int C, int c4n,
-                                                      int rows_per_wg, float* __restrict__ out) {
+                                                      int rows_per_wg, float* __restrict__ part) {
     __shared__ float4 s[256];
     const int t = threadIdx.x;
     const int rlanes = 256 / c4n;                  // c4n <= 256 column groups per pass
@@ -251,11 +268,31 @@ __global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ 
         if (rl == 0 && cb + col < C4) {
             float4 tot = s[col];
             for (int q = 1; q < rlanes; ++q) { const float4 v = s[q * c4n + col]; tot.x += v.x; tot.y += v.y; tot.z += v.z; tot.w += v.w; }
-            float* o = out + (cb + col) * 4;
-            atomicAdd(o, tot.x); atomicAdd(o + 1, tot.y); atomicAdd(o + 2, tot.z); atomicAdd(o + 3, tot.w);
+            reinterpret_cast<float4*>(part + (int64_t)blockIdx.x * C)[cb + col] = tot;
         }
         __syncthreads();
     }
+}
+
+// out[c] = sum over the partial rows, fixed order (deterministic); 64 channels x 4 partial-lanes per workgroup
+__global__ __launch_bounds__(256) void col_sum_combine_kernel(const float* __restrict__ part, int wgs, int C,
+                                                              float* __restrict__ out) {
+    __shared__ float s[256];
+    const int t = threadIdx.x, cl = t & 63, pl = t >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float d = 0.f;
+    if (c < C) {
+        int w = pl;
+        for (; w + 12 < wgs; w += 16) {
+            const float p0 = part[(int64_t)w * C + c], p1 = part[(int64_t)(w + 4) * C + c];
+            const float p2 = part[(int64_t)(w + 8) * C + c], p3 = part[(int64_t)(w + 12) * C + c];
+            d += (p0 + p1) + (p2 + p3);
+        }
+        for (; w < wgs; w += 4) d += part[(int64_t)w * C + c];
+    }
+    s[t] = d;
+    __syncthreads();
+    if (pl == 0 && c < C) out[c] = (s[cl] + s[64 + cl]) + (s[128 + cl] + s[192 + cl]);
 }
 
 // scalar-column variant for channel counts that are not a multiple of 4
@@ -315,8 +352,8 @@ extern "C" int dsf_bn_forward(const float* x, const float* residual, const float
     const int rows = bn_rows_per_wg(M, C);
     const int wgs = (int)((M + rows - 1) / rows);
     BnFinal fin = {eps, momentum, save_mean, save_invstd, running_mean, running_var, nullptr, nullptr, nullptr};
-    hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(wgs), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, M, C, 0, rows,
-                       bn_ws_part(workspace, C));
+    hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(wgs), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                       M, C, 0, rows, bn_ws_part(workspace, C));
     hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3((C + 15) / 16), dim3(256), 0, st, bn_ws_part(workspace, C), wgs, M, C, fin);
     const int64_t n4 = M * (C >> 2);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_apply_grid(n4)), dim3(256), 0, st, x, residual, save_mean, save_invstd, gamma,
@@ -336,40 +373,45 @@ extern "C" int dsf_bn_apply(const float* x, const float* residual, const float* 
     return dsf_launch_status();
 }
 
-extern "C" int dsf_bn_backward(const float* x, const float* grad_y, const float* y, const float* gamma,
+extern "C" int dsf_bn_backward(const float* x, const float* grad_y, const float* y, const float* gamma, const float* beta,
                                const float* save_mean, const float* save_invstd, int64_t M, int C, int relu,
                                float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta,
                                double* workspace, dsf_stream_t stream) {
-    DSF_CHECK_ARG(x && grad_y && save_mean && save_invstd && grad_x && workspace && M > 0 && (!relu || y));
+    DSF_CHECK_ARG(x && grad_y && save_mean && save_invstd && grad_x && workspace && M > 0 && relu >= 0 && relu <= 2 &&
+                  (relu != 1 || y));
     if (!bn_shape_ok(C)) return DSF_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const int rows = bn_rows_per_wg(M, C);
     const int wgs = (int)((M + rows - 1) / rows);
     BnFinal fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, workspace, grad_gamma, grad_beta};
-    hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(wgs), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd, M, C, relu,
-                       rows, bn_ws_part(workspace, C));
+    hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(wgs), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd, gamma, beta, M, C,
+                       relu, rows, bn_ws_part(workspace, C));
     hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(256), 0, st, bn_ws_part(workspace, C), wgs, M, C, fin);
     const int64_t n4 = M * (C >> 2);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_apply_grid(n4)), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd,
-                       gamma, workspace, M, n4, C, relu, grad_x, grad_residual);
+                       gamma, beta, workspace, M, n4, C, relu, grad_x, grad_residual);
     return dsf_launch_status();
 }
 
-extern "C" int dsf_col_sum(const float* x, int64_t M, int C, float* out, dsf_stream_t stream) {
+constexpr int COLSUM_MAX_WGS = 256;
+extern "C" int64_t dsf_col_sum_workspace_bytes(int C) { return (int64_t)COLSUM_MAX_WGS * C * 4; }
+
+extern "C" int dsf_col_sum(const float* x, int64_t M, int C, float* out, float* workspace, dsf_stream_t stream) {
     DSF_CHECK_ARG(x && out && M > 0 && C > 0);
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(out, 0, sizeof(float) * C, st) != hipSuccess) return DSF_ERR_LAUNCH;
-    if ((C & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    if (workspace && (C & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0) {
         int c4n = 1;
         while (c4n < (C >> 2) && c4n < 256) c4n <<= 1;        // float4 column groups per pass (power of two <= 256)
         const int rlanes = 256 / c4n;
-        int64_t rows = (M + 2047) / 2048;                      // ~2048 workgroups
+        int64_t rows = (M + COLSUM_MAX_WGS - 1) / COLSUM_MAX_WGS;
         const int64_t min_rows = (int64_t)rlanes * 8;          // at least one unrolled trip per lane
         if (rows < min_rows) rows = min_rows;
         const int wgs = (int)((M + rows - 1) / rows);
-        hipLaunchKernelGGL(col_sum_kernel, dim3(wgs), dim3(256), 0, st, x, M, C, c4n, (int)rows, out);
+        hipLaunchKernelGGL(col_sum_kernel, dim3(wgs), dim3(256), 0, st, x, M, C, c4n, (int)rows, workspace);
+        hipLaunchKernelGGL(col_sum_combine_kernel, dim3((C + 63) / 64), dim3(256), 0, st, workspace, wgs, C, out);
         return dsf_launch_status();
     }
+    if (hipMemsetAsync(out, 0, sizeof(float) * C, st) != hipSuccess) return DSF_ERR_LAUNCH;
     int cpad = 1;
     while (cpad < C && cpad < 256) cpad <<= 1;         // columns handled per pass (power of two <= 256)
     int64_t rows = (M + 255) / 256;

@@ -53,7 +53,8 @@ def _bias_grad(gy):
     B, Co, H, W = gy.shape
     out = torch.empty(Co, device=gy.device, dtype=torch.float32)
     from ._lib import I64
-    check(L.lib().dsf_col_sum(ptr_nhwc(gy), I64(B * H * W), I(Co), ptr(out), stream_ptr()), "dsf_col_sum")
+    ws = torch.empty(256 * Co, device=gy.device, dtype=torch.float32)            # dsf_col_sum_workspace_bytes(Co)
+    check(L.lib().dsf_col_sum(ptr_nhwc(gy), I64(B * H * W), I(Co), ptr(out), ptr(ws), stream_ptr()), "dsf_col_sum")
     return out
 
 

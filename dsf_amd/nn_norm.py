@@ -55,15 +55,17 @@ class _BNFunction(Function):
         check(L.lib().dsf_bn_forward(_p(x), _p(residual), _p(gamma), _p(beta), I64(M), I(C), CF(eps), CF(momentum),
                                      I(int(relu)), _p(running_mean), _p(running_var), _p(y), _p(mean), _p(invstd), _p(ws),
                                      stream_ptr()), "dsf_bn_forward")
-        ctx.save_for_backward(x, y if relu else None, gamma, mean, invstd)
+        # ReLU mask in the backward: recomputed from x when no residual was added (y is then not kept alive for it)
+        ctx.save_for_backward(x, y if (relu and residual is not None) else None, gamma, beta, mean, invstd)
         ctx.cfg = (relu, residual is not None, gamma is not None, beta is not None)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        x, y, gamma, mean, invstd = ctx.saved_tensors
+        x, y, gamma, beta, mean, invstd = ctx.saved_tensors
         relu, has_res, has_g, has_b = ctx.cfg
+        relu_mode = 0 if not relu else (1 if has_res else 2)
         gy = gy.contiguous(memory_format=CL)
         B, C, H, W = x.shape
         M = B * H * W
@@ -72,7 +74,7 @@ class _BNFunction(Function):
         gg = torch.empty(C, device=x.device, dtype=torch.float32) if has_g else None
         gb = torch.empty(C, device=x.device, dtype=torch.float32) if has_b else None
         ws = _workspace(x.device, C)
-        check(L.lib().dsf_bn_backward(_p(x), _p(gy), _p(y), _p(gamma), _p(mean), _p(invstd), I64(M), I(C), I(int(relu)), _p(gx),
+        check(L.lib().dsf_bn_backward(_p(x), _p(gy), _p(y), _p(gamma), _p(beta), _p(mean), _p(invstd), I64(M), I(C), I(relu_mode), _p(gx),
                                       _p(gres), _p(gg), _p(gb), _p(ws), stream_ptr()), "dsf_bn_backward")
         return gx, gres, gg, gb, None, None, None, None, None
 

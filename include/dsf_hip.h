@@ -329,15 +329,19 @@ int dsf_bn_forward(const float* x, const float* residual, const float* gamma, co
 int dsf_bn_apply(const float* x, const float* residual, const float* gamma, const float* beta,
                  const float* mean, const float* invstd, int64_t M, int C, int relu, float* y,
                  dsf_stream_t stream);
-/* grad_x (M,C) written; grad_residual (M,C) = relu-masked grad_y, may be NULL; grad_gamma / grad_beta (C). */
-int dsf_bn_backward(const float* x, const float* grad_y, const float* y, const float* gamma,
+/* grad_x (M,C) written; grad_residual (M,C) = relu-masked grad_y, may be NULL; grad_gamma / grad_beta (C).
+ * relu: 0 none; 1 ReLU mask from the saved output y (needed when a residual was added); 2 mask recomputed from x,
+ * gamma, beta with the forward's own expression (no residual: y is neither read nor needs to be kept, may be NULL). */
+int dsf_bn_backward(const float* x, const float* grad_y, const float* y, const float* gamma, const float* beta,
                     const float* save_mean, const float* save_invstd, int64_t M, int C, int relu,
                     float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta,
                     double* workspace, dsf_stream_t stream);
 
 /* out[c] = sum_m x[m][c] of a row-major (M, C) matrix (bias gradient of an NHWC convolution output:
- * the `gy.sum((0,2,3))` of nn.Conv2d's backward). */
-int dsf_col_sum(const float* x, int64_t M, int C, float* out, dsf_stream_t stream);
+ * the `gy.sum((0,2,3))` of nn.Conv2d's backward).  workspace: dsf_col_sum_workspace_bytes(C) bytes of 16-byte
+ * aligned scratch (partial rows; deterministic two-launch reduction), or NULL (single launch with float atomics). */
+int64_t dsf_col_sum_workspace_bytes(int C);
+int dsf_col_sum(const float* x, int64_t M, int C, float* out, float* workspace, dsf_stream_t stream);
 
 #ifdef __cplusplus
 }
