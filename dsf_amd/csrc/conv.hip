@@ -21,6 +21,7 @@
 // with zeros): forward conv (stride s, dil 1), backward-data of a stride-1 conv (flipped weights),
 // backward-data of a stride-2 conv and ConvTranspose2d forward (dil 2) all run the same kernel.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -287,16 +288,21 @@ __device__ __forceinline__ int xcd_contiguous(int bid, int total) {
 template <int BKT>
 __device__ __forceinline__ int lds_swz(int k) { return BKT == 32 ? (k & 28) : ((k & 12) << 1); }
 
+struct NoPiece { __device__ __forceinline__ void operator()(int) const {} };
+
 // One BKT-deep chunk of the block GEMM from one LDS stage: BKT/2 k-steps x (TM x TN) MFMAs per wave.
-template <int BN, int TM, int TN, int BKT, bool SWZ = true>
+// `piece(s)` is issued right after the MFMAs of k-step s: the loader hands its global loads (address arithmetic +
+// buffer_load) over one per k-step, so that VALU work runs in the shadow of the 64-cycle MFMAs instead of in front of
+// them (one wave's loader was ~1000 cycles per chunk against 2048-4096 cycles of MFMA).
+template <int BN, int TM, int TN, int BKT, bool SWZ = true, int BMT = BM, typename Piece = NoPiece>
 __device__ __forceinline__ void mma_chunk(const float* __restrict__ Asb, const float* __restrict__ Bsb, int arow, int bcol,
-                                          int lane, f32x16 (&acc)[TM][TN]) {
+                                          int lane, f32x16 (&acc)[TM][TN], Piece piece = Piece()) {
     const int h = lane >> 5, l31 = lane & 31;
     float af[2][TM], bf[2][TN];
     auto frag = [&](int kk, float* a, float* b) {
         const int k = kk + h, sw = SWZ ? (l31 ^ lds_swz<BKT>(kk)) : l31;       // kk is even: swz(kk + h) == swz(kk)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = Asb[k * BM + arow + i * 32 + sw];
+        for (int i = 0; i < TM; ++i) a[i] = Asb[k * BMT + arow + i * 32 + sw];
 #pragma unroll
         for (int j = 0; j < TN; ++j) b[j] = Bsb[k * BN + bcol + j * 32 + sw];
     };
@@ -310,33 +316,33 @@ __device__ __forceinline__ void mma_chunk(const float* __restrict__ Asb, const f
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][i], bf[s & 1][j], acc[i][j], 0, 0, 0);
+        piece(s);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-// WT = true: W is the FORWARD operand [KH][KW][N][Kc] of the same layer (i.e. this launch is the backward-data pass of
-// a stride-1 convolution): taps are read flipped and the B tile transposed, so no re-laid copy of the weights is needed.
-// BKT: K depth of one pipeline stage.  32: two 32 KiB stages (BN = 128), 2 workgroups per CU.  16: two 16 KiB stages,
-// 4-5 workgroups per CU -- twice the barriers per FLOP but twice the waves to cover them.
-template <int BN, bool WT, int BKT>
+// BMT: pixel rows per tile.  128, or 64 (BN = 128 only; each wave a 32x64 sub-tile) for small maps: twice the tiles, so
+// 8x8..32x32 layers need half the split-K partials (or none) -- their float-atomic epilogues cost more than the MFMAs saved.
+template <int BN, bool WT, int BKT, int BMT>
 __global__ __launch_bounds__(256) void igemm_fwd_fast_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                              const float* __restrict__ bias, float* __restrict__ Y,
                                                              ConvP p, int m_tiles, int n_tiles, int k_splits,
                                                              uint32_t x_bytes, uint32_t w_bytes) {
-    constexpr int WM = (BN == 128) ? 64 : 32;
+    constexpr int WM = (BN == 128) ? BMT / 2 : BMT / 4;
     constexpr int TM = WM / 32, TN = 2;
     constexpr int KQ = BKT / 4;                      // k-quads per tile row
-    constexpr int AROWS = 256 / KQ, APASS = BM / AROWS;          // transposing loader: thread -> (row, k-quad)
+    constexpr int AROWS = 256 / KQ, APASS = BMT / AROWS;         // transposing loader: thread -> (row, k-quad)
     constexpr int B4 = BN / 4, BROWS = 256 / B4, BPASS = BKT / BROWS;
     constexpr int WTPASS = BN / AROWS;               // WT: thread -> (column, k-quad)
-    static_assert(APASS >= 1 && BPASS >= 1 && WTPASS >= 1, "tile / thread mapping");
-    __shared__ float As[2][BKT * BM];
+    static_assert(TM >= 1 && APASS >= 1 && BPASS >= 1 && WTPASS >= 1, "tile / thread mapping");
+    __shared__ float As[2][BKT * BMT];
     __shared__ float Bs[2][BKT * BN];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = (BN == 128) ? (wave >> 1) : wave, wn = (BN == 128) ? (wave & 1) : 0;
     int tile = xcd_contiguous(blockIdx.x, m_tiles * n_tiles * k_splits);
     const int n_tile = tile % n_tiles; tile /= n_tiles;
     const int m_tile = tile % m_tiles; const int ks = tile / m_tiles;
-    const int m0 = m_tile * BM, n0 = n_tile * BN;
+    const int m0 = m_tile * BMT, n0 = n_tile * BN;
     const int M = p.B * p.Ho * p.Wo;
     const __amdgpu_buffer_rsrc_t xbuf = dsf_buffer(X, x_bytes), wbuf = dsf_buffer(W, w_bytes);
 
@@ -368,80 +374,100 @@ __global__ __launch_bounds__(256) void igemm_fwd_fast_kernel(const float* __rest
     const int per_split = (n_chunks + k_splits - 1) / k_splits;
     const int chunk_lo = ks * per_split, chunk_hi = min(n_chunks, chunk_lo + per_split);
 
-    float4 ra[APASS], rb[WT ? WTPASS : BPASS];
+    // two register sets for the global loads: chunk c + 2 is requested while chunk c + 1 still waits in the other set
+    // for its LDS stage, so a load has two chunk times (1.7-3.4 us of MFMA work) to come back, not one
+    float4 ra[2][APASS], rb[2][WT ? WTPASS : BPASS];
     // wave-uniform walk state of the chunk being loaded
     int l_tap = chunk_lo / chunks_per_tap, l_c0 = (chunk_lo % chunks_per_tap) * BKT;
     int l_kh = l_tap / p.KW, l_kw = l_tap % p.KW;
-    auto load_next = [&]() {
-        const int tap_off = (l_kh * p.Wi + l_kw) * p.Ci + l_c0;
-        const bool c_ok = l_c0 + a_k4 < p.Ci;
-#pragma unroll
-        for (int i = 0; i < APASS; ++i) {
+    constexpr int NB = WT ? WTPASS : BPASS, NPIECE = APASS + NB;
+    static_assert(NPIECE <= BKT / 2, "one loader piece per k-step");
+    // piece i of a chunk's loads into register set SET: i < APASS an A row group, then the B groups; the last piece
+    // advances the walk.  `live` = the chunk exists (loads past the end are still issued, with the out-of-range offset,
+    // so the number of loads in flight -- what s_waitcnt vmcnt counts -- does not depend on the trip count)
+    auto load_piece = [&](auto SET, int i, bool live) {
+        constexpr int S = decltype(SET)::value;
+        const bool c_ok = live && l_c0 + a_k4 < p.Ci;
+        if (i < APASS) {
+            const int tap_off = (l_kh * p.Wi + l_kw) * p.Ci + l_c0;
             const bool ok = c_ok && (unsigned)(a_iy[i] + l_kh) < (unsigned)p.Hi && (unsigned)(a_ix[i] + l_kw) < (unsigned)p.Wi;
-            ra[i] = dsf_buffer_load4(xbuf, ok ? (uint32_t)(a_base[i] + tap_off) * 4u : OOB);
-        }
-        if (WT) {
+            ra[S][i] = dsf_buffer_load4(xbuf, ok ? (uint32_t)(a_base[i] + tap_off) * 4u : OOB);
+        } else if (WT) {
+            const int j = i - APASS;
             const int tapf = (p.KH - 1 - l_kh) * p.KW + (p.KW - 1 - l_kw);
-#pragma unroll
-            for (int i = 0; i < WTPASS; ++i) {
-                const int n = n0 + a_r + AROWS * i;
-                const bool ok = c_ok && n < p.Co;
-                rb[i] = dsf_buffer_load4(wbuf, ok ? (uint32_t)((tapf * p.Co + n) * p.Ci + l_c0 + a_k4) * 4u : OOB);
-            }
+            const int n = n0 + a_r + AROWS * j;
+            const bool ok = c_ok && n < p.Co;
+            rb[S][j] = dsf_buffer_load4(wbuf, ok ? (uint32_t)((tapf * p.Co + n) * p.Ci + l_c0 + a_k4) * 4u : OOB);
         } else {
+            const int j = i - APASS;
             const int wrow = l_tap * p.Ci + l_c0;
-#pragma unroll
-            for (int i = 0; i < BPASS; ++i) {
-                const int kk = b_row + BROWS * i;
-                const bool ok = b_nok && (l_c0 + kk < p.Ci);
-                rb[i] = dsf_buffer_load4(wbuf, ok ? (uint32_t)((wrow + kk) * p.Co + n0 + b_n4) * 4u : OOB);
-            }
+            const int kk = b_row + BROWS * j;
+            const bool ok = live && b_nok && (l_c0 + kk < p.Ci);
+            rb[S][j] = dsf_buffer_load4(wbuf, ok ? (uint32_t)((wrow + kk) * p.Co + n0 + b_n4) * 4u : OOB);
         }
-        // advance (scalar)
-        l_c0 += BKT;
-        if (l_c0 >= p.Ci) {
-            l_c0 = 0; ++l_tap; ++l_kw;
-            if (l_kw == p.KW) { l_kw = 0; ++l_kh; }
+        if (i == NPIECE - 1) {                                      // advance (scalar)
+            l_c0 += BKT;
+            if (l_c0 >= p.Ci) {
+                l_c0 = 0; ++l_tap; ++l_kw;
+                if (l_kw == p.KW) { l_kw = 0; ++l_kh; }
+            }
         }
     };
-    auto stage = [&](int buf) {                                     // registers -> LDS stage `buf` (k-major, swizzled)
+    auto load_all = [&](auto SET, bool live) {
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) load_piece(SET, i, live);
+    };
+    auto stage = [&](auto SET, int buf) {                           // register set -> LDS stage `buf` (k-major, swizzled)
+        constexpr int S = decltype(SET)::value;
         float* Asb = As[buf];
         float* Bsb = Bs[buf];
         const int swz = lds_swz<BKT>(a_k4);                         // same for the 4 k-rows of the quad
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
             const int r = (a_r + AROWS * i) ^ swz;
-            Asb[(a_k4 + 0) * BM + r] = ra[i].x; Asb[(a_k4 + 1) * BM + r] = ra[i].y;
-            Asb[(a_k4 + 2) * BM + r] = ra[i].z; Asb[(a_k4 + 3) * BM + r] = ra[i].w;
+            Asb[(a_k4 + 0) * BMT + r] = ra[S][i].x; Asb[(a_k4 + 1) * BMT + r] = ra[S][i].y;
+            Asb[(a_k4 + 2) * BMT + r] = ra[S][i].z; Asb[(a_k4 + 3) * BMT + r] = ra[S][i].w;
         }
         if (WT) {
 #pragma unroll
             for (int i = 0; i < WTPASS; ++i) {
                 const int c = (a_r + AROWS * i) ^ swz;
-                Bsb[(a_k4 + 0) * BN + c] = rb[i].x; Bsb[(a_k4 + 1) * BN + c] = rb[i].y;
-                Bsb[(a_k4 + 2) * BN + c] = rb[i].z; Bsb[(a_k4 + 3) * BN + c] = rb[i].w;
+                Bsb[(a_k4 + 0) * BN + c] = rb[S][i].x; Bsb[(a_k4 + 1) * BN + c] = rb[S][i].y;
+                Bsb[(a_k4 + 2) * BN + c] = rb[S][i].z; Bsb[(a_k4 + 3) * BN + c] = rb[S][i].w;
             }
         } else {
 #pragma unroll
             for (int i = 0; i < BPASS; ++i) {
                 const int kk = b_row + BROWS * i;
-                *reinterpret_cast<float4*>(&Bsb[kk * BN + (b_n4 ^ lds_swz<BKT>(kk))]) = rb[i];
+                *reinterpret_cast<float4*>(&Bsb[kk * BN + (b_n4 ^ lds_swz<BKT>(kk))]) = rb[S][i];
             }
         }
     };
 
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, 1>;
     if (chunk_lo < chunk_hi) {
-        load_next();
-        stage(0);
+        load_all(Set0{}, true);
+        load_all(Set1{}, chunk_lo + 1 < chunk_hi);
+        stage(Set0{}, 0);
     }
     __syncthreads();
-    for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
-        const int buf = (chunk - chunk_lo) & 1;
-        const bool more = chunk + 1 < chunk_hi;
-        if (more) load_next();
-        mma_chunk<BN, TM, TN, BKT>(As[buf], Bs[buf], wm * WM, wn * 64, lane, acc);
-        if (more) stage(buf ^ 1);
+    // chunk c computes from LDS stage (c - lo) & 1; its register set (same parity) is free and receives chunk c + 2;
+    // chunk c + 1 moves from the other set to the other stage after the MFMAs
+    auto body = [&](auto SET, auto OTHER, int chunk) {
+        constexpr int buf = decltype(SET)::value;
+        const bool live2 = chunk + 2 < chunk_hi;
+        mma_chunk<BN, TM, TN, BKT, true, BMT>(As[buf], Bs[buf], wm * WM, wn * 64, lane, acc, [&](int s) {
+#pragma unroll
+            for (int i = 0; i < NPIECE; ++i)
+                if (i == s) load_piece(SET, i, live2);              // constant index after unrolling
+        });
+        if (chunk + 1 < chunk_hi) stage(OTHER, buf ^ 1);
         __syncthreads();
+    };
+    for (int chunk = chunk_lo; chunk < chunk_hi; chunk += 2) {
+        body(Set0{}, Set1{}, chunk);
+        if (chunk + 1 < chunk_hi) body(Set1{}, Set0{}, chunk + 1);
     }
 
 #pragma unroll
@@ -874,15 +900,18 @@ static int conv_forward_impl(const float* X, const float* W, const float* bias, 
     ConvP p = {B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, dil, pad_h, pad_w};
     const int64_t M = (int64_t)B * Ho * Wo;
     DSF_CHECK_ARG(M < (1ll << 31));
-    const int m_tiles = (int)((M + BM - 1) / BM);
     const int bn = (Co > 64) ? 128 : 64;
     const int n_tiles = (Co + bn - 1) / bn;
     const bool flat = Ci < BK && dil == 1;
+    const int64_t x_bytes = (int64_t)B * Hi * Wi * Ci * 4, w_bytes = (int64_t)KH * KW * Ci * Co * 4;
+    const bool fast = dil == 1 && !flat && (Ci & 3) == 0 && (Co & 3) == 0 && x_bytes < 0xFFFFFFF0ll && w_bytes < 0xFFFFFFF0ll;
+    // 64-row tiles (fast kernel, BN 128) when 128-row tiles would leave fewer than 2 per CU
+    static const int bm_env = [] { const char* e = getenv("DSF_CONV_BM"); return e ? atoi(e) : 0; }();
+    const int bmt = (fast && bn == 128 && (bm_env == 64 || (bm_env != 128 && ((M + BM - 1) / BM) * n_tiles < 512))) ? 64 : BM;
+    const int m_tiles = (int)((M + bmt - 1) / bmt);
     const int perm = (dil > 1 && Ho % dil == 0 && Wo % dil == 0) ? 1 : 0;
     const int n_chunks = flat ? (KH * KW * Ci + BK - 1) / BK : KH * KW * ((Ci + BK - 1) / BK);
     const int live_chunks = perm ? n_chunks / (dil * dil) : n_chunks;
-    const int64_t x_bytes = (int64_t)B * Hi * Wi * Ci * 4, w_bytes = (int64_t)KH * KW * Ci * Co * 4;
-    const bool fast = dil == 1 && !flat && (Ci & 3) == 0 && (Co & 3) == 0 && x_bytes < 0xFFFFFFF0ll && w_bytes < 0xFFFFFFF0ll;
     const bool fast2 = dil == 2 && stride == 1 && perm && (Ci & 3) == 0 && (Co & 3) == 0 && Ci >= BK &&
                        x_bytes < 0xFFFFFFF0ll && w_bytes < 0xFFFFFFF0ll;
     static const int bk_env = [] { const char* e = getenv("DSF_CONV_BK"); return e ? atoi(e) : 0; }();
@@ -899,6 +928,8 @@ static int conv_forward_impl(const float* X, const float* W, const float* bias, 
         if (k_splits > live_chunks / 4) k_splits = live_chunks / 4;
         if (k_splits < 1) k_splits = 1;
     }
+    static const int ks_env = [] { const char* e = getenv("DSF_CONV_SPLITS"); return e ? atoi(e) : 0; }();   // tuning aid
+    if (ks_env > 0) k_splits = ks_env > live_chunks ? live_chunks : ks_env;
     if (k_splits > 1 &&
         hipMemsetAsync(Y, 0, sizeof(float) * (size_t)M * Co, (hipStream_t)stream) != hipSuccess) return DSF_ERR_LAUNCH;
     const dim3 grid(m_tiles * n_tiles * k_splits);
@@ -914,11 +945,14 @@ static int conv_forward_impl(const float* X, const float* W, const float* bias, 
     }
     if (w_fwd_layout && !fast) return DSF_ERR_UNSUPPORTED;
     if (fast) {
-#define DSF_LAUNCH_FAST(BNv, WTv, BKv) hipLaunchKernelGGL((igemm_fwd_fast_kernel<BNv, WTv, BKv>), grid, dim3(256), 0, (hipStream_t)stream, \
-                                                         X, W, bias, Y, p, m_tiles, n_tiles, k_splits, (uint32_t)x_bytes, (uint32_t)w_bytes)
-#define DSF_LAUNCH_FAST_BK(BNv, WTv) do { if (bkt == 16) DSF_LAUNCH_FAST(BNv, WTv, 16); else DSF_LAUNCH_FAST(BNv, WTv, 32); } while (0)
-        if (bn == 128) { if (w_fwd_layout) DSF_LAUNCH_FAST_BK(128, true); else DSF_LAUNCH_FAST_BK(128, false); }
-        else { if (w_fwd_layout) DSF_LAUNCH_FAST_BK(64, true); else DSF_LAUNCH_FAST_BK(64, false); }
+        static const int lds_pad = [] { const char* e = getenv("DSF_CONV_LDS_PAD"); return e ? atoi(e) : 0; }();      // tuning aid
+#define DSF_LAUNCH_FAST(BNv, WTv, BKv, BMv) hipLaunchKernelGGL((igemm_fwd_fast_kernel<BNv, WTv, BKv, BMv>), grid, dim3(256), (BMv == 64 ? lds_pad : 0), \
+                                                              (hipStream_t)stream, X, W, bias, Y, p, m_tiles, n_tiles, k_splits,      \
+                                                              (uint32_t)x_bytes, (uint32_t)w_bytes)
+#define DSF_LAUNCH_FAST_BK(BNv, WTv, BMv) do { if (bkt == 16) DSF_LAUNCH_FAST(BNv, WTv, 16, BMv); else DSF_LAUNCH_FAST(BNv, WTv, 32, BMv); } while (0)
+        if (bn == 128 && bmt == 64) { if (w_fwd_layout) DSF_LAUNCH_FAST_BK(128, true, 64); else DSF_LAUNCH_FAST_BK(128, false, 64); }
+        else if (bn == 128) { if (w_fwd_layout) DSF_LAUNCH_FAST_BK(128, true, 128); else DSF_LAUNCH_FAST_BK(128, false, 128); }
+        else { if (w_fwd_layout) DSF_LAUNCH_FAST_BK(64, true, 128); else DSF_LAUNCH_FAST_BK(64, false, 128); }
 #undef DSF_LAUNCH_FAST_BK
 #undef DSF_LAUNCH_FAST
         return dsf_launch_status();
