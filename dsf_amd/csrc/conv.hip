@@ -834,10 +834,13 @@ __global__ __launch_bounds__(256) void igemm_wrw_fast_kernel(const float* __rest
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[APASS], rb[BPASS];
-    auto load_chunk = [&](int mc) {
-#pragma unroll
-        for (int i = 0; i < APASS; ++i) {
+    // two register sets: chunk c + 2 is requested while chunk c + 1 waits in the other set for its LDS stage
+    float4 ra[2][APASS], rb[2][BPASS];
+    constexpr int NPIECE = APASS + BPASS;
+    static_assert(NPIECE <= BKT / 2, "one loader piece per k-step");
+    auto load_piece = [&](auto SET, int i, int mc) {                 // rows past m_end get the out-of-range offset (zeros)
+        constexpr int S = decltype(SET)::value;
+        if (i < APASS) {
             const int m = mc + (t >> 5) + 8 * i;
             const uint32_t mm = (uint32_t)min(m, M - 1);
             const uint32_t q = fast_div(mm, magic_wo);
@@ -846,34 +849,47 @@ __global__ __launch_bounds__(256) void igemm_wrw_fast_kernel(const float* __rest
             const int oy = (int)(q - b * (uint32_t)p.Ho);
             const int iy = oy * p.stride + a_kh - p.pad_h, ix = ox * p.stride + a_kw - p.pad_w;
             const bool ok = a_kok && m < m_end && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-            ra[i] = dsf_buffer_load4(xbuf, ok ? (uint32_t)((((int)b * p.Hi + iy) * p.Wi + ix) * p.Ci + a_c) * 4u : OOB);
-        }
-#pragma unroll
-        for (int i = 0; i < BPASS; ++i) {
-            const int m = mc + b_row + BROWS * i;
+            ra[S][i] = dsf_buffer_load4(xbuf, ok ? (uint32_t)((((int)b * p.Hi + iy) * p.Wi + ix) * p.Ci + a_c) * 4u : OOB);
+        } else {
+            const int j = i - APASS;
+            const int m = mc + b_row + BROWS * j;
             const bool ok = b_nok && m < m_end;
-            rb[i] = dsf_buffer_load4(ybuf, ok ? (uint32_t)(m * p.Co + n0 + b_n4) * 4u : OOB);
+            rb[S][j] = dsf_buffer_load4(ybuf, ok ? (uint32_t)(m * p.Co + n0 + b_n4) * 4u : OOB);
         }
     };
-    auto stage = [&](int buf) {
+    auto load_all = [&](auto SET, int mc) {
 #pragma unroll
-        for (int i = 0; i < APASS; ++i) *reinterpret_cast<float4*>(&As[buf][((t >> 5) + 8 * i) * KT + (t & 31) * 4]) = ra[i];
+        for (int i = 0; i < NPIECE; ++i) load_piece(SET, i, mc);
+    };
+    auto stage = [&](auto SET, int buf) {
+        constexpr int S = decltype(SET)::value;
 #pragma unroll
-        for (int i = 0; i < BPASS; ++i) *reinterpret_cast<float4*>(&Bs[buf][(b_row + BROWS * i) * BN + b_n4]) = rb[i];
+        for (int i = 0; i < APASS; ++i) *reinterpret_cast<float4*>(&As[buf][((t >> 5) + 8 * i) * KT + (t & 31) * 4]) = ra[S][i];
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i) *reinterpret_cast<float4*>(&Bs[buf][(b_row + BROWS * i) * BN + b_n4]) = rb[S][i];
     };
 
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, 1>;
     if (m_begin < m_end) {
-        load_chunk(m_begin);
-        stage(0);
+        load_all(Set0{}, m_begin);
+        load_all(Set1{}, m_begin + BKT);
+        stage(Set0{}, 0);
     }
     __syncthreads();
-    int buf = 0;
-    for (int mc = m_begin; mc < m_end; mc += BKT, buf ^= 1) {
-        const bool more = mc + BKT < m_end;
-        if (more) load_chunk(mc + BKT);
-        mma_chunk<BN, TM, TN, BKT, false>(As[buf], Bs[buf], wm * WM, wn * 64, lane, acc);
-        if (more) stage(buf ^ 1);
+    auto body = [&](auto SET, auto OTHER, int mc) {
+        constexpr int buf = decltype(SET)::value;
+        mma_chunk<BN, TM, TN, BKT, false>(As[buf], Bs[buf], wm * WM, wn * 64, lane, acc, [&](int s) {
+#pragma unroll
+            for (int i = 0; i < NPIECE; ++i)
+                if (i == s) load_piece(SET, i, mc + 2 * BKT);
+        });
+        if (mc + BKT < m_end) stage(OTHER, buf ^ 1);
         __syncthreads();
+    };
+    for (int mc = m_begin; mc < m_end; mc += 2 * BKT) {
+        body(Set0{}, Set1{}, mc);
+        if (mc + BKT < m_end) body(Set1{}, Set0{}, mc + BKT);
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
