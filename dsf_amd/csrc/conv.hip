@@ -547,101 +547,110 @@ __global__ __launch_bounds__(256) void igemm_fwd_dil2_kernel(const float* __rest
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // Live taps of this tile: with a uniform parity class only taps kh == (pad_h - py) mod 2 (and likewise kw) can meet
+    // data, the others read inserted zeros for every row and are never visited.  The K range of a split is cut in this
+    // LIVE chunk space, so split-K partitions carry equal work (cutting the full tap list left some splits empty).
     const int chunks_per_tap = (p.Ci + BKT - 1) / BKT;
-    const int n_chunks = p.KH * p.KW * chunks_per_tap;
+    const bool uniform = tile_py >= 0;
+    const int kh0 = uniform ? ((p.pad_h - tile_py) & 1) : 0, kw0 = uniform ? ((p.pad_w - tile_px) & 1) : 0;
+    const int kstep = uniform ? 2 : 1;
+    const int cnt_h = (p.KH - kh0 + kstep - 1) / kstep, cnt_w = (p.KW - kw0 + kstep - 1) / kstep;
+    const int n_chunks = cnt_h * cnt_w * chunks_per_tap;
     const int per_split = (n_chunks + k_splits - 1) / k_splits;
     const int chunk_lo = ks * per_split, chunk_hi = min(n_chunks, chunk_lo + per_split);
 
-    float4 ra[APASS], rb[WT ? WTPASS : BPASS];
-    // wave-uniform walk state of the chunk being loaded
-    int l_tap = chunk_lo / chunks_per_tap, l_c0 = (chunk_lo % chunks_per_tap) * BKT;
-    int l_kh = l_tap / p.KW, l_kw = l_tap % p.KW;
-    auto tap_dead = [&]() -> bool {                   // every row of this tile reads inserted zeros for this tap
-        return tile_py >= 0 && ((((tile_py + l_kh - p.pad_h) & 1) != 0) || (((tile_px + l_kw - p.pad_w) & 1) != 0));
-    };
-    int l_chunk = chunk_lo;                           // chunk index of the walk state
-    auto skip_dead = [&]() {
-        while (l_chunk < chunk_hi && tap_dead()) {    // jump to the first chunk of the next tap
-            l_chunk += chunks_per_tap - l_c0 / BKT;
-            l_c0 = 0; ++l_tap; ++l_kw;
-            if (l_kw == p.KW) { l_kw = 0; ++l_kh; }
-        }
-    };
+    float4 ra[2][APASS], rb[2][WT ? WTPASS : BPASS];    // two register sets: see igemm_fwd_fast_kernel
+    // wave-uniform walk state of the chunk being loaded (live-chunk index -> live tap -> (kh, kw), channel offset)
+    int l_chunk = chunk_lo;
+    int l_lt = chunk_lo / chunks_per_tap, l_c0 = (chunk_lo % chunks_per_tap) * BKT;
+    int l_kh = kh0 + kstep * (l_lt / cnt_w), l_kw = kw0 + kstep * (l_lt % cnt_w);
+    int l_tap = l_kh * p.KW + l_kw;
     const int vH = (p.Hi - 1) * 2 + 1, vW = (p.Wi - 1) * 2 + 1;
-    auto load_next = [&]() {
-        const bool c_ok = l_c0 + a_k4 < p.Ci;
-#pragma unroll
-        for (int i = 0; i < APASS; ++i) {
+    constexpr int NB = WT ? WTPASS : BPASS, NPIECE = APASS + NB;
+    static_assert(NPIECE <= BKT / 2, "one loader piece per k-step");
+    auto load_piece = [&](auto SET, int i, bool live) {
+        constexpr int S = decltype(SET)::value;
+        const bool c_ok = live && l_c0 + a_k4 < p.Ci;
+        if (i < APASS) {
             const int vy = a_iy[i] + l_kh, vx = a_ix[i] + l_kw;
             const bool ok = c_ok && (unsigned)vy < (unsigned)vH && (unsigned)vx < (unsigned)vW && ((vy | vx) & 1) == 0;
-            ra[i] = dsf_buffer_load4(xbuf, ok ? (uint32_t)(((a_base[i] + (vy >> 1)) * p.Wi + (vx >> 1)) * p.Ci + l_c0 + a_k4) * 4u : OOB);
-        }
-        if (WT) {
+            ra[S][i] = dsf_buffer_load4(xbuf, ok ? (uint32_t)(((a_base[i] + (vy >> 1)) * p.Wi + (vx >> 1)) * p.Ci + l_c0 + a_k4) * 4u : OOB);
+        } else if (WT) {
+            const int j = i - APASS;
             const int tapf = (p.KH - 1 - l_kh) * p.KW + (p.KW - 1 - l_kw);
-#pragma unroll
-            for (int i = 0; i < WTPASS; ++i) {
-                const int n = n0 + a_r + AROWS * i;
-                const bool ok = c_ok && n < p.Co;
-                rb[i] = dsf_buffer_load4(wbuf, ok ? (uint32_t)((tapf * p.Co + n) * p.Ci + l_c0 + a_k4) * 4u : OOB);
-            }
+            const int n = n0 + a_r + AROWS * j;
+            const bool ok = c_ok && n < p.Co;
+            rb[S][j] = dsf_buffer_load4(wbuf, ok ? (uint32_t)((tapf * p.Co + n) * p.Ci + l_c0 + a_k4) * 4u : OOB);
         } else {
+            const int j = i - APASS;
             const int wrow = l_tap * p.Ci + l_c0;
-#pragma unroll
-            for (int i = 0; i < BPASS; ++i) {
-                const int kk = b_row + BROWS * i;
-                const bool ok = b_nok && (l_c0 + kk < p.Ci);
-                rb[i] = dsf_buffer_load4(wbuf, ok ? (uint32_t)((wrow + kk) * p.Co + n0 + b_n4) * 4u : OOB);
+            const int kk = b_row + BROWS * j;
+            const bool ok = live && b_nok && (l_c0 + kk < p.Ci);
+            rb[S][j] = dsf_buffer_load4(wbuf, ok ? (uint32_t)((wrow + kk) * p.Co + n0 + b_n4) * 4u : OOB);
+        }
+        if (i == NPIECE - 1 && live) {                              // advance (scalar) to the next live chunk
+            l_c0 += BKT; ++l_chunk;
+            if (l_c0 >= p.Ci) {
+                l_c0 = 0; l_kw += kstep;
+                if (l_kw >= p.KW) { l_kw = kw0; l_kh += kstep; }
+                l_tap = l_kh * p.KW + l_kw;
             }
         }
-        // advance (scalar)
-        l_c0 += BKT; ++l_chunk;
-        if (l_c0 >= p.Ci) {
-            l_c0 = 0; ++l_tap; ++l_kw;
-            if (l_kw == p.KW) { l_kw = 0; ++l_kh; }
-        }
-        skip_dead();
     };
-    auto stage = [&](int buf) {
+    auto load_all = [&](auto SET, bool live) {
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) load_piece(SET, i, live);
+    };
+    auto stage = [&](auto SET, int buf) {
+        constexpr int S = decltype(SET)::value;
         float* Asb = As[buf];
         float* Bsb = Bs[buf];
         const int swz = lds_swz<BKT>(a_k4);
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
             const int r = (a_r + AROWS * i) ^ swz;
-            Asb[(a_k4 + 0) * BM + r] = ra[i].x; Asb[(a_k4 + 1) * BM + r] = ra[i].y;
-            Asb[(a_k4 + 2) * BM + r] = ra[i].z; Asb[(a_k4 + 3) * BM + r] = ra[i].w;
+            Asb[(a_k4 + 0) * BM + r] = ra[S][i].x; Asb[(a_k4 + 1) * BM + r] = ra[S][i].y;
+            Asb[(a_k4 + 2) * BM + r] = ra[S][i].z; Asb[(a_k4 + 3) * BM + r] = ra[S][i].w;
         }
         if (WT) {
 #pragma unroll
             for (int i = 0; i < WTPASS; ++i) {
                 const int c = (a_r + AROWS * i) ^ swz;
-                Bsb[(a_k4 + 0) * BN + c] = rb[i].x; Bsb[(a_k4 + 1) * BN + c] = rb[i].y;
-                Bsb[(a_k4 + 2) * BN + c] = rb[i].z; Bsb[(a_k4 + 3) * BN + c] = rb[i].w;
+                Bsb[(a_k4 + 0) * BN + c] = rb[S][i].x; Bsb[(a_k4 + 1) * BN + c] = rb[S][i].y;
+                Bsb[(a_k4 + 2) * BN + c] = rb[S][i].z; Bsb[(a_k4 + 3) * BN + c] = rb[S][i].w;
             }
         } else {
 #pragma unroll
             for (int i = 0; i < BPASS; ++i) {
                 const int kk = b_row + BROWS * i;
-                *reinterpret_cast<float4*>(&Bsb[kk * BN + (b_n4 ^ lds_swz<BKT>(kk))]) = rb[i];
+                *reinterpret_cast<float4*>(&Bsb[kk * BN + (b_n4 ^ lds_swz<BKT>(kk))]) = rb[S][i];
             }
         }
     };
 
-    skip_dead();
-    bool have = l_chunk < chunk_hi;
-    if (have) {
-        load_next();
-        stage(0);
-    }
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, 1>;
+    bool cur = l_chunk < chunk_hi;                    // the chunk about to be computed exists
+    load_all(Set0{}, cur);
+    bool nxt = l_chunk < chunk_hi;                    // ... and the one after it
+    load_all(Set1{}, nxt);
+    if (cur) stage(Set0{}, 0);
     __syncthreads();
-    int buf = 0;
-    while (have) {
-        const bool more = l_chunk < chunk_hi;
-        if (more) load_next();
-        mma_chunk<BN, TM, TN, BKT>(As[buf], Bs[buf], wm * WM, wn * 64, lane, acc);
-        if (more) stage(buf ^ 1);
+    auto body = [&](auto SET, auto OTHER) {
+        constexpr int buf = decltype(SET)::value;
+        const bool live2 = l_chunk < chunk_hi;        // the walk stands at the chunk two ahead
+        mma_chunk<BN, TM, TN, BKT>(As[buf], Bs[buf], wm * WM, wn * 64, lane, acc, [&](int s) {
+#pragma unroll
+            for (int i = 0; i < NPIECE; ++i)
+                if (i == s) load_piece(SET, i, live2);
+        });
+        if (nxt) stage(OTHER, buf ^ 1);
         __syncthreads();
-        have = more; buf ^= 1;
+        cur = nxt; nxt = live2;
+    };
+    while (cur) {
+        body(Set0{}, Set1{});
+        if (cur) body(Set1{}, Set0{});
     }
 
 #pragma unroll

@@ -262,17 +262,21 @@ def replay(rec, iters=3):
 
 
 def kernel_name(rec):
-    """Name of the kernel conv.hip launches for a recorded call, as rocprofv3 prints it (mirrors the host heuristics)."""
+    """Name of the kernel conv.hip launches for a recorded call, as rocprofv3 prints it (mirrors the host heuristics of
+    conv_forward_impl / dsf_conv_igemm_wrw: tile rows BMT, stage depth BKT)."""
     kind, B, Hi, Wi, Ci, Ho, Wo, Co = rec[:8]
     dil = rec[11]
     bn = 128 if Co > 64 else 64
     M = B * Ho * Wo
-    tiles = ((M + 127) // 128) * ((Co + bn - 1) // bn)
+    n_tiles = (Co + bn - 1) // bn
     vec = Ci % 4 == 0 and Co % 4 == 0
     if kind in ("fwd", "fwd_wt", "bwd_s1"):
         wt = "false" if kind == "fwd" else "true"
         if dil == 1 and Ci >= 32 and vec:
-            return "igemm_fwd_fast_kernel<%d, %s, %d>" % (bn, wt, 16 if tiles >= 1024 else 32)
+            bmt = 64 if (bn == 128 and ((M + 127) // 128) * n_tiles < 512) else 128
+            tiles = ((M + bmt - 1) // bmt) * n_tiles
+            return "igemm_fwd_fast_kernel<%d, %s, %d, %d>" % (bn, wt, 16 if tiles >= 1024 else 32, bmt)
+        tiles = ((M + 127) // 128) * n_tiles
         if dil == 2 and Ci >= 32 and vec and Ho % 2 == 0 and Wo % 2 == 0:
             return "igemm_fwd_dil2_kernel<%d, %d, %s>" % (bn, 16 if (tiles >= 1024 and bn == 128) else 32, wt)
         return "igemm_fwd_kernel<%d, %s>" % (bn, "true" if (Ci < 32 and dil == 1) else "false")
