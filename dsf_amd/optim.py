@@ -1,0 +1,117 @@
+"""AdamW with the whole parameter set updated by ONE kernel launch (``dsf_adamw_multi``).
+
+Drop-in for ``torch.optim.AdamW(params, lr, betas, eps, weight_decay)`` as the reference constructs it
+(train_render.py:131-139; amsgrad / maximize / capturable are not used there and not supported here): same
+hyper-parameter names, ``param_groups``, ``state_dict`` layout (``step``, ``exp_avg``, ``exp_avg_sq`` per parameter), so
+``StepLR`` and checkpoints work unchanged.  GPU fp32 dense parameters only; anything else raises."""
+import ctypes
+import math
+
+import torch
+
+from . import _lib as L
+from ._lib import I, check, stream_ptr
+
+D = ctypes.c_double
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
+            raise ValueError("invalid AdamW hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._tables = {}
+
+    def _table(self, gi, plist):
+        """static per-group chunk table + reusable pointer buffers (host pinned, device)"""
+        key = (gi, tuple(id(p) for p in plist))
+        tb = self._tables.get(gi)
+        if tb is not None and tb["key"] == key:
+            return tb
+        dev = plist[0].device
+        E = int(L.lib().dsf_adamw_chunk_elems())
+        ct, ci = [], []
+        for t, p in enumerate(plist):
+            n = (p.numel() + E - 1) // E
+            ct += [t] * n
+            ci += list(range(n))
+        tb = {"key": key,
+              "chunk_tensor": torch.tensor(ct, dtype=torch.int32, device=dev), "chunk_index": torch.tensor(ci, dtype=torch.int32, device=dev),
+              "sizes": torch.tensor([p.numel() for p in plist], dtype=torch.int64, device=dev), "n_chunks": len(ct),
+              "rows": None, "ptrs": torch.empty((len(plist), 4), dtype=torch.int64, device=dev)}
+        self._tables[gi] = tb
+        return tb
+
+    def _prepare(self, gi, group):
+        """per-group cache: parameters with gradients, their state tensors and the shared step count"""
+        plist = [p for p in group["params"] if p.grad is not None]
+        for p in plist:
+            if not (p.is_cuda and p.dtype == torch.float32) or p.grad.is_sparse:
+                raise RuntimeError("FusedAdamW handles dense fp32 GPU parameters only")
+            st = self.state[p]
+            if not st:
+                st["step"] = torch.tensor(0.0)                           # host scalar, as torch's non-capturable AdamW keeps it
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            if st["exp_avg"].stride() != p.stride():                     # e.g. state loaded from a checkpoint: adopt the parameter's layout
+                st["exp_avg"] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(st["exp_avg"])
+                st["exp_avg_sq"] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(st["exp_avg_sq"])
+        steps = {int(self.state[p]["step"]) for p in plist}
+        if len(steps) > 1:
+            raise RuntimeError("FusedAdamW: parameters of one group must share a step count")
+        return {"plist": plist, "ids": tuple(id(p) for p in plist), "step": steps.pop() if steps else 0,
+                "m": [self.state[p]["exp_avg"] for p in plist], "v": [self.state[p]["exp_avg_sq"] for p in plist]}
+
+    def _sync_steps(self):
+        """the per-parameter `step` entries of the state dict are refreshed from the per-group counters on demand"""
+        for c in getattr(self, "_cache", {}).values():
+            for p in c["plist"]:
+                self.state[p]["step"].fill_(float(c["step"]))
+
+    def state_dict(self):
+        self._sync_steps()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._cache, self._tables = {}, {}
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if not hasattr(self, "_cache"):
+            self._cache = {}
+        for gi, group in enumerate(self.param_groups):
+            c = self._cache.get(gi)
+            if c is None or c["ids"] != tuple(id(p) for p in group["params"] if p.grad is not None):
+                if c is not None:
+                    self._sync_steps()
+                c = self._cache[gi] = self._prepare(gi, group)
+            plist = c["plist"]
+            if not plist:
+                continue
+            b1, b2 = group["betas"]
+            c["step"] += 1
+            step = c["step"]
+            rows = []
+            for p, m, v in zip(plist, c["m"], c["v"]):
+                g = p.grad
+                if g.stride() != p.stride():                             # walk everything in the parameter's memory order
+                    g = torch.empty_like(p, memory_format=torch.preserve_format).copy_(g)
+                    p.grad = g
+                rows.append((p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()))
+            tb = self._table(gi, plist)
+            if rows != tb["rows"]:
+                # addresses changed (first step, or the allocator handed out different gradient blocks): refresh the device
+                # table with a pageable -> device copy, which is staged and therefore safe against the CPU running ahead
+                tb["ptrs"].copy_(torch.tensor(rows, dtype=torch.int64))
+                tb["rows"] = rows
+            vp = lambda t: ctypes.c_void_p(t.data_ptr())
+            check(L.lib().dsf_adamw_multi(vp(tb["ptrs"]), vp(tb["sizes"]), vp(tb["chunk_tensor"]), vp(tb["chunk_index"]),
+                                          I(tb["n_chunks"]), D(group["lr"]), D(b1), D(b2), D(group["eps"]),
+                                          D(group["weight_decay"]), D(1.0 - math.pow(b1, step)), D(1.0 - math.pow(b2, step)),
+                                          stream_ptr()), "dsf_adamw_multi")
+        return loss

@@ -53,6 +53,17 @@ def synthetic_batch(B, device, seed=0, dtype=torch.float32):
     return p.to(device, dtype), center.to(device, dtype), cube.to(device, dtype)
 
 
+def _default_adamw(params, lr, weight_decay):
+    """AdamW as the reference builds it (train_render.py:131-139): the one-launch HIP version on the GPU
+    (dsf_amd.optim.FusedAdamW; DSF_FUSED_ADAMW=0 or CPU parameters: torch.optim.AdamW)."""
+    import os
+    params = list(params)
+    if params and params[0].is_cuda and os.environ.get("DSF_FUSED_ADAMW", "1") == "1":
+        from .optim import FusedAdamW
+        return FusedAdamW(params, lr=lr, weight_decay=weight_decay)
+    return torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay)
+
+
 class RenderSupervisedStep:
     """BASELINE config 2: backbone forward (incl. the stage-2 re-render bridge) -> per stage the
     pixel-branch losses and the MANO-branch losses of ``Pretrain`` (train_render.py:444-466), plus
@@ -63,7 +74,7 @@ class RenderSupervisedStep:
         self.net, self.render, self.cfg = net, render, config
         self.L1 = SmoothL1Loss()
         self.gfm = GFM()
-        self.opt = optimizer if optimizer is not None else torch.optim.AdamW(net.parameters(), lr=config.lr,
+        self.opt = optimizer if optimizer is not None else _default_adamw(net.parameters(), lr=config.lr,
                                                                              weight_decay=config.weight_decay)
         self.grad_sync = grad_sync                    # dsf_amd.parallel.GradAllReducer or None
         self.utils = TensorUtils(img_size=config.input_size)
@@ -125,7 +136,7 @@ class MeshLossStep:
     def __init__(self, net, render, config=Config, optimizer=None, grad_sync=None, n_points=2048):
         self.net, self.render, self.cfg, self.n_points = net, render, config, n_points
         self.L1 = SmoothL1Loss()
-        self.opt = optimizer if optimizer is not None else torch.optim.AdamW(net.parameters(), lr=config.lr,
+        self.opt = optimizer if optimizer is not None else _default_adamw(net.parameters(), lr=config.lr,
                                                                              weight_decay=config.weight_decay)
         self.grad_sync = grad_sync
         self.utils = TensorUtils(img_size=config.input_size)
@@ -192,7 +203,7 @@ class FinetuneStageStep:
         self.net, self.render, self.transfer, self.cfg, self.mask = net, render, transfer_net, config, mask
         self.L1 = SmoothL1Loss()
         self.gfm = GFM()
-        self.opt = optimizer if optimizer is not None else torch.optim.AdamW(net.parameters(), lr=config.lr,
+        self.opt = optimizer if optimizer is not None else _default_adamw(net.parameters(), lr=config.lr,
                                                                              weight_decay=config.weight_decay)
         self.grad_sync = grad_sync
         self.utils = TensorUtils(img_size=config.input_size)

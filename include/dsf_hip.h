@@ -343,6 +343,19 @@ int dsf_bn_backward(const float* x, const float* grad_y, const float* y, const f
 int64_t dsf_col_sum_workspace_bytes(int C);
 int dsf_col_sum(const float* x, int64_t M, int C, float* out, float* workspace, dsf_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * AdamW step of every parameter tensor in one launch (torch.optim.AdamW as constructed at train_render.py:131-139;
+ * arithmetic of torch/optim/adamw.py, amsgrad off): ptrs (T,4) device array of {param, grad, exp_avg, exp_avg_sq}
+ * addresses (fp32, one dense layout per tensor, walked in memory order), sizes (T) element counts, and the static
+ * chunk table: chunk c covers elements [chunk_index[c] * E, +E) of tensor chunk_tensor[c], E = dsf_adamw_chunk_elems().
+ * bias_correction{1,2} = 1 - beta^step are computed by the caller (no device-side step counter, no sync); scalars are
+ * doubles so that derived factors (1 - beta2, lr / bias_correction1, ...) are rounded to fp32 once, as torch does.
+ * ---------------------------------------------------------------------------------- */
+int dsf_adamw_chunk_elems(void);
+int dsf_adamw_multi(const uint64_t* ptrs, const int64_t* sizes, const int32_t* chunk_tensor,
+                    const int32_t* chunk_index, int n_chunks, double lr, double beta1, double beta2, double eps,
+                    double weight_decay, double bias_correction1, double bias_correction2, dsf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -84,3 +84,33 @@ def test_fused_heads_equal_separate_heads():
     g2 = torch.autograd.grad(y2, [x] + params, gy)
     for a, b in zip(g1, g2):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))
+
+
+def test_fused_adamw_matches_torch_adamw():
+    from dsf_amd.optim import FusedAdamW
+    from dsf_amd.nn_conv import kernel_layout_
+    torch.manual_seed(11)
+    shapes = [(64, 32, 3, 3), (257,), (5000, 3), (1,), (84, 256, 1, 1)]
+    pa = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    kernel_layout_(pa[0], (2, 3, 1, 0))                                 # a parameter with the conv kernels' memory order
+    pb = [torch.nn.Parameter(p.detach().clone(memory_format=torch.preserve_format)) for p in pa]
+    oa = FusedAdamW(pa, lr=1e-3, weight_decay=0.01)
+    ob = torch.optim.AdamW(pb, lr=1e-3, weight_decay=0.01)
+    sched = torch.optim.lr_scheduler.StepLR(oa, step_size=2, gamma=0.5)
+    schedb = torch.optim.lr_scheduler.StepLR(ob, step_size=2, gamma=0.5)
+    for it in range(5):
+        for a, b in zip(pa, pb):
+            g = torch.randn(a.shape, device="cuda") * (10.0 ** (it - 2))
+            a.grad = g.clone() if it % 2 else g.clone().contiguous()
+            b.grad = g.clone()
+        oa.step(); ob.step(); sched.step(); schedb.step()
+        for a, b in zip(pa, pb):
+            assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), (it, a.shape, float((a - b).abs().max()))
+    sa, sb = oa.state_dict(), ob.state_dict()
+    assert sa["param_groups"][0]["lr"] == sb["param_groups"][0]["lr"]
+    for k in sb["state"]:
+        ea, eb = sa["state"][k]["exp_avg"], sb["state"][k]["exp_avg"]            # torch's lerp may contract to an fma
+        assert torch.allclose(ea, eb, rtol=1e-5, atol=1e-6 * float(eb.abs().max()))
+        va, vb = sa["state"][k]["exp_avg_sq"], sb["state"][k]["exp_avg_sq"]
+        assert torch.allclose(va, vb, rtol=1e-5, atol=1e-6 * float(vb.abs().max()))
+        assert float(sa["state"][k]["step"]) == float(sb["state"][k]["step"]) == 5.0
