@@ -76,7 +76,24 @@ def ptr(t):
         raise RuntimeError("dsf_amd ops run on the GPU only (got a %s tensor); there is no CPU path" % t.device)
     if not t.is_contiguous():
         raise RuntimeError("dsf_amd ops need contiguous tensors")
+    if t.numel() == 0:                                   # empty batch: a valid (never dereferenced) address instead of NULL
+        return ctypes.c_void_p(_dummy(t.device).data_ptr())
     return ctypes.c_void_p(t.data_ptr())
+
+
+def addr(t):
+    """Device address of a (possibly strided / empty) GPU tensor's first element, for launchers that take strides."""
+    return ctypes.c_void_p(t.data_ptr() if t.numel() else _dummy(t.device).data_ptr())
+
+
+_DUMMY = {}
+
+
+def _dummy(device):
+    d = _DUMMY.get(device.index)
+    if d is None:
+        d = _DUMMY[device.index] = torch.zeros(16, device=device)
+    return d
 
 
 def f32(t):

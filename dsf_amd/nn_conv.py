@@ -64,6 +64,8 @@ def ptr_nhwc(t):
                            "a plain torch.nn CPU twin" % t.device)
     assert t.is_contiguous(memory_format=CL) or t.is_contiguous()
     import ctypes
+    if t.numel() == 0:                                   # empty batch: a valid (never dereferenced) address instead of NULL
+        return ctypes.c_void_p(L._dummy(t.device).data_ptr())
     return ctypes.c_void_p(t.data_ptr())
 
 

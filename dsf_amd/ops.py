@@ -385,12 +385,12 @@ class Joint2Offset(Function):
     def forward(ctx, joints, img, kernel_size, S, channels_last=False):
         joints, img = f32(joints), f32(img)
         B = img.shape[0]
-        joints = joints.reshape(B, -1, 3)
+        joints = joints.reshape(B, -1, 3) if B else joints.reshape(0, joints.shape[-2] if joints.dim() >= 2 else 0, 3)
         J, H = joints.shape[1], img.shape[-1]
         maps = torch.empty((B, 4 * J, S, S), device=img.device, dtype=torch.float32,
                            memory_format=torch.channels_last if channels_last else torch.contiguous_format)
         check(L.lib().dsf_joint2offset_forward(ptr(joints), ptr(img), I(B), I(J), I(H), I(S), F(kernel_size),
-                                               ctypes.c_void_p(maps.data_ptr()), _map_strides(maps), stream_ptr()),
+                                               L.addr(maps), _map_strides(maps), stream_ptr()),
               "dsf_joint2offset_forward")
         ctx.save_for_backward(joints, img)
         ctx.args = (kernel_size, S)
@@ -409,7 +409,7 @@ class Joint2Offset(Function):
         if st is None:
             g = g.contiguous()
             st = _map_strides(g)
-        check(L.lib().dsf_joint2offset_backward(ptr(joints), ptr(img), ctypes.c_void_p(g.data_ptr()), I(B), I(J),
+        check(L.lib().dsf_joint2offset_backward(ptr(joints), ptr(img), L.addr(g), I(B), I(J),
                                                 I(img.shape[-1]), I(S), F(ks), ptr(gj), st, stream_ptr()),
               "dsf_joint2offset_backward")
         return gj, None, None, None, None
@@ -425,7 +425,7 @@ class HuberMean(Function):
         n = x.numel()
         loss = torch.empty((), device=x.device, dtype=torch.float32)
         ws = torch.empty(1024, device=x.device, dtype=torch.float32) if n > 4096 else None
-        check(L.lib().dsf_huber_mean_forward(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), I64(n), F(delta),
+        check(L.lib().dsf_huber_mean_forward(L.addr(x), L.addr(y), I64(n), F(delta),
                                              F(scale), ptr(loss), ptr(ws), stream_ptr()), "dsf_huber_mean_forward")
         ctx.save_for_backward(x, y)
         ctx.args = (delta, scale)
@@ -438,9 +438,9 @@ class HuberMean(Function):
         delta, scale = ctx.args
         gx = torch.empty_like(x)                      # preserve_format: same dense strides as x
         assert gx.stride() == x.stride()
-        check(L.lib().dsf_huber_mean_backward(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()),
+        check(L.lib().dsf_huber_mean_backward(L.addr(x), L.addr(y),
                                               ptr(f32(g)), I64(x.numel()), F(delta), F(scale),
-                                              ctypes.c_void_p(gx.data_ptr()), stream_ptr()), "dsf_huber_mean_backward")
+                                              L.addr(gx), stream_ptr()), "dsf_huber_mean_backward")
         return gx, None, None, None
 
 
