@@ -79,7 +79,7 @@ __device__ __forceinline__ void rodrigues_bwd(const float* th, const float* G, f
 __global__ __launch_bounds__(256) void mano_fwd_kernel(dsf_mano_model m, const float* __restrict__ beta,
                                                        const float* __restrict__ theta,
                                                        const float* __restrict__ rot,
-                                                       const float* __restrict__ cam, int ncomp, int rot_dim,
+                                                       const float* __restrict__ cam, int ncomp, int rot_dim, int ps,
                                                        float k1, float k2, float* __restrict__ verts,
                                                        float* __restrict__ joints, float* __restrict__ Rs_out,
                                                        float* __restrict__ save) {
@@ -89,9 +89,12 @@ __global__ __launch_bounds__(256) void mano_fwd_kernel(dsf_mano_model m, const f
     __shared__ float s_R[16 * 9], s_J[48], s_G[16 * 12], s_A[16 * 12], s_jnt[63];
     const int b = blockIdx.x, t = threadIdx.x;
 
-    if (t < 10) s_beta[t] = beta[b * 10 + t];
-    if (t >= 64 && t < 64 + ncomp) s_theta[t - 64] = theta[b * ncomp + t - 64];
-    if (t >= 128 && t < 128 + rot_dim) s_rot[t - 128] = rot[b * rot_dim + t - 128];
+    // ps: floats between consecutive samples of beta / theta / rot / cam (0 = each array tightly packed); the four
+    // pointers may be column offsets into one (B, 62) parameter matrix
+    const int sb = ps ? ps : 10, st = ps ? ps : ncomp, sr = ps ? ps : rot_dim, scam = ps ? ps : 4;
+    if (t < 10) s_beta[t] = beta[b * sb + t];
+    if (t >= 64 && t < 64 + ncomp) s_theta[t - 64] = theta[b * st + t - 64];
+    if (t >= 128 && t < 128 + rot_dim) s_rot[t - 128] = rot[b * sr + t - 128];
     __syncthreads();
 
     // full pose = theta . comp[:ncomp] + mean (:601); rest joints J = J_template + beta . J_shapedirs
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(256) void mano_fwd_kernel(dsf_mano_model m, const f
     __syncthreads();
 
     float sc = 1.f, tr[3] = {0.f, 0.f, 0.f};
-    if (cam) { sc = cam[b * 4]; tr[0] = cam[b * 4 + 1]; tr[1] = cam[b * 4 + 2]; tr[2] = cam[b * 4 + 3]; }
+    if (cam) { sc = cam[b * scam]; tr[0] = cam[b * scam + 1]; tr[1] = cam[b * scam + 2]; tr[2] = cam[b * scam + 3]; }
     for (int e = t; e < NEO; e += 256) verts[(size_t)b * NEO + e] = ((s_v[e] * k1) * k2) * sc + tr[e % 3];
     if (t < 63) joints[b * 63 + t] = ((s_jnt[t] * k1) * k2) * sc + tr[t % 3];
     if (Rs_out && t < 135) Rs_out[b * 135 + t] = s_R[9 + t];
@@ -227,9 +230,10 @@ __global__ __launch_bounds__(256) void mano_bwd_kernel(dsf_mano_model m, const f
                                                        const float* __restrict__ cam,
                                                        const float* __restrict__ save,
                                                        const float* __restrict__ gV, const float* __restrict__ gJ,
-                                                       int ncomp, int rot_dim, float k1, float k2,
+                                                       int ncomp, int rot_dim, int ps, float k1, float k2,
                                                        float* __restrict__ g_beta, float* __restrict__ g_theta,
                                                        float* __restrict__ g_rot, float* __restrict__ g_cam) {
+    const int sb = ps ? ps : 10, st = ps ? ps : ncomp, sr = ps ? ps : rot_dim, scam = ps ? ps : 4;    // as in mano_fwd_kernel
     __shared__ float s_gv[NEO];
     __shared__ float s_gvp[NE];
     __shared__ float s_vp[NE];
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(256) void mano_bwd_kernel(dsf_mano_model m, const f
     __shared__ float s_part[135 * 4], s_partb[10 * 4], s_red[4 * 4], s_gthf[45];
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const float* sv = save + (size_t)b * DSF_MANO_SAVE_FLOATS;
-    const float sc = cam ? cam[b * 4] : 1.f;
+    const float sc = cam ? cam[b * scam] : 1.f;
     const float kk = k1 * k2;
 
     // ---- upstream grads, d/d(cam) ----
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(256) void mano_bwd_kernel(dsf_mano_model m, const f
         if (lane == 0) { s_red[wave * 4] = acc_s; s_red[wave * 4 + 1] = acc_t[0]; s_red[wave * 4 + 2] = acc_t[1]; s_red[wave * 4 + 3] = acc_t[2]; }
     }
     __syncthreads();
-    if (g_cam && t < 4) g_cam[b * 4 + t] = s_red[t] + s_red[4 + t] + s_red[8 + t] + s_red[12 + t];
+    if (g_cam && t < 4) g_cam[b * scam + t] = s_red[t] + s_red[4 + t] + s_red[8 + t] + s_red[12 + t];
 
     // ---- wrist cap (:636) and joint regression (:630-633) ----
     if (t < 3) {
@@ -384,7 +388,7 @@ __global__ __launch_bounds__(256) void mano_bwd_kernel(dsf_mano_model m, const f
         const int s = t - 192;
         float acc = s_partb[s * 4] + s_partb[s * 4 + 1] + s_partb[s * 4 + 2] + s_partb[s * 4 + 3];
         for (int k = 0; k < 48; ++k) acc = fmaf(m.j_shapedirs[s * 48 + k], s_gJ16[k], acc);
-        g_beta[b * 10 + s] = acc;
+        g_beta[b * sb + s] = acc;
     }
     __syncthreads();
 
@@ -393,11 +397,11 @@ __global__ __launch_bounds__(256) void mano_bwd_kernel(dsf_mano_model m, const f
         if (t == 0) {
             float g[4];
             if (rot_dim == 3) {
-                rodrigues_bwd(rot + b * 3, s_gR, g);
-                g_rot[b * 3] = g[0]; g_rot[b * 3 + 1] = g[1]; g_rot[b * 3 + 2] = g[2];
+                rodrigues_bwd(rot + b * sr, s_gR, g);
+                g_rot[b * sr] = g[0]; g_rot[b * sr + 1] = g[1]; g_rot[b * sr + 2] = g[2];
             } else {
-                quat_bwd(rot + b * 4, s_gR, g);
-                g_rot[b * 4] = g[0]; g_rot[b * 4 + 1] = g[1]; g_rot[b * 4 + 2] = g[2]; g_rot[b * 4 + 3] = g[3];
+                quat_bwd(rot + b * sr, s_gR, g);
+                g_rot[b * sr] = g[0]; g_rot[b * sr + 1] = g[1]; g_rot[b * sr + 2] = g[2]; g_rot[b * sr + 3] = g[3];
             }
         } else {
             rodrigues_bwd(s_thf + (t - 1) * 3, s_gR + t * 9, s_gthf + (t - 1) * 3);
@@ -407,32 +411,32 @@ __global__ __launch_bounds__(256) void mano_bwd_kernel(dsf_mano_model m, const f
     if (t < ncomp) {
         float acc = 0.f;
         for (int k = 0; k < 45; ++k) acc = fmaf(m.hands_comp[t * 45 + k], s_gthf[k], acc);
-        g_theta[b * ncomp + t] = acc;
+        g_theta[b * st + t] = acc;
     }
 }
 
 }  // namespace
 
 extern "C" int dsf_mano_forward(const dsf_mano_model* m, const float* beta, const float* theta, const float* rot,
-                                const float* cam, int B, int ncomp, int rot_dim, float k1, float k2, float* verts,
-                                float* joints, float* Rs, float* save, dsf_stream_t stream) {
+                                const float* cam, int B, int ncomp, int rot_dim, int param_stride, float k1, float k2,
+                                float* verts, float* joints, float* Rs, float* save, dsf_stream_t stream) {
     DSF_CHECK_ARG(m && beta && theta && rot && verts && joints);
-    DSF_CHECK_ARG(B >= 0 && ncomp >= 0 && ncomp <= 45 && (rot_dim == 3 || rot_dim == 4));
+    DSF_CHECK_ARG(B >= 0 && ncomp >= 0 && ncomp <= 45 && (rot_dim == 3 || rot_dim == 4) && param_stride >= 0);
     if (B == 0) return DSF_OK;
     hipLaunchKernelGGL(mano_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, *m, beta, theta, rot, cam, ncomp,
-                       rot_dim, k1, k2, verts, joints, Rs, save);
+                       rot_dim, param_stride, k1, k2, verts, joints, Rs, save);
     return dsf_launch_status();
 }
 
 extern "C" int dsf_mano_backward(const dsf_mano_model* m, const float* theta, const float* rot, const float* cam,
                                  const float* save, const float* grad_verts, const float* grad_joints, int B,
-                                 int ncomp, int rot_dim, float k1, float k2, float* grad_beta, float* grad_theta,
-                                 float* grad_rot, float* grad_cam, dsf_stream_t stream) {
+                                 int ncomp, int rot_dim, int param_stride, float k1, float k2, float* grad_beta,
+                                 float* grad_theta, float* grad_rot, float* grad_cam, dsf_stream_t stream) {
     DSF_CHECK_ARG(m && rot && save && grad_beta && grad_theta && grad_rot);
-    DSF_CHECK_ARG(B >= 0 && ncomp >= 0 && ncomp <= 45 && (rot_dim == 3 || rot_dim == 4));
+    DSF_CHECK_ARG(B >= 0 && ncomp >= 0 && ncomp <= 45 && (rot_dim == 3 || rot_dim == 4) && param_stride >= 0);
     DSF_CHECK_ARG(!(grad_cam && !cam));
     if (B == 0) return DSF_OK;
     hipLaunchKernelGGL(mano_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, *m, theta, rot, cam, save,
-                       grad_verts, grad_joints, ncomp, rot_dim, k1, k2, grad_beta, grad_theta, grad_rot, grad_cam);
+                       grad_verts, grad_joints, ncomp, rot_dim, param_stride, k1, k2, grad_beta, grad_theta, grad_rot, grad_cam);
     return dsf_launch_status();
 }

@@ -36,7 +36,7 @@ class ManoFunction(Function):
         need_grad = any(ctx.needs_input_grad[1:5])
         save = _empty((B, SAVE_FLOATS), beta) if need_grad else None
         check(L.lib().dsf_mano_forward(ctypes.byref(model.c_struct), ptr(beta), ptr(theta), ptr(rot), ptr(cam), I(B),
-                                       I(ncomp), I(rot_dim), F(k1), F(k2), ptr(verts), ptr(joints), ptr(Rs),
+                                       I(ncomp), I(rot_dim), I(0), F(k1), F(k2), ptr(verts), ptr(joints), ptr(Rs),
                                        ptr(save), stream_ptr()), "dsf_mano_forward")
         ctx.model, ctx.k = model, (k1, k2)
         ctx.has_cam = cam is not None
@@ -57,10 +57,50 @@ class ManoFunction(Function):
         g_cam = _empty((B, 4), theta) if ctx.has_cam else None
         k1, k2 = ctx.k
         check(L.lib().dsf_mano_backward(ctypes.byref(ctx.model.c_struct), ptr(theta), ptr(rot), ptr(cam), ptr(save),
-                                        ptr(g_verts), ptr(g_joints), I(B), I(ncomp), I(rot_dim), F(k1), F(k2),
+                                        ptr(g_verts), ptr(g_joints), I(B), I(ncomp), I(rot_dim), I(0), F(k1), F(k2),
                                         ptr(g_beta), ptr(g_theta), ptr(g_rot), ptr(g_cam), stream_ptr()),
               "dsf_mano_backward")
         return None, g_beta, g_theta, g_rot, g_cam, None, None
+
+
+class ManoPackedFunction(Function):
+    """ManoFunction on the network's packed parameter rows (B, 3|4 + 45 + 10 + 4) = [rot | theta | beta | cam]
+    (Render._split's layout): the kernels read the four fields as column offsets of one row and write one gradient row,
+    so the ~12 slice / contiguous / zero-fill / add kernels per call of the sliced formulation disappear."""
+
+    @staticmethod
+    def forward(ctx, model, paras, k1, k2):
+        paras = f32(paras)
+        B, W = paras.shape
+        rot_dim = W - 59
+        assert rot_dim in (3, 4)
+        verts = _empty((B, 779, 3), paras)
+        joints = _empty((B, 21, 3), paras)
+        save = _empty((B, SAVE_FLOATS), paras) if ctx.needs_input_grad[1] else None
+        col = lambda c: ctypes.c_void_p((paras.data_ptr() if B else L._dummy(paras.device).data_ptr()) + 4 * c)
+        check(L.lib().dsf_mano_forward(ctypes.byref(model.c_struct), col(rot_dim + 45), col(rot_dim), col(0), col(rot_dim + 55),
+                                       I(B), I(45), I(rot_dim), I(W), F(k1), F(k2), ptr(verts), ptr(joints), ptr(None),
+                                       ptr(save), stream_ptr()), "dsf_mano_forward")
+        ctx.model, ctx.k = model, (k1, k2)
+        ctx.save_for_backward(paras, save)
+        return verts, joints
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_verts, g_joints):
+        paras, save = ctx.saved_tensors
+        B, W = paras.shape
+        rot_dim = W - 59
+        g_verts = f32(g_verts) if g_verts is not None else None
+        g_joints = f32(g_joints) if g_joints is not None else None
+        g = _empty((B, W), paras)                                        # every column is written by the kernel
+        base = lambda t, c: ctypes.c_void_p((t.data_ptr() if B else L._dummy(t.device).data_ptr()) + 4 * c)
+        k1, k2 = ctx.k
+        check(L.lib().dsf_mano_backward(ctypes.byref(ctx.model.c_struct), base(paras, rot_dim), base(paras, 0),
+                                        base(paras, rot_dim + 55), ptr(save), ptr(g_verts), ptr(g_joints), I(B), I(45),
+                                        I(rot_dim), I(W), F(k1), F(k2), base(g, rot_dim + 45), base(g, rot_dim), base(g, 0),
+                                        base(g, rot_dim + 55), stream_ptr()), "dsf_mano_backward")
+        return None, g, None, None
 
 
 # --------------------------------------------------------------------------------------------

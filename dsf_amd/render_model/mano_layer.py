@@ -240,6 +240,12 @@ class MANO_SMPL(nn.Module):
         verts, joints, Rs = ops.ManoFunction.apply(self._native(), beta, theta, quat_or_euler, None, 1.0, 1.0)
         return (verts, joints, Rs) if get_skin else joints
 
+    def get_mano_vertices_packed(self, model_paras, global_scale=None):
+        """get_mano_vertices on packed rows [rot 3|4, theta 45, beta 10, cam 4] (the network's output / Render._split
+        layout) without slicing them apart: same values, one kernel each way."""
+        k2 = 1.0 if global_scale is None else float(global_scale)
+        return ops.ManoPackedFunction.apply(self._native(), model_paras, 1000.0, k2)
+
     def get_mano_vertices(self, quat_or_euler, pose, shape, cam, global_scale=None):
         """-> verts (B,779,3), joints (B,21,3) in mm * global_scale * cam scale + cam trans."""
         quat_or_euler, pose, shape = self._as_tensor(quat_or_euler), self._as_tensor(pose), self._as_tensor(shape)
@@ -416,8 +422,7 @@ class Render(nn.Module):
 
     def render(self, model_paras, center3d, cube_size, M=None):
         """MANO params (cube-normalised) -> (img (B,1,128,128), joint_uvd, joint_xyz, mesh_xyz) (reference :1071-1097)."""
-        quat, theta, beta, cam = self._split(model_paras[:, :62])
-        hand_verts, hand_joints = self.mano_layer.get_mano_vertices(quat, theta, beta, cam, global_scale=1 / 125)
+        hand_verts, hand_joints = self.mano_layer.get_mano_vertices_packed(model_paras[:, :62], global_scale=1 / 125)
         hand_verts = hand_verts * cube_size.unsqueeze(1) / 2 + center3d.unsqueeze(1)
         hand_joints = hand_joints * cube_size.unsqueeze(1) / 2 + center3d.unsqueeze(1)
         img, center2d, M, _ = self._depth_crop(hand_verts, center3d, cube_size)
@@ -427,8 +432,7 @@ class Render(nn.Module):
         return img, joint_uvd, joint_xyz, mesh_xyz
 
     def normal_render(self, model_paras, center3d, cube_size):
-        quat, theta, beta, cam = self._split(model_paras[:, :62])
-        hand_verts, hand_joints = self.mano_layer.get_mano_vertices(quat, theta, beta, cam, global_scale=1 / 125)
+        hand_verts, hand_joints = self.mano_layer.get_mano_vertices_packed(model_paras[:, :62], global_scale=1 / 125)
         hand_verts = (hand_verts + 1) / 2 * cube_size.unsqueeze(1) + center3d.unsqueeze(1)
         hand_joints = (hand_joints + 1) / 2 * cube_size.unsqueeze(1) + center3d.unsqueeze(1)
         img, center2d, M, _ = self._depth_crop(hand_verts, center3d, cube_size)
@@ -446,8 +450,7 @@ class Render(nn.Module):
         return img
 
     def get_mesh_xyz(self, model_paras):
-        quat, theta, beta, cam = self._split(model_paras[:, :62])
-        hand_mesh, hand_joints = self.mano_layer.get_mano_vertices(quat, theta, beta, cam, global_scale=1 / 125)
+        hand_mesh, hand_joints = self.mano_layer.get_mano_vertices_packed(model_paras[:, :62], global_scale=1 / 125)
         return hand_joints, hand_mesh
 
     def mesh2img(self, hand_mesh, center3d, cube_size):

@@ -62,17 +62,21 @@ typedef struct dsf_mano_model {
  * out = ((raw * k1) * k2) * cam[0] + cam[1:4]   (k1 = 1000, k2 = global_scale in get_mano_vertices;
  * k1 = k2 = 1 and cam = NULL reproduce MANO_SMPL.forward).
  * verts (B,779,3), joints (B,21,3), Rs (B,15,3,3) (may be NULL), save (B,DSF_MANO_SAVE_FLOATS)
- * (may be NULL when no backward is needed). */
+ * (may be NULL when no backward is needed).
+ * param_stride: floats between consecutive samples of beta / theta / rot / cam; 0 = each array tightly packed.  With
+ * param_stride = 62 the four pointers can be column offsets into the network's (B,62) output row
+ * [rot 3 | theta 45 | beta 10 | cam 4] (Render._split, mano_layer.py:1071-1076): no slicing copies. */
 int dsf_mano_forward(const dsf_mano_model* m, const float* beta, const float* theta, const float* rot,
-                     const float* cam, int B, int ncomp, int rot_dim, float k1, float k2,
+                     const float* cam, int B, int ncomp, int rot_dim, int param_stride, float k1, float k2,
                      float* verts, float* joints, float* Rs, float* save, dsf_stream_t stream);
 
 /* grad_verts (B,779,3) / grad_joints (B,21,3): either may be NULL (= zeros).
  * Outputs (all written, not accumulated): grad_beta (B,10), grad_theta (B,ncomp),
- * grad_rot (B,rot_dim), grad_cam (B,4) or NULL. */
+ * grad_rot (B,rot_dim), grad_cam (B,4) or NULL; param_stride applies to the inputs and to the four gradients
+ * (column offsets into one (B,62) gradient row). */
 int dsf_mano_backward(const dsf_mano_model* m, const float* theta, const float* rot, const float* cam,
                       const float* save, const float* grad_verts, const float* grad_joints,
-                      int B, int ncomp, int rot_dim, float k1, float k2,
+                      int B, int ncomp, int rot_dim, int param_stride, float k1, float k2,
                       float* grad_beta, float* grad_theta, float* grad_rot, float* grad_cam,
                       dsf_stream_t stream);
 

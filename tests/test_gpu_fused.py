@@ -114,3 +114,24 @@ def test_fused_adamw_matches_torch_adamw():
         va, vb = sa["state"][k]["exp_avg_sq"], sb["state"][k]["exp_avg_sq"]
         assert torch.allclose(va, vb, rtol=1e-5, atol=1e-6 * float(vb.abs().max()))
         assert float(sa["state"][k]["step"]) == float(sb["state"][k]["step"]) == 5.0
+
+
+def test_mano_packed_rows_equal_sliced_call():
+    from dsf_amd.render_model.mano_layer import Render
+    from dsf_amd.train_step import synthetic_batch
+    render = Render("synthetic", "nyu", (588.03, 587.07, 320.0, 240.0), (640, 480)).cuda()
+    mano = render.mano_layer
+    p, _, _ = synthetic_batch(7, "cuda", seed=21)
+    pa = p.clone().requires_grad_(True)
+    pb = p.clone().requires_grad_(True)
+    va, ja = mano.get_mano_vertices_packed(pa, 1 / 125)
+    vb, jb = mano.get_mano_vertices(pb[:, :3], pb[:, 3:48], pb[:, 48:58], pb[:, 58:62], 1 / 125)
+    assert torch.equal(va, vb) and torch.equal(ja, jb)
+    gv, gj = torch.randn_like(va), torch.randn_like(ja)
+    ((va * gv).sum() + (ja * gj).sum()).backward()
+    ((vb * gv).sum() + (jb * gj).sum()).backward()
+    assert torch.equal(pa.grad, pb.grad)
+    # a (B, 64) row block (extra trailing columns are ignored by slicing to 62 first)
+    wide = torch.cat([p, torch.zeros(7, 2, device="cuda")], 1)
+    vc, _ = mano.get_mano_vertices_packed(wide[:, :62].contiguous(), 1 / 125)
+    assert torch.equal(vc, va.detach())
