@@ -1016,10 +1016,13 @@ extern "C" int dsf_conv_igemm_forward_wt(const float* X, const float* Wt, const 
 }
 
 extern "C" int dsf_conv_igemm_wrw(const float* X, const float* dY, float* dW, int B, int Hi, int Wi, int Ci, int Ho, int Wo,
-                                  int Co, int KH, int KW, int stride, int pad_h, int pad_w, dsf_stream_t stream) {
+                                  int Co, int KH, int KW, int stride, int pad_h, int pad_w, int accumulate,
+                                  dsf_stream_t stream) {
     DSF_CHECK_ARG(X && dY && dW && B >= 0 && Hi > 0 && Wi > 0 && Ci > 0 && Ho > 0 && Wo > 0 && Co > 0 && KH > 0 && KW > 0);
     const int K = KH * KW * Ci;
-    if (hipMemsetAsync(dW, 0, sizeof(float) * (size_t)K * Co, (hipStream_t)stream) != hipSuccess) return DSF_ERR_LAUNCH;
+    // accumulate != 0: dW += ... (the caller zeroed it, e.g. one memset over a whole gradient pool, or wants accumulation)
+    if (!accumulate &&
+        hipMemsetAsync(dW, 0, sizeof(float) * (size_t)K * Co, (hipStream_t)stream) != hipSuccess) return DSF_ERR_LAUNCH;
     if (B == 0) return DSF_OK;
     ConvP p = {B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, 1, pad_h, pad_w};
     const int64_t M = (int64_t)B * Ho * Wo;

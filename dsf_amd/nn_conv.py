@@ -41,10 +41,53 @@ def _wrw(x, gy, KH, KW, stride, pad):
     _, Co, Ho, Wo = gy.shape
     if RECORD is not None:
         RECORD.append(("wrw", B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, 1, pad[0], pad[1]))
-    dw = torch.empty((KH, KW, Ci, Co), device=x.device, dtype=torch.float32)
+    dw = _pool_take(KH * KW * Ci * Co, x.device)
+    pooled = dw is not None
+    dw = dw.view(KH, KW, Ci, Co) if pooled else torch.empty((KH, KW, Ci, Co), device=x.device, dtype=torch.float32)
     check(L.lib().dsf_conv_igemm_wrw(ptr_nhwc(x), ptr_nhwc(gy), ptr(dw), I(B), I(Hi), I(Wi), I(Ci), I(Ho), I(Wo), I(Co),
-                                     I(KH), I(KW), I(stride), I(pad[0]), I(pad[1]), stream_ptr()), "dsf_conv_igemm_wrw")
+                                     I(KH), I(KW), I(stride), I(pad[0]), I(pad[1]), I(1 if pooled else 0), stream_ptr()),
+          "dsf_conv_igemm_wrw")
     return dw
+
+
+# ---- weight-gradient pool: one zero-fill per step instead of one memset per layer ------------------------------------
+_POOL = None         # [flat zeroed tensor, next offset]
+
+
+class grad_pool:
+    """``with grad_pool(n_floats, device):`` around a backward pass: the backward-weights kernels (which accumulate their
+    pixel splits with float atomics and therefore need zeroed outputs) take their outputs from ONE pre-zeroed buffer,
+    16-byte aligned slices handed out in call order, instead of zeroing ~50 separate tensors.  The slices stay valid as
+    long as the gradients that view them live; a pool that runs out falls back to per-layer buffers."""
+
+    def __init__(self, n_floats, device):
+        self.n, self.device = int(n_floats), device
+
+    def __enter__(self):
+        global _POOL
+        self.saved = _POOL
+        _POOL = [torch.zeros(self.n, device=self.device, dtype=torch.float32), 0] if self.n > 0 else None
+        return self
+
+    def __exit__(self, *a):
+        global _POOL
+        _POOL = self.saved
+
+
+def _pool_take(n, device):
+    if _POOL is None or _POOL[0].device != device:
+        return None
+    off = _POOL[1]
+    end = off + ((n + 3) & ~3)
+    if end > _POOL[0].numel():
+        return None
+    _POOL[1] = end
+    return _POOL[0][off:off + n]
+
+
+def weight_grad_floats(module):
+    """pool size for one backward pass over ``module``: the weights of its dsf_amd convolution layers"""
+    return sum(((m.weight.numel() + 3) & ~3) for m in module.modules() if isinstance(m, (Conv2d, ConvTranspose2d)))
 
 
 def _bias_grad(gy):

@@ -118,9 +118,14 @@ class RenderSupervisedStep:
         return total + l_m2d, terms
 
     def __call__(self, tgt):
+        from . import nn_conv
         self.opt.zero_grad(set_to_none=True)
         loss, terms = self.loss(tgt)
-        loss.backward()
+        if not hasattr(self, "_pool_floats"):
+            self._pool_floats = nn_conv.weight_grad_floats(self.net) + 64          # fused heads re-lay one merged weight
+            self._pool_dev = next(self.net.parameters()).device
+        with nn_conv.grad_pool(self._pool_floats if self._pool_dev.type == "cuda" else 0, self._pool_dev):
+            loss.backward()
         if self.grad_sync is not None:
             self.grad_sync.finish()
         self.opt.step()

@@ -312,9 +312,11 @@ int dsf_conv_igemm_forward_wt(const float* X, const float* Wt, const float* bias
                               int pad_w, dsf_stream_t stream);
 
 /* dW[(kh*KW+kw)*Ci+c][n] = sum_{b,oy,ox} X[b, oy*stride+kh-pad_h, ox*stride+kw-pad_w, c] * dY[b,oy,ox,n]
- * (zeroed by the call, accumulated with float atomics across the pixel splits). */
+ * (accumulated with float atomics across the pixel splits).  accumulate = 0: dW is zeroed by the call;
+ * accumulate != 0: the sums are added to what dW holds (a caller that zeroes one pool for all layers, or
+ * gradient accumulation). */
 int dsf_conv_igemm_wrw(const float* X, const float* dY, float* dW, int B, int Hi, int Wi, int Ci, int Ho, int Wo,
-                       int Co, int KH, int KW, int stride, int pad_h, int pad_w, dsf_stream_t stream);
+                       int Co, int KH, int KW, int stride, int pad_h, int pad_w, int accumulate, dsf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Fused training-mode BatchNorm2d (+ residual add) (+ ReLU) on NHWC activations, x viewed as (M, C).
