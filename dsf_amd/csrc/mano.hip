@@ -1,6 +1,6 @@
 // K5: fused MANO layer forward / backward for gfx950.
 //
-// One 256-thread workgroup per sample.  The 1.4 MB of model constants
+// One 1024-thread workgroup per sample.  The 1.4 MB of model constants
 // (posedirs 135x2334, shapedirs 10x2334, weights, regressor) are read with
 // lane-contiguous dword loads and stay L2/Infinity-Cache resident across the
 // batch; everything per-sample (v_posed, posed verts, the 16 joint transforms)
@@ -76,7 +76,12 @@ __device__ __forceinline__ void rodrigues_bwd(const float* th, const float* G, f
     gth[2] = gn2 / a + ga * (t2 / a);
 }
 
-__global__ __launch_bounds__(256) void mano_fwd_kernel(dsf_mano_model m, const float* __restrict__ beta,
+// 1024 threads per sample: every element / vertex loop is thread-parallel, and with one workgroup per sample (32 per
+// GPU at the benchmark batch) the launch is latency-bound, so a CU's worth of waves per sample is what hides the 145
+// dependent posedirs loads per element (88 -> see profiles).  Each output is still produced by one thread with an
+// unchanged operation order: results are bit-identical to the 256-thread version.
+constexpr int FWD_NT = 1024;
+__global__ __launch_bounds__(FWD_NT) void mano_fwd_kernel(dsf_mano_model m, const float* __restrict__ beta,
                                                        const float* __restrict__ theta,
                                                        const float* __restrict__ rot,
                                                        const float* __restrict__ cam, int ncomp, int rot_dim, int ps,
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(256) void mano_fwd_kernel(dsf_mano_model m, const f
     __syncthreads();
 
     // v_posed = v_template + beta.shapedirs + pose_feature.posedirs   (:586, :613)
-    for (int e = t; e < NE; e += 256) {
+    for (int e = t; e < NE; e += FWD_NT) {
         float acc = m.v_template[e];
 #pragma unroll
         for (int s = 0; s < 10; ++s) acc = fmaf(s_beta[s], m.shapedirs[s * NE + e], acc);
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(256) void mano_fwd_kernel(dsf_mano_model m, const f
     __syncthreads();
 
     // linear blend skinning (:619-629)
-    for (int v = t; v < NV; v += 256) {
+    for (int v = t; v < NV; v += FWD_NT) {
         float T[12];
 #pragma unroll
         for (int k = 0; k < 12; ++k) T[k] = 0.f;
@@ -210,13 +215,13 @@ __global__ __launch_bounds__(256) void mano_fwd_kernel(dsf_mano_model m, const f
 
     float sc = 1.f, tr[3] = {0.f, 0.f, 0.f};
     if (cam) { sc = cam[b * scam]; tr[0] = cam[b * scam + 1]; tr[1] = cam[b * scam + 2]; tr[2] = cam[b * scam + 3]; }
-    for (int e = t; e < NEO; e += 256) verts[(size_t)b * NEO + e] = ((s_v[e] * k1) * k2) * sc + tr[e % 3];
+    for (int e = t; e < NEO; e += FWD_NT) verts[(size_t)b * NEO + e] = ((s_v[e] * k1) * k2) * sc + tr[e % 3];
     if (t < 63) joints[b * 63 + t] = ((s_jnt[t] * k1) * k2) * sc + tr[t % 3];
     if (Rs_out && t < 135) Rs_out[b * 135 + t] = s_R[9 + t];
     if (save) {
         float* sv = save + (size_t)b * DSF_MANO_SAVE_FLOATS;
-        for (int e = t; e < NE; e += 256) sv[SV_VPOSED + e] = s_vp[e];
-        for (int e = t; e < NEO; e += 256) sv[SV_VERTS + e] = s_v[e];
+        for (int e = t; e < NE; e += FWD_NT) sv[SV_VPOSED + e] = s_vp[e];
+        for (int e = t; e < NEO; e += FWD_NT) sv[SV_VERTS + e] = s_v[e];
         if (t < 63) sv[SV_JOINTS + t] = s_jnt[t];
         if (t < 192) sv[SV_G + t] = s_G[t];
         if (t < 144) sv[SV_RS + t] = s_R[t];
@@ -225,7 +230,10 @@ __global__ __launch_bounds__(256) void mano_fwd_kernel(dsf_mano_model m, const f
     }
 }
 
-__global__ __launch_bounds__(256) void mano_bwd_kernel(dsf_mano_model m, const float* __restrict__ theta,
+// 1024 threads per sample as in the forward; cross-thread reductions keep a fixed order (per-wave partials summed
+// wave 0..15, five vertex lanes per d/dA entry summed 0..4), so the gradients are deterministic.
+constexpr int BWD_NT = 1024, BWD_NW = BWD_NT / 64, BWD_VL = 5, BWD_KPT = (NE + BWD_NT - 1) / BWD_NT;
+__global__ __launch_bounds__(BWD_NT) void mano_bwd_kernel(dsf_mano_model m, const float* __restrict__ theta,
                                                        const float* __restrict__ rot,
                                                        const float* __restrict__ cam,
                                                        const float* __restrict__ save,
@@ -240,7 +248,7 @@ __global__ __launch_bounds__(256) void mano_bwd_kernel(dsf_mano_model m, const f
     __shared__ float s_gj[63];
     __shared__ float s_G[192], s_R[144], s_J[48], s_thf[45];
     __shared__ float s_gA[192], s_gRg[144], s_gt[48], s_gJ16[48], s_gR[144], s_add[9], s_gd[3];
-    __shared__ float s_part[135 * 4], s_partb[10 * 4], s_red[4 * 4], s_gthf[45];
+    __shared__ float s_part[135 * BWD_NW], s_partb[10 * BWD_NW], s_red[BWD_NW * 4], s_gthf[45], s_gAp[BWD_VL * 192];
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const float* sv = save + (size_t)b * DSF_MANO_SAVE_FLOATS;
     const float sc = cam ? cam[b * scam] : 1.f;
@@ -248,7 +256,7 @@ __global__ __launch_bounds__(256) void mano_bwd_kernel(dsf_mano_model m, const f
 
     // ---- upstream grads, d/d(cam) ----
     float acc_s = 0.f, acc_t[3] = {0.f, 0.f, 0.f};
-    for (int e = t; e < NEO; e += 256) {
+    for (int e = t; e < NEO; e += BWD_NT) {
         const float g = gV ? gV[(size_t)b * NEO + e] : 0.f;
         s_gv[e] = g * (kk * sc);
         acc_s += g * ((sv[SV_VERTS + e] * k1) * k2);
@@ -262,7 +270,7 @@ __global__ __launch_bounds__(256) void mano_bwd_kernel(dsf_mano_model m, const f
         const int c = t % 3;
         acc_t[0] += (c == 0) ? g : 0.f; acc_t[1] += (c == 1) ? g : 0.f; acc_t[2] += (c == 2) ? g : 0.f;
     }
-    for (int e = t; e < NE; e += 256) s_vp[e] = sv[SV_VPOSED + e];
+    for (int e = t; e < NE; e += BWD_NT) s_vp[e] = sv[SV_VPOSED + e];
     if (t < 192) s_G[t] = sv[SV_G + t];
     if (t < 144) s_R[t] = sv[SV_RS + t];
     if (t < 48) s_J[t] = sv[SV_J + t];
@@ -273,7 +281,12 @@ __global__ __launch_bounds__(256) void mano_bwd_kernel(dsf_mano_model m, const f
         if (lane == 0) { s_red[wave * 4] = acc_s; s_red[wave * 4 + 1] = acc_t[0]; s_red[wave * 4 + 2] = acc_t[1]; s_red[wave * 4 + 3] = acc_t[2]; }
     }
     __syncthreads();
-    if (g_cam && t < 4) g_cam[b * scam + t] = s_red[t] + s_red[4 + t] + s_red[8 + t] + s_red[12 + t];
+    if (g_cam && t < 4) {
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < BWD_NW; ++w) acc += s_red[w * 4 + t];
+        g_cam[b * scam + t] = acc;
+    }
 
     // ---- wrist cap (:636) and joint regression (:630-633) ----
     if (t < 3) {
@@ -281,7 +294,7 @@ __global__ __launch_bounds__(256) void mano_bwd_kernel(dsf_mano_model m, const f
         for (int r = 0; r < 16; ++r) s_gv[m.wrist_ring[r] * 3 + t] += g;
     }
     __syncthreads();
-    for (int v = t; v < NV; v += 256) {
+    for (int v = t; v < NV; v += BWD_NT) {
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
         for (int j = 0; j < 21; ++j) {
             const float w = m.j_regressor[v * 21 + j];
@@ -292,7 +305,7 @@ __global__ __launch_bounds__(256) void mano_bwd_kernel(dsf_mano_model m, const f
     __syncthreads();
 
     // ---- skinning: d/d(v_posed) = Trot^T g ; d/dA_i = sum_v W[v,i] g_v (x) [vp_v;1] ----
-    for (int v = t; v < NV; v += 256) {
+    for (int v = t; v < NV; v += BWD_NT) {
         float T[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) T[k] = 0.f;
@@ -310,14 +323,23 @@ __global__ __launch_bounds__(256) void mano_bwd_kernel(dsf_mano_model m, const f
         s_gvp[v * 3 + 1] = T[1] * g0 + T[4] * g1 + T[7] * g2;
         s_gvp[v * 3 + 2] = T[2] * g0 + T[5] * g1 + T[8] * g2;
     }
-    if (t < 192) {
-        const int i = t & 15, k = t >> 4, r = k >> 2, c = k & 3;
+    if (t < 192 * BWD_VL) {                                      // 192 entries of d/dA x 5 vertex lanes
+        const int o = t % 192, vl = t / 192;
+        const int i = o & 15, k = o >> 4, r = k >> 2, c = k & 3;
         float acc = 0.f;
-        for (int v = 0; v < NV; ++v) {
+        for (int v = vl; v < NV; v += BWD_VL) {
             const float w = m.weights[v * 16 + i];
             const float x = (c < 3) ? s_vp[v * 3 + c] : 1.f;
             acc = fmaf(w * s_gv[v * 3 + r], x, acc);
         }
+        s_gAp[vl * 192 + o] = acc;
+    }
+    __syncthreads();
+    if (t < 192) {
+        const int i = t & 15, k = t >> 4;
+        float acc = s_gAp[t];
+#pragma unroll
+        for (int vl = 1; vl < BWD_VL; ++vl) acc += s_gAp[vl * 192 + t];
         s_gA[i * 12 + k] = acc;
     }
     __syncthreads();
@@ -362,31 +384,36 @@ __global__ __launch_bounds__(256) void mano_bwd_kernel(dsf_mano_model m, const f
     else if (t >= 64 && t < 67) s_gJ16[t - 64] += s_gt[t - 64];
 
     // ---- blendshape reductions: g_pf[j] = <posedirs_j, g_vp>, g_beta[k] = <shapedirs_k, g_vp> ----
-    float gk[10];
+    float gk[BWD_KPT];
 #pragma unroll
-    for (int k = 0; k < 10; ++k) { const int e = t + 256 * k; gk[k] = (e < NE) ? s_gvp[e] : 0.f; }
+    for (int k = 0; k < BWD_KPT; ++k) { const int e = t + BWD_NT * k; gk[k] = (e < NE) ? s_gvp[e] : 0.f; }
     for (int j = 0; j < 135; ++j) {
         const float* row = m.posedirs + j * NE;
         float p = 0.f;
 #pragma unroll
-        for (int k = 0; k < 10; ++k) { const int e = t + 256 * k; p = fmaf((e < NE) ? row[e] : 0.f, gk[k], p); }
+        for (int k = 0; k < BWD_KPT; ++k) { const int e = t + BWD_NT * k; p = fmaf((e < NE) ? row[e] : 0.f, gk[k], p); }
         p = wave_sum(p);
-        if (lane == 0) s_part[j * 4 + wave] = p;
+        if (lane == 0) s_part[j * BWD_NW + wave] = p;
     }
     for (int s = 0; s < 10; ++s) {
         const float* row = m.shapedirs + s * NE;
         float p = 0.f;
 #pragma unroll
-        for (int k = 0; k < 10; ++k) { const int e = t + 256 * k; p = fmaf((e < NE) ? row[e] : 0.f, gk[k], p); }
+        for (int k = 0; k < BWD_KPT; ++k) { const int e = t + BWD_NT * k; p = fmaf((e < NE) ? row[e] : 0.f, gk[k], p); }
         p = wave_sum(p);
-        if (lane == 0) s_partb[s * 4 + wave] = p;
+        if (lane == 0) s_partb[s * BWD_NW + wave] = p;
     }
     __syncthreads();
     if (t < 135) {
-        s_gR[9 + t] += s_part[t * 4] + s_part[t * 4 + 1] + s_part[t * 4 + 2] + s_part[t * 4 + 3];
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < BWD_NW; ++w) acc += s_part[t * BWD_NW + w];
+        s_gR[9 + t] += acc;
     } else if (t >= 192 && t < 202) {
         const int s = t - 192;
-        float acc = s_partb[s * 4] + s_partb[s * 4 + 1] + s_partb[s * 4 + 2] + s_partb[s * 4 + 3];
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < BWD_NW; ++w) acc += s_partb[s * BWD_NW + w];
         for (int k = 0; k < 48; ++k) acc = fmaf(m.j_shapedirs[s * 48 + k], s_gJ16[k], acc);
         g_beta[b * sb + s] = acc;
     }
@@ -423,7 +450,7 @@ extern "C" int dsf_mano_forward(const dsf_mano_model* m, const float* beta, cons
     DSF_CHECK_ARG(m && beta && theta && rot && verts && joints);
     DSF_CHECK_ARG(B >= 0 && ncomp >= 0 && ncomp <= 45 && (rot_dim == 3 || rot_dim == 4) && param_stride >= 0);
     if (B == 0) return DSF_OK;
-    hipLaunchKernelGGL(mano_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, *m, beta, theta, rot, cam, ncomp,
+    hipLaunchKernelGGL(mano_fwd_kernel, dim3(B), dim3(FWD_NT), 0, (hipStream_t)stream, *m, beta, theta, rot, cam, ncomp,
                        rot_dim, param_stride, k1, k2, verts, joints, Rs, save);
     return dsf_launch_status();
 }
@@ -436,7 +463,7 @@ extern "C" int dsf_mano_backward(const dsf_mano_model* m, const float* theta, co
     DSF_CHECK_ARG(B >= 0 && ncomp >= 0 && ncomp <= 45 && (rot_dim == 3 || rot_dim == 4) && param_stride >= 0);
     DSF_CHECK_ARG(!(grad_cam && !cam));
     if (B == 0) return DSF_OK;
-    hipLaunchKernelGGL(mano_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, *m, theta, rot, cam, save,
+    hipLaunchKernelGGL(mano_bwd_kernel, dim3(B), dim3(BWD_NT), 0, (hipStream_t)stream, *m, theta, rot, cam, save,
                        grad_verts, grad_joints, ncomp, rot_dim, param_stride, k1, k2, grad_beta, grad_theta, grad_rot, grad_cam);
     return dsf_launch_status();
 }
