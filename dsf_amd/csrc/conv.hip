@@ -1037,7 +1037,8 @@ extern "C" int dsf_conv_igemm_wrw(const float* X, const float* dY, float* dW, in
     const int bkt = !fast ? 32 : (bk_env == 16 || bk_env == 32) ? bk_env : (M >= 32768 ? 16 : 32);
     // split the pixel reduction so that one round of resident workgroups covers the chip (4 per CU with 16-pixel
     // stages, 2 per CU with 32-pixel ones); at least 4 chunks per split
-    int splits = (bkt == 16 ? 1024 : 512) / (k_tiles * n_tiles);
+    static const int wg_env = [] { const char* e = getenv("DSF_WRW_WGS"); return e ? atoi(e) : 0; }();          // tuning aid
+    int splits = (wg_env > 0 ? wg_env : (bkt == 16 ? 1024 : 512)) / (k_tiles * n_tiles);
     if (splits < 1) splits = 1;
     int64_t per = (M + splits - 1) / splits;
     per = ((per + BK - 1) / BK) * BK;

@@ -38,7 +38,11 @@ class FusedAdamW(torch.optim.Optimizer):
         tb = {"key": key,
               "chunk_tensor": torch.tensor(ct, dtype=torch.int32, device=dev), "chunk_index": torch.tensor(ci, dtype=torch.int32, device=dev),
               "sizes": torch.tensor([p.numel() for p in plist], dtype=torch.int64, device=dev), "n_chunks": len(ct),
-              "rows": None, "ptrs": torch.empty((len(plist), 4), dtype=torch.int64, device=dev)}
+              "rows": None, "ptrs": torch.empty((len(plist), 4), dtype=torch.int64, device=dev),
+              # ring of pinned staging buffers for pointer-table refreshes: the copy is asynchronous (the host may run a
+              # whole step ahead of the GPU), a buffer is reused only after the copy that read it has completed
+              "ring": [torch.empty((len(plist), 4), dtype=torch.int64).pin_memory() for _ in range(4)],
+              "ring_ev": [None] * 4, "ring_i": 0}
         self._tables[gi] = tb
         return tb
 
@@ -105,10 +109,16 @@ class FusedAdamW(torch.optim.Optimizer):
                 rows.append((p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()))
             tb = self._table(gi, plist)
             if rows != tb["rows"]:
-                # addresses changed (first step, or the allocator handed out different gradient blocks): refresh the device
-                # table with a pageable -> device copy, which is staged and therefore safe against the CPU running ahead
-                tb["ptrs"].copy_(torch.tensor(rows, dtype=torch.int64))
-                tb["rows"] = rows
+                # addresses changed (first step, a different gradient block from the allocator, or the per-step flat
+                # buckets of data-parallel runs): refresh the device table without draining the stream
+                i = tb["ring_i"]
+                if tb["ring_ev"][i] is not None:
+                    tb["ring_ev"][i].synchronize()
+                tb["ring"][i].copy_(torch.tensor(rows, dtype=torch.int64))
+                tb["ptrs"].copy_(tb["ring"][i], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                tb["ring_ev"][i], tb["ring_i"], tb["rows"] = ev, (i + 1) % 4, rows
             vp = lambda t: ctypes.c_void_p(t.data_ptr())
             check(L.lib().dsf_adamw_multi(vp(tb["ptrs"]), vp(tb["sizes"]), vp(tb["chunk_tensor"]), vp(tb["chunk_index"]),
                                           I(tb["n_chunks"]), D(group["lr"]), D(b1), D(b2), D(group["eps"]),
