@@ -10,17 +10,20 @@ class SmoothL1Loss(torch.nn.Module):
         super().__init__()
         self.size_average = size_average
 
-    def forward(self, x, y):
+    def forward(self, x, y, weight=None):
+        """``weight``: optional loss weight folded into the fused kernel's scale factor (the trainer multiplies every
+        term by a constant, train_render.py:444-466; folding it saves a scalar multiply kernel each way)."""
         assert x.shape == y.shape
         if x.is_cuda:
             from .. import ops
-            fused = ops.huber_mean(x, y, 0.01, self.size_average)       # one reduction + one backward kernel
+            fused = ops.huber_mean(x, y, 0.01, self.size_average, 1.0 if weight is None else float(weight))
             if fused is not None:
                 return fused
         z = (x - y).float()
         a = z.abs()
         per = torch.where(a < 0.01, 0.5 * z * z, 0.01 * (a - 0.005)).mean(dim=-1)
-        return per.mean() if self.size_average else per.sum()
+        out = per.mean() if self.size_average else per.sum()
+        return out if weight is None else out * weight
 
 
 class WeightSmoothL1Loss(torch.nn.Module):

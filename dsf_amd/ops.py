@@ -488,7 +488,7 @@ def _dense(t):
     return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
 
 
-def huber_mean(x, y, delta=0.01, size_average=True):
+def huber_mean(x, y, delta=0.01, size_average=True, weight=1.0):
     """mean_{rows}(mean_{last dim} h(x - y)) (or the sum over rows) on the fused kernels; falls back to None when the
     inputs are not plain fp32 GPU tensors or y needs a gradient (caller then uses the composite formula)."""
     if not (x.is_cuda and y.is_cuda and x.dtype == torch.float32 and y.dtype == torch.float32) or y.requires_grad:
@@ -501,7 +501,7 @@ def huber_mean(x, y, delta=0.01, size_average=True):
         y = y.contiguous(memory_format=torch.channels_last) if (x.dim() == 4 and not x.is_contiguous()) else y.contiguous()
         if y.stride() != x.stride():              # size-1 dims can make strides ambiguous: settle on plain contiguous
             x, y = x.contiguous(), y.contiguous()
-    scale = 1.0 / x.numel() if size_average else 1.0 / x.shape[-1]
+    scale = (1.0 / x.numel() if size_average else 1.0 / x.shape[-1]) * weight
     return HuberMean.apply(x, y, float(delta), float(scale))
 
 

@@ -94,28 +94,25 @@ class RenderSupervisedStep:
         cfg = self.cfg
         img, center, cube = tgt["img"], tgt["center"], tgt["cube"]
         outputs = self.net(img, self.render, center, cube)
-        total = 0
         terms = {}
         for s, (pixel_pd, mano_pd) in enumerate(outputs):
             S = pixel_pd.size(-1)
-            # pixel-wise branch (:451-456)
+            # pixel-wise branch (:451-456); loss weights are folded into the fused Huber kernels
             pixel_gt = self.gfm.joint2feature(tgt["joint_uvd"], img, cfg.feature_para, S, cfg.feature_type)
             juvd_pd = self.gfm.feature2joint(img, pixel_pd, cfg.feature_type, cfg.feature_para)
-            l_pix = self.L1(pixel_pd, pixel_gt) * cfg.deconv_weight
-            l_crd = self.L1(juvd_pd, tgt["joint_uvd"]) * cfg.coord_weight
+            terms["pix%d" % s] = self.L1(pixel_pd, pixel_gt, weight=cfg.deconv_weight)
+            terms["coord%d" % s] = self.L1(juvd_pd, tgt["joint_uvd"], weight=cfg.coord_weight)
             # model branch (:459-466)
             jxyz_pd, mesh_pd = self.render.get_mesh_xyz(mano_pd)
-            l_j = self.L1(jxyz_pd, tgt["joint_xyz"]) * cfg.coord_weight
-            l_v = self.L1(mesh_pd, tgt["mesh_xyz"]) * cfg.coord_weight
-            l_beta = torch.mean(torch.pow(mano_pd[:, 48:58], 2)) * cfg.coord_weight * 10
-            l_scale = torch.mean(torch.abs(torch.clamp(mano_pd[:, 58], max=0.0))) * 0.1
-            total = total + l_pix + l_crd + l_j + l_v + l_beta + l_scale
-            terms["pix%d" % s], terms["coord%d" % s], terms["joint%d" % s], terms["vert%d" % s] = l_pix, l_crd, l_j, l_v
+            terms["joint%d" % s] = self.L1(jxyz_pd, tgt["joint_xyz"], weight=cfg.coord_weight)
+            terms["vert%d" % s] = self.L1(mesh_pd, tgt["mesh_xyz"], weight=cfg.coord_weight)
+            terms["beta%d" % s] = torch.mean(torch.pow(mano_pd[:, 48:58], 2)) * (cfg.coord_weight * 10)
+            terms["scale%d" % s] = torch.mean(torch.abs(torch.clamp(mano_pd[:, 58], max=0.0))) * 0.1
         # render loss on the final estimate (:719, :728-732, :745)
         img_pd, _, _, _ = self.render.render(outputs[-1][1], center, cube)
-        l_m2d = m2d_loss(img, img_pd) * cfg.model_weight
-        terms["m2d"] = l_m2d
-        return total + l_m2d, terms
+        terms["m2d"] = m2d_loss(img, img_pd) * cfg.model_weight
+        # one stack + one sum instead of a chain of scalar adds (and their backward kernels)
+        return torch.stack(list(terms.values())).sum(), terms
 
     def __call__(self, tgt):
         from . import nn_conv
