@@ -52,7 +52,7 @@ FP32_MATRIX_PEAK_TFLOPS = 157.3
 
 def pmc_traffic(kernel):
     """HBM-side bytes per launch of `kernel` from the committed PMC passes (profiles/r01_pmc_traffic.json, made by
-    scratch/pmc_summary.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this script;
+    tools/pmc_summary.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this script;
     FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md).  A profiler cannot run inside the timed
     process, so the figure is read back from the profile of the same command; null when the file has no entry."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")

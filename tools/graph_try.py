@@ -1,5 +1,5 @@
 import sys, time, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dsf_amd.render_model.mano_layer import Render
 from dsf_amd.model.backbone import MANO_OCR_stage
 from dsf_amd.train_step import RenderSupervisedStep, synthetic_batch, Config

@@ -1,6 +1,6 @@
-"""Builds the committed profile artefacts of a round from gpurun_out/prof_<tag>/ (made by scratch/profile_round.sh):
+"""Builds the committed profile artefacts of a round from gpurun_out/prof_<tag>/ (made by tools/profile_round.sh):
 profiles/<tag>_*.{json,csv,txt} copies, profiles/<tag>_pmc_traffic.json (what bench.py reports as roofline.traffic)
-and profiles/<tag>_summary.txt.  usage: python scratch/make_profile_summary.py r01"""
+and profiles/<tag>_summary.txt.  usage: python tools/make_profile_summary.py r01"""
 import csv, json, os, re, shutil, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,7 +16,7 @@ under = json.loads(open(os.path.join(src, tag + "_bench_under_rocprof.json")).re
 g = lambda d, k, c: d.get(k, {}).get(c, {}).get("avg", 0.0)
 ours = sorted(k for k in sq if k.startswith("igemm") or any(s in k for s in ("render_crop", "mano_", "bn_", "raster", "huber", "col_sum", "joint2offset", "offset2joint")))
 traffic = {"source": "separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of `python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline` "
-                     "(scratch/profile_round.sh); FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE doubled (gfx950 reports half "
+                     "(tools/profile_round.sh); FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE doubled (gfx950 reports half "
                      "the bytes of 16-B/lane streaming reads, MI355X_MICROARCH.md HBM section); counts L2 misses to the fabric, "
                      "Infinity-Cache hits included", "kernels": {}}
 for k in ours:
@@ -30,7 +30,7 @@ for r in csv.DictReader(open(os.path.join(src, tag + "_kernel_stats.csv"))):
     m = re.match(r"([A-Za-z_0-9:]+(<[^(]*>)?)", name)
     stats[(m.group(1) if m else name)[:120]] = r
 out = []
-out.append("%s profile summary (MI355X, B=32 ResNet_stage_18 2-stage step; see scratch/profile_round.sh)" % tag)
+out.append("%s profile summary (MI355X, B=32 ResNet_stage_18 2-stage step; see tools/profile_round.sh)" % tag)
 out.append("bench default : %.2f img/s, %.3f ms/step | under rocprofv3 --kernel-trace: %.2f img/s" % (bench["value"], bench["ms_per_step"], under["value"]))
 r = bench["roofline"]
 out.append("dominant kernel (bench, live HIP-event replay): %s  %.1f us/launch  %.1f TFLOP/s  frac %.3f of %.1f" % (r["kernel"], r["avg_launch_us"], r["achieved"], r["frac"], r["peak"]))

@@ -1,5 +1,5 @@
 import torch, sys
-sys.path.insert(0,'.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dsf_amd.nn_norm import FusedBatchNorm2d
 import torch.nn.functional as F
 def bench(f, n=30):

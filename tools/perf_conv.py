@@ -1,5 +1,5 @@
 import time, torch, sys
-sys.path.insert(0,'.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dsf_amd.nn_conv import Conv2dFunction, ConvTranspose2dFunction
 def bench(f, n=20):
     for _ in range(3): f()

@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from torch.profiler import profile, ProfilerActivity
 from dsf_amd.render_model.mano_layer import Render
 from dsf_amd.model.backbone import MANO_OCR_stage

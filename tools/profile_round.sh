@@ -1,15 +1,15 @@
 #!/bin/bash
 # Round profile: default bench line, rocprofv3 kernel stats of the same command, PMC passes (separate runs).
-# usage (GPU box): bash scratch/profile_round.sh r01
+# usage (GPU box): bash tools/profile_round.sh r01
 TAG=${1:-r01}; R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/prof_$TAG; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 timeout 400 python3 $R/bench.py > $O/${TAG}_bench_default.json 2> $O/bench.err
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o k -- python3 $R/bench.py --steps 10 --warmup 4 --no-cpu-baseline > $O/${TAG}_bench_under_rocprof.json 2> $O/rocprof.err
 cp $O/kt/k_kernel_stats.csv $O/${TAG}_kernel_stats.csv
-python3 $R/scratch/kstats.py $O/kt/k_kernel_trace.csv 15 > $O/${TAG}_kernel_categories.txt
+python3 $R/tools/kstats.py $O/kt/k_kernel_trace.csv 15 > $O/${TAG}_kernel_categories.txt
 rm -rf $O/kt
 run() { name=$1; shift
   timeout 400 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/$name -o p -- python3 $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline > $O/$name.log 2>&1
-  python3 $R/scratch/pmc_summary.py $O/${TAG}_pmc_$name.json $O/$name/p_counter_collection.csv && rm -rf $O/$name $O/$name.log; }
+  python3 $R/tools/pmc_summary.py $O/${TAG}_pmc_$name.json $O/$name/p_counter_collection.csv && rm -rf $O/$name $O/$name.log; }
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 run sq SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE
