@@ -1,0 +1,27 @@
+"""Timing of the other BASELINE configs' per-GPU steps on one GPU (not bench lines; sanity / regression numbers)."""
+import sys, os, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dsf_amd.render_model.mano_layer import Render
+from dsf_amd.train_step import MeshLossStep, RenderSupervisedStep, FinetuneStageStep, synthetic_batch, Config
+render = Render("synthetic", "nyu", (588.03, 587.07, 320.0, 240.0), (640, 480)).cuda()
+def timeit(step, tgt, n=10, w=4):
+    for _ in range(w): step(tgt)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): step(tgt)
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
+# config 3: batch 64, hourglass 2-stack + MANO head, full mesh loss + collision
+from dsf_amd.model.hourglass import PoseNetMANO
+torch.manual_seed(0)
+net = PoseNetMANO(2, 21).cuda()
+step = MeshLossStep(net, render, Config)
+p, c, cube = synthetic_batch(64, "cuda", seed=9)
+tgt = step.make_targets(p, c, cube)
+ms = timeit(step, tgt)
+print(f"config 3 (B=64 hourglass-2 + meshLoss + collision): {ms:.1f} ms/step, {64/ms*1e3:.0f} img/s")
+# config 4 per-GPU share: batch 64 (256 / 4 GPUs), ResNet-50 2-stage
+from dsf_amd.model.backbone import MANO_OCR_stage
+net = MANO_OCR_stage('ResNet_stage_50', 21, True).cuda()
+step = RenderSupervisedStep(net, render, Config)
+tgt = step.make_targets(p, c, cube)
+ms = timeit(step, tgt, n=6, w=3)
+print(f"config 4 share (B=64 ResNet-50 2-stage + MANO + render loss): {ms:.1f} ms/step, {64/ms*1e3:.0f} img/s")
