@@ -1,0 +1,50 @@
+#!/usr/bin/env python
+"""Golden vectors for the evaluation metric of the reference (``Trainer.xyz2error``, train_render.py:826-864), made by
+IMPORTING the reference's trainer module (third-party modules the container lacks are empty import-time stand-ins, as in
+make_golden.py; no arithmetic of the reference is stubbed).  Writes tests/golden/reference_eval.npz (arrays only).
+
+    python tests/golden/make_golden_eval.py        # build container only: /root/reference is not on the GPU box
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as mg          # noqa: E402
+
+
+def main():
+    mg._install_stubs()
+    pmd = types.ModuleType("pytorch3d.loss.point_mesh_distance")
+    sys.modules["pytorch3d.loss"].point_mesh_distance = pmd
+    sys.modules["pytorch3d.loss.point_mesh_distance"] = pmd
+    sys.path.insert(0, mg.REF)
+    cwd = os.getcwd()
+    os.chdir("/tmp")                                   # the trainer module creates log directories relative to cwd
+    import train_render as tr
+    os.chdir(cwd)
+    rng = np.random.default_rng(77)
+    out = {}
+    for ds, J in (("nyu", 14), ("msra", 21), ("icvl", 16)):
+        B = 5
+        pred = rng.uniform(-1, 1, (B, J, 3)).astype(np.float32)
+        gt = (pred + rng.normal(size=(B, J, 3)).astype(np.float32) * 0.05).astype(np.float32)
+        center = np.stack([rng.uniform(-40, 40, B), rng.uniform(-40, 40, B), rng.uniform(500, 1200, B)], 1).astype(np.float32)
+        cube = np.full((B, 3), 250.0, dtype=np.float32)
+        cube[1] = (200.0, 300.0, 250.0)
+        fake = types.SimpleNamespace(config=types.SimpleNamespace(dataset=ds), phase="train")
+        T = torch.tensor
+        out[ds + "_pred"], out[ds + "_gt"], out[ds + "_center"], out[ds + "_cube"] = pred, gt, center, cube
+        out[ds + "_err"] = np.float64(tr.Trainer.xyz2error(fake, T(pred), T(gt), T(center), T(cube)))
+        out[ds + "_err_batch"] = tr.Trainer.xyz2error(fake, T(pred), T(gt), T(center), T(cube), keep_batch=True)
+        out[ds + "_err_joint"] = tr.Trainer.xyz2error(fake, T(pred), T(gt), T(center), T(cube), keep_joint=True)
+    np.savez_compressed(os.path.join(HERE, "reference_eval.npz"), **out)
+    print("reference_eval.npz", os.path.getsize(os.path.join(HERE, "reference_eval.npz")), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -176,3 +176,15 @@ def test_gfm_and_losses(golden):
     ga, = torch.autograd.grad(val, a)
     close(ga, golden["sl1_grad"], atol=1e-9, rtol=1e-5)
     close(I.masked_depth_l1(T(golden["dl_a"]), T(golden["dl_b"])), golden["dl_val"], atol=1e-7)
+
+
+def test_eval_metric_vs_reference_golden():
+    """oracle.eval_ref.xyz_to_error == the reference's Trainer.xyz2error (imported to make reference_eval.npz)"""
+    import os
+    from oracle import eval_ref
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_eval.npz"))
+    for ds in ("nyu", "msra", "icvl"):
+        a = (g[ds + "_pred"], g[ds + "_gt"], g[ds + "_center"], g[ds + "_cube"])
+        assert abs(eval_ref.xyz_to_error(*a, dataset=ds) - float(g[ds + "_err"])) < 1e-4
+        assert np.allclose(eval_ref.xyz_to_error(*a, dataset=ds, keep_batch=True), g[ds + "_err_batch"], atol=1e-4)
+        assert np.allclose(eval_ref.xyz_to_error(*a, dataset=ds, keep_joint=True), g[ds + "_err_joint"], atol=1e-4)

@@ -25,3 +25,19 @@ step = RenderSupervisedStep(net, render, Config)
 tgt = step.make_targets(p, c, cube)
 ms = timeit(step, tgt, n=6, w=3)
 print(f"config 4 share (B=64 ResNet-50 2-stage + MANO + render loss): {ms:.1f} ms/step, {64/ms*1e3:.0f} img/s")
+# evaluation path: eval-mode forward + decode + MANO joints + mean joint error, B = 32 and 128
+from dsf_amd.eval_step import EvalStep
+from dsf_amd import ops
+net = MANO_OCR_stage('ResNet_stage_18', 21, True).cuda()
+ev = EvalStep(net, render, Config)
+for Bv in (32, 128):
+    p, c, cube = synthetic_batch(Bv, "cuda", seed=3)
+    with torch.no_grad():
+        img, juvd, jxyz, _ = render.render(p, c, cube)
+        _, M, _, _ = ops.crop_setup(c, cube, render.cam, 128)
+    batch = (img, jxyz[:, render.mano_layer.transfer], juvd, c, M, cube)
+    ev.test([batch] * 3)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    ev.test([batch] * 20)
+    torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 20 * 1e3
+    print(f"eval test_iter B={Bv} ResNet-18 2-stage: {ms:.2f} ms/batch, {Bv/ms*1e3:.0f} img/s")
