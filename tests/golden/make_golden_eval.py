@@ -42,6 +42,27 @@ def main():
         out[ds + "_err"] = np.float64(tr.Trainer.xyz2error(fake, T(pred), T(gt), T(center), T(cube)))
         out[ds + "_err_batch"] = tr.Trainer.xyz2error(fake, T(pred), T(gt), T(center), T(cube), keep_batch=True)
         out[ds + "_err_joint"] = tr.Trainer.xyz2error(fake, T(pred), T(gt), T(center), T(cube), keep_joint=True)
+    # ---- Render.mask_img (mano_layer.py:1326-1340) with its random draws made explicit: the draws are reproduced by
+    #      replaying the same RNG calls from the same seeds, then the reference runs from those seeds
+    from render_model import mano_layer as ml
+    R = ml.Render.__new__(ml.Render)
+    torch.nn.Module.__init__(R)
+    xx, yy = np.meshgrid(np.arange(128), np.arange(128))
+    R.xy_mesh = torch.from_numpy(np.stack((2 * (xx + 0.5) / 128 - 1.0, 2 * (yy + 0.5) / 128 - 1.0), axis=-1).reshape([1, -1, 2])).float()
+    B, J = 3, 21
+    img = rng.uniform(-1, 1, (B, 1, 128, 128)).astype(np.float32)
+    img[img > 0.2] = 1.0
+    juvd = rng.uniform(-0.7, 0.7, (B, J, 3)).astype(np.float32)
+    np.random.seed(123); torch.manual_seed(456)
+    k = np.random.choice(np.arange(3, 10), 1, replace=False)[0]
+    joint_id = np.random.choice(np.arange(0, J), k, replace=False)
+    uvd_offset = (torch.rand(B, k, 3) - 0.5) * 0.15 * 2
+    mask_range = torch.rand([B, k]) * 0.3
+    np.random.seed(123); torch.manual_seed(456)
+    masked = R.mask_img(torch.tensor(img), torch.tensor(juvd), 0.15, 0.3)
+    out["mask_img"], out["mask_juvd"], out["mask_joint_id"] = img, juvd, joint_id.astype(np.int64)
+    out["mask_offset"], out["mask_radius"], out["mask_out"] = uvd_offset.numpy(), mask_range.numpy(), masked.numpy()
+    assert (masked.numpy() != img).any()
     np.savez_compressed(os.path.join(HERE, "reference_eval.npz"), **out)
     print("reference_eval.npz", os.path.getsize(os.path.join(HERE, "reference_eval.npz")), "bytes")
 

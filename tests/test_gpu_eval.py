@@ -65,3 +65,82 @@ def test_test_iter_vs_oracle_composition_and_checkpoint_keys():
         assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), (errs, want)
     mean, per = ev.test([(img, jxyz[:, render.mano_layer.transfer], juvd, c, M, cube)] * 2)
     assert abs(mean - sum(errs) / 4) < 1e-3 and net.training is False
+
+
+def test_mask_img_matches_reference_golden_with_explicit_draws():
+    """Render.mask_img (mano_layer.py:1326-1340): the reference's output for recorded random draws."""
+    from dsf_amd.render_model.mano_layer import Render
+    g = np.load(os.path.join(HERE, "golden", "reference_eval.npz"))
+    render = Render("synthetic", "nyu", (588.03, 587.07, 320.0, 240.0), (640, 480)).cuda()
+    T = lambda a: torch.tensor(a, device="cuda")
+    out = render.mask_img(T(g["mask_img"]), T(g["mask_juvd"]), 0.15, 0.3,
+                          draws=(list(g["mask_joint_id"]), T(g["mask_offset"]), T(g["mask_radius"])))
+    assert np.array_equal(out.cpu().numpy(), g["mask_out"])
+
+
+def test_native_networks_reproduce_reference_outputs():
+    """Hourglass and CycleGAN generator on the HIP convolutions, weights taken from the torch.nn twin built with the
+    seed the reference used for tests/golden/reference_nets.npz: outputs match the REFERENCE's recorded outputs."""
+    from dsf_amd.model.backbone import MANO_OCR_stage
+    from dsf_amd.model.hourglass import PoseNet
+    from dsf_amd.render_model.transfer import define_G
+    g = np.load(os.path.join(HERE, "golden", "reference_nets.npz"))
+    x = torch.tensor(g["x"]).cuda()
+
+    def twin(build):
+        torch.manual_seed(7)
+        cpu = build(False)
+        gpu = build(True).cuda()
+        gpu.load_state_dict(cpu.state_dict())
+        return gpu.eval()
+
+    net = twin(lambda native: MANO_OCR_stage("ResNet_stage_18", 21, False, native=native))
+    with torch.no_grad():
+        (pix, par), = net(x)
+    assert np.abs(pix.cpu().numpy()[:, :, ::8, ::8] - g["r18_pix_sub"]).max() < 2e-3 * max(1.0, np.abs(g["r18_pix_sub"]).max())
+    assert np.abs(par.cpu().numpy() - g["r18_par"]).max() < 2e-3 * max(1.0, np.abs(g["r18_par"]).max())
+
+    hg = twin(lambda native: PoseNet(2, 21, native=native))
+    flat = []
+
+    def _flat(o):
+        if isinstance(o, (list, tuple)):
+            for q in o:
+                _flat(q)
+        else:
+            flat.append(o)
+    with torch.no_grad():
+        _flat(hg(x))
+    for i, o in enumerate(flat):
+        want = g["hg_out%d_sub" % i]
+        assert tuple(o.shape) == tuple(g["hg_out%d_shape" % i])
+        assert np.abs(o.cpu().numpy()[:, ::8, ::4, ::4] - want).max() < 2e-3 * max(1.0, np.abs(want).max())
+
+    gen = twin(lambda native: define_G(1, 1, 64, "resnet_9blocks", "instance", False, "xavier", native=native))
+    with torch.no_grad():
+        go = gen(x)
+    assert np.abs(go.cpu().numpy()[:, :, ::4, ::4] - g["gen_out_sub"]).max() < 2e-3
+
+
+def test_render_forward_tuple_is_self_consistent():
+    """Render.forward (mano_layer.py:983-1039): 8-tuple; the image equals mesh2img of the returned mesh, the uvd
+    outputs equal the transform of the xyz outputs, the rotation augmentation preserves distances to the centre."""
+    from dsf_amd.render_model.mano_layer import Render
+    from dsf_amd.data.render_loader import loader
+    from dsf_amd.train_step import synthetic_batch
+    render = Render("synthetic", "nyu", (588.03, 587.07, 320.0, 240.0), (640, 480)).cuda()
+    p, c, cube = synthetic_batch(4, "cuda", seed=2)
+    view = torch.tensor([[0.3, -0.2, 0.5]] * 4, device="cuda")
+    out = render(p, c, cube, augmentView=view, mask=False)
+    assert len(out) == 8
+    img, j_uvd, v_uvd, j_xyz, v_xyz, center, cube_o, M = out
+    assert img.shape == (4, 1, 128, 128) and j_uvd.shape == (4, 21, 3) and v_uvd.shape == (4, 779, 3) and M.shape == (4, 3, 3)
+    world = v_xyz * cube_o.unsqueeze(1) / 2 + center.unsqueeze(1)
+    again = render.mesh2img(world.contiguous(), center, cube_o)     # vertices round-tripped through the normalisation: a few
+    assert ((again - img).abs() > 1e-4).float().mean() < 5e-3       # boundary pixels may flip
+    L = loader()
+    assert (L.xyz_nl2uvdnl_tensor(j_xyz, center, M, cube_o) - j_uvd).abs().max() < 1e-4
+    plain = render(p, c, cube, mask=False)
+    d0 = (plain[4] * cube.unsqueeze(1) / 2).norm(dim=-1)            # distances of the vertices to the crop centre
+    d1 = (v_xyz * cube_o.unsqueeze(1) / 2).norm(dim=-1)
+    assert (d0 - d1).abs().max() < 1e-2
