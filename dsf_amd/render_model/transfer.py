@@ -1,10 +1,12 @@
 """Frozen Consis-CycleGAN generator used to move synthetic renders to the real-depth domain
 (counterpart of the one constructor the trainer calls,
 ``define_G(1, 1, 64, 'resnet_9blocks', 'instance', False, 'xavier')``,
-/root/reference/render_model/transfer.py:197-238, 393-448, 547-604).  Inference-only dense
-convolutions -> PyTorch-ROCm / MIOpen.  Discriminators, GAN losses and U-Nets are out of scope."""
+/root/reference/render_model/transfer.py:197-238, 393-448, 547-604) on the HIP convolutions, plus the pieces its
+training needs: ``define_D`` / ``NLayerDiscriminator`` / ``PixelDiscriminator`` (:240-284, 709-786) and
+``GANLoss`` (:287-353).  U-Nets and the encoder / decoder split are not used by the trainer and not provided."""
 import functools
 
+import torch
 import torch.nn as nn
 from torch.nn import init
 
@@ -79,3 +81,118 @@ def define_G(input_nc, output_nc, ngf, netG, norm='batch', use_dropout=False, in
 
     net.apply(init_func)
     return net
+
+
+def _norm_layer(norm):
+    if norm == 'instance':
+        return functools.partial(nn.InstanceNorm2d, affine=False, track_running_stats=False)
+    if norm == 'batch':
+        return functools.partial(nn.BatchNorm2d, affine=True, track_running_stats=True)
+    if norm == 'none':
+        return lambda c: nn.Identity()
+    raise NotImplementedError(norm)
+
+
+def _init_net(net, init_type, init_gain):
+    def init_func(m):
+        name = m.__class__.__name__
+        if hasattr(m, 'weight') and ('Conv' in name or 'Linear' in name):
+            if init_type == 'xavier':
+                init.xavier_normal_(m.weight.data, gain=init_gain)
+            elif init_type == 'normal':
+                init.normal_(m.weight.data, 0.0, init_gain)
+            elif init_type == 'kaiming':
+                init.kaiming_normal_(m.weight.data, a=0, mode='fan_in')
+            elif init_type == 'orthogonal':
+                init.orthogonal_(m.weight.data, gain=init_gain)
+            else:
+                raise NotImplementedError(init_type)
+            if getattr(m, 'bias', None) is not None:
+                init.constant_(m.bias.data, 0.0)
+        elif 'BatchNorm2d' in name:
+            init.normal_(m.weight.data, 1.0, init_gain)
+            init.constant_(m.bias.data, 0.0)
+    net.apply(init_func)
+    return net
+
+
+class NLayerDiscriminator(nn.Module):
+    """PatchGAN discriminator (reference :709-755): k4 convolutions, LeakyReLU(0.2), stride 2 for the first n_layers."""
+
+    def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer=nn.BatchNorm2d):
+        super().__init__()
+        fn = norm_layer.func if isinstance(norm_layer, functools.partial) else norm_layer
+        use_bias = fn == nn.InstanceNorm2d
+        C = _L["conv"]
+        seq = [C(input_nc, ndf, kernel_size=4, stride=2, padding=1), nn.LeakyReLU(0.2, True)]
+        mult = 1
+        for n in range(1, n_layers):
+            prev, mult = mult, min(2 ** n, 8)
+            seq += [C(ndf * prev, ndf * mult, kernel_size=4, stride=2, padding=1, bias=use_bias), norm_layer(ndf * mult),
+                    nn.LeakyReLU(0.2, True)]
+        prev, mult = mult, min(2 ** n_layers, 8)
+        seq += [C(ndf * prev, ndf * mult, kernel_size=4, stride=1, padding=1, bias=use_bias), norm_layer(ndf * mult),
+                nn.LeakyReLU(0.2, True)]
+        seq += [C(ndf * mult, 1, kernel_size=4, stride=1, padding=1)]
+        self.model = nn.Sequential(*seq)
+
+    def forward(self, input):
+        return self.model(input)
+
+
+class PixelDiscriminator(nn.Module):
+    """1x1 PatchGAN (reference :757-786)."""
+
+    def __init__(self, input_nc, ndf=64, norm_layer=nn.BatchNorm2d):
+        super().__init__()
+        fn = norm_layer.func if isinstance(norm_layer, functools.partial) else norm_layer
+        use_bias = fn == nn.InstanceNorm2d
+        C = _L["conv"]
+        self.net = nn.Sequential(C(input_nc, ndf, kernel_size=1, stride=1, padding=0), nn.LeakyReLU(0.2, True),
+                                 C(ndf, ndf * 2, kernel_size=1, stride=1, padding=0, bias=use_bias), norm_layer(ndf * 2),
+                                 nn.LeakyReLU(0.2, True), C(ndf * 2, 1, kernel_size=1, stride=1, padding=0, bias=use_bias))
+
+    def forward(self, input):
+        return self.net(input)
+
+
+def define_D(input_nc, ndf, netD, n_layers_D=3, norm='batch', init_type='normal', init_gain=0.02, gpu_ids=[], native=True):
+    """reference :240-284.  ``native=False`` builds the plain torch.nn twin (needed for WGAN-GP's gradient penalty: the
+    HIP convolutions are once-differentiable)."""
+    _L["conv"], _L["convT"] = (nn_conv.Conv2d, nn_conv.ConvTranspose2d) if native else (nn.Conv2d, nn.ConvTranspose2d)
+    norm_layer = _norm_layer(norm)
+    if netD == 'basic':
+        net = NLayerDiscriminator(input_nc, ndf, n_layers=3, norm_layer=norm_layer)
+    elif netD == 'n_layers':
+        net = NLayerDiscriminator(input_nc, ndf, n_layers_D, norm_layer=norm_layer)
+    elif netD == 'pixel':
+        net = PixelDiscriminator(input_nc, ndf, norm_layer=norm_layer)
+    else:
+        raise NotImplementedError('Discriminator model name [%s] is not recognized' % netD)
+    return _init_net(net, init_type, init_gain)
+
+
+class GANLoss(nn.Module):
+    """reference :287-353: lsgan (MSE), vanilla (BCE with logits), wgangp (+-mean) against broadcast labels."""
+
+    def __init__(self, gan_mode, target_real_label=1.0, target_fake_label=0.0):
+        super().__init__()
+        self.register_buffer('real_label', torch.tensor(target_real_label))
+        self.register_buffer('fake_label', torch.tensor(target_fake_label))
+        self.gan_mode = gan_mode
+        if gan_mode == 'lsgan':
+            self.loss = nn.MSELoss()
+        elif gan_mode == 'vanilla':
+            self.loss = nn.BCEWithLogitsLoss()
+        elif gan_mode == 'wgangp':
+            self.loss = None
+        else:
+            raise NotImplementedError('gan mode %s not implemented' % gan_mode)
+
+    def get_target_tensor(self, prediction, target_is_real):
+        return (self.real_label if target_is_real else self.fake_label).expand_as(prediction)
+
+    def __call__(self, prediction, target_is_real):
+        if self.gan_mode in ('lsgan', 'vanilla'):
+            return self.loss(prediction, self.get_target_tensor(prediction, target_is_real))
+        return -prediction.mean() if target_is_real else prediction.mean()

@@ -63,6 +63,25 @@ def main():
     out["mask_img"], out["mask_juvd"], out["mask_joint_id"] = img, juvd, joint_id.astype(np.int64)
     out["mask_offset"], out["mask_radius"], out["mask_out"] = uvd_offset.numpy(), mask_range.numpy(), masked.numpy()
     assert (masked.numpy() != img).any()
+    # ---- discriminators and GAN losses of render_model/transfer.py ----
+    from render_model import transfer as rt
+    xg = torch.tensor(rng.uniform(-1, 1, (2, 1, 128, 128)).astype(np.float32))
+    for tag, args in (("basic", (1, 64, "basic", 3, "instance", "normal", 0.02)), ("pixel", (1, 64, "pixel", 3, "batch", "xavier", 0.02)),
+                      ("nl2", (1, 32, "n_layers", 2, "batch", "normal", 0.02))):
+        torch.manual_seed(11)
+        D = rt.define_D(*args)
+        D.eval()
+        with torch.no_grad():
+            o = D(xg)
+        out["D_%s_keys" % tag] = np.array(list(D.state_dict().keys()))
+        out["D_%s_out" % tag] = o.numpy()
+    out["D_x"] = xg.numpy()
+    pred = torch.tensor(rng.normal(size=(2, 1, 14, 14)).astype(np.float32))
+    out["gan_pred"] = pred.numpy()
+    for mode in ("lsgan", "vanilla", "wgangp"):
+        L = rt.GANLoss(mode)
+        out["gan_%s_real" % mode] = np.float64(L(pred, True))
+        out["gan_%s_fake" % mode] = np.float64(L(pred, False))
     np.savez_compressed(os.path.join(HERE, "reference_eval.npz"), **out)
     print("reference_eval.npz", os.path.getsize(os.path.join(HERE, "reference_eval.npz")), "bytes")
 

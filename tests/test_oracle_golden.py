@@ -188,3 +188,24 @@ def test_eval_metric_vs_reference_golden():
         assert abs(eval_ref.xyz_to_error(*a, dataset=ds) - float(g[ds + "_err"])) < 1e-4
         assert np.allclose(eval_ref.xyz_to_error(*a, dataset=ds, keep_batch=True), g[ds + "_err_batch"], atol=1e-4)
         assert np.allclose(eval_ref.xyz_to_error(*a, dataset=ds, keep_joint=True), g[ds + "_err_joint"], atol=1e-4)
+
+
+def test_discriminators_and_gan_loss_match_reference_golden():
+    """define_D / GANLoss twins (torch.nn build) == the reference's outputs for the same seed (reference_eval.npz)"""
+    import os
+    import torch
+    from dsf_amd.render_model import transfer as T
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_eval.npz"))
+    x = torch.tensor(g["D_x"])
+    for tag, args in (("basic", (1, 64, "basic", 3, "instance", "normal", 0.02)), ("pixel", (1, 64, "pixel", 3, "batch", "xavier", 0.02)),
+                      ("nl2", (1, 32, "n_layers", 2, "batch", "normal", 0.02))):
+        torch.manual_seed(11)
+        D = T.define_D(*args, native=False).eval()
+        assert list(D.state_dict().keys()) == list(g["D_%s_keys" % tag])
+        with torch.no_grad():
+            assert np.array_equal(D(x).numpy(), g["D_%s_out" % tag])
+    pred = torch.tensor(g["gan_pred"])
+    for mode in ("lsgan", "vanilla", "wgangp"):
+        L = T.GANLoss(mode)
+        assert abs(float(L(pred, True)) - float(g["gan_%s_real" % mode])) < 1e-6
+        assert abs(float(L(pred, False)) - float(g["gan_%s_fake" % mode])) < 1e-6
