@@ -242,9 +242,26 @@ class MANO_SMPL(nn.Module):
 
     def get_mano_vertices_packed(self, model_paras, global_scale=None):
         """get_mano_vertices on packed rows [rot 3|4, theta 45, beta 10, cam 4] (the network's output / Render._split
-        layout) without slicing them apart: same values, one kernel each way."""
+        layout) without slicing them apart: same values, one kernel each way.
+
+        The trainer evaluates the layer twice on the same parameters within a step (``Render.render(mano)`` and
+        ``get_mesh_xyz(mano)``, train_render.py:459-466 / 719): the last two results are kept, keyed by the memory,
+        layout and version of the parameter rows, so the second evaluation reuses the first one's output (and its
+        autograd node: the backward kernel then runs once on the summed gradients)."""
         k2 = 1.0 if global_scale is None else float(global_scale)
-        return ops.ManoPackedFunction.apply(self._native(), model_paras, 1000.0, k2)
+        key = (model_paras.data_ptr(), tuple(model_paras.shape), tuple(model_paras.stride()), model_paras._version,
+               model_paras.dtype, model_paras.requires_grad, torch.is_grad_enabled(), k2)
+        cache = self.__dict__.setdefault("_packed_cache", [])
+        for ent in cache:
+            if ent[0] == key:
+                return ent[2], ent[3]
+        verts, joints = ops.ManoPackedFunction.apply(self._native(), model_paras, 1000.0, k2)
+        cache.insert(0, (key, model_paras, verts, joints))         # the entry holds the rows, so their memory cannot be reused
+        del cache[2:]
+        return verts, joints
+
+    def clear_cache(self):
+        self.__dict__["_packed_cache"] = []
 
     def get_mano_vertices(self, quat_or_euler, pose, shape, cam, global_scale=None):
         """-> verts (B,779,3), joints (B,21,3) in mm * global_scale * cam scale + cam trans."""

@@ -117,6 +117,7 @@ class RenderSupervisedStep:
     def __call__(self, tgt):
         from . import nn_conv
         self.opt.zero_grad(set_to_none=True)
+        self.render.mano_layer.clear_cache()                 # results of the previous step must not outlive its graph
         loss, terms = self.loss(tgt)
         if not hasattr(self, "_pool_floats"):
             self._pool_floats = nn_conv.weight_grad_floats(self.net) + 64          # fused heads re-lay one merged weight
