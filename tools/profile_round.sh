@@ -5,8 +5,11 @@ TAG=${1:-r01}; R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/prof_$TAG; mkdi
 timeout 400 python3 $R/bench.py > $O/${TAG}_bench_default.json 2> $O/bench.err
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o k -- python3 $R/bench.py --steps 10 --warmup 4 --no-cpu-baseline > $O/${TAG}_bench_under_rocprof.json 2> $O/rocprof.err
 cp $O/kt/k_kernel_stats.csv $O/${TAG}_kernel_stats.csv
-python3 $R/tools/kstats.py $O/kt/k_kernel_trace.csv 15 > $O/${TAG}_kernel_categories.txt
 rm -rf $O/kt
+# per-step category table and GPU-busy fraction from a trace of bare training steps (no bench diagnostics in it)
+timeout 400 rocprofv3 --kernel-trace --output-format csv -d $O/ks -o k -- python3 $R/tools/step_only.py > /dev/null 2>&1
+( python3 $R/tools/kstats.py $O/ks/k_kernel_trace.csv 12; echo; echo "GPU busy per step (tools/busy.py, last steps):"; python3 $R/tools/busy.py $O/ks/k_kernel_trace.csv | tail -3 ) > $O/${TAG}_kernel_categories.txt
+rm -rf $O/ks
 run() { name=$1; shift
   timeout 400 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/$name -o p -- python3 $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline > $O/$name.log 2>&1
   python3 $R/tools/pmc_summary.py $O/${TAG}_pmc_$name.json $O/$name/p_counter_collection.csv && rm -rf $O/$name $O/$name.log; }
