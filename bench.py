@@ -144,6 +144,7 @@ def main():
     from dsf_amd.parallel import init_distributed, GradAllReducer
     rank, local, world = init_distributed()
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    local = local % max(torch.cuda.device_count(), 1)          # (ranks may share a device in single-GPU flow tests)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # MIOpen is still used for BatchNorm (faster than torch's native channels-last BN here: 41.5 vs 47.6 ms/step);
