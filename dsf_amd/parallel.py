@@ -67,7 +67,7 @@ class GradAllReducer:
     for ResNet-18 two-stage).
     """
 
-    def __init__(self, params, bucket_bytes=32 << 20, group=None):
+    def __init__(self, params, bucket_bytes=32 << 20, group=None, tail_bucket_bytes=2 << 20):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.group = group
         self.params = [p for p in params if p.requires_grad]
@@ -82,7 +82,22 @@ class GradAllReducer:
             cur.append(p)
             cur_bytes += nbytes
         if cur:
-            self._seal(cur)
+            # the last bucket holds the earliest layers, whose gradients arrive at the very end of backward: nothing is
+            # left to overlap its all-reduce with, so it is cut down to a small tail (the rest goes out one bucket earlier)
+            tail, tail_bytes = [], 0
+            while cur and tail_bytes + cur[-1].numel() * cur[-1].element_size() <= tail_bucket_bytes:
+                tail_bytes += cur[-1].numel() * cur[-1].element_size()
+                tail.insert(0, cur.pop())
+            if cur:
+                rest = sum(p.numel() * p.element_size() for p in cur)
+                if self.buckets and rest < bucket_bytes // 4 and self.buckets[-1][0].dtype == cur[0].dtype:
+                    for p in cur:                                   # a small remainder rides with the previous bucket
+                        self._bucket_of[p] = len(self.buckets) - 1
+                    self.buckets[-1].extend(cur)
+                else:
+                    self._seal(cur)
+            if tail:
+                self._seal(tail)
         self._reset()
         self.enabled = True          # False: hooks and finish() do nothing (single-rank diagnostic steps)
         self._hooks = []
