@@ -417,31 +417,30 @@ __global__ __launch_bounds__(256) void igemm_fwd_fast_kernel(const float* __rest
 #pragma unroll
         for (int i = 0; i < NPIECE; ++i) load_piece(SET, i, live);
     };
-    auto stage = [&](auto SET, int buf) {                           // register set -> LDS stage `buf` (k-major, swizzled)
+    // group i of register set SET -> LDS stage `buf` (k-major, swizzled): i < APASS an A row group, then the B groups
+    auto stage_piece = [&](auto SET, int buf, int i) {
         constexpr int S = decltype(SET)::value;
         float* Asb = As[buf];
         float* Bsb = Bs[buf];
         const int swz = lds_swz<BKT>(a_k4);                         // same for the 4 k-rows of the quad
-#pragma unroll
-        for (int i = 0; i < APASS; ++i) {
+        if (i < APASS) {
             const int r = (a_r + AROWS * i) ^ swz;
             Asb[(a_k4 + 0) * BMT + r] = ra[S][i].x; Asb[(a_k4 + 1) * BMT + r] = ra[S][i].y;
             Asb[(a_k4 + 2) * BMT + r] = ra[S][i].z; Asb[(a_k4 + 3) * BMT + r] = ra[S][i].w;
-        }
-        if (WT) {
-#pragma unroll
-            for (int i = 0; i < WTPASS; ++i) {
-                const int c = (a_r + AROWS * i) ^ swz;
-                Bsb[(a_k4 + 0) * BN + c] = rb[S][i].x; Bsb[(a_k4 + 1) * BN + c] = rb[S][i].y;
-                Bsb[(a_k4 + 2) * BN + c] = rb[S][i].z; Bsb[(a_k4 + 3) * BN + c] = rb[S][i].w;
-            }
+        } else if (WT) {
+            const int j = i - APASS;
+            const int c = (a_r + AROWS * j) ^ swz;
+            Bsb[(a_k4 + 0) * BN + c] = rb[S][j].x; Bsb[(a_k4 + 1) * BN + c] = rb[S][j].y;
+            Bsb[(a_k4 + 2) * BN + c] = rb[S][j].z; Bsb[(a_k4 + 3) * BN + c] = rb[S][j].w;
         } else {
-#pragma unroll
-            for (int i = 0; i < BPASS; ++i) {
-                const int kk = b_row + BROWS * i;
-                *reinterpret_cast<float4*>(&Bsb[kk * BN + (b_n4 ^ lds_swz<BKT>(kk))]) = rb[S][i];
-            }
+            const int j = i - APASS;
+            const int kk = b_row + BROWS * j;
+            *reinterpret_cast<float4*>(&Bsb[kk * BN + (b_n4 ^ lds_swz<BKT>(kk))]) = rb[S][j];
         }
+    };
+    auto stage = [&](auto SET, int buf) {
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) stage_piece(SET, buf, i);
     };
 
     using Set0 = std::integral_constant<int, 0>;
@@ -454,15 +453,20 @@ __global__ __launch_bounds__(256) void igemm_fwd_fast_kernel(const float* __rest
     __syncthreads();
     // chunk c computes from LDS stage (c - lo) & 1; its register set (same parity) is free and receives chunk c + 2;
     // chunk c + 1 moves from the other set to the other stage after the MFMAs
+    // The k-steps of a chunk carry, one per step, first the NPIECE loads of chunk c + 2 (into this chunk's own register
+    // set, free since its stage) and then the NPIECE LDS stores of chunk c + 1 (other set -> other stage, whose last
+    // reader finished before the previous barrier): by the end of the MFMA block only the barrier is left.
+    static_assert(2 * NPIECE <= BKT / 2, "loads and stage stores are handed out one per k-step");
     auto body = [&](auto SET, auto OTHER, int chunk) {
         constexpr int buf = decltype(SET)::value;
-        const bool live2 = chunk + 2 < chunk_hi;
+        const bool live1 = chunk + 1 < chunk_hi, live2 = chunk + 2 < chunk_hi;
         mma_chunk<BN, TM, TN, BKT, true, BMT>(As[buf], Bs[buf], wm * WM, wn * 64, lane, acc, [&](int s) {
 #pragma unroll
-            for (int i = 0; i < NPIECE; ++i)
+            for (int i = 0; i < NPIECE; ++i) {
                 if (i == s) load_piece(SET, i, live2);              // constant index after unrolling
+                if (i + NPIECE == s && live1) stage_piece(OTHER, buf ^ 1, i);
+            }
         });
-        if (chunk + 1 < chunk_hi) stage(OTHER, buf ^ 1);
         __syncthreads();
     };
     for (int chunk = chunk_lo; chunk < chunk_hi; chunk += 2) {
@@ -601,31 +605,29 @@ __global__ __launch_bounds__(256) void igemm_fwd_dil2_kernel(const float* __rest
 #pragma unroll
         for (int i = 0; i < NPIECE; ++i) load_piece(SET, i, live);
     };
-    auto stage = [&](auto SET, int buf) {
+    auto stage_piece = [&](auto SET, int buf, int i) {              // group i of register set SET -> LDS stage `buf`
         constexpr int S = decltype(SET)::value;
         float* Asb = As[buf];
         float* Bsb = Bs[buf];
         const int swz = lds_swz<BKT>(a_k4);
-#pragma unroll
-        for (int i = 0; i < APASS; ++i) {
+        if (i < APASS) {
             const int r = (a_r + AROWS * i) ^ swz;
             Asb[(a_k4 + 0) * BM + r] = ra[S][i].x; Asb[(a_k4 + 1) * BM + r] = ra[S][i].y;
             Asb[(a_k4 + 2) * BM + r] = ra[S][i].z; Asb[(a_k4 + 3) * BM + r] = ra[S][i].w;
-        }
-        if (WT) {
-#pragma unroll
-            for (int i = 0; i < WTPASS; ++i) {
-                const int c = (a_r + AROWS * i) ^ swz;
-                Bsb[(a_k4 + 0) * BN + c] = rb[S][i].x; Bsb[(a_k4 + 1) * BN + c] = rb[S][i].y;
-                Bsb[(a_k4 + 2) * BN + c] = rb[S][i].z; Bsb[(a_k4 + 3) * BN + c] = rb[S][i].w;
-            }
+        } else if (WT) {
+            const int j = i - APASS;
+            const int c = (a_r + AROWS * j) ^ swz;
+            Bsb[(a_k4 + 0) * BN + c] = rb[S][j].x; Bsb[(a_k4 + 1) * BN + c] = rb[S][j].y;
+            Bsb[(a_k4 + 2) * BN + c] = rb[S][j].z; Bsb[(a_k4 + 3) * BN + c] = rb[S][j].w;
         } else {
-#pragma unroll
-            for (int i = 0; i < BPASS; ++i) {
-                const int kk = b_row + BROWS * i;
-                *reinterpret_cast<float4*>(&Bsb[kk * BN + (b_n4 ^ lds_swz<BKT>(kk))]) = rb[S][i];
-            }
+            const int j = i - APASS;
+            const int kk = b_row + BROWS * j;
+            *reinterpret_cast<float4*>(&Bsb[kk * BN + (b_n4 ^ lds_swz<BKT>(kk))]) = rb[S][j];
         }
+    };
+    auto stage = [&](auto SET, int buf) {
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) stage_piece(SET, buf, i);
     };
 
     using Set0 = std::integral_constant<int, 0>;
@@ -636,15 +638,17 @@ __global__ __launch_bounds__(256) void igemm_fwd_dil2_kernel(const float* __rest
     load_all(Set1{}, nxt);
     if (cur) stage(Set0{}, 0);
     __syncthreads();
+    static_assert(2 * NPIECE <= BKT / 2, "loads and stage stores are handed out one per k-step");
     auto body = [&](auto SET, auto OTHER) {
         constexpr int buf = decltype(SET)::value;
-        const bool live2 = l_chunk < chunk_hi;        // the walk stands at the chunk two ahead
+        const bool live1 = nxt, live2 = l_chunk < chunk_hi;        // the walk stands at the chunk two ahead
         mma_chunk<BN, TM, TN, BKT>(As[buf], Bs[buf], wm * WM, wn * 64, lane, acc, [&](int s) {
 #pragma unroll
-            for (int i = 0; i < NPIECE; ++i)
+            for (int i = 0; i < NPIECE; ++i) {
                 if (i == s) load_piece(SET, i, live2);
+                if (i + NPIECE == s && live1) stage_piece(OTHER, buf ^ 1, i);
+            }
         });
-        if (nxt) stage(OTHER, buf ^ 1);
         __syncthreads();
         cur = nxt; nxt = live2;
     };
@@ -870,12 +874,14 @@ __global__ __launch_bounds__(256) void igemm_wrw_fast_kernel(const float* __rest
 #pragma unroll
         for (int i = 0; i < NPIECE; ++i) load_piece(SET, i, mc);
     };
-    auto stage = [&](auto SET, int buf) {
+    auto stage_piece = [&](auto SET, int buf, int i) {
         constexpr int S = decltype(SET)::value;
+        if (i < APASS) *reinterpret_cast<float4*>(&As[buf][((t >> 5) + 8 * i) * KT + (t & 31) * 4]) = ra[S][i];
+        else *reinterpret_cast<float4*>(&Bs[buf][(b_row + BROWS * (i - APASS)) * BN + b_n4]) = rb[S][i - APASS];
+    };
+    auto stage = [&](auto SET, int buf) {
 #pragma unroll
-        for (int i = 0; i < APASS; ++i) *reinterpret_cast<float4*>(&As[buf][((t >> 5) + 8 * i) * KT + (t & 31) * 4]) = ra[S][i];
-#pragma unroll
-        for (int i = 0; i < BPASS; ++i) *reinterpret_cast<float4*>(&Bs[buf][(b_row + BROWS * i) * BN + b_n4]) = rb[S][i];
+        for (int i = 0; i < NPIECE; ++i) stage_piece(SET, buf, i);
     };
 
     using Set0 = std::integral_constant<int, 0>;
@@ -886,14 +892,17 @@ __global__ __launch_bounds__(256) void igemm_wrw_fast_kernel(const float* __rest
         stage(Set0{}, 0);
     }
     __syncthreads();
+    static_assert(2 * NPIECE <= BKT / 2, "loads and stage stores are handed out one per k-step");
     auto body = [&](auto SET, auto OTHER, int mc) {
         constexpr int buf = decltype(SET)::value;
+        const bool live1 = mc + BKT < m_end;
         mma_chunk<BN, TM, TN, BKT, false>(As[buf], Bs[buf], wm * WM, wn * 64, lane, acc, [&](int s) {
 #pragma unroll
-            for (int i = 0; i < NPIECE; ++i)
+            for (int i = 0; i < NPIECE; ++i) {
                 if (i == s) load_piece(SET, i, mc + 2 * BKT);
+                if (i + NPIECE == s && live1) stage_piece(OTHER, buf ^ 1, i);
+            }
         });
-        if (mc + BKT < m_end) stage(OTHER, buf ^ 1);
         __syncthreads();
     };
     for (int mc = m_begin; mc < m_end; mc += 2 * BKT) {
