@@ -24,16 +24,15 @@ N_MANO = 3 + 45 + 10 + 4
 
 
 class _Layers:
-    """Layer factories: the HIP implicit-GEMM convolutions (native=True, GPU only) or plain torch.nn
-    (native=False: the CPU twin the oracle / cpu_baseline builds; same parameters and keys)."""
+    """Layer factories of one network under construction, taken from the registry ``nn_conv.LAYERS`` (the HIP
+    implicit-GEMM convolutions and the fused BN kernels)."""
 
-    def __init__(self, native):
-        self.native = native
+    def __init__(self):
         # fused BN(+add+ReLU) kernels (csrc/norm.hip): 3 launches each way instead of MIOpen's 3 + add + ReLU
         # (B=32 ResNet-18 step: 32.6 vs 33.0 ms).  DSF_FUSED_BN=0 keeps torch's BatchNorm2d / ReLU modules.
-        self.fused_bn = native and os.environ.get("DSF_FUSED_BN", "1") == "1"
-        self.Conv2d = nn_conv.Conv2d if native else nn.Conv2d
-        self.ConvTranspose2d = nn_conv.ConvTranspose2d if native else nn.ConvTranspose2d
+        self.fused_bn = bool(nn_conv.LAYERS["fused_bn"]) and os.environ.get("DSF_FUSED_BN", "1") == "1"
+        self.Conv2d = nn_conv.LAYERS["Conv2d"]
+        self.ConvTranspose2d = nn_conv.LAYERS["ConvTranspose2d"]
 
     def bn_relu(self, c, **kw):
         """[BatchNorm, ReLU] pair of an nn.Sequential: fused into one module (the ReLU slot becomes an
@@ -98,7 +97,7 @@ class _TwoBranchNet(nn.Module):
         mano = g('mano_regress')(c4)
         feat = g('deconv_layer2')(g('deconv_layer3')(g('deconv_layer4')(c4)))
         heads = g('finals')
-        pix = nn_conv.fused_heads(feat, heads) if self._L.native else torch.cat([head(feat) for head in heads], dim=1)
+        pix = nn_conv.fused_heads(feat, heads)
         return c4, feat, pix, mano
 
     def init_weights(self):
@@ -120,9 +119,9 @@ class _TwoBranchNet(nn.Module):
 
 
 class MANO_OCR(_TwoBranchNet):
-    def __init__(self, backbone, joint_num, native=True):
+    def __init__(self, backbone, joint_num):
         super().__init__()
-        self._L = _Layers(native)
+        self._L = _Layers()
         self.joint_num = joint_num
         self.feature_dim = [joint_num * 3, joint_num]
         block, layers = resnet[int(backbone.split('_')[-1])]
@@ -138,9 +137,9 @@ class MANO_OCR(_TwoBranchNet):
 
 
 class MANO_OCR_stage(_TwoBranchNet):
-    def __init__(self, backbone, joint_num, refine=False, coord='xyz', native=True):
+    def __init__(self, backbone, joint_num, refine=False, coord='xyz'):
         super().__init__()
-        self._L = _Layers(native)
+        self._L = _Layers()
         self.joint_num = joint_num
         self.feature_dim = [joint_num * 3, joint_num]
         self.refine = refine

@@ -8,14 +8,13 @@ from torch import nn
 
 from .. import nn_conv
 
-_CONV = [nn_conv.Conv2d]        # [nn.Conv2d] builds the plain-torch CPU twin
 
 
 class Conv(nn.Module):
     def __init__(self, inp_dim, out_dim, kernel_size=3, stride=1, bn=False, relu=True):
         super().__init__()
         self.inp_dim = inp_dim
-        self.conv = _CONV[0](inp_dim, out_dim, kernel_size, stride, padding=(kernel_size - 1) // 2, bias=True)
+        self.conv = nn_conv.LAYERS["Conv2d"](inp_dim, out_dim, kernel_size, stride, padding=(kernel_size - 1) // 2, bias=True)
         self.relu = nn.ReLU() if relu else None
         self.bn = nn.BatchNorm2d(out_dim) if bn else None
 
@@ -77,13 +76,9 @@ class Merge(nn.Module):
 
 
 class PoseNet(nn.Module):
-    def __init__(self, nstack, joint_num, inp_dim=256, bn=False, increase=0, native=True, **kwargs):
+    def __init__(self, nstack, joint_num, inp_dim=256, bn=False, increase=0, **kwargs):
         super().__init__()
-        saved, _CONV[0] = _CONV[0], (nn_conv.Conv2d if native else nn.Conv2d)
-        try:
-            self._build(nstack, joint_num, inp_dim, bn, increase)
-        finally:
-            _CONV[0] = saved
+        self._build(nstack, joint_num, inp_dim, bn, increase)
 
     def _build(self, nstack, joint_num, inp_dim, bn, increase):
         self.nstack = nstack
@@ -93,7 +88,7 @@ class PoseNet(nn.Module):
         self.hgs = nn.ModuleList([Hourglass(4, inp_dim, bn, increase) for _ in range(nstack)])
         self.features = nn.ModuleList([nn.Sequential(Residual(inp_dim, inp_dim), Conv(inp_dim, inp_dim, 1, bn=True, relu=True))
                                        for _ in range(nstack)])
-        head = lambda c: nn.ModuleList([_CONV[0](inp_dim, c, kernel_size=1, stride=1, padding=0) for _ in range(nstack)])
+        head = lambda c: nn.ModuleList([nn_conv.LAYERS["Conv2d"](inp_dim, c, kernel_size=1, stride=1, padding=0) for _ in range(nstack)])
         self.outs_1 = head(joint_num * 3)
         self.outs_2 = head(joint_num)
         self.outs_3 = head(joint_num)
@@ -132,9 +127,9 @@ class PoseNet(nn.Module):
 class PoseNetMANO(nn.Module):
     """PoseNet + a pooled linear head regressing the 62 MANO parameters (BASELINE config 3)."""
 
-    def __init__(self, nstack=2, joint_num=21, native=True):
+    def __init__(self, nstack=2, joint_num=21):
         super().__init__()
-        self.body = PoseNet(nstack, joint_num, native=native)
+        self.body = PoseNet(nstack, joint_num)
         self.mano_regress = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(256, 62))
         nn.init.normal_(self.mano_regress[2].weight, std=0.001)
         nn.init.zeros_(self.mano_regress[2].bias)

@@ -7,8 +7,8 @@ import torch.nn as nn
 from ..nn_conv import Conv2d as _HipConv2d
 from ..nn_norm import FusedBatchNorm2d, bn_act
 
-_CONV = [_HipConv2d]      # layer factory switch: [nn.Conv2d] builds the plain-torch CPU twin (oracle / tests)
-_FUSED_BN = [False]       # fused BN+add+ReLU kernels (opt-in, see model/backbone.py::_Layers)
+_CONV = [_HipConv2d]      # layer factory of the network under construction (set by model/backbone.py::_Layers)
+_FUSED_BN = [False]       # fused BN+add+ReLU kernels (see model/backbone.py::_Layers)
 
 
 def _norm(c, **kw):

@@ -1,8 +1,7 @@
 """Conv2d / ConvTranspose2d on the hand-written fp32 MFMA implicit-GEMM kernels
 (dsf_amd/csrc/conv.hip).  Drop-in subclasses of the torch modules: same parameters, state-dict
 keys and initialisation; only ``forward`` differs.  Activations are kept channels_last (NHWC in
-memory), which is what the kernels read and write.  GPU only: a CPU tensor raises (the CPU oracle
-builds the same architecture from plain ``torch.nn`` layers instead, ``native=False``).
+memory), which is what the kernels read and write.  GPU only: a CPU tensor raises.
 """
 import torch
 import torch.nn as nn
@@ -103,8 +102,7 @@ def _bias_grad(gy):
 
 def ptr_nhwc(t):
     if not t.is_cuda:
-        raise RuntimeError("dsf_amd convolution runs on the GPU only (got %s); build the net with native=False for "
-                           "a plain torch.nn CPU twin" % t.device)
+        raise RuntimeError("dsf_amd convolution runs on the GPU only (got a %s tensor); there is no CPU path" % t.device)
     assert t.is_contiguous(memory_format=CL) or t.is_contiguous()
     import ctypes
     if t.numel() == 0:                                   # empty batch: a valid (never dereferenced) address instead of NULL
@@ -253,6 +251,10 @@ class ConvTranspose2d(nn.ConvTranspose2d):
         return ConvTranspose2dFunction.apply(x, self.weight, self.bias, s[0], _pair(self.padding), _pair(self.output_padding))
 
 
+# Layer registry the model builders construct from (model/backbone.py, model/hourglass.py, render_model/transfer.py).
+LAYERS = {"Conv2d": None, "ConvTranspose2d": None, "fused_bn": True}
+
+
 def fused_heads(x, heads):
     """cat([h(x) for h in heads], dim=1) for parallel Conv2d heads of one geometry as ONE convolution over the
     concatenated output channels (the 63 + 21 channel 1x1 heads of the reference's ``finals`` become one 84-channel
@@ -267,6 +269,9 @@ def fused_heads(x, heads):
     w = torch.cat([h.weight for h in heads], dim=0)
     b = torch.cat([h.bias for h in heads], dim=0) if h0.bias is not None else None
     return Conv2dFunction.apply(x, w, b, _pair(h0.stride)[0], _pair(h0.padding))
+
+
+LAYERS["Conv2d"], LAYERS["ConvTranspose2d"] = Conv2d, ConvTranspose2d
 
 
 def replay(rec, iters=3):

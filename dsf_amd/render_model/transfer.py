@@ -12,7 +12,16 @@ from torch.nn import init
 
 from .. import nn_conv
 
-_L = {"conv": nn_conv.Conv2d, "convT": nn_conv.ConvTranspose2d}
+
+
+class _Factory:
+    """layer classes of the network under construction (the registry ``nn_conv.LAYERS``)"""
+
+    def __getitem__(self, k):
+        return nn_conv.LAYERS["Conv2d" if k == "conv" else "ConvTranspose2d"]
+
+
+_L = _Factory()
 
 
 class ResnetBlock(nn.Module):
@@ -50,9 +59,7 @@ class ResnetGenerator(nn.Module):
         return self.model(x)
 
 
-def define_G(input_nc, output_nc, ngf, netG, norm='batch', use_dropout=False, init_type='normal', init_gain=0.02, gpu_ids=[],
-             native=True):
-    _L["conv"], _L["convT"] = (nn_conv.Conv2d, nn_conv.ConvTranspose2d) if native else (nn.Conv2d, nn.ConvTranspose2d)
+def define_G(input_nc, output_nc, ngf, netG, norm='batch', use_dropout=False, init_type='normal', init_gain=0.02, gpu_ids=[]):
     if norm == 'instance':
         norm_layer = functools.partial(nn.InstanceNorm2d, affine=False, track_running_stats=False)
     elif norm == 'batch':
@@ -156,10 +163,9 @@ class PixelDiscriminator(nn.Module):
         return self.net(input)
 
 
-def define_D(input_nc, ndf, netD, n_layers_D=3, norm='batch', init_type='normal', init_gain=0.02, gpu_ids=[], native=True):
-    """reference :240-284.  ``native=False`` builds the plain torch.nn twin (needed for WGAN-GP's gradient penalty: the
-    HIP convolutions are once-differentiable)."""
-    _L["conv"], _L["convT"] = (nn_conv.Conv2d, nn_conv.ConvTranspose2d) if native else (nn.Conv2d, nn.ConvTranspose2d)
+def define_D(input_nc, ndf, netD, n_layers_D=3, norm='batch', init_type='normal', init_gain=0.02, gpu_ids=[]):
+    """reference :240-284.  (WGAN-GP's gradient penalty needs double backward; the HIP convolutions are
+    once-differentiable, so ``cal_gradient_penalty`` is not provided.)"""
     norm_layer = _norm_layer(norm)
     if netD == 'basic':
         net = NLayerDiscriminator(input_nc, ndf, n_layers=3, norm_layer=norm_layer)

@@ -142,10 +142,11 @@ def step_loss(net, render, tgt, coord_weight=100.0, deconv_weight=1.0, model_wei
 def timed_steps(mano_dict, B=2, steps=3, warmup=1, backbone="ResNet_stage_18", seed=0):
     """cpu_baseline leg: full step (fwd + bwd + AdamW) on the host cores; returns (images/s, seconds, n)."""
     import time
-    from dsf_amd.model.backbone import MANO_OCR_stage          # plain torch.nn trunk (no HIP inside its modules)
+    from dsf_amd.model.backbone import MANO_OCR_stage
+    from . import nets
     from dsf_amd.train_step import synthetic_batch
     torch.manual_seed(seed)
-    net = MANO_OCR_stage(backbone, 21, True, native=False)       # plain torch.nn twin of the product net
+    net = nets.build(MANO_OCR_stage, backbone, 21, True)         # plain torch.nn twin of the product net
     opt = torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=0.01)
     render = OracleRender(mano_dict)
     p, c, cube = synthetic_batch(B, "cpu", seed)

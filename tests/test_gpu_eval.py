@@ -87,20 +87,22 @@ def test_native_networks_reproduce_reference_outputs():
     g = np.load(os.path.join(HERE, "golden", "reference_nets.npz"))
     x = torch.tensor(g["x"]).cuda()
 
+    from oracle import nets
+
     def twin(build):
         torch.manual_seed(7)
-        cpu = build(False)
-        gpu = build(True).cuda()
+        cpu = nets.build(build)                                    # torch.nn twin initialised with the reference's seed
+        gpu = build().cuda()
         gpu.load_state_dict(cpu.state_dict())
         return gpu.eval()
 
-    net = twin(lambda native: MANO_OCR_stage("ResNet_stage_18", 21, False, native=native))
+    net = twin(lambda: MANO_OCR_stage("ResNet_stage_18", 21, False))
     with torch.no_grad():
         (pix, par), = net(x)
     assert np.abs(pix.cpu().numpy()[:, :, ::8, ::8] - g["r18_pix_sub"]).max() < 2e-3 * max(1.0, np.abs(g["r18_pix_sub"]).max())
     assert np.abs(par.cpu().numpy() - g["r18_par"]).max() < 2e-3 * max(1.0, np.abs(g["r18_par"]).max())
 
-    hg = twin(lambda native: PoseNet(2, 21, native=native))
+    hg = twin(lambda: PoseNet(2, 21))
     flat = []
 
     def _flat(o):
@@ -116,7 +118,7 @@ def test_native_networks_reproduce_reference_outputs():
         assert tuple(o.shape) == tuple(g["hg_out%d_shape" % i])
         assert np.abs(o.cpu().numpy()[:, ::8, ::4, ::4] - want).max() < 2e-3 * max(1.0, np.abs(want).max())
 
-    gen = twin(lambda native: define_G(1, 1, 64, "resnet_9blocks", "instance", False, "xavier", native=native))
+    gen = twin(lambda: define_G(1, 1, 64, "resnet_9blocks", "instance", False, "xavier"))
     with torch.no_grad():
         go = gen(x)
     assert np.abs(go.cpu().numpy()[:, :, ::4, ::4] - g["gen_out_sub"]).max() < 2e-3
@@ -151,8 +153,9 @@ def test_native_discriminator_matches_reference_output_and_trains():
     g = np.load(os.path.join(HERE, "golden", "reference_eval.npz"))
     x = torch.tensor(g["D_x"]).cuda()
     torch.manual_seed(11)
-    cpu = Tr.define_D(1, 64, "basic", 3, "instance", "normal", 0.02, native=False)
-    D = Tr.define_D(1, 64, "basic", 3, "instance", "normal", 0.02, native=True).cuda()
+    from oracle import nets
+    cpu = nets.build(Tr.define_D, 1, 64, "basic", 3, "instance", "normal", 0.02)
+    D = Tr.define_D(1, 64, "basic", 3, "instance", "normal", 0.02).cuda()
     D.load_state_dict(cpu.state_dict())
     with torch.no_grad():
         o = D(x)

@@ -562,7 +562,8 @@ def test_whole_step_loss_and_grads_vs_oracle_step(mano_dict, render):
     from dsf_amd.model.backbone import MANO_OCR_stage
     from dsf_amd.train_step import RenderSupervisedStep, synthetic_batch, Config
     torch.manual_seed(3)
-    net_cpu = MANO_OCR_stage("ResNet_stage_18", 21, True, native=False)
+    from oracle import nets
+    net_cpu = nets.build(MANO_OCR_stage, "ResNet_stage_18", 21, True)          # torch.nn twin (CPU side of the comparison)
     # make the MANO heads produce non-degenerate hands
     with torch.no_grad():
         for head in (net_cpu.mano_regress[2], net_cpu.mano_regress_s2[2]):

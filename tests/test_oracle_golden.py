@@ -195,12 +195,13 @@ def test_discriminators_and_gan_loss_match_reference_golden():
     import os
     import torch
     from dsf_amd.render_model import transfer as T
+    from oracle import nets
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_eval.npz"))
     x = torch.tensor(g["D_x"])
     for tag, args in (("basic", (1, 64, "basic", 3, "instance", "normal", 0.02)), ("pixel", (1, 64, "pixel", 3, "batch", "xavier", 0.02)),
                       ("nl2", (1, 32, "n_layers", 2, "batch", "normal", 0.02))):
         torch.manual_seed(11)
-        D = T.define_D(*args, native=False).eval()
+        D = nets.build(T.define_D, *args).eval()
         assert list(D.state_dict().keys()) == list(g["D_%s_keys" % tag])
         with torch.no_grad():
             assert np.array_equal(D(x).numpy(), g["D_%s_out" % tag])
@@ -209,3 +210,50 @@ def test_discriminators_and_gan_loss_match_reference_golden():
         L = T.GANLoss(mode)
         assert abs(float(L(pred, True)) - float(g["gan_%s_real" % mode])) < 1e-6
         assert abs(float(L(pred, False)) - float(g["gan_%s_fake" % mode])) < 1e-6
+
+
+def test_network_twins_are_bit_identical_to_the_reference(golden_nets):
+    """Same seed, same builder code on torch.nn layers (oracle.nets) => the reference's state-dict keys, parameter
+    counts and bit-identical outputs (tests/golden/reference_nets.npz was recorded from the imported reference)."""
+    import torch
+    from oracle import nets
+    from dsf_amd.model.backbone import MANO_OCR_stage
+    from dsf_amd.model.hourglass import PoseNet
+    from dsf_amd.render_model.transfer import define_G
+    g = golden_nets
+    x = torch.tensor(g["x"])
+    torch.manual_seed(7)
+    net = nets.build(MANO_OCR_stage, "ResNet_stage_18", 21, False).eval()
+    assert list(net.state_dict().keys()) == list(g["r18_keys"])
+    with torch.no_grad():
+        (pix, par), = net(x)
+    assert np.array_equal(pix.numpy()[:, :, ::8, ::8], g["r18_pix_sub"]) and np.array_equal(par.numpy(), g["r18_par"])
+    torch.manual_seed(7)
+    net2 = nets.build(MANO_OCR_stage, "ResNet_stage_18", 21, True)
+    assert list(net2.state_dict().keys()) == list(g["r18s2_keys"])
+    assert sum(p.numel() for p in net2.parameters()) == int(g["r18s2_nparams"][0])
+    torch.manual_seed(7)
+    net50 = nets.build(MANO_OCR_stage, "ResNet_stage_50", 21, True)
+    assert sum(p.numel() for p in net50.parameters()) == int(g["r50s2_nparams"][0])
+    assert len(net50.state_dict()) == int(g["r50s2_nkeys"][0])
+    torch.manual_seed(7)
+    hg = nets.build(PoseNet, 2, 21).eval()
+    assert list(hg.state_dict().keys()) == list(g["hg_keys"])
+    flat = []
+
+    def _flat(o):
+        if isinstance(o, (list, tuple)):
+            for q in o:
+                _flat(q)
+        else:
+            flat.append(o)
+    with torch.no_grad():
+        _flat(hg(x))
+    for i, o in enumerate(flat):
+        assert tuple(o.shape) == tuple(g["hg_out%d_shape" % i])
+        assert np.array_equal(o.numpy()[:, ::8, ::4, ::4], g["hg_out%d_sub" % i])
+    torch.manual_seed(7)
+    gen = nets.build(define_G, 1, 1, 64, "resnet_9blocks", "instance", False, "xavier").eval()
+    assert list(gen.state_dict().keys()) == list(g["gen_keys"])
+    with torch.no_grad():
+        assert np.array_equal(gen(x).numpy()[:, :, ::4, ::4], g["gen_out_sub"])
