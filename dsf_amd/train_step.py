@@ -54,11 +54,10 @@ def synthetic_batch(B, device, seed=0, dtype=torch.float32):
 
 
 def _default_adamw(params, lr, weight_decay):
-    """AdamW as the reference builds it (train_render.py:131-139): the one-launch HIP version on the GPU
-    (dsf_amd.optim.FusedAdamW; DSF_FUSED_ADAMW=0 or CPU parameters: torch.optim.AdamW)."""
+    """AdamW as the reference builds it (train_render.py:131-139): the one-launch HIP version
+    (dsf_amd.optim.FusedAdamW; DSF_FUSED_ADAMW=0 selects torch.optim.AdamW's multi-tensor kernels for A/B runs)."""
     import os
-    params = list(params)
-    if params and params[0].is_cuda and os.environ.get("DSF_FUSED_ADAMW", "1") == "1":
+    if os.environ.get("DSF_FUSED_ADAMW", "1") == "1":
         from .optim import FusedAdamW
         return FusedAdamW(params, lr=lr, weight_decay=weight_decay)
     return torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay)
