@@ -14,11 +14,13 @@ class SmoothL1Loss(torch.nn.Module):
         """``weight``: optional loss weight folded into the fused kernel's scale factor (the trainer multiplies every
         term by a constant, train_render.py:444-466; folding it saves a scalar multiply kernel each way)."""
         assert x.shape == y.shape
-        if x.is_cuda:
-            from .. import ops
-            fused = ops.huber_mean(x, y, 0.01, self.size_average, 1.0 if weight is None else float(weight))
-            if fused is not None:
-                return fused
+        if not x.is_cuda:
+            raise RuntimeError("dsf_amd SmoothL1Loss runs on the GPU only (got a %s tensor); there is no CPU path" % x.device)
+        from .. import ops
+        fused = ops.huber_mean(x, y, 0.01, self.size_average, 1.0 if weight is None else float(weight))
+        if fused is not None:
+            return fused
+        # target needs a gradient (or non-fp32 inputs): the reference's own formula, on the device
         z = (x - y).float()
         a = z.abs()
         per = torch.where(a < 0.01, 0.5 * z * z, 0.01 * (a - 0.005)).mean(dim=-1)

@@ -44,6 +44,15 @@ def test_product_path_has_no_cpu_fallback():
         ICPLoss(torch.zeros(1, 779, 3), torch.zeros(1, 8, 3), m.faces)
     with pytest.raises(RuntimeError):
         GFM().joint2offset(torch.zeros(1, 21, 3), torch.zeros(1, 1, 128, 128), 0.8, 64)
+    from dsf_amd.metric.losses import SmoothL1Loss
+    from dsf_amd.nn_conv import Conv2d
+    from dsf_amd.nn_norm import FusedBatchNorm2d
+    with pytest.raises(RuntimeError):
+        SmoothL1Loss()(torch.zeros(2, 3), torch.zeros(2, 3))
+    with pytest.raises(RuntimeError):
+        Conv2d(4, 4, 3)(torch.zeros(1, 4, 8, 8))
+    with pytest.raises(RuntimeError):
+        FusedBatchNorm2d(4)(torch.zeros(1, 4, 8, 8))
 
 
 def test_product_never_imports_the_oracle():
