@@ -1,8 +1,9 @@
 """Dual-branch backbone (counterpart of the reference's ``model/backbone.py``): a ResNet trunk
 regressing 62 MANO parameters plus a 3x-deconv pixel branch producing 84 offset/heat channels at
 64x64; with ``refine=True`` a second trunk consumes the stage-1 features fused with the re-encoded
-render of the stage-1 MANO estimate.  Convolutions run on PyTorch-ROCm (MIOpen MFMA kernels); the
-stage-2 bridge (``render.render`` + ``joint2offset``) runs on the HIP kernels of this package.
+render of the stage-1 MANO estimate.  Convolutions, BatchNorm(+add+ReLU) and the stage-2 bridge
+(``render.render`` + ``joint2offset``) all run on the HIP kernels of this package (csrc/conv.hip, norm.hip,
+raster.hip, image_ops.hip).
 Module / parameter names equal the reference's (``MANO_OCR_stage``, model/backbone.py:188-343) so
 its ``latest.pth`` / ``best.pth`` load unchanged."""
 import math
