@@ -1,0 +1,312 @@
+// fp32 convolution on the bf16 matrix cores by exact operand splitting ("bf16x6").
+//
+// gfx950 has no TF32/xf32 MFMA and its fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at 1/16 of the bf16 rate.  An fp32 value
+// is the exact sum of three bf16 values  x = h + m + l  (8 + 8 + 8 significand bits: h = bf16(x), m = bf16(x - h),
+// l = bf16(x - h - m); both subtractions are exact in fp32), so a product is  a b = ah bh + (ah bm + am bh) +
+// (ah bl + al bh + am bm) + O(2^-26 |a b|):  six bf16 MFMAs with fp32 accumulation reproduce the fp32 product to
+// better than one fp32 rounding (the dropped terms am bl, al bm, al bl are <= 2^-26 relative), at 16 / 6 = 2.7x the
+// fp32 MFMA rate.  Every bf16 product is exact in the fp32 accumulator (8 x 8 bit significands); what remains is the
+// same fp32 accumulation error the fp32 MFMA kernel has.  tests/test_gpu_conv.py compares both against float64.
+//
+// Data path of one workgroup (128 pixels x 128 channels of output, 4 waves of 64 x 64):
+//  * activations stay fp32 in HBM; the loader reads float4 (4 consecutive channels of one pixel, buffer loads with
+//    hardware zero fill for padding taps) and splits them into the three planes on its way to LDS;
+//  * weights are split ONCE per optimizer step by x6_split_weights_kernel into an image that is already laid out as the
+//    LDS tiles of this kernel (per tap, 16-channel chunk, 128-wide n tile: 3 planes x [k-group 2][n 128][8 bf16]), so a
+//    tile's B operand is three contiguous 4 KiB reads per chunk and needs no conversion in the hot loop;
+//  * LDS tiles are [plane][k-group][row] arrays of 16-byte granules (8 consecutive k of one row): the fragment of
+//    v_mfma_f32_32x32x16_bf16 (lane = row + 32 k-group, 8 consecutive k) is one conflict-free ds_read_b128;
+//  * two LDS stages of one 16-deep chunk each, two register sets for the global loads (chunk c + 2 in flight while
+//    chunk c + 1 waits for its stage), loader pieces handed out between the 24 MFMAs of a chunk.
+#include "common.h"
+
+#include <type_traits>
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct X6P { int B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad_h, pad_w; };
+
+constexpr int XBM = 128, XBN = 128, XBK = 16;
+constexpr uint32_t X_OOB = 0xFFFFFFFFu;
+constexpr int PLANE_GRANULES = 2 * 128;              // [k-group][row] granules of 16 bytes per plane
+constexpr int BLOCK_BYTES = 3 * PLANE_GRANULES * 16; // one (tap, chunk, n tile) block of the weight image
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t x6_buffer(const void* ptr, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 x6_load16(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
+    const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0);
+    return __builtin_bit_cast(u32x4, raw);
+}
+__device__ __forceinline__ int x6_xcd_contiguous(int bid, int total) {
+    const int q = total >> 3, rem = total & 7, xcd = bid & 7, local = bid >> 3;
+    return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
+}
+
+// two floats -> packed bf16 pair (round to nearest even; v_cvt_pk_bf16_f32), and back
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float pk_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float pk_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+// x = h + m + l exactly (to 2^-26 |x|): four floats -> three planes of four bf16
+__device__ __forceinline__ void split4(const u32x4 raw, uint2& h, uint2& m, uint2& l) {
+    const f32x4 v = __builtin_bit_cast(f32x4, raw);
+    h.x = pk_bf16(v[0], v[1]); h.y = pk_bf16(v[2], v[3]);
+    const float r0 = v[0] - pk_lo(h.x), r1 = v[1] - pk_hi(h.x), r2 = v[2] - pk_lo(h.y), r3 = v[3] - pk_hi(h.y);
+    m.x = pk_bf16(r0, r1); m.y = pk_bf16(r2, r3);
+    l.x = pk_bf16(r0 - pk_lo(m.x), r1 - pk_hi(m.x)); l.y = pk_bf16(r2 - pk_lo(m.y), r3 - pk_hi(m.y));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight image.  mode 0 (forward): n = output channel, k = input channel, taps in order;  W is the kernel layout
+// [KH][KW][Ci][Co].  mode 1 (backward-data of a stride-1 convolution): n = input channel, k = output channel, taps
+// flipped -- the image is that of the transposed, 180-degree-rotated filter, so the main kernel is the same.
+// One thread per granule (8 consecutive k of one n), all three planes.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void x6_split_weights_kernel(const float* __restrict__ W, uint4* __restrict__ img, int KH,
+                                                               int KW, int Ci, int Co, int mode, int chunks, int n_tiles,
+                                                               int64_t granules) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= granules) return;
+    const int nl = (int)(g & 127), kg = (int)((g >> 7) & 1);
+    int64_t blk = g >> 8;
+    const int n_tile = (int)(blk % n_tiles); blk /= n_tiles;
+    const int chunk = (int)(blk % chunks); const int tap = (int)(blk / chunks);
+    const int n = n_tile * 128 + nl, k0 = chunk * XBK + kg * 8;
+    const int Cn = mode ? Ci : Co, Ck = mode ? Co : Ci;
+    const int kh = tap / KW, kw = tap % KW;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = k0 + e;
+        float x = 0.f;
+        if (n < Cn && k < Ck)
+            x = mode ? W[((int64_t)((KH - 1 - kh) * KW + (KW - 1 - kw)) * Ci + n) * Co + k]
+                     : W[((int64_t)(kh * KW + kw) * Ci + k) * Co + n];
+        v[e] = x;
+    }
+    uint2 h0, m0, l0, h1, m1, l1;
+    split4(__builtin_bit_cast(u32x4, (f32x4){v[0], v[1], v[2], v[3]}), h0, m0, l0);
+    split4(__builtin_bit_cast(u32x4, (f32x4){v[4], v[5], v[6], v[7]}), h1, m1, l1);
+    const int64_t base = (g >> 8) * (3 * PLANE_GRANULES) + kg * 128 + nl;
+    img[base] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+    img[base + PLANE_GRANULES] = make_uint4(m0.x, m0.y, m1.x, m1.y);
+    img[base + 2 * PLANE_GRANULES] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Y[m][n] = bias[n] + sum_{tap, k} X[pixel(m) + tap][k] * Wimage[tap][k][n]      (dil 1, stride s)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void igemm_x6_kernel(const float* __restrict__ X, const uint4* __restrict__ Wimg,
+                                                         const float* __restrict__ bias, float* __restrict__ Y, X6P p,
+                                                         int m_tiles, int n_tiles, int k_splits, uint32_t x_bytes,
+                                                         uint32_t w_bytes) {
+    constexpr int TM = 2, TN = 2;
+    __shared__ uint4 As[2][3 * PLANE_GRANULES];
+    __shared__ uint4 Bs[2][3 * PLANE_GRANULES];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int tile = x6_xcd_contiguous(blockIdx.x, m_tiles * n_tiles * k_splits);
+    const int n_tile = tile % n_tiles; tile /= n_tiles;
+    const int m_tile = tile % m_tiles; const int ks = tile / m_tiles;
+    const int m0 = m_tile * XBM, n0 = n_tile * XBN;
+    const int M = p.B * p.Ho * p.Wo;
+    const __amdgpu_buffer_rsrc_t xbuf = x6_buffer(X, x_bytes), wbuf = x6_buffer(Wimg, w_bytes);
+
+    // A loader: thread -> (row (t >> 2) + 64 i, k-quad t & 3)
+    const int a_q = t & 3, a_k4 = a_q * 4, a_r = t >> 2;
+    int a_base[2], a_iy[2], a_ix[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + a_r + 64 * i;
+        const bool ok = m < M;
+        const int mm = ok ? m : 0;
+        const int ox = mm % p.Wo, q = mm / p.Wo, oy = q % p.Ho, b = q / p.Ho;
+        a_iy[i] = ok ? oy * p.stride - p.pad_h : -0x40000000;
+        a_ix[i] = ox * p.stride - p.pad_w;
+        a_base[i] = ((b * p.Hi + oy * p.stride - p.pad_h) * p.Wi + a_ix[i]) * p.Ci + a_k4;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int chunks_per_tap = (p.Ci + XBK - 1) / XBK;
+    const int n_chunks = p.KH * p.KW * chunks_per_tap;
+    const int per_split = (n_chunks + k_splits - 1) / k_splits;
+    const int chunk_lo = ks * per_split, chunk_hi = min(n_chunks, chunk_lo + per_split);
+
+    u32x4 ra[2][2], rb[2][3];
+    int l_tap = chunk_lo / chunks_per_tap, l_c0 = (chunk_lo % chunks_per_tap) * XBK;
+    int l_kh = l_tap / p.KW, l_kw = l_tap % p.KW;
+    int l_chunk = chunk_lo;
+    constexpr int NPIECE = 5;
+    auto load_piece = [&](auto SET, int i, bool live) {
+        constexpr int S = decltype(SET)::value;
+        if (i < 2) {
+            const int tap_off = (l_kh * p.Wi + l_kw) * p.Ci + l_c0;
+            const bool ok = live && l_c0 + a_k4 < p.Ci && (unsigned)(a_iy[i] + l_kh) < (unsigned)p.Hi &&
+                            (unsigned)(a_ix[i] + l_kw) < (unsigned)p.Wi;
+            ra[S][i] = x6_load16(xbuf, ok ? (uint32_t)(a_base[i] + tap_off) * 4u : X_OOB);
+        } else {
+            const int pl = i - 2;
+            const uint32_t dead = live ? 0u : X_OOB;                   // branch-free: (offset | ~0) is the out-of-range offset
+            rb[S][pl] = x6_load16(wbuf, ((uint32_t)(l_chunk * n_tiles + n_tile) * (uint32_t)BLOCK_BYTES +
+                                         (uint32_t)(pl * PLANE_GRANULES + t) * 16u) | dead);
+        }
+        if (i == NPIECE - 1) {
+            ++l_chunk; l_c0 += XBK;
+            if (l_c0 >= p.Ci) {
+                l_c0 = 0; ++l_kw;
+                if (l_kw == p.KW) { l_kw = 0; ++l_kh; }
+            }
+        }
+    };
+    auto stage_piece = [&](auto SET, int buf, int i) {
+        constexpr int S = decltype(SET)::value;
+        if (i < 2) {
+            uint2 h, m, l;
+            split4(ra[S][i], h, m, l);
+            // granule (k-group a_q >> 1, row), half a_q & 1
+            uint2* dst = reinterpret_cast<uint2*>(&As[buf][(a_q >> 1) * 128 + a_r + 64 * i]) + (a_q & 1);
+            dst[0] = h; dst[2 * PLANE_GRANULES] = m; dst[4 * PLANE_GRANULES] = l;
+        } else {
+            const int pl = i - 2;
+            Bs[buf][pl * PLANE_GRANULES + t] = __builtin_bit_cast(uint4, rb[S][pl]);
+        }
+    };
+
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, 1>;
+    if (chunk_lo < chunk_hi) {
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) load_piece(Set0{}, i, true);
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) load_piece(Set1{}, i, chunk_lo + 1 < chunk_hi);
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) stage_piece(Set0{}, 0, i);
+    }
+    __syncthreads();
+
+    const int frag_row = (lane >> 5) * 128 + (lane & 31);
+    auto body = [&](auto SET, auto OTHER, int chunk) {
+        constexpr int buf = decltype(SET)::value;
+        const bool live2 = chunk + 2 < chunk_hi;
+        bf16x8 a[3][TM], b[3][TN];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[pl][i] = __builtin_bit_cast(bf16x8, As[buf][pl * PLANE_GRANULES + frag_row + wm * 64 + i * 32]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b[pl][j] = __builtin_bit_cast(bf16x8, Bs[buf][pl * PLANE_GRANULES + frag_row + wn * 64 + j * 32]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // the six products; the ones on the low planes come last so that every fragment register stays live past the
+        // global loads issued in this chunk (a dead fragment register handed to a load forces `s_waitcnt vmcnt(0)` at
+        // the next fragment read).  Loader pieces in between: 5 loads of chunk c + 2, then 5 LDS stores of chunk c + 1.
+        constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};
+        int slot = 0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][i], b[PB[q]][j], acc[i][j], 0, 0, 0);
+                    if ((slot & 1) == 1) {
+#pragma unroll
+                        for (int pc = 0; pc < NPIECE; ++pc) {        // constant indices after unrolling
+                            if (pc == (slot >> 1)) load_piece(SET, pc, live2);
+                            // chunk c + 1 past the end was loaded as zeros into a stage nobody reads: no branch needed
+                            if (pc + NPIECE == (slot >> 1)) stage_piece(OTHER, buf ^ 1, pc);
+                        }
+                    }
+                    ++slot;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        __syncthreads();
+    };
+    for (int chunk = chunk_lo; chunk < chunk_hi; chunk += 2) {
+        body(Set0{}, Set1{}, chunk);
+        if (chunk + 1 < chunk_hi) body(Set1{}, Set0{}, chunk + 1);
+    }
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (n >= p.Co) continue;
+            const float bv = (bias && ks == 0) ? bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= M) continue;
+                if (k_splits > 1) atomicAdd(Y + (int64_t)m * p.Co + n, acc[i][j][r] + bv);
+                else Y[(int64_t)m * p.Co + n] = acc[i][j][r] + bv;
+            }
+        }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t dsf_conv_x6_image_bytes(int KH, int KW, int Ck, int Cn) {
+    const int64_t chunks = (Ck + XBK - 1) / XBK, n_tiles = (Cn + XBN - 1) / XBN;
+    return (int64_t)KH * KW * chunks * n_tiles * BLOCK_BYTES;
+}
+
+int dsf_conv_x6_split_weights(const float* W, void* image, int KH, int KW, int Ci, int Co, int mode, dsf_stream_t stream) {
+    DSF_CHECK_ARG(W && image && KH > 0 && KW > 0 && Ci > 0 && Co > 0 && (mode == 0 || mode == 1));
+    const int Ck = mode ? Co : Ci, Cn = mode ? Ci : Co;
+    const int chunks = (Ck + XBK - 1) / XBK, n_tiles = (Cn + XBN - 1) / XBN;
+    const int64_t granules = (int64_t)KH * KW * chunks * n_tiles * PLANE_GRANULES;
+    hipLaunchKernelGGL(x6_split_weights_kernel, dim3((unsigned)((granules + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W,
+                       (uint4*)image, KH, KW, Ci, Co, mode, chunks, n_tiles, granules);
+    return dsf_launch_status();
+}
+
+// Ci / Co are the reduction / output channel counts of the IMAGE (mode 1: those of the backward-data GEMM).
+int dsf_conv_x6_forward(const float* X, const void* image, const float* bias, float* Y, int B, int Hi, int Wi, int Ci, int Ho,
+                        int Wo, int Co, int KH, int KW, int stride, int pad_h, int pad_w, int k_splits, dsf_stream_t stream) {
+    DSF_CHECK_ARG(X && image && Y && B >= 0 && Hi > 0 && Wi > 0 && Ci > 0 && Ho > 0 && Wo > 0 && Co > 0 && KH > 0 && KW > 0);
+    DSF_CHECK_ARG(stride >= 1 && (Ci & 3) == 0);
+    if (B == 0) return DSF_OK;
+    X6P p = {B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad_h, pad_w};
+    const int64_t M = (int64_t)B * Ho * Wo;
+    const int64_t x_bytes = (int64_t)B * Hi * Wi * Ci * 4, w_bytes = dsf_conv_x6_image_bytes(KH, KW, Ci, Co);
+    DSF_CHECK_ARG(M < (1ll << 31) && x_bytes < 0xFFFFFFF0ll && w_bytes < 0xFFFFFFF0ll);
+    const int m_tiles = (int)((M + XBM - 1) / XBM), n_tiles = (Co + XBN - 1) / XBN;
+    const int n_chunks = KH * KW * ((Ci + XBK - 1) / XBK);
+    if (k_splits < 1) {                                 // auto: fewer tiles than ~1.5 per CU -> split K to ~2 workgroups per CU
+        const int tiles = m_tiles * n_tiles;
+        k_splits = tiles < 384 ? (512 + tiles / 2) / tiles : 1;
+        if (k_splits > n_chunks / 8) k_splits = n_chunks / 8;
+        if (k_splits < 1) k_splits = 1;
+    }
+    if (k_splits > n_chunks) k_splits = n_chunks;
+    if (k_splits > 1 &&
+        hipMemsetAsync(Y, 0, sizeof(float) * (size_t)M * Co, (hipStream_t)stream) != hipSuccess) return DSF_ERR_LAUNCH;
+    hipLaunchKernelGGL(igemm_x6_kernel, dim3(m_tiles * n_tiles * k_splits), dim3(256), 0, (hipStream_t)stream, X,
+                       (const uint4*)image, bias, Y, p, m_tiles, n_tiles, k_splits, (uint32_t)x_bytes, (uint32_t)w_bytes);
+    return dsf_launch_status();
+}
+
+}  // extern "C"

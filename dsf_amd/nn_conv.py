@@ -1,8 +1,11 @@
-"""Conv2d / ConvTranspose2d on the hand-written fp32 MFMA implicit-GEMM kernels
-(dsf_amd/csrc/conv.hip).  Drop-in subclasses of the torch modules: same parameters, state-dict
-keys and initialisation; only ``forward`` differs.  Activations are kept channels_last (NHWC in
-memory), which is what the kernels read and write.  GPU only: a CPU tensor raises.
+"""Conv2d / ConvTranspose2d on the hand-written implicit-GEMM kernels (dsf_amd/csrc/conv.hip: fp32 MFMA;
+dsf_amd/csrc/conv_x6.hip: the same fp32 products on the bf16 matrix cores by exact three-way operand splitting).
+Drop-in subclasses of the torch modules: same parameters, state-dict keys and initialisation; only ``forward``
+differs.  Activations are kept channels_last (NHWC in memory), which is what the kernels read and write.  GPU only:
+a CPU tensor raises.
 """
+import os
+
 import torch
 import torch.nn as nn
 from torch.autograd import Function
@@ -31,6 +34,56 @@ def _fwd(x, wk, bias, out_hw, Co, KH, KW, stride, dil, pad):
     check(L.lib().dsf_conv_igemm_forward(ptr_nhwc(x), ptr(wk), ptr(bias), ptr_nhwc(y), I(B), I(Hi), I(Wi), I(Ci), I(Ho),
                                          I(Wo), I(Co), I(KH), I(KW), I(stride), I(dil), I(pad[0]), I(pad[1]),
                                          stream_ptr()), "dsf_conv_igemm_forward")
+    return y
+
+
+# DSF_CONV_MATH=f32 keeps every convolution on the fp32 MFMA (v_mfma_f32_32x32x2_f32); the default routes the dilation-1
+# forward / backward-data GEMMs through conv_x6.hip (six bf16 MFMAs per fp32 product, fp32-grade results, ~1.5x faster).
+MATH = os.environ.get("DSF_CONV_MATH", "x6")
+_EPOCH = 0
+
+
+def weights_changed():
+    """Called by whoever rewrites parameters through raw pointers (optim.FusedAdamW): torch's version counter does not
+    see such writes, and the split weight images of conv_x6 are cached per (tensor version, epoch)."""
+    global _EPOCH
+    _EPOCH += 1
+
+
+def _x6_ok(Ck):
+    return MATH == "x6" and Ck % 4 == 0 and Ck >= 16
+
+
+def _x6_image(weight, wk, mode):
+    """bf16x3 image of ``wk`` = [KH][KW][Ci][Co] (a view of ``weight``'s memory): mode 0 the forward operand, mode 1
+    the stride-1 backward-data operand.  Cached on the parameter until it changes; temporaries are split per call."""
+    KH, KW, Ci, Co = wk.shape
+    key = (weight._version, _EPOCH, wk.data_ptr())
+    cache = weight.__dict__.get("_dsf_x6")
+    if cache is not None and mode in cache and cache[mode][0] == key:
+        return cache[mode][1]
+    Ck, Cn = (Co, Ci) if mode else (Ci, Co)
+    n = L.lib().dsf_conv_x6_image_bytes(I(KH), I(KW), I(Ck), I(Cn))
+    img = cache[mode][1] if (cache is not None and mode in cache and cache[mode][1].numel() == n) else \
+        torch.empty(n, device=wk.device, dtype=torch.uint8)
+    check(L.lib().dsf_conv_x6_split_weights(ptr(wk), ptr(img), I(KH), I(KW), I(Ci), I(Co), I(mode), stream_ptr()),
+          "dsf_conv_x6_split_weights")
+    if cache is None:
+        cache = weight.__dict__.setdefault("_dsf_x6", {})
+    cache[mode] = (key, img)
+    return img
+
+
+def _fwd_x6(x, image, bias, out_hw, Co, KH, KW, stride, pad):
+    """_fwd (dilation 1) with the weight operand given as a conv_x6 image whose reduction width is x's channel count."""
+    B, Ci, Hi, Wi = x.shape
+    Ho, Wo = out_hw
+    if RECORD is not None:
+        RECORD.append(("x6", B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, 1, pad[0], pad[1]))
+    y = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=CL)
+    check(L.lib().dsf_conv_x6_forward(ptr_nhwc(x), ptr(image), ptr(bias), ptr_nhwc(y), I(B), I(Hi), I(Wi), I(Ci), I(Ho), I(Wo),
+                                      I(Co), I(KH), I(KW), I(stride), I(pad[0]), I(pad[1]), I(0), stream_ptr()),
+          "dsf_conv_x6_forward")
     return y
 
 
@@ -159,8 +212,11 @@ class Conv2dFunction(Function):
         Ho = (Hi + 2 * padding[0] - KH) // stride + 1
         Wo = (Wi + 2 * padding[1] - KW) // stride + 1
         wk = weight.detach().float().permute(2, 3, 1, 0).contiguous()          # a free view when the weight has kernel layout
-        y = _fwd(x, wk, bias.detach().float().contiguous() if bias is not None else None, (Ho, Wo), Co, KH, KW, stride, 1,
-                 padding)
+        b = bias.detach().float().contiguous() if bias is not None else None
+        if _x6_ok(Ci):
+            y = _fwd_x6(x, _x6_image(weight, wk, 0), b, (Ho, Wo), Co, KH, KW, stride, padding)
+        else:
+            y = _fwd(x, wk, b, (Ho, Wo), Co, KH, KW, stride, 1, padding)
         ctx.save_for_backward(x, weight, wk)
         ctx.cfg = (stride, padding, bias is not None)
         return y
@@ -173,7 +229,10 @@ class Conv2dFunction(Function):
         Co, Ci, KH, KW = weight.shape
         gy = _nhwc(gy)
         gx = gw = gb = None
-        if ctx.needs_input_grad[0] and stride == 1 and Co >= 32 and Co % 4 == 0 and Ci % 4 == 0:
+        if ctx.needs_input_grad[0] and stride == 1 and _x6_ok(Co):
+            gx = _fwd_x6(gy, _x6_image(weight, wk, 1), None, (x.shape[2], x.shape[3]), Ci, KH, KW, 1,
+                         (KH - 1 - padding[0], KW - 1 - padding[1]))
+        elif ctx.needs_input_grad[0] and stride == 1 and Co >= 32 and Co % 4 == 0 and Ci % 4 == 0:
             gx = _bwd_data_s1(gy, wk, (x.shape[2], x.shape[3]), Ci, KH, KW, padding)
         elif ctx.needs_input_grad[0] and _wt_ok(Co, Ci, x.shape[2], x.shape[3], stride):
             # backward-data as a dilated convolution over gy; wk (the forward operand) is its transposed, flipped weight
@@ -217,7 +276,10 @@ class ConvTranspose2dFunction(Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             wd = weight.detach().float().permute(2, 3, 1, 0).contiguous()                     # [kh][kw][Cout][Cin]
-            gx = _fwd(gy, wd, None, (x.shape[2], x.shape[3]), Cin, KH, KW, stride, 1, padding)
+            if _x6_ok(Cout):
+                gx = _fwd_x6(gy, _x6_image(weight, wd, 0), None, (x.shape[2], x.shape[3]), Cin, KH, KW, stride, padding)
+            else:
+                gx = _fwd(gy, wd, None, (x.shape[2], x.shape[3]), Cin, KH, KW, stride, 1, padding)
         if ctx.needs_input_grad[1]:
             gw = _wrw(gy, x, KH, KW, stride, padding).permute(3, 2, 0, 1)                      # [kh][kw][Cout][Cin] -> (Cin,Cout,kh,kw)
         if has_bias and ctx.needs_input_grad[2]:
@@ -285,6 +347,10 @@ def replay(rec, iters=3):
     if kind == "fwd":
         wk = torch.randn(KH, KW, Ci, Co, device=dev)
         run = lambda: _fwd(x, wk, None, (Ho, Wo), Co, KH, KW, stride, dil, (ph, pw))
+    elif kind == "x6":
+        wk = torch.randn(KH, KW, Ci, Co, device=dev)
+        img = _x6_image(wk, wk, 0)
+        run = lambda: _fwd_x6(x, img, None, (Ho, Wo), Co, KH, KW, stride, (ph, pw))
     elif kind == "fwd_wt":
         wt = torch.randn(KH, KW, Co, Ci, device=dev)
         run = lambda: _fwd_wt(x, wt, None, (Ho, Wo), Co, KH, KW, stride, dil, (ph, pw))
@@ -320,6 +386,8 @@ def kernel_name(rec):
     M = B * Ho * Wo
     n_tiles = (Co + bn - 1) // bn
     vec = Ci % 4 == 0 and Co % 4 == 0
+    if kind == "x6":
+        return "igemm_x6_kernel"
     if kind in ("fwd", "fwd_wt", "bwd_s1"):
         wt = "false" if kind == "fwd" else "true"
         if dil == 1 and Ci >= 32 and vec:

@@ -124,4 +124,6 @@ class FusedAdamW(torch.optim.Optimizer):
                                           I(tb["n_chunks"]), D(group["lr"]), D(b1), D(b2), D(group["eps"]),
                                           D(group["weight_decay"]), D(1.0 - math.pow(b1, step)), D(1.0 - math.pow(b2, step)),
                                           stream_ptr()), "dsf_adamw_multi")
+        from . import nn_conv
+        nn_conv.weights_changed()            # the kernel wrote the parameters behind torch's version counters
         return loss

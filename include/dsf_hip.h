@@ -319,6 +319,26 @@ int dsf_conv_igemm_wrw(const float* X, const float* dY, float* dW, int B, int Hi
                        int Co, int KH, int KW, int stride, int pad_h, int pad_w, int accumulate, dsf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * fp32 convolution on the bf16 matrix cores by exact operand splitting (csrc/conv_x6.hip).  Same callers as
+ * dsf_conv_igemm_forward (model/backbone.py:200-233, model/resnet.py, model/hourglass.py, render_model/transfer.py).
+ * Every fp32 operand is the exact sum of three bf16 values; six bf16 MFMAs with fp32 accumulation reproduce the fp32
+ * product to 2^-26 relative, so results carry the same (accumulation-order) error as the fp32-MFMA kernels -- measured
+ * against float64 in tests/test_gpu_conv.py -- at up to 16/6 of their rate.
+ *
+ * The weight operand is an IMAGE made once per weight update by dsf_conv_x6_split_weights:
+ *   mode 0: W [KH][KW][Ci][Co] as the forward operand (reduction Ci, outputs Co);
+ *   mode 1: the same memory as the stride-1 backward-data operand (reduction Co, outputs Ci, taps flipped).
+ * dsf_conv_x6_image_bytes(KH, KW, Ck, Cn): size of an image with reduction width Ck and Cn outputs.
+ * dsf_conv_x6_forward: Y[b,oy,ox,:] = bias + sum_taps X[b, oy*stride - pad_h + kh, ox*stride - pad_w + kw, :] . image
+ *   (NHWC, dilation 1); Ci / Co are the image's reduction / output widths, Ci % 4 == 0.  k_splits <= 0: chosen by the
+ *   launcher (split-K partial sums meet in Y with float atomics when > 1).
+ * ---------------------------------------------------------------------------------- */
+int64_t dsf_conv_x6_image_bytes(int KH, int KW, int Ck, int Cn);
+int dsf_conv_x6_split_weights(const float* W, void* image, int KH, int KW, int Ci, int Co, int mode, dsf_stream_t stream);
+int dsf_conv_x6_forward(const float* X, const void* image, const float* bias, float* Y, int B, int Hi, int Wi, int Ci, int Ho,
+                        int Wo, int Co, int KH, int KW, int stride, int pad_h, int pad_w, int k_splits, dsf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Fused training-mode BatchNorm2d (+ residual add) (+ ReLU) on NHWC activations, x viewed as (M, C).
  * Replaces nn.BatchNorm2d + `out += identity` + nn.ReLU of model/resnet.py:38-55, 82-98 and the
  * conv-bn-relu sequences of model/backbone.py:16-42 (3 + 1 + 1 forward and 3 + 1 backward kernels in

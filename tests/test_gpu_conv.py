@@ -106,3 +106,66 @@ def test_fused_batchnorm_matches_torch_cpu(C, H, res, relu):
     with torch.no_grad():
         ye = ref(x)
         assert _rel(fused(xg.detach()).cpu(), ye) < 1e-5
+
+
+# ---- conv_x6: fp32 products on the bf16 matrix cores by exact three-way operand splitting --------------------------------
+X6_CASES = [
+    # Ci, Co, K, stride, pad, H, B
+    (488, 256, 3, 1, 1, 16, 4),           # stage-2 fusion conv: Ci % 16 != 0 (zero-padded last chunk), two n tiles
+    (64, 64, 3, 1, 1, 64, 2),
+    (256, 84, 1, 1, 0, 32, 2),            # merged heads: ragged n tile
+    (20, 36, 3, 2, 1, 17, 3),             # ragged everything, stride 2
+    (512, 512, 3, 1, 1, 8, 32),           # small map: split-K with float atomics
+    (256, 256, 4, 2, 1, 32, 2),           # ConvTranspose2d backward-data geometry
+]
+
+
+@pytest.mark.parametrize("Ci,Co,K,s,p,H,B", X6_CASES)
+def test_x6_matches_float64_as_closely_as_the_fp32_mfma(Ci, Co, K, s, p, H, B, monkeypatch):
+    """Both kernels against a float64 convolution: the split path must be in the same error class as the fp32 MFMA
+    (its products are exact to 2^-26; what is left is fp32 accumulation order), far inside the 1e-4 parity bar."""
+    from dsf_amd import nn_conv
+    g = torch.Generator().manual_seed(Ci + 3 * Co + K)
+    x = torch.randn(B, Ci, H, H, generator=g).cuda().requires_grad_(True)
+    w = (torch.randn(Co, Ci, K, K, generator=g) / (Ci * K * K) ** 0.5).cuda().requires_grad_(True)
+    gy = None
+    out = {}
+    for math in ("x6", "f32"):
+        monkeypatch.setattr(nn_conv, "MATH", math)
+        nn_conv.RECORD = []
+        y = nn_conv.Conv2dFunction.apply(x, w, None, s, (p, p))
+        gy = torch.randn(y.shape, generator=g).cuda() if gy is None else gy
+        gx, = torch.autograd.grad((y * gy).sum(), [x])
+        kinds = {r[0] for r in nn_conv.RECORD}
+        nn_conv.RECORD = None
+        assert ("x6" in kinds) == (math == "x6")
+        out[math] = (y.detach().double().cpu(), gx.double().cpu())
+    xd = x.detach().double().cpu().requires_grad_(True)
+    yd = F.conv2d(xd, w.detach().double().cpu(), None, stride=s, padding=p)
+    gxd, = torch.autograd.grad((yd * gy.double().cpu()).sum(), [xd])
+    for i, ref in enumerate((yd.detach(), gxd)):
+        e6, e32 = _rel(out["x6"][i], ref), _rel(out["f32"][i], ref)
+        assert e6 < 2e-6, (i, e6)
+        assert e6 < 3 * e32 + 1e-7, (i, e6, e32)
+
+
+def test_x6_weight_images_follow_the_weights():
+    """The split image is cached on the parameter: in-place torch updates (version counter) and FusedAdamW's raw-pointer
+    updates (nn_conv.weights_changed) must both invalidate it; an unchanged weight must not be split again."""
+    from dsf_amd import nn_conv
+    from dsf_amd.optim import FusedAdamW
+    torch.manual_seed(0)
+    conv = nn_conv.Conv2d(32, 48, 3, padding=1, bias=False).cuda()
+    x = torch.randn(2, 32, 12, 12, device="cuda")
+    ref = lambda: F.conv2d(x.double(), conv.weight.detach().double(), padding=1)
+    y0 = conv(x)
+    img = conv.weight.__dict__["_dsf_x6"][0][1]
+    conv(x)
+    assert conv.weight.__dict__["_dsf_x6"][0][1] is img and _rel(y0.double(), ref()) < 2e-6
+    with torch.no_grad():
+        conv.weight.mul_(-2.0)
+    assert _rel(conv(x).double(), ref()) < 2e-6
+    opt = FusedAdamW(conv.parameters(), lr=0.1)
+    conv(x).square().mean().backward()
+    opt.step()
+    assert _rel(conv(x).double(), ref()) < 2e-6
