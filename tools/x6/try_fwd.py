@@ -4,8 +4,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from dsf_amd import nn_conv, _lib as L
-x6 = ctypes.CDLL(os.path.join(ROOT, "dsf_amd", "lib", "libx6_try.so"))
-x6.dsf_conv_x6_image_bytes.restype = ctypes.c_int64
+x6 = L.lib()
 I = ctypes.c_int
 P = lambda t: ctypes.c_void_p(t.data_ptr())
 CL = torch.channels_last
