@@ -33,10 +33,15 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 struct X6P { int B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad_h, pad_w; };
 
-constexpr int XBM = 128, XBN = 128, XBK = 16;
+constexpr int XBM = 128, XBK = 16;
 constexpr uint32_t X_OOB = 0xFFFFFFFFu;
-constexpr int PLANE_GRANULES = 2 * 128;              // [k-group][row] granules of 16 bytes per plane
-constexpr int BLOCK_BYTES = 3 * PLANE_GRANULES * 16; // one (tap, chunk, n tile) block of the weight image
+// Weight image (HBM): per (tap, 16-channel chunk, n tile) one block of 3 planes x [k-group 2][n BN] granules of 16 bytes
+// (8 consecutive k of one n).  BN = 128 output channels per tile, 64 when the layer has at most 64.
+__host__ __device__ constexpr int x6_bn(int Cn) { return Cn > 64 ? 128 : 64; }
+// LDS copy of a plane: the second k-group starts 4 granules (16 banks) later, so that the 16-lane groups of the loader's
+// ds_write_b64 (4 rows x 4 k-quads: both k-groups of a row) do not meet on a bank (they were 2-way: 55 M conflict cycles
+// of 110 M LDS cycles on the 488->256 layer)
+template <int ROWS> struct LdsPlane { static constexpr int KG = ROWS + 4, SIZE = 2 * KG; };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t x6_buffer(const void* ptr, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, bytes, 0x00020000);
@@ -75,14 +80,14 @@ __device__ __forceinline__ void split4(const u32x4 raw, uint2& h, uint2& m, uint
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void x6_split_weights_kernel(const float* __restrict__ W, uint4* __restrict__ img, int KH,
                                                                int KW, int Ci, int Co, int mode, int chunks, int n_tiles,
-                                                               int64_t granules) {
+                                                               int bn, int64_t granules) {
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g >= granules) return;
-    const int nl = (int)(g & 127), kg = (int)((g >> 7) & 1);
-    int64_t blk = g >> 8;
+    const int nl = (int)(g % bn), kg = (int)((g / bn) & 1);
+    int64_t blk = g / (2 * bn);
     const int n_tile = (int)(blk % n_tiles); blk /= n_tiles;
     const int chunk = (int)(blk % chunks); const int tap = (int)(blk / chunks);
-    const int n = n_tile * 128 + nl, k0 = chunk * XBK + kg * 8;
+    const int n = n_tile * bn + nl, k0 = chunk * XBK + kg * 8;
     const int Cn = mode ? Ci : Co, Ck = mode ? Co : Ci;
     const int kh = tap / KW, kw = tap % KW;
     float v[8];
@@ -98,28 +103,34 @@ __global__ __launch_bounds__(256) void x6_split_weights_kernel(const float* __re
     uint2 h0, m0, l0, h1, m1, l1;
     split4(__builtin_bit_cast(u32x4, (f32x4){v[0], v[1], v[2], v[3]}), h0, m0, l0);
     split4(__builtin_bit_cast(u32x4, (f32x4){v[4], v[5], v[6], v[7]}), h1, m1, l1);
-    const int64_t base = (g >> 8) * (3 * PLANE_GRANULES) + kg * 128 + nl;
+    const int64_t base = (g / (2 * bn)) * (6 * bn) + kg * bn + nl;
     img[base] = make_uint4(h0.x, h0.y, h1.x, h1.y);
-    img[base + PLANE_GRANULES] = make_uint4(m0.x, m0.y, m1.x, m1.y);
-    img[base + 2 * PLANE_GRANULES] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    img[base + 2 * bn] = make_uint4(m0.x, m0.y, m1.x, m1.y);
+    img[base + 4 * bn] = make_uint4(l0.x, l0.y, l1.x, l1.y);
 }
 
 // ------------------------------------------------------------------------------------------------
 // Y[m][n] = bias[n] + sum_{tap, k} X[pixel(m) + tap][k] * Wimage[tap][k][n]      (dil 1, stride s)
 // ------------------------------------------------------------------------------------------------
+template <int BN>
 __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(const float* __restrict__ X, const uint4* __restrict__ Wimg,
                                                          const float* __restrict__ bias, float* __restrict__ Y, X6P p,
                                                          int m_tiles, int n_tiles, int k_splits, uint32_t x_bytes,
                                                          uint32_t w_bytes) {
-    constexpr int TM = 2, TN = 2;
-    __shared__ uint4 As[2][3 * PLANE_GRANULES];
-    __shared__ uint4 Bs[2][3 * PLANE_GRANULES];
+    constexpr int WM = (BN == 128) ? 64 : 32;            // wave sub-tile WM x 64: 2 x 2 waves (BN 128) or 4 x 1 (BN 64)
+    constexpr int TM = WM / 32, TN = 2;
+    using LA = LdsPlane<XBM>;
+    using LB = LdsPlane<BN>;
+    constexpr int B_GRANULES = 2 * BN;                   // per plane of one image block
+    __shared__ uint4 As[2][3 * LA::SIZE];
+    __shared__ uint4 Bs[2][3 * LB::SIZE];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = (BN == 128) ? (wave >> 1) : wave, wn = (BN == 128) ? (wave & 1) : 0;
     int tile = x6_xcd_contiguous(blockIdx.x, m_tiles * n_tiles * k_splits);
     const int n_tile = tile % n_tiles; tile /= n_tiles;
     const int m_tile = tile % m_tiles; const int ks = tile / m_tiles;
-    const int m0 = m_tile * XBM, n0 = n_tile * XBN;
+    const int m0 = m_tile * XBM, n0 = n_tile * BN;
+    const bool b_thread = t < B_GRANULES;                // BN 64: waves 0-1 carry the B tile (wave-uniform)
     const int M = p.B * p.Ho * p.Wo;
     const __amdgpu_buffer_rsrc_t xbuf = x6_buffer(X, x_bytes), wbuf = x6_buffer(Wimg, w_bytes);
 
@@ -164,9 +175,9 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(const float* __restric
             ra[S][i] = x6_load16(xbuf, ok ? (uint32_t)(a_base[i] + tap_off) * 4u : X_OOB);
         } else {
             const int pl = i - 2;
-            const uint32_t dead = live ? 0u : X_OOB;                   // branch-free: (offset | ~0) is the out-of-range offset
-            rb[S][pl] = x6_load16(wbuf, ((uint32_t)(l_chunk * n_tiles + n_tile) * (uint32_t)BLOCK_BYTES +
-                                         (uint32_t)(pl * PLANE_GRANULES + t) * 16u) | dead);
+            const uint32_t dead = (live && b_thread) ? 0u : X_OOB;     // branch-free: (offset | ~0) is the out-of-range offset
+            rb[S][pl] = x6_load16(wbuf, ((uint32_t)(l_chunk * n_tiles + n_tile) * (uint32_t)(3 * B_GRANULES * 16) +
+                                         (uint32_t)(pl * B_GRANULES + t) * 16u) | dead);
         }
         if (i == NPIECE - 1) {
             ++l_chunk; l_c0 += XBK;
@@ -182,11 +193,12 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(const float* __restric
             uint2 h, m, l;
             split4(ra[S][i], h, m, l);
             // granule (k-group a_q >> 1, row), half a_q & 1
-            uint2* dst = reinterpret_cast<uint2*>(&As[buf][(a_q >> 1) * 128 + a_r + 64 * i]) + (a_q & 1);
-            dst[0] = h; dst[2 * PLANE_GRANULES] = m; dst[4 * PLANE_GRANULES] = l;
+            uint2* dst = reinterpret_cast<uint2*>(&As[buf][(a_q >> 1) * LA::KG + a_r + 64 * i]) + (a_q & 1);
+            dst[0] = h; dst[2 * LA::SIZE] = m; dst[4 * LA::SIZE] = l;
         } else {
             const int pl = i - 2;
-            Bs[buf][pl * PLANE_GRANULES + t] = __builtin_bit_cast(uint4, rb[S][pl]);
+            if (BN == 128 || b_thread)
+                Bs[buf][pl * LB::SIZE + (t / BN) * LB::KG + (t % BN)] = __builtin_bit_cast(uint4, rb[S][pl]);
         }
     };
 
@@ -202,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(const float* __restric
     }
     __syncthreads();
 
-    const int frag_row = (lane >> 5) * 128 + (lane & 31);
+    const int a_frag = (lane >> 5) * LA::KG + (lane & 31) + wm * WM, b_frag = (lane >> 5) * LB::KG + (lane & 31) + wn * 64;
     auto body = [&](auto SET, auto OTHER, int chunk) {
         constexpr int buf = decltype(SET)::value;
         const bool live2 = chunk + 2 < chunk_hi;
@@ -211,10 +223,10 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(const float* __restric
         for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                a[pl][i] = __builtin_bit_cast(bf16x8, As[buf][pl * PLANE_GRANULES + frag_row + wm * 64 + i * 32]);
+                a[pl][i] = __builtin_bit_cast(bf16x8, As[buf][pl * LA::SIZE + a_frag + i * 32]);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                b[pl][j] = __builtin_bit_cast(bf16x8, Bs[buf][pl * PLANE_GRANULES + frag_row + wn * 64 + j * 32]);
+                b[pl][j] = __builtin_bit_cast(bf16x8, Bs[buf][pl * LB::SIZE + b_frag + j * 32]);
         }
         __builtin_amdgcn_sched_barrier(0);
         // the six products; the ones on the low planes come last so that every fragment register stays live past the
@@ -229,13 +241,12 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(const float* __restric
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][i], b[PB[q]][j], acc[i][j], 0, 0, 0);
-                    if ((slot & 1) == 1) {
 #pragma unroll
-                        for (int pc = 0; pc < NPIECE; ++pc) {        // constant indices after unrolling
-                            if (pc == (slot >> 1)) load_piece(SET, pc, live2);
-                            // chunk c + 1 past the end was loaded as zeros into a stage nobody reads: no branch needed
-                            if (pc + NPIECE == (slot >> 1)) stage_piece(OTHER, buf ^ 1, pc);
-                        }
+                    for (int pc = 0; pc < NPIECE; ++pc) {            // constant indices after unrolling
+                        // 24 MFMAs (BN 128): a piece behind every second one; 12 (BN 64): behind every one
+                        if (slot == (TM == 2 ? 2 * pc + 1 : pc)) load_piece(SET, pc, live2);
+                        // chunk c + 1 past the end was loaded as zeros into a stage nobody reads: no branch needed
+                        if (slot == (TM == 2 ? 2 * (pc + NPIECE) + 1 : pc + NPIECE)) stage_piece(OTHER, buf ^ 1, pc);
                     }
                     ++slot;
                     __builtin_amdgcn_sched_barrier(0);
@@ -256,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(const float* __restric
             const float bv = (bias && ks == 0) ? bias[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m >= M) continue;
                 if (k_splits > 1) atomicAdd(Y + (int64_t)m * p.Co + n, acc[i][j][r] + bv);
                 else Y[(int64_t)m * p.Co + n] = acc[i][j][r] + bv;
@@ -269,17 +280,19 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(const float* __restric
 extern "C" {
 
 int64_t dsf_conv_x6_image_bytes(int KH, int KW, int Ck, int Cn) {
-    const int64_t chunks = (Ck + XBK - 1) / XBK, n_tiles = (Cn + XBN - 1) / XBN;
-    return (int64_t)KH * KW * chunks * n_tiles * BLOCK_BYTES;
+    const int bn = x6_bn(Cn);
+    const int64_t chunks = (Ck + XBK - 1) / XBK, n_tiles = (Cn + bn - 1) / bn;
+    return (int64_t)KH * KW * chunks * n_tiles * (3 * 2 * bn * 16);
 }
 
 int dsf_conv_x6_split_weights(const float* W, void* image, int KH, int KW, int Ci, int Co, int mode, dsf_stream_t stream) {
     DSF_CHECK_ARG(W && image && KH > 0 && KW > 0 && Ci > 0 && Co > 0 && (mode == 0 || mode == 1));
     const int Ck = mode ? Co : Ci, Cn = mode ? Ci : Co;
-    const int chunks = (Ck + XBK - 1) / XBK, n_tiles = (Cn + XBN - 1) / XBN;
-    const int64_t granules = (int64_t)KH * KW * chunks * n_tiles * PLANE_GRANULES;
+    const int bn = x6_bn(Cn);
+    const int chunks = (Ck + XBK - 1) / XBK, n_tiles = (Cn + bn - 1) / bn;
+    const int64_t granules = (int64_t)KH * KW * chunks * n_tiles * 2 * bn;
     hipLaunchKernelGGL(x6_split_weights_kernel, dim3((unsigned)((granules + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W,
-                       (uint4*)image, KH, KW, Ci, Co, mode, chunks, n_tiles, granules);
+                       (uint4*)image, KH, KW, Ci, Co, mode, chunks, n_tiles, bn, granules);
     return dsf_launch_status();
 }
 
@@ -293,7 +306,8 @@ int dsf_conv_x6_forward(const float* X, const void* image, const float* bias, fl
     const int64_t M = (int64_t)B * Ho * Wo;
     const int64_t x_bytes = (int64_t)B * Hi * Wi * Ci * 4, w_bytes = dsf_conv_x6_image_bytes(KH, KW, Ci, Co);
     DSF_CHECK_ARG(M < (1ll << 31) && x_bytes < 0xFFFFFFF0ll && w_bytes < 0xFFFFFFF0ll);
-    const int m_tiles = (int)((M + XBM - 1) / XBM), n_tiles = (Co + XBN - 1) / XBN;
+    const int bn = x6_bn(Co);
+    const int m_tiles = (int)((M + XBM - 1) / XBM), n_tiles = (Co + bn - 1) / bn;
     const int n_chunks = KH * KW * ((Ci + XBK - 1) / XBK);
     if (k_splits < 1) {                                 // auto: fewer tiles than ~1.5 per CU -> split K to ~2 workgroups per CU
         const int tiles = m_tiles * n_tiles;
@@ -304,8 +318,13 @@ int dsf_conv_x6_forward(const float* X, const void* image, const float* bias, fl
     if (k_splits > n_chunks) k_splits = n_chunks;
     if (k_splits > 1 &&
         hipMemsetAsync(Y, 0, sizeof(float) * (size_t)M * Co, (hipStream_t)stream) != hipSuccess) return DSF_ERR_LAUNCH;
-    hipLaunchKernelGGL(igemm_x6_kernel, dim3(m_tiles * n_tiles * k_splits), dim3(256), 0, (hipStream_t)stream, X,
-                       (const uint4*)image, bias, Y, p, m_tiles, n_tiles, k_splits, (uint32_t)x_bytes, (uint32_t)w_bytes);
+    const dim3 grid(m_tiles * n_tiles * k_splits);
+    if (bn == 128)
+        hipLaunchKernelGGL(igemm_x6_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, X, (const uint4*)image, bias, Y, p,
+                           m_tiles, n_tiles, k_splits, (uint32_t)x_bytes, (uint32_t)w_bytes);
+    else
+        hipLaunchKernelGGL(igemm_x6_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, X, (const uint4*)image, bias, Y, p,
+                           m_tiles, n_tiles, k_splits, (uint32_t)x_bytes, (uint32_t)w_bytes);
     return dsf_launch_status();
 }
 
