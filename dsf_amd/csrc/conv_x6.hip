@@ -78,11 +78,8 @@ __device__ __forceinline__ void split4(const u32x4 raw, uint2& h, uint2& m, uint
 // flipped -- the image is that of the transposed, 180-degree-rotated filter, so the main kernel is the same.
 // One thread per granule (8 consecutive k of one n), all three planes.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void x6_split_weights_kernel(const float* __restrict__ W, uint4* __restrict__ img, int KH,
-                                                               int KW, int Ci, int Co, int mode, int chunks, int n_tiles,
-                                                               int bn, int64_t granules) {
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g >= granules) return;
+__device__ __forceinline__ void x6_split_granule(const float* __restrict__ W, uint4* __restrict__ img, int KH, int KW, int Ci,
+                                                 int Co, int mode, int chunks, int n_tiles, int bn, int64_t g) {
     const int nl = (int)(g % bn), kg = (int)((g / bn) & 1);
     int64_t blk = g / (2 * bn);
     const int n_tile = (int)(blk % n_tiles); blk /= n_tiles;
@@ -109,10 +106,38 @@ __global__ __launch_bounds__(256) void x6_split_weights_kernel(const float* __re
     img[base + 4 * bn] = make_uint4(l0.x, l0.y, l1.x, l1.y);
 }
 
+__global__ __launch_bounds__(256) void x6_split_weights_kernel(const float* __restrict__ W, uint4* __restrict__ img, int KH,
+                                                               int KW, int Ci, int Co, int mode, int chunks, int n_tiles,
+                                                               int bn, int64_t granules) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g < granules) x6_split_granule(W, img, KH, KW, Ci, Co, mode, chunks, n_tiles, bn, g);
+}
+
+// every image of a network in ONE launch (after an optimizer step): jobs[j] = {W, image, KH, KW, Ci, Co, mode, first granule
+// of the job in the launch-wide numbering}, jobs[n_jobs][7] = the total; a thread finds its job by bisection.
+__global__ __launch_bounds__(256) void x6_split_weights_multi_kernel(const int64_t* __restrict__ jobs, int n_jobs) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= jobs[(int64_t)n_jobs * 8 + 7]) return;
+    int lo = 0, hi = n_jobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[(int64_t)mid * 8 + 7] <= g) lo = mid; else hi = mid - 1;
+    }
+    const int64_t* j = jobs + (int64_t)lo * 8;
+    const int KH = (int)j[2], KW = (int)j[3], Ci = (int)j[4], Co = (int)j[5], mode = (int)j[6];
+    const int Ck = mode ? Co : Ci, Cn = mode ? Ci : Co, bn = x6_bn(Cn);
+    x6_split_granule(reinterpret_cast<const float*>(j[0]), reinterpret_cast<uint4*>(j[1]), KH, KW, Ci, Co, mode,
+                     (Ck + XBK - 1) / XBK, (Cn + bn - 1) / bn, bn, g - j[7]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Y[m][n] = bias[n] + sum_{tap, k} X[pixel(m) + tap][k] * Wimage[tap][k][n]      (dil 1, stride s)
 // ------------------------------------------------------------------------------------------------
-template <int BN>
+// DIL2: the transposed-convolution gather (virtual input = X upsampled by 2 with zeros, stride 1) of ConvTranspose2d forward
+// and of the backward-data pass of stride-2 convolutions.  Output pixels are then numbered parity-class-major
+// ((oy & 1, ox & 1) classes of B * Ho/2 * Wo/2 pixels each), so a tile shares its parity, only the taps of matching parity
+// can meet data and the walk visits just those (a quarter of a 4x4 filter's taps); Ho and Wo must be even.
+template <int BN, bool DIL2>
 __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(const float* __restrict__ X, const uint4* __restrict__ Wimg,
                                                          const float* __restrict__ bias, float* __restrict__ Y, X6P p,
                                                          int m_tiles, int n_tiles, int k_splits, uint32_t x_bytes,
@@ -134,18 +159,40 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(const float* __restric
     const int M = p.B * p.Ho * p.Wo;
     const __amdgpu_buffer_rsrc_t xbuf = x6_buffer(X, x_bytes), wbuf = x6_buffer(Wimg, w_bytes);
 
-    // A loader: thread -> (row (t >> 2) + 64 i, k-quad t & 3)
+    const int Hq = p.Ho >> 1, Wq = p.Wo >> 1, Mc = p.B * Hq * Wq;           // DIL2: pixels per parity class
+    auto decode = [&](int m, int& b, int& oy, int& ox) {
+        if (DIL2) {
+            const int cls = m / Mc, r = m % Mc;
+            const int qx = r % Wq, q = r / Wq;
+            ox = qx * 2 + (cls & 1); oy = (q % Hq) * 2 + (cls >> 1); b = q / Hq;
+        } else {
+            ox = m % p.Wo; const int q = m / p.Wo; oy = q % p.Ho; b = q / p.Ho;
+        }
+    };
+    int tile_py = -1, tile_px = -1;                      // DIL2: the tile's parity class when it has just one
+    if (DIL2) {
+        const int c0 = m0 / Mc, c1 = min(m0 + XBM - 1, M - 1) / Mc;
+        if (c0 == c1) { tile_py = c0 >> 1; tile_px = c0 & 1; }
+    }
+    // A loader: thread -> (row (t >> 2) + 64 i, k-quad t & 3).  dil 1: a_iy / a_ix = input coordinates of tap (0, 0) and
+    // a_base its element offset; DIL2: virtual (upsampled) coordinates and a_base = b * Hi.
     const int a_q = t & 3, a_k4 = a_q * 4, a_r = t >> 2;
     int a_base[2], a_iy[2], a_ix[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m = m0 + a_r + 64 * i;
         const bool ok = m < M;
-        const int mm = ok ? m : 0;
-        const int ox = mm % p.Wo, q = mm / p.Wo, oy = q % p.Ho, b = q / p.Ho;
-        a_iy[i] = ok ? oy * p.stride - p.pad_h : -0x40000000;
-        a_ix[i] = ox * p.stride - p.pad_w;
-        a_base[i] = ((b * p.Hi + oy * p.stride - p.pad_h) * p.Wi + a_ix[i]) * p.Ci + a_k4;
+        int b, oy, ox;
+        decode(ok ? m : 0, b, oy, ox);
+        if (DIL2) {
+            a_iy[i] = ok ? oy - p.pad_h : -0x40000000;
+            a_ix[i] = ox - p.pad_w;
+            a_base[i] = b * p.Hi;
+        } else {
+            a_iy[i] = ok ? oy * p.stride - p.pad_h : -0x40000000;
+            a_ix[i] = ox * p.stride - p.pad_w;
+            a_base[i] = ((b * p.Hi + oy * p.stride - p.pad_h) * p.Wi + a_ix[i]) * p.Ci + a_k4;
+        }
     }
 
     f32x16 acc[TM][TN];
@@ -156,34 +203,50 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(const float* __restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // K is walked in LIVE chunks: every (tap, 16-channel chunk), or with a uniform DIL2 parity only the taps
+    // kh == (pad_h - py) mod 2, kw likewise; split-K ranges are cut in this live space so that they carry equal work
     const int chunks_per_tap = (p.Ci + XBK - 1) / XBK;
-    const int n_chunks = p.KH * p.KW * chunks_per_tap;
+    const bool uniform = DIL2 && tile_py >= 0;
+    const int kh0 = uniform ? ((p.pad_h - tile_py) & 1) : 0, kw0 = uniform ? ((p.pad_w - tile_px) & 1) : 0;
+    const int kstep = uniform ? 2 : 1;
+    const int cnt_h = (p.KH - kh0 + kstep - 1) / kstep, cnt_w = (p.KW - kw0 + kstep - 1) / kstep;
+    const int n_chunks = cnt_h * cnt_w * chunks_per_tap;
     const int per_split = (n_chunks + k_splits - 1) / k_splits;
     const int chunk_lo = ks * per_split, chunk_hi = min(n_chunks, chunk_lo + per_split);
+    const int vH = (p.Hi - 1) * 2 + 1, vW = (p.Wi - 1) * 2 + 1;
 
     u32x4 ra[2][2], rb[2][3];
-    int l_tap = chunk_lo / chunks_per_tap, l_c0 = (chunk_lo % chunks_per_tap) * XBK;
-    int l_kh = l_tap / p.KW, l_kw = l_tap % p.KW;
-    int l_chunk = chunk_lo;
+    // wave-uniform walk state of the chunk being loaded
+    const int l_lt = chunk_lo / chunks_per_tap;
+    int l_c0 = (chunk_lo % chunks_per_tap) * XBK;
+    int l_kh = kh0 + kstep * (l_lt / cnt_w), l_kw = kw0 + kstep * (l_lt % cnt_w);
     constexpr int NPIECE = 5;
     auto load_piece = [&](auto SET, int i, bool live) {
         constexpr int S = decltype(SET)::value;
         if (i < 2) {
-            const int tap_off = (l_kh * p.Wi + l_kw) * p.Ci + l_c0;
-            const bool ok = live && l_c0 + a_k4 < p.Ci && (unsigned)(a_iy[i] + l_kh) < (unsigned)p.Hi &&
-                            (unsigned)(a_ix[i] + l_kw) < (unsigned)p.Wi;
-            ra[S][i] = x6_load16(xbuf, ok ? (uint32_t)(a_base[i] + tap_off) * 4u : X_OOB);
+            bool ok = live && l_c0 + a_k4 < p.Ci;
+            uint32_t off;
+            if (DIL2) {
+                const int vy = a_iy[i] + l_kh, vx = a_ix[i] + l_kw;
+                ok = ok && (unsigned)vy < (unsigned)vH && (unsigned)vx < (unsigned)vW && ((vy | vx) & 1) == 0;
+                off = (uint32_t)(((a_base[i] + (vy >> 1)) * p.Wi + (vx >> 1)) * p.Ci + l_c0 + a_k4);
+            } else {
+                ok = ok && (unsigned)(a_iy[i] + l_kh) < (unsigned)p.Hi && (unsigned)(a_ix[i] + l_kw) < (unsigned)p.Wi;
+                off = (uint32_t)(a_base[i] + (l_kh * p.Wi + l_kw) * p.Ci + l_c0);
+            }
+            ra[S][i] = x6_load16(xbuf, ok ? off * 4u : X_OOB);
         } else {
             const int pl = i - 2;
             const uint32_t dead = (live && b_thread) ? 0u : X_OOB;     // branch-free: (offset | ~0) is the out-of-range offset
-            rb[S][pl] = x6_load16(wbuf, ((uint32_t)(l_chunk * n_tiles + n_tile) * (uint32_t)(3 * B_GRANULES * 16) +
+            const int blk = (l_kh * p.KW + l_kw) * chunks_per_tap + (l_c0 >> 4);        // image block of (tap, chunk)
+            rb[S][pl] = x6_load16(wbuf, ((uint32_t)(blk * n_tiles + n_tile) * (uint32_t)(3 * B_GRANULES * 16) +
                                          (uint32_t)(pl * B_GRANULES + t) * 16u) | dead);
         }
-        if (i == NPIECE - 1) {
-            ++l_chunk; l_c0 += XBK;
+        if (i == NPIECE - 1) {                                         // advance (scalar) to the next live chunk
+            l_c0 += XBK;
             if (l_c0 >= p.Ci) {
-                l_c0 = 0; ++l_kw;
-                if (l_kw == p.KW) { l_kw = 0; ++l_kh; }
+                l_c0 = 0; l_kw += kstep;
+                if (l_kw >= p.KW) { l_kw = kw0; l_kh += kstep; }
             }
         }
     };
@@ -269,8 +332,14 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(const float* __restric
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m >= M) continue;
-                if (k_splits > 1) atomicAdd(Y + (int64_t)m * p.Co + n, acc[i][j][r] + bv);
-                else Y[(int64_t)m * p.Co + n] = acc[i][j][r] + bv;
+                int64_t row = m;
+                if (DIL2) {
+                    int b, oy, ox;
+                    decode(m, b, oy, ox);
+                    row = ((int64_t)b * p.Ho + oy) * p.Wo + ox;
+                }
+                if (k_splits > 1) atomicAdd(Y + row * p.Co + n, acc[i][j][r] + bv);
+                else Y[row * p.Co + n] = acc[i][j][r] + bv;
             }
         }
 }
@@ -296,11 +365,23 @@ int dsf_conv_x6_split_weights(const float* W, void* image, int KH, int KW, int C
     return dsf_launch_status();
 }
 
+int64_t dsf_conv_x6_image_granules(int KH, int KW, int Ck, int Cn) { return dsf_conv_x6_image_bytes(KH, KW, Ck, Cn) / 48; }
+
+int dsf_conv_x6_split_weights_multi(const int64_t* jobs, int n_jobs, int64_t total_granules, dsf_stream_t stream) {
+    DSF_CHECK_ARG(jobs && n_jobs >= 0 && total_granules >= 0);
+    if (n_jobs == 0 || total_granules == 0) return DSF_OK;
+    hipLaunchKernelGGL(x6_split_weights_multi_kernel, dim3((unsigned)((total_granules + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, jobs, n_jobs);
+    return dsf_launch_status();
+}
+
 // Ci / Co are the reduction / output channel counts of the IMAGE (mode 1: those of the backward-data GEMM).
 int dsf_conv_x6_forward(const float* X, const void* image, const float* bias, float* Y, int B, int Hi, int Wi, int Ci, int Ho,
-                        int Wo, int Co, int KH, int KW, int stride, int pad_h, int pad_w, int k_splits, dsf_stream_t stream) {
+                        int Wo, int Co, int KH, int KW, int stride, int dil, int pad_h, int pad_w, int k_splits,
+                        dsf_stream_t stream) {
     DSF_CHECK_ARG(X && image && Y && B >= 0 && Hi > 0 && Wi > 0 && Ci > 0 && Ho > 0 && Wo > 0 && Co > 0 && KH > 0 && KW > 0);
-    DSF_CHECK_ARG(stride >= 1 && (Ci & 3) == 0);
+    DSF_CHECK_ARG(stride >= 1 && (Ci & 3) == 0 && (dil == 1 || (dil == 2 && stride == 1)));
+    if (dil == 2 && ((Ho | Wo) & 1)) return DSF_ERR_UNSUPPORTED;
     if (B == 0) return DSF_OK;
     X6P p = {B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad_h, pad_w};
     const int64_t M = (int64_t)B * Ho * Wo;
@@ -308,23 +389,23 @@ int dsf_conv_x6_forward(const float* X, const void* image, const float* bias, fl
     DSF_CHECK_ARG(M < (1ll << 31) && x_bytes < 0xFFFFFFF0ll && w_bytes < 0xFFFFFFF0ll);
     const int bn = x6_bn(Co);
     const int m_tiles = (int)((M + XBM - 1) / XBM), n_tiles = (Co + bn - 1) / bn;
-    const int n_chunks = KH * KW * ((Ci + XBK - 1) / XBK);
+    const int n_chunks = (KH * KW / (dil * dil)) * ((Ci + XBK - 1) / XBK);          // live chunks of a tile
     if (k_splits < 1) {                                 // auto: fewer tiles than ~1.5 per CU -> split K to ~2 workgroups per CU
         const int tiles = m_tiles * n_tiles;
         k_splits = tiles < 384 ? (512 + tiles / 2) / tiles : 1;
         if (k_splits > n_chunks / 8) k_splits = n_chunks / 8;
         if (k_splits < 1) k_splits = 1;
     }
-    if (k_splits > n_chunks) k_splits = n_chunks;
+    if (k_splits > n_chunks) k_splits = n_chunks > 0 ? n_chunks : 1;
     if (k_splits > 1 &&
         hipMemsetAsync(Y, 0, sizeof(float) * (size_t)M * Co, (hipStream_t)stream) != hipSuccess) return DSF_ERR_LAUNCH;
     const dim3 grid(m_tiles * n_tiles * k_splits);
-    if (bn == 128)
-        hipLaunchKernelGGL(igemm_x6_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, X, (const uint4*)image, bias, Y, p,
-                           m_tiles, n_tiles, k_splits, (uint32_t)x_bytes, (uint32_t)w_bytes);
-    else
-        hipLaunchKernelGGL(igemm_x6_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, X, (const uint4*)image, bias, Y, p,
-                           m_tiles, n_tiles, k_splits, (uint32_t)x_bytes, (uint32_t)w_bytes);
+#define DSF_LAUNCH_X6(BNv, DILv) hipLaunchKernelGGL((igemm_x6_kernel<BNv, DILv>), grid, dim3(256), 0, (hipStream_t)stream, X,     \
+                                                  (const uint4*)image, bias, Y, p, m_tiles, n_tiles, k_splits,                   \
+                                                  (uint32_t)x_bytes, (uint32_t)w_bytes)
+    if (dil == 2) { if (bn == 128) DSF_LAUNCH_X6(128, true); else DSF_LAUNCH_X6(64, true); }
+    else { if (bn == 128) DSF_LAUNCH_X6(128, false); else DSF_LAUNCH_X6(64, false); }
+#undef DSF_LAUNCH_X6
     return dsf_launch_status();
 }
 

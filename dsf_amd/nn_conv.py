@@ -70,21 +70,61 @@ def _x6_image(weight, wk, mode):
           "dsf_conv_x6_split_weights")
     if cache is None:
         cache = weight.__dict__.setdefault("_dsf_x6", {})
-    cache[mode] = (key, img)
+    cache[mode] = (key, img, (KH, KW, Ci, Co))
     return img
 
 
-def _fwd_x6(x, image, bias, out_hw, Co, KH, KW, stride, pad):
-    """_fwd (dilation 1) with the weight operand given as a conv_x6 image whose reduction width is x's channel count."""
+_JOBS = {}           # id(params list owner) -> (rows, device table)
+
+
+def refresh_images(params, owner=None):
+    """Re-splits every cached conv_x6 image of ``params`` in ONE launch (instead of one small launch per layer and
+    direction at their next use): what an optimizer calls after it has rewritten the weights."""
+    rows, entries, total = [], [], 0
+    for p in params:
+        cache = p.__dict__.get("_dsf_x6")
+        if not cache or not p.is_cuda:
+            continue
+        for mode, (key, img, (KH, KW, Ci, Co)) in cache.items():
+            if key[2] != p.data_ptr():                  # the parameter moved (re-laid out): its next use splits it lazily
+                continue
+            Ck, Cn = (Co, Ci) if mode else (Ci, Co)
+            rows.append((p.data_ptr(), img.data_ptr(), KH, KW, Ci, Co, mode, total))
+            entries.append((p, mode))
+            total += L.lib().dsf_conv_x6_image_granules(I(KH), I(KW), I(Ck), I(Cn))
+    if not rows:
+        return
+    slot = _JOBS.get(id(owner))
+    if slot is None or slot[0] != rows:
+        dev = entries[0][0].device
+        table = torch.tensor(rows + [(0, 0, 0, 0, 0, 0, 0, total)], dtype=torch.int64).to(dev)
+        slot = _JOBS[id(owner)] = (rows, table)
+    from ._lib import I64
+    check(L.lib().dsf_conv_x6_split_weights_multi(ptr(slot[1]), I(len(rows)), I64(total), stream_ptr()),
+          "dsf_conv_x6_split_weights_multi")
+    for p, mode in entries:
+        cache = p.__dict__["_dsf_x6"]
+        _, img, geom = cache[mode]
+        cache[mode] = ((p._version, _EPOCH, p.data_ptr()), img, geom)
+
+
+def _fwd_x6(x, image, bias, out_hw, Co, KH, KW, stride, pad, dil=1):
+    """_fwd with the weight operand given as a conv_x6 image whose reduction width is x's channel count (dil 1, or the
+    dil-2 transposed-convolution gather with even output sizes)."""
     B, Ci, Hi, Wi = x.shape
     Ho, Wo = out_hw
     if RECORD is not None:
-        RECORD.append(("x6", B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, 1, pad[0], pad[1]))
+        RECORD.append(("x6", B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, dil, pad[0], pad[1]))
     y = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=CL)
     check(L.lib().dsf_conv_x6_forward(ptr_nhwc(x), ptr(image), ptr(bias), ptr_nhwc(y), I(B), I(Hi), I(Wi), I(Ci), I(Ho), I(Wo),
-                                      I(Co), I(KH), I(KW), I(stride), I(pad[0]), I(pad[1]), I(0), stream_ptr()),
+                                      I(Co), I(KH), I(KW), I(stride), I(dil), I(pad[0]), I(pad[1]), I(0), stream_ptr()),
           "dsf_conv_x6_forward")
     return y
+
+
+def _x6_dil_ok(Ck, Ho, Wo, dil):
+    """transposed-convolution gathers conv_x6 implements: dil 1, or dil 2 with even output sizes"""
+    return _x6_ok(Ck) and (dil == 1 or (dil == 2 and Ho % 2 == 0 and Wo % 2 == 0))
 
 
 def _wrw(x, gy, KH, KW, stride, pad):
@@ -234,6 +274,10 @@ class Conv2dFunction(Function):
                          (KH - 1 - padding[0], KW - 1 - padding[1]))
         elif ctx.needs_input_grad[0] and stride == 1 and Co >= 32 and Co % 4 == 0 and Ci % 4 == 0:
             gx = _bwd_data_s1(gy, wk, (x.shape[2], x.shape[3]), Ci, KH, KW, padding)
+        elif ctx.needs_input_grad[0] and _x6_dil_ok(Co, x.shape[2], x.shape[3], stride):
+            # backward-data of a strided convolution = transposed-convolution gather over gy with the mode-1 image
+            gx = _fwd_x6(gy, _x6_image(weight, wk, 1), None, (x.shape[2], x.shape[3]), Ci, KH, KW, 1,
+                         (KH - 1 - padding[0], KW - 1 - padding[1]), dil=stride)
         elif ctx.needs_input_grad[0] and _wt_ok(Co, Ci, x.shape[2], x.shape[3], stride):
             # backward-data as a dilated convolution over gy; wk (the forward operand) is its transposed, flipped weight
             gx = _fwd_wt(gy, wk, None, (x.shape[2], x.shape[3]), Ci, KH, KW, 1, stride, (KH - 1 - padding[0], KW - 1 - padding[1]))
@@ -256,7 +300,11 @@ class ConvTranspose2dFunction(Function):
         Ho = (Hi - 1) * stride - 2 * padding[0] + KH + output_padding[0]
         Wo = (Wi - 1) * stride - 2 * padding[1] + KW + output_padding[1]
         b = bias.detach().float().contiguous() if bias is not None else None
-        if _wt_ok(Cin, Cout, Ho, Wo, stride):
+        if _x6_dil_ok(Cin, Ho, Wo, stride):
+            wt = weight.detach().float().permute(2, 3, 1, 0).contiguous()                     # [kh][kw][Cout][Cin]: a free view in kernel layout
+            y = _fwd_x6(x, _x6_image(weight, wt, 1), b, (Ho, Wo), Cout, KH, KW, 1, (KH - 1 - padding[0], KW - 1 - padding[1]),
+                        dil=stride)
+        elif _wt_ok(Cin, Cout, Ho, Wo, stride):
             wt = weight.detach().float().permute(2, 3, 1, 0).contiguous()                     # [kh][kw][Cout][Cin]: a free view in kernel layout
             y = _fwd_wt(x, wt, b, (Ho, Wo), Cout, KH, KW, 1, stride, (KH - 1 - padding[0], KW - 1 - padding[1]))
         else:
@@ -350,7 +398,7 @@ def replay(rec, iters=3):
     elif kind == "x6":
         wk = torch.randn(KH, KW, Ci, Co, device=dev)
         img = _x6_image(wk, wk, 0)
-        run = lambda: _fwd_x6(x, img, None, (Ho, Wo), Co, KH, KW, stride, (ph, pw))
+        run = lambda: _fwd_x6(x, img, None, (Ho, Wo), Co, KH, KW, stride, (ph, pw), dil=dil)
     elif kind == "fwd_wt":
         wt = torch.randn(KH, KW, Co, Ci, device=dev)
         run = lambda: _fwd_wt(x, wt, None, (Ho, Wo), Co, KH, KW, stride, dil, (ph, pw))
@@ -387,7 +435,7 @@ def kernel_name(rec):
     n_tiles = (Co + bn - 1) // bn
     vec = Ci % 4 == 0 and Co % 4 == 0
     if kind == "x6":
-        return "igemm_x6_kernel"
+        return "igemm_x6_kernel<%d, %s>" % (128 if Co > 64 else 64, "true" if dil == 2 else "false")
     if kind in ("fwd", "fwd_wt", "bwd_s1"):
         wt = "false" if kind == "fwd" else "true"
         if dil == 1 and Ci >= 32 and vec:

@@ -126,4 +126,5 @@ class FusedAdamW(torch.optim.Optimizer):
                                           stream_ptr()), "dsf_adamw_multi")
         from . import nn_conv
         nn_conv.weights_changed()            # the kernel wrote the parameters behind torch's version counters
+        nn_conv.refresh_images([p for g in self.param_groups for p in g["params"]], owner=self)     # one launch
         return loss

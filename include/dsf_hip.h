@@ -330,13 +330,20 @@ int dsf_conv_igemm_wrw(const float* X, const float* dY, float* dW, int B, int Hi
  *   mode 1: the same memory as the stride-1 backward-data operand (reduction Co, outputs Ci, taps flipped).
  * dsf_conv_x6_image_bytes(KH, KW, Ck, Cn): size of an image with reduction width Ck and Cn outputs.
  * dsf_conv_x6_forward: Y[b,oy,ox,:] = bias + sum_taps X[b, oy*stride - pad_h + kh, ox*stride - pad_w + kw, :] . image
- *   (NHWC, dilation 1); Ci / Co are the image's reduction / output widths, Ci % 4 == 0.  k_splits <= 0: chosen by the
- *   launcher (split-K partial sums meet in Y with float atomics when > 1).
+ *   (NHWC); Ci / Co are the image's reduction / output widths, Ci % 4 == 0.  dil = 2 (stride 1, even Ho and Wo): X is read
+ *   as if upsampled by 2 with zeros -- ConvTranspose2d forward and the backward-data pass of stride-2 convolutions, both
+ *   with a mode-1 image.  k_splits <= 0: chosen by the launcher (split-K partial sums meet in Y with float atomics).
  * ---------------------------------------------------------------------------------- */
 int64_t dsf_conv_x6_image_bytes(int KH, int KW, int Ck, int Cn);
 int dsf_conv_x6_split_weights(const float* W, void* image, int KH, int KW, int Ci, int Co, int mode, dsf_stream_t stream);
+/* All images of a network in one launch (after an optimizer step).  jobs: device array of (n_jobs + 1) x 8 int64:
+ * row j = {W address, image address, KH, KW, Ci, Co, mode, first granule of job j}, where a job has
+ * dsf_conv_x6_image_granules(KH, KW, Ck, Cn) granules (one thread each) and row n_jobs holds the total in column 7. */
+int64_t dsf_conv_x6_image_granules(int KH, int KW, int Ck, int Cn);
+int dsf_conv_x6_split_weights_multi(const int64_t* jobs, int n_jobs, int64_t total_granules, dsf_stream_t stream);
 int dsf_conv_x6_forward(const float* X, const void* image, const float* bias, float* Y, int B, int Hi, int Wi, int Ci, int Ho,
-                        int Wo, int Co, int KH, int KW, int stride, int pad_h, int pad_w, int k_splits, dsf_stream_t stream);
+                        int Wo, int Co, int KH, int KW, int stride, int dil, int pad_h, int pad_w, int k_splits,
+                        dsf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Fused training-mode BatchNorm2d (+ residual add) (+ ReLU) on NHWC activations, x viewed as (M, C).

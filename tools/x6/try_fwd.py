@@ -23,7 +23,7 @@ def run(B, H, Ci, Co, k, stride, pad, splits=1, check=True):
     y = torch.empty(B, Co, Ho, Ho, device="cuda").contiguous(memory_format=CL)
     def f6():
         rc = x6.dsf_conv_x6_forward(P(x), P(img), P(bias), P(y), I(B), I(H), I(H), I(Ci), I(Ho), I(Ho), I(Co), I(k), I(k),
-                                    I(stride), I(pad), I(pad), I(splits), st)
+                                    I(stride), I(1), I(pad), I(pad), I(splits), st)
         assert rc == 0, rc
     def f32():
         return nn_conv._fwd(x, wk, bias, (Ho, Ho), Co, k, k, stride, 1, (pad, pad))
