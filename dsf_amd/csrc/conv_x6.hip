@@ -316,9 +316,9 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(const float* __restric
                 }
         __syncthreads();
     };
-    for (int chunk = chunk_lo; chunk < chunk_hi; chunk += 2) {
+    for (int chunk = chunk_lo; chunk < chunk_hi; chunk += 2) {  // chunks come in pairs: one past chunk_hi is all zeros
         body(Set0{}, Set1{}, chunk);
-        if (chunk + 1 < chunk_hi) body(Set1{}, Set0{}, chunk + 1);
+        body(Set1{}, Set0{}, chunk + 1);
     }
 
 #pragma unroll
@@ -340,6 +340,168 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(const float* __restric
                 }
                 if (k_splits > 1) atomicAdd(Y + row * p.Co + n, acc[i][j][r] + bv);
                 else Y[row * p.Co + n] = acc[i][j][r] + bv;
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward-weights:  dW[(tap, ci)][co] += sum_{m in split} X[pixel(m) + tap][ci] * dY[m][co]
+// The reduction runs over pixels, so an MFMA lane needs 8 consecutive PIXELS of one channel, while HBM (and the loader's
+// float4) hold consecutive CHANNELS of one pixel.  Both tiles are therefore staged as loaded -- [pixel 16][channel 128]
+// bf16 rows of 256 bytes per plane, split along the channel quad exactly as in the forward kernel -- and transposed on
+// the way out of LDS by gfx950's ds_read_b64_tr_b16 (4 pixels x 16 channels per 16-lane group, delivered channel-major):
+// two such reads make one 8-pixel fragment.  Rows are XOR-swizzled in 16-byte chunks (chunk ^ ((row & 3) << 2 | row >> 2))
+// so that the loader's ds_write_b64 and the transposed reads are both bank-conflict-free.
+// Both operands are activations, so both are split on the fly (2 + 2 float4 per thread and 16-pixel chunk).
+// Pixel splits meet in dW by float atomics.
+// ------------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t x6_fast_div(uint32_t n, uint64_t magic) { return (uint32_t)(((uint64_t)n * magic) >> 40); }
+// byte offset of 16-byte chunk `ch` (0..15) of pixel row `row` (0..15) inside one plane of a [16][128] bf16 tile
+__device__ __forceinline__ int x6_tr_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+__global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __restrict__ X, const float* __restrict__ dY,
+                                                             float* __restrict__ dW, X6P p, int k_tiles, int n_tiles,
+                                                             int n_splits, int m_per_split, uint64_t magic_wo,
+                                                             uint64_t magic_ho, uint32_t x_bytes, uint32_t dy_bytes) {
+    constexpr int TM = 2, TN = 2, PLANE = 16 * 256;      // bytes per plane of a tile
+    __shared__ __attribute__((aligned(16))) char As[2][3 * PLANE];
+    __shared__ __attribute__((aligned(16))) char Bs[2][3 * PLANE];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int tile = x6_xcd_contiguous(blockIdx.x, k_tiles * n_tiles * n_splits);
+    const int k_tile = tile % k_tiles; tile /= k_tiles;
+    const int n_tile = tile % n_tiles; const int split = tile / n_tiles;
+    const int k0 = k_tile * 128, n0 = n_tile * 128;
+    const int M = p.B * p.Ho * p.Wo, K = p.KH * p.KW * p.Ci;
+    const int m_begin = split * m_per_split, m_end = min(M, m_begin + m_per_split);
+    const __amdgpu_buffer_rsrc_t xbuf = x6_buffer(X, x_bytes), ybuf = x6_buffer(dY, dy_bytes);
+
+    // loader: thread -> (channel quad l_q of the tile's 128 rows, pixel (t >> 5) + 8 i of the chunk), for both tiles
+    const int l_q = t & 31, l_p = t >> 5;
+    const int a_k = k0 + l_q * 4;
+    const bool a_kok = a_k < K;
+    const int a_tap = min(a_k, K - 1) / p.Ci;
+    const int a_c = min(a_k, K - 1) % p.Ci, a_kh = a_tap / p.KW, a_kw = a_tap % p.KW;
+    const int b_n = n0 + l_q * 4;
+    const bool b_nok = b_n < p.Co;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    u32x4 rl[2][4];                                      // [set][A px 0, A px 8, B px 0, B px 8]
+    auto load_piece = [&](auto SET, int j, int mc) {     // rows past m_end get the out-of-range offset (zeros)
+        constexpr int S = decltype(SET)::value;
+        const int m = mc + l_p + 8 * (j & 1);
+        if (j < 2) {
+            const uint32_t mm = (uint32_t)min(m, M - 1);
+            const uint32_t q = x6_fast_div(mm, magic_wo);
+            const int ox = (int)(mm - q * (uint32_t)p.Wo);
+            const uint32_t b = x6_fast_div(q, magic_ho);
+            const int oy = (int)(q - b * (uint32_t)p.Ho);
+            const int iy = oy * p.stride + a_kh - p.pad_h, ix = ox * p.stride + a_kw - p.pad_w;
+            // bitwise & (no short-circuit): straight-line code, one select
+            const bool ok = a_kok & (m < m_end) & ((unsigned)iy < (unsigned)p.Hi) & ((unsigned)ix < (unsigned)p.Wi);
+            const uint32_t off = (uint32_t)((((int)b * p.Hi + iy) * p.Wi + ix) * p.Ci + a_c) * 4u;
+            rl[S][j] = x6_load16(xbuf, ok ? off : X_OOB);
+        } else {
+            const bool ok = b_nok & (m < m_end);
+            rl[S][j] = x6_load16(ybuf, ok ? (uint32_t)(m * p.Co + b_n) * 4u : X_OOB);
+        }
+    };
+    const int st_off0 = x6_tr_off(l_p, l_q >> 1) + 8 * (l_q & 1), st_off1 = x6_tr_off(l_p + 8, l_q >> 1) + 8 * (l_q & 1);
+    auto stage_piece = [&](auto SET, int buf, int j) {
+        constexpr int S = decltype(SET)::value;
+        uint2 h, m, l;
+        split4(rl[S][j], h, m, l);
+        char* base = (j < 2 ? As[buf] : Bs[buf]) + ((j & 1) ? st_off1 : st_off0);
+        *reinterpret_cast<uint2*>(base) = h;
+        *reinterpret_cast<uint2*>(base + PLANE) = m;
+        *reinterpret_cast<uint2*>(base + 2 * PLANE) = l;
+    };
+
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, 1>;
+    if (m_begin < m_end) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) load_piece(Set0{}, j, m_begin);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) load_piece(Set1{}, j, m_begin + XBK);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) stage_piece(Set0{}, 0, j);
+    }
+    __syncthreads();
+
+    // transposed fragment reads: 16-lane group g = channels 16 g .. 16 g + 15 of the 32-channel MFMA tile; lane 4 q + c of
+    // the group addresses pixel row q, channels 4 c .. 4 c + 3 of the block and receives channel (lane & 15) of 4 pixels
+    const int f_row = 8 * (lane >> 5) + ((lane & 15) >> 2);                    // + 4 for the second read
+    const int f_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);                 // first channel addressed, within the MFMA tile
+    auto frag_off = [&](int cbase, int r) {                                     // cbase: first channel of the MFMA tile
+        const int c = cbase + f_col;
+        return x6_tr_off(f_row + 4 * r, c >> 3) + 2 * (c & 7);
+    };
+    int fa[TM][2], fb[TN][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { fa[i][0] = frag_off(wm * 64 + i * 32, 0); fa[i][1] = frag_off(wm * 64 + i * 32, 1); }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { fb[j][0] = frag_off(wn * 64 + j * 32, 0); fb[j][1] = frag_off(wn * 64 + j * 32, 1); }
+    auto tr_read = [&](const char* base, int off0, int off1) {
+        struct { s16x4 lo, hi; } v;
+        v.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off0));
+        v.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off1));
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+    auto body = [&](auto SET, auto OTHER, int mc) {
+        constexpr int buf = decltype(SET)::value;
+        bf16x8 a[3][TM], b[3][TN];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[pl][i] = tr_read(As[buf] + pl * PLANE, fa[i][0], fa[i][1]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[pl][j] = tr_read(Bs[buf] + pl * PLANE, fb[j][0], fb[j][1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};
+        int slot = 0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][i], b[PB[q]][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int pc = 0; pc < 4; ++pc) {
+                        if (slot == 2 * pc + 1) load_piece(SET, pc, mc + 2 * XBK);
+                        if (slot == 2 * (pc + 4) + 1) stage_piece(OTHER, buf ^ 1, pc);
+                    }
+                    ++slot;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        __syncthreads();
+    };
+    for (int mc = m_begin; mc < m_end; mc += 2 * XBK) {         // chunks come in pairs: one past m_end is all zeros
+        body(Set0{}, Set1{}, mc);
+        body(Set1{}, Set0{}, mc + XBK);
+    }
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (n >= p.Co) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = k0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (k < K) atomicAdd(dW + (int64_t)k * p.Co + n, acc[i][j][r]);
             }
         }
 }
@@ -406,6 +568,33 @@ int dsf_conv_x6_forward(const float* X, const void* image, const float* bias, fl
     if (dil == 2) { if (bn == 128) DSF_LAUNCH_X6(128, true); else DSF_LAUNCH_X6(64, true); }
     else { if (bn == 128) DSF_LAUNCH_X6(128, false); else DSF_LAUNCH_X6(64, false); }
 #undef DSF_LAUNCH_X6
+    return dsf_launch_status();
+}
+
+int dsf_conv_x6_wrw(const float* X, const float* dY, float* dW, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
+                    int KW, int stride, int pad_h, int pad_w, int accumulate, dsf_stream_t stream) {
+    DSF_CHECK_ARG(X && dY && dW && B >= 0 && Hi > 0 && Wi > 0 && Ci > 0 && Ho > 0 && Wo > 0 && Co > 0 && KH > 0 && KW > 0);
+    DSF_CHECK_ARG(stride >= 1 && (Ci & 3) == 0 && (Co & 3) == 0);
+    const int K = KH * KW * Ci;
+    if (!accumulate &&
+        hipMemsetAsync(dW, 0, sizeof(float) * (size_t)K * Co, (hipStream_t)stream) != hipSuccess) return DSF_ERR_LAUNCH;
+    if (B == 0) return DSF_OK;
+    X6P p = {B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad_h, pad_w};
+    const int64_t M = (int64_t)B * Ho * Wo;
+    const int64_t x_bytes = (int64_t)B * Hi * Wi * Ci * 4, dy_bytes = M * Co * 4;
+    DSF_CHECK_ARG(M < (1ll << 31) && x_bytes < 0xFFFFFFF0ll && dy_bytes < 0xFFFFFFF0ll);
+    const int k_tiles = (K + 127) / 128, n_tiles = (Co + 127) / 128;
+    // split the pixel reduction so that one round of resident workgroups (2 per CU) covers the chip; >= 4 chunks per split
+    static const int wg_env = [] { const char* e = getenv("DSF_X6_WRW_WGS"); return e ? atoi(e) : 0; }();          // tuning aid
+    int splits = (wg_env > 0 ? wg_env : 512) / (k_tiles * n_tiles);
+    if (splits < 1) splits = 1;
+    int64_t per = (M + splits - 1) / splits;
+    per = ((per + 2 * XBK - 1) / (2 * XBK)) * (2 * XBK);
+    if (per < 4 * XBK) per = 4 * XBK;
+    splits = (int)((M + per - 1) / per);
+    const uint64_t mwo = ((1ull << 40) + Wo - 1) / Wo, mho = ((1ull << 40) + Ho - 1) / Ho;
+    hipLaunchKernelGGL(igemm_wrw_x6_kernel, dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream, X, dY, dW, p,
+                       k_tiles, n_tiles, splits, (int)per, mwo, mho, (uint32_t)x_bytes, (uint32_t)dy_bytes);
     return dsf_launch_status();
 }
 

@@ -54,6 +54,10 @@ def _x6_ok(Ck):
     return MATH == "x6" and Ck % 4 == 0 and Ck >= 16
 
 
+def _wrw_x6_ok(Ci, Co):
+    return MATH == "x6" and Ci % 4 == 0 and Co % 4 == 0 and Ci >= 16
+
+
 def _x6_image(weight, wk, mode):
     """bf16x3 image of ``wk`` = [KH][KW][Ci][Co] (a view of ``weight``'s memory): mode 0 the forward operand, mode 1
     the stride-1 backward-data operand.  Cached on the parameter until it changes; temporaries are split per call."""
@@ -136,9 +140,11 @@ def _wrw(x, gy, KH, KW, stride, pad):
     dw = _pool_take(KH * KW * Ci * Co, x.device)
     pooled = dw is not None
     dw = dw.view(KH, KW, Ci, Co) if pooled else torch.empty((KH, KW, Ci, Co), device=x.device, dtype=torch.float32)
-    check(L.lib().dsf_conv_igemm_wrw(ptr_nhwc(x), ptr_nhwc(gy), ptr(dw), I(B), I(Hi), I(Wi), I(Ci), I(Ho), I(Wo), I(Co),
-                                     I(KH), I(KW), I(stride), I(pad[0]), I(pad[1]), I(1 if pooled else 0), stream_ptr()),
-          "dsf_conv_igemm_wrw")
+    # both operands are activations: conv_x6 splits them on the fly (Ci % 4 == 0 and Co % 4 == 0), else the fp32 MFMA kernel
+    fn, name = (L.lib().dsf_conv_x6_wrw, "dsf_conv_x6_wrw") if _wrw_x6_ok(Ci, Co) else \
+        (L.lib().dsf_conv_igemm_wrw, "dsf_conv_igemm_wrw")
+    check(fn(ptr_nhwc(x), ptr_nhwc(gy), ptr(dw), I(B), I(Hi), I(Wi), I(Ci), I(Ho), I(Wo), I(Co), I(KH), I(KW), I(stride),
+             I(pad[0]), I(pad[1]), I(1 if pooled else 0), stream_ptr()), name)
     return dw
 
 
@@ -446,6 +452,8 @@ def kernel_name(rec):
         if dil == 2 and Ci >= 32 and vec and Ho % 2 == 0 and Wo % 2 == 0:
             return "igemm_fwd_dil2_kernel<%d, %d, %s>" % (bn, 16 if (tiles >= 1024 and bn == 128) else 32, wt)
         return "igemm_fwd_kernel<%d, %s>" % (bn, "true" if (Ci < 32 and dil == 1) else "false")
+    if _wrw_x6_ok(Ci, Co):
+        return "igemm_wrw_x6_kernel"
     if vec:
         return "igemm_wrw_fast_kernel<%d, %d>" % (bn, 16 if M >= 32768 else 32)
     return "igemm_wrw_kernel<%d>" % bn

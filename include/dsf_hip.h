@@ -344,6 +344,11 @@ int dsf_conv_x6_split_weights_multi(const int64_t* jobs, int n_jobs, int64_t tot
 int dsf_conv_x6_forward(const float* X, const void* image, const float* bias, float* Y, int B, int Hi, int Wi, int Ci, int Ho,
                         int Wo, int Co, int KH, int KW, int stride, int dil, int pad_h, int pad_w, int k_splits,
                         dsf_stream_t stream);
+/* Backward-weights twin of dsf_conv_igemm_wrw (same arguments and accumulate semantics; Ci % 4 == 0 and Co % 4 == 0):
+ * both operands are split on the fly and transposed by the LDS read (ds_read_b64_tr_b16); the pixel reduction is cut into
+ * splits that meet in dW by float atomics. */
+int dsf_conv_x6_wrw(const float* X, const float* dY, float* dW, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
+                    int KW, int stride, int pad_h, int pad_w, int accumulate, dsf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Fused training-mode BatchNorm2d (+ residual add) (+ ReLU) on NHWC activations, x viewed as (M, C).

@@ -135,15 +135,16 @@ def test_x6_matches_float64_as_closely_as_the_fp32_mfma(Ci, Co, K, s, p, H, B, m
         nn_conv.RECORD = []
         y = nn_conv.Conv2dFunction.apply(x, w, None, s, (p, p))
         gy = torch.randn(y.shape, generator=g).cuda() if gy is None else gy
-        gx, = torch.autograd.grad((y * gy).sum(), [x])
+        gx, gw = torch.autograd.grad((y * gy).sum(), [x, w])
         kinds = {r[0] for r in nn_conv.RECORD}
         nn_conv.RECORD = None
         assert ("x6" in kinds) == (math == "x6")
-        out[math] = (y.detach().double().cpu(), gx.double().cpu())
+        out[math] = (y.detach().double().cpu(), gx.double().cpu(), gw.double().cpu())
     xd = x.detach().double().cpu().requires_grad_(True)
-    yd = F.conv2d(xd, w.detach().double().cpu(), None, stride=s, padding=p)
-    gxd, = torch.autograd.grad((yd * gy.double().cpu()).sum(), [xd])
-    for i, ref in enumerate((yd.detach(), gxd)):
+    wd = w.detach().double().cpu().requires_grad_(True)
+    yd = F.conv2d(xd, wd, None, stride=s, padding=p)
+    gxd, gwd = torch.autograd.grad((yd * gy.double().cpu()).sum(), [xd, wd])
+    for i, ref in enumerate((yd.detach(), gxd, gwd)):
         e6, e32 = _rel(out["x6"][i], ref), _rel(out["f32"][i], ref)
         assert e6 < 2e-6, (i, e6)
         assert e6 < 3 * e32 + 1e-7, (i, e6, e32)
