@@ -552,9 +552,11 @@ int dsf_conv_x6_forward(const float* X, const void* image, const float* bias, fl
     const int bn = x6_bn(Co);
     const int m_tiles = (int)((M + XBM - 1) / XBM), n_tiles = (Co + bn - 1) / bn;
     const int n_chunks = (KH * KW / (dil * dil)) * ((Ci + XBK - 1) / XBK);          // live chunks of a tile
-    if (k_splits < 1) {                                 // auto: fewer tiles than ~1.5 per CU -> split K to ~2 workgroups per CU
+    if (k_splits < 1) {
+        // auto: fewer than ~0.8 tiles per CU -> split K towards 2 workgroups per CU.  Each split adds M x Co float atomics
+        // (~1.3 TB/s chip-wide), so 256 tiles run unsplit (69 vs 83 us on the 32x32x128 layers), 128 tiles 4-way, 64 8-way.
         const int tiles = m_tiles * n_tiles;
-        k_splits = tiles < 384 ? (512 + tiles / 2) / tiles : 1;
+        k_splits = tiles < 200 ? (512 + tiles / 2) / tiles : 1;
         if (k_splits > n_chunks / 8) k_splits = n_chunks / 8;
         if (k_splits < 1) k_splits = 1;
     }

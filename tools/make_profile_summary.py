@@ -14,7 +14,7 @@ fetch, write, sq, sq2, l2 = L("fetch"), L("write"), L("sq"), L("sq2"), L("l2")
 bench = json.loads(open(os.path.join(src, tag + "_bench_default.json")).read().strip().splitlines()[-1])
 under = json.loads(open(os.path.join(src, tag + "_bench_under_rocprof.json")).read().strip().splitlines()[-1])
 g = lambda d, k, c: d.get(k, {}).get(c, {}).get("avg", 0.0)
-ours = sorted(k for k in sq if k.startswith("igemm") or any(s in k for s in ("render_crop", "mano_", "bn_", "raster", "huber", "col_sum", "joint2offset", "offset2joint")))
+ours = sorted(k for k in sq if k.startswith("igemm") or any(s in k for s in ("render_crop", "mano_", "bn_", "raster", "huber", "col_sum", "joint2offset", "offset2joint", "x6_split", "adamw")))
 traffic = {"source": "separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of `python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline` "
                      "(tools/profile_round.sh); FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE doubled (gfx950 reports half "
                      "the bytes of 16-B/lane streaming reads, MI355X_MICROARCH.md HBM section); counts L2 misses to the fabric, "
