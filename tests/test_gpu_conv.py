@@ -150,11 +150,12 @@ def test_x6_matches_float64_as_closely_as_the_fp32_mfma(Ci, Co, K, s, p, H, B, m
         assert e6 < 3 * e32 + 1e-7, (i, e6, e32)
 
 
-def test_x6_weight_images_follow_the_weights():
+def test_x6_weight_images_follow_the_weights(monkeypatch):
     """The split image is cached on the parameter: in-place torch updates (version counter) and FusedAdamW's raw-pointer
     updates (nn_conv.weights_changed) must both invalidate it; an unchanged weight must not be split again."""
     from dsf_amd import nn_conv
     from dsf_amd.optim import FusedAdamW
+    monkeypatch.setattr(nn_conv, "MATH", "x6")            # (the suite also runs under DSF_CONV_MATH=f32)
     torch.manual_seed(0)
     conv = nn_conv.Conv2d(32, 48, 3, padding=1, bias=False).cuda()
     x = torch.randn(2, 32, 12, 12, device="cuda")
