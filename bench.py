@@ -6,7 +6,9 @@
 Workload (BASELINE.json configs[1]): per-GPU batch 32, ResNet-18 two-stage backbone
 (``MANO_OCR_stage('ResNet_stage_18', 21, refine=True)``, reference config.py:38,80,93) + MANO layer +
 fused crop rasteriser + GFM offset maps + SmoothL1 / m2d losses, backward, AdamW -- synthetic
-NYU-shape inputs, random-init weights, fp32 (the reference's precision).
+NYU-shape inputs, random-init weights, fp32 (the reference's precision; the convolutions form every fp32
+product from six bf16 MFMAs on exactly split operands -- same error against float64 as the fp32 MFMA, tests/test_gpu_conv.py;
+DSF_CONV_MATH=f32 selects the fp32 MFMA kernels).
 Weak scaling: every rank processes its own 32 images, gradients are averaged with a bucketed,
 backward-overlapped RCCL all-reduce.  One JSON line on rank 0.
 """
@@ -200,6 +202,8 @@ def main():
             "value": round(images / dt, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "conv_math": os.environ.get("DSF_CONV_MATH", "x6") + (": fp32 products as 6 bf16 MFMAs on exact 3-way operand splits, fp32 accumulate"
+                                                                if os.environ.get("DSF_CONV_MATH", "x6") == "x6" else ": fp32 MFMA"),
             "config": {"workload": "BASELINE configs[1]: batch=%d/GPU %s 2-stage + MANO + depth rasteriser, single view"
                                    % (args.batch, args.backbone),
                        "global_batch": args.batch * world, "crop": 128, "raster": 640, "parallelism": "dp%d" % world,

@@ -50,12 +50,16 @@ def weights_changed():
     _EPOCH += 1
 
 
-def _x6_ok(Ck):
-    return MATH == "x6" and Ck % 4 == 0 and Ck >= 16
+_X6_MAX_ELEMS = 0xFFFFFFF0 // 4        # the x6 kernels address their fp32 inputs with 32-bit byte offsets (buffer loads)
 
 
-def _wrw_x6_ok(Ci, Co):
-    return MATH == "x6" and Ci % 4 == 0 and Co % 4 == 0 and Ci >= 16
+def _x6_ok(Ck, n_in=0):
+    """reduction width Ck and input element count the conv_x6 forward-type kernel takes (else: the fp32 MFMA kernels)"""
+    return MATH == "x6" and Ck % 4 == 0 and Ck >= 16 and n_in <= _X6_MAX_ELEMS
+
+
+def _wrw_x6_ok(Ci, Co, n_x=0, n_gy=0):
+    return MATH == "x6" and Ci % 4 == 0 and Co % 4 == 0 and Ci >= 16 and max(n_x, n_gy) <= _X6_MAX_ELEMS
 
 
 def _x6_image(weight, wk, mode):
@@ -126,9 +130,9 @@ def _fwd_x6(x, image, bias, out_hw, Co, KH, KW, stride, pad, dil=1):
     return y
 
 
-def _x6_dil_ok(Ck, Ho, Wo, dil):
+def _x6_dil_ok(Ck, Ho, Wo, dil, n_in=0):
     """transposed-convolution gathers conv_x6 implements: dil 1, or dil 2 with even output sizes"""
-    return _x6_ok(Ck) and (dil == 1 or (dil == 2 and Ho % 2 == 0 and Wo % 2 == 0))
+    return _x6_ok(Ck, n_in) and (dil == 1 or (dil == 2 and Ho % 2 == 0 and Wo % 2 == 0))
 
 
 def _wrw(x, gy, KH, KW, stride, pad):
@@ -141,7 +145,7 @@ def _wrw(x, gy, KH, KW, stride, pad):
     pooled = dw is not None
     dw = dw.view(KH, KW, Ci, Co) if pooled else torch.empty((KH, KW, Ci, Co), device=x.device, dtype=torch.float32)
     # both operands are activations: conv_x6 splits them on the fly (Ci % 4 == 0 and Co % 4 == 0), else the fp32 MFMA kernel
-    fn, name = (L.lib().dsf_conv_x6_wrw, "dsf_conv_x6_wrw") if _wrw_x6_ok(Ci, Co) else \
+    fn, name = (L.lib().dsf_conv_x6_wrw, "dsf_conv_x6_wrw") if _wrw_x6_ok(Ci, Co, x.numel(), gy.numel()) else \
         (L.lib().dsf_conv_igemm_wrw, "dsf_conv_igemm_wrw")
     check(fn(ptr_nhwc(x), ptr_nhwc(gy), ptr(dw), I(B), I(Hi), I(Wi), I(Ci), I(Ho), I(Wo), I(Co), I(KH), I(KW), I(stride),
              I(pad[0]), I(pad[1]), I(1 if pooled else 0), stream_ptr()), name)
@@ -259,7 +263,7 @@ class Conv2dFunction(Function):
         Wo = (Wi + 2 * padding[1] - KW) // stride + 1
         wk = weight.detach().float().permute(2, 3, 1, 0).contiguous()          # a free view when the weight has kernel layout
         b = bias.detach().float().contiguous() if bias is not None else None
-        if _x6_ok(Ci):
+        if _x6_ok(Ci, x.numel()):
             y = _fwd_x6(x, _x6_image(weight, wk, 0), b, (Ho, Wo), Co, KH, KW, stride, padding)
         else:
             y = _fwd(x, wk, b, (Ho, Wo), Co, KH, KW, stride, 1, padding)
@@ -275,12 +279,12 @@ class Conv2dFunction(Function):
         Co, Ci, KH, KW = weight.shape
         gy = _nhwc(gy)
         gx = gw = gb = None
-        if ctx.needs_input_grad[0] and stride == 1 and _x6_ok(Co):
+        if ctx.needs_input_grad[0] and stride == 1 and _x6_ok(Co, gy.numel()):
             gx = _fwd_x6(gy, _x6_image(weight, wk, 1), None, (x.shape[2], x.shape[3]), Ci, KH, KW, 1,
                          (KH - 1 - padding[0], KW - 1 - padding[1]))
         elif ctx.needs_input_grad[0] and stride == 1 and Co >= 32 and Co % 4 == 0 and Ci % 4 == 0:
             gx = _bwd_data_s1(gy, wk, (x.shape[2], x.shape[3]), Ci, KH, KW, padding)
-        elif ctx.needs_input_grad[0] and _x6_dil_ok(Co, x.shape[2], x.shape[3], stride):
+        elif ctx.needs_input_grad[0] and _x6_dil_ok(Co, x.shape[2], x.shape[3], stride, gy.numel()):
             # backward-data of a strided convolution = transposed-convolution gather over gy with the mode-1 image
             gx = _fwd_x6(gy, _x6_image(weight, wk, 1), None, (x.shape[2], x.shape[3]), Ci, KH, KW, 1,
                          (KH - 1 - padding[0], KW - 1 - padding[1]), dil=stride)
@@ -306,7 +310,7 @@ class ConvTranspose2dFunction(Function):
         Ho = (Hi - 1) * stride - 2 * padding[0] + KH + output_padding[0]
         Wo = (Wi - 1) * stride - 2 * padding[1] + KW + output_padding[1]
         b = bias.detach().float().contiguous() if bias is not None else None
-        if _x6_dil_ok(Cin, Ho, Wo, stride):
+        if _x6_dil_ok(Cin, Ho, Wo, stride, x.numel()):
             wt = weight.detach().float().permute(2, 3, 1, 0).contiguous()                     # [kh][kw][Cout][Cin]: a free view in kernel layout
             y = _fwd_x6(x, _x6_image(weight, wt, 1), b, (Ho, Wo), Cout, KH, KW, 1, (KH - 1 - padding[0], KW - 1 - padding[1]),
                         dil=stride)
@@ -330,7 +334,7 @@ class ConvTranspose2dFunction(Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             wd = weight.detach().float().permute(2, 3, 1, 0).contiguous()                     # [kh][kw][Cout][Cin]
-            if _x6_ok(Cout):
+            if _x6_ok(Cout, gy.numel()):
                 gx = _fwd_x6(gy, _x6_image(weight, wd, 0), None, (x.shape[2], x.shape[3]), Cin, KH, KW, stride, padding)
             else:
                 gx = _fwd(gy, wd, None, (x.shape[2], x.shape[3]), Cin, KH, KW, stride, 1, padding)
@@ -452,7 +456,7 @@ def kernel_name(rec):
         if dil == 2 and Ci >= 32 and vec and Ho % 2 == 0 and Wo % 2 == 0:
             return "igemm_fwd_dil2_kernel<%d, %d, %s>" % (bn, 16 if (tiles >= 1024 and bn == 128) else 32, wt)
         return "igemm_fwd_kernel<%d, %s>" % (bn, "true" if (Ci < 32 and dil == 1) else "false")
-    if _wrw_x6_ok(Ci, Co):
+    if _wrw_x6_ok(Ci, Co, B * Hi * Wi * Ci, M * Co):
         return "igemm_wrw_x6_kernel"
     if vec:
         return "igemm_wrw_fast_kernel<%d, %d>" % (bn, 16 if M >= 32768 else 32)
