@@ -364,19 +364,23 @@ __device__ __forceinline__ uint32_t x6_fast_div(uint32_t n, uint64_t magic) { re
 // byte offset of 16-byte chunk `ch` (0..15) of pixel row `row` (0..15) inside one plane of a [16][128] bf16 tile
 __device__ __forceinline__ int x6_tr_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
 
+template <int BN>
 __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __restrict__ X, const float* __restrict__ dY,
                                                              float* __restrict__ dW, X6P p, int k_tiles, int n_tiles,
                                                              int n_splits, int m_per_split, uint64_t magic_wo,
                                                              uint64_t magic_ho, uint32_t x_bytes, uint32_t dy_bytes) {
-    constexpr int TM = 2, TN = 2, PLANE = 16 * 256;      // bytes per plane of a tile
+    // BN = 128: 2 x 2 waves of 64 (k rows) x 64 (channels);  BN = 64 (layers with <= 64 output channels): 4 x 1 waves of
+    // 32 x 64 -- half the MFMAs instead of multiplying zero columns; the dY tile keeps its 256-byte LDS rows, half used
+    constexpr int WM = (BN == 128) ? 64 : 32;
+    constexpr int TM = WM / 32, TN = 2, PLANE = 16 * 256;      // bytes per plane of a tile
     __shared__ __attribute__((aligned(16))) char As[2][3 * PLANE];
     __shared__ __attribute__((aligned(16))) char Bs[2][3 * PLANE];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = (BN == 128) ? (wave >> 1) : wave, wn = (BN == 128) ? (wave & 1) : 0;
     int tile = x6_xcd_contiguous(blockIdx.x, k_tiles * n_tiles * n_splits);
     const int k_tile = tile % k_tiles; tile /= k_tiles;
     const int n_tile = tile % n_tiles; const int split = tile / n_tiles;
-    const int k0 = k_tile * 128, n0 = n_tile * 128;
+    const int k0 = k_tile * 128, n0 = n_tile * BN;
     const int M = p.B * p.Ho * p.Wo, K = p.KH * p.KW * p.Ci;
     const int m_begin = split * m_per_split, m_end = min(M, m_begin + m_per_split);
     const __amdgpu_buffer_rsrc_t xbuf = x6_buffer(X, x_bytes), ybuf = x6_buffer(dY, dy_bytes);
@@ -388,7 +392,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
     const int a_tap = min(a_k, K - 1) / p.Ci;
     const int a_c = min(a_k, K - 1) % p.Ci, a_kh = a_tap / p.KW, a_kw = a_tap % p.KW;
     const int b_n = n0 + l_q * 4;
-    const bool b_nok = b_n < p.Co;
+    const bool b_nok = b_n < p.Co && l_q * 4 < BN;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -451,7 +455,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
     };
     int fa[TM][2], fb[TN][2];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) { fa[i][0] = frag_off(wm * 64 + i * 32, 0); fa[i][1] = frag_off(wm * 64 + i * 32, 1); }
+    for (int i = 0; i < TM; ++i) { fa[i][0] = frag_off(wm * WM + i * 32, 0); fa[i][1] = frag_off(wm * WM + i * 32, 1); }
 #pragma unroll
     for (int j = 0; j < TN; ++j) { fb[j][0] = frag_off(wn * 64 + j * 32, 0); fb[j][1] = frag_off(wn * 64 + j * 32, 1); }
     auto tr_read = [&](const char* base, int off0, int off1) {
@@ -482,9 +486,9 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
                 for (int j = 0; j < TN; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][i], b[PB[q]][j], acc[i][j], 0, 0, 0);
 #pragma unroll
-                    for (int pc = 0; pc < 4; ++pc) {
-                        if (slot == 2 * pc + 1) load_piece(SET, pc, mc + 2 * XBK);
-                        if (slot == 2 * (pc + 4) + 1) stage_piece(OTHER, buf ^ 1, pc);
+                    for (int pc = 0; pc < 4; ++pc) {     // 24 MFMAs: a piece behind every second one; 12: behind every one
+                        if (slot == (TM == 2 ? 2 * pc + 1 : pc)) load_piece(SET, pc, mc + 2 * XBK);
+                        if (slot == (TM == 2 ? 2 * (pc + 4) + 1 : pc + 4)) stage_piece(OTHER, buf ^ 1, pc);
                     }
                     ++slot;
                     __builtin_amdgcn_sched_barrier(0);
@@ -504,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
             if (n >= p.Co) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int k = k0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int k = k0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (k < K) atomicAdd(dW + (int64_t)k * p.Co + n, acc[i][j][r]);
             }
         }
@@ -589,7 +593,8 @@ int dsf_conv_x6_wrw(const float* X, const float* dY, float* dW, int B, int Hi, i
     const int64_t M = (int64_t)B * Ho * Wo;
     const int64_t x_bytes = (int64_t)B * Hi * Wi * Ci * 4, dy_bytes = M * Co * 4;
     DSF_CHECK_ARG(M < (1ll << 31) && x_bytes < 0xFFFFFFF0ll && dy_bytes < 0xFFFFFFF0ll);
-    const int k_tiles = (K + 127) / 128, n_tiles = (Co + 127) / 128;
+    const int bn = x6_bn(Co);
+    const int k_tiles = (K + 127) / 128, n_tiles = (Co + bn - 1) / bn;
     // split the pixel reduction so that one round of resident workgroups (2 per CU) covers the chip; >= 4 chunks per split
     static const int wg_env = [] { const char* e = getenv("DSF_X6_WRW_WGS"); return e ? atoi(e) : 0; }();          // tuning aid
     int splits = (wg_env > 0 ? wg_env : 512) / (k_tiles * n_tiles);
@@ -599,8 +604,12 @@ int dsf_conv_x6_wrw(const float* X, const float* dY, float* dW, int B, int Hi, i
     if (per < 4 * XBK) per = 4 * XBK;
     splits = (int)((M + per - 1) / per);
     const uint64_t mwo = ((1ull << 40) + Wo - 1) / Wo, mho = ((1ull << 40) + Ho - 1) / Ho;
-    hipLaunchKernelGGL(igemm_wrw_x6_kernel, dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream, X, dY, dW, p,
-                       k_tiles, n_tiles, splits, (int)per, mwo, mho, (uint32_t)x_bytes, (uint32_t)dy_bytes);
+    if (bn == 128)
+        hipLaunchKernelGGL(igemm_wrw_x6_kernel<128>, dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream, X, dY,
+                           dW, p, k_tiles, n_tiles, splits, (int)per, mwo, mho, (uint32_t)x_bytes, (uint32_t)dy_bytes);
+    else
+        hipLaunchKernelGGL(igemm_wrw_x6_kernel<64>, dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream, X, dY,
+                           dW, p, k_tiles, n_tiles, splits, (int)per, mwo, mho, (uint32_t)x_bytes, (uint32_t)dy_bytes);
     return dsf_launch_status();
 }
 

@@ -457,7 +457,7 @@ def kernel_name(rec):
             return "igemm_fwd_dil2_kernel<%d, %d, %s>" % (bn, 16 if (tiles >= 1024 and bn == 128) else 32, wt)
         return "igemm_fwd_kernel<%d, %s>" % (bn, "true" if (Ci < 32 and dil == 1) else "false")
     if _wrw_x6_ok(Ci, Co, B * Hi * Wi * Ci, M * Co):
-        return "igemm_wrw_x6_kernel"
+        return "igemm_wrw_x6_kernel<%d>" % (128 if Co > 64 else 64)
     if vec:
         return "igemm_wrw_fast_kernel<%d, %d>" % (bn, 16 if M >= 32768 else 32)
     return "igemm_wrw_kernel<%d>" % bn
