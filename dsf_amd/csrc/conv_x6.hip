@@ -37,7 +37,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 struct X6P { int B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad_h, pad_w; };
 
-constexpr int XBM = 128, XBK = 16;
+constexpr int XBK = 16;
 constexpr uint32_t X_OOB = 0xFFFFFFFFu;
 // Weight image (HBM): per (tap, 16-channel chunk, n tile) one block of 3 planes x [k-group 2][n BN] granules of 16 bytes
 // (8 consecutive k of one n).  BN = 128 output channels per tile, 64 when the layer has at most 64.
@@ -141,14 +141,18 @@ __global__ __launch_bounds__(256) void x6_split_weights_multi_kernel(const int64
 // and of the backward-data pass of stride-2 convolutions.  Output pixels are then numbered parity-class-major
 // ((oy & 1, ox & 1) classes of B * Ho/2 * Wo/2 pixels each), so a tile shares its parity, only the taps of matching parity
 // can meet data and the walk visits just those (a quarter of a 4x4 filter's taps); Ho and Wo must be even.
-template <int BN, bool DIL2>
+// BMT: pixel rows per tile, 128 or (BN 128 only) 64 for the 8x8 .. 32x32 maps: twice the tiles, so those layers need no
+// split-K or half of it (every split adds M x Co float atomics to the epilogue).
+template <int BN, bool DIL2, int BMT = 128>
 __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(const float* __restrict__ X, const uint4* __restrict__ Wimg,
                                                          const float* __restrict__ bias, float* __restrict__ Y, X6P p,
                                                          int m_tiles, int n_tiles, int k_splits, uint32_t x_bytes,
                                                          uint32_t w_bytes) {
-    constexpr int WM = (BN == 128) ? 64 : 32;            // wave sub-tile WM x 64: 2 x 2 waves (BN 128) or 4 x 1 (BN 64)
+    static_assert(BMT == 128 || (BMT == 64 && BN == 128), "tile shapes");
+    constexpr int WM = (BN == 128) ? BMT / 2 : 32;       // wave sub-tile WM x 64: 2 x 2 waves (BN 128) or 4 x 1 (BN 64)
     constexpr int TM = WM / 32, TN = 2;
-    using LA = LdsPlane<XBM>;
+    constexpr int APASS = BMT / 64;                      // float4 loads of the A tile per thread
+    using LA = LdsPlane<BMT>;
     using LB = LdsPlane<BN>;
     constexpr int B_GRANULES = 2 * BN;                   // per plane of one image block
     __shared__ uint4 As[2][3 * LA::SIZE];
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(const float* __restric
     int tile = x6_xcd_contiguous(blockIdx.x, m_tiles * n_tiles * k_splits);
     const int n_tile = tile % n_tiles; tile /= n_tiles;
     const int m_tile = tile % m_tiles; const int ks = tile / m_tiles;
-    const int m0 = m_tile * XBM, n0 = n_tile * BN;
+    const int m0 = m_tile * BMT, n0 = n_tile * BN;
     const bool b_thread = t < B_GRANULES;                // BN 64: waves 0-1 carry the B tile (wave-uniform)
     const int M = p.B * p.Ho * p.Wo;
     const __amdgpu_buffer_rsrc_t xbuf = x6_buffer(X, x_bytes), wbuf = x6_buffer(Wimg, w_bytes);
@@ -175,15 +179,15 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(const float* __restric
     };
     int tile_py = -1, tile_px = -1;                      // DIL2: the tile's parity class when it has just one
     if (DIL2) {
-        const int c0 = m0 / Mc, c1 = min(m0 + XBM - 1, M - 1) / Mc;
+        const int c0 = m0 / Mc, c1 = min(m0 + BMT - 1, M - 1) / Mc;
         if (c0 == c1) { tile_py = c0 >> 1; tile_px = c0 & 1; }
     }
     // A loader: thread -> (row (t >> 2) + 64 i, k-quad t & 3).  dil 1: a_iy / a_ix = input coordinates of tap (0, 0) and
     // a_base its element offset; DIL2: virtual (upsampled) coordinates and a_base = b * Hi.
     const int a_q = t & 3, a_k4 = a_q * 4, a_r = t >> 2;
-    int a_base[2], a_iy[2], a_ix[2];
+    int a_base[APASS], a_iy[APASS], a_ix[APASS];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < APASS; ++i) {
         const int m = m0 + a_r + 64 * i;
         const bool ok = m < M;
         int b, oy, ox;
@@ -219,15 +223,15 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(const float* __restric
     const int chunk_lo = ks * per_split, chunk_hi = min(n_chunks, chunk_lo + per_split);
     const int vH = (p.Hi - 1) * 2 + 1, vW = (p.Wi - 1) * 2 + 1;
 
-    u32x4 ra[2][2], rb[2][3];
+    u32x4 ra[2][APASS], rb[2][3];
     // wave-uniform walk state of the chunk being loaded
     const int l_lt = chunk_lo / chunks_per_tap;
     int l_c0 = (chunk_lo % chunks_per_tap) * XBK;
     int l_kh = kh0 + kstep * (l_lt / cnt_w), l_kw = kw0 + kstep * (l_lt % cnt_w);
-    constexpr int NPIECE = 5;
+    constexpr int NPIECE = APASS + 3;
     auto load_piece = [&](auto SET, int i, bool live) {
         constexpr int S = decltype(SET)::value;
-        if (i < 2) {
+        if (i < APASS) {
             bool ok = live && l_c0 + a_k4 < p.Ci;
             uint32_t off;
             if (DIL2) {
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(const float* __restric
             }
             ra[S][i] = x6_load16(xbuf, ok ? off * 4u : X_OOB);
         } else {
-            const int pl = i - 2;
+            const int pl = i - APASS;
             const uint32_t dead = (live && b_thread) ? 0u : X_OOB;     // branch-free: (offset | ~0) is the out-of-range offset
             const int blk = (l_kh * p.KW + l_kw) * chunks_per_tap + (l_c0 >> 4);        // image block of (tap, chunk)
             rb[S][pl] = x6_load16(wbuf, ((uint32_t)(blk * n_tiles + n_tile) * (uint32_t)(3 * B_GRANULES * 16) +
@@ -256,14 +260,14 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(const float* __restric
     };
     auto stage_piece = [&](auto SET, int buf, int i) {
         constexpr int S = decltype(SET)::value;
-        if (i < 2) {
+        if (i < APASS) {
             uint2 h, m, l;
             split4(ra[S][i], h, m, l);
             // granule (k-group a_q >> 1, row), half a_q & 1
             uint2* dst = reinterpret_cast<uint2*>(&As[buf][(a_q >> 1) * LA::KG + a_r + 64 * i]) + (a_q & 1);
             dst[0] = h; dst[2 * LA::SIZE] = m; dst[4 * LA::SIZE] = l;
         } else {
-            const int pl = i - 2;
+            const int pl = i - APASS;
             if (BN == 128 || b_thread)
                 Bs[buf][pl * LB::SIZE + (t / BN) * LB::KG + (t % BN)] = __builtin_bit_cast(uint4, rb[S][pl]);
         }
@@ -558,13 +562,18 @@ int dsf_conv_x6_forward(const float* X, const void* image, const float* bias, fl
     const int64_t x_bytes = (int64_t)B * Hi * Wi * Ci * 4, w_bytes = dsf_conv_x6_image_bytes(KH, KW, Ci, Co);
     DSF_CHECK_ARG(M < (1ll << 31) && x_bytes < 0xFFFFFFF0ll && w_bytes < 0xFFFFFFF0ll);
     const int bn = x6_bn(Co);
-    const int m_tiles = (int)((M + XBM - 1) / XBM), n_tiles = (Co + bn - 1) / bn;
+    const int n_tiles = (Co + bn - 1) / bn;
+    // 64-row tiles when 128-row ones would leave most of the chip idle or force split-K (8x8 .. 32x32 maps)
+    static const int bm_env = [] { const char* e = getenv("DSF_X6_BM"); return e ? atoi(e) : 0; }();             // tuning aid
+    const int bmt = (bn == 128 && (bm_env == 64 || (bm_env != 128 && ((M + 127) / 128) * n_tiles < 384))) ? 64 : 128;
+    const int m_tiles = (int)((M + bmt - 1) / bmt);
     const int n_chunks = (KH * KW / (dil * dil)) * ((Ci + XBK - 1) / XBK);          // live chunks of a tile
     if (k_splits < 1) {
         // auto: fewer than ~0.8 tiles per CU -> split K towards 2 workgroups per CU.  Each split adds M x Co float atomics
         // (~1.3 TB/s chip-wide), so 256 tiles run unsplit (69 vs 83 us on the 32x32x128 layers), 128 tiles 4-way, 64 8-way.
+        // 64-row tiles (measured, B = 32): 512 tiles unsplit 63 us (128-row: 68), 256 tiles 2-way 70 (75), 128 tiles 4-way 68 (74).
         const int tiles = m_tiles * n_tiles;
-        k_splits = tiles < 200 ? (512 + tiles / 2) / tiles : 1;
+        k_splits = bmt == 64 ? (tiles < 512 ? (512 + tiles - 1) / tiles : 1) : (tiles < 200 ? (512 + tiles / 2) / tiles : 1);
         if (k_splits > n_chunks / 8) k_splits = n_chunks / 8;
         if (k_splits < 1) k_splits = 1;
     }
@@ -572,11 +581,11 @@ int dsf_conv_x6_forward(const float* X, const void* image, const float* bias, fl
     if (k_splits > 1 &&
         hipMemsetAsync(Y, 0, sizeof(float) * (size_t)M * Co, (hipStream_t)stream) != hipSuccess) return DSF_ERR_LAUNCH;
     const dim3 grid(m_tiles * n_tiles * k_splits);
-#define DSF_LAUNCH_X6(BNv, DILv) hipLaunchKernelGGL((igemm_x6_kernel<BNv, DILv>), grid, dim3(256), 0, (hipStream_t)stream, X,     \
-                                                  (const uint4*)image, bias, Y, p, m_tiles, n_tiles, k_splits,                   \
-                                                  (uint32_t)x_bytes, (uint32_t)w_bytes)
-    if (dil == 2) { if (bn == 128) DSF_LAUNCH_X6(128, true); else DSF_LAUNCH_X6(64, true); }
-    else { if (bn == 128) DSF_LAUNCH_X6(128, false); else DSF_LAUNCH_X6(64, false); }
+#define DSF_LAUNCH_X6(BNv, DILv, BMv) hipLaunchKernelGGL((igemm_x6_kernel<BNv, DILv, BMv>), grid, dim3(256), 0, (hipStream_t)stream, \
+                                                       X, (const uint4*)image, bias, Y, p, m_tiles, n_tiles, k_splits,              \
+                                                       (uint32_t)x_bytes, (uint32_t)w_bytes)
+    if (dil == 2) { if (bn == 64) DSF_LAUNCH_X6(64, true, 128); else if (bmt == 64) DSF_LAUNCH_X6(128, true, 64); else DSF_LAUNCH_X6(128, true, 128); }
+    else { if (bn == 64) DSF_LAUNCH_X6(64, false, 128); else if (bmt == 64) DSF_LAUNCH_X6(128, false, 64); else DSF_LAUNCH_X6(128, false, 128); }
 #undef DSF_LAUNCH_X6
     return dsf_launch_status();
 }

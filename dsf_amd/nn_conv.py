@@ -445,7 +445,9 @@ def kernel_name(rec):
     n_tiles = (Co + bn - 1) // bn
     vec = Ci % 4 == 0 and Co % 4 == 0
     if kind == "x6":
-        return "igemm_x6_kernel<%d, %s>" % (128 if Co > 64 else 64, "true" if dil == 2 else "false")
+        bn6 = 128 if Co > 64 else 64
+        bmt = 64 if (bn6 == 128 and ((B * Ho * Wo + 127) // 128) * ((Co + 127) // 128) < 384) else 128
+        return "igemm_x6_kernel<%d, %s, %d>" % (bn6, "true" if dil == 2 else "false", bmt)
     if kind in ("fwd", "fwd_wt", "bwd_s1"):
         wt = "false" if kind == "fwd" else "true"
         if dil == 1 and Ci >= 32 and vec:
