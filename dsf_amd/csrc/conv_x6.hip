@@ -21,7 +21,7 @@
 // Kernels: igemm_x6_kernel<BN, DIL2> (forward, backward-data, transposed convolution), igemm_wrw_x6_kernel
 // (backward-weights: both operands are activations and are split on the fly; LDS transposes with ds_read_b64_tr_b16),
 // x6_split_weights(_multi)_kernel.  MI355X, B = 32 ResNet-18 two-stage step: 175-200 TFLOP/s fp32-equivalent on the
-// 64x64-map layers against 120-134 for the fp32 MFMA kernels of conv.hip (whose peak is 157.3); 28.0 -> 21.8 ms per step.
+// 64x64-map layers against 120-134 for the fp32 MFMA kernels of conv.hip (whose peak is 157.3); 28.0 -> 21.1 ms per step.
 #include "common.h"
 
 #include <type_traits>
