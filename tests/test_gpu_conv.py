@@ -171,3 +171,46 @@ def test_x6_weight_images_follow_the_weights(monkeypatch):
     conv(x).square().mean().backward()
     opt.step()
     assert _rel(conv(x).double(), ref()) < 2e-6
+
+
+def test_x6_random_geometries_against_float64():
+    """Seeded sweep over ragged geometries (non-square maps, odd sizes, every channel-count class the split kernels accept,
+    kernel 1..5, stride 1 / 2, transposed convolutions): forward and all gradients against float64."""
+    from dsf_amd import nn_conv
+    rng = np.random.RandomState(7)
+    saved, nn_conv.RECORD = nn_conv.RECORD, []
+    try:
+        for case in range(36):
+            Ci = int(rng.choice([16, 20, 36, 64, 100, 132]))
+            Co = int(rng.choice([1, 4, 36, 64, 72, 130]))
+            K = int(rng.choice([1, 2, 3, 4, 5]))
+            s = int(rng.choice([1, 2]))
+            p = int(rng.randint(0, K))
+            H, W, B = int(rng.randint(K + 1, 20)), int(rng.randint(K + 1, 20)), int(rng.choice([1, 3]))
+            transposed = case % 3 == 2 and Co % 4 == 0
+            g = torch.Generator().manual_seed(case)
+            x = torch.randn(B, Ci, H, W, generator=g).cuda().requires_grad_(True)
+            if transposed:
+                op = int(rng.randint(0, s))
+                w = (torch.randn(Ci, Co, K, K, generator=g) / (Ci * K * K) ** 0.5).cuda().requires_grad_(True)
+                if (H - 1) * s - 2 * p + K + op < 1 or (W - 1) * s - 2 * p + K + op < 1:
+                    continue
+                y = nn_conv.ConvTranspose2dFunction.apply(x, w, None, s, (p, p), (op, op))
+                ref_fn = lambda xd, wd: F.conv_transpose2d(xd, wd, None, stride=s, padding=p, output_padding=op)
+            else:
+                w = (torch.randn(Co, Ci, K, K, generator=g) / (Ci * K * K) ** 0.5).cuda().requires_grad_(True)
+                y = nn_conv.Conv2dFunction.apply(x, w, None, s, (p, p))
+                ref_fn = lambda xd, wd: F.conv2d(xd, wd, None, stride=s, padding=p)
+            gy = torch.randn(y.shape, generator=g).cuda()
+            gx, gw = torch.autograd.grad((y * gy).sum(), [x, w])
+            xd = x.detach().double().cpu().requires_grad_(True)
+            wd = w.detach().double().cpu().requires_grad_(True)
+            yd = ref_fn(xd, wd)
+            assert yd.shape == y.shape, (case, yd.shape, y.shape)
+            gxd, gwd = torch.autograd.grad((yd * gy.double().cpu()).sum(), [xd, wd])
+            for name, a, r in (("y", y, yd), ("gx", gx, gxd), ("gw", gw, gwd)):
+                assert _rel(a.detach().double().cpu(), r.detach()) < 3e-6, (case, name, Ci, Co, K, s, p, H, W, B, transposed)
+        kinds = [r[0] for r in nn_conv.RECORD]
+        assert kinds.count("x6") >= 30, kinds          # the sweep really exercised the split kernels
+    finally:
+        nn_conv.RECORD = saved
