@@ -110,6 +110,33 @@ def conv_kernel_roofline(step, tgt):
             **pmc_traffic(dom), "note": note}, table
 
 
+def same_step_on_fp32_mfma(step, tgt, B, steps=10, warmup=3):
+    """Rank-0 diagnostic beside the headline: the same training step with every convolution on the plain fp32 MFMA
+    (v_mfma_f32_32x32x2_f32, conv.hip) instead of the split-operand kernels -- what DSF_CONV_MATH=f32 would measure."""
+    from dsf_amd import nn_conv
+    if nn_conv.MATH != "x6":
+        return None
+    if step.grad_sync is not None:
+        step.grad_sync.enabled = False
+    nn_conv.MATH = "f32"
+    try:
+        for _ in range(warmup):
+            step(tgt)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(tgt)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    finally:
+        nn_conv.MATH = "x6"
+        if step.grad_sync is not None:
+            step.grad_sync.enabled = True
+    return {"value": round(B / dt, 2), "unit": "images/s per GPU", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+            "note": "same step, convolutions on the fp32 MFMA kernels (peak 157.3 TFLOP/s); both paths agree with float64 to "
+                    "5e-7 of the largest output (tests/test_gpu_conv.py)"}
+
+
 def crop_kernel_roofline(render, B, launches=200):
     """Live timing of the fused crop rasteriser (dsf_render_crop_forward) with HIP events on the stream
     it is launched on.  Algorithmic bytes per image (SURVEY 8d, K1 crop mode): read verts 779*12 = 9,348 B,
@@ -212,6 +239,7 @@ def main():
         }
         out["roofline"], out["conv_kernels"] = conv_kernel_roofline(step, tgt)
         out["roofline_raster"] = crop_kernel_roofline(render, args.batch)
+        out["fp32_mfma_path"] = same_step_on_fp32_mfma(step, tgt, args.batch)
         flops_per_img = 3 * 25.42e9 if args.backbone.endswith("18") else 3 * 37.84e9     # fwd+bwd ~ 3x fwd
         tf = flops_per_img * images / dt / 1e12
         out["whole_step_mfma"] = {"achieved": round(tf, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
