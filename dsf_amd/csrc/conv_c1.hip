@@ -1,0 +1,183 @@
+// Direct convolution for 1-channel inputs (the 5x5 ResNet stem, the 7x7 stride-2 hourglass stem, the generator's first
+// layer; reference model/backbone.py:196-199, model/hourglass.py:178, render_model/transfer.py:409).  With Ci = 1 the
+// implicit GEMM has K = KH*KW <= 49: its tiles are mostly padding (the generic kernels ran at 10-20 TFLOP/s) and the layer
+// is bound by the 64-channel tensor on the other side (134 MB at B = 32, 128 x 128).  Here lane = output channel: a wave
+// walks row segments of 8 output pixels, reads each needed input row segment once (one coalesced load, then v_readlane
+// broadcasts into scalar registers) and does KH*KW*8 FMAs per lane against weights it keeps in registers; the 64-channel
+// tensor is read / written exactly once, 256 bytes per pixel per instruction.
+#include "common.h"
+
+namespace {
+
+constexpr int PX = 8;                                   // output pixels of one row per step
+
+struct C1P { int B, Hi, Wi, Ho, Wo, Co, pad; };
+
+// input columns ox0*S - pad + j, j < (PX-1)*S + K, of input row iy (zeros outside the image) -> lane j
+template <int K, int S>
+__device__ __forceinline__ float c1_row(const float* __restrict__ X, const C1P& p, int b, int iy, int ix0, int lane) {
+    constexpr int NIN = (PX - 1) * S + K;
+    const int ix = ix0 + lane;
+    const bool ok = lane < NIN && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+    return ok ? X[((int64_t)b * p.Hi + iy) * p.Wi + ix] : 0.f;
+}
+
+template <int K, int S>
+__global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                          const float* __restrict__ bias, float* __restrict__ Y, C1P p,
+                                                          int segs_per_row, int64_t n_segs) {
+    constexpr int NIN = (PX - 1) * S + K;
+    static_assert(NIN <= 64, "one wave-wide load per input row");
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    const bool c_ok = lane < p.Co;
+    float w[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) w[i] = c_ok ? W[i * p.Co + lane] : 0.f;
+    const float bv = (bias && c_ok) ? bias[lane] : 0.f;
+    for (int64_t seg = wave; seg < n_segs; seg += n_waves) {
+        const int sx = (int)(seg % segs_per_row);
+        const int64_t row = seg / segs_per_row;
+        const int oy = (int)(row % p.Ho), b = (int)(row / p.Ho);
+        const int ox0 = sx * PX, ix0 = ox0 * S - p.pad;
+        float acc[PX];
+#pragma unroll
+        for (int q = 0; q < PX; ++q) acc[q] = bv;
+        float v[K];
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) v[kh] = c1_row<K, S>(X, p, b, oy * S + kh - p.pad, ix0, lane);
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) {                 // one input row at a time: its NIN values live in scalar registers
+            float xs[NIN];
+#pragma unroll
+            for (int j = 0; j < NIN; ++j) xs[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[kh]), j));     // (the builtin is typed int)
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+                for (int q = 0; q < PX; ++q) acc[q] = fmaf(xs[q * S + kw], w[kh * K + kw], acc[q]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (c_ok) {
+            float* dst = Y + (((int64_t)b * p.Ho + oy) * p.Wo + ox0) * p.Co + lane;
+#pragma unroll
+            for (int q = 0; q < PX; ++q, dst += p.Co)
+                if (ox0 + q < p.Wo) *dst = acc[q];
+        }
+    }
+}
+
+// dW[kh][kw][co] = sum over pixels of x[iy][ix] * gy[pixel][co]: per-lane accumulators, workgroup partials, then a combine
+template <int K, int S>
+__global__ __launch_bounds__(256) void conv_c1_wrw_kernel(const float* __restrict__ X, const float* __restrict__ dY,
+                                                          float* __restrict__ part, C1P p, int segs_per_row, int64_t n_segs) {
+    constexpr int NIN = (PX - 1) * S + K;
+    __shared__ float red[4][K * K][64];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wv, n_waves = (int64_t)gridDim.x * 4;
+    const bool c_ok = lane < p.Co;
+    float acc[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) acc[i] = 0.f;
+    for (int64_t seg = wave; seg < n_segs; seg += n_waves) {
+        const int sx = (int)(seg % segs_per_row);
+        const int64_t row = seg / segs_per_row;
+        const int oy = (int)(row % p.Ho), b = (int)(row / p.Ho);
+        const int ox0 = sx * PX, ix0 = ox0 * S - p.pad;
+        float g[PX];
+        const float* src = dY + (((int64_t)b * p.Ho + oy) * p.Wo + ox0) * p.Co + lane;
+#pragma unroll
+        for (int q = 0; q < PX; ++q, src += p.Co) g[q] = (c_ok && ox0 + q < p.Wo) ? *src : 0.f;
+        float v[K];
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) v[kh] = c1_row<K, S>(X, p, b, oy * S + kh - p.pad, ix0, lane);
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) {
+            float xs[NIN];
+#pragma unroll
+            for (int j = 0; j < NIN; ++j) xs[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[kh]), j));     // (the builtin is typed int)
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+                for (int q = 0; q < PX; ++q) acc[kh * K + kw] = fmaf(xs[q * S + kw], g[q], acc[kh * K + kw]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) red[wv][i][lane] = acc[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * K * 64; i += 256) {
+        const int t = i >> 6, c = i & 63;
+        part[(int64_t)blockIdx.x * (K * K * 64) + i] = (red[0][t][c] + red[1][t][c]) + (red[2][t][c] + red[3][t][c]);
+    }
+}
+
+// one workgroup per tap: lane = channel, the four waves take every fourth partial; fixed order, double accumulation
+__global__ __launch_bounds__(256) void conv_c1_wrw_combine_kernel(const float* __restrict__ part, int n_part, int taps, int Co,
+                                                                  int accumulate, float* __restrict__ dW) {
+    __shared__ double red[4][64];
+    const int t = blockIdx.x, c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    double s = 0.0;
+#pragma unroll 4
+    for (int b = g; b < n_part; b += 4) s += (double)part[((int64_t)b * taps + t) * 64 + c];
+    red[g][c] = s;
+    __syncthreads();
+    if (g == 0 && c < Co) {
+        const float v = (float)((red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+        float* dst = dW + t * Co + c;
+        *dst = accumulate ? *dst + v : v;
+    }
+}
+
+constexpr int C1_WRW_WGS = 2048;                      // 8 waves per SIMD: the kernel lives on loads in flight
+
+inline bool c1_ok(int Co, int K, int stride) { return Co >= 1 && Co <= 64 && (K == 5 || K == 7) && (stride == 1 || stride == 2); }
+
+}  // namespace
+
+extern "C" {
+
+int dsf_conv_c1_supported(int Co, int KH, int KW, int stride) { return (KH == KW && c1_ok(Co, KH, stride)) ? 1 : 0; }
+
+int64_t dsf_conv_c1_workspace_bytes(int KH, int KW) { return (int64_t)C1_WRW_WGS * KH * KW * 64 * 4; }
+
+int dsf_conv_c1_forward(const float* X, const float* W, const float* bias, float* Y, int B, int Hi, int Wi, int Ho, int Wo, int Co,
+                        int K, int stride, int pad, dsf_stream_t stream) {
+    DSF_CHECK_ARG(X && W && Y && B >= 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && pad >= 0);
+    if (!c1_ok(Co, K, stride)) return DSF_ERR_UNSUPPORTED;
+    if (B == 0) return DSF_OK;
+    C1P p = {B, Hi, Wi, Ho, Wo, Co, pad};
+    const int spr = (Wo + PX - 1) / PX;
+    const int64_t n_segs = (int64_t)B * Ho * spr;
+    int64_t wgs = (n_segs + 3) / 4;
+    if (wgs > 4096) wgs = 4096;
+#define DSF_LAUNCH_C1(Kv, Sv) hipLaunchKernelGGL((conv_c1_fwd_kernel<Kv, Sv>), dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, \
+                                                 X, W, bias, Y, p, spr, n_segs)
+    if (K == 5) { if (stride == 1) DSF_LAUNCH_C1(5, 1); else DSF_LAUNCH_C1(5, 2); }
+    else { if (stride == 1) DSF_LAUNCH_C1(7, 1); else DSF_LAUNCH_C1(7, 2); }
+#undef DSF_LAUNCH_C1
+    return dsf_launch_status();
+}
+
+int dsf_conv_c1_wrw(const float* X, const float* dY, float* dW, float* workspace, int B, int Hi, int Wi, int Ho, int Wo, int Co,
+                    int K, int stride, int pad, int accumulate, dsf_stream_t stream) {
+    DSF_CHECK_ARG(X && dY && dW && workspace && B >= 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && pad >= 0);
+    if (!c1_ok(Co, K, stride)) return DSF_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0) {
+        if (!accumulate && hipMemsetAsync(dW, 0, sizeof(float) * K * K * Co, st) != hipSuccess) return DSF_ERR_LAUNCH;
+        return DSF_OK;
+    }
+    C1P p = {B, Hi, Wi, Ho, Wo, Co, pad};
+    const int spr = (Wo + PX - 1) / PX;
+    const int64_t n_segs = (int64_t)B * Ho * spr;
+    int wgs = (int)((n_segs + 3) / 4 < C1_WRW_WGS ? (n_segs + 3) / 4 : C1_WRW_WGS);
+#define DSF_LAUNCH_C1W(Kv, Sv) hipLaunchKernelGGL((conv_c1_wrw_kernel<Kv, Sv>), dim3(wgs), dim3(256), 0, st, X, dY, workspace, p, spr, n_segs)
+    if (K == 5) { if (stride == 1) DSF_LAUNCH_C1W(5, 1); else DSF_LAUNCH_C1W(5, 2); }
+    else { if (stride == 1) DSF_LAUNCH_C1W(7, 1); else DSF_LAUNCH_C1W(7, 2); }
+#undef DSF_LAUNCH_C1W
+    hipLaunchKernelGGL(conv_c1_wrw_combine_kernel, dim3(K * K), dim3(256), 0, st, workspace, wgs, K * K, Co, accumulate, dW);
+    return dsf_launch_status();
+}
+
+}  // extern "C"

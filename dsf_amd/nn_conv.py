@@ -135,6 +135,36 @@ def _x6_dil_ok(Ck, Ho, Wo, dil, n_in=0):
     return _x6_ok(Ck, n_in) and (dil == 1 or (dil == 2 and Ho % 2 == 0 and Wo % 2 == 0))
 
 
+def _c1_ok(Ci, Co, KH, KW, stride, pad):
+    """1-channel direct kernels (conv_c1.hip): the stems"""
+    return Ci == 1 and pad[0] == pad[1] and bool(L.lib().dsf_conv_c1_supported(I(Co), I(KH), I(KW), I(stride)))
+
+
+def _fwd_c1(x, wk, bias, out_hw, Co, K, stride, pad):
+    B, _, Hi, Wi = x.shape
+    Ho, Wo = out_hw
+    if RECORD is not None:
+        RECORD.append(("c1_fwd", B, Hi, Wi, 1, Ho, Wo, Co, K, K, stride, 1, pad, pad))
+    y = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=CL)
+    check(L.lib().dsf_conv_c1_forward(ptr_nhwc(x), ptr(wk), ptr(bias), ptr_nhwc(y), I(B), I(Hi), I(Wi), I(Ho), I(Wo), I(Co), I(K),
+                                      I(stride), I(pad), stream_ptr()), "dsf_conv_c1_forward")
+    return y
+
+
+def _wrw_c1(x, gy, K, stride, pad):
+    B, _, Hi, Wi = x.shape
+    _, Co, Ho, Wo = gy.shape
+    if RECORD is not None:
+        RECORD.append(("c1_wrw", B, Hi, Wi, 1, Ho, Wo, Co, K, K, stride, 1, pad, pad))
+    dw = _pool_take(K * K * Co, x.device)
+    pooled = dw is not None
+    dw = dw.view(K, K, 1, Co) if pooled else torch.empty((K, K, 1, Co), device=x.device, dtype=torch.float32)
+    ws = torch.empty(L.lib().dsf_conv_c1_workspace_bytes(I(K), I(K)) // 4, device=x.device, dtype=torch.float32)
+    check(L.lib().dsf_conv_c1_wrw(ptr_nhwc(x), ptr_nhwc(gy), ptr(dw), ptr(ws), I(B), I(Hi), I(Wi), I(Ho), I(Wo), I(Co), I(K),
+                                  I(stride), I(pad), I(1 if pooled else 0), stream_ptr()), "dsf_conv_c1_wrw")
+    return dw
+
+
 def _wrw(x, gy, KH, KW, stride, pad):
     """-> dW [KH][KW][Ci][Co] for x (B,Ci,Hi,Wi), gy (B,Co,Ho,Wo), both channels_last."""
     B, Ci, Hi, Wi = x.shape
@@ -263,7 +293,9 @@ class Conv2dFunction(Function):
         Wo = (Wi + 2 * padding[1] - KW) // stride + 1
         wk = weight.detach().float().permute(2, 3, 1, 0).contiguous()          # a free view when the weight has kernel layout
         b = bias.detach().float().contiguous() if bias is not None else None
-        if _x6_ok(Ci, x.numel()):
+        if _c1_ok(Ci, Co, KH, KW, stride, padding):
+            y = _fwd_c1(x, wk, b, (Ho, Wo), Co, KH, stride, padding[0])
+        elif _x6_ok(Ci, x.numel()):
             y = _fwd_x6(x, _x6_image(weight, wk, 0), b, (Ho, Wo), Co, KH, KW, stride, padding)
         else:
             y = _fwd(x, wk, b, (Ho, Wo), Co, KH, KW, stride, 1, padding)
@@ -295,7 +327,10 @@ class Conv2dFunction(Function):
             wd = weight.detach().float().flip(2, 3).permute(2, 3, 0, 1).contiguous()          # [kh'][kw'][Co][Ci]
             gx = _fwd(gy, wd, None, (x.shape[2], x.shape[3]), Ci, KH, KW, 1, stride, (KH - 1 - padding[0], KW - 1 - padding[1]))
         if ctx.needs_input_grad[1]:
-            gw = _wrw(x, gy, KH, KW, stride, padding).permute(3, 2, 0, 1)
+            if _c1_ok(Ci, Co, KH, KW, stride, padding):
+                gw = _wrw_c1(x, gy, KH, stride, padding[0]).permute(3, 2, 0, 1)
+            else:
+                gw = _wrw(x, gy, KH, KW, stride, padding).permute(3, 2, 0, 1)
         if has_bias and ctx.needs_input_grad[2]:
             gb = _bias_grad(gy)
         return gx, gw, gb, None, None
@@ -405,6 +440,12 @@ def replay(rec, iters=3):
     if kind == "fwd":
         wk = torch.randn(KH, KW, Ci, Co, device=dev)
         run = lambda: _fwd(x, wk, None, (Ho, Wo), Co, KH, KW, stride, dil, (ph, pw))
+    elif kind == "c1_fwd":
+        wk = torch.randn(KH, KW, 1, Co, device=dev)
+        run = lambda: _fwd_c1(x, wk, None, (Ho, Wo), Co, KH, stride, ph)
+    elif kind == "c1_wrw":
+        gy = torch.randn(B, Co, Ho, Wo, device=dev).contiguous(memory_format=CL)
+        run = lambda: _wrw_c1(x, gy, KH, stride, ph)
     elif kind == "x6":
         wk = torch.randn(KH, KW, Ci, Co, device=dev)
         img = _x6_image(wk, wk, 0)
@@ -444,6 +485,8 @@ def kernel_name(rec):
     M = B * Ho * Wo
     n_tiles = (Co + bn - 1) // bn
     vec = Ci % 4 == 0 and Co % 4 == 0
+    if kind in ("c1_fwd", "c1_wrw"):
+        return "conv_c1_%s_kernel<%d, %d>" % (kind[3:], rec[8], rec[10])
     if kind == "x6":
         bn6 = 128 if Co > 64 else 64
         bmt = 64 if (bn6 == 128 and ((B * Ho * Wo + 127) // 128) * ((Co + 127) // 128) < 384) else 128

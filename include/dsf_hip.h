@@ -319,6 +319,21 @@ int dsf_conv_igemm_wrw(const float* X, const float* dY, float* dW, int B, int Hi
                        int Co, int KH, int KW, int stride, int pad_h, int pad_w, int accumulate, dsf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Direct convolution for 1-channel inputs (csrc/conv_c1.hip): the 5x5 ResNet stem (model/backbone.py:196-199), the 7x7
+ * stride-2 hourglass stem (model/hourglass.py:178) and the generator's first layer (render_model/transfer.py:409).
+ * X (B,Hi,Wi) f32, W [K][K][1][Co] (= [K*K][Co]), Y / dY (B,Ho,Wo,Co) NHWC, Co <= 64, square K in {5, 7}, stride 1 or 2,
+ * symmetric zero padding `pad`; other shapes return DSF_ERR_UNSUPPORTED (dsf_conv_c1_supported tells beforehand) and go
+ * through dsf_conv_igemm_*.  fp32 FMAs, lane = output channel.  dsf_conv_c1_wrw: dW [K*K][Co] (accumulate as in
+ * dsf_conv_igemm_wrw), workspace = dsf_conv_c1_workspace_bytes(K, K) bytes of per-workgroup partial sums; deterministic.
+ * ---------------------------------------------------------------------------------- */
+int dsf_conv_c1_supported(int Co, int KH, int KW, int stride);
+int64_t dsf_conv_c1_workspace_bytes(int KH, int KW);
+int dsf_conv_c1_forward(const float* X, const float* W, const float* bias, float* Y, int B, int Hi, int Wi, int Ho, int Wo, int Co,
+                        int K, int stride, int pad, dsf_stream_t stream);
+int dsf_conv_c1_wrw(const float* X, const float* dY, float* dW, float* workspace, int B, int Hi, int Wi, int Ho, int Wo, int Co,
+                    int K, int stride, int pad, int accumulate, dsf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * fp32 convolution on the bf16 matrix cores by exact operand splitting (csrc/conv_x6.hip).  Same callers as
  * dsf_conv_igemm_forward (model/backbone.py:200-233, model/resnet.py, model/hourglass.py, render_model/transfer.py).
  * Every fp32 operand is the exact sum of three bf16 values; six bf16 MFMAs with fp32 accumulation reproduce the fp32

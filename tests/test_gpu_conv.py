@@ -20,6 +20,9 @@ CASES = [
     (1, 64, 7, 2, 3, 32, True),           # hourglass stem
     (64, 1, 7, 1, 0, 22, True),           # generator output conv (Co = 1)
     (128, 256, 3, 1, 1, 9, False),        # odd spatial size -> M tail
+    (1, 36, 5, 2, 2, 29, True),           # 1-channel direct kernels (conv_c1.hip): partial lanes, ragged row segments
+    (1, 64, 7, 1, 3, 21, False),
+    (1, 8, 5, 1, 0, 13, True),
 ]
 
 
