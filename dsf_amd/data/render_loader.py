@@ -1,6 +1,7 @@
 """Counterpart of the GPU-side tensor utilities of the reference's ``data/render_loader.py``
-``loader`` class (coordinate transforms, crop_hand, Img2pcl; :336-353, 1044-1227).  Dataset
-readers / cv2 augmentation are out of scope."""
+``loader`` class (coordinate transforms, crop_hand, Img2pcl; :336-353, 1044-1227) plus the test-phase depth crop
+(``Crop_Image_deep_pp`` + ``normalize_img``, :748-810, 738-745) as one device kernel over a batch of raw frames
+(SURVEY 8f row 1).  File readers and the training-phase cv2 augmentations are out of scope."""
 import torch
 
 from .. import _lib as L
@@ -19,6 +20,12 @@ class loader:
         self.flip = 1
         self.ori_img_size = ori_img_size
         self.cam = L.camera(paras, ori_img_size)
+
+    def crop_normalize(self, depth, com, cube_size, paras=None, want_raw=False):
+        """Batched device version of the ``phase == 'test'`` branch of ``__getitem__`` (:1909-1916):
+        ``Crop_Image_deep_pp(depth, center_uvd, cube_size, (img_size, img_size), paras)`` followed by
+        ``normalize_img(crop.max(), crop, center, cube_size)`` -> data (B,1,S,S) f32, M (B,3,3) f64 [, raw crop]."""
+        return ops.depth_crop_normalize(depth, com, cube_size, paras or self.paras, self.img_size, want_raw)
 
     @staticmethod
     def _b3(x, B):

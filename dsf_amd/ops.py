@@ -408,6 +408,26 @@ def img2pcl(img, center, minv, cube, cam, n_sample, rand_keys=None):
     return pcl, counts
 
 
+def depth_crop_normalize(depth, com, cube, paras, dsize=128, want_raw=False):
+    """Test-phase data path of loader.__getitem__ (data/render_loader.py:1909-1916): Crop_Image_deep_pp + normalize_img on
+    raw depth frames.  depth (B,Hd,Wd) f32 mm, com (B,3) (u, v, z) and cube (B,3) / (3,) are used as float64 (the reference's
+    numpy arithmetic) -> img (B,1,dsize,dsize) f32, trans (B,3,3) f64 [, raw crop (B,dsize,dsize)]."""
+    if not depth.is_cuda:
+        raise RuntimeError("dsf_amd ops run on the GPU only (got a %s tensor); there is no CPU path" % depth.device)
+    depth = depth.float().contiguous()
+    B, Hd, Wd = depth.shape
+    com = torch.as_tensor(com, dtype=torch.float64, device=depth.device).reshape(B, 3).contiguous()
+    cube = torch.as_tensor(cube, dtype=torch.float64, device=depth.device)
+    cube = (cube.reshape(1, 3).expand(B, 3) if cube.numel() == 3 else cube.reshape(B, 3)).contiguous()
+    img = _empty((B, 1, dsize, dsize), depth)
+    trans = torch.empty((B, 3, 3), device=depth.device, dtype=torch.float64)
+    raw = _empty((B, dsize, dsize), depth) if want_raw else None
+    D = ctypes.c_double
+    check(L.lib().dsf_depth_crop_normalize(ptr(depth), ptr(com), ptr(cube), D(paras[0]), D(paras[1]), I(B), I(Hd), I(Wd),
+                                           I(dsize), ptr(img), ptr(trans), ptr(raw), stream_ptr()), "dsf_depth_crop_normalize")
+    return (img, trans, raw) if want_raw else (img, trans)
+
+
 def _map_strides(t):
     """(batch, channel, pixel) strides of a (B,C,S,S) tensor whose pixels are uniformly strided (NCHW, channels-last,
     or a channel slice of either) as a ctypes int64[3]; None if the layout is anything else."""

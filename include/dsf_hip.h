@@ -319,6 +319,17 @@ int dsf_conv_igemm_wrw(const float* X, const float* dY, float* dW, int B, int Hi
                        int Co, int KH, int KW, int stride, int pad_h, int pad_w, int accumulate, dsf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Depth data path (csrc/data_ops.hip): the test-phase crop of loader.__getitem__
+ * (data/render_loader.py:1909-1916) = Crop_Image_deep_pp (:748-810; comToBounds :356-364, getCrop :867-905,
+ * cv2.resize INTER_NEAREST) + normalize_img (:738-745) on raw depth frames in HBM.
+ * depth (B,Hd,Wd) f32 mm (0 = hole), com (B,3) f64 = centre of mass (u, v, z mm), cube (B,3) f64 mm, fx / fy the focal
+ * lengths -> img (B,dsize,dsize) f32 in [-1,1], trans (B,3,3) f64 (may be NULL) = the crop's pixel transform,
+ * raw_crop (B,dsize,dsize) f32 (may be NULL) = the crop before normalisation (what the training-phase augmentations
+ * take).  Source-pixel selection is bit-exact with the numpy code; normalised values agree to 1 float32 ulp. */
+int dsf_depth_crop_normalize(const float* depth, const double* com, const double* cube, double fx, double fy, int B, int Hd,
+                             int Wd, int dsize, float* img, double* trans, float* raw_crop, dsf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Direct convolution for 1-channel inputs (csrc/conv_c1.hip): the 5x5 ResNet stem (model/backbone.py:196-199), the 7x7
  * stride-2 hourglass stem (model/hourglass.py:178) and the generator's first layer (render_model/transfer.py:409).
  * X (B,Hi,Wi) f32, W [K][K][1][Co] (= [K*K][Co]), Y / dY (B,Ho,Wo,Co) NHWC, Co <= 64, square K in {5, 7}, stride 1 or 2,
