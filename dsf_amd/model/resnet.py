@@ -1,7 +1,6 @@
-"""Residual blocks of the backbone (counterpart of the reference's ``model/resnet.py:18-98``).
-Dense convolutions stay on PyTorch-ROCm (MIOpen / hipBLASLt MFMA kernels): the north star keeps
-MFMA for the backbone's conv GEMMs only.  Attribute names follow the reference so its
-checkpoints (state-dict keys) load unchanged."""
+"""Residual blocks of the backbone (counterpart of the reference's ``model/resnet.py:18-98``) on the HIP convolution
+and fused BN(+add+ReLU) kernels of this package.  Attribute names follow the reference so its checkpoints (state-dict
+keys) load unchanged."""
 import torch.nn as nn
 
 from ..nn_conv import Conv2d as _HipConv2d
