@@ -68,6 +68,20 @@ class EvalStep:
         return errors
 
     @torch.no_grad()
+    @torch.no_grad()
+    def test_frames(self, depth, center_uvd, cube, xyz_gt, paras=(588.03, 587.07, 320., 240.), writers=None):
+        """``test_iter`` straight from raw depth frames: the reference's test-phase ``loader.__getitem__``
+        (data/render_loader.py:1897-1916: ``Crop_Image_deep_pp`` + ``normalize_img``, ``com3D = jointImgTo3D(com2D)``)
+        runs on the device first (``dsf_depth_crop_normalize``), so no cropped images cross PCIe.
+        depth (B,Hd,Wd) f32 mm, center_uvd (B,3) (u, v, z mm), cube (B,3) mm, xyz_gt as for ``test_iter``."""
+        from . import ops
+        img, trans = ops.depth_crop_normalize(depth, center_uvd, cube, paras, self.cfg.input_size)
+        uvd = torch.as_tensor(center_uvd, dtype=torch.float32, device=img.device).reshape(-1, 3)
+        fx, fy, fu, fv = paras
+        center = torch.stack(((uvd[:, 0] - fu) * uvd[:, 2] / fx, (uvd[:, 1] - fv) * uvd[:, 2] / fy, uvd[:, 2]), dim=1)   # flip = 1 (NYU)
+        cube = torch.as_tensor(cube, dtype=torch.float32, device=img.device).reshape(-1, 3).expand(img.size(0), 3)
+        return self.test_iter(img, xyz_gt, center, cube, trans.float(), writers)
+
     def test(self, batches):
         """``Trainer.test`` (:316-352) over an iterable of (img, xyz_gt, uvd_gt, center, M, cube) device batches:
         -> (mean over outputs of the batch-averaged errors, per-output list).  One host sync at the end."""

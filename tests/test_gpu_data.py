@@ -55,3 +55,32 @@ def test_crop_normalize_empty_batch_and_cpu_tensor():
     assert img.shape == (0, 1, 128, 128) and trans.shape == (0, 3, 3)
     with pytest.raises(RuntimeError):
         ops.depth_crop_normalize(torch.zeros(1, 480, 640), np.zeros((1, 3)), np.zeros((1, 3)), (588.03, 587.07, 320.0, 240.0))
+
+
+def test_eval_from_raw_frames_equals_eval_from_oracle_crops():
+    """EvalStep.test_frames (device crop -> test_iter) against test_iter fed with the oracle's crops, transform and the
+    reference's jointImgTo3D centre (render_loader.py:290-301)."""
+    from oracle import data_ref
+    from dsf_amd.eval_step import EvalStep
+    from dsf_amd.model.backbone import MANO_OCR_stage
+    from dsf_amd.render_model.mano_layer import Render
+    from dsf_amd.train_step import Config
+    mgd, _, _, _, _ = _cases()
+    depth, com, cube = mgd.frames(np.random.RandomState(3), 4)
+    torch.manual_seed(0)
+    net = MANO_OCR_stage("ResNet_stage_18", 21, True).cuda().eval()
+    render = Render("synthetic", "nyu", mgd.PARAS, (640, 480)).cuda()
+    ev = EvalStep(net, render, Config, dataset="nyu")
+    xyz_gt = torch.randn(4, 21, 3, device="cuda") * 0.3
+    e_dev = torch.stack(ev.test_frames(torch.tensor(depth).cuda(), com, cube, xyz_gt, mgd.PARAS))
+    crops, Ms, centers = [], [], []
+    fx, fy, fu, fv = mgd.PARAS
+    for i in range(4):
+        n, t, _ = data_ref.crop_and_normalize(depth[i], com[i], cube[i], (128, 128), mgd.PARAS)
+        crops.append(n); Ms.append(t)
+        u = com[i].astype(np.float32)
+        centers.append([(u[0] - np.float32(fu)) * u[2] / np.float32(fx), (u[1] - np.float32(fv)) * u[2] / np.float32(fy), u[2]])
+    T = lambda a, dt=torch.float32: torch.tensor(np.asarray(a), dtype=dt, device="cuda")
+    e_ref = torch.stack(ev.test_iter(T(crops).unsqueeze(1), xyz_gt, T(centers), T(cube), T(Ms)))
+    assert torch.isfinite(e_dev).all()
+    assert torch.allclose(e_dev, e_ref, rtol=1e-4, atol=1e-3), (e_dev, e_ref)
