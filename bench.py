@@ -110,6 +110,31 @@ def conv_kernel_roofline(step, tgt):
             **pmc_traffic(dom), "note": note}, table
 
 
+def measured_mfma_ceiling():
+    """Live: TFLOP/s a bare bf16 MFMA loop (random operands, no memory traffic, 2 workgroups per CU) sustains on this GPU,
+    and the same in fp32-equivalent terms (/ 6) -- the practical ceiling of the split-operand convolution kernels."""
+    import ctypes
+    from dsf_amd import _lib as L
+    ops_ = (torch.randint(0, 256, (4096,), device="cuda", dtype=torch.int32) | 0x3f00)
+    ops_ = (ops_ | (ops_.roll(1) << 16)).contiguous()                       # bf16 pairs in [0.5, 1)
+    wgs, iters = 512, 3000
+    out = torch.empty(wgs * 256, device="cuda")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    call = lambda n: L.lib().dsf_mfma_bf16_probe(ctypes.c_void_p(ops_.data_ptr()), ctypes.c_void_p(out.data_ptr()), ctypes.c_int(wgs),
+                                                 ctypes.c_int(n), st)
+    call(100)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    n = sum(call(iters) for _ in range(4))
+    e1.record()
+    torch.cuda.synchronize()
+    tf = n * 2.0 * 32 * 32 * 16 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    return {"bf16_TFLOP/s": round(tf, 1), "fp32_equivalent_TFLOP/s": round(tf / 6.0, 1),
+            "note": "bare v_mfma_f32_32x32x16_bf16 loop, 2 workgroups per CU, timed here: what the matrix pipe sustains at the "
+                    "clock the chip holds under it (nominal 2500 assumes 2.4 GHz)"}
+
+
 def same_step_on_fp32_mfma(step, tgt, B, steps=10, warmup=3):
     """Rank-0 diagnostic beside the headline: the same training step with every convolution on the plain fp32 MFMA
     (v_mfma_f32_32x32x2_f32, conv.hip) instead of the split-operand kernels -- what DSF_CONV_MATH=f32 would measure."""
@@ -240,6 +265,10 @@ def main():
         out["roofline"], out["conv_kernels"] = conv_kernel_roofline(step, tgt)
         out["roofline_raster"] = crop_kernel_roofline(render, args.batch)
         out["fp32_mfma_path"] = same_step_on_fp32_mfma(step, tgt, args.batch)
+        if "x6" in out["roofline"]["kernel"]:
+            out["roofline"]["measured_mfma_ceiling"] = measured_mfma_ceiling()
+            out["roofline"]["frac_of_measured_ceiling"] = round(
+                out["roofline"]["achieved"] / out["roofline"]["measured_mfma_ceiling"]["fp32_equivalent_TFLOP/s"], 4)
         flops_per_img = 3 * 25.42e9 if args.backbone.endswith("18") else 3 * 37.84e9     # fwd+bwd ~ 3x fwd
         tf = flops_per_img * images / dt / 1e12
         out["whole_step_mfma"] = {"achieved": round(tf, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",

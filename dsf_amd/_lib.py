@@ -47,7 +47,7 @@ SYMBOLS = [
     "dsf_conv_igemm_forward", "dsf_conv_igemm_bwd_data_s1", "dsf_conv_igemm_forward_wt", "dsf_conv_igemm_wrw",
     "dsf_depth_crop_normalize", "dsf_conv_c1_supported", "dsf_conv_c1_workspace_bytes", "dsf_conv_c1_forward", "dsf_conv_c1_wrw",
     "dsf_conv_x6_image_bytes", "dsf_conv_x6_split_weights", "dsf_conv_x6_image_granules",
-    "dsf_conv_x6_split_weights_multi", "dsf_conv_x6_forward", "dsf_conv_x6_wrw", "dsf_bn_forward", "dsf_bn_apply", "dsf_bn_backward", "dsf_bn_workspace_bytes", "dsf_col_sum", "dsf_col_sum_workspace_bytes",
+    "dsf_conv_x6_split_weights_multi", "dsf_conv_x6_forward", "dsf_conv_x6_wrw", "dsf_mfma_bf16_probe", "dsf_bn_forward", "dsf_bn_apply", "dsf_bn_backward", "dsf_bn_workspace_bytes", "dsf_col_sum", "dsf_col_sum_workspace_bytes",
     "dsf_huber_mean_forward", "dsf_huber_mean_backward", "dsf_adamw_multi", "dsf_adamw_chunk_elems",
 ]
 
@@ -63,6 +63,7 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.dsf_status_string.restype = ctypes.c_char_p
         _lib.dsf_conv_x6_image_bytes.restype = ctypes.c_int64
+        _lib.dsf_mfma_bf16_probe.restype = ctypes.c_int64
         _lib.dsf_conv_c1_workspace_bytes.restype = ctypes.c_int64
         _lib.dsf_conv_x6_image_granules.restype = ctypes.c_int64
         for s in SYMBOLS:

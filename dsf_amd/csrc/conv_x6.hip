@@ -518,9 +518,46 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
         }
 }
 
+// Measurement aid (bench.py): a bare v_mfma_f32_32x32x16_bf16 loop on pseudo-random operands, four accumulators per wave,
+// no memory traffic -- the matrix-pipe rate this chip sustains at the clock it holds under that load, i.e. the practical
+// ceiling of the split-operand kernels (their nominal peak, 2500 / 6 TFLOP/s, assumes the 2.4 GHz boost clock).
+__global__ __launch_bounds__(256) void mfma_bf16_probe_kernel(const u32x4* __restrict__ in, float* __restrict__ out, int iters) {
+    u32x4 ra[6], rb[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { ra[i] = in[(threadIdx.x + 64 * i) & 1023]; rb[i] = in[(threadIdx.x * 3 + 17 * i) & 1023]; }
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ra[(q + t) % 6]),
+                                                                 __builtin_bit_cast(bf16x8, rb[(q * 2 + t) % 6]), acc[t], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[t][r];
+    out[(int64_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 }  // namespace
 
 extern "C" {
+
+// operands: 1024 x 16 bytes of bf16 pairs; out: workgroups * 256 floats (ignored values); returns the MFMA count issued
+int64_t dsf_mfma_bf16_probe(const void* operands, float* out, int workgroups, int iters, dsf_stream_t stream) {
+    if (!operands || !out || workgroups <= 0 || iters <= 0) return -1;
+    hipLaunchKernelGGL(mfma_bf16_probe_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, (const u32x4*)operands, out,
+                       iters);
+    if (dsf_launch_status() != DSF_OK) return -1;
+    return (int64_t)workgroups * 4 * iters * 24;
+}
 
 int64_t dsf_conv_x6_image_bytes(int KH, int KW, int Ck, int Cn) {
     const int bn = x6_bn(Cn);

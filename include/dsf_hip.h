@@ -370,6 +370,10 @@ int dsf_conv_x6_split_weights_multi(const int64_t* jobs, int n_jobs, int64_t tot
 int dsf_conv_x6_forward(const float* X, const void* image, const float* bias, float* Y, int B, int Hi, int Wi, int Ci, int Ho,
                         int Wo, int Co, int KH, int KW, int stride, int dil, int pad_h, int pad_w, int k_splits,
                         dsf_stream_t stream);
+/* Measurement aid for bench.py: launches a bare v_mfma_f32_32x32x16_bf16 loop (no memory traffic) on `workgroups` x 4 waves,
+ * `iters` x 24 MFMAs each, operands = 16 KiB of bf16 pairs; returns the number of MFMAs issued (each 2*32*32*16 flop), -1 on error.
+ * Timed by the caller: the matrix-pipe rate the chip sustains at the clock it holds under that load. */
+int64_t dsf_mfma_bf16_probe(const void* operands, float* out, int workgroups, int iters, dsf_stream_t stream);
 /* Backward-weights twin of dsf_conv_igemm_wrw (same arguments and accumulate semantics; Ci % 4 == 0 and Co % 4 == 0):
  * both operands are split on the fly and transposed by the LDS read (ds_read_b64_tr_b16); the pixel reduction is cut into
  * splits that meet in dW by float atomics. */
