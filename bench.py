@@ -213,8 +213,8 @@ def main():
     local = local % max(torch.cuda.device_count(), 1)          # (ranks may share a device in single-GPU flow tests)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    # MIOpen is still used for BatchNorm (faster than torch's native channels-last BN here: 41.5 vs 47.6 ms/step);
-    # convolutions never reach it (dsf_conv_igemm_*)
+    # neither convolutions (dsf_conv_x6_* / dsf_conv_igemm_*) nor BatchNorm (dsf_bn_*) reach MIOpen; the switch only matters for
+    # DSF_FUSED_BN=0 runs
     torch.backends.cudnn.benchmark = os.environ.get("DSF_MIOPEN_FIND", "0") == "1"   # reference :87 uses find mode; gfx950 ships no MIOpen find-db, find mode JIT-compiles every solver (hours)
 
     from dsf_amd.render_model.mano_layer import Render
