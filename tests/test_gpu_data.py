@@ -84,3 +84,29 @@ def test_eval_from_raw_frames_equals_eval_from_oracle_crops():
     e_ref = torch.stack(ev.test_iter(T(crops).unsqueeze(1), xyz_gt, T(centers), T(cube), T(Ms)))
     assert torch.isfinite(e_dev).all()
     assert torch.allclose(e_dev, e_ref, rtol=1e-4, atol=1e-3), (e_dev, e_ref)
+
+
+def test_crop_normalize_adversarial_boxes():
+    """Crop boxes entirely outside the frame (all background), larger than the frame (hand close to the camera), frames of
+    another size, an all-zero frame: device == oracle bit for bit."""
+    from oracle import data_ref
+    from dsf_amd import ops
+    rng = np.random.RandomState(99)
+    H, W = 240, 320
+    paras = (294.0, 293.5, 160.0, 120.0)
+    depth = (rng.uniform(300, 1500, (6, H, W)) * (rng.uniform(size=(6, H, W)) > 0.1)).astype(np.float32)
+    depth[5] = 0.0
+    com = np.array([[-400.0, 100.0, 600.0],        # far left of the frame
+                    [160.2, 119.7, 120.0],          # 12 cm from the camera: box larger than the frame
+                    [319.0, 239.0, 900.0],          # bottom-right corner
+                    [10.5, 200.25, 1400.0],
+                    [160.0, 120.0, 700.0],
+                    [100.0, 100.0, 650.0]])         # all-zero frame
+    cube = np.array([[250.0] * 3, [250.0] * 3, [300.0] * 3, [180.0, 220.0, 200.0], [250.0, 250.0, 60.0], [250.0] * 3])
+    img, trans, raw = ops.depth_crop_normalize(torch.tensor(depth).cuda(), com, cube, paras, 128, want_raw=True)
+    for i in range(6):
+        n, t, c = data_ref.crop_and_normalize(depth[i], com[i], cube[i], (128, 128), paras)
+        assert np.array_equal(raw[i].cpu().numpy(), c), i
+        assert np.array_equal(trans[i].cpu().numpy(), t), i
+        assert np.array_equal(img[i, 0].cpu().numpy(), n), i
+    assert float(img[0].min()) == 1.0 and float(img[5].max()) == 1.0           # nothing but background -> far plane
