@@ -85,3 +85,29 @@ def test_conv_shapes_at_kernel_limits(cin, cout, k, s, h):
     assert torch.allclose(xg.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-4)
     assert torch.allclose(conv.weight.grad.cpu(), ref.weight.grad, rtol=1e-3, atol=1e-3)
     assert torch.allclose(conv.bias.grad.cpu(), ref.bias.grad, rtol=1e-3, atol=1e-3)
+
+
+def test_new_convolution_entry_points_follow_the_error_convention():
+    """Status codes of the split-operand / 1-channel entry points for arguments they do not take: an error status
+    (never a wrong answer), which the Python layer turns into RuntimeError."""
+    import ctypes
+    from dsf_amd import _lib as L
+    from dsf_amd._lib import I, ptr, stream_ptr
+    lib = L.lib()
+    x = torch.randn(2, 8, 8, 18, device="cuda")                    # NHWC, Ci = 18: not a multiple of 4
+    img = torch.zeros(lib.dsf_conv_x6_image_bytes(I(3), I(3), I(20), I(16)), dtype=torch.uint8, device="cuda")
+    y = torch.empty(2, 8, 8, 16, device="cuda")
+    st = lib.dsf_conv_x6_forward(ptr(x), ptr(img), ptr(None), ptr(y), I(2), I(8), I(8), I(18), I(8), I(8), I(16), I(3), I(3), I(1),
+                                 I(1), I(1), I(1), I(0), stream_ptr())
+    assert st != 0 and b"argument" in lib.dsf_status_string(st).lower()
+    x4 = torch.randn(2, 8, 8, 20, device="cuda")
+    y_odd = torch.empty(2, 15, 15, 16, device="cuda")              # dil 2 needs even output sizes
+    st = lib.dsf_conv_x6_forward(ptr(x4), ptr(img), ptr(None), ptr(y_odd), I(2), I(8), I(8), I(20), I(15), I(15), I(16), I(3), I(3),
+                                 I(1), I(2), I(1), I(1), I(0), stream_ptr())
+    assert st == 2                                                  # DSF_ERR_UNSUPPORTED
+    assert lib.dsf_conv_c1_supported(I(64), I(5), I(5), I(1)) == 1 and lib.dsf_conv_c1_supported(I(65), I(5), I(5), I(1)) == 0
+    assert lib.dsf_conv_c1_supported(I(64), I(3), I(3), I(1)) == 0
+    st = lib.dsf_conv_c1_forward(ptr(x), ptr(x), ptr(None), ptr(y), I(2), I(8), I(8), I(8), I(8), I(16), I(3), I(1), I(1), stream_ptr())
+    assert st == 2
+    with pytest.raises(RuntimeError):
+        L.check(st, "dsf_conv_c1_forward")
