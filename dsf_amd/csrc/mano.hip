@@ -389,14 +389,16 @@ __global__ __launch_bounds__(BWD_NT) void mano_bwd_kernel(dsf_mano_model m, cons
     for (int k = 0; k < BWD_KPT; ++k) { const int e = t + BWD_NT * k; gk[k] = (e < NE) ? s_gvp[e] : 0.f; }
     // rows are taken JB at a time with all their loads issued before the first reduction: the loop was one L2 round trip
     // (~0.6 us) per row, 145 rows deep (87 of the kernel's 123 us at B = 32); same arithmetic, same order
-    constexpr int JB = 9;
-    static_assert(135 % JB == 0, "row blocking");
-    for (int j0 = 0; j0 < 135; j0 += JB) {
-        float v[JB][BWD_KPT];
+    constexpr int JB = 9, NBLK = 135 / JB;
+    static_assert(135 % JB == 0 && NBLK % 2 == 1, "row blocking");
+    float va[JB][BWD_KPT], vb[JB][BWD_KPT];              // two row blocks: the next one is in flight while this one is reduced
+    auto load_block = [&](int j0, float (&v)[JB][BWD_KPT]) {
 #pragma unroll
         for (int u = 0; u < JB; ++u)
 #pragma unroll
             for (int k = 0; k < BWD_KPT; ++k) { const int e = t + BWD_NT * k; v[u][k] = (e < NE) ? m.posedirs[(j0 + u) * NE + e] : 0.f; }
+    };
+    auto reduce_block = [&](int j0, const float (&v)[JB][BWD_KPT]) {
 #pragma unroll
         for (int u = 0; u < JB; ++u) {
             float p = 0.f;
@@ -405,7 +407,15 @@ __global__ __launch_bounds__(BWD_NT) void mano_bwd_kernel(dsf_mano_model m, cons
             p = wave_sum(p);
             if (lane == 0) s_part[(j0 + u) * BWD_NW + wave] = p;
         }
+    };
+    load_block(0, va);
+    for (int blk = 0; blk + 2 < NBLK; blk += 2) {
+        load_block((blk + 1) * JB, vb);
+        reduce_block(blk * JB, va);
+        load_block((blk + 2) * JB, va);
+        reduce_block((blk + 1) * JB, vb);
     }
+    reduce_block((NBLK - 1) * JB, va);
     {
         float v[10][BWD_KPT];
 #pragma unroll
