@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libdsf_hip.so")
 
 c_float_p = ctypes.c_void_p
 _lib = None
+WRITE_EPOCH = [0]      # bumped by nn_conv.weights_changed(): parameter writes torch's version counters cannot see
 
 
 class MissingNativeLibrary(RuntimeError):

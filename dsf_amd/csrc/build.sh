@@ -2,16 +2,35 @@
 # Builds libdsf_hip.so for gfx950 (MI355X) in-tree.  hipcc cross-compiles without a GPU.
 # -ffp-contract=off: coverage / argmin decisions must be bit-identical to the oracle's
 # separate IEEE ops; fused multiply-adds are written explicitly (fmaf) where wanted.
+# A failed compile fails the build: the stale object is removed before compiling, every background
+# job's status is collected, and a change of FLAGS rebuilds everything.
 set -e
 cd "$(dirname "$0")"
 OUT=../lib
 mkdir -p $OUT
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function"
-for f in api mano raster pfd hand_geom image_ops data_ops conv conv_x6 conv_c1 norm loss optim; do
+SRCS="api mano raster pfd hand_geom image_ops data_ops conv conv_x6 conv_c1 norm loss optim"
+if [ "$(cat $OUT/.flags 2>/dev/null)" != "$FLAGS" ]; then
+  rm -f $OUT/*.o
+  echo "$FLAGS" > $OUT/.flags
+fi
+pids=()
+for f in $SRCS; do
   if [ ! -f $OUT/$f.o ] || [ $f.hip -nt $OUT/$f.o ] || [ common.h -nt $OUT/$f.o ] || [ ../../include/dsf_hip.h -nt $OUT/$f.o ]; then
+    rm -f $OUT/$f.o
     /opt/rocm/bin/hipcc $FLAGS -c $f.hip -o $OUT/$f.o &
+    pids+=($!)
   fi
 done
-wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libdsf_hip.so $OUT/api.o $OUT/mano.o $OUT/raster.o $OUT/pfd.o $OUT/hand_geom.o $OUT/image_ops.o $OUT/data_ops.o $OUT/conv.o $OUT/conv_x6.o $OUT/conv_c1.o $OUT/norm.o $OUT/loss.o $OUT/optim.o
+fail=0
+for p in "${pids[@]}"; do
+  wait $p || fail=1
+done
+if [ $fail -ne 0 ]; then
+  echo "build.sh: a compile failed" >&2
+  exit 1
+fi
+OBJS=""
+for f in $SRCS; do OBJS="$OBJS $OUT/$f.o"; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libdsf_hip.so $OBJS
 echo built $OUT/libdsf_hip.so

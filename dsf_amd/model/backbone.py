@@ -101,15 +101,19 @@ class _TwoBranchNet(nn.Module):
         pix = nn_conv.fused_heads(feat, heads)
         return c4, feat, pix, mano
 
+    @torch.no_grad()
     def init_weights(self):
+        # in-place ops on the parameters themselves (not `.data`): torch's version counters see them; the write epoch is
+        # bumped as well so that nothing keyed on parameter contents (conv_x6 weight images) can outlive a re-initialisation
+        nn_conv.weights_changed()
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
-                m.weight.data.normal_(0, math.sqrt(2. / (m.kernel_size[0] * m.kernel_size[1] * m.out_channels)))
+                m.weight.normal_(0, math.sqrt(2. / (m.kernel_size[0] * m.kernel_size[1] * m.out_channels)))
             elif isinstance(m, nn.BatchNorm2d):
-                m.weight.data.fill_(1)
-                m.bias.data.zero_()
+                m.weight.fill_(1)
+                m.bias.zero_()
             elif isinstance(m, nn.Linear):
-                m.weight.data.normal_(0, 0.001)
+                m.weight.normal_(0, 0.001)
             elif isinstance(m, nn.ConvTranspose2d):
                 nn.init.normal_(m.weight, std=0.001)
         for name in ('finals', 'finals_s2'):

@@ -97,15 +97,19 @@ class PoseNet(nn.Module):
         self.merge_all = nn.ModuleList([Merge(inp_dim * 2, inp_dim) for _ in range(nstack - 1)])
         self.init_weights()
 
+    @torch.no_grad()
     def init_weights(self):
+        # in-place ops on the parameters themselves (not `.data`): torch's version counters see them; the write epoch is
+        # bumped as well so that nothing keyed on parameter contents (conv_x6 weight images) can outlive a re-initialisation
+        nn_conv.weights_changed()
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
-                m.weight.data.normal_(0, math.sqrt(2. / (m.kernel_size[0] * m.kernel_size[1] * m.out_channels)))
+                m.weight.normal_(0, math.sqrt(2. / (m.kernel_size[0] * m.kernel_size[1] * m.out_channels)))
             elif isinstance(m, nn.BatchNorm2d):
-                m.weight.data.fill_(1)
-                m.bias.data.zero_()
+                m.weight.fill_(1)
+                m.bias.zero_()
             elif isinstance(m, nn.Linear):
-                m.weight.data.normal_(0, 0.001)
+                m.weight.normal_(0, 0.001)
         for heads in (self.outs_1, self.outs_2):
             for m in heads:
                 nn.init.normal_(m.weight, std=0.001)

@@ -44,10 +44,22 @@ _EPOCH = 0
 
 
 def weights_changed():
-    """Called by whoever rewrites parameters through raw pointers (optim.FusedAdamW): torch's version counter does not
-    see such writes, and the split weight images of conv_x6 are cached per (tensor version, epoch)."""
+    """Called by whoever rewrites parameters behind torch's version counters (optim.FusedAdamW's raw-pointer kernel, the
+    model builders' init_weights, user code that writes through ``.data``): bumps the global write epoch that every cache
+    keyed on parameter contents includes (the split weight images of conv_x6 here, the MANO layer's result memo)."""
     global _EPOCH
     _EPOCH += 1
+    L.WRITE_EPOCH[0] = _EPOCH
+
+
+def manage_weights(params, managed=True):
+    """Declares that every write to ``params`` from now on is announced (in-place torch ops on the parameter itself, which
+    bump its version counter, or ``weights_changed()``): only then are the split weight images of conv_x6 kept from one
+    use to the next.  optim.FusedAdamW manages the parameters it updates, EvalStep the frozen net it scores.  Unmanaged
+    parameters (the default) are re-split at every use, so that a write torch cannot see -- ``w.data.mul_(2)``, a
+    ``.data``-style optimizer or EMA -- is never served from a stale image."""
+    for p in params:
+        p.__dict__["_dsf_managed"] = bool(managed)
 
 
 _X6_MAX_ELEMS = 0xFFFFFFF0 // 4        # the x6 kernels address their fp32 inputs with 32-bit byte offsets (buffer loads)
@@ -68,7 +80,7 @@ def _x6_image(weight, wk, mode):
     KH, KW, Ci, Co = wk.shape
     key = (weight._version, _EPOCH, wk.data_ptr())
     cache = weight.__dict__.get("_dsf_x6")
-    if cache is not None and mode in cache and cache[mode][0] == key:
+    if cache is not None and mode in cache and cache[mode][0] == key and weight.__dict__.get("_dsf_managed", False):
         return cache[mode][1]
     Ck, Cn = (Co, Ci) if mode else (Ci, Co)
     n = L.lib().dsf_conv_x6_image_bytes(I(KH), I(KW), I(Ck), I(Cn))

@@ -90,10 +90,17 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
 
     def flush_batch_counter(self):
         """num_batches_tracked is only an output when momentum is set (the running statistics do not depend on it), so
-        the per-step `add_(1)` launch is deferred and folded in when the state dict is taken."""
-        if self._pending_batches and self.num_batches_tracked is not None:
-            self.num_batches_tracked.add_(self._pending_batches)
-        self._pending_batches = 0
+        the per-step `add_(1)` launch is deferred and folded in when the buffer is read (attribute access, state dict)."""
+        n, self._pending_batches = self._pending_batches, 0
+        if n:
+            nbt = self._buffers.get("num_batches_tracked")
+            if nbt is not None:
+                nbt.add_(n)
+
+    def __getattr__(self, name):
+        if name == "num_batches_tracked" and self.__dict__.get("_pending_batches"):
+            self.flush_batch_counter()
+        return super().__getattr__(name)
 
     def _save_to_state_dict(self, destination, prefix, keep_vars):
         self.flush_batch_counter()
@@ -108,6 +115,8 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
         if not x.is_cuda:
             raise RuntimeError("dsf_amd FusedBatchNorm2d runs on the GPU only (got %s)" % x.device)
         C = x.shape[1]
+        if x.numel() == 0:                                   # empty batch: nothing to normalise, no statistics to update
+            return x.contiguous(memory_format=CL)
         use_batch_stats = self.training or not self.track_running_stats
         if supported(C) and x.dtype == torch.float32:
             if use_batch_stats:
@@ -120,7 +129,9 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
                 rm = self.running_mean if (self.training and self.track_running_stats) else None
                 rv = self.running_var if (self.training and self.track_running_stats) else None
                 return _BNFunction.apply(x, residual, self.weight, self.bias, rm, rv, self.eps, mom, relu)
-            if torch.is_grad_enabled() and (x.requires_grad or (residual is not None and residual.requires_grad)):
+            if torch.is_grad_enabled() and (x.requires_grad or (residual is not None and residual.requires_grad) or
+                                            (self.weight is not None and self.weight.requires_grad) or
+                                            (self.bias is not None and self.bias.requires_grad)):
                 y = super().forward(x)                      # frozen-statistics BN inside a differentiated graph: torch's kernels
                 if residual is not None:
                     y = y + residual

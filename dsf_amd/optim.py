@@ -21,11 +21,13 @@ class FusedAdamW(torch.optim.Optimizer):
             raise ValueError("invalid AdamW hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._tables = {}
+        from . import nn_conv
+        nn_conv.manage_weights(p for g in self.param_groups for p in g["params"])     # this optimizer announces its writes
 
-    def _table(self, gi, plist):
-        """static per-group chunk table + reusable pointer buffers (host pinned, device)"""
-        key = (gi, tuple(id(p) for p in plist))
-        tb = self._tables.get(gi)
+    def _table(self, slot, plist):
+        """static chunk table of one launch + reusable pointer buffers (host pinned, device)"""
+        key = tuple(id(p) for p in plist)
+        tb = self._tables.get(slot)
         if tb is not None and tb["key"] == key:
             return tb
         dev = plist[0].device
@@ -43,11 +45,13 @@ class FusedAdamW(torch.optim.Optimizer):
               # whole step ahead of the GPU), a buffer is reused only after the copy that read it has completed
               "ring": [torch.empty((len(plist), 4), dtype=torch.int64).pin_memory() for _ in range(4)],
               "ring_ev": [None] * 4, "ring_i": 0}
-        self._tables[gi] = tb
+        self._tables[slot] = tb
         return tb
 
     def _prepare(self, gi, group):
-        """per-group cache: parameters with gradients, their state tensors and the shared step count"""
+        """per-group cache: the parameters with gradients, partitioned by their step count (torch.optim.AdamW keeps one
+        step per parameter: a parameter that sat out some steps -- no gradient under zero_grad(set_to_none=True) -- has
+        its own bias corrections).  Normally there is ONE partition = one launch; k distinct counts cost k launches."""
         plist = [p for p in group["params"] if p.grad is not None]
         for p in plist:
             if not (p.is_cuda and p.dtype == torch.float32) or p.grad.is_sparse:
@@ -60,17 +64,19 @@ class FusedAdamW(torch.optim.Optimizer):
             if st["exp_avg"].stride() != p.stride():                     # e.g. state loaded from a checkpoint: adopt the parameter's layout
                 st["exp_avg"] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(st["exp_avg"])
                 st["exp_avg_sq"] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(st["exp_avg_sq"])
-        steps = {int(self.state[p]["step"]) for p in plist}
-        if len(steps) > 1:
-            raise RuntimeError("FusedAdamW: parameters of one group must share a step count")
-        return {"plist": plist, "ids": tuple(id(p) for p in plist), "step": steps.pop() if steps else 0,
-                "m": [self.state[p]["exp_avg"] for p in plist], "v": [self.state[p]["exp_avg_sq"] for p in plist]}
+        by_step = {}
+        for p in plist:
+            by_step.setdefault(int(self.state[p]["step"]), []).append(p)
+        parts = [{"plist": ps, "step": s, "m": [self.state[p]["exp_avg"] for p in ps],
+                  "v": [self.state[p]["exp_avg_sq"] for p in ps]} for s, ps in sorted(by_step.items())]
+        return {"ids": tuple(id(p) for p in plist), "parts": parts}
 
     def _sync_steps(self):
-        """the per-parameter `step` entries of the state dict are refreshed from the per-group counters on demand"""
+        """the per-parameter `step` entries of the state dict are refreshed from the partition counters on demand"""
         for c in getattr(self, "_cache", {}).values():
-            for p in c["plist"]:
-                self.state[p]["step"].fill_(float(c["step"]))
+            for part in c["parts"]:
+                for p in part["plist"]:
+                    self.state[p]["step"].fill_(float(part["step"]))
 
     def state_dict(self):
         self._sync_steps()
@@ -94,36 +100,35 @@ class FusedAdamW(torch.optim.Optimizer):
                 if c is not None:
                     self._sync_steps()
                 c = self._cache[gi] = self._prepare(gi, group)
-            plist = c["plist"]
-            if not plist:
-                continue
             b1, b2 = group["betas"]
-            c["step"] += 1
-            step = c["step"]
-            rows = []
-            for p, m, v in zip(plist, c["m"], c["v"]):
-                g = p.grad
-                if g.stride() != p.stride():                             # walk everything in the parameter's memory order
-                    g = torch.empty_like(p, memory_format=torch.preserve_format).copy_(g)
-                    p.grad = g
-                rows.append((p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()))
-            tb = self._table(gi, plist)
-            if rows != tb["rows"]:
-                # addresses changed (first step, a different gradient block from the allocator, or the per-step flat
-                # buckets of data-parallel runs): refresh the device table without draining the stream
-                i = tb["ring_i"]
-                if tb["ring_ev"][i] is not None:
-                    tb["ring_ev"][i].synchronize()
-                tb["ring"][i].copy_(torch.tensor(rows, dtype=torch.int64))
-                tb["ptrs"].copy_(tb["ring"][i], non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record()
-                tb["ring_ev"][i], tb["ring_i"], tb["rows"] = ev, (i + 1) % 4, rows
-            vp = lambda t: ctypes.c_void_p(t.data_ptr())
-            check(L.lib().dsf_adamw_multi(vp(tb["ptrs"]), vp(tb["sizes"]), vp(tb["chunk_tensor"]), vp(tb["chunk_index"]),
-                                          I(tb["n_chunks"]), D(group["lr"]), D(b1), D(b2), D(group["eps"]),
-                                          D(group["weight_decay"]), D(1.0 - math.pow(b1, step)), D(1.0 - math.pow(b2, step)),
-                                          stream_ptr()), "dsf_adamw_multi")
+            for pi, part in enumerate(c["parts"]):
+                plist = part["plist"]
+                part["step"] += 1
+                step = part["step"]
+                rows = []
+                for p, m, v in zip(plist, part["m"], part["v"]):
+                    g = p.grad
+                    if g.stride() != p.stride():                             # walk everything in the parameter's memory order
+                        g = torch.empty_like(p, memory_format=torch.preserve_format).copy_(g)
+                        p.grad = g
+                    rows.append((p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()))
+                tb = self._table((gi, pi), plist)
+                if rows != tb["rows"]:
+                    # addresses changed (first step, a different gradient block from the allocator, or the per-step flat
+                    # buckets of data-parallel runs): refresh the device table without draining the stream
+                    i = tb["ring_i"]
+                    if tb["ring_ev"][i] is not None:
+                        tb["ring_ev"][i].synchronize()
+                    tb["ring"][i].copy_(torch.tensor(rows, dtype=torch.int64))
+                    tb["ptrs"].copy_(tb["ring"][i], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    tb["ring_ev"][i], tb["ring_i"], tb["rows"] = ev, (i + 1) % 4, rows
+                vp = lambda t: ctypes.c_void_p(t.data_ptr())
+                check(L.lib().dsf_adamw_multi(vp(tb["ptrs"]), vp(tb["sizes"]), vp(tb["chunk_tensor"]), vp(tb["chunk_index"]),
+                                              I(tb["n_chunks"]), D(group["lr"]), D(b1), D(b2), D(group["eps"]),
+                                              D(group["weight_decay"]), D(1.0 - math.pow(b1, step)), D(1.0 - math.pow(b2, step)),
+                                              stream_ptr()), "dsf_adamw_multi")
         from . import nn_conv
         nn_conv.weights_changed()            # the kernel wrote the parameters behind torch's version counters
         nn_conv.refresh_images([p for g in self.param_groups for p in g["params"]], owner=self)     # one launch

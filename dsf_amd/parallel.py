@@ -114,6 +114,7 @@ class GradAllReducer:
         self._arrived = [0] * len(self.buckets)
         self._flat = [None] * len(self.buckets)
         self._work = [None] * len(self.buckets)
+        self._missing = [None] * len(self.buckets)
 
     def _on_grad(self, p):
         if not self.enabled:
@@ -124,11 +125,18 @@ class GradAllReducer:
             self._launch(b)
 
     def _launch(self, b):
+        plist = self.buckets[b]
+        missing = [p.grad is None for p in plist]
         parts = [_flat(p.grad if p.grad is not None and p.grad.stride() == p.stride() else
-                       (torch.zeros_like(p) if p.grad is None else torch.empty_like(p).copy_(p.grad))) for p in self.buckets[b]]
-        flat = torch.cat(parts)
+                       (torch.zeros_like(p) if p.grad is None else torch.empty_like(p).copy_(p.grad))) for p in plist]
+        # presence row: one float per parameter, 1 where this rank produced a gradient.  After the sum it tells which
+        # parameters got a gradient on NO rank: those keep ``grad = None`` (as in a single-GPU run, where AdamW then skips
+        # them -- no weight decay, no moment decay), see finish()
+        present = torch.tensor([0.0 if m else float(self.world) for m in missing], dtype=parts[0].dtype).to(parts[0].device, non_blocking=True)
+        flat = torch.cat(parts + [present])
         flat.div_(self.world)
         self._flat[b] = flat
+        self._missing[b] = missing
         self._work[b] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self):
@@ -139,10 +147,17 @@ class GradAllReducer:
                     self._launch(b)
             for b, plist in enumerate(self.buckets):
                 self._work[b].wait()
+                n_par = len(plist)
+                anywhere = None
+                if any(self._missing[b]):                # only a rank that lacks a gradient has to look (one small D2H copy)
+                    anywhere = self._flat[b][-n_par:].tolist()
                 off = 0
-                for p in plist:
+                for i, p in enumerate(plist):
                     n = p.numel()
-                    p.grad = self._flat[b][off:off + n].as_strided(p.shape, p.stride())      # same (possibly kernel) layout as p
+                    if anywhere is not None and self._missing[b][i] and anywhere[i] == 0.0:
+                        p.grad = None                    # no rank produced it
+                    else:
+                        p.grad = self._flat[b][off:off + n].as_strided(p.shape, p.stride())  # same (possibly kernel) layout as p
                     off += n
         self._reset()
 

@@ -246,11 +246,13 @@ class MANO_SMPL(nn.Module):
 
         The trainer evaluates the layer twice on the same parameters within a step (``Render.render(mano)`` and
         ``get_mesh_xyz(mano)``, train_render.py:459-466 / 719): the last two results are kept, keyed by the memory,
-        layout and version of the parameter rows, so the second evaluation reuses the first one's output (and its
-        autograd node: the backward kernel then runs once on the summed gradients)."""
+        layout and version of the parameter rows (plus the global write epoch that raw-pointer writers such as FusedAdamW
+        bump, which torch's version counter does not see), so the second evaluation reuses the first one's output (and
+        its autograd node: the backward kernel then runs once on the summed gradients).  Every step class clears the
+        memo before it builds a new graph."""
         k2 = 1.0 if global_scale is None else float(global_scale)
         key = (model_paras.data_ptr(), tuple(model_paras.shape), tuple(model_paras.stride()), model_paras._version,
-               model_paras.dtype, model_paras.requires_grad, torch.is_grad_enabled(), k2)
+               model_paras.dtype, model_paras.requires_grad, torch.is_grad_enabled(), k2, L.WRITE_EPOCH[0])
         cache = self.__dict__.setdefault("_packed_cache", [])
         for ent in cache:
             if ent[0] == key:

@@ -75,18 +75,19 @@ def define_G(input_nc, output_nc, ngf, netG, norm='batch', use_dropout=False, in
         name = m.__class__.__name__
         if hasattr(m, 'weight') and ('Conv' in name or 'Linear' in name):
             if init_type == 'xavier':
-                init.xavier_normal_(m.weight.data, gain=init_gain)
+                init.xavier_normal_(m.weight, gain=init_gain)
             elif init_type == 'normal':
-                init.normal_(m.weight.data, 0.0, init_gain)
+                init.normal_(m.weight, 0.0, init_gain)
             else:
                 raise NotImplementedError(init_type)
             if getattr(m, 'bias', None) is not None:
-                init.constant_(m.bias.data, 0.0)
+                init.constant_(m.bias, 0.0)
         elif 'BatchNorm2d' in name:
-            init.normal_(m.weight.data, 1.0, init_gain)
-            init.constant_(m.bias.data, 0.0)
+            init.normal_(m.weight, 1.0, init_gain)
+            init.constant_(m.bias, 0.0)
 
-    net.apply(init_func)
+    net.apply(init_func)            # torch.nn.init writes in place on the parameters (version counters see it)
+    nn_conv.weights_changed()
     return net
 
 
@@ -105,21 +106,22 @@ def _init_net(net, init_type, init_gain):
         name = m.__class__.__name__
         if hasattr(m, 'weight') and ('Conv' in name or 'Linear' in name):
             if init_type == 'xavier':
-                init.xavier_normal_(m.weight.data, gain=init_gain)
+                init.xavier_normal_(m.weight, gain=init_gain)
             elif init_type == 'normal':
-                init.normal_(m.weight.data, 0.0, init_gain)
+                init.normal_(m.weight, 0.0, init_gain)
             elif init_type == 'kaiming':
-                init.kaiming_normal_(m.weight.data, a=0, mode='fan_in')
+                init.kaiming_normal_(m.weight, a=0, mode='fan_in')
             elif init_type == 'orthogonal':
-                init.orthogonal_(m.weight.data, gain=init_gain)
+                init.orthogonal_(m.weight, gain=init_gain)
             else:
                 raise NotImplementedError(init_type)
             if getattr(m, 'bias', None) is not None:
-                init.constant_(m.bias.data, 0.0)
+                init.constant_(m.bias, 0.0)
         elif 'BatchNorm2d' in name:
-            init.normal_(m.weight.data, 1.0, init_gain)
-            init.constant_(m.bias.data, 0.0)
-    net.apply(init_func)
+            init.normal_(m.weight, 1.0, init_gain)
+            init.constant_(m.bias, 0.0)
+    net.apply(init_func)            # torch.nn.init writes in place on the parameters (version counters see it)
+    nn_conv.weights_changed()
     return net
 
 

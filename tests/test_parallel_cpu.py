@@ -43,6 +43,25 @@ def _worker(rank, world, port, q):
         loss.backward()
         sync.finish()
         out.append([p.grad.clone() for p in net.parameters()])
+    # a head that no rank uses keeps grad None (a single-GPU run leaves it None too: AdamW must skip it); a head only
+    # rank 1 uses arrives averaged on both ranks
+    sync.enabled = False
+    torch.manual_seed(3)
+    idle, lone = nn.Linear(4, 2), nn.Linear(4, 2)
+    sync2 = GradAllReducer(list(net.parameters()) + list(idle.parameters()) + list(lone.parameters()), bucket_bytes=1024)
+    net.zero_grad(set_to_none=True)
+    loss = ((net(xs) - ys) ** 2).mean()
+    if rank == 1:
+        loss = loss + lone(torch.ones(1, 4)).sum()
+    loss.backward()
+    sync2.finish()
+    assert all(p.grad is None for p in idle.parameters()), "unused parameters must keep grad=None under DP"
+    assert all(p.grad is not None for p in lone.parameters())
+    assert torch.allclose(lone.bias.grad, torch.full((2,), 0.5)) and torch.allclose(lone.weight.grad, torch.full((2, 4), 0.5))
+    for got, p in zip(out[1], net.parameters()):
+        assert torch.allclose(got, p.grad, atol=1e-6)
+    for h in sync2._hooks:
+        h.remove()
     # exact masked mean across shards
     vals = torch.arange(4.0) + 4 * rank
     mask = (vals % 3 == 0).float()
