@@ -196,6 +196,74 @@ def crop_kernel_roofline(render, B, launches=200):
             "note": "VALU/latency-bound at this size (4.5 MB of algorithmic traffic per launch); 2 launches per step"}
 
 
+def self_launch(n):
+    """One torch.distributed.run child with n ranks on 127.0.0.1; returns its exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL needs it on this driver
+    return subprocess.call(cmd, env=env)
+
+
+def rccl_debug_file():
+    """Asks RCCL for its init / graph log in a per-process file (unless the caller configured NCCL_DEBUG already), so
+    that the JSON line can carry what the library itself reports: ranks of the communicator, channels, rings / trees."""
+    if "NCCL_DEBUG" in os.environ:
+        return os.environ.get("NCCL_DEBUG_FILE")
+    import tempfile
+    path = os.path.join(tempfile.gettempdir(), "dsf_rccl_%d.log" % os.getpid())
+    os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH", NCCL_DEBUG_FILE=path)
+    return path
+
+
+def rccl_summary(path):
+    """Counts of the lines RCCL wrote about this rank's communicator (best effort: the wording is RCCL's)."""
+    import re
+    out = {"log": None}
+    try:
+        txt = open(path).read() if path else ""
+    except OSError:
+        return out
+    lines = txt.splitlines()
+    out["log"] = {"lines": len(lines),
+                  "ring_lines": sum(1 for l in lines if re.search(r"\bRing \d+", l)),
+                  "tree_lines": sum(1 for l in lines if re.search(r"\bTrees? ", l)),
+                  "channels": max([int(m.group(1)) for l in lines for m in [re.search(r"(\d+) coll channels", l)] if m] or [0]),
+                  "nranks_reported": sorted({int(m.group(1)) for l in lines for m in [re.search(r"nranks (\d+)", l)] if m}),
+                  "version": next((l.split("version", 1)[1].strip() for l in lines if "NCCL version" in l or "RCCL version" in l), None)}
+    return out
+
+
+def distributed_facts(world, dev, rccl_log):
+    """What the process group itself reports (all ranks call this): backend, observed world size, one row per rank
+    (host pid, device index, device name, PCI bus id) and an all-reduce of ones as a live check that the collective
+    spans that many ranks."""
+    if world == 1:
+        return {"backend": None, "world_size_observed": 1}
+    props = torch.cuda.get_device_properties(dev)
+    mine = {"rank": dist.get_rank(), "pid": os.getpid(), "device": dev.index, "name": props.name,
+            "pci_bus_id": getattr(props, "pci_bus_id", None)}
+    rows = [None] * world
+    dist.all_gather_object(rows, mine)
+    ones = torch.ones(1, device=dev)
+    dist.all_reduce(ones)
+    facts = {"backend": dist.get_backend(), "world_size_observed": dist.get_world_size(), "allreduce_of_ones": float(ones.item()),
+             "distinct_devices": len({(r["device"], r["pci_bus_id"]) for r in rows}), "ranks": rows}
+    if dist.get_backend() == "nccl":
+        try:
+            facts["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            pass
+        facts.update(rccl_summary(rccl_log))
+    return facts
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -207,9 +275,20 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=60)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (one per GPU) before this
+        # process has made any GPU call, relay rank 0's JSON line (the children inherit stdout) and exit with their code.
+        # Never re-exec: a process that has initialised the GPU must not be replaced on this pool.
+        sys.exit(self_launch(args.gpus))
+
     from dsf_amd.parallel import init_distributed, GradAllReducer
+    rccl_log = rccl_debug_file() if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None
     rank, local, world = init_distributed()
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %d rank(s); launch with torch.distributed.run "
+                         "--nproc-per-node %d (or run `python bench.py --gpus %d` bare: it launches itself)\n"
+                         % (args.gpus, world, args.gpus, args.gpus))
+        sys.exit(2)
     local = local % max(torch.cuda.device_count(), 1)          # (ranks may share a device in single-GPU flow tests)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -246,6 +325,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     loss_val = float(loss)
+    facts = distributed_facts(world, dev, rccl_log)
 
     if rank == 0:
         images = args.batch * world * args.steps
@@ -261,6 +341,7 @@ def main():
                        "global_batch": args.batch * world, "crop": 128, "raster": 640, "parallelism": "dp%d" % world,
                        "mano_asset": "synthetic MANO-shaped hand (real MANO_RIGHT.pkl is license-gated)"},
             "final_loss": round(loss_val, 5),
+            "distributed": facts,
         }
         out["roofline"], out["conv_kernels"] = conv_kernel_roofline(step, tgt)
         out["roofline_raster"] = crop_kernel_roofline(render, args.batch)

@@ -154,8 +154,10 @@ def test_x6_matches_float64_as_closely_as_the_fp32_mfma(Ci, Co, K, s, p, H, B, m
 
 
 def test_x6_weight_images_follow_the_weights(monkeypatch):
-    """The split image is cached on the parameter: in-place torch updates (version counter) and FusedAdamW's raw-pointer
-    updates (nn_conv.weights_changed) must both invalidate it; an unchanged weight must not be split again."""
+    """The split image of a weight is kept from one use to the next only for MANAGED parameters (FusedAdamW's, EvalStep's):
+    in-place torch updates (version counter) and FusedAdamW's raw-pointer updates (nn_conv.weights_changed) both invalidate
+    it, an unchanged managed weight is not split again.  An unmanaged parameter is re-split at every use, so a write
+    through ``.data`` -- invisible to torch's version counter -- can never be served from a stale image."""
     from dsf_amd import nn_conv
     from dsf_amd.optim import FusedAdamW
     monkeypatch.setattr(nn_conv, "MATH", "x6")            # (the suite also runs under DSF_CONV_MATH=f32)
@@ -163,16 +165,32 @@ def test_x6_weight_images_follow_the_weights(monkeypatch):
     conv = nn_conv.Conv2d(32, 48, 3, padding=1, bias=False).cuda()
     x = torch.randn(2, 32, 12, 12, device="cuda")
     ref = lambda: F.conv2d(x.double(), conv.weight.detach().double(), padding=1)
+    # unmanaged: forward, write through .data, forward must change
     y0 = conv(x)
-    img = conv.weight.__dict__["_dsf_x6"][0][1]
+    v0 = conv.weight._version
+    conv.weight.data.mul_(2.0)
+    assert conv.weight._version == v0                       # torch did not see the write ...
+    y1 = conv(x)
+    assert _rel(y1.double(), 2.0 * y0.double()) < 1e-6 and _rel(y1.double(), ref()) < 2e-6      # ... the layer did
+    # init_weights-style re-initialisation after a forward
+    with torch.no_grad():
+        conv.weight.normal_(0, 0.1)
+    assert _rel(conv(x).double(), ref()) < 2e-6
+    # managed: cached until announced
+    opt = FusedAdamW(conv.parameters(), lr=0.1)
+    assert conv.weight.__dict__["_dsf_managed"]
+    y0 = conv(x)
+    img = conv.weight.__dict__["_dsf_x6"][0]
     conv(x)
-    assert conv.weight.__dict__["_dsf_x6"][0][1] is img and _rel(y0.double(), ref()) < 2e-6
+    assert conv.weight.__dict__["_dsf_x6"][0] is img and _rel(y0.double(), ref()) < 2e-6     # same cache entry: no re-split
     with torch.no_grad():
         conv.weight.mul_(-2.0)
     assert _rel(conv(x).double(), ref()) < 2e-6
-    opt = FusedAdamW(conv.parameters(), lr=0.1)
     conv(x).square().mean().backward()
     opt.step()
+    assert _rel(conv(x).double(), ref()) < 2e-6
+    conv.weight.data.mul_(0.5)
+    nn_conv.weights_changed()                               # the documented way to announce a .data write on managed weights
     assert _rel(conv(x).double(), ref()) < 2e-6
 
 

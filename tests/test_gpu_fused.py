@@ -116,6 +116,48 @@ def test_fused_adamw_matches_torch_adamw():
         assert float(sa["state"][k]["step"]) == float(sb["state"][k]["step"]) == 5.0
 
 
+def test_fused_adamw_keeps_a_step_count_per_parameter():
+    """A parameter that sits out a step (grad None under zero_grad(set_to_none=True)) keeps its own step count and bias
+    corrections, as torch.optim.AdamW does: A and B at step 1, only A at step 2, both at step 3."""
+    from dsf_amd.optim import FusedAdamW
+    torch.manual_seed(5)
+    pa = [torch.nn.Parameter(torch.randn(300, device="cuda")), torch.nn.Parameter(torch.randn(7, 9, device="cuda"))]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa, ob = FusedAdamW(pa, lr=1e-2, weight_decay=0.01), torch.optim.AdamW(pb, lr=1e-2, weight_decay=0.01)
+    for it, active in enumerate([(0, 1), (0,), (0, 1), (1,), (0, 1)]):
+        for i in range(2):
+            g = torch.randn(pa[i].shape, device="cuda") if i in active else None
+            pa[i].grad = None if g is None else g.clone()
+            pb[i].grad = None if g is None else g.clone()
+        oa.step(); ob.step()
+        for a, b in zip(pa, pb):
+            assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), (it, float((a - b).abs().max()))
+    sa, sb = oa.state_dict(), ob.state_dict()
+    assert [float(sa["state"][k]["step"]) for k in (0, 1)] == [float(sb["state"][k]["step"]) for k in (0, 1)] == [4.0, 4.0]
+
+
+def test_mano_memo_sees_raw_pointer_writes():
+    """The MANO result memo is keyed on the parameter rows' version AND the global write epoch: a leaf row block fitted
+    directly with FusedAdamW (whose kernel writes behind torch's version counter) must not be served the previous step's
+    vertices."""
+    from dsf_amd.render_model.mano_layer import Render
+    from dsf_amd.optim import FusedAdamW
+    from dsf_amd.train_step import synthetic_batch
+    render = Render("synthetic", "nyu", (588.03, 587.07, 320.0, 240.0), (640, 480)).cuda()
+    p, _, _ = synthetic_batch(3, "cuda", seed=2)
+    rows = torch.nn.Parameter(p.clone())
+    opt = FusedAdamW([rows], lr=0.05, weight_decay=0.0)
+    j0, v0 = render.get_mesh_xyz(rows)
+    (v0.square().sum() + j0.square().sum()).backward()
+    ver = rows._version
+    opt.step()
+    assert rows._version == ver                              # torch did not see the write
+    j1, v1 = render.get_mesh_xyz(rows)
+    fresh = render.mano_layer.get_mano_vertices(rows[:, :3], rows[:, 3:48], rows[:, 48:58], rows[:, 58:62], 1 / 125)[0]
+    assert torch.equal(v1, fresh) and not torch.equal(v1, v0)
+    (v1.square().sum()).backward()                           # and its graph is alive
+
+
 def test_mano_packed_rows_equal_sliced_call():
     from dsf_amd.render_model.mano_layer import Render
     from dsf_amd.train_step import synthetic_batch

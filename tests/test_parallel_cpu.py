@@ -101,3 +101,57 @@ def test_single_process_reducer_is_a_noop():
     net(torch.randn(2, 1, 16, 16)).sum().backward()
     sync.finish()
     assert all(p.grad is not None for p in net.parameters())
+
+
+def test_bench_refuses_a_rank_count_other_than_gpus():
+    """`bench.py --gpus 2` inside a 1-rank launch must fail (exit 2), not measure one GPU and label it n_gpus 1."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "--gpus 2" in r.stderr and r.stdout.strip() == ""
+
+
+def test_bench_launches_its_own_ranks(monkeypatch):
+    """Bare `python bench.py --gpus 4` (no WORLD_SIZE): one torch.distributed.run child with 4 ranks on 127.0.0.1, started
+    before any GPU call, its exit code passed on."""
+    import importlib
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_rccl_log_summary_parses_what_it_can(tmp_path):
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    f = tmp_path / "rccl.log"
+    f.write_text("host:1:1 [0] NCCL INFO NCCL version 2.22.3+hip\n"
+                 "host:1:1 [0] NCCL INFO comm 0x1 rank 0 nranks 8 cudaDev 0 busId 5000 - Init START\n"
+                 "host:1:1 [0] NCCL INFO Ring 00 : 0 1 2 3 4 5 6 7\nhost:1:1 [0] NCCL INFO Ring 01 : 0 7 6 5 4 3 2 1\n"
+                 "host:1:1 [0] NCCL INFO Trees [0] 1/-1/-1->0->-1\n"
+                 "host:1:1 [0] NCCL INFO 16 coll channels, 16 collnet channels, 0 nvls channels, 16 p2p channels\n")
+    s = bench.rccl_summary(str(f))["log"]
+    assert s["ring_lines"] == 2 and s["tree_lines"] == 1 and s["channels"] == 16 and s["nranks_reported"] == [8]
+    assert bench.rccl_summary(str(tmp_path / "absent.log")) == {"log": None}
