@@ -144,7 +144,8 @@ class MeshLossStep:
         self.utils = TensorUtils(img_size=config.input_size)
 
     @torch.no_grad()
-    def make_targets(self, params_gt, center, cube, seed=1):
+    def make_targets(self, params_gt, center, cube, seed=1, keys=None):
+        """``keys``: the two (B, 128*128) int32 sampling-key images of Img2pcl as explicit inputs (else drawn from ``seed``)."""
         img, juvd, jxyz, mesh = self.render.render(params_gt, center, cube)
         _, M, _, _ = ops.crop_setup(center, cube, self.render.cam, 128)
         u = self.utils
@@ -152,7 +153,9 @@ class MeshLossStep:
         mano = self.render.mano_layer
         B = img.size(0)
         g = torch.Generator(device=img.device).manual_seed(seed)
-        keys = lambda: torch.randint(0, 2 ** 31 - 1, (B, 128 * 128), device=img.device, dtype=torch.int32, generator=g)
+        given = iter(keys) if keys is not None else None
+        keys = (lambda: next(given)) if given is not None else \
+            (lambda: torch.randint(0, 2 ** 31 - 1, (B, 128 * 128), device=img.device, dtype=torch.int32, generator=g))
         _, pts = u.crop_hand(crop, jxyz, center, M, cube, return_points=True)
         seg_img = mano.seg_pcl(jxyz, jxyz, mesh, pts)                                    # (:695)
         seg_img = torch.where(crop.lt(0.99).reshape(B, -1), seg_img, torch.zeros_like(seg_img)).reshape(B, 1, 128, 128)
@@ -179,6 +182,7 @@ class MeshLossStep:
 
     def __call__(self, tgt):
         self.opt.zero_grad(set_to_none=True)
+        self.render.mano_layer.clear_cache()                 # results of the previous step must not outlive its graph
         loss, terms = self.loss(tgt)
         loss.backward()
         if self.grad_sync is not None:
@@ -187,21 +191,43 @@ class MeshLossStep:
         return loss.detach(), terms
 
 
-class FinetuneStageStep:
-    """Counterpart of ``Trainer.FinetuneStage`` (train_render.py:622-823), the reference's default
-    self-boosting step (config.py:36-38): a synthetic supervised pass through the frozen transfer
-    generator + a real-image pass where the detached stage-2 outputs teach stage 1 and the geometry
-    terms (m2d, ICP, part-aware ICP, collision, P2M, M2P) close the self-supervised loop.
+def draw_augmentation(B, device, generator=None, host_rng=None, n_joints=21, crop=128, views=1, depth_range=(500, 1200),
+                      view_scale=1.0, mask=True):
+    """Every random draw one synthetic-branch pass consumes, as explicit tensors, in the order the reference
+    draws them: train_render.py:628-631 (shape N(0,3^2), centre U(+-20 mm), size U(0.8,1.2), view U(0,2pi)^3 * view_scale),
+    mano_layer.py:1007 (centre depth U(depth_range)), :1328-1334 (mask_img: 3..9 occluders drawn on the HOST -- numpy in
+    the reference, ``host_rng`` here, so no device sync --, their joints, uvd offsets U(+-0.15) and radii U(0,0.3)), plus
+    the two sampling-key images of ``Img2pcl`` (render_loader.py:1151-1154).  ``views`` > 1 draws for views*B renders."""
+    g = generator if generator is not None else torch.Generator(device=device)
+    rng = host_rng if host_rng is not None else np.random.default_rng()
+    n = B * views
+    rnd = lambda *s: torch.rand(*s, device=device, generator=g)
+    d = {"aug_shape": torch.randn(n, 10, device=device, generator=g) * 3,
+         "aug_center": (rnd(n, 3) - 0.5) * 40,
+         "aug_size": 1 + (rnd(n, 1) - 0.5) * 0.4,
+         "aug_view": rnd(n, 3) * math.pi * 2 * view_scale}
+    depth = rnd(n, 1) * (depth_range[1] - depth_range[0]) + depth_range[0]
+    d["center0"] = torch.cat((torch.zeros(n, 2, device=device), depth), dim=-1)
+    if mask:
+        k = int(rng.choice(np.arange(3, 10), 1)[0])                                   # mano_layer.py:1328 (min 3, max 10 exclusive)
+        jid = torch.as_tensor(rng.choice(np.arange(0, n_joints), k, replace=False).astype(np.int64))
+        d["mask_joint_id"] = jid.to(device)
+        d["mask_offset"] = (rnd(n, k, 3) - 0.5) * 0.15 * 2
+        d["mask_radius"] = rnd(n, k) * 0.3
+    keys = lambda: torch.randint(0, 2 ** 31 - 1, (B, crop * crop), device=device, dtype=torch.int32, generator=g)
+    d["keys_joint"], d["keys_pcl"] = keys(), keys()
+    return d
 
-    Differences from the reference, all forced by "no host sync inside the step":
-      * random draws are explicit (a ``torch.Generator`` per step instead of global RNG state);
-      * the M2P term (:784-801) selects rows with ``nonzero()`` + ``index_select`` and branches on
-        ``joint_mano_mask.sum() == 0`` on the host; here it is the algebraically identical masked mean
-        (same rows, same divisor, same "sum of selected indices == 0 -> 0" rule), evaluated on device;
-      * ``xyz2error`` / TensorBoard / colour LUT host round trips (:654-667, :703, :713-721) are dropped.
-    """
 
-    def __init__(self, net, render, transfer_net, config=Config, optimizer=None, grad_sync=None, mask=True):
+def draws_to(d, device):
+    return {k: v.to(device) for k, v in d.items()}
+
+
+class _StepBase:
+    """What the step classes share: Huber / GFM / loader utilities, AdamW as the reference builds it, the optional
+    gradient all-reducer, and the synthetic-branch pass of ``Pretrain`` / ``Finetune`` / ``FinetuneStage``."""
+
+    def __init__(self, net, render, transfer_net=None, config=Config, optimizer=None, grad_sync=None, mask=True):
         self.net, self.render, self.transfer, self.cfg, self.mask = net, render, transfer_net, config, mask
         self.L1 = SmoothL1Loss()
         self.gfm = GFM()
@@ -214,11 +240,41 @@ class FinetuneStageStep:
                 p.requires_grad_(False)
             transfer_net.eval()
 
-    def _keys(self, B, g, dev):
-        return torch.randint(0, 2 ** 31 - 1, (B, 128 * 128), device=dev, dtype=torch.int32, generator=g)
+    def draw(self, B, device, generator=None, host_rng=None, views=1, view_scale=1.0):
+        return draw_augmentation(B, device, generator, host_rng, views=views, depth_range=self.render.depth_range,
+                                 view_scale=view_scale, mask=self.mask)
+
+    @torch.no_grad()
+    def synth(self, model_para, cube, d):
+        """``RenderNet(model_para, None, cube, augment..., mask)`` + the frozen transfer generator
+        (train_render.py:428-435 / 502-509 / 633-639) -> dict of the 8-tuple + the transferred image."""
+        R = self.render
+        img, juvd, vuvd, jxyz, vxyz, center, cube_s, M = R(model_para, d["center0"], cube, augmentView=d["aug_view"],
+                                                          augmentShape=d["aug_shape"], augmentCenter=d["aug_center"],
+                                                          augmentSize=d["aug_size"], mask=False)
+        if self.mask and "mask_joint_id" in d:
+            img = R.mask_img(img, juvd, 0.15, 0.3, draws=(d["mask_joint_id"], d["mask_offset"], d["mask_radius"]))
+        img_t = self.transfer(img) if self.transfer is not None else img
+        return {"img": img, "img_t": img_t, "joint_uvd": juvd, "joint_xyz": jxyz, "mesh_xyz": vxyz, "center": center,
+                "cube": cube_s, "M": M}
+
+    def _real_targets(self, img_src, crop_r, jxyz_pix, jxyz_mano, mesh_mano, center_r, M_r, cube_r, d):
+        """Part labels and the two point clouds of the real image (train_render.py:561-575 / 693-701): ``img_src`` is the
+        image the part pixels are taken from (``img_r`` in Finetune :566, the crop in FinetuneStage :698)."""
+        u, mano_layer = self.utils, self.render.mano_layer
+        B = crop_r.size(0)
+        _, pts = u.crop_hand(crop_r, jxyz_mano, center_r, M_r, cube_r, return_points=True)       # uvdImg2xyzImg(crop) (:561 / :693)
+        seg_img = mano_layer.seg_pcl(jxyz_pix, jxyz_mano, mesh_mano, pts)
+        seg_img = torch.where(crop_r.lt(0.99).reshape(B, -1), seg_img, torch.zeros_like(seg_img)).reshape(B, 1, 128, 128)
+        joint_img = torch.where(seg_img.gt(0), img_src, torch.ones_like(img_src))
+        joint_pcl = u.Img2pcl(joint_img, 128, center_r, M_r, cube_r, 2048, rand_keys=d["keys_joint"])
+        segment = mano_layer.seg_pcl(jxyz_pix, jxyz_mano, mesh_mano, joint_pcl)
+        pcl = u.Img2pcl(crop_r, 128, center_r, M_r, cube_r, 2048, rand_keys=d["keys_pcl"])
+        return joint_pcl, segment, pcl, seg_img
 
     def _masked_huber(self, a, b, row_mask):
-        """L1Loss(index_select(a, rows), index_select(b, rows)) with the reference's empty rule (:796-801)."""
+        """L1Loss(index_select(a, rows), index_select(b, rows)) with the reference's empty rule (:600-603 / :798-801):
+        the host branch ``joint_mano_mask.sum() == 0`` tests the SUM OF THE SELECTED INDICES, evaluated here on device."""
         z = (a - b).float()
         az = z.abs()
         per_row = torch.where(az < 0.01, 0.5 * z * z, 0.01 * (az - 0.005)).mean(-1)          # (rows,)
@@ -228,33 +284,156 @@ class FinetuneStageStep:
         val = (per_row * m).sum() / torch.clamp(n, min=1.0)
         return torch.where(idx_sum == 0, torch.zeros_like(val), val)
 
-    def loss(self, model_para, cube, img_r, center_r, cube_r, M_r, generator=None):
+    def _m2p(self, juvd_pix, juvd_mano, mano_ok, pd2m_j):
+        """M2P selection (:590-603 / :787-801): samples whose render and ICP agree with the data teach the pixel branch,
+        joint by joint (part distance < 1e-3; wrist always; the five tips follow joints 2,5,8,11,14)."""
+        B = juvd_pix.size(0)
+        jm = pd2m_j.lt(1e-3)
+        jm = torch.cat((torch.ones(B, 1, device=jm.device, dtype=torch.bool), jm, jm[:, [2, 5, 8, 11, 14]]), dim=-1)
+        rows = (mano_ok.unsqueeze(-1) & jm).detach().reshape(-1)
+        return self._masked_huber(juvd_pix.reshape(-1, 3), juvd_mano.detach().reshape(-1, 3), rows) * self.cfg.coord_weight
+
+    def _optimise(self, loss):
+        from . import nn_conv
+        if not hasattr(self, "_pool_floats"):
+            self._pool_floats = nn_conv.weight_grad_floats(self.net) + 64
+            self._pool_dev = next(self.net.parameters()).device
+        with nn_conv.grad_pool(self._pool_floats if self._pool_dev.type == "cuda" else 0, self._pool_dev):
+            loss.backward()
+        if self.grad_sync is not None:
+            self.grad_sync.finish()
+        self.opt.step()
+
+    def _begin(self):
+        self.opt.zero_grad(set_to_none=True)
+        self.render.mano_layer.clear_cache()                 # results of the previous step must not outlive its graph
+
+
+class PretrainStep(_StepBase):
+    """Counterpart of ``Trainer.Pretrain`` (train_render.py:415-488): B synthetic hands rendered through ``Render.forward``
+    with shape / centre / size augmentation and random occluders, the frozen transfer generator, then per stage the
+    pixel-branch and MANO-branch supervised losses.  ``views`` > 1 is BASELINE config 4: every sample is rendered from
+    ``views`` random ``augmentView`` rotations (views*B meshes through the rasteriser and the backbone); the reference's
+    own Pretrain multiplies its view draw by 0 (:424), ``view_scale=0`` reproduces that."""
+
+    def __init__(self, net, render, transfer_net=None, config=Config, optimizer=None, grad_sync=None, mask=True, views=1,
+                 view_scale=None):
+        super().__init__(net, render, transfer_net, config, optimizer, grad_sync, mask)
+        self.views = views
+        self.view_scale = (0.0 if views == 1 else 1.0) if view_scale is None else view_scale
+
+    def draw(self, B, device, generator=None, host_rng=None):
+        return super().draw(B, device, generator, host_rng, views=self.views, view_scale=self.view_scale)
+
+    def loss(self, model_para, cube, draws=None):
+        cfg, R, L1, gfm = self.cfg, self.render, self.L1, self.gfm
+        d = draws if draws is not None else self.draw(model_para.size(0), model_para.device)
+        if self.views > 1:
+            model_para = model_para.repeat_interleave(self.views, dim=0)
+            cube = cube.repeat_interleave(self.views, dim=0)
+        s = self.synth(model_para, cube, d)
+        img = s["img"]
+        outputs = self.net(s["img_t"], R, s["center"], s["cube"])
+        terms = {}
+        for i, (pixel_pd, mano_pd) in enumerate(outputs):
+            S = pixel_pd.size(-1)
+            pixel_gt = gfm.joint2feature(s["joint_uvd"], img, cfg.feature_para, S, cfg.feature_type)
+            juvd_pd = gfm.feature2joint(img, pixel_pd, cfg.feature_type, cfg.feature_para)
+            terms["pix%d" % i] = L1(pixel_pd, pixel_gt, weight=cfg.deconv_weight)
+            terms["coord%d" % i] = L1(juvd_pd, s["joint_uvd"], weight=cfg.coord_weight)
+            jxyz_pd, mesh_pd = R.get_mesh_xyz(mano_pd)
+            terms["joint%d" % i] = L1(jxyz_pd, s["joint_xyz"], weight=cfg.coord_weight)
+            terms["vert%d" % i] = L1(mesh_pd, s["mesh_xyz"], weight=cfg.coord_weight)
+            terms["beta%d" % i] = torch.mean(torch.pow(mano_pd[:, 48:58], 2)) * (cfg.coord_weight * 10)
+            terms["scale%d" % i] = torch.mean(torch.abs(torch.clamp(mano_pd[:, 58], max=0.0))) * 0.1
+        return torch.stack(list(terms.values())).sum(), terms
+
+    def __call__(self, model_para, cube, draws=None):
+        self._begin()
+        loss, terms = self.loss(model_para, cube, draws)
+        self._optimise(loss)
+        return loss.detach(), terms
+
+
+class FinetuneStep(_StepBase):
+    """Counterpart of ``Trainer.Finetune`` (train_render.py:490-620), the single-stage self-supervised step: a synthetic
+    supervised pass (stage-1 outputs only) + a real-image pass whose MANO branch is fitted to the data by the model-to-data
+    depth term, ICP and part-aware ICP, tied to the pixel branch by P2M / M2P, with the collision prior."""
+
+    def loss(self, model_para, cube, img_r, center_r, cube_r, M_r, draws=None):
+        cfg, R, u, gfm, L1 = self.cfg, self.render, self.utils, self.gfm, self.L1
+        mano_layer = R.mano_layer
+        B = img_r.size(0)
+        d = draws if draws is not None else self.draw(model_para.size(0), model_para.device)
+        # ---- synthetic image (:496-527): stage-1 outputs only ----
+        s = self.synth(model_para, cube, d)
+        img = s["img"]
+        pixel_pd, mano_pd = self.net(s["img_t"], R, s["center"], s["cube"])[0]
+        pixel_gt = gfm.joint2feature(s["joint_uvd"], img, cfg.feature_para, pixel_pd.size(-1), cfg.feature_type)
+        juvd_pd = gfm.feature2joint(img, pixel_pd, cfg.feature_type, cfg.feature_para)
+        total = L1(pixel_pd[:, :pixel_gt.size(1)], pixel_gt) * cfg.deconv_weight + L1(juvd_pd, s["joint_uvd"]) * cfg.coord_weight
+        jx, mx = R.get_mesh_xyz(mano_pd)
+        total = total + L1(mx, s["mesh_xyz"]) * cfg.coord_weight + L1(jx, s["joint_xyz"]) * cfg.coord_weight \
+            + mano_layer.calculate_coll(jx, mx.detach()) * cfg.coll_weight
+        # ---- real image (:530-610) ----
+        pixel_r, mano_r = self.net(img_r, R, center_r, cube_r)[0]
+        juvd_r = gfm.feature2joint(img_r, pixel_r, cfg.feature_type, cfg.feature_para)
+        jxyz_r = u.uvd_nl2xyznl_tensor(juvd_r, center_r, M_r, cube_r)
+        img_m, mjuvd, mjxyz, mesh = R.render(mano_r, center_r, cube_r)
+        coll = mano_layer.calculate_coll(mjxyz, mesh.detach())
+        crop_r = u.crop_hand(img_r, mjxyz.detach(), center_r, M_r, cube_r)                     # (:554)
+        crop_m = u.crop_hand(img_m, mjxyz.detach(), center_r, M_r, cube_r)
+        union = (crop_r.lt(0.99) | crop_m.lt(0.99)).float()
+        m2d = (torch.abs(crop_r - crop_m).mean(-1).mean(-1) / (union.mean(-1).mean(-1) + 1e-8)).mean()      # (:556-558)
+        with torch.no_grad():
+            joint_pcl, segment, pcl, _ = self._real_targets(img_r, crop_r, jxyz_r, mjxyz, mesh, center_r, M_r, cube_r, d)
+        pd2m_j = JointICPLoss(mesh, joint_pcl, mano_layer.joint_faces, segment)               # (:570-572)
+        d2m_b = ICPLoss(mesh, pcl, mano_layer.faces)                                           # (:576-577)
+        p2m = L1(mjuvd, juvd_r.detach()) * cfg.coord_weight                                    # (:583)
+        both = (crop_r.lt(0.95) & img_m.lt(0.95)).float()                                      # (:586-589): the UNcropped render
+        depth_b = (torch.abs(crop_r - img_m) * both).sum(-1).sum(-1) / both.sum(-1).sum(-1)   # 0/0 = NaN fails lt(): as the reference
+        mano_ok = depth_b.lt(0.04).squeeze(-1) & d2m_b.lt(1e-3)
+        m2p = self._m2p(juvd_r, mjuvd, mano_ok, pd2m_j)
+        terms = {"m2d": m2d, "pd2m": pd2m_j.mean(-1).mean(-1), "P2M": p2m, "coll": coll, "M2P": m2p, "d2m": d2m_b.mean(-1)}
+        total = total + p2m + m2d * 0.1 * cfg.model_weight + terms["d2m"] * cfg.model_weight + terms["pd2m"] * cfg.partICP_weight \
+            + m2p * cfg.M2P_weight + coll * cfg.coll_weight
+        return total, terms
+
+    def __call__(self, model_para, cube, img_r, center_r, cube_r, M_r, draws=None):
+        self._begin()
+        loss, terms = self.loss(model_para, cube, img_r, center_r, cube_r, M_r, draws)
+        self._optimise(loss)
+        return loss.detach(), terms
+
+
+class FinetuneStageStep(_StepBase):
+    """Counterpart of ``Trainer.FinetuneStage`` (train_render.py:622-823), the reference's default
+    self-boosting step (config.py:36-38): a synthetic supervised pass through the frozen transfer
+    generator + a real-image pass where the detached stage-2 outputs teach stage 1 and the geometry
+    terms (m2d, ICP, part-aware ICP, collision, P2M, M2P) close the self-supervised loop.
+
+    Differences from the reference, all forced by "no host sync inside the step":
+      * random draws are explicit (``draw()`` / ``draws=``; the occluder COUNT 3..9 and the occluded joints come from a host
+        RNG exactly as in the reference, which uses numpy there -- no device value is read);
+      * the M2P term (:784-801) selects rows with ``nonzero()`` + ``index_select`` and branches on
+        ``joint_mano_mask.sum() == 0`` on the host; here it is the algebraically identical masked mean
+        (same rows, same divisor, same "sum of selected indices == 0 -> 0" rule), evaluated on device;
+      * ``xyz2error`` / TensorBoard / colour LUT host round trips (:654-667, :703, :713-721) are dropped.
+    """
+
+    def __init__(self, net, render, transfer_net, config=Config, optimizer=None, grad_sync=None, mask=True):
+        super().__init__(net, render, transfer_net, config, optimizer, grad_sync, mask)
+
+    def loss(self, model_para, cube, img_r, center_r, cube_r, M_r, generator=None, draws=None):
         cfg, R, u, gfm, L1 = self.cfg, self.render, self.utils, self.gfm, self.L1
         mano_layer = R.mano_layer
         dev = model_para.device
-        B = model_para.size(0)
-        g = generator if generator is not None else torch.Generator(device=dev)
-        rnd = lambda *s: torch.rand(*s, device=dev, generator=g)
+        B = img_r.size(0)
+        d = draws if draws is not None else self.draw(model_para.size(0), dev, generator)
         # ---- synthetic branch (:628-667) ----
-        aug_shape = torch.randn(B, 10, device=dev, generator=g) * 3
-        aug_center = (rnd(B, 3) - 0.5) * 40
-        aug_size = 1 + (rnd(B, 1) - 0.5) * 0.4
-        aug_view = rnd(B, 3) * math.pi * 2
-        depth = rnd(B, 1) * (R.depth_range[1] - R.depth_range[0]) + R.depth_range[0]
-        center0 = torch.cat((torch.zeros(B, 2, device=dev), depth), dim=-1)
-        with torch.no_grad():
-            draws = None
-            if self.mask:
-                k = 6                                   # reference: 3..9 occluders drawn on the host (:1328); fixed count keeps the step sync-free
-                jid = torch.randperm(21, device=dev, generator=g)[:k]
-                draws = (jid, (rnd(B, k, 3) - 0.5) * 0.15 * 2, rnd(B, k) * 0.3)
-            img, juvd_gt, _, jxyz_gt, mesh_gt, center_s, cube_s, M_s = R(model_para, center0, cube, augmentView=aug_view,
-                                                                        augmentShape=aug_shape, augmentCenter=aug_center,
-                                                                        augmentSize=aug_size, mask=False)
-            if draws is not None:
-                img = R.mask_img(img, juvd_gt, 0.15, 0.3, draws=draws)
-            img_t = self.transfer(img) if self.transfer is not None else img
-        outputs = self.net(img_t, R, center=center_s, cube=cube_s)
+        s = self.synth(model_para, cube, d)
+        img, juvd_gt, jxyz_gt, mesh_gt = s["img"], s["joint_uvd"], s["joint_xyz"], s["mesh_xyz"]
+        outputs = self.net(s["img_t"], R, center=s["center"], cube=s["cube"])
         total = 0
         for pixel_pd, mano_pd in outputs:
             S = pixel_pd.size(-1)
@@ -271,14 +450,8 @@ class FinetuneStageStep:
             juvd_t = gfm.feature2joint(img_r, pix_t, cfg.feature_type, cfg.feature_para)
             jxyz_t = u.uvd_nl2xyznl_tensor(juvd_t, center_r, M_r, cube_r)
             mj_t, mm_t = R.get_mesh_xyz(mano_t)
-            crop_r, pts = u.crop_hand(img_r, mj_t, center_r, M_r, cube_r, return_points=True)
-            _, pts = u.crop_hand(crop_r, mj_t, center_r, M_r, cube_r, return_points=True)
-            seg_img = mano_layer.seg_pcl(jxyz_t, mj_t, mm_t, pts)
-            seg_img = torch.where(crop_r.lt(0.99).reshape(B, -1), seg_img, torch.zeros_like(seg_img)).reshape(B, 1, 128, 128)
-            joint_img = torch.where(seg_img.gt(0), crop_r, torch.ones_like(img_r))
-            joint_pcl = u.Img2pcl(joint_img, 128, center_r, M_r, cube_r, 2048, rand_keys=self._keys(B, g, dev))
-            segment = mano_layer.seg_pcl(jxyz_t, mj_t, mm_t, joint_pcl)
-            pcl = u.Img2pcl(crop_r, 128, center_r, M_r, cube_r, 2048, rand_keys=self._keys(B, g, dev))
+            crop_r = u.crop_hand(img_r, mj_t, center_r, M_r, cube_r)
+            joint_pcl, segment, pcl, _ = self._real_targets(crop_r, crop_r, jxyz_t, mj_t, mm_t, center_r, M_r, cube_r, d)
         # ---- stage 1 student (:706-749) ----
         pix1, mano1 = outputs[0]
         juvd1 = gfm.feature2joint(img_r, pix1, cfg.feature_type, cfg.feature_para)
@@ -304,20 +477,14 @@ class FinetuneStageStep:
         both = (crop_r.lt(0.99) & crop2.lt(0.99)).float()
         depth_b = ((crop_r - crop2).abs() * both).sum(-1).sum(-1) / (union.sum(-1).sum(-1) + 1e-8)
         mano_ok = depth_b.lt(0.04).squeeze(-1) & d2m_b.lt(1e-3)                              # (:787-789)
-        jm = pd2m_j.lt(1e-3)
-        jm = torch.cat((torch.ones(B, 1, device=dev, dtype=torch.bool), jm, jm[:, [2, 5, 8, 11, 14]]), dim=-1)
-        rows = (mano_ok.unsqueeze(-1) & jm).detach().reshape(-1)
-        m2p = self._masked_huber(juvd2.reshape(-1, 3), mjuvd2.detach().reshape(-1, 3), rows) * cfg.coord_weight
+        m2p = self._m2p(juvd2, mjuvd2, mano_ok, pd2m_j)
         total = total + p2m + coll2 * cfg.coll_weight + m2d2 * cfg.model_weight + d2m_b.mean(-1) * cfg.model_weight \
             + pd2m_j.mean(-1).mean(-1) * cfg.partICP_weight + m2p * cfg.M2P_weight
         terms = {"P2M": p2m, "m2d": m2d2, "d2m": d2m_b.mean(-1), "pd2m": pd2m_j.mean(-1).mean(-1), "M2P": m2p, "coll": coll2}
         return total, terms
 
-    def __call__(self, model_para, cube, img_r, center_r, cube_r, M_r, generator=None):
-        self.opt.zero_grad(set_to_none=True)
-        loss, terms = self.loss(model_para, cube, img_r, center_r, cube_r, M_r, generator)
-        loss.backward()
-        if self.grad_sync is not None:
-            self.grad_sync.finish()
-        self.opt.step()
+    def __call__(self, model_para, cube, img_r, center_r, cube_r, M_r, generator=None, draws=None):
+        self._begin()
+        loss, terms = self.loss(model_para, cube, img_r, center_r, cube_r, M_r, generator, draws)
+        self._optimise(loss)
         return loss.detach(), terms

@@ -162,8 +162,8 @@ def depth_image_to_xyz(img, center, Minv, cube, cam=CAM_NYU):
     return back(a), back(b)
 
 
-def crop_hand(img, joints_nl, center, Minv, cube, cam=CAM_NYU, offsetxy=25.0, offsetz=20.0, thick=20.0):
-    """crop_hand (render_loader.py:1209-1227)."""
+def crop_hand_keep(img, joints_nl, center, Minv, cube, cam=CAM_NYU, offsetxy=25.0, offsetz=20.0, thick=20.0):
+    """Pixel mask of crop_hand (render_loader.py:1209-1226): inside the joints' bounding box grown by the offsets."""
     img = np.asarray(img, dtype=F)
     sk = np.asarray(joints_nl, dtype=F) * np.asarray(cube, dtype=F)[:, None, :] / F(2) + np.asarray(center, dtype=F)[:, None, :]
     lo = sk.min(1)
@@ -175,7 +175,14 @@ def crop_hand(img, joints_nl, center, Minv, cube, cam=CAM_NYU, offsetxy=25.0, of
     keep = np.ones(img[:, 0].shape, dtype=bool)
     for a in range(3):
         keep &= (xyz[:, a] > lo[:, a, None, None]) & (xyz[:, a] < hi[:, a, None, None])
-    return np.where(keep[:, None], img, F(1.0)).astype(F)
+    return keep[:, None]
+
+
+def crop_hand(img, joints_nl, center, Minv, cube, cam=CAM_NYU, offsetxy=25.0, offsetz=20.0, thick=20.0):
+    """crop_hand (render_loader.py:1209-1227)."""
+    img = np.asarray(img, dtype=F)
+    keep = crop_hand_keep(img, joints_nl, center, Minv, cube, cam, offsetxy, offsetz, thick)
+    return np.where(keep, img, F(1.0)).astype(F)
 
 
 def image_to_points_candidates(img, center, Minv, cube, cam=CAM_NYU):
