@@ -50,6 +50,7 @@ SYMBOLS = [
     "dsf_conv_x6_image_bytes", "dsf_conv_x6_split_weights", "dsf_conv_x6_image_granules",
     "dsf_conv_x6_split_weights_multi", "dsf_conv_x6_forward", "dsf_conv_x6_wrw", "dsf_mfma_bf16_probe", "dsf_bn_forward", "dsf_bn_apply", "dsf_bn_backward", "dsf_bn_workspace_bytes", "dsf_col_sum", "dsf_col_sum_workspace_bytes",
     "dsf_huber_mean_forward", "dsf_huber_mean_backward", "dsf_adamw_multi", "dsf_adamw_chunk_elems",
+    "dsf_maxpool_forward", "dsf_maxpool_backward", "dsf_part_volume_workspace_bytes", "dsf_part_intersection_volume",
 ]
 
 
@@ -67,6 +68,7 @@ def lib():
         _lib.dsf_mfma_bf16_probe.restype = ctypes.c_int64
         _lib.dsf_conv_c1_workspace_bytes.restype = ctypes.c_int64
         _lib.dsf_conv_x6_image_granules.restype = ctypes.c_int64
+        _lib.dsf_part_volume_workspace_bytes.restype = ctypes.c_int64
         for s in SYMBOLS:
             getattr(_lib, s)
     return _lib

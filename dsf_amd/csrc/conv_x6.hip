@@ -353,6 +353,227 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// igemm_x6b_kernel: the same GEMM with the B operand (weight image) read STRAIGHT INTO THE MFMA FRAGMENT REGISTERS.
+//
+// Why: with both operands staged through LDS the 128 x 128 kernel moves, per 16-deep chunk and wave, 12 KB of fragment
+// reads for 24 MFMAs (768 matrix-pipe cycles); four waves per chunk plus the 24 KB of tile stores are 72 KB per 768
+// cycles = 94 of the CU's 128 LDS bytes per clock -- the kernel is LDS-bandwidth-bound at ~0.6 MFMA utilisation (measured
+// 0.587; rocprof SQ_VALU_MFMA_BUSY_CYCLES, profiles/r01_summary.txt).  The weight image is already laid out granule by
+// granule as the fragment of v_mfma_f32_32x32x16_bf16 (lane = n + 32 k-group, 8 consecutive k): lane l of a wave reads
+// granule (k-group l >> 5, n = 64 wn + 32 j + (l & 31)) of plane pl with ONE coalesced 16-byte buffer load -- no LDS round
+// trip, no conversion.  The image block of a (tap, chunk, n tile) is shared by every workgroup of the XCD that walks K in
+// step, so these loads hit L2.  LDS then carries the A tile only: 4 x 6 KB of reads + 12 KB of stores per chunk = 47
+// bytes per clock, and the B-side ds_write / ds_read instructions disappear from the issue stream.
+// Three register sets for the B fragments (loads run two chunks ahead, as the A loads do): the chunk loop is unrolled by
+// three, the A stage toggles at run time; a K range is padded with at most two all-zero chunks (out-of-range loads).
+// Tiles: BN 128: 128 x 128 (2 x 2 waves of 64 x 64) or 64 x 128 (2 x 2 waves of 32 x 64: the 8x8 .. 32x32 maps);
+//        BN 64:  256 x 64  (4 x 1 waves of 64 x 64): the 64-channel layers get the 64 x 64 wave tile too.
+// ------------------------------------------------------------------------------------------------
+template <int BN, bool DIL2, int BMT>
+__global__ __launch_bounds__(256, 2) void igemm_x6b_kernel(const float* __restrict__ X, const uint4* __restrict__ Wimg,
+                                                          const float* __restrict__ bias, float* __restrict__ Y, X6P p,
+                                                          int m_tiles, int n_tiles, int k_splits, uint32_t x_bytes,
+                                                          uint32_t w_bytes) {
+    static_assert((BN == 128 && (BMT == 128 || BMT == 64)) || (BN == 64 && BMT == 256), "tile shapes");
+    constexpr int WM = (BN == 128) ? BMT / 2 : 64;       // wave sub-tile WM x 64: 2 x 2 waves (BN 128) or 4 x 1 (BN 64)
+    constexpr int TM = WM / 32, TN = 2;
+    constexpr int APASS = BMT / 64;                      // float4 loads of the A tile per thread
+    using LA = LdsPlane<BMT>;
+    constexpr int B_GRANULES = 2 * BN;                   // per plane of one image block
+    __shared__ uint4 As[2][3 * LA::SIZE];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = (BN == 128) ? (wave >> 1) : wave, wn = (BN == 128) ? (wave & 1) : 0;
+    int tile = x6_xcd_contiguous(blockIdx.x, m_tiles * n_tiles * k_splits);
+    const int n_tile = tile % n_tiles; tile /= n_tiles;
+    const int m_tile = tile % m_tiles; const int ks = tile / m_tiles;
+    const int m0 = m_tile * BMT, n0 = n_tile * BN;
+    const int M = p.B * p.Ho * p.Wo;
+    const __amdgpu_buffer_rsrc_t xbuf = x6_buffer(X, x_bytes), wbuf = x6_buffer(Wimg, w_bytes);
+
+    const int Hq = p.Ho >> 1, Wq = p.Wo >> 1, Mc = p.B * Hq * Wq;           // DIL2: pixels per parity class
+    auto decode = [&](int m, int& b, int& oy, int& ox) {
+        if (DIL2) {
+            const int cls = m / Mc, r = m % Mc;
+            const int qx = r % Wq, q = r / Wq;
+            ox = qx * 2 + (cls & 1); oy = (q % Hq) * 2 + (cls >> 1); b = q / Hq;
+        } else {
+            ox = m % p.Wo; const int q = m / p.Wo; oy = q % p.Ho; b = q / p.Ho;
+        }
+    };
+    int tile_py = -1, tile_px = -1;                      // DIL2: the tile's parity class when it has just one
+    if (DIL2) {
+        const int c0 = m0 / Mc, c1 = min(m0 + BMT - 1, M - 1) / Mc;
+        if (c0 == c1) { tile_py = c0 >> 1; tile_px = c0 & 1; }
+    }
+    const int a_q = t & 3, a_k4 = a_q * 4, a_r = t >> 2;
+    int a_base[APASS], a_iy[APASS], a_ix[APASS];
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+        const int m = m0 + a_r + 64 * i;
+        const bool ok = m < M;
+        int b, oy, ox;
+        decode(ok ? m : 0, b, oy, ox);
+        if (DIL2) {
+            a_iy[i] = ok ? oy - p.pad_h : -0x40000000;
+            a_ix[i] = ox - p.pad_w;
+            a_base[i] = b * p.Hi;
+        } else {
+            a_iy[i] = ok ? oy * p.stride - p.pad_h : -0x40000000;
+            a_ix[i] = ox * p.stride - p.pad_w;
+            a_base[i] = ((b * p.Hi + oy * p.stride - p.pad_h) * p.Wi + a_ix[i]) * p.Ci + a_k4;
+        }
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int chunks_per_tap = (p.Ci + XBK - 1) / XBK;
+    const bool uniform = DIL2 && tile_py >= 0;
+    const int kh0 = uniform ? ((p.pad_h - tile_py) & 1) : 0, kw0 = uniform ? ((p.pad_w - tile_px) & 1) : 0;
+    const int kstep = uniform ? 2 : 1;
+    const int cnt_h = (p.KH - kh0 + kstep - 1) / kstep, cnt_w = (p.KW - kw0 + kstep - 1) / kstep;
+    const int n_chunks = cnt_h * cnt_w * chunks_per_tap;
+    const int per_split = (n_chunks + k_splits - 1) / k_splits;
+    const int chunk_lo = ks * per_split, chunk_hi = min(n_chunks, chunk_lo + per_split);
+    const int vH = (p.Hi - 1) * 2 + 1, vW = (p.Wi - 1) * 2 + 1;
+
+    u32x4 ra[2][APASS];
+    u32x4 rbf[2][3][TN];                                 // [set][plane][n block]: B fragments as loaded
+    // byte offset of this lane's granule inside a plane of an image block: (k-group, n)
+    const uint32_t b_lane = (uint32_t)((lane >> 5) * BN + wn * 64 + (lane & 31)) * 16u;
+    // wave-uniform walk states: `la` = the chunk whose A tile is being loaded (two ahead), `lb` = the chunk whose B fragments
+    // are being loaded (one ahead: they go straight to registers, there is no LDS stage to wait for)
+    struct Walk { int c0, kh, kw; };
+    auto advance = [&](Walk& w) {
+        w.c0 += XBK;
+        if (w.c0 >= p.Ci) {
+            w.c0 = 0; w.kw += kstep;
+            if (w.kw >= p.KW) { w.kw = kw0; w.kh += kstep; }
+        }
+    };
+    const int l_lt = chunk_lo / chunks_per_tap;
+    Walk la = {(chunk_lo % chunks_per_tap) * XBK, kh0 + kstep * (l_lt / cnt_w), kw0 + kstep * (l_lt % cnt_w)};
+    Walk lb = la;
+    auto load_a = [&](auto SET, int i, bool live) {
+        constexpr int S = decltype(SET)::value;
+        bool ok = live && la.c0 + a_k4 < p.Ci;
+        uint32_t off;
+        if (DIL2) {
+            const int vy = a_iy[i] + la.kh, vx = a_ix[i] + la.kw;
+            ok = ok && (unsigned)vy < (unsigned)vH && (unsigned)vx < (unsigned)vW && ((vy | vx) & 1) == 0;
+            off = (uint32_t)(((a_base[i] + (vy >> 1)) * p.Wi + (vx >> 1)) * p.Ci + la.c0 + a_k4);
+        } else {
+            ok = ok && (unsigned)(a_iy[i] + la.kh) < (unsigned)p.Hi && (unsigned)(a_ix[i] + la.kw) < (unsigned)p.Wi;
+            off = (uint32_t)(a_base[i] + (la.kh * p.Wi + la.kw) * p.Ci + la.c0);
+        }
+        ra[S][i] = x6_load16(xbuf, ok ? off * 4u : X_OOB);
+        if (i == APASS - 1) advance(la);
+    };
+    auto load_b = [&](auto SET, int f, bool live) {
+        constexpr int S = decltype(SET)::value;
+        const int pl = f / TN, j = f % TN;
+        const uint32_t dead = live ? 0u : X_OOB;                            // (offset | ~0) is the out-of-range offset: zeros
+        const int blk = (lb.kh * p.KW + lb.kw) * chunks_per_tap + (lb.c0 >> 4);
+        rbf[S][pl][j] = x6_load16(wbuf, ((uint32_t)(blk * n_tiles + n_tile) * (uint32_t)(3 * B_GRANULES * 16) +
+                                         (uint32_t)(pl * B_GRANULES * 16 + j * 32 * 16) + b_lane) | dead);
+        if (f == 3 * TN - 1) advance(lb);
+    };
+    auto stage_piece = [&](auto SET, int buf, int i) {
+        constexpr int S = decltype(SET)::value;
+        uint2 h, m, l;
+        split4(ra[S][i], h, m, l);
+        uint2* dst = reinterpret_cast<uint2*>(&As[buf][(a_q >> 1) * LA::KG + a_r + 64 * i]) + (a_q & 1);
+        dst[0] = h; dst[2 * LA::SIZE] = m; dst[4 * LA::SIZE] = l;
+    };
+
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, 1>;
+    if (chunk_lo < chunk_hi) {
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) load_a(Set0{}, i, true);
+#pragma unroll
+        for (int f = 0; f < 3 * TN; ++f) load_b(Set0{}, f, true);
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) load_a(Set1{}, i, chunk_lo + 1 < chunk_hi);
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) stage_piece(Set0{}, 0, i);
+    }
+    __syncthreads();
+
+    const int a_frag = (lane >> 5) * LA::KG + (lane & 31) + wm * WM;
+    // chunk c (parity SET): A fragments from LDS stage SET, B fragments = register set SET.  Handed out between its MFMAs:
+    // the B fragment loads of chunk c + 1 (into set OTHER, free since chunk c - 1 finished), the A loads of chunk c + 2
+    // (into ra[SET], whose contents went to LDS during chunk c - 1), then the LDS stores of chunk c + 1's A tile.
+    auto body = [&](auto SET, auto OTHER, int chunk) {
+        constexpr int buf = decltype(SET)::value;
+        const bool live1 = chunk + 1 < chunk_hi, live2 = chunk + 2 < chunk_hi;
+        bf16x8 a[3][TM];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[pl][i] = __builtin_bit_cast(bf16x8, As[buf][pl * LA::SIZE + a_frag + i * 32]);
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};
+        constexpr int NM = 6 * TM * TN;                                   // MFMAs of the chunk: 24 or 12
+        constexpr int NB = 3 * TN, NP = NB + 2 * APASS;                   // pieces: B loads, A loads, A stores
+        int slot = 0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][i], __builtin_bit_cast(bf16x8, rbf[buf][PB[q]][j]),
+                                                                        acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int pc = 0; pc < NP; ++pc) {
+                        // piece pc goes behind MFMA (pc * NM / NP): spread evenly over the chunk (constant after unrolling)
+                        if (slot == (pc * NM) / NP) {
+                            if (pc < NB) load_b(OTHER, pc, live1);
+                            else if (pc < NB + APASS) load_a(SET, pc - NB, live2);
+                            else stage_piece(OTHER, buf ^ 1, pc - NB - APASS);
+                        }
+                    }
+                    ++slot;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        __syncthreads();
+    };
+    for (int chunk = chunk_lo; chunk < chunk_hi; chunk += 2) {  // chunks come in pairs: one past chunk_hi is all zeros
+        body(Set0{}, Set1{}, chunk);
+        body(Set1{}, Set0{}, chunk + 1);
+    }
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (n >= p.Co) continue;
+            const float bv = (bias && ks == 0) ? bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= M) continue;
+                int64_t row = m;
+                if (DIL2) {
+                    int b, oy, ox;
+                    decode(m, b, oy, ox);
+                    row = ((int64_t)b * p.Ho + oy) * p.Wo + ox;
+                }
+                if (k_splits > 1) atomicAdd(Y + row * p.Co + n, acc[i][j][r] + bv);
+                else Y[row * p.Co + n] = acc[i][j][r] + bv;
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Backward-weights:  dW[(tap, ci)][co] += sum_{m in split} X[pixel(m) + tap][ci] * dY[m][co]
 // The reduction runs over pixels, so an MFMA lane needs 8 consecutive PIXELS of one channel, while HBM (and the loader's
 // float4) hold consecutive CHANNELS of one pixel.  Both tiles are therefore staged as loaded -- [pixel 16][channel 128]
@@ -600,9 +821,13 @@ int dsf_conv_x6_forward(const float* X, const void* image, const float* bias, fl
     DSF_CHECK_ARG(M < (1ll << 31) && x_bytes < 0xFFFFFFF0ll && w_bytes < 0xFFFFFFF0ll);
     const int bn = x6_bn(Co);
     const int n_tiles = (Co + bn - 1) / bn;
+    // DSF_X6_BDIRECT=0: the first-generation kernels (both operands through LDS); default: igemm_x6b_kernel (B operand straight
+    // from the L2-resident weight image into the MFMA fragment registers)
+    static const int bdirect = [] { const char* e = getenv("DSF_X6_BDIRECT"); return e ? atoi(e) : 1; }();
     // 64-row tiles when 128-row ones would leave most of the chip idle or force split-K (8x8 .. 32x32 maps)
     static const int bm_env = [] { const char* e = getenv("DSF_X6_BM"); return e ? atoi(e) : 0; }();             // tuning aid
-    const int bmt = (bn == 128 && (bm_env == 64 || (bm_env != 128 && ((M + 127) / 128) * n_tiles < 384))) ? 64 : 128;
+    int bmt = (bn == 128 && (bm_env == 64 || (bm_env != 128 && ((M + 127) / 128) * n_tiles < 384))) ? 64 : 128;
+    if (bdirect && bn == 64) bmt = 256;                                  // 4 x 1 waves of 64 x 64
     const int m_tiles = (int)((M + bmt - 1) / bmt);
     const int n_chunks = (KH * KW / (dil * dil)) * ((Ci + XBK - 1) / XBK);          // live chunks of a tile
     if (k_splits < 1) {
@@ -618,11 +843,16 @@ int dsf_conv_x6_forward(const float* X, const void* image, const float* bias, fl
     if (k_splits > 1 &&
         hipMemsetAsync(Y, 0, sizeof(float) * (size_t)M * Co, (hipStream_t)stream) != hipSuccess) return DSF_ERR_LAUNCH;
     const dim3 grid(m_tiles * n_tiles * k_splits);
-#define DSF_LAUNCH_X6(BNv, DILv, BMv) hipLaunchKernelGGL((igemm_x6_kernel<BNv, DILv, BMv>), grid, dim3(256), 0, (hipStream_t)stream, \
+#define DSF_LAUNCH_X6(KERNEL, BNv, DILv, BMv) hipLaunchKernelGGL((KERNEL<BNv, DILv, BMv>), grid, dim3(256), 0, (hipStream_t)stream, \
                                                        X, (const uint4*)image, bias, Y, p, m_tiles, n_tiles, k_splits,              \
                                                        (uint32_t)x_bytes, (uint32_t)w_bytes)
-    if (dil == 2) { if (bn == 64) DSF_LAUNCH_X6(64, true, 128); else if (bmt == 64) DSF_LAUNCH_X6(128, true, 64); else DSF_LAUNCH_X6(128, true, 128); }
-    else { if (bn == 64) DSF_LAUNCH_X6(64, false, 128); else if (bmt == 64) DSF_LAUNCH_X6(128, false, 64); else DSF_LAUNCH_X6(128, false, 128); }
+    if (bdirect) {
+        if (dil == 2) { if (bn == 64) DSF_LAUNCH_X6(igemm_x6b_kernel, 64, true, 256); else if (bmt == 64) DSF_LAUNCH_X6(igemm_x6b_kernel, 128, true, 64); else DSF_LAUNCH_X6(igemm_x6b_kernel, 128, true, 128); }
+        else { if (bn == 64) DSF_LAUNCH_X6(igemm_x6b_kernel, 64, false, 256); else if (bmt == 64) DSF_LAUNCH_X6(igemm_x6b_kernel, 128, false, 64); else DSF_LAUNCH_X6(igemm_x6b_kernel, 128, false, 128); }
+    } else {
+        if (dil == 2) { if (bn == 64) DSF_LAUNCH_X6(igemm_x6_kernel, 64, true, 128); else if (bmt == 64) DSF_LAUNCH_X6(igemm_x6_kernel, 128, true, 64); else DSF_LAUNCH_X6(igemm_x6_kernel, 128, true, 128); }
+        else { if (bn == 64) DSF_LAUNCH_X6(igemm_x6_kernel, 64, false, 128); else if (bmt == 64) DSF_LAUNCH_X6(igemm_x6_kernel, 128, false, 64); else DSF_LAUNCH_X6(igemm_x6_kernel, 128, false, 128); }
+    }
 #undef DSF_LAUNCH_X6
     return dsf_launch_status();
 }

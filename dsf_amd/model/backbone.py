@@ -34,6 +34,7 @@ class _Layers:
         self.fused_bn = bool(nn_conv.LAYERS["fused_bn"]) and os.environ.get("DSF_FUSED_BN", "1") == "1"
         self.Conv2d = nn_conv.LAYERS["Conv2d"]
         self.ConvTranspose2d = nn_conv.LAYERS["ConvTranspose2d"]
+        self.MaxPool2d = nn_conv.LAYERS["MaxPool2d"]
 
     def bn_relu(self, c, **kw):
         """[BatchNorm, ReLU] pair of an nn.Sequential: fused into one module (the ReLU slot becomes an
@@ -67,7 +68,7 @@ class _TwoBranchNet(nn.Module):
         L = self._L
         self.pre = nn.Sequential(L.Conv2d(1, 64, kernel_size=5, stride=1, padding=2, bias=False),
                                  *L.bn_relu(64, momentum=BN_MOMENTUM),
-                                 nn.MaxPool2d(kernel_size=3, stride=2, padding=1))
+                                 L.MaxPool2d(kernel_size=3, stride=2, padding=1))
 
     def _make_layer(self, block, planes, blocks, stride=1):
         down = None

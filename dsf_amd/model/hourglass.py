@@ -55,7 +55,7 @@ class Hourglass(nn.Module):
         super().__init__()
         nf = f + increase
         self.up1 = Residual(f, f)
-        self.pool1 = nn.MaxPool2d(2, 2)
+        self.pool1 = nn_conv.LAYERS["MaxPool2d"](2, 2)
         self.low1 = Residual(f, nf)
         self.n = n
         self.low2 = Hourglass(n - 1, nf, bn=bn) if n > 1 else Residual(nf, nf)
@@ -83,7 +83,7 @@ class PoseNet(nn.Module):
     def _build(self, nstack, joint_num, inp_dim, bn, increase):
         self.nstack = nstack
         self.joint_num = joint_num
-        self.pre = nn.Sequential(Conv(1, 64, 7, 2, bn=True, relu=True), Residual(64, 128), nn.MaxPool2d(2, 2),
+        self.pre = nn.Sequential(Conv(1, 64, 7, 2, bn=True, relu=True), Residual(64, 128), nn_conv.LAYERS["MaxPool2d"](2, 2),
                                  Residual(128, 256), Residual(256, inp_dim))
         self.hgs = nn.ModuleList([Hourglass(4, inp_dim, bn, increase) for _ in range(nstack)])
         self.features = nn.ModuleList([nn.Sequential(Residual(inp_dim, inp_dim), Conv(inp_dim, inp_dim, 1, bn=True, relu=True))

@@ -316,8 +316,27 @@ class Conv2dFunction(Function):
         return y
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, gy):
+        x, weight, wk = ctx.saved_tensors
+        stride, padding, has_bias = ctx.cfg
+        Co, Ci, KH, KW = weight.shape
+        if torch.is_grad_enabled():
+            # backward of the backward is wanted (create_graph=True: WGAN-GP's gradient penalty, reference
+            # render_model/transfer.py:356-391): express both gradients through differentiable Functions
+            gx = gw = gb = None
+            if ctx.needs_input_grad[0]:
+                op = (x.shape[2] - ((gy.shape[2] - 1) * stride - 2 * padding[0] + KH), x.shape[3] - ((gy.shape[3] - 1) * stride - 2 * padding[1] + KW))
+                gx = ConvTranspose2dFunction.apply(gy, weight, None, stride, padding, op)     # (Co -> Ci): the conv's weight IS its (in, out, kh, kw)
+            if ctx.needs_input_grad[1]:
+                gw = _WeightGradFunction.apply(x, gy, (KH, KW), stride, padding)
+            if has_bias and ctx.needs_input_grad[2]:
+                gb = gy.sum((0, 2, 3))
+            return gx, gw, gb, None, None
+        with torch.no_grad():
+            return Conv2dFunction._backward_fast(ctx, gy)
+
+    @staticmethod
+    def _backward_fast(ctx, gy):
         x, weight, wk = ctx.saved_tensors
         stride, padding, has_bias = ctx.cfg
         Co, Ci, KH, KW = weight.shape
@@ -346,6 +365,39 @@ class Conv2dFunction(Function):
         if has_bias and ctx.needs_input_grad[2]:
             gb = _bias_grad(gy)
         return gx, gw, gb, None, None
+
+
+class _WeightGradFunction(Function):
+    """dW (Co,Ci,KH,KW) of a convolution as a differentiable function of (x, gy): used only under create_graph=True.
+    Its own backward is two ordinary convolutions:  d/dx = conv_transpose(gy, ggW),  d/dgy = conv(x, ggW)."""
+
+    @staticmethod
+    def forward(ctx, x, gy, ksize, stride, padding):
+        x, gy = _nhwc(x), _nhwc(gy)
+        KH, KW = ksize
+        Ci = x.shape[1]
+        Co = gy.shape[1]
+        if _c1_ok(Ci, Co, KH, KW, stride, padding):
+            gw = _wrw_c1(x, gy, KH, stride, padding[0]).permute(3, 2, 0, 1)
+        else:
+            gw = _wrw(x, gy, KH, KW, stride, padding).permute(3, 2, 0, 1)
+        ctx.save_for_backward(x, gy)
+        ctx.cfg = (ksize, stride, padding)
+        return gw
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, ggw):
+        x, gy = ctx.saved_tensors
+        (KH, KW), stride, padding = ctx.cfg
+        gx = ggy = None
+        ggw = ggw.contiguous()
+        if ctx.needs_input_grad[0]:
+            op = (x.shape[2] - ((gy.shape[2] - 1) * stride - 2 * padding[0] + KH), x.shape[3] - ((gy.shape[3] - 1) * stride - 2 * padding[1] + KW))
+            gx = ConvTranspose2dFunction.apply(gy, ggw, None, stride, padding, op)
+        if ctx.needs_input_grad[1]:
+            ggy = Conv2dFunction.apply(x, ggw, None, stride, padding)
+        return gx, ggy, None, None, None
 
 
 class ConvTranspose2dFunction(Function):
@@ -419,7 +471,7 @@ class ConvTranspose2d(nn.ConvTranspose2d):
 
 
 # Layer registry the model builders construct from (model/backbone.py, model/hourglass.py, render_model/transfer.py).
-LAYERS = {"Conv2d": None, "ConvTranspose2d": None, "fused_bn": True}
+LAYERS = {"Conv2d": None, "ConvTranspose2d": None, "fused_bn": True, "MaxPool2d": None}
 
 
 def fused_heads(x, heads):
@@ -439,6 +491,8 @@ def fused_heads(x, heads):
 
 
 LAYERS["Conv2d"], LAYERS["ConvTranspose2d"] = Conv2d, ConvTranspose2d
+from .nn_pool import MaxPool2d as _HipMaxPool2d          # noqa: E402  (registry entry; oracle.nets swaps in nn.MaxPool2d)
+LAYERS["MaxPool2d"] = _HipMaxPool2d
 
 
 def replay(rec, iters=3):

@@ -166,8 +166,7 @@ class PixelDiscriminator(nn.Module):
 
 
 def define_D(input_nc, ndf, netD, n_layers_D=3, norm='batch', init_type='normal', init_gain=0.02, gpu_ids=[]):
-    """reference :240-284.  (WGAN-GP's gradient penalty needs double backward; the HIP convolutions are
-    once-differentiable, so ``cal_gradient_penalty`` is not provided.)"""
+    """reference :240-284."""
     norm_layer = _norm_layer(norm)
     if netD == 'basic':
         net = NLayerDiscriminator(input_nc, ndf, n_layers=3, norm_layer=norm_layer)
@@ -204,3 +203,31 @@ class GANLoss(nn.Module):
         if self.gan_mode in ('lsgan', 'vanilla'):
             return self.loss(prediction, self.get_target_tensor(prediction, target_is_real))
         return -prediction.mean() if target_is_real else prediction.mean()
+
+
+def cal_gradient_penalty(netD, real_data, fake_data, device, type='mixed', constant=1.0, lambda_gp=10.0, alpha=None):
+    """WGAN-GP gradient penalty (reference :356-391): ``(||d netD(x) / d x||_2 - constant)^2 * lambda_gp`` at real / fake /
+    mixed samples, built with ``create_graph=True`` -- the HIP convolutions provide the backward of their backward
+    (``nn_conv.Conv2dFunction.backward`` re-expresses itself through differentiable Functions when autograd asks).
+    ``alpha`` (B,1): the mixing draw of type 'mixed' as an explicit input; drawn here when None."""
+    if lambda_gp > 0.0:
+        if type == 'real':
+            interpolatesv = real_data
+        elif type == 'fake':
+            interpolatesv = fake_data
+        elif type == 'mixed':
+            if alpha is None:
+                alpha = torch.rand(real_data.shape[0], 1, device=device)
+            alpha = alpha.expand(real_data.shape[0], real_data.nelement() // real_data.shape[0]).contiguous().view(*real_data.shape)
+            interpolatesv = alpha * real_data + ((1 - alpha) * fake_data)
+        else:
+            raise NotImplementedError('{} not implemented'.format(type))
+        interpolatesv.requires_grad_(True)
+        disc_interpolates = netD(interpolatesv)
+        gradients = torch.autograd.grad(outputs=disc_interpolates, inputs=interpolatesv,
+                                        grad_outputs=torch.ones(disc_interpolates.size()).to(device),
+                                        create_graph=True, retain_graph=True, only_inputs=True)
+        gradients = gradients[0].reshape(real_data.size(0), -1)
+        gradient_penalty = (((gradients + 1e-16).norm(2, dim=1) - constant) ** 2).mean() * lambda_gp
+        return gradient_penalty, gradients
+    return 0.0, None

@@ -424,6 +424,39 @@ int dsf_adamw_multi(const uint64_t* ptrs, const int64_t* sizes, const int32_t* c
                     const int32_t* chunk_index, int n_chunks, double lr, double beta1, double beta2, double eps,
                     double weight_decay, double bias_correction1, double bias_correction2, dsf_stream_t stream);
 
+/* ----------------------------------------------------------------------------------
+ * NHWC max pooling (nn.MaxPool2d(kernel_size=3, stride=2, padding=1) of the backbone stem, reference
+ * model/backbone.py:200-204; nn.MaxPool2d(2, 2) of model/hourglass.py:131).  x (B,Hi,Wi,C) -> y (B,Ho,Wo,C), C % 4 == 0.
+ * argmax (B,Ho,Wo,C) uint8: window position kh * k + kw of the maximum (torch's rule: first maximum in scan order, NaN
+ * wins), consumed by the backward, which is a deterministic gather (no atomics, grad_x fully written).
+ * ---------------------------------------------------------------------------------- */
+int dsf_maxpool_forward(const float* x, float* y, uint8_t* argmax, int B, int Hi, int Wi, int C, int Ho, int Wo, int k,
+                        int stride, int pad, dsf_stream_t stream);
+int dsf_maxpool_backward(const float* grad_y, const uint8_t* argmax, float* grad_x, int B, int Hi, int Wi, int C, int Ho,
+                         int Wo, int k, int stride, int pad, dsf_stream_t stream);
+
+/* ----------------------------------------------------------------------------------
+ * Self-intersection volume of watertight hand parts: replaces trimesh's `voxelized(pitch)` +
+ * `contains(points)` inside the reference's `self_intersection` (/root/reference/eval_coll.py:611-626; also
+ * util/intersect.py:102-107) for a BATCH of meshes.
+ *   verts (B,V,3) f32: the vertex pool of every sample (the 779 MANO vertices + the cap vertices the reference
+ *       appends, eval_coll.py:348-366); faces (n_faces,3) int32 into that pool, the faces of part i being rows
+ *       [part_first[i], part_first[i+1]) (part_first has n_parts + 1 entries); pairs (n_pairs,2) int32 = the (s, t) part
+ *       pairs to evaluate (the reference: t > s, not parent / child); max_part_faces = the largest part's face count.
+ *   pitch: voxel size (the reference uses 2, then 1 for the colliding meshes); grid: cells per axis of a part's occupancy
+ *       mask, a multiple of 32 with (part extent / pitch) + 3 <= grid.
+ *   workspace: dsf_part_volume_workspace_bytes(B, n_parts, grid) bytes (16-byte aligned).
+ *   count (B) uint64: sum over the pairs of #{surface voxels of part t inside part s}  (volume = count * pitch^3);
+ *   pair_count (B, n_pairs) int32 or NULL; status (1) int32: 0 ok, bit 0 = a part does not fit `grid`, bit 1 = a face
+ *       needs more than trimesh's 10 subdivision rounds (the reference raises there).  All outputs are integers:
+ *       bit-exact against oracle/volume_ref.py.  No allocation, no sync (the caller reads `status` when it reads `count`).
+ * ---------------------------------------------------------------------------------- */
+int64_t dsf_part_volume_workspace_bytes(int B, int n_parts, int grid);
+int dsf_part_intersection_volume(const float* verts, const int32_t* faces, const int32_t* part_first, const int32_t* pairs,
+                                 int B, int V, int n_parts, int n_faces, int n_pairs, int max_part_faces, double pitch, int grid,
+                                 void* workspace, unsigned long long* count, int32_t* pair_count, int32_t* status,
+                                 dsf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

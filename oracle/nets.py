@@ -14,7 +14,7 @@ import torch.nn as nn
 def torch_twin():
     from dsf_amd import nn_conv
     saved = dict(nn_conv.LAYERS)
-    nn_conv.LAYERS.update(Conv2d=nn.Conv2d, ConvTranspose2d=nn.ConvTranspose2d, fused_bn=False)
+    nn_conv.LAYERS.update(Conv2d=nn.Conv2d, ConvTranspose2d=nn.ConvTranspose2d, fused_bn=False, MaxPool2d=nn.MaxPool2d)
     try:
         yield
     finally:

@@ -2,6 +2,7 @@
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
@@ -177,3 +178,27 @@ def test_mano_packed_rows_equal_sliced_call():
     wide = torch.cat([p, torch.zeros(7, 2, device="cuda")], 1)
     vc, _ = mano.get_mano_vertices_packed(wide[:, :62].contiguous(), 1 / 125)
     assert torch.equal(vc, va.detach())
+
+
+def test_hip_maxpool_matches_torch():
+    """dsf_maxpool_forward / _backward (NHWC, 1-byte argmax, gather backward) against torch.nn.functional.max_pool2d on the
+    CPU: values bit-equal, gradients bit-equal (ties: first maximum in scan order), both pooling geometries of the nets."""
+    from dsf_amd.nn_pool import MaxPool2d
+    g = torch.Generator().manual_seed(3)
+    for (B, C, H, W, k, s, p) in [(3, 64, 32, 32, 3, 2, 1), (2, 8, 17, 23, 3, 2, 1), (2, 128, 16, 16, 2, 2, 0), (1, 4, 5, 7, 3, 1, 1), (0, 8, 8, 8, 2, 2, 0)]:
+        x = torch.randn(B, C, H, W, generator=g)
+        x = (x * 4).round() / 4                                                  # many exact ties inside windows
+        xc = x.clone().requires_grad_(True)
+        yc = F.max_pool2d(xc, k, s, p)
+        gy = torch.randn(yc.shape, generator=g)
+        yc.backward(gy)
+        xg = x.cuda().requires_grad_(True)
+        yg = MaxPool2d(k, s, p)(xg)
+        assert yg.shape == yc.shape and (B == 0 or yg.is_contiguous(memory_format=torch.channels_last))
+        yg.backward(gy.cuda())
+        assert torch.equal(yg.cpu(), yc) and torch.equal(xg.grad.cpu(), xc.grad), (B, C, H, W, k, s, p)
+    x = torch.randn(1, 4, 6, 6)
+    x[0, 1, 2, 2] = float("nan")
+    assert torch.equal(torch.isnan(MaxPool2d(3, 2, 1)(x.cuda()).cpu()), torch.isnan(F.max_pool2d(x, 3, 2, 1)))
+    with pytest.raises(RuntimeError):
+        MaxPool2d(2, 2)(torch.randn(1, 4, 4, 4))

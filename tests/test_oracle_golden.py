@@ -257,3 +257,45 @@ def test_network_twins_are_bit_identical_to_the_reference(golden_nets):
     assert list(gen.state_dict().keys()) == list(g["gen_keys"])
     with torch.no_grad():
         assert np.array_equal(gen(x).numpy()[:, :, ::4, ::4], g["gen_out_sub"])
+
+
+def _r50_inputs(g):
+    import torch
+    rng = np.random.default_rng(15)
+    x = torch.tensor(rng.uniform(-1, 1, (2, 1, 128, 128)).astype(np.float32))
+    gw_pix = torch.tensor(rng.normal(size=(2, 84, 64, 64)).astype(np.float32))
+    gw_par = torch.tensor(rng.normal(size=(2, 62)).astype(np.float32))
+    assert np.array_equal(x.numpy(), g["x"])
+    assert np.allclose([float(gw_pix.double().sum()), float(gw_par.double().sum())], g["gw_pix_checksum"])
+    return x, gw_pix, gw_par
+
+
+def test_resnet50_twin_is_bit_identical_to_the_reference():
+    """ResNet-50 / Bottleneck (model/resnet.py:58-98): keys, eval outputs, training-mode outputs and gradients of the
+    torch.nn twin equal the arrays recorded from the imported reference (tests/golden/make_golden_r50.py)."""
+    import os
+    import torch
+    from oracle import nets
+    from dsf_amd.model.backbone import MANO_OCR_stage
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_r50.npz"))
+    x, gw_pix, gw_par = _r50_inputs(g)
+    torch.manual_seed(7)
+    net = nets.build(MANO_OCR_stage, "ResNet_stage_50", 21, False)
+    assert list(net.state_dict().keys()) == list(g["keys"])
+    assert sum(p.numel() for p in net.parameters()) == int(g["nparams"][0])
+    net.eval()
+    with torch.no_grad():
+        (pix, par), = net(x)
+    assert np.array_equal(pix.numpy()[:, :, ::8, ::8], g["eval_pix_sub"]) and np.array_equal(par.numpy(), g["eval_par"])
+    net.train()
+    xg = x.clone().requires_grad_(True)
+    (pix, par), = net(xg)
+    ((pix * gw_pix).sum() + (par * gw_par).sum()).backward()
+    assert np.array_equal(pix.detach().numpy()[:, :, ::8, ::8], g["train_pix_sub"])
+    assert np.array_equal(par.detach().numpy(), g["train_par"])
+    assert np.allclose(xg.grad.numpy()[:, :, ::4, ::4], g["grad_x_sub"], rtol=1e-4, atol=1e-6 * np.abs(g["grad_x_sub"]).max())
+    named = dict(net.named_parameters())
+    for i, n in enumerate(g["probe_names"]):
+        got = named[str(n)].grad.numpy()
+        ref = g["probe%d_head" % i]
+        assert np.allclose(got.reshape(-1)[:64], ref, rtol=1e-4, atol=1e-5 * max(np.abs(ref).max(), 1e-12)), n

@@ -1,0 +1,39 @@
+"""Which fp32 path is closer to the float64 gradients of an ill-conditioned two-stage net?  (diagnostic for
+tests/test_gpu_steps.py::test_pretrain_and_config4_multiview_step_vs_oracle)
+  python tools/step_truth.py ResNet_stage_50 3 2      [DSF_CONV_MATH=f32] [DSF_FUSED_BN=0]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np, torch
+import test_gpu_steps as T
+from oracle import step_ref
+from dsf_amd.assets import build_synthetic_mano
+from dsf_amd.model.backbone import MANO_OCR_stage
+from dsf_amd.render_model.mano_layer import Render
+from dsf_amd.train_step import PretrainStep, synthetic_batch, draws_to, Config
+backbone, views, B = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+render = Render("synthetic", "nyu", T.CAM, (640, 480)).cuda()
+orender = step_ref.OracleRender(build_synthetic_mano(0))
+net_cpu, net_gpu = T._twin_pair(MANO_OCR_stage, backbone, 21, True, seed=5)
+step = PretrainStep(net_gpu, render, None, Config, views=views)
+p, _, cube = synthetic_batch(B, "cpu", seed=31)
+d = step.draw(B, "cpu", torch.Generator().manual_seed(32), np.random.default_rng(33))
+rec = T._Recording(orender)
+step_ref.pretrain_loss(net_cpu, rec, None, p, cube, d, Config, views=views).backward()
+pinned = PretrainStep(net_gpu, T._PinnedBridge(render, rec.images), None, Config, views=views, optimizer=step.opt)
+lg, _ = pinned.loss(p.cuda(), cube.cuda(), draws_to(d, "cuda"))
+lg.backward()
+net64 = T._Net64(net_cpu)
+l64 = step_ref.pretrain_loss(net64, T._PinnedBridge(orender, rec.images), None, p, cube, d, Config, views=views)
+l64.backward()
+print("loss64 %.6f lossgpu %.6f" % (float(l64), float(lg)))
+print("cpu32 vs 64 (cos, rel):", T._grad_error(net64, net_cpu))
+print("gpu   vs 64 (cos, rel):", T._grad_error(net64, net_gpu))
+rows = []
+for (n, p64), (_, pc), (_, pg) in zip(net64.named_parameters(), net_cpu.named_parameters(), net_gpu.named_parameters()):
+    if p64.grad is None: continue
+    r = p64.grad.double().flatten(); nr = float(r.norm()) + 1e-300
+    rows.append((n, float((pc.grad.double().flatten() - r).norm()) / nr, float((pg.grad.cpu().double().flatten() - r).norm()) / nr))
+print("per tensor rel error (cpu32, gpu), every 12th + the 8 with the largest gpu/cpu ratio:")
+for r in rows[::12]: print("  %-36s %.4f %.4f" % r)
+for r in sorted(rows, key=lambda r: -r[2] / max(r[1], 1e-9))[:8]: print("  worst ratio %-30s %.4f %.4f" % r)
