@@ -51,6 +51,7 @@ SYMBOLS = [
     "dsf_conv_x6_split_weights_multi", "dsf_conv_x6_forward", "dsf_conv_x6_wrw", "dsf_mfma_bf16_probe", "dsf_bn_forward", "dsf_bn_apply", "dsf_bn_backward", "dsf_bn_workspace_bytes", "dsf_col_sum", "dsf_col_sum_workspace_bytes",
     "dsf_huber_mean_forward", "dsf_huber_mean_backward", "dsf_adamw_multi", "dsf_adamw_chunk_elems",
     "dsf_maxpool_forward", "dsf_maxpool_backward", "dsf_part_volume_workspace_bytes", "dsf_part_intersection_volume",
+    "dsf_set_deterministic", "dsf_get_deterministic", "dsf_conv_x6_wrw_workspace_bytes", "dsf_conv_x6_wrw_ws",
 ]
 
 
@@ -69,9 +70,20 @@ def lib():
         _lib.dsf_conv_c1_workspace_bytes.restype = ctypes.c_int64
         _lib.dsf_conv_x6_image_granules.restype = ctypes.c_int64
         _lib.dsf_part_volume_workspace_bytes.restype = ctypes.c_int64
+        _lib.dsf_conv_x6_wrw_workspace_bytes.restype = ctypes.c_int64
         for s in SYMBOLS:
             getattr(_lib, s)
     return _lib
+
+
+def set_deterministic(on=True):
+    """Bit-reproducible mode of every kernel of the library (include/dsf_hip.h, "Deterministic mode"); also selected by
+    DSF_DETERMINISTIC=1 in the environment.  -> the previous setting."""
+    return bool(lib().dsf_set_deterministic(ctypes.c_int(1 if on else 0)))
+
+
+def deterministic():
+    return bool(lib().dsf_get_deterministic())
 
 
 def stream_ptr():

@@ -13,6 +13,27 @@ static inline int dsf_launch_status() {
     return hipGetLastError() == hipSuccess ? DSF_OK : DSF_ERR_LAUNCH;
 }
 
+// Deterministic mode (dsf_set_deterministic(1) / DSF_DETERMINISTIC=1): every backward accumulation that many
+// lanes add into gives bit-identical results run to run.  Host launchers read the flag with dsf_deterministic().
+int dsf_deterministic();
+
+// Accumulator cells of the backward kernels.  Acc<false>: float atomics (fast; the order of the additions, hence the last
+// bits of the sum, vary from run to run).  Acc<true>: 64-bit fixed point with 2^-40 resolution (range +-8.3e6): integer
+// addition is associative, so the sum does not depend on the order -- the deterministic mode's "segmented reduce".
+template <bool DET> struct Acc;
+template <> struct Acc<false> {
+    typedef float T;
+    static __device__ __forceinline__ void add(T* p, float v) { atomicAdd(p, v); }
+    static __device__ __forceinline__ float get(T v) { return v; }
+};
+template <> struct Acc<true> {
+    typedef long long T;
+    static __device__ __forceinline__ void add(T* p, float v) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double2ll_rn((double)v * 1099511627776.0));
+    }
+    static __device__ __forceinline__ float get(T v) { return (float)((double)v * (1.0 / 1099511627776.0)); }
+};
+
 // wave-wide sum via DPP-lowered shuffles (64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

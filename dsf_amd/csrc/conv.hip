@@ -964,6 +964,7 @@ static int conv_forward_impl(const float* X, const float* W, const float* bias, 
     }
     static const int ks_env = [] { const char* e = getenv("DSF_CONV_SPLITS"); return e ? atoi(e) : 0; }();   // tuning aid
     if (ks_env > 0) k_splits = ks_env > live_chunks ? live_chunks : ks_env;
+    if (dsf_deterministic()) k_splits = 1;                               // no float atomics in the epilogue
     if (k_splits > 1 &&
         hipMemsetAsync(Y, 0, sizeof(float) * (size_t)M * Co, (hipStream_t)stream) != hipSuccess) return DSF_ERR_LAUNCH;
     const dim3 grid(m_tiles * n_tiles * k_splits);
@@ -1048,7 +1049,7 @@ extern "C" int dsf_conv_igemm_wrw(const float* X, const float* dY, float* dW, in
     // stages, 2 per CU with 32-pixel ones); at least 4 chunks per split
     static const int wg_env = [] { const char* e = getenv("DSF_WRW_WGS"); return e ? atoi(e) : 0; }();          // tuning aid
     int splits = (wg_env > 0 ? wg_env : (bkt == 16 ? 1024 : 512)) / (k_tiles * n_tiles);
-    if (splits < 1) splits = 1;
+    if (splits < 1 || dsf_deterministic()) splits = 1;                  // deterministic mode: one workgroup walks all pixels of its tile
     int64_t per = (M + splits - 1) / splits;
     per = ((per + BK - 1) / BK) * BK;
     if (per < 4 * BK) per = 4 * BK;

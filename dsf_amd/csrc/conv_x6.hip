@@ -593,7 +593,10 @@ template <int BN>
 __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __restrict__ X, const float* __restrict__ dY,
                                                              float* __restrict__ dW, X6P p, int k_tiles, int n_tiles,
                                                              int n_splits, int m_per_split, uint64_t magic_wo,
-                                                             uint64_t magic_ho, uint32_t x_bytes, uint32_t dy_bytes) {
+                                                             uint64_t magic_ho, uint32_t x_bytes, uint32_t dy_bytes,
+                                                             float* __restrict__ partial) {
+    // partial != nullptr (deterministic mode): every pixel split stores its tile to partial[split][K][Co] (plain stores,
+    // one writer per element); x6_wrw_reduce_kernel adds the splits in order.  Else: float atomics into dW.
     // BN = 128: 2 x 2 waves of 64 (k rows) x 64 (channels);  BN = 64 (layers with <= 64 output channels): 4 x 1 waves of
     // 32 x 64 -- half the MFMAs instead of multiplying zero columns; the dY tile keeps its 256-byte LDS rows, half used
     constexpr int WM = (BN == 128) ? 64 : 32;
@@ -734,9 +737,21 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int k = k0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (k < K) atomicAdd(dW + (int64_t)k * p.Co + n, acc[i][j][r]);
+                if (k >= K) continue;
+                if (partial) partial[((int64_t)split * K + k) * p.Co + n] = acc[i][j][r];
+                else atomicAdd(dW + (int64_t)k * p.Co + n, acc[i][j][r]);
             }
         }
+}
+
+// dW[e] = sum over the pixel splits, ascending (deterministic mode)
+__global__ __launch_bounds__(256) void x6_wrw_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dW, int64_t n,
+                                                           int splits) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    float s = 0.f;
+    for (int q = 0; q < splits; ++q) s += partial[(int64_t)q * n + e];
+    dW[e] = s;
 }
 
 // Measurement aid (bench.py): a bare v_mfma_f32_32x32x16_bf16 loop on pseudo-random operands, four accumulators per wave,
@@ -840,6 +855,7 @@ int dsf_conv_x6_forward(const float* X, const void* image, const float* bias, fl
         if (k_splits < 1) k_splits = 1;
     }
     if (k_splits > n_chunks) k_splits = n_chunks > 0 ? n_chunks : 1;
+    if (dsf_deterministic()) k_splits = 1;                               // no float atomics in the epilogue
     if (k_splits > 1 &&
         hipMemsetAsync(Y, 0, sizeof(float) * (size_t)M * Co, (hipStream_t)stream) != hipSuccess) return DSF_ERR_LAUNCH;
     const dim3 grid(m_tiles * n_tiles * k_splits);
@@ -857,12 +873,37 @@ int dsf_conv_x6_forward(const float* X, const void* image, const float* bias, fl
     return dsf_launch_status();
 }
 
-int dsf_conv_x6_wrw(const float* X, const float* dY, float* dW, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
-                    int KW, int stride, int pad_h, int pad_w, int accumulate, dsf_stream_t stream) {
+static int x6_wrw_plan(int B, int Ho, int Wo, int Ci, int Co, int KH, int KW, int& k_tiles, int& n_tiles, int64_t& per) {
+    const int64_t M = (int64_t)B * Ho * Wo;
+    const int K = KH * KW * Ci;
+    const int bn = x6_bn(Co);
+    k_tiles = (K + 127) / 128; n_tiles = (Co + bn - 1) / bn;
+    // split the pixel reduction so that one round of resident workgroups (2 per CU) covers the chip; >= 4 chunks per split
+    static const int wg_env = [] { const char* e = getenv("DSF_X6_WRW_WGS"); return e ? atoi(e) : 0; }();          // tuning aid
+    int splits = (wg_env > 0 ? wg_env : 512) / (k_tiles * n_tiles);
+    if (splits < 1) splits = 1;
+    per = (M + splits - 1) / splits;
+    per = ((per + 2 * XBK - 1) / (2 * XBK)) * (2 * XBK);
+    if (per < 4 * XBK) per = 4 * XBK;
+    return (int)((M + per - 1) / per);
+}
+
+// bytes of scratch dsf_conv_x6_wrw needs in deterministic mode (0 otherwise): one dW-sized tile per pixel split
+int64_t dsf_conv_x6_wrw_workspace_bytes(int B, int Ho, int Wo, int Ci, int Co, int KH, int KW) {
+    if (!dsf_deterministic() || B <= 0) return 0;
+    int k_tiles, n_tiles; int64_t per;
+    const int splits = x6_wrw_plan(B, Ho, Wo, Ci, Co, KH, KW, k_tiles, n_tiles, per);
+    return (int64_t)splits * KH * KW * Ci * Co * 4;
+}
+
+int dsf_conv_x6_wrw_ws(const float* X, const float* dY, float* dW, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
+                       int KW, int stride, int pad_h, int pad_w, int accumulate, float* workspace, dsf_stream_t stream) {
     DSF_CHECK_ARG(X && dY && dW && B >= 0 && Hi > 0 && Wi > 0 && Ci > 0 && Ho > 0 && Wo > 0 && Co > 0 && KH > 0 && KW > 0);
     DSF_CHECK_ARG(stride >= 1 && (Ci & 3) == 0 && (Co & 3) == 0);
     const int K = KH * KW * Ci;
-    if (!accumulate &&
+    const bool det = dsf_deterministic() != 0;
+    DSF_CHECK_ARG(!det || workspace || B == 0);
+    if (!accumulate && !(det && B > 0) &&
         hipMemsetAsync(dW, 0, sizeof(float) * (size_t)K * Co, (hipStream_t)stream) != hipSuccess) return DSF_ERR_LAUNCH;
     if (B == 0) return DSF_OK;
     X6P p = {B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad_h, pad_w};
@@ -870,23 +911,28 @@ int dsf_conv_x6_wrw(const float* X, const float* dY, float* dW, int B, int Hi, i
     const int64_t x_bytes = (int64_t)B * Hi * Wi * Ci * 4, dy_bytes = M * Co * 4;
     DSF_CHECK_ARG(M < (1ll << 31) && x_bytes < 0xFFFFFFF0ll && dy_bytes < 0xFFFFFFF0ll);
     const int bn = x6_bn(Co);
-    const int k_tiles = (K + 127) / 128, n_tiles = (Co + bn - 1) / bn;
-    // split the pixel reduction so that one round of resident workgroups (2 per CU) covers the chip; >= 4 chunks per split
-    static const int wg_env = [] { const char* e = getenv("DSF_X6_WRW_WGS"); return e ? atoi(e) : 0; }();          // tuning aid
-    int splits = (wg_env > 0 ? wg_env : 512) / (k_tiles * n_tiles);
-    if (splits < 1) splits = 1;
-    int64_t per = (M + splits - 1) / splits;
-    per = ((per + 2 * XBK - 1) / (2 * XBK)) * (2 * XBK);
-    if (per < 4 * XBK) per = 4 * XBK;
-    splits = (int)((M + per - 1) / per);
+    int k_tiles, n_tiles; int64_t per;
+    const int splits = x6_wrw_plan(B, Ho, Wo, Ci, Co, KH, KW, k_tiles, n_tiles, per);
     const uint64_t mwo = ((1ull << 40) + Wo - 1) / Wo, mho = ((1ull << 40) + Ho - 1) / Ho;
+    float* partial = det ? workspace : nullptr;
     if (bn == 128)
         hipLaunchKernelGGL(igemm_wrw_x6_kernel<128>, dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream, X, dY,
-                           dW, p, k_tiles, n_tiles, splits, (int)per, mwo, mho, (uint32_t)x_bytes, (uint32_t)dy_bytes);
+                           dW, p, k_tiles, n_tiles, splits, (int)per, mwo, mho, (uint32_t)x_bytes, (uint32_t)dy_bytes, partial);
     else
         hipLaunchKernelGGL(igemm_wrw_x6_kernel<64>, dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream, X, dY,
-                           dW, p, k_tiles, n_tiles, splits, (int)per, mwo, mho, (uint32_t)x_bytes, (uint32_t)dy_bytes);
+                           dW, p, k_tiles, n_tiles, splits, (int)per, mwo, mho, (uint32_t)x_bytes, (uint32_t)dy_bytes, partial);
+    if (det) {
+        const int64_t n = (int64_t)K * Co;
+        hipLaunchKernelGGL(x6_wrw_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial, dW, n,
+                           splits);
+    }
     return dsf_launch_status();
+}
+
+int dsf_conv_x6_wrw(const float* X, const float* dY, float* dW, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
+                    int KW, int stride, int pad_h, int pad_w, int accumulate, dsf_stream_t stream) {
+    if (dsf_deterministic() && B > 0) return DSF_ERR_INVALID_ARG;        // deterministic mode needs the scratch: dsf_conv_x6_wrw_ws
+    return dsf_conv_x6_wrw_ws(X, dY, dW, B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad_h, pad_w, accumulate, nullptr, stream);
 }
 
 }  // extern "C"

@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256) void collision_fwd_kernel(dsf_sphere_model sm,
     }
 }
 
+template <bool DET>
 __global__ __launch_bounds__(256) void collision_bwd_kernel(dsf_sphere_model sm, const float* __restrict__ joints,
                                                             const float* __restrict__ mesh,
                                                             const float* __restrict__ centres,
@@ -134,15 +135,19 @@ __global__ __launch_bounds__(256) void collision_bwd_kernel(dsf_sphere_model sm,
                                                             const int32_t* __restrict__ topk,
                                                             const float* __restrict__ grad_rows, int V,
                                                             float* __restrict__ g_joints, float* __restrict__ g_mesh) {
-    __shared__ float s_c[NS * 3], s_r[NS], s_gc[NS * 3], s_gr[NS], s_gate[NS], s_J[63], s_gJ[63], s_gjr[21], s_jr0;
+    typedef Acc<DET> A;                               // float atomics, or order-independent fixed point (deterministic mode)
+    typedef typename A::T AT;
+    __shared__ float s_c[NS * 3], s_r[NS], s_gate[NS], s_J[63], s_jr0;
+    __shared__ AT s_gc[NS * 3], s_gr[NS], s_gJ[63], s_gjr[21];
+    __shared__ AT s_gm[DET ? 16 * TOPK * 3 : 1];      // deterministic mode: the (joint, rank) mesh contributions, summed per vertex below
     const int b = blockIdx.x, t = threadIdx.x;
     if (t < NS) {
         s_r[t] = radii[b * NS + t];
         s_c[t * 3] = centres[(b * NS + t) * 3]; s_c[t * 3 + 1] = centres[(b * NS + t) * 3 + 1]; s_c[t * 3 + 2] = centres[(b * NS + t) * 3 + 2];
-        s_gr[t] = 0.f; s_gc[t * 3] = 0.f; s_gc[t * 3 + 1] = 0.f; s_gc[t * 3 + 2] = 0.f;
+        s_gr[t] = 0; s_gc[t * 3] = 0; s_gc[t * 3 + 1] = 0; s_gc[t * 3 + 2] = 0;
     }
-    if (t >= 64 && t < 127) { s_J[t - 64] = joints[b * 63 + t - 64]; s_gJ[t - 64] = 0.f; }
-    if (t >= 128 && t < 149) s_gjr[t - 128] = 0.f;
+    if (t >= 64 && t < 127) { s_J[t - 64] = joints[b * 63 + t - 64]; s_gJ[t - 64] = 0; }
+    if (t >= 128 && t < 149) s_gjr[t - 128] = 0;
     __syncthreads();
     // row gates (recomputed) ------------------------------------------------------------
     if (t < NS) {
@@ -162,32 +167,32 @@ __global__ __launch_bounds__(256) void collision_bwd_kernel(dsf_sphere_model sm,
         const float dx = s_c[i * 3] - s_c[j * 3], dy = s_c[i * 3 + 1] - s_c[j * 3 + 1], dz = s_c[i * 3 + 2] - s_c[j * 3 + 2];
         const float d = sqrtf(dx * dx + dy * dy + dz * dz + 1e-8f);
         if (s_r[i] + s_r[j] - d <= 0.f) continue;
-        atomicAdd(&s_gr[i], g); atomicAdd(&s_gr[j], g);
+        A::add(&s_gr[i], g); A::add(&s_gr[j], g);
         const float k = g / d;
-        atomicAdd(&s_gc[i * 3], -k * dx); atomicAdd(&s_gc[i * 3 + 1], -k * dy); atomicAdd(&s_gc[i * 3 + 2], -k * dz);
-        atomicAdd(&s_gc[j * 3], k * dx); atomicAdd(&s_gc[j * 3 + 1], k * dy); atomicAdd(&s_gc[j * 3 + 2], k * dz);
+        A::add(&s_gc[i * 3], -k * dx); A::add(&s_gc[i * 3 + 1], -k * dy); A::add(&s_gc[i * 3 + 2], -k * dz);
+        A::add(&s_gc[j * 3], k * dx); A::add(&s_gc[j * 3 + 1], k * dy); A::add(&s_gc[j * 3 + 2], k * dz);
     }
     __syncthreads();
     // spheres -> joint radii / joint positions ----------------------------------------------
     if (t < NS) {
-        const float gr = s_gr[t];
-        const float* gc = s_gc + t * 3;
+        const float gr = A::get(s_gr[t]);
+        const float gc[3] = {A::get(s_gc[t * 3]), A::get(s_gc[t * 3 + 1]), A::get(s_gc[t * 3 + 2])};
         if (t == 0) {
-            atomicAdd(&s_gjr[0], gr);                       // routed through the clamp below (as r_root)
-            for (int a = 0; a < 3; ++a) atomicAdd(&s_gJ[a], gc[a]);
+            A::add(&s_gjr[0], gr);                          // routed through the clamp below (as r_root)
+            for (int a = 0; a < 3; ++a) A::add(&s_gJ[a], gc[a]);
         } else if (t < NPALM) {
             const int k = (t - 1) >> 2, m = (t - 1) & 3, kn = c_knuckle[k];
             const float tt = sm.t_palm[m];
-            atomicAdd(&s_gjr[kn], gr * tt);
-            atomicAdd(&s_gjr[0], gr * (1.f - tt));
-            for (int a = 0; a < 3; ++a) { atomicAdd(&s_gJ[kn * 3 + a], gc[a] * tt); atomicAdd(&s_gJ[a], gc[a] * (1.f - tt)); }
+            A::add(&s_gjr[kn], gr * tt);
+            A::add(&s_gjr[0], gr * (1.f - tt));
+            for (int a = 0; a < 3; ++a) { A::add(&s_gJ[kn * 3 + a], gc[a] * tt); A::add(&s_gJ[a], gc[a] * (1.f - tt)); }
         } else {
             const int i = (t - NPALM) / 3, m = (t - NPALM) % 3, ch = c_child[i], pa = i + 1;
             const float tt = sm.t_finger[m];
             // radii of bones are not routed through r_root: joint_r[1:16] / children
-            atomicAdd(&s_gjr[ch], gr * tt);
-            atomicAdd(&s_gjr[pa], gr * (1.f - tt));
-            for (int a = 0; a < 3; ++a) { atomicAdd(&s_gJ[ch * 3 + a], gc[a] * tt); atomicAdd(&s_gJ[pa * 3 + a], gc[a] * (1.f - tt)); }
+            A::add(&s_gjr[ch], gr * tt);
+            A::add(&s_gjr[pa], gr * (1.f - tt));
+            for (int a = 0; a < 3; ++a) { A::add(&s_gJ[ch * 3 + a], gc[a] * tt); A::add(&s_gJ[pa * 3 + a], gc[a] * (1.f - tt)); }
         }
     }
     __syncthreads();
@@ -206,27 +211,44 @@ __global__ __launch_bounds__(256) void collision_bwd_kernel(dsf_sphere_model sm,
         s_jr0 = (x >= 0.01f && x <= 0.4f) ? 1.f : 0.f;
     }
     __syncthreads();
-    if (t < 5) atomicAdd(&s_gjr[3 + 3 * t], s_gjr[16 + t] / 1.5f);     // tip radii = parent / 1.5 (:281)
-    __syncthreads();
-    if (t == 0) s_gjr[0] *= s_jr0;
+    if (t < 5) A::add(&s_gjr[3 + 3 * t], A::get(s_gjr[16 + t]) / 1.5f);     // tip radii = parent / 1.5 (:281)
     __syncthreads();
     // joint radii -> joints / mesh through the 10 selected distances ------------------------------
     if (t < 16 * TOPK) {
         const int j = t / TOPK;
         const int v = topk[(b * 16 + j) * TOPK + (t % TOPK)];
-        const float g = s_gjr[j] / (float)TOPK;
+        const float g = A::get(s_gjr[j]) * (j == 0 ? s_jr0 : 1.f) / (float)TOPK;     // (joint 0: through the clamp)
+        float c[3] = {0.f, 0.f, 0.f};
         if (v >= 0 && g != 0.f) {
             const float* mv = mesh + ((int64_t)b * V + v) * 3;
             const float dx = s_J[j * 3] - mv[0], dy = s_J[j * 3 + 1] - mv[1], dz = s_J[j * 3 + 2] - mv[2];
             const float d = sqrtf(dx * dx + dy * dy + dz * dz + 1e-8f);
             const float k = g / d;
-            atomicAdd(&s_gJ[j * 3], k * dx); atomicAdd(&s_gJ[j * 3 + 1], k * dy); atomicAdd(&s_gJ[j * 3 + 2], k * dz);
-            float* gm = g_mesh + ((int64_t)b * V + v) * 3;
-            atomicAdd(gm, -k * dx); atomicAdd(gm + 1, -k * dy); atomicAdd(gm + 2, -k * dz);
+            A::add(&s_gJ[j * 3], k * dx); A::add(&s_gJ[j * 3 + 1], k * dy); A::add(&s_gJ[j * 3 + 2], k * dz);
+            c[0] = -k * dx; c[1] = -k * dy; c[2] = -k * dz;
+            if (!DET) {
+                float* gm = g_mesh + ((int64_t)b * V + v) * 3;
+                atomicAdd(gm, c[0]); atomicAdd(gm + 1, c[1]); atomicAdd(gm + 2, c[2]);
+            }
         }
+        if (DET) { s_gm[t * 3] = 0; A::add(&s_gm[t * 3], c[0]); s_gm[t * 3 + 1] = 0; A::add(&s_gm[t * 3 + 1], c[1]);
+                   s_gm[t * 3 + 2] = 0; A::add(&s_gm[t * 3 + 2], c[2]); }
     }
     __syncthreads();
-    if (t < 63) g_joints[b * 63 + t] = s_gJ[t];
+    if (DET && t < 16 * TOPK) {
+        // a vertex can sit in the top-10 lists of several joints: the FIRST (joint, rank) slot that names it sums them all
+        const int v = topk[(b * 16 + t / TOPK) * TOPK + (t % TOPK)];
+        bool first = v >= 0;
+        for (int u = 0; u < t && first; ++u) first = topk[(b * 16 + u / TOPK) * TOPK + (u % TOPK)] != v;
+        if (first) {
+            AT s0 = 0, s1 = 0, s2 = 0;
+            for (int u = t; u < 16 * TOPK; ++u)
+                if (topk[(b * 16 + u / TOPK) * TOPK + (u % TOPK)] == v) { s0 += s_gm[u * 3]; s1 += s_gm[u * 3 + 1]; s2 += s_gm[u * 3 + 2]; }
+            float* gm = g_mesh + ((int64_t)b * V + v) * 3;
+            gm[0] = A::get(s0); gm[1] = A::get(s1); gm[2] = A::get(s2);
+        }
+    }
+    if (t < 63) g_joints[b * 63 + t] = A::get(s_gJ[t]);
 }
 
 __global__ __launch_bounds__(256) void seg_pcl_kernel(const float* __restrict__ centres, const float* __restrict__ radii,
@@ -288,8 +310,12 @@ extern "C" int dsf_collision_backward(const dsf_sphere_model* sm, const float* j
     if (hipMemsetAsync(grad_mesh, 0, sizeof(float) * 3 * (size_t)B * V, (hipStream_t)stream) != hipSuccess)
         return DSF_ERR_LAUNCH;
     if (B == 0) return DSF_OK;
-    hipLaunchKernelGGL(collision_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, *sm, joints, mesh, centres,
-                       radii, topk_idx, grad_rows, V, grad_joints, grad_mesh);
+    if (dsf_deterministic())
+        hipLaunchKernelGGL(collision_bwd_kernel<true>, dim3(B), dim3(256), 0, (hipStream_t)stream, *sm, joints, mesh, centres,
+                           radii, topk_idx, grad_rows, V, grad_joints, grad_mesh);
+    else
+        hipLaunchKernelGGL(collision_bwd_kernel<false>, dim3(B), dim3(256), 0, (hipStream_t)stream, *sm, joints, mesh, centres,
+                           radii, topk_idx, grad_rows, V, grad_joints, grad_mesh);
     return dsf_launch_status();
 }
 

@@ -248,17 +248,19 @@ __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __rest
 
 constexpr int BWD_MAX_V = 1024;
 
+template <bool DET>
 __global__ __launch_bounds__(256) void mesh_point_bwd_kernel(const float* __restrict__ verts,
                                                              const float* __restrict__ points,
                                                              const int32_t* __restrict__ faces,
                                                              const int32_t* __restrict__ idxs,
                                                              const float* __restrict__ gd, int V, int P, int per_wg,
                                                              float* __restrict__ gverts, float* __restrict__ gpoints) {
-    __shared__ float s_g[BWD_MAX_V * 3];
+    typedef Acc<DET> A;                               // float atomics, or order-independent fixed point (deterministic mode)
+    __shared__ typename A::T s_g[BWD_MAX_V * 3];
     const int t = threadIdx.x;
     const int wgs = (P + per_wg - 1) / per_wg;
     const int b = blockIdx.x / wgs, chunk = blockIdx.x % wgs;
-    for (int e = t; e < V * 3; e += 256) s_g[e] = 0.f;
+    for (int e = t; e < V * 3; e += 256) s_g[e] = 0;
     __syncthreads();
     const float* vb = verts + (int64_t)b * V * 3;
     const int pend = min(P, (chunk + 1) * per_wg);
@@ -272,15 +274,15 @@ __global__ __launch_bounds__(256) void mesh_point_bwd_kernel(const float* __rest
             f3 g0, g1, g2;
             point_tri_backward(ld3(points + o * 3), ld3(vb + fc[0] * 3), ld3(vb + fc[1] * 3), ld3(vb + fc[2] * 3), g, gp,
                                g0, g1, g2);
-            atomicAdd(&s_g[fc[0] * 3], g0.x); atomicAdd(&s_g[fc[0] * 3 + 1], g0.y); atomicAdd(&s_g[fc[0] * 3 + 2], g0.z);
-            atomicAdd(&s_g[fc[1] * 3], g1.x); atomicAdd(&s_g[fc[1] * 3 + 1], g1.y); atomicAdd(&s_g[fc[1] * 3 + 2], g1.z);
-            atomicAdd(&s_g[fc[2] * 3], g2.x); atomicAdd(&s_g[fc[2] * 3 + 1], g2.y); atomicAdd(&s_g[fc[2] * 3 + 2], g2.z);
+            A::add(&s_g[fc[0] * 3], g0.x); A::add(&s_g[fc[0] * 3 + 1], g0.y); A::add(&s_g[fc[0] * 3 + 2], g0.z);
+            A::add(&s_g[fc[1] * 3], g1.x); A::add(&s_g[fc[1] * 3 + 1], g1.y); A::add(&s_g[fc[1] * 3 + 2], g1.z);
+            A::add(&s_g[fc[2] * 3], g2.x); A::add(&s_g[fc[2] * 3 + 1], g2.y); A::add(&s_g[fc[2] * 3 + 2], g2.z);
         }
         if (gpoints) { gpoints[o * 3] = gp.x; gpoints[o * 3 + 1] = gp.y; gpoints[o * 3 + 2] = gp.z; }
     }
     __syncthreads();
     for (int e = t; e < V * 3; e += 256) {
-        const float v = s_g[e];
+        const float v = A::get(s_g[e]);
         if (v != 0.f) atomicAdd(gverts + (int64_t)b * V * 3 + e, v);
     }
 }
@@ -333,9 +335,14 @@ extern "C" int dsf_mesh_point_dist_backward(const float* verts, const float* poi
     if (hipMemsetAsync(grad_verts, 0, sizeof(float) * 3 * (size_t)B * V, (hipStream_t)stream) != hipSuccess)
         return DSF_ERR_LAUNCH;
     if (B == 0 || P == 0) return DSF_OK;
+    if (dsf_deterministic()) {                    // one workgroup per sample: its fixed-point table holds the whole sum
+        hipLaunchKernelGGL(mesh_point_bwd_kernel<true>, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, verts, points,
+                           faces, idxs, grad_dists, V, P, P, grad_verts, grad_points);
+        return dsf_launch_status();
+    }
     const int per_wg = 1024;
     const int wgs = (P + per_wg - 1) / per_wg;
-    hipLaunchKernelGGL(mesh_point_bwd_kernel, dim3((unsigned)(B * wgs)), dim3(256), 0, (hipStream_t)stream, verts, points,
+    hipLaunchKernelGGL(mesh_point_bwd_kernel<false>, dim3((unsigned)(B * wgs)), dim3(256), 0, (hipStream_t)stream, verts, points,
                        faces, idxs, grad_dists, V, P, per_wg, grad_verts, grad_points);
     return dsf_launch_status();
 }

@@ -581,6 +581,7 @@ __global__ __launch_bounds__(256) void render_crop_fwd_kernel(const float* __res
     }
 }
 
+template <bool DET>
 __global__ __launch_bounds__(256) void render_crop_bwd_kernel(const float* __restrict__ verts,
                                                               const int32_t* __restrict__ faces,
                                                               const float* __restrict__ minv,
@@ -591,7 +592,8 @@ __global__ __launch_bounds__(256) void render_crop_bwd_kernel(const float* __res
                                                               const float* __restrict__ gimg, int V, int F, int S,
                                                               int crop, int wg_per_sample, float* __restrict__ gverts) {
     __shared__ float s_pv[CROP_MAX_V * 3];
-    __shared__ float s_g[CROP_MAX_V * 3];            // grads w.r.t. (x_ndc, y_ndc, z_view) per vertex
+    typedef Acc<DET> A;                               // float atomics, or order-independent fixed point (deterministic mode)
+    __shared__ typename A::T s_g[CROP_MAX_V * 3];     // grads w.r.t. (x_ndc, y_ndc, z_view) per vertex
     __shared__ float s_mi[6];
     const int t = threadIdx.x;
     const int b = blockIdx.x / wg_per_sample, part = blockIdx.x % wg_per_sample;
@@ -602,7 +604,7 @@ __global__ __launch_bounds__(256) void render_crop_bwd_kernel(const float* __res
         float xn, yn, zv;
         project(k, p[0], p[1], p[2], xn, yn, zv);
         s_pv[v * 3] = xn; s_pv[v * 3 + 1] = yn; s_pv[v * 3 + 2] = zv;
-        s_g[v * 3] = 0.f; s_g[v * 3 + 1] = 0.f; s_g[v * 3 + 2] = 0.f;
+        s_g[v * 3] = 0; s_g[v * 3 + 1] = 0; s_g[v * 3 + 2] = 0;
     }
     __syncthreads();
     const bool normalise = (center_z != nullptr);
@@ -638,15 +640,15 @@ __global__ __launch_bounds__(256) void render_crop_bwd_kernel(const float* __res
         const int vid[3] = {a, c1, c2};
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
-            atomicAdd(&s_g[vid[u] * 3], g[u * 3]);
-            atomicAdd(&s_g[vid[u] * 3 + 1], g[u * 3 + 1]);
-            atomicAdd(&s_g[vid[u] * 3 + 2], g[u * 3 + 2]);
+            A::add(&s_g[vid[u] * 3], g[u * 3]);
+            A::add(&s_g[vid[u] * 3 + 1], g[u * 3 + 1]);
+            A::add(&s_g[vid[u] * 3 + 2], g[u * 3 + 2]);
         }
     }
     __syncthreads();
     // chain through the projection: x_ndc = (-X fxn + Z pxn)/Z, y likewise, z_view = Z
     for (int v = t; v < V; v += 256) {
-        const float gxn = s_g[v * 3], gyn = s_g[v * 3 + 1], gzv = s_g[v * 3 + 2];
+        const float gxn = A::get(s_g[v * 3]), gyn = A::get(s_g[v * 3 + 1]), gzv = A::get(s_g[v * 3 + 2]);
         if (gxn == 0.f && gyn == 0.f && gzv == 0.f) continue;
         const float Z = s_pv[v * 3 + 2];
         const float gX = -gxn * k.fxn / Z, gY = -gyn * k.fyn / Z;
@@ -752,8 +754,14 @@ extern "C" int dsf_render_crop_backward(const float* verts, const int32_t* faces
     if (hipMemsetAsync(grad_verts, 0, sizeof(float) * 3 * (size_t)B * V, (hipStream_t)stream) != hipSuccess)
         return DSF_ERR_LAUNCH;
     if (B == 0) return DSF_OK;
+    if (dsf_deterministic()) {
+        // one workgroup per sample: the fixed-point LDS table holds the whole sum, the flush adds one value onto a zero
+        hipLaunchKernelGGL(render_crop_bwd_kernel<true>, dim3(B), dim3(256), 0, (hipStream_t)stream, verts, faces, minv,
+                           resize_rowmap, center_z, cube_z, *cam, pix_to_face, grad_img, V, F, raster_size, crop, 1, grad_verts);
+        return dsf_launch_status();
+    }
     const int g = (B >= 512) ? 1 : (B >= 128 ? 2 : 4);
-    hipLaunchKernelGGL(render_crop_bwd_kernel, dim3(B * g), dim3(256), 0, (hipStream_t)stream, verts, faces, minv,
+    hipLaunchKernelGGL(render_crop_bwd_kernel<false>, dim3(B * g), dim3(256), 0, (hipStream_t)stream, verts, faces, minv,
                        resize_rowmap, center_z, cube_z, *cam, pix_to_face, grad_img, V, F, raster_size, crop, g,
                        grad_verts);
     return dsf_launch_status();

@@ -187,10 +187,15 @@ def _wrw(x, gy, KH, KW, stride, pad):
     pooled = dw is not None
     dw = dw.view(KH, KW, Ci, Co) if pooled else torch.empty((KH, KW, Ci, Co), device=x.device, dtype=torch.float32)
     # both operands are activations: conv_x6 splits them on the fly (Ci % 4 == 0 and Co % 4 == 0), else the fp32 MFMA kernel
-    fn, name = (L.lib().dsf_conv_x6_wrw, "dsf_conv_x6_wrw") if _wrw_x6_ok(Ci, Co, x.numel(), gy.numel()) else \
-        (L.lib().dsf_conv_igemm_wrw, "dsf_conv_igemm_wrw")
-    check(fn(ptr_nhwc(x), ptr_nhwc(gy), ptr(dw), I(B), I(Hi), I(Wi), I(Ci), I(Ho), I(Wo), I(Co), I(KH), I(KW), I(stride),
-             I(pad[0]), I(pad[1]), I(1 if pooled else 0), stream_ptr()), name)
+    if _wrw_x6_ok(Ci, Co, x.numel(), gy.numel()):
+        nws = int(L.lib().dsf_conv_x6_wrw_workspace_bytes(I(B), I(Ho), I(Wo), I(Ci), I(Co), I(KH), I(KW)))    # > 0: deterministic mode
+        ws = torch.empty(nws // 4, device=x.device, dtype=torch.float32) if nws else None
+        check(L.lib().dsf_conv_x6_wrw_ws(ptr_nhwc(x), ptr_nhwc(gy), ptr(dw), I(B), I(Hi), I(Wi), I(Ci), I(Ho), I(Wo), I(Co), I(KH),
+                                         I(KW), I(stride), I(pad[0]), I(pad[1]), I(1 if pooled else 0), ptr(ws), stream_ptr()),
+              "dsf_conv_x6_wrw_ws")
+        return dw
+    check(L.lib().dsf_conv_igemm_wrw(ptr_nhwc(x), ptr_nhwc(gy), ptr(dw), I(B), I(Hi), I(Wi), I(Ci), I(Ho), I(Wo), I(Co), I(KH),
+                                     I(KW), I(stride), I(pad[0]), I(pad[1]), I(1 if pooled else 0), stream_ptr()), "dsf_conv_igemm_wrw")
     return dw
 
 

@@ -425,6 +425,21 @@ int dsf_adamw_multi(const uint64_t* ptrs, const int64_t* sizes, const int32_t* c
                     double weight_decay, double bias_correction1, double bias_correction2, dsf_stream_t stream);
 
 /* ----------------------------------------------------------------------------------
+ * Deterministic mode (SURVEY 5.2, 8b "deterministic segmented reduce (flag)"; pytorch3d's backward kernels use float
+ * atomicAdd and are not reproducible run to run).  dsf_set_deterministic(1) -- or DSF_DETERMINISTIC=1 in the environment
+ * when the library is loaded -- makes every launcher of this library bit-reproducible: the raster / point-face / collision
+ * backward kernels accumulate in 64-bit fixed point (order-independent), the forward-type convolutions do not split
+ * their reduction, backward-weights writes one partial tile per pixel split and adds them in ascending order
+ * (dsf_conv_x6_wrw_ws with dsf_conv_x6_wrw_workspace_bytes(...) bytes of scratch; dsf_conv_x6_wrw refuses in this mode).
+ * Returns the previous setting.  Off (default): float atomics, results agree to ~1e-7 relative.
+ * ---------------------------------------------------------------------------------- */
+int dsf_set_deterministic(int on);
+int dsf_get_deterministic(void);
+int64_t dsf_conv_x6_wrw_workspace_bytes(int B, int Ho, int Wo, int Ci, int Co, int KH, int KW);
+int dsf_conv_x6_wrw_ws(const float* X, const float* dY, float* dW, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
+                       int KW, int stride, int pad_h, int pad_w, int accumulate, float* workspace, dsf_stream_t stream);
+
+/* ----------------------------------------------------------------------------------
  * NHWC max pooling (nn.MaxPool2d(kernel_size=3, stride=2, padding=1) of the backbone stem, reference
  * model/backbone.py:200-204; nn.MaxPool2d(2, 2) of model/hourglass.py:131).  x (B,Hi,Wi,C) -> y (B,Ho,Wo,C), C % 4 == 0.
  * argmax (B,Ho,Wo,C) uint8: window position kh * k + kw of the maximum (torch's rule: first maximum in scan order, NaN

@@ -1,0 +1,112 @@
+"""DSF_DETERMINISTIC / dsf_set_deterministic(1): two runs of a whole step from the same state are
+BITWISE equal -- the raster / point-face / collision backward kernels (fixed-point accumulators), the convolutions (no
+split-K, ordered backward-weights partials) and everything downstream -- and the deterministic results agree with the
+default (float-atomic) ones to fp32 accuracy."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+CAM = (588.03, 587.07, 320.0, 240.0)
+
+
+@pytest.fixture(scope="module")
+def render():
+    from dsf_amd.render_model.mano_layer import Render
+    return Render("synthetic", "nyu", CAM, (640, 480)).cuda()
+
+
+@pytest.fixture()
+def det_mode():
+    from dsf_amd import _lib as L
+    old = L.set_deterministic(True)
+    yield
+    L.set_deterministic(old)
+
+
+def _grads(net):
+    return [p.grad.detach().clone() for p in net.parameters() if p.grad is not None]
+
+
+def _run_twice(make_loss, net):
+    out = []
+    for _ in range(2):
+        net.zero_grad(set_to_none=True)
+        loss = make_loss()
+        loss.backward()
+        torch.cuda.synchronize()
+        out.append((loss.detach().clone(), _grads(net)))
+    return out
+
+
+def test_geometry_backward_kernels_are_bit_reproducible(render, det_mode):
+    """crop rasteriser, fused point-to-mesh distance (whole hand + 15 parts), sphere collision: gradients w.r.t. the MANO
+    parameters, twice, B = 16."""
+    from dsf_amd.metric.meshLoss import ICPLoss, JointICPLoss
+    from dsf_amd.train_step import synthetic_batch
+    p, c, cube = synthetic_batch(16, "cuda", seed=4)
+    mano = render.mano_layer
+    with torch.no_grad():
+        _, _, jx, mesh = render.render(p, c, cube)
+        pcl = (mesh[:, torch.randint(0, 779, (2048,), device="cuda")] + 0.01 * torch.randn(16, 2048, 3, device="cuda")).contiguous()
+        seg = mano.seg_pcl(jx, jx, mesh, pcl)
+    gw = torch.randn(16, 1, 128, 128, device="cuda")
+    res = []
+    for _ in range(3):
+        q = (p + 0.01).clone().requires_grad_(True)
+        mano.clear_cache()
+        img, juvd, jxyz, m = render.render(q, c, cube)
+        loss = (img * gw).sum() + ICPLoss(m, pcl, mano.faces).sum() * 100 + JointICPLoss(m, pcl, mano.joint_faces, seg).sum() * 100 \
+            + mano.calculate_coll(jxyz, m) * 10
+        g, = torch.autograd.grad(loss, q)
+        res.append((loss.detach().clone(), g.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[1][1], res[2][1])
+    assert float(res[0][1].abs().sum()) > 0
+
+
+def test_whole_step_is_bit_reproducible_and_matches_the_default_mode(render):
+    from dsf_amd import _lib as L
+    from dsf_amd.model.backbone import MANO_OCR_stage
+    from dsf_amd.train_step import RenderSupervisedStep, synthetic_batch, Config
+    torch.manual_seed(0)
+    net = MANO_OCR_stage("ResNet_stage_18", 21, True).cuda()
+    with torch.no_grad():
+        for head in (net.mano_regress[2], net.mano_regress_s2[2]):
+            head.bias[58] = 1.0
+    step = RenderSupervisedStep(net, render, Config)
+    p, c, cube = synthetic_batch(8, "cuda", seed=2)
+    tgt = step.make_targets(p, c, cube)
+
+    def loss():
+        render.mano_layer.clear_cache()
+        return step.loss(tgt)[0]
+    default = _run_twice(loss, net)
+    old = L.set_deterministic(True)
+    try:
+        det = _run_twice(loss, net)
+    finally:
+        L.set_deterministic(old)
+    assert torch.equal(det[0][0], det[1][0])
+    assert len(det[0][1]) == len(det[1][1]) > 100
+    for a, b in zip(det[0][1], det[1][1]):
+        assert torch.equal(a, b)                                        # bitwise
+    # same mathematics as the default mode
+    assert abs(float(det[0][0]) - float(default[0][0])) <= 1e-5 * abs(float(default[0][0]))
+    num = sum(float(((a - b).double() ** 2).sum()) for a, b in zip(det[0][1], default[0][1]))
+    den = sum(float((b.double() ** 2).sum()) for b in default[0][1])
+    assert (num / den) ** 0.5 < 1e-3
+    # (the default mode is allowed to differ between its two runs: float atomics)
+
+
+def test_flag_round_trip_and_wrw_scratch_contract():
+    import ctypes
+    from dsf_amd import _lib as L
+    old = L.set_deterministic(True)
+    try:
+        assert L.deterministic()
+        assert int(L.lib().dsf_conv_x6_wrw_workspace_bytes(*(ctypes.c_int(v) for v in (4, 16, 16, 64, 64, 3, 3)))) > 0
+    finally:
+        L.set_deterministic(old)
+    assert L.deterministic() == old
+    if not old:
+        assert int(L.lib().dsf_conv_x6_wrw_workspace_bytes(*(ctypes.c_int(v) for v in (4, 16, 16, 64, 64, 3, 3)))) == 0
