@@ -38,9 +38,11 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
     // (x - mean) * (invstd * gamma) + beta > 0 -- bit-identical to the forward, and y is not read (nor kept) at all
     __shared__ float s_part[2][256 * 4];
     const int t = threadIdx.x;
-    const int c4n = C >> 2;                       // float4 columns; c4n <= 256 and 256 % c4n == 0
-    const int col = t % c4n, rl = t / c4n;
-    const int rlanes = 256 / c4n;
+    // float4 columns: a workgroup covers a block of c4b <= 256 of them (blockIdx.y: C > 1024 takes several blocks)
+    const int c4b = min(C >> 2, 256);             // 256 % c4b == 0
+    const int lcol = t % c4b, rl = t / c4b;
+    const int col = blockIdx.y * c4b + lcol;
+    const int rlanes = 256 / c4b;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
     const int64_t r1 = (r0 + rows_per_wg < M) ? r0 + rows_per_wg : M;
     float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
@@ -97,11 +99,11 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
     for (int k = 0; k < 4; ++k) { s_part[0][t * 4 + k] = a0[k]; s_part[1][t * 4 + k] = a1[k]; }
     __syncthreads();
     const int nv = 2 * C;
-    float* out = part + (int64_t)blockIdx.x * nv;
-    for (int ch = t; ch < C; ch += 256) {
+    float* out = part + (int64_t)blockIdx.x * nv + blockIdx.y * c4b * 4;
+    for (int ch = t; ch < c4b * 4; ch += 256) {
         const int cc = ch >> 2, kk = ch & 3;
         float d0 = 0.f, d1 = 0.f;
-        for (int q = 0; q < rlanes; ++q) { d0 += s_part[0][(q * c4n + cc) * 4 + kk]; d1 += s_part[1][(q * c4n + cc) * 4 + kk]; }
+        for (int q = 0; q < rlanes; ++q) { d0 += s_part[0][(q * c4b + cc) * 4 + kk]; d1 += s_part[1][(q * c4b + cc) * 4 + kk]; }
         out[ch] = d0;
         out[C + ch] = d1;
     }
@@ -318,19 +320,26 @@ __global__ __launch_bounds__(256) void col_sum_scalar_kernel(const float* __rest
     }
 }
 
-inline bool bn_shape_ok(int C) { return C >= 4 && (C & 3) == 0 && (C >> 2) <= 256 && 256 % (C >> 2) == 0; }
+// channel counts: a power of two from 4 to 1024 (one column block), or a multiple of 1024 (ResNet-50's 2048)
+inline bool bn_shape_ok(int C) {
+    const int c4n = C >> 2;
+    return C >= 4 && (C & 3) == 0 && (c4n <= 256 ? 256 % c4n == 0 : c4n % 256 == 0);
+}
+inline int bn_col_blocks(int C) { return ((C >> 2) + 255) / 256; }
 
 constexpr int BN_MAX_WGS = 256;
 inline int bn_rows_per_wg(int64_t M, int C) {
-    const int rlanes = 256 / (C >> 2);
+    const int rlanes = 256 / min(C >> 2, 256);
     int64_t r = (M + BN_MAX_WGS - 1) / BN_MAX_WGS;
     if (r < (int64_t)rlanes * 4) r = (int64_t)rlanes * 4;      // at least one unrolled trip per row-lane
     return (int)r;
 }
-inline int bn_apply_grid(int64_t n4) {
+inline int bn_apply_grid(int64_t n4, int C) {
     int64_t g = (n4 + 1023) / 1024;                             // >= 4 float4 per thread
     if (g > 2048) g = 2048;
     if (g < 1) g = 1;
+    const int m = bn_col_blocks(C);                             // the grid stride must be a multiple of the float4 column count
+    g = ((g + m - 1) / m) * m;
     return (int)g;
 }
 // workspace layout: [0, 2C) doubles = channel sums of the backward pass; then BN_MAX_WGS * 2C floats of per-workgroup
@@ -352,11 +361,11 @@ extern "C" int dsf_bn_forward(const float* x, const float* residual, const float
     const int rows = bn_rows_per_wg(M, C);
     const int wgs = (int)((M + rows - 1) / rows);
     BnFinal fin = {eps, momentum, save_mean, save_invstd, running_mean, running_var, nullptr, nullptr, nullptr};
-    hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(wgs), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+    hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(wgs, bn_col_blocks(C)), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                        M, C, 0, rows, bn_ws_part(workspace, C));
     hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3((C + 15) / 16), dim3(256), 0, st, bn_ws_part(workspace, C), wgs, M, C, fin);
     const int64_t n4 = M * (C >> 2);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_apply_grid(n4)), dim3(256), 0, st, x, residual, save_mean, save_invstd, gamma,
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_apply_grid(n4, C)), dim3(256), 0, st, x, residual, save_mean, save_invstd, gamma,
                        beta, n4, C, relu, y);
     return dsf_launch_status();
 }
@@ -368,7 +377,7 @@ extern "C" int dsf_bn_apply(const float* x, const float* residual, const float* 
     DSF_CHECK_ARG(x && y && mean && invstd && M > 0);
     if (!bn_shape_ok(C)) return DSF_ERR_UNSUPPORTED;
     const int64_t n4 = M * (C >> 2);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_apply_grid(n4)), dim3(256), 0, (hipStream_t)stream, x, residual, mean, invstd,
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_apply_grid(n4, C)), dim3(256), 0, (hipStream_t)stream, x, residual, mean, invstd,
                        gamma, beta, n4, C, relu, y);
     return dsf_launch_status();
 }
@@ -384,11 +393,11 @@ extern "C" int dsf_bn_backward(const float* x, const float* grad_y, const float*
     const int rows = bn_rows_per_wg(M, C);
     const int wgs = (int)((M + rows - 1) / rows);
     BnFinal fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, workspace, grad_gamma, grad_beta};
-    hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(wgs), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd, gamma, beta, M, C,
+    hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(wgs, bn_col_blocks(C)), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd, gamma, beta, M, C,
                        relu, rows, bn_ws_part(workspace, C));
     hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(256), 0, st, bn_ws_part(workspace, C), wgs, M, C, fin);
     const int64_t n4 = M * (C >> 2);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_apply_grid(n4)), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_apply_grid(n4, C)), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd,
                        gamma, beta, workspace, M, n4, C, relu, grad_x, grad_residual);
     return dsf_launch_status();
 }

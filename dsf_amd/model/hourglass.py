@@ -1,12 +1,22 @@
-"""Stacked-hourglass pixel network (counterpart of the reference's ``model/hourglass.py:62-259``).
-Pure dense convolutions -> PyTorch-ROCm / MIOpen.  ``PoseNetMANO`` adds the 62-d MANO head that
-BASELINE config 3 needs (the reference's PoseNet has none and is not used by its trainer)."""
+"""Stacked-hourglass pixel network (counterpart of the reference's ``model/hourglass.py:62-259``) on the HIP
+convolutions, the fused BatchNorm(+ReLU) kernels (csrc/norm.hip) and the HIP max pooling of this package.
+``PoseNetMANO`` adds the 62-d MANO head that BASELINE config 3 needs (the reference's PoseNet has none and is not used
+by its trainer).  Module / parameter names equal the reference's."""
 import math
 
 import torch
 from torch import nn
 
 from .. import nn_conv
+from ..nn_norm import FusedBatchNorm2d
+
+
+def _bn_relu(c, relu=True):
+    """(BatchNorm2d, ReLU) pair: the fused kernel (ReLU inside, an Identity keeps the attribute) unless the layer registry
+    asks for plain torch modules (oracle.nets twins)"""
+    if nn_conv.LAYERS["fused_bn"]:
+        return FusedBatchNorm2d(c, fuse_relu=relu), (nn.Identity() if relu else None)
+    return nn.BatchNorm2d(c), (nn.ReLU() if relu else None)
 
 
 
@@ -15,8 +25,10 @@ class Conv(nn.Module):
         super().__init__()
         self.inp_dim = inp_dim
         self.conv = nn_conv.LAYERS["Conv2d"](inp_dim, out_dim, kernel_size, stride, padding=(kernel_size - 1) // 2, bias=True)
-        self.relu = nn.ReLU() if relu else None
-        self.bn = nn.BatchNorm2d(out_dim) if bn else None
+        if bn:
+            self.bn, self.relu = _bn_relu(out_dim, relu)
+        else:
+            self.bn, self.relu = None, (nn.ReLU() if relu else None)
 
     def forward(self, x):
         x = self.conv(x)
@@ -31,14 +43,11 @@ class Residual(nn.Module):
     def __init__(self, inp_dim, out_dim):
         super().__init__()
         mid = int(out_dim / 2)
-        self.bn1 = nn.BatchNorm2d(inp_dim)
-        self.relu1 = nn.ReLU()
+        self.bn1, self.relu1 = _bn_relu(inp_dim)
         self.conv1 = Conv(inp_dim, mid, 1, relu=False)
-        self.bn2 = nn.BatchNorm2d(mid)
-        self.relu2 = nn.ReLU()
+        self.bn2, self.relu2 = _bn_relu(mid)
         self.conv2 = Conv(mid, mid, 3, relu=False)
-        self.bn3 = nn.BatchNorm2d(mid)
-        self.relu3 = nn.ReLU()
+        self.bn3, self.relu3 = _bn_relu(mid)
         self.conv3 = Conv(mid, out_dim, 1, relu=False)
         self.skip_layer = Conv(inp_dim, out_dim, 1, relu=False)
         self.need_skip = inp_dim != out_dim

@@ -560,7 +560,13 @@ def kernel_name(rec):
         return "conv_c1_%s_kernel<%d, %d>" % (kind[3:], rec[8], rec[10])
     if kind == "x6":
         bn6 = 128 if Co > 64 else 64
-        bmt = 64 if (bn6 == 128 and ((B * Ho * Wo + 127) // 128) * ((Co + 127) // 128) < 384) else 128
+        n6 = (Co + bn6 - 1) // bn6
+        bmt = 64 if (bn6 == 128 and ((B * Ho * Wo + 127) // 128) * n6 < 384) else 128
+        direct = os.environ.get("DSF_X6_BDIRECT", "1") != "0"
+        if direct and bn6 == 64:
+            bmt = 256
+        if direct and not (bmt == 64 and n6 >= 2):            # weight operand straight into the MFMA fragments (conv_x6.hip)
+            return "igemm_x6b_kernel<%d, %s, %d>" % (bn6, "true" if dil == 2 else "false", bmt)
         return "igemm_x6_kernel<%d, %s, %d>" % (bn6, "true" if dil == 2 else "false", bmt)
     if kind in ("fwd", "fwd_wt", "bwd_s1"):
         wt = "false" if kind == "fwd" else "true"

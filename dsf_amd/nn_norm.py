@@ -16,8 +16,9 @@ CL = torch.channels_last
 
 
 def supported(C):
+    """channel counts of the HIP kernels: a power of two from 4 to 1024, or a multiple of 1024 (ResNet-50's 2048)"""
     c4 = C >> 2
-    return C >= 4 and C % 4 == 0 and c4 <= 256 and 256 % c4 == 0
+    return C >= 4 and C % 4 == 0 and (256 % c4 == 0 if c4 <= 256 else c4 % 256 == 0)
 
 
 def _p(t):

@@ -72,7 +72,7 @@ def test_conv_transpose2d_matches_torch_cpu(Ci, Co, K, s, p, op, H):
 
 
 @pytest.mark.parametrize("C,H,res,relu", [(64, 16, True, True), (256, 8, False, True), (512, 4, True, False), (8, 5, False, False),
-                                          (1024, 3, True, True)])
+                                          (1024, 3, True, True), (2048, 4, True, True), (2048, 3, False, False)])
 def test_fused_batchnorm_matches_torch_cpu(C, H, res, relu):
     """bn(x) (+ residual) (relu) in training mode vs torch CPU: output, running stats, all gradients."""
     from dsf_amd.nn_norm import FusedBatchNorm2d
