@@ -124,7 +124,7 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
                 if self.momentum is None:
                     raise NotImplementedError("FusedBatchNorm2d: cumulative moving average (momentum=None) is not used by "
                                               "the reference and not implemented")
-                if self.training and self.track_running_stats and self.num_batches_tracked is not None:
+                if self.training and self.track_running_stats and self._buffers.get("num_batches_tracked") is not None:   # (not the attribute: reading it flushes)
                     self._pending_batches += 1
                 mom = self.momentum
                 rm = self.running_mean if (self.training and self.track_running_stats) else None
