@@ -69,13 +69,15 @@ def pmc_traffic(kernel):
     tools/pmc_summary.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this script;
     FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md).  A profiler cannot run inside the timed
     process, so the figure is read back from the profile of the same command; null when the file has no entry."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            e = json.load(f)["kernels"][kernel]
-        return {"traffic": e["hbm_bytes_per_launch"], "traffic_source": "profiles/r01_pmc_traffic.json (fetch x2 + write)"}
-    except (OSError, KeyError, ValueError):
-        return {"traffic": None}
+    here = os.path.dirname(os.path.abspath(__file__))
+    for tag in ("r02", "r01"):                                   # the newest committed round that measured this kernel
+        try:
+            with open(os.path.join(here, "profiles", tag + "_pmc_traffic.json")) as f:
+                e = json.load(f)["kernels"][kernel]
+            return {"traffic": e["hbm_bytes_per_launch"], "traffic_source": "profiles/%s_pmc_traffic.json (fetch x2 + write)" % tag}
+        except (OSError, KeyError, ValueError):
+            continue
+    return {"traffic": None}
 
 
 def conv_kernel_roofline(step, tgt):
@@ -190,10 +192,13 @@ def crop_kernel_roofline(render, B, launches=200):
     us = e0.elapsed_time(e1) * 1e3 / launches
     bytes_per_launch = B * (779 * 12 + 128 * 128 * 4 + 128 * 128 * 4)
     achieved = bytes_per_launch / (us * 1e-6) / 1e9
-    return {"kernel": "render_crop_fwd_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), **pmc_traffic("render_crop_fwd_kernel"),
-            "avg_launch_us": round(us, 2), "bytes_per_launch": bytes_per_launch,
-            "note": "VALU/latency-bound at this size (4.5 MB of algorithmic traffic per launch); 2 launches per step"}
+    return {"kernel": "render_crop_fwd_kernel", "bound": "valu", "avg_launch_us": round(us, 2),
+            "images_per_s": round(B / (us * 1e-6), 1), "hbm_achieved": round(achieved, 2), "hbm_peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "hbm_frac": round(achieved / HBM_PEAK_GBS, 5), **pmc_traffic("render_crop_fwd_kernel"),
+            "bytes_per_launch": bytes_per_launch,
+            "note": "VALU / latency-bound, not a bandwidth kernel: 4.5 MB of algorithmic traffic per launch; its time is the "
+                    "coverage tests of the heaviest 8x8 tile (one wave walks that tile's candidate faces) on top of a ~25 us "
+                    "floor (projection + face boxes per workgroup, empty-tile walks; tools/perf_crop.py); 2 launches per step"}
 
 
 def self_launch(n):
