@@ -97,3 +97,170 @@ def crop_and_normalize(depth, com, size, dsize, paras):
     """the `phase == 'test'` branch of loader.__getitem__ (:1909-1916): crop, then normalise with the crop's own maximum"""
     crop, trans = crop_image_deep_pp(depth, com, size, dsize, paras)
     return normalize_img(crop.max(), crop, com, size), trans, crop
+
+
+# ======================================================================================================================
+# training-phase augmentation (SURVEY 8f row 1): `rand_augment` draws are inputs; `augmentCrop` (data/render_loader.py:
+# 653-695) = one of moveCoM (:427-456) / rotateHand (:458-497) / scaleHand (:499-527) on the ALREADY CROPPED image, then
+# `normalize_img` (:738-745).  The image warps are OpenCV's (`cv2.warpPerspective` inside recropHand :403-424,
+# `cv2.getRotationMatrix2D` + `cv2.warpAffine` in rotateHand); OpenCV is absent from the image, so their published
+# nearest-neighbour rules (imgproc/imgwarp.cpp) are restated below -- those three functions are UNPINNED, everything around
+# them is pinned by running the reference's own methods with these stand-ins (tests/golden/make_golden_data.py).
+# Arithmetic convention: float64 throughout, rounded to float32 exactly where the reference stores into float32 arrays
+# (`jointImgTo3D` / `joint3DToImg` results) -- NumPy 1.x promotion, the NumPy the reference was written for; under
+# NumPy >= 2 the reference's `comToBounds` on such a float32 centre runs in float32 and can move a crop bound by one pixel.
+# ======================================================================================================================
+AUG_MODES = ('rot', 'com', 'sc', 'none')                   # render_loader.py:1816 (nyu_loader)
+
+
+def img_to_3d(uvd, paras, flip=1):
+    """jointImgTo3D (render_loader.py:288-310): float32 result"""
+    fx, fy, fu, fv = paras
+    uvd = np.asarray(uvd, dtype=np.float64)
+    out = np.stack([(uvd[..., 0] - fu) * uvd[..., 2] / fx, flip * (uvd[..., 1] - fv) * uvd[..., 2] / fy, uvd[..., 2]], -1)
+    return out.astype(np.float32)
+
+
+def to_img(xyz, paras, flip=1):
+    """joint3DToImg (render_loader.py:312-333): float32 result"""
+    fx, fy, fu, fv = paras
+    xyz = np.asarray(xyz, dtype=np.float64)
+    out = np.stack([xyz[..., 0] * fx / xyz[..., 2] + fu, flip * xyz[..., 1] * fy / xyz[..., 2] + fv, xyz[..., 2]], -1)
+    return out.astype(np.float32)
+
+
+def com_to_transform(com, size, dsize, paras):
+    """comToTransform (render_loader.py:366-401) -> 3x3 float64"""
+    xstart, xend, ystart, yend, _, _ = com_to_bounds(com, size, paras)
+    wb, hb = xend - xstart, yend - ystart
+    if wb > hb:
+        s, sz = dsize[0] / float(wb), (dsize[0], hb * dsize[0] / wb)
+    else:
+        s, sz = dsize[1] / float(hb), (wb * dsize[1] / hb, dsize[1])
+    x0 = int(np.floor(dsize[0] / 2. - sz[0] / 2.))
+    y0 = int(np.floor(dsize[1] / 2. - sz[1] / 2.))
+    return np.array([[s, 0., s * (-xstart) + x0], [0., s, s * (-ystart) + y0], [0., 0., 1.]])
+
+
+def _cv_round(v):
+    """cv::saturate_cast<int>(double) = cvRound: to nearest, ties to even"""
+    return np.rint(v).astype(np.int64)
+
+
+def cv_warp_perspective_nn(src, M, dsize, border=0.0):
+    """cv2.warpPerspective(src, M, dsize, flags=INTER_NEAREST, borderMode=BORDER_CONSTANT, borderValue=border):
+    M is inverted (dst -> src), the source position of a destination pixel is evaluated in 64 x 16 blocks as
+    ((m0 bx + m1 y + m2) + m0 (x - bx)) / w and rounded with cvRound (imgwarp.cpp WarpPerspectiveInvoker)."""
+    W, H = int(dsize[0]), int(dsize[1])
+    Mi = np.linalg.inv(np.asarray(M, dtype=np.float64))
+    bh = min(16, H)
+    bw = min(1024 // bh, W)
+    bh = min(1024 // bw, H)
+    y, x = np.mgrid[0:H, 0:W].astype(np.float64)
+    bx = np.floor(x / bw) * bw
+    X0 = (Mi[0, 0] * bx + Mi[0, 1] * y) + Mi[0, 2]
+    Y0 = (Mi[1, 0] * bx + Mi[1, 1] * y) + Mi[1, 2]
+    W0 = (Mi[2, 0] * bx + Mi[2, 1] * y) + Mi[2, 2]
+    x1 = x - bx
+    w = W0 + Mi[2, 0] * x1
+    with np.errstate(divide="ignore"):
+        w = np.where(w != 0, 1.0 / w, 0.0)
+    fx = np.clip((X0 + Mi[0, 0] * x1) * w, -2147483648.0, 2147483647.0)
+    fy = np.clip((Y0 + Mi[1, 0] * x1) * w, -2147483648.0, 2147483647.0)
+    sx, sy = _cv_round(fx), _cv_round(fy)
+    ok = (sx >= 0) & (sx < src.shape[1]) & (sy >= 0) & (sy < src.shape[0])
+    out = np.full((H, W), border, dtype=src.dtype)
+    out[ok] = src[sy[ok], sx[ok]]
+    return out
+
+
+def cv_get_rotation_matrix_2d(center, angle, scale):
+    """cv2.getRotationMatrix2D: center is a Point2f, angle in degrees"""
+    cx, cy = float(np.float32(center[0])), float(np.float32(center[1]))
+    a = angle * np.pi / 180.0
+    alpha, beta = np.cos(a) * scale, np.sin(a) * scale
+    return np.array([[alpha, beta, (1 - alpha) * cx - beta * cy], [-beta, alpha, beta * cx + (1 - alpha) * cy]])
+
+
+def cv_warp_affine_nn(src, M, dsize, border=0.0):
+    """cv2.warpAffine(src, M, dsize, flags=INTER_NEAREST, borderMode=BORDER_CONSTANT): M (2x3) is inverted in double, then
+    fixed point with 10 fractional bits: X = (round((m1 y + m2) 1024) + 512 + round(m0 x 1024)) >> 10 (WarpAffineInvoker)."""
+    W, H = int(dsize[0]), int(dsize[1])
+    m = np.asarray(M, dtype=np.float64).reshape(2, 3).copy()
+    D = m[0, 0] * m[1, 1] - m[0, 1] * m[1, 0]
+    D = 1.0 / D if D != 0 else 0.0
+    A11, A22 = m[1, 1] * D, m[0, 0] * D
+    m[0, 0] = A11; m[0, 1] *= -D; m[1, 0] *= -D; m[1, 1] = A22
+    b1 = -m[0, 0] * m[0, 2] - m[0, 1] * m[1, 2]
+    b2 = -m[1, 0] * m[0, 2] - m[1, 1] * m[1, 2]
+    m[0, 2], m[1, 2] = b1, b2
+    xs, ys = np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64)
+    adelta, bdelta = _cv_round(m[0, 0] * xs * 1024), _cv_round(m[1, 0] * xs * 1024)
+    X0 = _cv_round((m[0, 1] * ys + m[0, 2]) * 1024) + 512
+    Y0 = _cv_round((m[1, 1] * ys + m[1, 2]) * 1024) + 512
+    sx = (X0[:, None] + adelta[None, :]) >> 10
+    sy = (Y0[:, None] + bdelta[None, :]) >> 10
+    ok = (sx >= 0) & (sx < src.shape[1]) & (sy >= 0) & (sy < src.shape[0])
+    out = np.full((H, W), border, dtype=src.dtype)
+    out[ok] = src[sy[ok], sx[ok]]
+    return out
+
+
+def recrop_hand(crop, M, Mnew, target, paras, background, nv_val, com, size):
+    """recropHand (render_loader.py:403-424), thresh_z=True"""
+    warped = cv_warp_perspective_nn(crop, np.dot(M, Mnew), target, border=float(background))
+    warped[warped < nv_val] = background
+    _, _, _, _, zstart, zend = com_to_bounds(com, size, paras)
+    front = np.logical_and(warped < zstart, warped != 0)
+    back = np.logical_and(warped > zend, warped != 0)
+    warped[front] = zstart
+    warped[back] = 0.
+    return warped
+
+
+def augment_crop(img, joints, com, cube, M, mode, off, rot, sc, paras, flip=1):
+    """augmentCrop (render_loader.py:653-695).  img (S,S) float32 raw crop (mm, 0 = background), joints (J,3) float32 relative
+    to the centre, com (3,) image coordinates (u, v, z), cube (3,), M (3,3), mode in AUG_MODES, off (3,) mm, rot degrees, sc.
+    -> (normalised image float32, joints float32, cube (3,) float64, com (3,), M (3,3))"""
+    img = np.asarray(img, dtype=np.float32)
+    joints = np.asarray(joints, dtype=np.float32)
+    com = np.asarray(com)
+    cube = [float(c) for c in cube]
+    S = img.shape[0]
+    premax = img.max()
+    new_img, new_joints = img, joints
+    if img.max() == 0 or mode == 'none':
+        pass
+    elif mode == 'com' and not np.allclose(off, 0.):
+        new_com = to_img(img_to_3d(com, paras, flip).astype(np.float64) + np.asarray(off, dtype=np.float64), paras, flip)
+        if not (np.allclose(com[2], 0.) or np.allclose(new_com[2], 0.)):
+            Mnew = com_to_transform(new_com.astype(np.float64), cube, img.shape, paras)
+            new_img = recrop_hand(img.copy(), Mnew, np.linalg.inv(M), img.shape, paras, 0, img[img > 0].min() - 1, new_com.astype(np.float64), cube)
+        else:
+            Mnew = M
+        new_joints = (joints + img_to_3d(com, paras, flip) - img_to_3d(new_com, paras, flip)).astype(np.float32)
+        com, M = new_com, Mnew
+    elif mode == 'rot' and not np.allclose(rot, 0.):
+        r = np.mod(rot, 360)
+        R = cv_get_rotation_matrix_2d((S // 2, S // 2), -r, 1)
+        new_img = cv_warp_affine_nn(img, R, (S, S), border=0.0)
+        if (img > 0).sum() > 0:
+            new_img[new_img < img[img > 0].min() - 1] = 0
+        com3d = img_to_3d(com, paras, flip)
+        j2d = to_img(joints + com3d, paras, flip).astype(np.float64)         # float32 values, rotated in double
+        a = r * np.pi / 180.
+        c2 = np.asarray(com[0:2], dtype=np.float64)
+        pp = j2d[:, 0:2] - c2
+        rotd = np.stack([pp[:, 0] * np.cos(a) - pp[:, 1] * np.sin(a), pp[:, 0] * np.sin(a) + pp[:, 1] * np.cos(a)], -1) + c2
+        d2 = np.concatenate([rotd, j2d[:, 2:3]], -1).astype(np.float32)      # (the reference rotates float32 rows in place)
+        new_joints = (img_to_3d(d2, paras, flip) - com3d).astype(np.float32)
+    elif mode == 'sc' and not np.allclose(sc, 1.):
+        new_cube = [s * sc for s in cube]
+        if not np.allclose(com[2], 0.):
+            Mnew = com_to_transform(np.asarray(com, dtype=np.float64), new_cube, img.shape, paras)
+            new_img = recrop_hand(img.copy(), Mnew, np.linalg.inv(M), img.shape, paras, 0, img[img > 0].min() - 1,
+                                  np.asarray(com, dtype=np.float64), cube)
+            M = Mnew
+        cube = new_cube
+    out = normalize_img(premax, new_img, np.asarray(com, dtype=np.float64), cube)
+    return out, new_joints, np.asarray(cube, dtype=np.float64), np.asarray(com), np.asarray(M, dtype=np.float64)
