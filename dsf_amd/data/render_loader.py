@@ -27,6 +27,22 @@ class loader:
         ``normalize_img(crop.max(), crop, center, cube_size)`` -> data (B,1,S,S) f32, M (B,3,3) f64 [, raw crop]."""
         return ops.depth_crop_normalize(depth, com, cube_size, paras or self.paras, self.img_size, want_raw)
 
+    aug_modes = ['rot', 'com', 'sc', 'none']                      # nyu_loader (:1816)
+
+    def rand_augment(self, B, sigma_com=10., sigma_sc=0.2, rot_range=180., rng=None):
+        """``rand_augment`` (:625-650) for a batch, on the host (as the reference: Python's ``random``): mode index,
+        off = U(-1,1)^3 * sigma_com mm, rot = U(-rot_range, rot_range) degrees, sc = |1 + U(-1,1) * sigma_sc|
+        (defaults: config.py:85 ``augment_para``).  -> numpy arrays, the explicit inputs of ``augmentCrop``."""
+        import numpy as np
+        rng = rng if rng is not None else np.random.default_rng()
+        return (rng.integers(0, len(self.aug_modes), B).astype(np.int32), rng.uniform(-1, 1, (B, 3)) * sigma_com,
+                rng.uniform(-rot_range, rot_range, B), np.abs(1. + rng.uniform(-1, 1, B) * sigma_sc))
+
+    def augmentCrop(self, crop, gt3Dcrop, com, cube, M, mode, off, rot, sc, paras=None):
+        """Batched device version of ``augmentCrop`` (:653-695) on raw crops (``crop_normalize(..., want_raw=True)[2]``):
+        -> (imgD (B,1,S,S) normalised, new_joints3D (B,J,3), cube (B,3), com (B,3), M (B,3,3))."""
+        return ops.depth_augment_crop(crop, gt3Dcrop, com, cube, M, mode, off, rot, sc, paras or self.paras, self.flip)
+
     @staticmethod
     def _b3(x, B):
         return x.reshape(B, 3)

@@ -428,6 +428,31 @@ def depth_crop_normalize(depth, com, cube, paras, dsize=128, want_raw=False):
     return (img, trans, raw) if want_raw else (img, trans)
 
 
+def depth_augment_crop(crop, joints, com, cube, M, mode, off, rot, sc, paras, flip=1):
+    """Training-phase ``augmentCrop`` (data/render_loader.py:653-695) for a batch of raw crops on the device.
+    crop (B,S,S) f32 (un-normalised), joints (B,J,3) f32, com / cube (B,3), M (B,3,3), mode (B,) ints into
+    ['rot','com','sc','none'], off (B,3) mm, rot (B,) degrees, sc (B,) -> img (B,1,S,S), joints, cube, com, M (f64)."""
+    if not crop.is_cuda:
+        raise RuntimeError("dsf_amd ops run on the GPU only (got a %s tensor); there is no CPU path" % crop.device)
+    dev = crop.device
+    crop = crop.float().contiguous()
+    B, S, _ = crop.shape
+    joints = joints.to(dev).float().contiguous()
+    J = joints.shape[1]
+    d64 = lambda t, shape: torch.as_tensor(t, dtype=torch.float64, device=dev).reshape(shape).contiguous()
+    com, cube, M, off, rot, sc = d64(com, (B, 3)), d64(cube, (B, 3)), d64(M, (B, 3, 3)), d64(off, (B, 3)), d64(rot, (B,)), d64(sc, (B,))
+    mode = torch.as_tensor(mode, dtype=torch.int32, device=dev).reshape(B).contiguous()
+    img = _empty((B, 1, S, S), crop)
+    jout = _empty((B, J, 3), crop)
+    cube_o, com_o = torch.empty((B, 3), device=dev, dtype=torch.float64), torch.empty((B, 3), device=dev, dtype=torch.float64)
+    M_o = torch.empty((B, 3, 3), device=dev, dtype=torch.float64)
+    D = ctypes.c_double
+    check(L.lib().dsf_depth_augment_crop(ptr(crop), ptr(joints), ptr(com), ptr(cube), ptr(M), ptr(mode), ptr(off), ptr(rot), ptr(sc),
+                                         D(paras[0]), D(paras[1]), D(paras[2]), D(paras[3]), I(int(flip)), I(B), I(S), I(J), ptr(img),
+                                         ptr(jout), ptr(cube_o), ptr(com_o), ptr(M_o), stream_ptr()), "dsf_depth_augment_crop")
+    return img, jout, cube_o, com_o, M_o
+
+
 def _map_strides(t):
     """(batch, channel, pixel) strides of a (B,C,S,S) tensor whose pixels are uniformly strided (NCHW, channels-last,
     or a channel slice of either) as a ctypes int64[3]; None if the layout is anything else."""

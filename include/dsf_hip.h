@@ -425,6 +425,22 @@ int dsf_adamw_multi(const uint64_t* ptrs, const int64_t* sizes, const int32_t* c
                     double weight_decay, double bias_correction1, double bias_correction2, dsf_stream_t stream);
 
 /* ----------------------------------------------------------------------------------
+ * Training-phase augmentation of cropped frames: `loader.augmentCrop`
+ * (/root/reference/data/render_loader.py:653-695 = rotateHand :458-497 / moveCoM :427-456 / scaleHand :499-527 through
+ * recropHand :403-424, then normalize_img :738-745) for a batch, replacing the cv2 / numpy DataLoader workers.
+ *   crop (B,S,S) f32: the un-normalised crops (dsf_depth_crop_normalize's raw_crop); joints (B,J,3) f32 mm relative to
+ *   the centre; com (B,3) f64 image coordinates (u, v, z); cube (B,3) f64 mm; M (B,3,3) f64 the crop transform;
+ *   mode (B) int32 index into the reference's aug_modes ['rot','com','sc','none'] (:1816); off (B,3) f64 mm, rot (B) f64
+ *   degrees, sc (B) f64: the `rand_augment` draws (:625-650) as explicit inputs; (fx, fy, fu, fv), flip: camera.
+ *   -> img (B,1,S,S) f32 normalised to [-1,1], joints_out (B,J,3) f32, cube_out / com_out (B,3) f64, M_out (B,3,3) f64.
+ * cv2.warpPerspective / getRotationMatrix2D / warpAffine (INTER_NEAREST, BORDER_CONSTANT) follow OpenCV's published rules.
+ * ---------------------------------------------------------------------------------- */
+int dsf_depth_augment_crop(const float* crop, const float* joints, const double* com, const double* cube, const double* M,
+                           const int32_t* mode, const double* off, const double* rot, const double* sc, double fx, double fy,
+                           double fu, double fv, int flip, int B, int S, int J, float* img, float* joints_out,
+                           double* cube_out, double* com_out, double* M_out, dsf_stream_t stream);
+
+/* ----------------------------------------------------------------------------------
  * Deterministic mode (SURVEY 5.2, 8b "deterministic segmented reduce (flag)"; pytorch3d's backward kernels use float
  * atomicAdd and are not reproducible run to run).  dsf_set_deterministic(1) -- or DSF_DETERMINISTIC=1 in the environment
  * when the library is loaded -- makes every launcher of this library bit-reproducible: the raster / point-face / collision

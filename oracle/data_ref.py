@@ -142,6 +142,14 @@ def com_to_transform(com, size, dsize, paras):
     return np.array([[s, 0., s * (-xstart) + x0], [0., s, s * (-ystart) + y0], [0., 0., 1.]])
 
 
+def affine_inverse(M):
+    """inverse of a scale-and-shift transform [[s,0,tx],[0,s,ty],[0,0,1]] in closed form, one rounding per entry
+    (r = 1/s; -(t r)): what `np.linalg.inv` / `cv::invert` return up to the last ulp, and the form the HIP kernel uses"""
+    M = np.asarray(M, dtype=np.float64)
+    r = 1.0 / M[0, 0]
+    return np.array([[r, 0., -(M[0, 2] * r)], [0., r, -(M[1, 2] * r)], [0., 0., 1.]])
+
+
 def _cv_round(v):
     """cv::saturate_cast<int>(double) = cvRound: to nearest, ties to even"""
     return np.rint(v).astype(np.int64)
@@ -152,7 +160,9 @@ def cv_warp_perspective_nn(src, M, dsize, border=0.0):
     M is inverted (dst -> src), the source position of a destination pixel is evaluated in 64 x 16 blocks as
     ((m0 bx + m1 y + m2) + m0 (x - bx)) / w and rounded with cvRound (imgwarp.cpp WarpPerspectiveInvoker)."""
     W, H = int(dsize[0]), int(dsize[1])
-    Mi = np.linalg.inv(np.asarray(M, dtype=np.float64))
+    M = np.asarray(M, dtype=np.float64)
+    affine = M[0, 1] == 0 and M[1, 0] == 0 and M[0, 0] == M[1, 1] and M[2, 0] == 0 and M[2, 1] == 0 and M[2, 2] == 1
+    Mi = affine_inverse(M) if affine else np.linalg.inv(M)
     bh = min(16, H)
     bw = min(1024 // bh, W)
     bh = min(1024 // bw, H)
@@ -235,7 +245,7 @@ def augment_crop(img, joints, com, cube, M, mode, off, rot, sc, paras, flip=1):
         new_com = to_img(img_to_3d(com, paras, flip).astype(np.float64) + np.asarray(off, dtype=np.float64), paras, flip)
         if not (np.allclose(com[2], 0.) or np.allclose(new_com[2], 0.)):
             Mnew = com_to_transform(new_com.astype(np.float64), cube, img.shape, paras)
-            new_img = recrop_hand(img.copy(), Mnew, np.linalg.inv(M), img.shape, paras, 0, img[img > 0].min() - 1, new_com.astype(np.float64), cube)
+            new_img = recrop_hand(img.copy(), Mnew, affine_inverse(M), img.shape, paras, 0, img[img > 0].min() - 1, new_com.astype(np.float64), cube)
         else:
             Mnew = M
         new_joints = (joints + img_to_3d(com, paras, flip) - img_to_3d(new_com, paras, flip)).astype(np.float32)
@@ -250,15 +260,17 @@ def augment_crop(img, joints, com, cube, M, mode, off, rot, sc, paras, flip=1):
         j2d = to_img(joints + com3d, paras, flip).astype(np.float64)         # float32 values, rotated in double
         a = r * np.pi / 180.
         c2 = np.asarray(com[0:2], dtype=np.float64)
-        pp = j2d[:, 0:2] - c2
-        rotd = np.stack([pp[:, 0] * np.cos(a) - pp[:, 1] * np.sin(a), pp[:, 0] * np.sin(a) + pp[:, 1] * np.cos(a)], -1) + c2
-        d2 = np.concatenate([rotd, j2d[:, 2:3]], -1).astype(np.float32)      # (the reference rotates float32 rows in place)
+        # rotatePoint2D (:130-147) works in place on float32 rows: every statement rounds to float32
+        pp = (j2d[:, 0:2] - c2).astype(np.float32).astype(np.float64)
+        rotd = np.stack([pp[:, 0] * np.cos(a) - pp[:, 1] * np.sin(a), pp[:, 0] * np.sin(a) + pp[:, 1] * np.cos(a)], -1)
+        rotd = (rotd.astype(np.float32).astype(np.float64) + c2).astype(np.float32)
+        d2 = np.concatenate([rotd, j2d[:, 2:3].astype(np.float32)], -1)
         new_joints = (img_to_3d(d2, paras, flip) - com3d).astype(np.float32)
     elif mode == 'sc' and not np.allclose(sc, 1.):
         new_cube = [s * sc for s in cube]
         if not np.allclose(com[2], 0.):
             Mnew = com_to_transform(np.asarray(com, dtype=np.float64), new_cube, img.shape, paras)
-            new_img = recrop_hand(img.copy(), Mnew, np.linalg.inv(M), img.shape, paras, 0, img[img > 0].min() - 1,
+            new_img = recrop_hand(img.copy(), Mnew, affine_inverse(M), img.shape, paras, 0, img[img > 0].min() - 1,
                                   np.asarray(com, dtype=np.float64), cube)
             M = Mnew
         cube = new_cube
