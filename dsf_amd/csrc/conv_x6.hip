@@ -373,7 +373,7 @@ template <int BN, bool DIL2, int BMT>
 __global__ __launch_bounds__(256, 2) void igemm_x6b_kernel(const float* __restrict__ X, const uint4* __restrict__ Wimg,
                                                           const float* __restrict__ bias, float* __restrict__ Y, X6P p,
                                                           int m_tiles, int n_tiles, int k_splits, uint32_t x_bytes,
-                                                          uint32_t w_bytes) {
+                                                          uint32_t w_bytes, float* __restrict__ stats) {
     static_assert((BN == 128 && (BMT == 128 || BMT == 64)) || (BN == 64 && BMT == 256), "tile shapes");
     constexpr int WM = (BN == 128) ? BMT / 2 : 64;       // wave sub-tile WM x 64: 2 x 2 waves (BN 128) or 4 x 1 (BN 64)
     constexpr int TM = WM / 32, TN = 2;
@@ -571,6 +571,36 @@ __global__ __launch_bounds__(256, 2) void igemm_x6b_kernel(const float* __restri
                 else Y[row * p.Co + n] = acc[i][j][r] + bv;
             }
         }
+
+    // BatchNorm batch statistics of this tile (stats != nullptr: unsplit, bias-free convolution followed by a BatchNorm):
+    // per-channel sum and sum of squares over the tile's rows as ONE partial row [m_tile][2][Co] -- the rows bn_finalize_kernel
+    // folds in double (rows past M hold exact zeros: their A rows were zero-filled).  Saves the BN reduce pass over Y.
+    if (stats) {
+        __shared__ float s_st[4][2][64];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float su = 0.f, sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { su += acc[i][j][r]; sq = fmaf(acc[i][j][r], acc[i][j][r], sq); }
+            su += __shfl_xor(su, 32, 64); sq += __shfl_xor(sq, 32, 64);
+            if (lane < 32) { s_st[wave][0][j * 32 + lane] = su; s_st[wave][1][j * 32 + lane] = sq; }
+        }
+        __syncthreads();
+        constexpr int WAVES_M = (BN == 128) ? 2 : 4;                     // waves stacked along the rows of the tile
+        for (int e = t; e < 2 * BN; e += 256) {
+            const int which = e / BN, c = e % BN;
+            const int n = n0 + c;
+            if (n >= p.Co) continue;
+            const int wcol = (BN == 128) ? (c >> 6) : 0, lc = c & 63;
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES_M; ++w) tot += s_st[(BN == 128) ? (w * 2 + wcol) : w][which][lc];
+            stats[((int64_t)m_tile * 2 + which) * p.Co + n] = tot;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -823,9 +853,10 @@ int dsf_conv_x6_split_weights_multi(const int64_t* jobs, int n_jobs, int64_t tot
 }
 
 // Ci / Co are the reduction / output channel counts of the IMAGE (mode 1: those of the backward-data GEMM).
-int dsf_conv_x6_forward(const float* X, const void* image, const float* bias, float* Y, int B, int Hi, int Wi, int Ci, int Ho,
-                        int Wo, int Co, int KH, int KW, int stride, int dil, int pad_h, int pad_w, int k_splits,
-                        dsf_stream_t stream) {
+static int x6_forward_impl(const float* X, const void* image, const float* bias, float* Y, int B, int Hi, int Wi, int Ci, int Ho,
+                           int Wo, int Co, int KH, int KW, int stride, int dil, int pad_h, int pad_w, int k_splits,
+                           float* bn_stats, int* bn_rows, dsf_stream_t stream) {
+    if (bn_rows) *bn_rows = 0;
     DSF_CHECK_ARG(X && image && Y && B >= 0 && Hi > 0 && Wi > 0 && Ci > 0 && Ho > 0 && Wo > 0 && Co > 0 && KH > 0 && KW > 0);
     DSF_CHECK_ARG(stride >= 1 && (Ci & 3) == 0 && (dil == 1 || (dil == 2 && stride == 1)));
     if (dil == 2 && ((Ho | Wo) & 1)) return DSF_ERR_UNSUPPORTED;
@@ -859,20 +890,28 @@ int dsf_conv_x6_forward(const float* X, const void* image, const float* bias, fl
     if (k_splits > 1 &&
         hipMemsetAsync(Y, 0, sizeof(float) * (size_t)M * Co, (hipStream_t)stream) != hipSuccess) return DSF_ERR_LAUNCH;
     const dim3 grid(m_tiles * n_tiles * k_splits);
+    // BatchNorm statistics in the epilogue: only the B-direct kernels, unsplit, without a bias
+    const bool direct_pre = bdirect && !(bmt == 64 && n_tiles >= 2);
+    float* stats = (bn_stats && bn_rows && direct_pre && k_splits == 1 && !bias) ? bn_stats : nullptr;
+    if (bn_rows) *bn_rows = stats ? m_tiles : 0;
 #define DSF_LAUNCH_X6(KERNEL, BNv, DILv, BMv) hipLaunchKernelGGL((KERNEL<BNv, DILv, BMv>), grid, dim3(256), 0, (hipStream_t)stream, \
                                                        X, (const uint4*)image, bias, Y, p, m_tiles, n_tiles, k_splits,              \
                                                        (uint32_t)x_bytes, (uint32_t)w_bytes)
+#define DSF_LAUNCH_X6B(BNv, DILv, BMv) hipLaunchKernelGGL((igemm_x6b_kernel<BNv, DILv, BMv>), grid, dim3(256), 0, (hipStream_t)stream, \
+                                                       X, (const uint4*)image, bias, Y, p, m_tiles, n_tiles, k_splits,              \
+                                                       (uint32_t)x_bytes, (uint32_t)w_bytes, stats)
     // 64-row tiles with several n tiles (16x16x256, 8x8x512 maps): every wave of the many small tiles would pull its own copy of
     // the weight block from L2 -- the LDS-staged kernel is faster there (measured 136 / 139 vs 133 / 133 TFLOP/s)
     const bool direct = bdirect && !(bmt == 64 && n_tiles >= 2);
     if (direct) {
-        if (dil == 2) { if (bn == 64) DSF_LAUNCH_X6(igemm_x6b_kernel, 64, true, 256); else if (bmt == 64) DSF_LAUNCH_X6(igemm_x6b_kernel, 128, true, 64); else DSF_LAUNCH_X6(igemm_x6b_kernel, 128, true, 128); }
-        else { if (bn == 64) DSF_LAUNCH_X6(igemm_x6b_kernel, 64, false, 256); else if (bmt == 64) DSF_LAUNCH_X6(igemm_x6b_kernel, 128, false, 64); else DSF_LAUNCH_X6(igemm_x6b_kernel, 128, false, 128); }
+        if (dil == 2) { if (bn == 64) DSF_LAUNCH_X6B(64, true, 256); else if (bmt == 64) DSF_LAUNCH_X6B(128, true, 64); else DSF_LAUNCH_X6B(128, true, 128); }
+        else { if (bn == 64) DSF_LAUNCH_X6B(64, false, 256); else if (bmt == 64) DSF_LAUNCH_X6B(128, false, 64); else DSF_LAUNCH_X6B(128, false, 128); }
     } else {
         if (dil == 2) { if (bn == 64) DSF_LAUNCH_X6(igemm_x6_kernel, 64, true, 128); else if (bmt == 64) DSF_LAUNCH_X6(igemm_x6_kernel, 128, true, 64); else DSF_LAUNCH_X6(igemm_x6_kernel, 128, true, 128); }
         else { if (bn == 64) DSF_LAUNCH_X6(igemm_x6_kernel, 64, false, 128); else if (bmt == 64) DSF_LAUNCH_X6(igemm_x6_kernel, 128, false, 64); else DSF_LAUNCH_X6(igemm_x6_kernel, 128, false, 128); }
     }
 #undef DSF_LAUNCH_X6
+#undef DSF_LAUNCH_X6B
     return dsf_launch_status();
 }
 
@@ -892,6 +931,24 @@ static int x6_wrw_plan(int B, int Ho, int Wo, int Ci, int Co, int KH, int KW, in
 }
 
 // bytes of scratch dsf_conv_x6_wrw needs in deterministic mode (0 otherwise): one dW-sized tile per pixel split
+int dsf_conv_x6_forward(const float* X, const void* image, const float* bias, float* Y, int B, int Hi, int Wi, int Ci, int Ho,
+                        int Wo, int Co, int KH, int KW, int stride, int dil, int pad_h, int pad_w, int k_splits,
+                        dsf_stream_t stream) {
+    return x6_forward_impl(X, image, bias, Y, B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, dil, pad_h, pad_w, k_splits, nullptr, nullptr,
+                           stream);
+}
+
+// partial rows a BatchNorm-statistics epilogue may write for an (M = B Ho Wo)-row output: one per 64 rows at most
+int dsf_conv_x6_bn_stats_rows(int B, int Ho, int Wo) { return (int)(((int64_t)B * Ho * Wo + 63) / 64); }
+
+int dsf_conv_x6_forward_bn(const float* X, const void* image, float* Y, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
+                           int KH, int KW, int stride, int dil, int pad_h, int pad_w, float* bn_stats, int* bn_rows,
+                           dsf_stream_t stream) {
+    DSF_CHECK_ARG(bn_stats && bn_rows);
+    return x6_forward_impl(X, image, nullptr, Y, B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, dil, pad_h, pad_w, 0, bn_stats, bn_rows,
+                           stream);
+}
+
 int64_t dsf_conv_x6_wrw_workspace_bytes(int B, int Ho, int Wo, int Ci, int Co, int KH, int KW) {
     if (!dsf_deterministic() || B <= 0) return 0;
     int k_tiles, n_tiles; int64_t per;

@@ -15,7 +15,7 @@ import torch.nn as nn
 from . import resnet as _resnet
 from .resnet import BasicBlock, Bottleneck
 from .. import nn_conv
-from ..nn_norm import FusedBatchNorm2d
+from ..nn_norm import FusedBatchNorm2d, ConvBN
 from ..util.generateFeature import joint2offset, offset2joint_softmax
 
 BN_MOMENTUM = 0.1
@@ -57,8 +57,8 @@ class _Layers:
 
 
 def convtranspose_bn_relu(cin, cout, kernel, L):
-    return nn.Sequential(L.ConvTranspose2d(cin, cout, kernel, stride=2, padding=1, output_padding=0, bias=False),
-                         *L.bn_relu(cout, momentum=0.1))
+    seq = ConvBN if L.fused_bn else nn.Sequential
+    return seq(L.ConvTranspose2d(cin, cout, kernel, stride=2, padding=1, output_padding=0, bias=False), *L.bn_relu(cout, momentum=0.1))
 
 
 class _TwoBranchNet(nn.Module):
@@ -73,8 +73,9 @@ class _TwoBranchNet(nn.Module):
     def _make_layer(self, block, planes, blocks, stride=1):
         down = None
         if stride != 1 or self.inplanes != planes * block.expansion:
-            down = nn.Sequential(self._L.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
-                                 self._L.bn(planes * block.expansion, momentum=BN_MOMENTUM))
+            down = (ConvBN if self._L.fused_bn else nn.Sequential)(
+                self._L.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
+                self._L.bn(planes * block.expansion, momentum=BN_MOMENTUM))
         layers = [block(self.inplanes, planes, stride, down)]
         self.inplanes = planes * block.expansion
         layers += [block(self.inplanes, planes) for _ in range(1, blocks)]

@@ -4,7 +4,7 @@ keys) load unchanged."""
 import torch.nn as nn
 
 from ..nn_conv import Conv2d as _HipConv2d
-from ..nn_norm import FusedBatchNorm2d, bn_act
+from ..nn_norm import FusedBatchNorm2d, bn_act, conv_bn_act
 
 _CONV = [_HipConv2d]      # layer factory of the network under construction (set by model/backbone.py::_Layers)
 _FUSED_BN = [False]       # fused BN+add+ReLU kernels (see model/backbone.py::_Layers)
@@ -32,9 +32,9 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        y = bn_act(self.bn1, self.conv1(x), relu=True)
+        y = conv_bn_act(self.conv1, self.bn1, x, relu=True)                       # (BN statistics from the conv epilogue)
         identity = x if self.downsample is None else self.downsample(x)
-        return bn_act(self.bn2, self.conv2(y), residual=identity, relu=True)      # bn + skip + relu in one pass
+        return conv_bn_act(self.conv2, self.bn2, y, residual=identity, relu=True)    # bn + skip + relu in one pass
 
 
 class Bottleneck(nn.Module):
@@ -53,7 +53,7 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        y = bn_act(self.bn1, self.conv1(x), relu=True)
-        y = bn_act(self.bn2, self.conv2(y), relu=True)
+        y = conv_bn_act(self.conv1, self.bn1, x, relu=True)
+        y = conv_bn_act(self.conv2, self.bn2, y, relu=True)
         identity = x if self.downsample is None else self.downsample(x)
-        return bn_act(self.bn3, self.conv3(y), residual=identity, relu=True)
+        return conv_bn_act(self.conv3, self.bn3, y, residual=identity, relu=True)

@@ -128,6 +128,16 @@ def refresh_images(params, owner=None):
         cache[mode] = ((p._version, _EPOCH, p.data_ptr()), img, geom)
 
 
+class StatsRequest:
+    """Side channel between a convolution and the BatchNorm that follows it (nn_norm.conv_bn_act): while ``STATS`` holds a
+    request, a bias-free conv_x6 forward also writes the per-tile partial rows of the BatchNorm batch statistics
+    (dsf_conv_x6_forward_bn) and leaves them here; ``rows`` stays 0 when the launch it chose cannot (split K, ...)."""
+    part, rows = None, 0
+
+
+STATS = None
+
+
 def _fwd_x6(x, image, bias, out_hw, Co, KH, KW, stride, pad, dil=1):
     """_fwd with the weight operand given as a conv_x6 image whose reduction width is x's channel count (dil 1, or the
     dil-2 transposed-convolution gather with even output sizes)."""
@@ -136,6 +146,18 @@ def _fwd_x6(x, image, bias, out_hw, Co, KH, KW, stride, pad, dil=1):
     if RECORD is not None:
         RECORD.append(("x6", B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, dil, pad[0], pad[1]))
     y = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=CL)
+    req = STATS
+    if req is not None and bias is None and B > 0:
+        import ctypes
+        rows_max = int(L.lib().dsf_conv_x6_bn_stats_rows(I(B), I(Ho), I(Wo)))
+        part = torch.empty(rows_max * 2 * Co, device=x.device, dtype=torch.float32)
+        rows = ctypes.c_int(0)
+        check(L.lib().dsf_conv_x6_forward_bn(ptr_nhwc(x), ptr(image), ptr_nhwc(y), I(B), I(Hi), I(Wi), I(Ci), I(Ho), I(Wo), I(Co),
+                                             I(KH), I(KW), I(stride), I(dil), I(pad[0]), I(pad[1]), ptr(part), ctypes.byref(rows),
+                                             stream_ptr()), "dsf_conv_x6_forward_bn")
+        if rows.value > 0:
+            req.part, req.rows = part, rows.value
+        return y
     check(L.lib().dsf_conv_x6_forward(ptr_nhwc(x), ptr(image), ptr(bias), ptr_nhwc(y), I(B), I(Hi), I(Wi), I(Ci), I(Ho), I(Wo),
                                       I(Co), I(KH), I(KW), I(stride), I(dil), I(pad[0]), I(pad[1]), I(0), stream_ptr()),
           "dsf_conv_x6_forward")

@@ -3,6 +3,8 @@ dsf_amd/csrc/norm.hip (NHWC).  Drop-in subclass of nn.BatchNorm2d: same paramete
 state-dict keys; ``forward(x, residual=None, relu=False)``.  GPU only."""
 import ctypes
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -43,7 +45,7 @@ def _workspace(device, C):
 
 class _BNFunction(Function):
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, eps, momentum, relu):
+    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, eps, momentum, relu, part=None, rows=0):
         x = x.contiguous(memory_format=CL)
         if residual is not None:
             residual = residual.contiguous(memory_format=CL)
@@ -52,10 +54,16 @@ class _BNFunction(Function):
         y = torch.empty_like(x, memory_format=CL)
         mean = torch.empty(C, device=x.device, dtype=torch.float32)
         invstd = torch.empty(C, device=x.device, dtype=torch.float32)
-        ws = _workspace(x.device, C)
-        check(L.lib().dsf_bn_forward(_p(x), _p(residual), _p(gamma), _p(beta), I64(M), I(C), CF(eps), CF(momentum),
-                                     I(int(relu)), _p(running_mean), _p(running_var), _p(y), _p(mean), _p(invstd), _p(ws),
-                                     stream_ptr()), "dsf_bn_forward")
+        if part is not None and rows > 0:
+            # the producing convolution's epilogue already reduced the tile sums (dsf_conv_x6_forward_bn): finalise + apply only
+            check(L.lib().dsf_bn_forward_from_stats(_p(x), _p(residual), _p(gamma), _p(beta), I64(M), I(C), CF(eps), CF(momentum),
+                                                    I(int(relu)), _p(running_mean), _p(running_var), _p(y), _p(mean), _p(invstd),
+                                                    _p(part), I(int(rows)), stream_ptr()), "dsf_bn_forward_from_stats")
+        else:
+            ws = _workspace(x.device, C)
+            check(L.lib().dsf_bn_forward(_p(x), _p(residual), _p(gamma), _p(beta), I64(M), I(C), CF(eps), CF(momentum),
+                                         I(int(relu)), _p(running_mean), _p(running_var), _p(y), _p(mean), _p(invstd), _p(ws),
+                                         stream_ptr()), "dsf_bn_forward")
         # ReLU mask in the backward: recomputed from x when no residual was added (y is then not kept alive for it)
         ctx.save_for_backward(x, y if (relu and residual is not None) else None, gamma, beta, mean, invstd)
         ctx.cfg = (relu, residual is not None, gamma is not None, beta is not None)
@@ -77,7 +85,7 @@ class _BNFunction(Function):
         ws = _workspace(x.device, C)
         check(L.lib().dsf_bn_backward(_p(x), _p(gy), _p(y), _p(gamma), _p(beta), _p(mean), _p(invstd), I64(M), I(C), I(relu_mode), _p(gx),
                                       _p(gres), _p(gg), _p(gb), _p(ws), stream_ptr()), "dsf_bn_backward")
-        return gx, gres, gg, gb, None, None, None, None, None
+        return gx, gres, gg, gb, None, None, None, None, None, None, None
 
 
 class FusedBatchNorm2d(nn.BatchNorm2d):
@@ -111,7 +119,7 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
         self._pending_batches = 0
         super()._load_from_state_dict(*args, **kwargs)
 
-    def forward(self, x, residual=None, relu=None):
+    def forward(self, x, residual=None, relu=None, stats=None):
         relu = self.fuse_relu if relu is None else relu
         if not x.is_cuda:
             raise RuntimeError("dsf_amd FusedBatchNorm2d runs on the GPU only (got %s)" % x.device)
@@ -129,7 +137,8 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
                 mom = self.momentum
                 rm = self.running_mean if (self.training and self.track_running_stats) else None
                 rv = self.running_var if (self.training and self.track_running_stats) else None
-                return _BNFunction.apply(x, residual, self.weight, self.bias, rm, rv, self.eps, mom, relu)
+                part, rows = stats if stats is not None else (None, 0)
+                return _BNFunction.apply(x, residual, self.weight, self.bias, rm, rv, self.eps, mom, relu, part, rows)
             if torch.is_grad_enabled() and (x.requires_grad or (residual is not None and residual.requires_grad) or
                                             (self.weight is not None and self.weight.requires_grad) or
                                             (self.bias is not None and self.bias.requires_grad)):
@@ -161,3 +170,32 @@ def bn_act(bn, x, residual=None, relu=False):
     if residual is not None:
         y = y + residual
     return F.relu(y) if relu else y
+
+
+# BatchNorm statistics from the producing convolution's epilogue (DSF_BN_EPILOGUE=0: the separate reduction pass)
+EPILOGUE_STATS = [os.environ.get("DSF_BN_EPILOGUE", "1") == "1"]
+
+
+def conv_bn_act(conv, bn, x, residual=None, relu=None):
+    """``bn(conv(x))`` (+ residual) (relu) with the BatchNorm batch statistics taken from the convolution's epilogue when
+    both are this package's HIP layers in training mode (one pass over the convolution output less, two launches instead of
+    three); any other combination is the plain composition."""
+    from . import nn_conv
+    fusable = (EPILOGUE_STATS[0] and isinstance(bn, FusedBatchNorm2d) and isinstance(conv, (nn_conv.Conv2d, nn_conv.ConvTranspose2d)) and bn.training and
+               bn.track_running_stats and conv.bias is None and x.is_cuda and supported(bn.num_features) and nn_conv.STATS is None)
+    if not fusable:
+        return bn_act(bn, conv(x), residual, relu if relu is not None else getattr(bn, "fuse_relu", False))
+    req = nn_conv.StatsRequest()
+    nn_conv.STATS = req
+    try:
+        y = conv(x)
+    finally:
+        nn_conv.STATS = None
+    return bn(y, residual, relu, stats=(req.part, req.rows) if req.rows else None)
+
+
+class ConvBN(nn.Sequential):
+    """nn.Sequential(conv, bn[, nn.Identity]) -- same indices and state-dict keys -- evaluated through ``conv_bn_act``."""
+
+    def forward(self, x):
+        return conv_bn_act(self[0], self[1], x)

@@ -425,6 +425,22 @@ int dsf_adamw_multi(const uint64_t* ptrs, const int64_t* sizes, const int32_t* c
                     double weight_decay, double bias_correction1, double bias_correction2, dsf_stream_t stream);
 
 /* ----------------------------------------------------------------------------------
+ * Convolution + BatchNorm statistics in one pass (conv -> BatchNorm pairs of model/resnet.py, model/backbone.py).
+ * dsf_conv_x6_forward_bn = dsf_conv_x6_forward without a bias that ALSO writes, per 64 / 128 / 256-row output tile, one
+ * partial row [2][Co] (per-channel sum and sum of squares of the tile) into bn_stats -- when the launch it chooses can
+ * (unsplit reduction, weight-direct kernel); *bn_rows (host) = the number of rows written, 0 = none (the caller then runs
+ * the ordinary dsf_bn_forward).  bn_stats: dsf_conv_x6_bn_stats_rows(B, Ho, Wo) * 2 * Co floats.
+ * dsf_bn_forward_from_stats = dsf_bn_forward with its statistics pass replaced by those rows (finalise + apply).
+ * ---------------------------------------------------------------------------------- */
+int dsf_conv_x6_bn_stats_rows(int B, int Ho, int Wo);
+int dsf_conv_x6_forward_bn(const float* X, const void* image, float* Y, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
+                           int KH, int KW, int stride, int dil, int pad_h, int pad_w, float* bn_stats, int* bn_rows,
+                           dsf_stream_t stream);
+int dsf_bn_forward_from_stats(const float* x, const float* residual, const float* gamma, const float* beta, int64_t M, int C,
+                              float eps, float momentum, int relu, float* running_mean, float* running_var, float* y,
+                              float* save_mean, float* save_invstd, const float* part, int rows, dsf_stream_t stream);
+
+/* ----------------------------------------------------------------------------------
  * Training-phase augmentation of cropped frames: `loader.augmentCrop`
  * (/root/reference/data/render_loader.py:653-695 = rotateHand :458-497 / moveCoM :427-456 / scaleHand :499-527 through
  * recropHand :403-424, then normalize_img :738-745) for a batch, replacing the cv2 / numpy DataLoader workers.

@@ -235,3 +235,94 @@ def test_x6_random_geometries_against_float64():
         assert kinds.count("x6") >= 30, kinds          # the sweep really exercised the split kernels
     finally:
         nn_conv.RECORD = saved
+
+
+@pytest.mark.parametrize("kind,Ci,Co,K,s,p,H,B,res", [
+    ("conv", 64, 64, 3, 1, 1, 64, 16, True),         # BasicBlock conv2 + skip (BN 64: the 256-row tile)
+    ("conv", 64, 128, 3, 2, 1, 64, 32, False),       # stride 2 (64-row tiles)
+    ("conv", 64, 128, 1, 2, 0, 32, 4, False),        # downsample 1x1
+    ("conv", 128, 128, 3, 1, 1, 33, 31, True),       # M tail: rows of the last tile past M must not count
+    ("conv", 256, 512, 3, 1, 1, 32, 12, False),      # four column tiles
+    ("conv", 512, 2048, 1, 1, 0, 32, 3, False),      # Bottleneck expansion (C = 2048: two BN column blocks)
+    ("deconv", 512, 256, 4, 2, 1, 32, 6, False),     # decoder transposed convolution (dil-2 gather)
+    ("deconv", 128, 64, 4, 2, 1, 32, 13, False),
+])
+def test_bn_statistics_from_the_conv_epilogue_equal_the_reduction_pass(kind, Ci, Co, K, s, p, H, B, res):
+    """dsf_conv_x6_forward_bn + dsf_bn_forward_from_stats (statistics as per-tile partial rows written by the convolution
+    epilogue) against conv -> dsf_bn_forward: same output / saved statistics / running buffers to accumulation-order noise
+    and the same gradients; the request is honoured (rows > 0) on these shapes."""
+    from dsf_amd import nn_conv, nn_norm
+    torch.manual_seed(3)
+    conv = (nn_conv.Conv2d(Ci, Co, K, s, p, bias=False) if kind == "conv"
+            else nn_conv.ConvTranspose2d(Ci, Co, K, stride=s, padding=p, output_padding=0, bias=False)).cuda()
+    nn_conv.weights_changed()
+    outs = []
+    for fused in (True, False):
+        bn = nn_norm.FusedBatchNorm2d(Co, momentum=0.1).cuda()
+        torch.manual_seed(7)
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.3, 0.3)
+        torch.manual_seed(11)
+        x = (torch.randn(B, Ci, H, H, device="cuda") + 0.5).requires_grad_(True)
+        with torch.no_grad():
+            Ho = conv(x).shape[-1]
+        r = torch.randn(B, Co, Ho, Ho, device="cuda").requires_grad_(True) if res else None
+        conv.weight.grad = None
+        nn_norm.EPILOGUE_STATS[0] = fused
+        try:
+            if fused:                                        # the request must be honoured, not silently dropped
+                req = nn_conv.StatsRequest()
+                nn_conv.STATS = req
+                try:
+                    with torch.no_grad():
+                        conv(x)
+                finally:
+                    nn_conv.STATS = None
+                assert req.rows > 0 and req.part is not None
+                rows_max = nn_conv.L.lib().dsf_conv_x6_bn_stats_rows(B, Ho, Ho)
+                assert req.rows <= rows_max and req.part.numel() == rows_max * 2 * Co
+            y = nn_norm.conv_bn_act(conv, bn, x, residual=r, relu=True)
+        finally:
+            nn_norm.EPILOGUE_STATS[0] = True
+        (y * torch.linspace(-1, 1, y.numel(), device="cuda").view_as(y)).sum().backward()
+        outs.append((y.detach(), bn.running_mean.clone(), bn.running_var.clone(), x.grad.clone(), conv.weight.grad.clone(),
+                     bn.weight.grad.clone(), bn.bias.grad.clone(), None if r is None else r.grad.clone(),
+                     int(bn.num_batches_tracked)))
+    a, b = outs
+    assert a[8] == b[8] == 1
+    for i, (u, v) in enumerate(zip(a[:8], b[:8])):
+        if u is None:
+            continue
+        assert _rel(u, v) < 2e-5, (i, _rel(u, v))
+    # and against float64 statistics of the convolution output itself
+    with torch.no_grad():
+        yc = conv(x).double()
+    m = yc.mean((0, 2, 3))
+    v = yc.var((0, 2, 3), unbiased=True)
+    assert _rel(a[1].double(), 0.1 * m) < 1e-5
+    assert _rel(a[2].double(), 0.9 + 0.1 * v) < 1e-5
+
+
+def test_bn_epilogue_request_is_declined_where_the_launch_cannot_serve_it():
+    """A convolution with a bias (the BN would have to see y + bias) never gets a statistics request; a launch that splits K
+    leaves rows = 0 and conv_bn_act takes the reduction pass -- same numbers either way."""
+    from dsf_amd import nn_conv, nn_norm
+    torch.manual_seed(5)
+    conv = nn_conv.Conv2d(512, 512, 3, 1, 1, bias=False).cuda()      # tiny M, long K: the launcher splits K
+    bn = nn_norm.FusedBatchNorm2d(512).cuda()
+    nn_conv.weights_changed()
+    x = torch.randn(2, 512, 4, 4, device="cuda")
+    y = nn_norm.conv_bn_act(conv, bn, x, relu=False)
+    with torch.no_grad():
+        yc = conv(x).double()
+    ref = (yc - yc.mean((0, 2, 3), keepdim=True)) / torch.sqrt(yc.var((0, 2, 3), unbiased=False, keepdim=True) + bn.eps)
+    assert _rel(y.detach().double(), ref) < 1e-4
+    cb = nn_conv.Conv2d(64, 64, 3, 1, 1, bias=True).cuda()
+    bb = nn_norm.FusedBatchNorm2d(64).cuda()
+    xb = torch.randn(2, 64, 16, 16, device="cuda")
+    yb = nn_norm.conv_bn_act(cb, bb, xb, relu=False)
+    with torch.no_grad():
+        yc = cb(xb).double()
+    ref = (yc - yc.mean((0, 2, 3), keepdim=True)) / torch.sqrt(yc.var((0, 2, 3), unbiased=False, keepdim=True) + bb.eps)
+    assert _rel(yb.detach().double(), ref) < 1e-4
