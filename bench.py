@@ -277,6 +277,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
     ap.add_argument("--backbone", default="ResNet_stage_18")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay forward+backward from a HIP graph (train_step.GraphedStep; "
+                    "single GPU): same kernels, no host issue -- pays below batch 16, where the step is host-bound")
     ap.add_argument("--cpu-steps", type=int, default=60)
     args = ap.parse_args()
 
@@ -313,14 +315,20 @@ def main():
     p, c, cube = synthetic_batch(args.batch, dev, seed=0 + rank)           # per-rank shard of the global batch
     tgt = step.make_targets(p, c, cube, seed=1 + rank)
 
+    run = step
+    if args.graph:
+        if world > 1:
+            raise SystemExit("--graph is single-GPU (the bucketed all-reduce overlaps the eager backward)")
+        from dsf_amd.train_step import GraphedStep
+        run = GraphedStep(step, tgt)
     for _ in range(args.warmup):
-        step(tgt)
+        run(tgt)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, _ = step(tgt)
+        loss, _ = run(tgt)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -343,7 +351,7 @@ def main():
                                                                 if os.environ.get("DSF_CONV_MATH", "x6") == "x6" else ": fp32 MFMA"),
             "config": {"workload": "BASELINE configs[1]: batch=%d/GPU %s 2-stage + MANO + depth rasteriser, single view"
                                    % (args.batch, args.backbone),
-                       "global_batch": args.batch * world, "crop": 128, "raster": 640, "parallelism": "dp%d" % world,
+                       "global_batch": args.batch * world, "hip_graph": bool(args.graph), "crop": 128, "raster": 640, "parallelism": "dp%d" % world,
                        "mano_asset": "synthetic MANO-shaped hand (real MANO_RIGHT.pkl is license-gated)"},
             "final_loss": round(loss_val, 5),
             "distributed": facts,

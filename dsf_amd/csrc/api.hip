@@ -22,3 +22,24 @@ static int g_deterministic = [] { const char* e = getenv("DSF_DETERMINISTIC"); r
 int dsf_deterministic() { return g_deterministic; }
 extern "C" int dsf_set_deterministic(int on) { const int old = g_deterministic; g_deterministic = on ? 1 : 0; return old; }
 extern "C" int dsf_get_deterministic(void) { return g_deterministic; }
+
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void zero_kernel(T* __restrict__ p, size_t n) {
+    T z; __builtin_memset(&z, 0, sizeof(T));
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = z;
+}
+}  // namespace
+
+hipError_t dsf_zero_async(void* ptr, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return hipSuccess;
+    if (!ptr) return hipErrorInvalidValue;
+    auto grid = [](size_t n) { const size_t g = (n + 255) / 256; return dim3((unsigned)(g < 4096 ? g : 4096)); };
+    if ((((uintptr_t)ptr | bytes) & 15) == 0)
+        hipLaunchKernelGGL(zero_kernel<uint4>, grid(bytes / 16), dim3(256), 0, stream, (uint4*)ptr, bytes / 16);
+    else if ((((uintptr_t)ptr | bytes) & 3) == 0)
+        hipLaunchKernelGGL(zero_kernel<uint32_t>, grid(bytes / 4), dim3(256), 0, stream, (uint32_t*)ptr, bytes / 4);
+    else
+        hipLaunchKernelGGL(zero_kernel<uint8_t>, grid(bytes), dim3(256), 0, stream, (uint8_t*)ptr, bytes);
+    return hipGetLastError();
+}

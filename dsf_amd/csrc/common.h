@@ -13,6 +13,11 @@ static inline int dsf_launch_status() {
     return hipGetLastError() == hipSuccess ? DSF_OK : DSF_ERR_LAUNCH;
 }
 
+// Zero fill by a kernel (api.hip).  NOT hipMemsetAsync: a memset node captured into a HIP graph does not replay
+// correctly on ROCm 7.2 (tools/graph_memset.py: the second replay leaves inf/garbage for sizes between 256 B and
+// ~300 KB), and every launcher here must be capturable (train_step.GraphedStep).  Returns hipSuccess or an error.
+hipError_t dsf_zero_async(void* ptr, size_t bytes, hipStream_t stream);
+
 // Deterministic mode (dsf_set_deterministic(1) / DSF_DETERMINISTIC=1): every backward accumulation that many
 // lanes add into gives bit-identical results run to run.  Host launchers read the flag with dsf_deterministic().
 int dsf_deterministic();

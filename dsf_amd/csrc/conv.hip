@@ -966,7 +966,7 @@ static int conv_forward_impl(const float* X, const float* W, const float* bias, 
     if (ks_env > 0) k_splits = ks_env > live_chunks ? live_chunks : ks_env;
     if (dsf_deterministic()) k_splits = 1;                               // no float atomics in the epilogue
     if (k_splits > 1 &&
-        hipMemsetAsync(Y, 0, sizeof(float) * (size_t)M * Co, (hipStream_t)stream) != hipSuccess) return DSF_ERR_LAUNCH;
+        dsf_zero_async(Y, sizeof(float) * (size_t)M * Co, (hipStream_t)stream) != hipSuccess) return DSF_ERR_LAUNCH;
     const dim3 grid(m_tiles * n_tiles * k_splits);
     if (fast2) {
 #define DSF_LAUNCH_DIL2(BNv, BKv, WTv) hipLaunchKernelGGL((igemm_fwd_dil2_kernel<BNv, BKv, WTv>), grid, dim3(256), 0, (hipStream_t)stream, \
@@ -1032,7 +1032,7 @@ extern "C" int dsf_conv_igemm_wrw(const float* X, const float* dY, float* dW, in
     const int K = KH * KW * Ci;
     // accumulate != 0: dW += ... (the caller zeroed it, e.g. one memset over a whole gradient pool, or wants accumulation)
     if (!accumulate &&
-        hipMemsetAsync(dW, 0, sizeof(float) * (size_t)K * Co, (hipStream_t)stream) != hipSuccess) return DSF_ERR_LAUNCH;
+        dsf_zero_async(dW, sizeof(float) * (size_t)K * Co, (hipStream_t)stream) != hipSuccess) return DSF_ERR_LAUNCH;
     if (B == 0) return DSF_OK;
     ConvP p = {B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, 1, pad_h, pad_w};
     const int64_t M = (int64_t)B * Ho * Wo;

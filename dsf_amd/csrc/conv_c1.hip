@@ -165,7 +165,7 @@ int dsf_conv_c1_wrw(const float* X, const float* dY, float* dW, float* workspace
     if (!c1_ok(Co, K, stride)) return DSF_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     if (B == 0) {
-        if (!accumulate && hipMemsetAsync(dW, 0, sizeof(float) * K * K * Co, st) != hipSuccess) return DSF_ERR_LAUNCH;
+        if (!accumulate && dsf_zero_async(dW, sizeof(float) * K * K * Co, st) != hipSuccess) return DSF_ERR_LAUNCH;
         return DSF_OK;
     }
     C1P p = {B, Hi, Wi, Ho, Wo, Co, pad};

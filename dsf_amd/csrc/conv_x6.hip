@@ -888,7 +888,7 @@ static int x6_forward_impl(const float* X, const void* image, const float* bias,
     if (k_splits > n_chunks) k_splits = n_chunks > 0 ? n_chunks : 1;
     if (dsf_deterministic()) k_splits = 1;                               // no float atomics in the epilogue
     if (k_splits > 1 &&
-        hipMemsetAsync(Y, 0, sizeof(float) * (size_t)M * Co, (hipStream_t)stream) != hipSuccess) return DSF_ERR_LAUNCH;
+        dsf_zero_async(Y, sizeof(float) * (size_t)M * Co, (hipStream_t)stream) != hipSuccess) return DSF_ERR_LAUNCH;
     const dim3 grid(m_tiles * n_tiles * k_splits);
     // BatchNorm statistics in the epilogue: only the B-direct kernels, unsplit, without a bias
     const bool direct_pre = bdirect && !(bmt == 64 && n_tiles >= 2);
@@ -964,7 +964,7 @@ int dsf_conv_x6_wrw_ws(const float* X, const float* dY, float* dW, int B, int Hi
     const bool det = dsf_deterministic() != 0;
     DSF_CHECK_ARG(!det || workspace || B == 0);
     if (!accumulate && !(det && B > 0) &&
-        hipMemsetAsync(dW, 0, sizeof(float) * (size_t)K * Co, (hipStream_t)stream) != hipSuccess) return DSF_ERR_LAUNCH;
+        dsf_zero_async(dW, sizeof(float) * (size_t)K * Co, (hipStream_t)stream) != hipSuccess) return DSF_ERR_LAUNCH;
     if (B == 0) return DSF_OK;
     X6P p = {B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad_h, pad_w};
     const int64_t M = (int64_t)B * Ho * Wo;

@@ -307,7 +307,7 @@ extern "C" int dsf_collision_backward(const dsf_sphere_model* sm, const float* j
                                       dsf_stream_t stream) {
     DSF_CHECK_ARG(sm && joints && mesh && centres && radii && topk_idx && grad_rows && grad_joints && grad_mesh);
     DSF_CHECK_ARG(B >= 0 && V >= 778);
-    if (hipMemsetAsync(grad_mesh, 0, sizeof(float) * 3 * (size_t)B * V, (hipStream_t)stream) != hipSuccess)
+    if (dsf_zero_async(grad_mesh, sizeof(float) * 3 * (size_t)B * V, (hipStream_t)stream) != hipSuccess)
         return DSF_ERR_LAUNCH;
     if (B == 0) return DSF_OK;
     if (dsf_deterministic())

@@ -87,7 +87,7 @@ inline int aligned16(const void* a, const void* b, const void* c) {
 extern "C" int dsf_huber_mean_forward(const float* x, const float* y, int64_t n, float delta, float scale, float* loss,
                                       float* workspace, dsf_stream_t stream) {
     DSF_CHECK_ARG(loss && n >= 0 && delta > 0.f);
-    if (n == 0) return hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)stream) == hipSuccess ? DSF_OK : DSF_ERR_LAUNCH;
+    if (n == 0) return dsf_zero_async(loss, sizeof(float), (hipStream_t)stream) == hipSuccess ? DSF_OK : DSF_ERR_LAUNCH;
     DSF_CHECK_ARG(x && y);
     int blocks = (int)((n + 4095) / 4096);                     // >= 16 elements per thread
     if (blocks > MAX_PARTIALS) blocks = MAX_PARTIALS;

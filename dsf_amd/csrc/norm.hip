@@ -437,7 +437,7 @@ extern "C" int dsf_col_sum(const float* x, int64_t M, int C, float* out, float* 
         hipLaunchKernelGGL(col_sum_combine_kernel, dim3((C + 63) / 64), dim3(256), 0, st, workspace, wgs, C, out);
         return dsf_launch_status();
     }
-    if (hipMemsetAsync(out, 0, sizeof(float) * C, st) != hipSuccess) return DSF_ERR_LAUNCH;
+    if (dsf_zero_async(out, sizeof(float) * C, st) != hipSuccess) return DSF_ERR_LAUNCH;
     int cpad = 1;
     while (cpad < C && cpad < 256) cpad <<= 1;         // columns handled per pass (power of two <= 256)
     int64_t rows = (M + 255) / 256;

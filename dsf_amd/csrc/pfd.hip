@@ -304,8 +304,8 @@ extern "C" int dsf_point_face_dist_backward(const float* points, const float* tr
                                             const float* grad_dists, int64_t P, int64_t T, float* grad_points,
                                             float* grad_tris, dsf_stream_t stream) {
     DSF_CHECK_ARG(idxs && grad_dists && grad_points && grad_tris && P >= 0 && T >= 0);
-    if (hipMemsetAsync(grad_points, 0, sizeof(float) * 3 * P, (hipStream_t)stream) != hipSuccess ||
-        hipMemsetAsync(grad_tris, 0, sizeof(float) * 9 * T, (hipStream_t)stream) != hipSuccess)
+    if (dsf_zero_async(grad_points, sizeof(float) * 3 * P, (hipStream_t)stream) != hipSuccess ||
+        dsf_zero_async(grad_tris, sizeof(float) * 9 * T, (hipStream_t)stream) != hipSuccess)
         return DSF_ERR_LAUNCH;
     if (P == 0) return DSF_OK;
     hipLaunchKernelGGL(pfd_packed_bwd_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
@@ -332,7 +332,7 @@ extern "C" int dsf_mesh_point_dist_backward(const float* verts, const float* poi
                                             const int32_t* idxs, const float* grad_dists, int B, int V, int P,
                                             float* grad_verts, float* grad_points, dsf_stream_t stream) {
     DSF_CHECK_ARG(verts && points && faces && idxs && grad_dists && grad_verts && B >= 0 && V > 0 && V <= BWD_MAX_V);
-    if (hipMemsetAsync(grad_verts, 0, sizeof(float) * 3 * (size_t)B * V, (hipStream_t)stream) != hipSuccess)
+    if (dsf_zero_async(grad_verts, sizeof(float) * 3 * (size_t)B * V, (hipStream_t)stream) != hipSuccess)
         return DSF_ERR_LAUNCH;
     if (B == 0 || P == 0) return DSF_OK;
     if (dsf_deterministic()) {                    // one workgroup per sample: its fixed-point table holds the whole sum

@@ -708,7 +708,7 @@ extern "C" int dsf_rasterize_meshes_backward(const float* face_verts, const int6
                                              dsf_stream_t stream) {
     DSF_CHECK_ARG(face_verts && pix_to_face && grad_zbuf && grad_face_verts && N >= 0 && image_size > 0);
     if (grad_bary || grad_dists) return DSF_ERR_UNSUPPORTED;     // the reference consumes zbuf only (:1023)
-    if (hipMemsetAsync(grad_face_verts, 0, sizeof(float) * 9 * F_total, (hipStream_t)stream) != hipSuccess)
+    if (dsf_zero_async(grad_face_verts, sizeof(float) * 9 * F_total, (hipStream_t)stream) != hipSuccess)
         return DSF_ERR_LAUNCH;
     const int64_t npix = (int64_t)N * image_size * image_size;
     if (npix == 0) return DSF_OK;
@@ -751,7 +751,7 @@ extern "C" int dsf_render_crop_backward(const float* verts, const int32_t* faces
     DSF_CHECK_ARG(verts && faces && minv && resize_rowmap && cam && pix_to_face && grad_img && grad_verts);
     DSF_CHECK_ARG(B >= 0 && V > 0 && V <= CROP_MAX_V && F >= 0 && crop > 0);
     DSF_CHECK_ARG((center_z == nullptr) == (cube_z == nullptr));
-    if (hipMemsetAsync(grad_verts, 0, sizeof(float) * 3 * (size_t)B * V, (hipStream_t)stream) != hipSuccess)
+    if (dsf_zero_async(grad_verts, sizeof(float) * 3 * (size_t)B * V, (hipStream_t)stream) != hipSuccess)
         return DSF_ERR_LAUNCH;
     if (B == 0) return DSF_OK;
     if (dsf_deterministic()) {

@@ -226,10 +226,10 @@ int dsf_part_intersection_volume(const float* verts, const int32_t* faces, const
     DSF_CHECK_ARG(B >= 0 && V > 0 && n_parts > 0 && n_parts <= MAX_PARTS && n_faces > 0 && n_pairs >= 0 && pitch > 0.0);
     DSF_CHECK_ARG(grid >= 32 && (grid & 31) == 0 && grid <= 512 && max_part_faces > 0 && max_part_faces * 36 <= 64 * 1024);
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(count, 0, sizeof(unsigned long long) * (size_t)(B > 0 ? B : 1), st) != hipSuccess) return DSF_ERR_LAUNCH;
+    if (dsf_zero_async(count, sizeof(unsigned long long) * (size_t)(B > 0 ? B : 1), st) != hipSuccess) return DSF_ERR_LAUNCH;
     if (pair_count && B * n_pairs > 0 &&
-        hipMemsetAsync(pair_count, 0, sizeof(int32_t) * (size_t)B * n_pairs, st) != hipSuccess) return DSF_ERR_LAUNCH;
-    if (hipMemsetAsync(status, 0, sizeof(int32_t), st) != hipSuccess) return DSF_ERR_LAUNCH;
+        dsf_zero_async(pair_count, sizeof(int32_t) * (size_t)B * n_pairs, st) != hipSuccess) return DSF_ERR_LAUNCH;
+    if (dsf_zero_async(status, sizeof(int32_t), st) != hipSuccess) return DSF_ERR_LAUNCH;
     if (B == 0 || n_pairs == 0) return DSF_OK;
     VolP p = {B, V, n_parts, grid, pitch, pitch / 2.0};           // trimesh voxelize_subdivide: edge_factor = 2
     char* ws = (char*)workspace;
@@ -237,7 +237,7 @@ int dsf_part_intersection_volume(const float* verts, const int32_t* faces, const
     float* bbox = (float*)(origin + (int64_t)B * n_parts * 3);
     uint32_t* mask = (uint32_t*)(bbox + (int64_t)B * n_parts * 6);
     const int64_t words = (int64_t)grid * grid * grid / 32;
-    if (hipMemsetAsync(mask, 0, (size_t)B * n_parts * words * 4, st) != hipSuccess) return DSF_ERR_LAUNCH;
+    if (dsf_zero_async(mask, (size_t)B * n_parts * words * 4, st) != hipSuccess) return DSF_ERR_LAUNCH;
     hipLaunchKernelGGL(vox_origin_kernel, dim3(B * n_parts), dim3(256), 0, st, verts, faces, part_first, p, origin, bbox, status);
     const int64_t waves = (int64_t)B * n_faces;
     hipLaunchKernelGGL(vox_mark_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, verts, faces, part_first, origin, p,

@@ -137,13 +137,22 @@ class PoseNet(nn.Module):
         return preds_all, hg
 
 
+class GlobalAvgPool2d(nn.Module):
+    """nn.AdaptiveAvgPool2d(1) as two single-pass sums (over W, then over H).  torch's one-shot mean over a large H x W
+    to B x C outputs is a multi-block reduction whose semaphores are zeroed by a hipMemsetAsync -- a node a captured HIP
+    graph does not replay correctly on ROCm 7.2 (train_step.GraphedStep refuses such graphs)."""
+
+    def forward(self, x):
+        return (x.sum(3).sum(2) * (1.0 / (x.shape[2] * x.shape[3]))).reshape(x.shape[0], x.shape[1], 1, 1)
+
+
 class PoseNetMANO(nn.Module):
     """PoseNet + a pooled linear head regressing the 62 MANO parameters (BASELINE config 3)."""
 
     def __init__(self, nstack=2, joint_num=21):
         super().__init__()
         self.body = PoseNet(nstack, joint_num)
-        self.mano_regress = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(256, 62))
+        self.mano_regress = nn.Sequential(GlobalAvgPool2d(), nn.Flatten(), nn.Linear(256, 62))
         nn.init.normal_(self.mano_regress[2].weight, std=0.001)
         nn.init.zeros_(self.mano_regress[2].bias)
 

@@ -113,7 +113,8 @@ class RenderSupervisedStep:
         # one stack + one sum instead of a chain of scalar adds (and their backward kernels)
         return torch.stack(list(terms.values())).sum(), terms
 
-    def __call__(self, tgt):
+    def forward_backward(self, tgt):
+        """Everything of the step that runs on the device without host decisions (the part ``GraphedStep`` captures)."""
         from . import nn_conv
         self.opt.zero_grad(set_to_none=True)
         self.render.mano_layer.clear_cache()                 # results of the previous step must not outlive its graph
@@ -123,10 +124,14 @@ class RenderSupervisedStep:
             self._pool_dev = next(self.net.parameters()).device
         with nn_conv.grad_pool(self._pool_floats if self._pool_dev.type == "cuda" else 0, self._pool_dev):
             loss.backward()
+        return loss.detach(), terms
+
+    def __call__(self, tgt):
+        out = self.forward_backward(tgt)
         if self.grad_sync is not None:
             self.grad_sync.finish()
         self.opt.step()
-        return loss.detach(), terms
+        return out
 
 
 class MeshLossStep:
@@ -180,15 +185,141 @@ class MeshLossStep:
         terms = {"m2d": l_m2d, "pd2m": l_part, "d2m": l_icp, "coll": l_coll, "sup": l_sup}
         return l_m2d + l_part + l_icp + l_coll + l_sup, terms
 
-    def __call__(self, tgt):
+    def forward_backward(self, tgt):
         self.opt.zero_grad(set_to_none=True)
         self.render.mano_layer.clear_cache()                 # results of the previous step must not outlive its graph
         loss, terms = self.loss(tgt)
         loss.backward()
+        return loss.detach(), terms
+
+    def __call__(self, tgt):
+        out = self.forward_backward(tgt)
         if self.grad_sync is not None:
             self.grad_sync.finish()
         self.opt.step()
-        return loss.detach(), terms
+        return out
+
+
+def _graph_node_types(raw_graph):
+    """{hipGraphNodeType: count} of a captured graph (0 kernel, 1 memcpy, 2 memset, ...) through the HIP runtime."""
+    import collections
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    n = ctypes.c_size_t(0)
+    if hip.hipGraphGetNodes(ctypes.c_void_p(raw_graph), None, ctypes.byref(n)) != 0:
+        raise RuntimeError("hipGraphGetNodes failed")
+    nodes = (ctypes.c_void_p * max(n.value, 1))()
+    if n.value and hip.hipGraphGetNodes(ctypes.c_void_p(raw_graph), nodes, ctypes.byref(n)) != 0:
+        raise RuntimeError("hipGraphGetNodes failed")
+    types = collections.Counter()
+    for i in range(n.value):
+        ty = ctypes.c_int(-1)
+        if hip.hipGraphNodeGetType(ctypes.c_void_p(nodes[i]), ctypes.byref(ty)) != 0:
+            raise RuntimeError("hipGraphNodeGetType failed")
+        types[ty.value] += 1
+    return dict(types)
+
+
+class GraphedStep:
+    """``forward_backward`` of a step (RenderSupervisedStep, MeshLossStep) captured ONCE in a HIP graph and replayed per
+    batch: the ~700 launches of a step are issued by the driver from one graph launch instead of by the Python host, which
+    removes the host-issue gaps between the many small kernels (GPU busy 92 % -> 99 %).  The same
+    kernels run on the same data in the same order -- results are those of the eager step (tests/test_gpu_steps.py).
+    What stays eager, after each replay: the gradient all-reduce (``grad_sync``) and the optimizer step, whose learning
+    rate, bias corrections and per-parameter step counts are host state that changes from step to step.
+    Requirements, as for any stream capture: static shapes (one graph per batch shape), no host decision inside the step
+    (the occluder count of ``FinetuneStageStep`` is one -- that step is not graphable), batches are COPIED into the static
+    input buffers the graph reads.  The reference has no counterpart (PyTorch eager, train_render.py:636-823)."""
+
+    def __init__(self, step, tgt, warmup=2, validate=True):
+        if not torch.cuda.is_available():
+            raise RuntimeError("GraphedStep needs the GPU (HIP graph capture)")
+        self.step = step
+        self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in tgt.items()}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # eager warm-up on a side stream: allocator, lazy tables, weight images
+            for _ in range(warmup):
+                step(self.static)
+        torch.cuda.current_stream().wait_stream(side)
+        from .nn_norm import FusedBatchNorm2d
+        self._bns = [m for m in step.net.modules() if isinstance(m, FusedBatchNorm2d)]
+        before = [m._pending_batches for m in self._bns]
+        self.graph = torch.cuda.CUDAGraph(keep_graph=True)
+        with torch.cuda.graph(self.graph):
+            self.loss, self.terms = step.forward_backward(self.static)
+        self.node_types = _graph_node_types(self.graph.raw_cuda_graph())
+        if self.node_types.get(2, 0):
+            # hipGraphNodeTypeMemset: does not replay correctly on ROCm 7.2 (tools/graph_memset.py).  csrc/ has none
+            # (tests/test_library_abi.py); torch's multi-block reductions (a large .mean()/.sum() to few outputs) zero
+            # their semaphores with one -- such a step captures fine and then replays wrong numbers at some later step.
+            raise RuntimeError("GraphedStep: the captured step holds %d memset node(s), which this ROCm runtime does not "
+                               "replay correctly (a torch multi-block reduction issues one); run this step eagerly or "
+                               "reduce in two stages (model/hourglass.py::GlobalAvgPool2d)" % self.node_types[2])
+        self.graph.instantiate()
+        # host-side bookkeeping the captured region did once (BatchNorm's deferred num_batches_tracked) is repeated per replay
+        self._bn_calls = [m._pending_batches - b for m, b in zip(self._bns, before)]
+        for m, b in zip(self._bns, before):
+            m._pending_batches = b                          # the capture itself ran no kernel
+        self._grads = [(p, p.grad) for p in step.net.parameters() if p.grad is not None]   # the tensors the graph writes
+        if validate:
+            self._validate()
+
+    def _validate(self):
+        """Two replays from the current state must reproduce the eager step (loss terms and gradients; bitwise in
+        deterministic mode), else the graph is refused.  Why this is not paranoia: on ROCm 7.2 a memset node does not
+        replay correctly (tools/graph_memset.py) -- this library has none (tests/test_library_abi.py), but torch's own
+        multi-block reductions zero their semaphores with hipMemsetAsync, and a step that contains one captures fine and
+        then replays wrong numbers.  The network state (BatchNorm statistics) is restored afterwards."""
+        from . import _lib as L
+        net = self.step.net
+        bufs = [(b, b.clone()) for b in net.buffers()]
+        pend = [m._pending_batches for m in self._bns]
+
+        def restore():
+            with torch.no_grad():
+                for b, c in bufs:
+                    b.copy_(c)
+            for m, n in zip(self._bns, pend):
+                m._pending_batches = n
+        _, terms = self.step.forward_backward(self.static)                    # eager, same state, same inputs
+        ref_t = torch.stack([v.detach().float().reshape(()) for v in terms.values()])
+        ref_g = {p: p.grad.detach().clone() for p, _ in self._grads if p.grad is not None}
+        restore()
+        exact = L.deterministic()
+        for p, g in self._grads:
+            p.grad = g                                                         # back to the tensors the graph writes
+        try:
+            for r in range(2):
+                self.graph.replay()
+                got_t = torch.stack([v.detach().float().reshape(()) for v in self.terms.values()])
+                if exact:
+                    ok = torch.equal(got_t, ref_t) and all(torch.equal(p.grad, ref_g[p]) for p, _ in self._grads if p in ref_g)
+                else:
+                    num = sum(((p.grad - ref_g[p]).double() ** 2).sum() for p, _ in self._grads if p in ref_g)
+                    den = sum((ref_g[p].double() ** 2).sum() for p, _ in self._grads if p in ref_g)
+                    ok = bool(((got_t - ref_t).abs() <= 2e-3 * ref_t.abs() + 1e-6).all()) and float(num) <= (2e-2 ** 2) * float(den)
+                restore()
+                if not ok:
+                    raise RuntimeError(
+                        "GraphedStep: replay %d of the captured step does not reproduce the eager step (terms %s vs %s). A "
+                        "captured hipMemsetAsync does not replay on this ROCm (torch's multi-block reductions issue one); run "
+                        "this step eagerly." % (r + 1, [round(float(v), 6) for v in got_t], [round(float(v), 6) for v in ref_t]))
+        finally:
+            restore()
+
+    def __call__(self, tgt=None):
+        if tgt is not None and tgt is not self.static:
+            for k, v in tgt.items():
+                if torch.is_tensor(v):
+                    self.static[k].copy_(v, non_blocking=True)
+        self.graph.replay()
+        for m, n in zip(self._bns, self._bn_calls):
+            m._pending_batches += n
+        if self.step.grad_sync is not None:
+            self.step.grad_sync.finish()
+        self.step.opt.step()
+        return self.loss, self.terms
 
 
 def draw_augmentation(B, device, generator=None, host_rng=None, n_joints=21, crop=128, views=1, depth_range=(500, 1200),

@@ -110,3 +110,68 @@ def test_flag_round_trip_and_wrw_scratch_contract():
     assert L.deterministic() == old
     if not old:
         assert int(L.lib().dsf_conv_x6_wrw_workspace_bytes(*(ctypes.c_int(v) for v in (4, 16, 16, 64, 64, 3, 3)))) == 0
+
+
+@pytest.mark.parametrize("kind", ["config2", "config3"])
+def test_graphed_step_equals_the_eager_step_bitwise(render, det_mode, kind):
+    """train_step.GraphedStep (forward + backward captured once in a HIP graph, replayed per batch; optimizer eager): in
+    deterministic mode the trajectory -- losses, parameters, BatchNorm buffers incl. num_batches_tracked -- is BITWISE the
+    eager one over several steps and a change of batch, and pure replays reproduce themselves (a captured hipMemsetAsync
+    did not on ROCm 7.2, tools/graph_memset.py: every zero fill in csrc/ is a kernel)."""
+    from dsf_amd.model.backbone import MANO_OCR_stage
+    from dsf_amd.model.hourglass import PoseNetMANO
+    from dsf_amd.train_step import RenderSupervisedStep, MeshLossStep, GraphedStep, synthetic_batch, Config
+
+    def make():
+        torch.manual_seed(0)
+        if kind == "config2":
+            net = MANO_OCR_stage("ResNet_stage_18", 21, True).cuda()
+            with torch.no_grad():
+                for head in (net.mano_regress[2], net.mano_regress_s2[2]):
+                    head.bias[58] = 1.0
+            return RenderSupervisedStep(net, render, Config)
+        net = PoseNetMANO(1, 21).cuda()
+        return MeshLossStep(net, render, Config, n_points=512)
+    eager, other = make(), make()
+    tgts = []
+    for seed in (2, 5):
+        p, c, cube = synthetic_batch(4, "cuda", seed=seed)
+        tgts.append(eager.make_targets(p, c, cube))
+    graphed = GraphedStep(other, tgts[0], warmup=2)
+    assert graphed.node_types.get(2, 0) == 0 and graphed.node_types.get(0, 0) > 300          # kernels only (+ a few copies)
+    for _ in range(2):
+        eager(tgts[0])
+    seq = [tgts[0], tgts[0], tgts[1], tgts[0]]
+    for t in seq:
+        le, _ = eager(t)
+        lg, _ = graphed(t)
+        assert torch.equal(le, lg)
+    for (n, a), b in zip(eager.net.named_parameters(), other.net.parameters()):
+        assert torch.equal(a, b), n
+    for (n, a), (_, b) in zip(eager.net.state_dict().items(), other.net.state_dict().items()):
+        assert torch.equal(a, b), n                                      # running statistics and the batch counters
+    # pure replays from one state reproduce themselves
+    graphed.graph.replay()
+    torch.cuda.synchronize()
+    first = [p.grad.clone() for p in other.net.parameters() if p.grad is not None]
+    for _ in range(3):
+        graphed.graph.replay()
+    torch.cuda.synchronize()
+    for a, p in zip(first, [p for p in other.net.parameters() if p.grad is not None]):
+        assert torch.equal(a, p.grad)
+
+
+def test_graphed_step_refuses_a_graph_with_memset_nodes(render):
+    """A step holding a torch multi-block reduction (here: a one-shot global mean over a channels-last map) captures a
+    hipMemsetAsync node; GraphedStep must refuse it rather than replay wrong numbers at some later step."""
+    from dsf_amd.model.hourglass import PoseNetMANO
+    from dsf_amd.train_step import MeshLossStep, GraphedStep, synthetic_batch, Config
+    torch.manual_seed(0)
+    net = PoseNetMANO(1, 21).cuda()
+    net.mano_regress[0] = torch.nn.AdaptiveAvgPool2d(1)
+    step = MeshLossStep(net, render, Config, n_points=512)
+    p, c, cube = synthetic_batch(4, "cuda", seed=2)
+    tgt = step.make_targets(p, c, cube)
+    with pytest.raises(RuntimeError, match="memset node"):
+        GraphedStep(step, tgt, warmup=1)
+    step(tgt)                                                        # the step itself is untouched and still runs eagerly

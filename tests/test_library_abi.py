@@ -77,3 +77,18 @@ def test_model_buffers_match_reference(golden):
     assert np.array_equal(m.mask.numpy().astype(np.uint8), golden["mano_coll_mask"])
     assert np.array_equal(m.parents, golden["mano_parents"])
     assert m.transfer == [18, 8, 19, 11, 17, 5, 16, 2, 20, 15, 14, 0]
+
+
+def test_library_is_capturable_no_memset_nodes():
+    """Every launcher must be capturable into a HIP graph (train_step.GraphedStep); a captured hipMemsetAsync does not
+    replay correctly on ROCm 7.2 (tools/graph_memset.py), so csrc/ zero-fills with a kernel (dsf_zero_async), and nothing
+    there synchronises or copies through host memory."""
+    import glob
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dsf_amd", "csrc")
+    banned = re.compile(r"\b(hipMemsetAsync|hipMemset|hipMemcpyAsync|hipMemcpy|hipStreamSynchronize|hipDeviceSynchronize|hipMalloc|hipFree)\s*\(")
+    for f in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h"))):
+        for i, line in enumerate(open(f), 1):
+            code = line.split("//")[0]
+            assert not banned.search(code), "%s:%d %s" % (os.path.basename(f), i, line.strip())
