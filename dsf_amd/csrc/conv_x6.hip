@@ -443,6 +443,9 @@ __global__ __launch_bounds__(256, 2) void igemm_x6b_kernel(const float* __restri
     const int vH = (p.Hi - 1) * 2 + 1, vW = (p.Wi - 1) * 2 + 1;
 
     u32x4 ra[2][APASS];
+#ifdef DSF_X6_APPLY_PROBE
+    u32x4 rsc[2], rsh[2]; uint32_t rok[2] = {0u, 0u};
+#endif
     u32x4 rbf[2][3][TN];                                 // [set][plane][n block]: B fragments as loaded
     // byte offset of this lane's granule inside a plane of an image block: (k-group, n)
     const uint32_t b_lane = (uint32_t)((lane >> 5) * BN + wn * 64 + (lane & 31)) * 16u;
@@ -472,6 +475,16 @@ __global__ __launch_bounds__(256, 2) void igemm_x6b_kernel(const float* __restri
             off = (uint32_t)(a_base[i] + (la.kh * p.Wi + la.kw) * p.Ci + la.c0);
         }
         ra[S][i] = x6_load16(xbuf, ok ? off * 4u : X_OOB);
+#ifdef DSF_X6_APPLY_PROBE
+        // MEASUREMENT PROBE (never shipped; DESIGN.md section 5 "BatchNorm apply in the consumer's loader"): the cost of
+        // y = max(x * scale[c] + shift[c], 0) on the A operand before the split -- per-channel vectors fetched with the
+        // tile (their VALUES are taken from the head of the weight image: timing only), padding kept at zero.
+        if (i == 0) {
+            rsc[S] = x6_load16(wbuf, (uint32_t)(la.c0 + a_k4) * 4u);
+            rsh[S] = x6_load16(wbuf, (uint32_t)(la.c0 + a_k4) * 4u + 4096u);
+        }
+        rok[S] = (rok[S] & ~(1u << i)) | ((ok ? 1u : 0u) << i);
+#endif
         if (i == APASS - 1) advance(la);
     };
     auto load_b = [&](auto SET, int f, bool live) {
@@ -486,6 +499,16 @@ __global__ __launch_bounds__(256, 2) void igemm_x6b_kernel(const float* __restri
     auto stage_piece = [&](auto SET, int buf, int i) {
         constexpr int S = decltype(SET)::value;
         uint2 h, m, l;
+#ifdef DSF_X6_APPLY_PROBE
+        {
+            const bool ok = (rok[S] >> i) & 1u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = fmaxf(fmaf(__uint_as_float(ra[S][i][e]), __uint_as_float(rsc[S][e]), __uint_as_float(rsh[S][e])), 0.f);
+                ra[S][i][e] = ok ? __float_as_uint(v) : 0u;
+            }
+        }
+#endif
         split4(ra[S][i], h, m, l);
         uint2* dst = reinterpret_cast<uint2*>(&As[buf][(a_q >> 1) * LA::KG + a_r + 64 * i]) + (a_q & 1);
         dst[0] = h; dst[2 * LA::SIZE] = m; dst[4 * LA::SIZE] = l;
