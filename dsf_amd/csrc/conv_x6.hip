@@ -688,6 +688,10 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
         constexpr int S = decltype(SET)::value;
         const int m = mc + l_p + 8 * (j & 1);
         if (j < 2) {
+#if defined(DSF_WRW_PROBE) && DSF_WRW_PROBE == 3
+            rl[S][j] = x6_load16(xbuf, (m < m_end) ? (uint32_t)(m * p.Ci + a_c) * 4u : X_OOB);             // (timing probe: linear addressing)
+            return;
+#endif
             const uint32_t mm = (uint32_t)min(m, M - 1);
             const uint32_t q = x6_fast_div(mm, magic_wo);
             const int ox = (int)(mm - q * (uint32_t)p.Wo);
@@ -707,7 +711,11 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
     auto stage_piece = [&](auto SET, int buf, int j) {
         constexpr int S = decltype(SET)::value;
         uint2 h, m, l;
+#if defined(DSF_WRW_PROBE) && DSF_WRW_PROBE == 1
+        h = make_uint2(rl[S][j][0], rl[S][j][1]); m = make_uint2(rl[S][j][2], rl[S][j][3]); l = h;      // (timing probe: no split VALU)
+#else
         split4(rl[S][j], h, m, l);
+#endif
         char* base = (j < 2 ? As[buf] : Bs[buf]) + ((j & 1) ? st_off1 : st_off0);
         *reinterpret_cast<uint2*>(base) = h;
         *reinterpret_cast<uint2*>(base + PLANE) = m;
@@ -754,7 +762,11 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
 #pragma unroll
             for (int i = 0; i < TM; ++i) a[pl][i] = tr_read(As[buf] + pl * PLANE, fa[i][0], fa[i][1]);
 #pragma unroll
+#if defined(DSF_WRW_PROBE) && DSF_WRW_PROBE == 2
+            for (int j = 0; j < TN; ++j) b[pl][j] = a[pl][j % TM];                                          // (timing probe: half the LDS reads)
+#else
             for (int j = 0; j < TN; ++j) b[pl][j] = tr_read(Bs[buf] + pl * PLANE, fb[j][0], fb[j][1]);
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
         constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};
