@@ -147,9 +147,13 @@ def test_x6_matches_float64_as_closely_as_the_fp32_mfma(Ci, Co, K, s, p, H, B, m
     wd = w.detach().double().cpu().requires_grad_(True)
     yd = F.conv2d(xd, wd, None, stride=s, padding=p)
     gxd, gwd = torch.autograd.grad((yd * gy.double().cpu()).sum(), [xd, wd])
+    from dsf_amd import _lib as L
+    # deterministic mode (DSF_DETERMINISTIC=1 in the environment) does not split the reduction: one fp32 accumulation chain
+    # over all of K instead of several shorter ones, hence a slightly larger -- still accumulation-order -- error
+    bar = 4e-6 if L.deterministic() else 2e-6
     for i, ref in enumerate((yd.detach(), gxd, gwd)):
         e6, e32 = _rel(out["x6"][i], ref), _rel(out["f32"][i], ref)
-        assert e6 < 2e-6, (i, e6)
+        assert e6 < bar, (i, e6)
         assert e6 < 3 * e32 + 1e-7, (i, e6, e32)
 
 
