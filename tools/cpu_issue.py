@@ -19,3 +19,14 @@ for trial in range(3):
         step(tgt); ts.append(time.perf_counter())
     torch.cuda.synchronize(); t_end = time.perf_counter()
     print("issue ms per step:", [round((b - a) * 1e3, 2) for a, b in zip(ts, ts[1:])], "  3 steps incl. drain:", round((t_end - ts[0]) * 1e3, 2))
+from dsf_amd.train_step import GraphedStep
+g = GraphedStep(step, tgt)
+for _ in range(3): g(tgt)
+for trial in range(2):
+    torch.cuda.synchronize()
+    ts = [time.perf_counter()]
+    for _ in range(3):
+        g(tgt); ts.append(time.perf_counter())
+    torch.cuda.synchronize(); t_end = time.perf_counter()
+    print("GraphedStep issue ms per step:", [round((b - a) * 1e3, 2) for a, b in zip(ts, ts[1:])], "  3 steps incl. drain:", round((t_end - ts[0]) * 1e3, 2),
+          " graph nodes:", g.node_types)
