@@ -52,7 +52,7 @@ SYMBOLS = [
     "dsf_huber_mean_forward", "dsf_huber_mean_backward", "dsf_adamw_multi", "dsf_adamw_chunk_elems",
     "dsf_maxpool_forward", "dsf_maxpool_backward", "dsf_part_volume_workspace_bytes", "dsf_part_intersection_volume",
     "dsf_set_deterministic", "dsf_get_deterministic", "dsf_conv_x6_wrw_workspace_bytes", "dsf_conv_x6_wrw_ws",
-    "dsf_depth_augment_crop", "dsf_conv_x6_bn_stats_rows", "dsf_conv_x6_forward_bn", "dsf_bn_forward_from_stats",
+    "dsf_depth_augment_crop", "dsf_conv_x6_bn_stats_rows", "dsf_conv_x6_forward_bn", "dsf_conv_x6_forward_affine", "dsf_bn_forward_from_stats",
 ]
 
 

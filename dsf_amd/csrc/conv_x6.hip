@@ -369,11 +369,13 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(const float* __restric
 // Tiles: BN 128: 128 x 128 (2 x 2 waves of 64 x 64) or 64 x 128 (2 x 2 waves of 32 x 64: the 8x8 .. 32x32 maps);
 //        BN 64:  256 x 64  (4 x 1 waves of 64 x 64): the 64-channel layers get the 64 x 64 wave tile too.
 // ------------------------------------------------------------------------------------------------
+struct X6Ep { const float* scale; const float* shift; const float* residual; int relu; };   // output epilogue (all null: none)
+
 template <int BN, bool DIL2, int BMT>
 __global__ __launch_bounds__(256, 2) void igemm_x6b_kernel(const float* __restrict__ X, const uint4* __restrict__ Wimg,
                                                           const float* __restrict__ bias, float* __restrict__ Y, X6P p,
                                                           int m_tiles, int n_tiles, int k_splits, uint32_t x_bytes,
-                                                          uint32_t w_bytes, float* __restrict__ stats) {
+                                                          uint32_t w_bytes, float* __restrict__ stats, X6Ep ep) {
     static_assert((BN == 128 && (BMT == 128 || BMT == 64)) || (BN == 64 && BMT == 256), "tile shapes");
     constexpr int WM = (BN == 128) ? BMT / 2 : 64;       // wave sub-tile WM x 64: 2 x 2 waves (BN 128) or 4 x 1 (BN 64)
     constexpr int TM = WM / 32, TN = 2;
@@ -580,6 +582,10 @@ __global__ __launch_bounds__(256, 2) void igemm_x6b_kernel(const float* __restri
             const int n = n0 + wn * 64 + j * 32 + (lane & 31);
             if (n >= p.Co) continue;
             const float bv = (bias && ks == 0) ? bias[n] : 0.f;
+            // fused output epilogue (unsplit launches only): y = max((acc + bias) * scale[n] + shift[n] + residual, 0) -- the
+            // frozen-statistics BatchNorm (+ skip connection)(+ ReLU) that follows the convolution in evaluation mode
+            const bool affine = ep.scale != nullptr;
+            const float es = affine ? ep.scale[n] : 1.f, et = affine ? ep.shift[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -591,7 +597,11 @@ __global__ __launch_bounds__(256, 2) void igemm_x6b_kernel(const float* __restri
                     row = ((int64_t)b * p.Ho + oy) * p.Wo + ox;
                 }
                 if (k_splits > 1) atomicAdd(Y + row * p.Co + n, acc[i][j][r] + bv);
-                else Y[row * p.Co + n] = acc[i][j][r] + bv;
+                else if (affine) {
+                    float v = fmaf(acc[i][j][r] + bv, es, et);
+                    if (ep.residual) v += ep.residual[row * p.Co + n];
+                    Y[row * p.Co + n] = ep.relu ? fmaxf(v, 0.f) : v;
+                } else Y[row * p.Co + n] = acc[i][j][r] + bv;
             }
         }
 
@@ -890,7 +900,7 @@ int dsf_conv_x6_split_weights_multi(const int64_t* jobs, int n_jobs, int64_t tot
 // Ci / Co are the reduction / output channel counts of the IMAGE (mode 1: those of the backward-data GEMM).
 static int x6_forward_impl(const float* X, const void* image, const float* bias, float* Y, int B, int Hi, int Wi, int Ci, int Ho,
                            int Wo, int Co, int KH, int KW, int stride, int dil, int pad_h, int pad_w, int k_splits,
-                           float* bn_stats, int* bn_rows, dsf_stream_t stream) {
+                           float* bn_stats, int* bn_rows, X6Ep ep, int* ep_applied, dsf_stream_t stream) {
     if (bn_rows) *bn_rows = 0;
     DSF_CHECK_ARG(X && image && Y && B >= 0 && Hi > 0 && Wi > 0 && Ci > 0 && Ho > 0 && Wo > 0 && Co > 0 && KH > 0 && KW > 0);
     DSF_CHECK_ARG(stride >= 1 && (Ci & 3) == 0 && (dil == 1 || (dil == 2 && stride == 1)));
@@ -929,12 +939,16 @@ static int x6_forward_impl(const float* X, const void* image, const float* bias,
     const bool direct_pre = bdirect && !(bmt == 64 && n_tiles >= 2);
     float* stats = (bn_stats && bn_rows && direct_pre && k_splits == 1 && !bias) ? bn_stats : nullptr;
     if (bn_rows) *bn_rows = stats ? m_tiles : 0;
+    // the affine output epilogue has the same conditions (a split reduction meets in Y by atomics; the staged kernel has none)
+    const bool ep_on = ep.scale && direct_pre && k_splits == 1;
+    if (!ep_on) ep = X6Ep{nullptr, nullptr, nullptr, 0};
+    if (ep_applied) *ep_applied = ep_on ? 1 : 0;
 #define DSF_LAUNCH_X6(KERNEL, BNv, DILv, BMv) hipLaunchKernelGGL((KERNEL<BNv, DILv, BMv>), grid, dim3(256), 0, (hipStream_t)stream, \
                                                        X, (const uint4*)image, bias, Y, p, m_tiles, n_tiles, k_splits,              \
                                                        (uint32_t)x_bytes, (uint32_t)w_bytes)
 #define DSF_LAUNCH_X6B(BNv, DILv, BMv) hipLaunchKernelGGL((igemm_x6b_kernel<BNv, DILv, BMv>), grid, dim3(256), 0, (hipStream_t)stream, \
                                                        X, (const uint4*)image, bias, Y, p, m_tiles, n_tiles, k_splits,              \
-                                                       (uint32_t)x_bytes, (uint32_t)w_bytes, stats)
+                                                       (uint32_t)x_bytes, (uint32_t)w_bytes, stats, ep)
     // 64-row tiles with several n tiles (16x16x256, 8x8x512 maps): every wave of the many small tiles would pull its own copy of
     // the weight block from L2 -- the LDS-staged kernel is faster there (measured 136 / 139 vs 133 / 133 TFLOP/s)
     const bool direct = bdirect && !(bmt == 64 && n_tiles >= 2);
@@ -970,7 +984,7 @@ int dsf_conv_x6_forward(const float* X, const void* image, const float* bias, fl
                         int Wo, int Co, int KH, int KW, int stride, int dil, int pad_h, int pad_w, int k_splits,
                         dsf_stream_t stream) {
     return x6_forward_impl(X, image, bias, Y, B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, dil, pad_h, pad_w, k_splits, nullptr, nullptr,
-                           stream);
+                           X6Ep{nullptr, nullptr, nullptr, 0}, nullptr, stream);
 }
 
 // partial rows a BatchNorm-statistics epilogue may write for an (M = B Ho Wo)-row output: one per 64 rows at most
@@ -981,7 +995,21 @@ int dsf_conv_x6_forward_bn(const float* X, const void* image, float* Y, int B, i
                            dsf_stream_t stream) {
     DSF_CHECK_ARG(bn_stats && bn_rows);
     return x6_forward_impl(X, image, nullptr, Y, B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, dil, pad_h, pad_w, 0, bn_stats, bn_rows,
-                           stream);
+                           X6Ep{nullptr, nullptr, nullptr, 0}, nullptr, stream);
+}
+
+// Convolution with a fused per-channel output epilogue: Y = act((conv + bias) * scale[c] + shift[c] (+ residual)), act = ReLU
+// when relu != 0 -- a frozen-statistics BatchNorm (scale = gamma * invstd, shift = beta - mean * scale), the block's skip
+// connection and its activation without a second pass over Y.  *applied = 1 when the epilogue ran; 0 when the launch this
+// shape takes cannot carry it (split reduction, staged kernel): Y then holds the plain convolution (+ bias) and the caller
+// applies the rest (dsf_bn_apply).
+int dsf_conv_x6_forward_affine(const float* X, const void* image, const float* bias, float* Y, int B, int Hi, int Wi, int Ci,
+                               int Ho, int Wo, int Co, int KH, int KW, int stride, int dil, int pad_h, int pad_w,
+                               const float* scale, const float* shift, const float* residual, int relu, int* applied,
+                               dsf_stream_t stream) {
+    DSF_CHECK_ARG(scale && shift && applied);
+    return x6_forward_impl(X, image, bias, Y, B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, dil, pad_h, pad_w, 0, nullptr, nullptr,
+                           X6Ep{scale, shift, residual, relu}, applied, stream);
 }
 
 int64_t dsf_conv_x6_wrw_workspace_bytes(int B, int Ho, int Wo, int Ci, int Co, int KH, int KW) {

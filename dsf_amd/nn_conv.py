@@ -135,6 +135,14 @@ class StatsRequest:
     part, rows = None, 0
 
 
+class AffineRequest:
+    """The same side channel for the evaluation-mode epilogue: y = act((conv + bias) * scale + shift (+ residual)) in the
+    convolution's own launch (dsf_conv_x6_forward_affine); ``applied`` tells nn_norm.conv_bn_act whether it happened."""
+
+    def __init__(self, scale, shift, residual, relu):
+        self.scale, self.shift, self.residual, self.relu, self.applied = scale, shift, residual, bool(relu), False
+
+
 STATS = None
 
 
@@ -147,7 +155,17 @@ def _fwd_x6(x, image, bias, out_hw, Co, KH, KW, stride, pad, dil=1):
         RECORD.append(("x6", B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, dil, pad[0], pad[1]))
     y = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=CL)
     req = STATS
-    if req is not None and bias is None and B > 0:
+    if isinstance(req, AffineRequest) and B > 0:
+        import ctypes
+        done = ctypes.c_int(0)
+        res = req.residual
+        check(L.lib().dsf_conv_x6_forward_affine(ptr_nhwc(x), ptr(image), ptr(bias), ptr_nhwc(y), I(B), I(Hi), I(Wi), I(Ci), I(Ho),
+                                                 I(Wo), I(Co), I(KH), I(KW), I(stride), I(dil), I(pad[0]), I(pad[1]), ptr(req.scale),
+                                                 ptr(req.shift), ptr_nhwc(res) if res is not None else None, I(int(req.relu)),
+                                                 ctypes.byref(done), stream_ptr()), "dsf_conv_x6_forward_affine")
+        req.applied = bool(done.value)
+        return y
+    if isinstance(req, StatsRequest) and bias is None and B > 0:
         import ctypes
         rows_max = int(L.lib().dsf_conv_x6_bn_stats_rows(I(B), I(Ho), I(Wo)))
         part = torch.empty(rows_max * 2 * Co, device=x.device, dtype=torch.float32)

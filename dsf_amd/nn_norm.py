@@ -106,6 +106,25 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
             if nbt is not None:
                 nbt.add_(n)
 
+    def folded_affine(self):
+        """(scale, shift) of the frozen-statistics transform y = x * scale + shift, cached until the statistics or the affine
+        parameters change (torch's version counters for ordinary writes, ``_stats_epoch`` for the training kernels' raw-pointer
+        updates of the running statistics, the global write epoch for FusedAdamW)."""
+        w, b = self.weight, self.bias
+        key = (self.running_mean._version, self.running_var._version, None if w is None else w._version,
+               None if b is None else b._version, self.__dict__.get("_stats_epoch", 0), L.WRITE_EPOCH[0], self.running_mean.data_ptr())
+        hit = self.__dict__.get("_folded")
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                scale = torch.rsqrt(self.running_var + self.eps)
+                if w is not None:
+                    scale = scale * w
+                shift = -self.running_mean * scale
+                if b is not None:
+                    shift = shift + b
+            hit = self.__dict__["_folded"] = (key, scale.contiguous(), shift.contiguous())
+        return hit[1], hit[2]
+
     def __getattr__(self, name):
         if name == "num_batches_tracked" and self.__dict__.get("_pending_batches"):
             self.flush_batch_counter()
@@ -134,6 +153,8 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
                                               "the reference and not implemented")
                 if self.training and self.track_running_stats and self._buffers.get("num_batches_tracked") is not None:   # (not the attribute: reading it flushes)
                     self._pending_batches += 1
+                if self.training and self.track_running_stats:
+                    self.__dict__["_stats_epoch"] = self.__dict__.get("_stats_epoch", 0) + 1   # the kernel rewrites the running statistics
                 mom = self.momentum
                 rm = self.running_mean if (self.training and self.track_running_stats) else None
                 rv = self.running_var if (self.training and self.track_running_stats) else None
@@ -174,13 +195,28 @@ def bn_act(bn, x, residual=None, relu=False):
 
 # BatchNorm statistics from the producing convolution's epilogue (DSF_BN_EPILOGUE=0: the separate reduction pass)
 EPILOGUE_STATS = [os.environ.get("DSF_BN_EPILOGUE", "1") == "1"]
+EPILOGUE_AFFINE = [os.environ.get("DSF_BN_EPILOGUE", "1") == "1"]
 
 
 def conv_bn_act(conv, bn, x, residual=None, relu=None):
-    """``bn(conv(x))`` (+ residual) (relu) with the BatchNorm batch statistics taken from the convolution's epilogue when
-    both are this package's HIP layers in training mode (one pass over the convolution output less, two launches instead of
-    three); any other combination is the plain composition."""
+    """``bn(conv(x))`` (+ residual) (relu).  Both this package's HIP layers, training mode: the BatchNorm batch statistics
+    come from the convolution's epilogue (one pass over the convolution output less, two launches instead of three).
+    Evaluation mode without autograd: the whole frozen-statistics BatchNorm (+ residual)(+ ReLU) rides in the convolution's
+    output epilogue -- one launch, no second pass.  Any other combination is the plain composition."""
     from . import nn_conv
+    ours = isinstance(bn, FusedBatchNorm2d) and isinstance(conv, (nn_conv.Conv2d, nn_conv.ConvTranspose2d)) and x.is_cuda
+    if (ours and EPILOGUE_AFFINE[0] and not bn.training and bn.track_running_stats and supported(bn.num_features) and
+            x.dtype == torch.float32 and nn_conv.STATS is None and not torch.is_grad_enabled()):
+        r = bn.fuse_relu if relu is None else relu
+        scale, shift = bn.folded_affine()
+        res = residual.contiguous(memory_format=CL) if residual is not None else None
+        req = nn_conv.AffineRequest(scale, shift, res, r)
+        nn_conv.STATS = req
+        try:
+            y = conv(x)
+        finally:
+            nn_conv.STATS = None
+        return y if req.applied else bn(y, residual, r)
     fusable = (EPILOGUE_STATS[0] and isinstance(bn, FusedBatchNorm2d) and isinstance(conv, (nn_conv.Conv2d, nn_conv.ConvTranspose2d)) and bn.training and
                bn.track_running_stats and conv.bias is None and x.is_cuda and supported(bn.num_features) and nn_conv.STATS is None)
     if not fusable:

@@ -316,6 +316,7 @@ class GraphedStep:
         self.graph.replay()
         for m, n in zip(self._bns, self._bn_calls):
             m._pending_batches += n
+            m.__dict__["_stats_epoch"] = m.__dict__.get("_stats_epoch", 0) + 1        # the replay rewrote the running statistics
         if self.step.grad_sync is not None:
             self.step.grad_sync.finish()
         self.step.opt.step()

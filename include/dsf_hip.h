@@ -436,6 +436,16 @@ int dsf_conv_x6_bn_stats_rows(int B, int Ho, int Wo);
 int dsf_conv_x6_forward_bn(const float* X, const void* image, float* Y, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
                            int KH, int KW, int stride, int dil, int pad_h, int pad_w, float* bn_stats, int* bn_rows,
                            dsf_stream_t stream);
+
+/* Convolution with a fused per-channel output epilogue, Y = act((conv + bias) * scale[c] + shift[c] (+ residual)) -- the
+ * evaluation-mode sequence conv -> BatchNorm (frozen statistics: scale = gamma / sqrt(var + eps), shift = beta - mean * scale)
+ * (-> + identity) (-> ReLU) of model/resnet.py:18-98 in one launch (torch runs 2-4 kernels).  residual (or NULL): NHWC, the
+ * shape of Y.  *applied: 1 = the epilogue ran; 0 = this shape's launch cannot carry it (split reduction / staged kernel): Y is
+ * the plain convolution (+ bias) and the caller finishes with dsf_bn_apply. */
+int dsf_conv_x6_forward_affine(const float* X, const void* image, const float* bias, float* Y, int B, int Hi, int Wi, int Ci,
+                               int Ho, int Wo, int Co, int KH, int KW, int stride, int dil, int pad_h, int pad_w,
+                               const float* scale, const float* shift, const float* residual, int relu, int* applied,
+                               dsf_stream_t stream);
 int dsf_bn_forward_from_stats(const float* x, const float* residual, const float* gamma, const float* beta, int64_t M, int C,
                               float eps, float momentum, int relu, float* running_mean, float* running_var, float* y,
                               float* save_mean, float* save_invstd, const float* part, int rows, dsf_stream_t stream);

@@ -330,3 +330,68 @@ def test_bn_epilogue_request_is_declined_where_the_launch_cannot_serve_it():
         yc = cb(xb).double()
     ref = (yc - yc.mean((0, 2, 3), keepdim=True)) / torch.sqrt(yc.var((0, 2, 3), unbiased=False, keepdim=True) + bb.eps)
     assert _rel(yb.detach().double(), ref) < 1e-4
+
+
+@pytest.mark.parametrize("kind,Ci,Co,K,s,p,H,B,res,bias", [
+    ("conv", 64, 64, 3, 1, 1, 64, 16, True, False),       # BasicBlock conv2 + skip + ReLU
+    ("conv", 64, 128, 3, 2, 1, 64, 32, False, False),
+    ("conv", 128, 128, 3, 1, 1, 33, 31, True, False),     # M tail
+    ("conv", 488, 256, 3, 1, 1, 32, 12, False, True),     # the stage-2 fusion convolution: bias AND BatchNorm
+    ("conv", 512, 2048, 1, 1, 0, 32, 3, True, False),     # Bottleneck expansion + skip
+    ("deconv", 512, 256, 4, 2, 1, 32, 6, False, False),
+    ("conv", 512, 512, 3, 1, 1, 4, 2, True, False),       # split reduction: the epilogue is declined, same numbers
+])
+def test_eval_mode_batchnorm_rides_in_the_conv_epilogue(kind, Ci, Co, K, s, p, H, B, res, bias):
+    """dsf_conv_x6_forward_affine: conv -> frozen-statistics BatchNorm (+ residual) (+ ReLU) in one launch (nn_norm.conv_bn_act
+    under torch.no_grad() in eval mode) against the two-pass composition and against float64; the cached folded (scale, shift)
+    follow in-place updates of the statistics / affine parameters, training steps and FusedAdamW-style raw writes."""
+    from dsf_amd import nn_conv, nn_norm
+    torch.manual_seed(4)
+    conv = (nn_conv.Conv2d(Ci, Co, K, s, p, bias=bias) if kind == "conv"
+            else nn_conv.ConvTranspose2d(Ci, Co, K, stride=s, padding=p, output_padding=0, bias=False)).cuda()
+    bn = nn_norm.FusedBatchNorm2d(Co).cuda()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.3, 0.3)
+        bn.running_mean.uniform_(-0.5, 0.5); bn.running_var.uniform_(0.3, 2.0)
+    nn_conv.weights_changed()
+    bn.eval()
+    x = torch.randn(B, Ci, H, H, device="cuda") + 0.3
+
+    def both():
+        with torch.no_grad():
+            Ho = conv(x).shape[-1]
+            r = torch.randn(B, Co, Ho, Ho, device="cuda", generator=torch.Generator(device="cuda").manual_seed(9)) if res else None
+            nn_norm.EPILOGUE_AFFINE[0] = True
+            fused = nn_norm.conv_bn_act(conv, bn, x, residual=r, relu=True)
+            nn_norm.EPILOGUE_AFFINE[0] = False
+            try:
+                plain = nn_norm.conv_bn_act(conv, bn, x, residual=r, relu=True)
+            finally:
+                nn_norm.EPILOGUE_AFFINE[0] = True
+            yc = conv(x).double()
+        ref = (yc - bn.running_mean.double().view(1, -1, 1, 1)) / torch.sqrt(bn.running_var.double().view(1, -1, 1, 1) + bn.eps) \
+            * bn.weight.double().view(1, -1, 1, 1) + bn.bias.double().view(1, -1, 1, 1)
+        if r is not None:
+            ref = ref + r.double()
+        return fused, plain, ref.clamp_min(0)
+    fused, plain, ref = both()
+    assert fused.is_contiguous(memory_format=torch.channels_last)
+    assert _rel(fused, plain) < 2e-6 and _rel(fused.double(), ref) < 5e-6
+    if Ci * K * K > 4000 and H <= 4:
+        return                                                         # (declined launch: nothing cached to invalidate)
+    # the folded transform follows every kind of update
+    with torch.no_grad():
+        bn.running_mean.add_(0.25)                                     # ordinary in-place write: version counter
+    fused, plain, ref = both()
+    assert _rel(fused.double(), ref) < 5e-6
+    bn.train()
+    with torch.no_grad():
+        nn_norm.conv_bn_act(conv, bn, x, relu=True)                    # a training step rewrites the statistics through raw pointers
+    bn.eval()
+    fused, plain, ref = both()
+    assert _rel(fused, plain) < 2e-6 and _rel(fused.double(), ref) < 5e-6
+    # with autograd on, the epilogue path must not be taken (it records no graph): gradients still flow
+    xg = x.clone().requires_grad_(True)
+    y = nn_norm.conv_bn_act(conv, bn, xg, relu=True)
+    y.sum().backward()
+    assert xg.grad is not None and torch.isfinite(xg.grad).all()
