@@ -475,7 +475,7 @@ def test_loader_utils_vs_golden(golden):
     # crop_hand / point image
     full_in = T(golden["ld_crop_hand_full_in"])
     out, xyz_nl, keep = ops.CropHand.apply(full_in, T(golden["ld_crop_joints"][:2]), c3[:2], Minv[:2], cube[:2], cam, 25.0, 20.0, 20.0)
-    assert (N(out) != golden["ld_crop_hand_full_out"]).mean() < 1e-4
+    assert np.array_equal(N(out), golden["ld_crop_hand_full_out"])            # bit-exact: every keep / drop decision and every kept value
     exp_n = golden["ld_xyzimg_n"][:2]
     got = N(xyz_nl).reshape(2, 128, 128, 3).transpose(0, 3, 1, 2)[:, :, ::4, ::4]
     assert np.abs(got - exp_n).max() < 1e-5
@@ -586,7 +586,9 @@ def test_whole_step_loss_and_grads_vs_oracle_step(mano_dict, render):
     # gradients: batch-norm at B=2 amplifies fp32 summation-order noise through ~40 layers, so compare
     # the whole gradient vector (relative L2 error, cosine) and bound the worst single tensor loosely
     num = den = dot = ng = 0.0
-    worst = 0.0
+    worst = worst_l2 = 0.0
+    worst_cos = 1.0
+    noise = []
     for (n, pc), (_, pg) in zip(net_cpu.named_parameters(), net_gpu.named_parameters()):
         if pc.grad is None:
             continue
@@ -594,6 +596,17 @@ def test_whole_step_loss_and_grads_vs_oracle_step(mano_dict, render):
         num += float(((got - ref) ** 2).sum()); den += float((ref ** 2).sum())
         dot += float((got * ref).sum()); ng += float((got ** 2).sum())
         worst = max(worst, (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6))
+        l2, cs = float((got - ref).norm() / ref.norm().clamp_min(1e-30)), float((got * ref).sum() / (got.norm() * ref.norm()).clamp_min(1e-30))
+        if l2 > 3e-2 or cs < 0.9995:
+            noise.append((n, l2, cs, float(ref.norm())))
+        else:
+            worst_l2, worst_cos = max(worst_l2, l2), min(worst_cos, cs)
     assert (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5
     assert dot / (den * ng) ** 0.5 > 0.9995
-    assert worst < 0.25, worst
+    # every single tensor: direction and size of its gradient (measured: cosine >= 0.99996, relative L2 <= 0.85 %), and its
+    # worst element relative to its largest (measured 6.9 %: one element of a long row through 40 BatchNorm layers at B = 2).
+    # The only tensor outside those bars is the bias of the fusion convolution: it feeds a BatchNorm, its true gradient is
+    # exactly zero and both fp32 paths return rounding noise (norm 1.5e-7 against 4.9e2 for the whole gradient).
+    assert worst_cos > 0.9999 and worst_l2 < 2e-2, (worst_cos, worst_l2)
+    assert all(n == "fusion.0.bias" and nr < 1e-6 * den ** 0.5 for n, _, _, nr in noise), noise
+    assert worst < 0.15, worst
