@@ -610,3 +610,53 @@ def test_whole_step_loss_and_grads_vs_oracle_step(mano_dict, render):
     assert worst_cos > 0.9999 and worst_l2 < 2e-2, (worst_cos, worst_l2)
     assert all(n == "fusion.0.bias" and nr < 1e-6 * den ** 0.5 for n, _, _, nr in noise), noise
     assert worst < 0.15, worst
+
+
+def test_torch_library_ops_equal_the_function_path_and_trace(mano_dict, render):
+    """torch.ops.dsf.* (dsf_amd/torch_ops.py: dispatcher registration of the pytorch3d._C boundary) run the same
+    launchers as dsf_amd.ops: bitwise equal outputs and gradients; torch.library.opcheck (schema, fake kernel, autograd
+    registration) passes; a function through them traces under make_fx with fake tensors."""
+    import dsf_amd.torch_ops  # noqa: F401
+    from dsf_amd import ops
+    from dsf_amd.train_step import synthetic_batch
+    p, c, cube = synthetic_batch(2, "cuda", seed=4)
+    mano = render.mano_layer
+    with torch.no_grad():
+        v, _ = mano.get_mano_vertices(p[:, :3], p[:, 3:48], p[:, 48:58], p[:, 58:62], 1 / 125)
+        verts = (v * cube.unsqueeze(1) / 2 + c.unsqueeze(1)).contiguous()
+    fv = ops.project_face_verts(verts, mano.faces_i32, render.cam).requires_grad_(True)
+    Fn = mano.faces_i32.shape[0]
+    first = torch.arange(2, device="cuda") * Fn
+    nf = torch.full((2,), Fn, device="cuda", dtype=torch.int64)
+    a = ops.RasterizeMeshesFunction.apply(fv, first, nf, 160)
+    b = torch.ops.dsf.rasterize_meshes(fv, first, nf, 160)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    gz = torch.randn_like(a[1])
+    ga, = torch.autograd.grad((a[1] * gz).sum(), fv)
+    gb, = torch.autograd.grad((b[1] * gz).sum(), fv)
+    assert torch.allclose(ga, gb, rtol=0, atol=1e-6 * float(ga.abs().max())) and float(ga.abs().sum()) > 0   # (float atomics per face)
+    # point-face distance: 2 clouds of 300 points against the 2 meshes' triangles
+    tris = verts[:, mano.faces_i32.long()].reshape(-1, 3, 3).contiguous().requires_grad_(True)
+    pts = (verts[:, ::2][:, :300] + 3.0 * torch.randn(2, 300, 3, device="cuda")).reshape(-1, 3).contiguous().requires_grad_(True)
+    pfirst = torch.tensor([0, 300], device="cuda")
+    da = ops.PointFaceDistance.apply(pts, pfirst, tris, first, 300)
+    db, ib = torch.ops.dsf.point_face_dist_forward(pts, pfirst, tris, first, 300)
+    assert torch.equal(da, db) and ib.dtype == torch.int64 and int(ib.min()) >= 0
+    w = torch.randn_like(da)
+    g1 = torch.autograd.grad((da * w).sum(), [pts, tris])
+    g2 = torch.autograd.grad((db * w).sum(), [pts, tris])
+    assert torch.equal(g1[0], g2[0]) and torch.allclose(g1[1], g2[1], rtol=0, atol=1e-6 * float(g1[1].abs().max()))   # (float atomics on shared triangles)
+    torch.library.opcheck(torch.ops.dsf.point_face_dist_forward.default, (pts.detach(), pfirst, tris.detach(), first, 300),
+                          test_utils=("test_schema", "test_faketensor", "test_autograd_registration"))
+    torch.library.opcheck(torch.ops.dsf.rasterize_meshes.default, (fv.detach(), first, nf, 64),
+                          test_utils=("test_schema", "test_faketensor", "test_autograd_registration"))
+    # traces with fake tensors (what torch.compile / export do first)
+    from torch.fx.experimental.proxy_tensor import make_fx
+
+    def icp(points, pf, triangles, tf):
+        d, _ = torch.ops.dsf.point_face_dist_forward(points, pf, triangles, tf, 300)
+        return d.mean()
+    gm = make_fx(icp, tracing_mode="fake")(pts.detach(), pfirst, tris.detach(), first)
+    assert any("point_face_dist_forward" in str(n.target) for n in gm.graph.nodes)
+    assert torch.equal(gm(pts.detach(), pfirst, tris.detach(), first), db.detach().mean())

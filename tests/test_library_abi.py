@@ -92,3 +92,28 @@ def test_library_is_capturable_no_memset_nodes():
         for i, line in enumerate(open(f), 1):
             code = line.split("//")[0]
             assert not banned.search(code), "%s:%d %s" % (os.path.basename(f), i, line.strip())
+
+
+def test_torch_library_ops_are_registered_with_fake_kernels():
+    """dsf_amd.torch_ops (torch.library registration of the pytorch3d._C boundary): schemas, shape propagation
+    through FakeTensorMode without touching a device, and no CPU kernel behind them."""
+    import pytest
+    import torch
+    import dsf_amd.torch_ops  # noqa: F401  (registers)
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    for name in ("rasterize_meshes", "rasterize_meshes_backward", "point_face_dist_forward", "point_face_dist_backward"):
+        assert hasattr(torch.ops.dsf, name)
+    assert "image_size" in str(torch.ops.dsf.rasterize_meshes.default._schema)
+    with FakeTensorMode():
+        fv = torch.empty(2 * 1554, 3, 3, device="cuda")
+        first = torch.empty(2, dtype=torch.int64, device="cuda")
+        p2f, zbuf, bary, dists = torch.ops.dsf.rasterize_meshes(fv, first, first, 640)
+        assert p2f.shape == (2, 640, 640, 1) and p2f.dtype == torch.int64 and bary.shape == (2, 640, 640, 1, 3)
+        assert torch.ops.dsf.rasterize_meshes_backward(fv, p2f, zbuf).shape == fv.shape
+        d, i = torch.ops.dsf.point_face_dist_forward(torch.empty(4096, 3, device="cuda"), first, fv, first, 2048)
+        assert d.shape == (4096,) and i.dtype == torch.int64
+        gp, gt = torch.ops.dsf.point_face_dist_backward(torch.empty(4096, 3, device="cuda"), fv, i, d)
+        assert gp.shape == (4096, 3) and gt.shape == fv.shape
+    with pytest.raises((NotImplementedError, RuntimeError)):             # CPU tensors: no kernel registered, no fallback
+        torch.ops.dsf.point_face_dist_forward(torch.zeros(4, 3), torch.zeros(1, dtype=torch.int64), torch.zeros(2, 3, 3),
+                                              torch.zeros(1, dtype=torch.int64), 4)
