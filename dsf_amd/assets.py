@@ -22,7 +22,6 @@ one extra cell-centre vertex Euler's formula gives exactly V=778, F=1538.
 ``load_mano_dict(path)`` also reads a real MANO pickle when the user has
 one (chumpy objects are unpickled through a shim, chumpy is not needed).
 """
-import io
 import os
 import pickle
 

@@ -4,7 +4,7 @@ keys) load unchanged."""
 import torch.nn as nn
 
 from ..nn_conv import Conv2d as _HipConv2d
-from ..nn_norm import FusedBatchNorm2d, bn_act, conv_bn_act
+from ..nn_norm import FusedBatchNorm2d, conv_bn_act
 
 _CONV = [_HipConv2d]      # layer factory of the network under construction (set by model/backbone.py::_Layers)
 _FUSED_BN = [False]       # fused BN+add+ReLU kernels (see model/backbone.py::_Layers)

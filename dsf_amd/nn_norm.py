@@ -12,7 +12,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import _lib as L
-from ._lib import I, I64, F as CF, ptr, check, stream_ptr
+from ._lib import I, I64, F as CF, check, stream_ptr
 
 CL = torch.channels_last
 

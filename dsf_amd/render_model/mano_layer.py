@@ -8,8 +8,6 @@ Same classes, method names, argument order and return tuples
 followed by two ``grid_sample`` calls is the fused crop renderer.  There is no
 CPU fallback: calling these on CPU tensors raises.
 """
-import ctypes
-import math
 
 import numpy as np
 import torch
