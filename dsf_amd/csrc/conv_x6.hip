@@ -225,8 +225,15 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(const float* __restric
 
     u32x4 ra[2][APASS], rb[2][3];
     // wave-uniform walk state of the chunk being loaded
+    // (taps of one channel chunk first, then the next chunk: see igemm_x6b_kernel)
+#ifndef DSF_X6_TAPS_OUTER
+    const int taps_n = cnt_h * cnt_w;
+    const int l_lt = chunk_lo % taps_n;
+    int l_c0 = (chunk_lo / taps_n) * XBK;
+#else
     const int l_lt = chunk_lo / chunks_per_tap;
     int l_c0 = (chunk_lo % chunks_per_tap) * XBK;
+#endif
     int l_kh = kh0 + kstep * (l_lt / cnt_w), l_kw = kw0 + kstep * (l_lt % cnt_w);
     constexpr int NPIECE = APASS + 3;
     auto load_piece = [&](auto SET, int i, bool live) {
@@ -251,11 +258,19 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(const float* __restric
                                          (uint32_t)(pl * B_GRANULES + t) * 16u) | dead);
         }
         if (i == NPIECE - 1) {                                         // advance (scalar) to the next live chunk
+#ifndef DSF_X6_TAPS_OUTER
+            l_kw += kstep;
+            if (l_kw >= p.KW) {
+                l_kw = kw0; l_kh += kstep;
+                if (l_kh >= p.KH) { l_kh = kh0; l_c0 += XBK; }
+            }
+#else
             l_c0 += XBK;
             if (l_c0 >= p.Ci) {
                 l_c0 = 0; l_kw += kstep;
                 if (l_kw >= p.KW) { l_kw = kw0; l_kh += kstep; }
             }
+#endif
         }
     };
     auto stage_piece = [&](auto SET, int buf, int i) {
@@ -454,6 +469,20 @@ __global__ __launch_bounds__(256, 2) void igemm_x6b_kernel(const float* __restri
     // wave-uniform walk states: `la` = the chunk whose A tile is being loaded (two ahead), `lb` = the chunk whose B fragments
     // are being loaded (one ahead: they go straight to registers, there is no LDS stage to wait for)
     struct Walk { int c0, kh, kw; };
+#ifndef DSF_X6_TAPS_OUTER
+    // reduction order: the taps of one 16-channel chunk first, then the next chunk -- consecutive iterations re-read the same
+    // input rows shifted by one pixel (L1 / L2 hits) instead of coming back to them a whole channel sweep later
+    auto advance = [&](Walk& w) {
+        w.kw += kstep;
+        if (w.kw >= p.KW) {
+            w.kw = kw0; w.kh += kstep;
+            if (w.kh >= p.KH) { w.kh = kh0; w.c0 += XBK; }
+        }
+    };
+    const int taps_n = cnt_h * cnt_w;
+    const int l_lt = chunk_lo % taps_n;
+    Walk la = {(chunk_lo / taps_n) * XBK, kh0 + kstep * (l_lt / cnt_w), kw0 + kstep * (l_lt % cnt_w)};
+#else
     auto advance = [&](Walk& w) {
         w.c0 += XBK;
         if (w.c0 >= p.Ci) {
@@ -463,6 +492,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x6b_kernel(const float* __restri
     };
     const int l_lt = chunk_lo / chunks_per_tap;
     Walk la = {(chunk_lo % chunks_per_tap) * XBK, kh0 + kstep * (l_lt / cnt_w), kw0 + kstep * (l_lt % cnt_w)};
+#endif
     Walk lb = la;
     auto load_a = [&](auto SET, int i, bool live) {
         constexpr int S = decltype(SET)::value;
