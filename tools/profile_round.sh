@@ -11,7 +11,7 @@ timeout 400 rocprofv3 --kernel-trace --output-format csv -d $O/ks -o k -- python
 ( python3 $R/tools/kstats.py $O/ks/k_kernel_trace.csv 12; echo; echo "GPU busy per step (tools/busy.py, last steps):"; python3 $R/tools/busy.py $O/ks/k_kernel_trace.csv | tail -3 ) > $O/${TAG}_kernel_categories.txt
 rm -rf $O/ks
 run() { name=$1; shift
-  timeout 400 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/$name -o p -- python3 $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline > $O/$name.log 2>&1
+  timeout 200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/$name -o p -- python3 $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline > $O/$name.log 2>&1
   python3 $R/tools/pmc_summary.py $O/${TAG}_pmc_$name.json $O/$name/p_counter_collection.csv && rm -rf $O/$name $O/$name.log; }
 run fetch FETCH_SIZE
 run write WRITE_SIZE
