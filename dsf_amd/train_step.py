@@ -225,8 +225,8 @@ class GraphedStep:
     batch: the ~700 launches of a step are issued by the driver from one graph launch instead of by the Python host, which
     removes the host-issue gaps between the many small kernels (GPU busy 92 % -> 99 %).  The same
     kernels run on the same data in the same order -- results are those of the eager step (tests/test_gpu_steps.py).
-    What stays eager, after each replay: the gradient all-reduce (``grad_sync``) and the optimizer step, whose learning
-    rate, bias corrections and per-parameter step counts are host state that changes from step to step.
+    What stays eager, after each replay: the optimizer step, whose learning rate, bias corrections and per-parameter step
+    counts are host state that changes from step to step.  Single-GPU (a step with a gradient all-reducer is refused).
     Requirements, as for any stream capture: static shapes (one graph per batch shape), no host decision inside the step
     (the occluder count of ``FinetuneStageStep`` is one -- that step is not graphable), batches are COPIED into the static
     input buffers the graph reads.  The reference has no counterpart (PyTorch eager, train_render.py:636-823)."""
@@ -234,6 +234,12 @@ class GraphedStep:
     def __init__(self, step, tgt, warmup=2, validate=True):
         if not torch.cuda.is_available():
             raise RuntimeError("GraphedStep needs the GPU (HIP graph capture)")
+        if getattr(step, "grad_sync", None) is not None:
+            raise RuntimeError("GraphedStep is single-GPU: the bucketed gradient all-reduce is launched from autograd hooks "
+                               "inside the backward pass the graph would replace")
+        if not hasattr(step, "forward_backward"):
+            raise TypeError("GraphedStep needs a step with forward_backward(tgt) (RenderSupervisedStep, MeshLossStep); the "
+                            "steps that draw their occluder count on the host cannot be captured")
         self.step = step
         self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in tgt.items()}
         side = torch.cuda.Stream()
@@ -317,8 +323,6 @@ class GraphedStep:
         for m, n in zip(self._bns, self._bn_calls):
             m._pending_batches += n
             m.__dict__["_stats_epoch"] = m.__dict__.get("_stats_epoch", 0) + 1        # the replay rewrote the running statistics
-        if self.step.grad_sync is not None:
-            self.step.grad_sync.finish()
         self.step.opt.step()
         return self.loss, self.terms
 
