@@ -9,7 +9,7 @@
 
 namespace {
 
-constexpr int NJ = 21, NS = 66, NPALM = 21, TOPK = 10;
+constexpr int NS = 66, NPALM = 21, TOPK = 10;      // (21 joints)
 __constant__ int c_child[15] = {2, 3, 16, 5, 6, 17, 8, 9, 18, 11, 12, 19, 14, 15, 20};
 __constant__ int c_knuckle[5] = {1, 4, 7, 10, 13};
 

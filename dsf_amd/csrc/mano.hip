@@ -14,7 +14,7 @@ namespace {
 
 constexpr int NV = 778;
 constexpr int NE = 2334;            // 778*3
-constexpr int NVO = 779;
+// (779 output vertices: 778 + the wrist vertex) *
 constexpr int NEO = 2337;           // 779*3
 constexpr int SV_VPOSED = 0, SV_VERTS = 2334, SV_JOINTS = 4671, SV_G = 4734, SV_RS = 4926, SV_J = 5070,
               SV_TH = 5118;
