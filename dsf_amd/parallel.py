@@ -104,6 +104,7 @@ class GradAllReducer:
         if self.world > 1:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+                p.__dict__["_dsf_hooks_join"] = True     # (nn_conv._side_ok: this hook joins the side stream before it reads)
 
     def _seal(self, plist):
         for p in plist:
@@ -126,6 +127,9 @@ class GradAllReducer:
 
     def _launch(self, b):
         plist = self.buckets[b]
+        if plist and plist[0].is_cuda:
+            from . import nn_conv
+            nn_conv.join_side_streams()        # weight gradients still being written on the backward-weights stream
         missing = [p.grad is None for p in plist]
         parts = [_flat(p.grad if p.grad is not None and p.grad.stride() == p.stride() else
                        (torch.zeros_like(p) if p.grad is None else torch.empty_like(p).copy_(p.grad))) for p in plist]

@@ -175,3 +175,89 @@ def test_graphed_step_refuses_a_graph_with_memset_nodes(render):
     with pytest.raises(RuntimeError, match="memset node"):
         GraphedStep(step, tgt, warmup=1)
     step(tgt)                                                        # the step itself is untouched and still runs eagerly
+
+
+def test_backward_weights_side_stream_is_invisible(det_mode):
+    """nn_conv runs dW of a convolution on a second stream when nothing can read that gradient before the backward pass ends
+    (leaf weight, one use in the graph, no gradient yet, no foreign hooks).  In deterministic mode every variant below must
+    give BITWISE the gradients of the single-stream run: one use (side stream taken), a network applied to two batches (the
+    engine adds the two contributions on the main stream: side stream refused), accumulation over two backward calls, a
+    tensor hook on the weight, a non-leaf (merged) weight, and a create_graph pass followed by a second backward."""
+    from dsf_amd import nn_conv, nn_norm
+    torch.manual_seed(2)
+    net = torch.nn.Sequential(nn_conv.Conv2d(64, 128, 3, 1, 1, bias=False), nn_norm.FusedBatchNorm2d(128, fuse_relu=True),
+                              nn_conv.Conv2d(128, 128, 3, 2, 1, bias=True), nn_norm.FusedBatchNorm2d(128, fuse_relu=True),
+                              nn_conv.Conv2d(128, 64, 1, 1, 0, bias=False)).cuda()
+    nn_conv.weights_changed()
+    xa = torch.randn(8, 64, 32, 32, device="cuda")
+    xb = torch.randn(8, 64, 32, 32, device="cuda")
+    convs = [m for m in net if isinstance(m, nn_conv.Conv2d)]
+
+    def grads():
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in net.parameters()]
+
+    def one_use():
+        net.zero_grad(set_to_none=True)
+        net(xa).square().mean().backward()
+        return grads()
+
+    def two_uses():
+        net.zero_grad(set_to_none=True)
+        (net(xa).square().mean() + net(xb).abs().mean()).backward()
+        return grads()
+
+    def two_backwards():
+        net.zero_grad(set_to_none=True)
+        net(xa).square().mean().backward()
+        net(xb).abs().mean().backward()
+        return grads()
+
+    def hooked():
+        net.zero_grad(set_to_none=True)
+        seen = []
+        h = convs[1].weight.register_hook(lambda g: seen.append(float(g.abs().sum())) or g)
+        try:
+            net(xa).square().mean().backward()
+        finally:
+            h.remove()
+        assert seen and seen[0] > 0
+        return grads() + [torch.tensor(seen[0])]
+
+    def merged_weight():
+        net.zero_grad(set_to_none=True)
+        w = torch.cat([convs[2].weight, convs[2].weight * 0.5], 0)                # non-leaf: autograd splits its gradient at once
+        y = net[:4](xa)
+        nn_conv.Conv2dFunction.apply(y, w, None, 1, (0, 0)).square().mean().backward()
+        return grads()[:-1] + [convs[2].weight.grad.clone()]
+
+    def double_backward():                                                       # (convolutions only: the fused BatchNorm is once-differentiable)
+        net.zero_grad(set_to_none=True)
+        xi = xa.clone().requires_grad_(True)
+        out = convs[2](torch.nn.functional.leaky_relu(convs[0](xi), 0.2))
+        g, = torch.autograd.grad(out.sum(), xi, create_graph=True)
+        (g.square().mean() + out.square().mean()).backward()
+        torch.cuda.synchronize()
+        return [convs[0].weight.grad.clone(), convs[2].weight.grad.clone()]
+
+    for case in (one_use, two_uses, two_backwards, hooked, merged_weight, double_backward):
+        nn_conv.WRW_STREAM[0] = False
+        try:
+            ref = case()
+        finally:
+            nn_conv.WRW_STREAM[0] = True
+        for rep in range(3):
+            got = case()
+            for i, (a, b) in enumerate(zip(ref, got)):
+                assert torch.equal(a, b), (case.__name__, rep, i)
+    # the side stream is really taken in the plain case
+    taken = []
+    orig = nn_conv._on_side_stream
+    nn_conv._on_side_stream = lambda fn, inputs: taken.append(1) or orig(fn, inputs)
+    try:
+        one_use()
+        n_one = len(taken)
+        two_uses()
+    finally:
+        nn_conv._on_side_stream = orig
+    assert n_one == 3 and len(taken) == n_one                                  # three convolutions; none when the net is used twice
