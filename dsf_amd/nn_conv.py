@@ -408,9 +408,14 @@ class Conv2dFunction(Function):
             wd = weight.detach().float().flip(2, 3).permute(2, 3, 0, 1).contiguous()          # [kh'][kw'][Co][Ci]
             gx = _fwd(gy, wd, None, (x.shape[2], x.shape[3]), Ci, KH, KW, 1, stride, (KH - 1 - padding[0], KW - 1 - padding[1]))
         if ctx.needs_input_grad[1]:
+            side = _side_ok(weight) and ctx.uses is not None and ctx.uses[0] == 1
             if _c1_ok(Ci, Co, KH, KW, stride, padding):
-                gw = _wrw_c1(x, gy, KH, stride, padding[0]).permute(3, 2, 0, 1)
-            elif _side_ok(weight) and ctx.uses is not None and ctx.uses[0] == 1:
+                if side:
+                    gw = _on_side_stream(lambda: _wrw_c1(x, gy, KH, stride, padding[0]), (x, gy)).permute(3, 2, 0, 1)
+                else:
+                    join_side_streams()
+                    gw = _wrw_c1(x, gy, KH, stride, padding[0]).permute(3, 2, 0, 1)
+            elif side:
                 gw = _on_side_stream(lambda: _wrw(x, gy, KH, KW, stride, padding), (x, gy)).permute(3, 2, 0, 1)
             else:
                 join_side_streams()                      # whatever reads this gradient next may also read a pending one
@@ -428,11 +433,12 @@ class Conv2dFunction(Function):
 # Only where nothing can read the gradient earlier: the weight is a leaf parameter (not, e.g., the merged head weight,
 # whose gradient autograd splits right away), it has no gradient yet (else AccumulateGrad adds into it), and no tensor /
 # post-accumulate hooks other than GradAllReducer's, which joins the streams itself before it packs a bucket.
-# DSF_WRW_STREAM=0 keeps everything on one stream.
+# DSF_WRW_STREAM=0 keeps everything on one stream (needed under torch's own DistributedDataParallel, whose reducer hooks the
+# gradient accumulator nodes, which a tensor cannot report).
 # ------------------------------------------------------------------------------------------------
 WRW_STREAM = [os.environ.get("DSF_WRW_STREAM", "1") == "1"]
 _SIDE = {}
-_JOIN_QUEUED = [False]
+_JOIN_QUEUED = [-1]
 _PENDING = [False]
 
 
@@ -444,6 +450,13 @@ def _count_use(weight, wants_grad):
     if not wants_grad:
         return None
     cell = weight.__dict__.get("_dsf_uses")
+    if torch._C._current_graph_task_id() >= 0:
+        # a node built INSIDE a backward pass (create_graph): it joins the graph that pass is differentiating, whose other
+        # nodes already hold this weight's cell -- never a fresh count
+        if cell is None:
+            cell = weight.__dict__["_dsf_uses"] = [0, True]
+        cell[0] += 1 << 20
+        return cell
     if cell is None or cell[1]:
         cell = weight.__dict__["_dsf_uses"] = [0, False]     # first forward after a backward pass: a new graph
     cell[0] += 1
@@ -469,15 +482,11 @@ def _on_side_stream(fn, inputs):
         t.record_stream(side)                            # (the allocator must not hand their memory out before the side stream is done)
     out.record_stream(cur)
     _PENDING[0] = True
-    if not _JOIN_QUEUED[0]:
-        _JOIN_QUEUED[0] = True
-        torch.autograd.Variable._execution_engine.queue_callback(_join_after_backward)
+    task = torch._C._current_graph_task_id()             # one join callback per backward pass (ids are never reused, so a pass
+    if _JOIN_QUEUED[0] != task:                           # that died with an exception cannot leave a stale "already queued")
+        _JOIN_QUEUED[0] = task
+        torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
     return out
-
-
-def _join_after_backward():
-    _JOIN_QUEUED[0] = False
-    join_side_streams()
 
 
 def join_side_streams():
@@ -562,7 +571,11 @@ class ConvTranspose2dFunction(Function):
             else:
                 gx = _fwd(gy, wd, None, (x.shape[2], x.shape[3]), Cin, KH, KW, stride, 1, padding)
         if ctx.needs_input_grad[1]:
-            gw = _wrw(gy, x, KH, KW, stride, padding).permute(3, 2, 0, 1)                      # [kh][kw][Cout][Cin] -> (Cin,Cout,kh,kw)
+            if _side_ok(weight) and ctx.uses is not None and ctx.uses[0] == 1:
+                gw = _on_side_stream(lambda: _wrw(gy, x, KH, KW, stride, padding), (x, gy)).permute(3, 2, 0, 1)
+            else:
+                join_side_streams()
+                gw = _wrw(gy, x, KH, KW, stride, padding).permute(3, 2, 0, 1)                  # [kh][kw][Cout][Cin] -> (Cin,Cout,kh,kw)
         if has_bias and ctx.needs_input_grad[2]:
             gb = _bias_grad(gy)
         return gx, gw, gb, None, None, None

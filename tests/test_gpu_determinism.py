@@ -187,7 +187,8 @@ def test_backward_weights_side_stream_is_invisible(det_mode):
     torch.manual_seed(2)
     net = torch.nn.Sequential(nn_conv.Conv2d(64, 128, 3, 1, 1, bias=False), nn_norm.FusedBatchNorm2d(128, fuse_relu=True),
                               nn_conv.Conv2d(128, 128, 3, 2, 1, bias=True), nn_norm.FusedBatchNorm2d(128, fuse_relu=True),
-                              nn_conv.Conv2d(128, 64, 1, 1, 0, bias=False)).cuda()
+                              nn_conv.Conv2d(128, 64, 1, 1, 0, bias=False),
+                              nn_conv.ConvTranspose2d(64, 32, 4, stride=2, padding=1, bias=False)).cuda()
     nn_conv.weights_changed()
     xa = torch.randn(8, 64, 32, 32, device="cuda")
     xb = torch.randn(8, 64, 32, 32, device="cuda")
@@ -229,7 +230,8 @@ def test_backward_weights_side_stream_is_invisible(det_mode):
         w = torch.cat([convs[2].weight, convs[2].weight * 0.5], 0)                # non-leaf: autograd splits its gradient at once
         y = net[:4](xa)
         nn_conv.Conv2dFunction.apply(y, w, None, 1, (0, 0)).square().mean().backward()
-        return grads()[:-1] + [convs[2].weight.grad.clone()]
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in net[:5].parameters()]
 
     def double_backward():                                                       # (convolutions only: the fused BatchNorm is once-differentiable)
         net.zero_grad(set_to_none=True)
@@ -260,4 +262,4 @@ def test_backward_weights_side_stream_is_invisible(det_mode):
         two_uses()
     finally:
         nn_conv._on_side_stream = orig
-    assert n_one == 3 and len(taken) == n_one                                  # three convolutions; none when the net is used twice
+    assert n_one == 4 and len(taken) == n_one                                  # 3 convolutions + 1 transposed; none when the net is used twice
