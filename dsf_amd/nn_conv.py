@@ -440,6 +440,7 @@ WRW_STREAM = [os.environ.get("DSF_WRW_STREAM", "1") == "1"]
 _SIDE = {}
 _JOIN_QUEUED = [-1]
 _PENDING = [False]
+_HELD = []
 
 
 def _count_use(weight, wants_grad):
@@ -478,9 +479,12 @@ def _on_side_stream(fn, inputs):
     side.wait_stream(cur)
     with torch.cuda.stream(side):
         out = fn()
-    for t in inputs:
-        t.record_stream(side)                            # (the allocator must not hand their memory out before the side stream is done)
-    out.record_stream(cur)
+    # the side stream still reads `inputs`: they are kept alive until the streams have met again (dropping them after the join is
+    # ordinary same-stream reuse).  Not Tensor.record_stream: its event-deferred frees made the caching allocator fall back to
+    # hipMalloc on the big configurations (config 4: 193 -> 276 ms per step); holding the gradients of one backward pass costs
+    # memory instead, of which there is plenty
+    _HELD.extend(inputs)
+    _HELD.append(out)
     _PENDING[0] = True
     task = torch._C._current_graph_task_id()             # one join callback per backward pass (ids are never reused, so a pass
     if _JOIN_QUEUED[0] != task:                           # that died with an exception cannot leave a stale "already queued")
@@ -495,6 +499,7 @@ def join_side_streams():
         _PENDING[0] = False
         for dev, side in _SIDE.items():
             torch.cuda.current_stream(dev).wait_stream(side)
+        del _HELD[:]
 
 
 class _WeightGradFunction(Function):
