@@ -351,7 +351,8 @@ def main():
                                                                 if os.environ.get("DSF_CONV_MATH", "x6") == "x6" else ": fp32 MFMA"),
             "config": {"workload": "BASELINE configs[1]: batch=%d/GPU %s 2-stage + MANO + depth rasteriser, single view"
                                    % (args.batch, args.backbone),
-                       "global_batch": args.batch * world, "hip_graph": bool(args.graph), "crop": 128, "raster": 640, "parallelism": "dp%d" % world,
+                       "global_batch": args.batch * world, "hip_graph": bool(args.graph),
+                       "weight_gradients_on_second_stream": os.environ.get("DSF_WRW_STREAM", "1") != "0", "crop": 128, "raster": 640, "parallelism": "dp%d" % world,
                        "mano_asset": "synthetic MANO-shaped hand (real MANO_RIGHT.pkl is license-gated)"},
             "final_loss": round(loss_val, 5),
             "distributed": facts,
