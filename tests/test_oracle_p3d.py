@@ -260,3 +260,42 @@ def test_oracle_against_pytorch3d_golden():
     assert moved.mean() < 1e-2                                # ties between triangles sharing the nearest edge / vertex
     gp, gt = p3d.point_face_dist_backward(inp["points"].reshape(-1, 3), tris, g["pfd_idxs"], np.ones_like(d))
     assert np.abs(gp - g["pfd_grad_points"]).max() <= 1e-3 * max(1.0, np.abs(gp).max())
+
+
+def test_point_face_restatement_vs_float64_evaluation():
+    """oracle/p3d_ref.c's point_face_dist (float32, one IEEE op per expression) against oracle/pfd_exact.py (the published
+    rule written independently in vectorised float64): posed hands in millimetres AND in cube-normalised units (where the
+    rule's 1e-8 regularisers are NOT negligible: denom ~ 1e-6), clouds on / near / far from the surface, and lattice
+    triangle soups with duplicated and degenerate triangles.  Every distance agrees to float32 rounding and every chosen
+    triangle is a float64 minimiser to that bar; index disagreements are ties."""
+    from oracle import pfd_exact as X
+    inp, _ = _golden_inputs()
+    faces, world = inp["faces"], inp["world"]
+    rng = np.random.default_rng(7)
+    tot = {"points": 0, "ties": 0, "dist": 0, "argmin": 0}
+    for b in range(min(world.shape[0], 3)):
+        for scale in (1.0, 1.0 / 125.0):                                   # mm, and the trainer's cube-normalised units
+            v = (world[b] - world[b].mean(0)) * scale
+            tris = v[faces].astype(np.float32)
+            on = tris[rng.integers(0, tris.shape[0], 400)].mean(1)                     # centroids: exactly on the surface
+            near = v[rng.integers(0, v.shape[0], 600)] + rng.normal(0, 4.0 * scale, (600, 3))
+            far = rng.normal(0, 150.0 * scale, (200, 3))
+            edge = 0.5 * (tris[rng.integers(0, tris.shape[0], 300), 0] + tris[rng.integers(0, tris.shape[0], 300), 1])
+            pts = np.concatenate([on, near, far, edge]).astype(np.float32)
+            d, i = p3d.point_face_dist_forward(pts, np.zeros(1, np.int64), tris, np.zeros(1, np.int64))
+            r = X.explain(pts, tris, d, i)
+            assert r["dist"] == 0 and r["argmin"] == 0, (b, scale, r)
+            for k in tot:
+                tot[k] += r[k]
+    # lattice soup: shared vertices / edges everywhere, duplicated and zero-area triangles
+    g = rng.integers(-3, 4, (120, 3, 3)).astype(np.float32)
+    g[10] = g[11]                                                          # duplicate
+    g[20, 2] = g[20, 1]                                                    # degenerate (two equal vertices)
+    g[21] = g[21, 0]                                                       # a point
+    pts = rng.integers(-8, 9, (500, 3)).astype(np.float32) * 0.5
+    d, i = p3d.point_face_dist_forward(pts, np.zeros(1, np.int64), g, np.zeros(1, np.int64))
+    r = X.explain(pts, g, d, i)
+    assert r["dist"] == 0 and r["argmin"] == 0, r
+    # exact ties resolve to the lowest index in the restatement (the float64 argmin does too: same values)
+    assert r["ties"] >= 0 and tot["points"] == 9000 and tot["ties"] > 0
+    print("hands:", tot, "soup:", r)
