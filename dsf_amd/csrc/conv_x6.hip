@@ -850,13 +850,26 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
 }
 
 // dW[e] = sum over the pixel splits, ascending (deterministic mode)
+// (n is a multiple of 4: K * Co with Co % 4 == 0; four elements per lane, the splits still added one by one in ascending order)
 __global__ __launch_bounds__(256) void x6_wrw_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dW, int64_t n,
                                                            int splits) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (e >= n) return;
-    float s = 0.f;
-    for (int q = 0; q < splits; ++q) s += partial[(int64_t)q * n + e];
-    dW[e] = s;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int q = 0;
+    for (; q + 4 <= splits; q += 4) {                    // four independent loads in flight, added in order
+        const float4 a = *reinterpret_cast<const float4*>(partial + (int64_t)q * n + e);
+        const float4 b = *reinterpret_cast<const float4*>(partial + (int64_t)(q + 1) * n + e);
+        const float4 c = *reinterpret_cast<const float4*>(partial + (int64_t)(q + 2) * n + e);
+        const float4 d = *reinterpret_cast<const float4*>(partial + (int64_t)(q + 3) * n + e);
+        s.x = (((s.x + a.x) + b.x) + c.x) + d.x; s.y = (((s.y + a.y) + b.y) + c.y) + d.y;
+        s.z = (((s.z + a.z) + b.z) + c.z) + d.z; s.w = (((s.w + a.w) + b.w) + c.w) + d.w;
+    }
+    for (; q < splits; ++q) {
+        const float4 a = *reinterpret_cast<const float4*>(partial + (int64_t)q * n + e);
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+    *reinterpret_cast<float4*>(dW + e) = s;
 }
 
 // Measurement aid (bench.py): a bare v_mfma_f32_32x32x16_bf16 loop on pseudo-random operands, four accumulators per wave,
@@ -1076,8 +1089,8 @@ int dsf_conv_x6_wrw_ws(const float* X, const float* dY, float* dW, int B, int Hi
                            dW, p, k_tiles, n_tiles, splits, (int)per, mwo, mho, (uint32_t)x_bytes, (uint32_t)dy_bytes, partial);
     if (det) {
         const int64_t n = (int64_t)K * Co;
-        hipLaunchKernelGGL(x6_wrw_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial, dW, n,
-                           splits);
+        hipLaunchKernelGGL(x6_wrw_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial, dW,
+                           n, splits);
     }
     return dsf_launch_status();
 }
