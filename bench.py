@@ -213,7 +213,18 @@ def self_launch(n):
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL needs it on this driver
-    return subprocess.call(cmd, env=env)
+    return relay_one_line(cmd, env)
+
+
+def relay_one_line(cmd, env):
+    """Runs the launcher child; of what its ranks write to stdout only the bench line reaches this process's stdout (the
+    contract is ONE JSON line), everything else -- a backend's connection banner, a stray print -- goes to stderr."""
+    import subprocess
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in child.stdout:
+        (sys.stdout if line.startswith('{"metric"') else sys.stderr).write(line)
+    sys.stdout.flush()
+    return child.wait()
 
 
 def rccl_debug_file():

@@ -125,10 +125,10 @@ def test_bench_launches_its_own_ranks(monkeypatch):
     bench = importlib.import_module("bench")
     seen = {}
 
-    def fake_call(cmd, env=None):
+    def fake_relay(cmd, env):
         seen["cmd"], seen["env"] = cmd, env
         return 7
-    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(bench, "relay_one_line", fake_relay)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     with pytest.raises(SystemExit) as e:
@@ -138,6 +138,20 @@ def test_bench_launches_its_own_ranks(monkeypatch):
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_bench_relays_exactly_the_json_line(capfd):
+    """The self-launching parent passes on ONE stdout line (the ranks' JSON); a backend banner on the child's stdout goes to
+    stderr, and the child's exit code is returned."""
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    code = 'print("[Gloo] Rank 0 is connected to 1 peer ranks"); print(\'{"metric": "x", "value": 1}\'); print("tail"); raise SystemExit(3)'
+    rc = bench.relay_one_line([sys.executable, "-c", code], dict(os.environ))
+    out, err = capfd.readouterr()
+    assert rc == 3 and out == '{"metric": "x", "value": 1}\n' and "[Gloo]" in err and "tail" in err
 
 
 def test_rccl_log_summary_parses_what_it_can(tmp_path):
