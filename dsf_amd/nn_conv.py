@@ -433,8 +433,8 @@ class Conv2dFunction(Function):
 # Only where nothing can read the gradient earlier: the weight is a leaf parameter (not, e.g., the merged head weight,
 # whose gradient autograd splits right away), it has no gradient yet (else AccumulateGrad adds into it), and no tensor /
 # post-accumulate hooks other than GradAllReducer's, which joins the streams itself before it packs a bucket.
-# DSF_WRW_STREAM=0 keeps everything on one stream (needed under torch's own DistributedDataParallel, whose reducer hooks the
-# gradient accumulator nodes, which a tensor cannot report).
+# DSF_WRW_STREAM=0 keeps everything on one stream.  In a multi-rank process group only weights managed by GradAllReducer take
+# the side stream (torch's own DistributedDataParallel hooks the gradient accumulator nodes, which a tensor cannot report).
 # ------------------------------------------------------------------------------------------------
 WRW_STREAM = [os.environ.get("DSF_WRW_STREAM", "1") == "1"]
 _SIDE = {}
@@ -467,8 +467,15 @@ def _count_use(weight, wants_grad):
 def _side_ok(weight):
     if not (WRW_STREAM[0] and weight.is_leaf and weight.grad is None and not weight._backward_hooks):
         return False
-    hooks = getattr(weight, "_post_accumulate_grad_hooks", None)
-    return not hooks or bool(weight.__dict__.get("_dsf_hooks_join"))
+    ours = bool(weight.__dict__.get("_dsf_hooks_join"))
+    if getattr(weight, "_post_accumulate_grad_hooks", None) and not ours:
+        return False
+    # a multi-rank process group without GradAllReducer on this weight: some other data-parallel wrapper (torch's
+    # DistributedDataParallel hooks the gradient-accumulator nodes, which a tensor cannot report) may read the gradient as
+    # soon as it is accumulated -- stay on one stream
+    if not ours and torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        return False
+    return True
 
 
 def _on_side_stream(fn, inputs):
