@@ -486,12 +486,17 @@ def _on_side_stream(fn, inputs):
     side.wait_stream(cur)
     with torch.cuda.stream(side):
         out = fn()
-    # the side stream still reads `inputs`: they are kept alive until the streams have met again (dropping them after the join is
-    # ordinary same-stream reuse).  Not Tensor.record_stream: its event-deferred frees made the caching allocator fall back to
-    # hipMalloc on the big configurations (config 4: 193 -> 276 ms per step); holding the gradients of one backward pass costs
-    # memory instead, of which there is plenty
-    _HELD.extend(inputs)
-    _HELD.append(out)
+    # the side stream still reads `inputs`: they are kept alive until its launch has finished (polled, oldest first) or the streams
+    # have met again.  Not Tensor.record_stream: its event-deferred frees made the caching allocator fall back to hipMalloc on
+    # the big configurations (config 4: 193 -> 276 ms per step)
+    if torch.cuda.is_current_stream_capturing():         # (no event queries inside a graph capture: held until the join)
+        _HELD.append((None, inputs, out))
+    else:
+        ev = torch.cuda.Event()
+        ev.record(side)
+        _HELD.append((ev, inputs, out))
+        while len(_HELD) > 1 and _HELD[0][0] is not None and _HELD[0][0].query():    # launches the side stream has finished:
+            _HELD.pop(0)                                                             # nothing reads their inputs any more
     _PENDING[0] = True
     task = torch._C._current_graph_task_id()             # one join callback per backward pass (ids are never reused, so a pass
     if _JOIN_QUEUED[0] != task:                           # that died with an exception cannot leave a stale "already queued")
