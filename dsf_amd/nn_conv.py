@@ -217,13 +217,13 @@ def _wrw_c1(x, gy, K, stride, pad):
     return dw
 
 
-def _wrw(x, gy, KH, KW, stride, pad):
-    """-> dW [KH][KW][Ci][Co] for x (B,Ci,Hi,Wi), gy (B,Co,Ho,Wo), both channels_last."""
+def _wrw(x, gy, KH, KW, stride, pad, out=None):
+    """-> dW [KH][KW][Ci][Co] for x (B,Ci,Hi,Wi), gy (B,Co,Ho,Wo), both channels_last; ``out``: add into this dW instead."""
     B, Ci, Hi, Wi = x.shape
     _, Co, Ho, Wo = gy.shape
     if RECORD is not None:
         RECORD.append(("wrw", B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, 1, pad[0], pad[1]))
-    dw = _pool_take(KH * KW * Ci * Co, x.device)
+    dw = _pool_take(KH * KW * Ci * Co, x.device) if out is None else out
     pooled = dw is not None
     dw = dw.view(KH, KW, Ci, Co) if pooled else torch.empty((KH, KW, Ci, Co), device=x.device, dtype=torch.float32)
     # both operands are activations: conv_x6 splits them on the fly (Ci % 4 == 0 and Co % 4 == 0), else the fp32 MFMA kernel
@@ -408,18 +408,18 @@ class Conv2dFunction(Function):
             wd = weight.detach().float().flip(2, 3).permute(2, 3, 0, 1).contiguous()          # [kh'][kw'][Co][Ci]
             gx = _fwd(gy, wd, None, (x.shape[2], x.shape[3]), Ci, KH, KW, 1, stride, (KH - 1 - padding[0], KW - 1 - padding[1]))
         if ctx.needs_input_grad[1]:
-            side = _side_ok(weight) and ctx.uses is not None and ctx.uses[0] == 1
-            if _c1_ok(Ci, Co, KH, KW, stride, padding):
-                if side:
-                    gw = _on_side_stream(lambda: _wrw_c1(x, gy, KH, stride, padding[0]), (x, gy)).permute(3, 2, 0, 1)
-                else:
-                    join_side_streams()
-                    gw = _wrw_c1(x, gy, KH, stride, padding[0]).permute(3, 2, 0, 1)
-            elif side:
-                gw = _on_side_stream(lambda: _wrw(x, gy, KH, KW, stride, padding), (x, gy)).permute(3, 2, 0, 1)
+            c1 = _c1_ok(Ci, Co, KH, KW, stride, padding)
+            held = (x, gy)
+            if c1:
+                dw = _on_side_stream(lambda: _wrw_c1(x, gy, KH, stride, padding[0]), held) \
+                    if (_side_ok(weight) and ctx.uses is not None and ctx.uses[0] == 1) else None
             else:
+                dw = _wrw_side(weight, ctx.uses, lambda: _wrw(x, gy, KH, KW, stride, padding),
+                               lambda acc: _wrw(x, gy, KH, KW, stride, padding, out=acc), held)
+            if dw is None:
                 join_side_streams()                      # whatever reads this gradient next may also read a pending one
-                gw = _wrw(x, gy, KH, KW, stride, padding).permute(3, 2, 0, 1)
+                dw = _wrw_c1(x, gy, KH, stride, padding[0]) if c1 else _wrw(x, gy, KH, KW, stride, padding)
+            gw = None if dw is False else dw.permute(3, 2, 0, 1)
         if has_bias and ctx.needs_input_grad[2]:
             gb = _bias_grad(gy)
         return gx, gw, gb, None, None
@@ -455,13 +455,35 @@ def _count_use(weight, wants_grad):
         # a node built INSIDE a backward pass (create_graph): it joins the graph that pass is differentiating, whose other
         # nodes already hold this weight's cell -- never a fresh count
         if cell is None:
-            cell = weight.__dict__["_dsf_uses"] = [0, True]
+            cell = weight.__dict__["_dsf_uses"] = [0, True, None]
         cell[0] += 1 << 20
         return cell
     if cell is None or cell[1]:
-        cell = weight.__dict__["_dsf_uses"] = [0, False]     # first forward after a backward pass: a new graph
+        cell = weight.__dict__["_dsf_uses"] = [0, False, None]    # first forward after a backward pass: a new graph
     cell[0] += 1
     return cell
+
+
+def _wrw_side(weight, cell, fn_new, fn_add, held):
+    """The weight-gradient launch of one node on the side stream, or None when it must stay on the main stream.
+    One use in the graph: ``fn_new()`` -> dW, handed to autograd.  Several uses (a network applied to two batches): the first
+    node to run creates dW and hands it to autograd, the others ADD into that same buffer on the side stream and hand
+    autograd nothing (``False``), so the engine -- which would add the contributions on the main stream as they arrive -- sees a
+    single one.  (Float atomics only: the deterministic mode's ordered reduction overwrites its output.)"""
+    if cell is None or not _side_ok(weight):
+        return None
+    n = cell[0]
+    if n == 1:
+        return _on_side_stream(fn_new, held)
+    if not (1 < n < (1 << 20)) or L.deterministic() or MATH != "x6":
+        return None
+    task = torch._C._current_graph_task_id()
+    if cell[2] is None or cell[2][0] != task:             # first node of THIS backward pass (a retained graph may be walked again)
+        cell[2] = (task, _on_side_stream(fn_new, held))
+        return cell[2][1]
+    acc = cell[2][1]
+    _on_side_stream(lambda: fn_add(acc), held)
+    return False
 
 
 def _side_ok(weight):
@@ -588,11 +610,12 @@ class ConvTranspose2dFunction(Function):
             else:
                 gx = _fwd(gy, wd, None, (x.shape[2], x.shape[3]), Cin, KH, KW, stride, 1, padding)
         if ctx.needs_input_grad[1]:
-            if _side_ok(weight) and ctx.uses is not None and ctx.uses[0] == 1:
-                gw = _on_side_stream(lambda: _wrw(gy, x, KH, KW, stride, padding), (x, gy)).permute(3, 2, 0, 1)
-            else:
+            dw = _wrw_side(weight, ctx.uses, lambda: _wrw(gy, x, KH, KW, stride, padding),
+                           lambda acc: _wrw(gy, x, KH, KW, stride, padding, out=acc), (x, gy))
+            if dw is None:
                 join_side_streams()
-                gw = _wrw(gy, x, KH, KW, stride, padding).permute(3, 2, 0, 1)                  # [kh][kw][Cout][Cin] -> (Cin,Cout,kh,kw)
+                dw = _wrw(gy, x, KH, KW, stride, padding)
+            gw = None if dw is False else dw.permute(3, 2, 0, 1)                               # [kh][kw][Cout][Cin] -> (Cin,Cout,kh,kw)
         if has_bias and ctx.needs_input_grad[2]:
             gb = _bias_grad(gy)
         return gx, gw, gb, None, None, None

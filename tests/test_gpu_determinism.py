@@ -183,7 +183,7 @@ def test_backward_weights_side_stream_is_invisible(det_mode):
     give BITWISE the gradients of the single-stream run: one use (side stream taken), a network applied to two batches (the
     engine adds the two contributions on the main stream: side stream refused), accumulation over two backward calls, a
     tensor hook on the weight, a non-leaf (merged) weight, and a create_graph pass followed by a second backward."""
-    from dsf_amd import nn_conv, nn_norm
+    from dsf_amd import nn_conv, nn_norm, _lib as L
     torch.manual_seed(2)
     net = torch.nn.Sequential(nn_conv.Conv2d(64, 128, 3, 1, 1, bias=False), nn_norm.FusedBatchNorm2d(128, fuse_relu=True),
                               nn_conv.Conv2d(128, 128, 3, 2, 1, bias=True), nn_norm.FusedBatchNorm2d(128, fuse_relu=True),
@@ -252,6 +252,37 @@ def test_backward_weights_side_stream_is_invisible(det_mode):
             got = case()
             for i, (a, b) in enumerate(zip(ref, got)):
                 assert torch.equal(a, b), (case.__name__, rep, i)
+    # a network applied to two batches in the default (float-atomic) mode: the second node of each weight ADDS into the first
+    # node's dW on the side stream and hands autograd nothing -- same sums as the single-stream run up to atomic order, also
+    # when the retained graph is differentiated a second time after zero_grad
+    old = L.set_deterministic(False)
+    try:
+        nn_conv.WRW_STREAM[0] = False
+        ref = two_uses()
+        again = two_uses()                                                     # the float-atomic mode's own run-to-run noise
+        dev = lambda u, v: max(float((a - b).abs().max() / a.abs().max().clamp_min(1e-30)) for a, b in zip(u, v))
+        bar = 5 * dev(ref, again) + 1e-5
+        nn_conv.WRW_STREAM[0] = True
+        for rep in range(3):
+            assert dev(ref, two_uses()) <= bar
+        net.zero_grad(set_to_none=True)
+        loss = net(xa).square().mean() + net(xb).abs().mean()
+        loss.backward(retain_graph=True)
+        net.zero_grad(set_to_none=True)
+        loss.backward()
+        torch.cuda.synchronize()
+        assert dev(ref, [p_.grad for p_ in net.parameters()]) <= bar
+        shared = []
+        orig_side = nn_conv._on_side_stream
+        nn_conv._on_side_stream = lambda fn, inputs: shared.append(1) or orig_side(fn, inputs)
+        try:
+            two_uses()
+        finally:
+            nn_conv._on_side_stream = orig_side
+        assert len(shared) == 8                                                # 4 weights x 2 uses, all on the side stream
+    finally:
+        L.set_deterministic(old)
+        nn_conv.WRW_STREAM[0] = True
     # the side stream is really taken in the plain case
     taken = []
     orig = nn_conv._on_side_stream
