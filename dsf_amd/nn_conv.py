@@ -432,7 +432,8 @@ class Conv2dFunction(Function):
 # optimizer, a test or anything else can look at a gradient.  19.9 vs 20.3 ms per step.
 # Only where nothing can read the gradient earlier: the weight is a leaf parameter (not, e.g., the merged head weight,
 # whose gradient autograd splits right away), it has no gradient yet (else AccumulateGrad adds into it), and no tensor /
-# post-accumulate hooks other than GradAllReducer's, which joins the streams itself before it packs a bucket.
+# post-accumulate hooks other than GradAllReducer's, which joins the streams itself before it packs a bucket; a weight
+# used by several nodes of the graph gets ONE dW that all of them add into (_wrw_side), so that the engine adds nothing.
 # DSF_WRW_STREAM=0 keeps everything on one stream.  In a multi-rank process group only weights managed by GradAllReducer take
 # the side stream (torch's own DistributedDataParallel hooks the gradient accumulator nodes, which a tensor cannot report).
 # ------------------------------------------------------------------------------------------------
@@ -444,10 +445,11 @@ _HELD = []
 
 
 def _count_use(weight, wants_grad):
-    """[uses in the graph being built, backward seen] of a weight, shared by every node that takes it as a differentiable
-    input.  A weight used by two nodes of one graph (a network applied to two batches, a discriminator on real and fake
-    images, the double-backward graph of a gradient penalty) has its gradient contributions ADDED by the autograd engine on
-    the main stream as they arrive: none of them may then be computed on the side stream."""
+    """[uses in the graph being built, backward seen, (backward pass id, shared dW)] of a weight, shared by every node that
+    takes it as a differentiable input.  A weight used by two nodes of one graph (a network applied to two batches, a
+    discriminator on real and fake images, the double-backward graph of a gradient penalty) has its gradient contributions
+    ADDED by the autograd engine on the main stream as they arrive: they may not simply be computed on the side stream
+    (``_wrw_side`` makes the nodes share one dW instead, or keeps them on the main stream)."""
     if not wants_grad:
         return None
     cell = weight.__dict__.get("_dsf_uses")
