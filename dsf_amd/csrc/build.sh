@@ -8,7 +8,7 @@ set -e
 cd "$(dirname "$0")"
 OUT=../lib
 mkdir -p $OUT
-FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function $DSF_EXTRA_FLAGS"
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function"
 SRCS="api mano raster pfd hand_geom image_ops data_ops conv conv_x6 conv_c1 norm loss optim pool volume"
 if [ "$(cat $OUT/.flags 2>/dev/null)" != "$FLAGS" ]; then
   rm -f $OUT/*.o

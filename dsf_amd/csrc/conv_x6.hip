@@ -226,14 +226,9 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(const float* __restric
     u32x4 ra[2][APASS], rb[2][3];
     // wave-uniform walk state of the chunk being loaded
     // (taps of one channel chunk first, then the next chunk: see igemm_x6b_kernel)
-#ifndef DSF_X6_TAPS_OUTER
     const int taps_n = cnt_h * cnt_w;
     const int l_lt = chunk_lo % taps_n;
     int l_c0 = (chunk_lo / taps_n) * XBK;
-#else
-    const int l_lt = chunk_lo / chunks_per_tap;
-    int l_c0 = (chunk_lo % chunks_per_tap) * XBK;
-#endif
     int l_kh = kh0 + kstep * (l_lt / cnt_w), l_kw = kw0 + kstep * (l_lt % cnt_w);
     constexpr int NPIECE = APASS + 3;
     auto load_piece = [&](auto SET, int i, bool live) {
@@ -258,19 +253,11 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(const float* __restric
                                          (uint32_t)(pl * B_GRANULES + t) * 16u) | dead);
         }
         if (i == NPIECE - 1) {                                         // advance (scalar) to the next live chunk
-#ifndef DSF_X6_TAPS_OUTER
             l_kw += kstep;
             if (l_kw >= p.KW) {
                 l_kw = kw0; l_kh += kstep;
                 if (l_kh >= p.KH) { l_kh = kh0; l_c0 += XBK; }
             }
-#else
-            l_c0 += XBK;
-            if (l_c0 >= p.Ci) {
-                l_c0 = 0; l_kw += kstep;
-                if (l_kw >= p.KW) { l_kw = kw0; l_kh += kstep; }
-            }
-#endif
         }
     };
     auto stage_piece = [&](auto SET, int buf, int i) {
@@ -460,16 +447,12 @@ __global__ __launch_bounds__(256, 2) void igemm_x6b_kernel(const float* __restri
     const int vH = (p.Hi - 1) * 2 + 1, vW = (p.Wi - 1) * 2 + 1;
 
     u32x4 ra[2][APASS];
-#ifdef DSF_X6_APPLY_PROBE
-    u32x4 rsc[2], rsh[2]; uint32_t rok[2] = {0u, 0u};
-#endif
     u32x4 rbf[2][3][TN];                                 // [set][plane][n block]: B fragments as loaded
     // byte offset of this lane's granule inside a plane of an image block: (k-group, n)
     const uint32_t b_lane = (uint32_t)((lane >> 5) * BN + wn * 64 + (lane & 31)) * 16u;
     // wave-uniform walk states: `la` = the chunk whose A tile is being loaded (two ahead), `lb` = the chunk whose B fragments
     // are being loaded (one ahead: they go straight to registers, there is no LDS stage to wait for)
     struct Walk { int c0, kh, kw; };
-#ifndef DSF_X6_TAPS_OUTER
     // reduction order: the taps of one 16-channel chunk first, then the next chunk -- consecutive iterations re-read the same
     // input rows shifted by one pixel (L1 / L2 hits) instead of coming back to them a whole channel sweep later
     auto advance = [&](Walk& w) {
@@ -482,17 +465,6 @@ __global__ __launch_bounds__(256, 2) void igemm_x6b_kernel(const float* __restri
     const int taps_n = cnt_h * cnt_w;
     const int l_lt = chunk_lo % taps_n;
     Walk la = {(chunk_lo / taps_n) * XBK, kh0 + kstep * (l_lt / cnt_w), kw0 + kstep * (l_lt % cnt_w)};
-#else
-    auto advance = [&](Walk& w) {
-        w.c0 += XBK;
-        if (w.c0 >= p.Ci) {
-            w.c0 = 0; w.kw += kstep;
-            if (w.kw >= p.KW) { w.kw = kw0; w.kh += kstep; }
-        }
-    };
-    const int l_lt = chunk_lo / chunks_per_tap;
-    Walk la = {(chunk_lo % chunks_per_tap) * XBK, kh0 + kstep * (l_lt / cnt_w), kw0 + kstep * (l_lt % cnt_w)};
-#endif
     Walk lb = la;
     auto load_a = [&](auto SET, int i, bool live) {
         constexpr int S = decltype(SET)::value;
@@ -507,16 +479,6 @@ __global__ __launch_bounds__(256, 2) void igemm_x6b_kernel(const float* __restri
             off = (uint32_t)(a_base[i] + (la.kh * p.Wi + la.kw) * p.Ci + la.c0);
         }
         ra[S][i] = x6_load16(xbuf, ok ? off * 4u : X_OOB);
-#ifdef DSF_X6_APPLY_PROBE
-        // MEASUREMENT PROBE (never shipped; DESIGN.md section 5 "BatchNorm apply in the consumer's loader"): the cost of
-        // y = max(x * scale[c] + shift[c], 0) on the A operand before the split -- per-channel vectors fetched with the
-        // tile (their VALUES are taken from the head of the weight image: timing only), padding kept at zero.
-        if (i == 0) {
-            rsc[S] = x6_load16(wbuf, (uint32_t)(la.c0 + a_k4) * 4u);
-            rsh[S] = x6_load16(wbuf, (uint32_t)(la.c0 + a_k4) * 4u + 4096u);
-        }
-        rok[S] = (rok[S] & ~(1u << i)) | ((ok ? 1u : 0u) << i);
-#endif
         if (i == APASS - 1) advance(la);
     };
     auto load_b = [&](auto SET, int f, bool live) {
@@ -531,16 +493,6 @@ __global__ __launch_bounds__(256, 2) void igemm_x6b_kernel(const float* __restri
     auto stage_piece = [&](auto SET, int buf, int i) {
         constexpr int S = decltype(SET)::value;
         uint2 h, m, l;
-#ifdef DSF_X6_APPLY_PROBE
-        {
-            const bool ok = (rok[S] >> i) & 1u;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float v = fmaxf(fmaf(__uint_as_float(ra[S][i][e]), __uint_as_float(rsc[S][e]), __uint_as_float(rsh[S][e])), 0.f);
-                ra[S][i][e] = ok ? __float_as_uint(v) : 0u;
-            }
-        }
-#endif
         split4(ra[S][i], h, m, l);
         uint2* dst = reinterpret_cast<uint2*>(&As[buf][(a_q >> 1) * LA::KG + a_r + 64 * i]) + (a_q & 1);
         dst[0] = h; dst[2 * LA::SIZE] = m; dst[4 * LA::SIZE] = l;
@@ -728,10 +680,6 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
         constexpr int S = decltype(SET)::value;
         const int m = mc + l_p + 8 * (j & 1);
         if (j < 2) {
-#if defined(DSF_WRW_PROBE) && DSF_WRW_PROBE == 3
-            rl[S][j] = x6_load16(xbuf, (m < m_end) ? (uint32_t)(m * p.Ci + a_c) * 4u : X_OOB);             // (timing probe: linear addressing)
-            return;
-#endif
             const uint32_t mm = (uint32_t)min(m, M - 1);
             const uint32_t q = x6_fast_div(mm, magic_wo);
             const int ox = (int)(mm - q * (uint32_t)p.Wo);
@@ -751,11 +699,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
     auto stage_piece = [&](auto SET, int buf, int j) {
         constexpr int S = decltype(SET)::value;
         uint2 h, m, l;
-#if defined(DSF_WRW_PROBE) && DSF_WRW_PROBE == 1
-        h = make_uint2(rl[S][j][0], rl[S][j][1]); m = make_uint2(rl[S][j][2], rl[S][j][3]); l = h;      // (timing probe: no split VALU)
-#else
         split4(rl[S][j], h, m, l);
-#endif
         char* base = (j < 2 ? As[buf] : Bs[buf]) + ((j & 1) ? st_off1 : st_off0);
         *reinterpret_cast<uint2*>(base) = h;
         *reinterpret_cast<uint2*>(base + PLANE) = m;
@@ -802,11 +746,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
 #pragma unroll
             for (int i = 0; i < TM; ++i) a[pl][i] = tr_read(As[buf] + pl * PLANE, fa[i][0], fa[i][1]);
 #pragma unroll
-#if defined(DSF_WRW_PROBE) && DSF_WRW_PROBE == 2
-            for (int j = 0; j < TN; ++j) b[pl][j] = a[pl][j % TM];                                          // (timing probe: half the LDS reads)
-#else
             for (int j = 0; j < TN; ++j) b[pl][j] = tr_read(Bs[buf] + pl * PLANE, fb[j][0], fb[j][1]);
-#endif
         }
         __builtin_amdgcn_sched_barrier(0);
         constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};
@@ -851,11 +791,12 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
 
 // dW[e] = sum over the pixel splits, ascending (deterministic mode)
 // (n is a multiple of 4: K * Co with Co % 4 == 0; four elements per lane, the splits still added one by one in ascending order)
+// accumulate != 0: the ordered sum starts from what dW holds (the launcher's `accumulate` contract; still one fixed order)
 __global__ __launch_bounds__(256) void x6_wrw_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dW, int64_t n,
-                                                           int splits) {
+                                                           int splits, int accumulate) {
     const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (e >= n) return;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 s = accumulate ? *reinterpret_cast<const float4*>(dW + e) : make_float4(0.f, 0.f, 0.f, 0.f);
     int q = 0;
     for (; q + 4 <= splits; q += 4) {                    // four independent loads in flight, added in order
         const float4 a = *reinterpret_cast<const float4*>(partial + (int64_t)q * n + e);
@@ -1090,7 +1031,7 @@ int dsf_conv_x6_wrw_ws(const float* X, const float* dY, float* dW, int B, int Hi
     if (det) {
         const int64_t n = (int64_t)K * Co;
         hipLaunchKernelGGL(x6_wrw_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial, dW,
-                           n, splits);
+                           n, splits, accumulate);
     }
     return dsf_launch_status();
 }

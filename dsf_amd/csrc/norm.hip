@@ -327,10 +327,7 @@ inline bool bn_shape_ok(int C) {
 }
 inline int bn_col_blocks(int C) { return ((C >> 2) + 255) / 256; }
 
-#ifndef DSF_BN_MAX_WGS
-#define DSF_BN_MAX_WGS 256
-#endif
-constexpr int BN_MAX_WGS = DSF_BN_MAX_WGS;
+constexpr int BN_MAX_WGS = 256;
 inline int bn_rows_per_wg(int64_t M, int C) {
     const int rlanes = 256 / min(C >> 2, 256);
     int64_t r = (M + BN_MAX_WGS - 1) / BN_MAX_WGS;

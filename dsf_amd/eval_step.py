@@ -36,6 +36,10 @@ class EvalStep:
         self.gfm = GFM()
         self.utils = TensorUtils(img_size=config.input_size)
         self.transfer = list(render.mano_layer.transfer)
+        from . import nn_conv
+        # the scored net is read-only here: its split weight images are kept from one batch to the next (a load_state_dict or an
+        # in-place torch write bumps the version counters; raw ``.data`` writes must call nn_conv.weights_changed())
+        nn_conv.manage_weights(net.parameters())
 
     @torch.no_grad()
     def test_iter(self, img, xyz_gt, center, cube, M, writers=None):

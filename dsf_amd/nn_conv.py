@@ -358,7 +358,6 @@ class Conv2dFunction(Function):
             y = _fwd(x, wk, b, (Ho, Wo), Co, KH, KW, stride, 1, padding)
         ctx.save_for_backward(x, weight, wk)
         ctx.cfg = (stride, padding, bias is not None)
-        ctx.uses = _count_use(weight, ctx.needs_input_grad[1])
         return y
 
     @staticmethod
@@ -366,10 +365,6 @@ class Conv2dFunction(Function):
         x, weight, wk = ctx.saved_tensors
         stride, padding, has_bias = ctx.cfg
         Co, Ci, KH, KW = weight.shape
-        if ctx.uses is not None:
-            ctx.uses[1] = True                           # a backward pass over this weight's graph has begun
-            if torch.is_grad_enabled():
-                ctx.uses[0] += 1 << 20                   # create_graph: the nodes built below add further contributions to this weight
         if torch.is_grad_enabled():
             # backward of the backward is wanted (create_graph=True: WGAN-GP's gradient penalty, reference
             # render_model/transfer.py:356-391): express both gradients through differentiable Functions
@@ -378,6 +373,9 @@ class Conv2dFunction(Function):
                 op = (x.shape[2] - ((gy.shape[2] - 1) * stride - 2 * padding[0] + KH), x.shape[3] - ((gy.shape[3] - 1) * stride - 2 * padding[1] + KW))
                 gx = ConvTranspose2dFunction.apply(gy, weight, None, stride, padding, op)     # (Co -> Ci): the conv's weight IS its (in, out, kh, kw)
             if ctx.needs_input_grad[1]:
+                join_side_streams()                      # a main-stream contribution: see _wrw_dispatch
+                if SIDE_API:
+                    weight.__dict__["_dsf_pass"] = (torch._C._current_graph_task_id(), None)
                 gw = _WeightGradFunction.apply(x, gy, (KH, KW), stride, padding)
             if has_bias and ctx.needs_input_grad[2]:
                 gb = gy.sum((0, 2, 3))
@@ -408,17 +406,11 @@ class Conv2dFunction(Function):
             wd = weight.detach().float().flip(2, 3).permute(2, 3, 0, 1).contiguous()          # [kh'][kw'][Co][Ci]
             gx = _fwd(gy, wd, None, (x.shape[2], x.shape[3]), Ci, KH, KW, 1, stride, (KH - 1 - padding[0], KW - 1 - padding[1]))
         if ctx.needs_input_grad[1]:
-            c1 = _c1_ok(Ci, Co, KH, KW, stride, padding)
-            held = (x, gy)
-            if c1:
-                dw = _on_side_stream(lambda: _wrw_c1(x, gy, KH, stride, padding[0]), held) \
-                    if (_side_ok(weight) and ctx.uses is not None and ctx.uses[0] == 1) else None
+            if _c1_ok(Ci, Co, KH, KW, stride, padding):  # (the stem kernel overwrites its output: never a shared dW)
+                dw = _wrw_dispatch(weight, lambda: _wrw_c1(x, gy, KH, stride, padding[0]), None, (x, gy))
             else:
-                dw = _wrw_side(weight, ctx.uses, lambda: _wrw(x, gy, KH, KW, stride, padding),
-                               lambda acc: _wrw(x, gy, KH, KW, stride, padding, out=acc), held)
-            if dw is None:
-                join_side_streams()                      # whatever reads this gradient next may also read a pending one
-                dw = _wrw_c1(x, gy, KH, stride, padding[0]) if c1 else _wrw(x, gy, KH, KW, stride, padding)
+                dw = _wrw_dispatch(weight, lambda: _wrw(x, gy, KH, KW, stride, padding),
+                                   lambda acc: _wrw(x, gy, KH, KW, stride, padding, out=acc), (x, gy))
             gw = None if dw is False else dw.permute(3, 2, 0, 1)
         if has_bias and ctx.needs_input_grad[2]:
             gb = _bias_grad(gy)
@@ -430,66 +422,81 @@ class Conv2dFunction(Function):
 # launched on a second stream (forked from the current one, so its inputs are ready) while the chain continues, and the
 # streams meet when the backward pass ends (an autograd-engine callback, as DistributedDataParallel uses) -- before an
 # optimizer, a test or anything else can look at a gradient.  19.9 vs 20.3 ms per step (DESIGN.md section 5).
-# Only where nothing can read the gradient earlier: the weight is a leaf parameter (not, e.g., the merged head weight,
-# whose gradient autograd splits right away), it has no gradient yet (else AccumulateGrad adds into it), and no tensor /
-# post-accumulate hooks other than GradAllReducer's, which joins the streams itself before it packs a bucket; a weight
-# used by several nodes of the graph gets ONE dW that all of them add into (_wrw_side), so that the engine adds nothing.
+# Only where nothing can read the gradient earlier (_side_ok): the weight is a leaf parameter (not, e.g., the merged head
+# weight, whose gradient autograd splits right away) in the kernels' memory layout (so that AccumulateGrad adopts dW
+# instead of copying it on the main stream), it has no gradient yet (else AccumulateGrad adds into it), and no tensor /
+# post-accumulate hooks other than GradAllReducer's, which joins the streams itself before it packs a bucket.
+# A weight that receives SEVERAL contributions in one backward pass (a network applied to two batches, a discriminator
+# on real and fake images, a retained graph walked together with a new one, the double-backward graph of a gradient
+# penalty) would have them ADDED by the autograd engine on the main stream as they arrive.  That is decided per backward
+# pass, not from a count taken in the forward (which a retained graph can falsify): the FIRST contribution of a pass is
+# recorded on the weight (graph task id, dW); every later one of the same pass adds into that same buffer on the side
+# stream and hands autograd nothing, or -- deterministic mode, the stem kernel, a first contribution that ran on the main
+# stream -- joins the streams and runs on the main stream, after which the rest of the pass stays there.
+# Limitation: a weight that ALSO feeds a non-convolution op of the same graph (a weight penalty written as w.pow(2).sum())
+# gets that op's gradient added by the engine, which this module cannot see: mark such weights with
+# ``no_side_stream(params)`` or set DSF_WRW_STREAM=0.
 # DSF_WRW_STREAM=0 keeps everything on one stream.  In a multi-rank process group only weights managed by GradAllReducer take
 # the side stream (torch's own DistributedDataParallel hooks the gradient accumulator nodes, which a tensor cannot report).
+# The feature rests on private torch interfaces (the graph task id, the engine's end-of-pass callback, the tensor's hook
+# dictionaries): _side_api_ok() probes them once and everything stays on one stream when one is missing.
 # ------------------------------------------------------------------------------------------------
-WRW_STREAM = [os.environ.get("DSF_WRW_STREAM", "1") == "1"]
+def _side_api_ok():
+    try:
+        t = torch.zeros(1)
+        return (callable(getattr(torch._C, "_current_graph_task_id", None)) and torch._C._current_graph_task_id() == -1 and
+                callable(getattr(torch.autograd.Variable._execution_engine, "queue_callback", None)) and
+                hasattr(t, "_backward_hooks") and hasattr(t, "_post_accumulate_grad_hooks"))
+    except Exception:
+        return False
+
+
+SIDE_API = _side_api_ok()
+WRW_STREAM = [os.environ.get("DSF_WRW_STREAM", "1") == "1" and SIDE_API]
+WRW_PRIORITY = int(os.environ.get("DSF_WRW_PRIORITY", "0"))          # priority of the side stream (lower number = higher priority)
 _SIDE = {}
 _JOIN_QUEUED = [-1]
 _PENDING = [False]
 _HELD = []
 
 
-def _count_use(weight, wants_grad):
-    """[uses in the graph being built, backward seen, (backward pass id, shared dW)] of a weight, shared by every node that
-    takes it as a differentiable input.  A weight used by two nodes of one graph (a network applied to two batches, a
-    discriminator on real and fake images, the double-backward graph of a gradient penalty) has its gradient contributions
-    ADDED by the autograd engine on the main stream as they arrive: they may not simply be computed on the side stream
-    (``_wrw_side`` makes the nodes share one dW instead, or keeps them on the main stream)."""
-    if not wants_grad:
-        return None
-    cell = weight.__dict__.get("_dsf_uses")
-    if torch._C._current_graph_task_id() >= 0:
-        # a node built INSIDE a backward pass (create_graph): it joins the graph that pass is differentiating, whose other
-        # nodes already hold this weight's cell -- never a fresh count
-        if cell is None:
-            cell = weight.__dict__["_dsf_uses"] = [0, True, None]
-        cell[0] += 1 << 20
-        return cell
-    if cell is None or cell[1]:
-        cell = weight.__dict__["_dsf_uses"] = [0, False, None]    # first forward after a backward pass: a new graph
-    cell[0] += 1
-    return cell
+def no_side_stream(params, flag=True):
+    """Keeps the weight gradients of ``params`` on the main stream (see the limitation above)."""
+    for p in params:
+        p.__dict__["_dsf_no_side"] = bool(flag)
 
 
-def _wrw_side(weight, cell, fn_new, fn_add, held):
-    """The weight-gradient launch of one node on the side stream, or None when it must stay on the main stream.
-    One use in the graph: ``fn_new()`` -> dW, handed to autograd.  Several uses (a network applied to two batches): the first
-    node to run creates dW and hands it to autograd, the others ADD into that same buffer on the side stream and hand
-    autograd nothing (``False``), so the engine -- which would add the contributions on the main stream as they arrive -- sees a
-    single one.  (Float atomics only: the deterministic mode's ordered reduction overwrites its output.)"""
-    if cell is None or not _side_ok(weight):
-        return None
-    n = cell[0]
-    if n == 1:
-        return _on_side_stream(fn_new, held)
-    if not (1 < n < (1 << 20)) or L.deterministic() or MATH != "x6":
-        return None
-    task = torch._C._current_graph_task_id()
-    if cell[2] is None or cell[2][0] != task:             # first node of THIS backward pass (a retained graph may be walked again)
-        cell[2] = (task, _on_side_stream(fn_new, held))
-        return cell[2][1]
-    acc = cell[2][1]
-    _on_side_stream(lambda: fn_add(acc), held)
-    return False
+def _wrw_dispatch(weight, fn_new, fn_add, held):
+    """One node's weight-gradient launch -> dW (handed to autograd) or False (added into the dW an earlier node of this
+    backward pass handed over; autograd gets None).  ``fn_new()`` -> dW;  ``fn_add(acc)`` adds into acc (None: this kernel cannot)."""
+    task = torch._C._current_graph_task_id() if SIDE_API else -1
+    rec = weight.__dict__.get("_dsf_pass")
+    first = task < 0 or rec is None or rec[0] != task
+    if _side_ok(weight) and task >= 0:
+        if first:
+            dw = _on_side_stream(fn_new, held)
+            weight.__dict__["_dsf_pass"] = (task, dw)
+            return dw
+        if rec[1] is not None and fn_add is not None and not L.deterministic() and MATH == "x6":
+            acc = rec[1]
+            _on_side_stream(lambda: fn_add(acc), held)
+            return False
+    # main stream: whatever reads this gradient next (the engine's add of two contributions, AccumulateGrad's add into an
+    # existing .grad) may also read a pending one of the side stream
+    join_side_streams()
+    if task >= 0:
+        weight.__dict__["_dsf_pass"] = (task, None)       # the rest of this pass stays on the main stream for this weight
+    return fn_new()
 
 
 def _side_ok(weight):
     if not (WRW_STREAM[0] and weight.is_leaf and weight.grad is None and not weight._backward_hooks):
+        return False
+    if weight.__dict__.get("_dsf_no_side") or weight.dtype != torch.float32 or weight.dim() != 4:
+        return False
+    # AccumulateGrad adopts dW only when it has the parameter's strides (else it clones it -- on the main stream, while the
+    # side stream still writes): dW comes in the kernels' memory order [KH][KW][.][.]
+    if not weight.permute(2, 3, 1, 0).is_contiguous():
         return False
     ours = bool(weight.__dict__.get("_dsf_hooks_join"))
     if getattr(weight, "_post_accumulate_grad_hooks", None) and not ours:
@@ -506,7 +513,7 @@ def _on_side_stream(fn, inputs):
     cur = torch.cuda.current_stream()
     side = _SIDE.get(cur.device)
     if side is None:
-        side = _SIDE[cur.device] = torch.cuda.Stream(device=cur.device)
+        side = _SIDE[cur.device] = torch.cuda.Stream(device=cur.device, priority=WRW_PRIORITY)
     side.wait_stream(cur)
     with torch.cuda.stream(side):
         out = fn()
@@ -592,7 +599,6 @@ class ConvTranspose2dFunction(Function):
             y = _fwd(x, wk, b, (Ho, Wo), Cout, KH, KW, 1, stride, (KH - 1 - padding[0], KW - 1 - padding[1]))
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, padding, bias is not None)
-        ctx.uses = _count_use(weight, ctx.needs_input_grad[1])
         return y
 
     @staticmethod
@@ -600,8 +606,6 @@ class ConvTranspose2dFunction(Function):
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
         stride, padding, has_bias = ctx.cfg
-        if ctx.uses is not None:
-            ctx.uses[1] = True
         Cin, Cout, KH, KW = weight.shape
         gy = _nhwc(gy)
         gx = gw = gb = None
@@ -612,11 +616,8 @@ class ConvTranspose2dFunction(Function):
             else:
                 gx = _fwd(gy, wd, None, (x.shape[2], x.shape[3]), Cin, KH, KW, stride, 1, padding)
         if ctx.needs_input_grad[1]:
-            dw = _wrw_side(weight, ctx.uses, lambda: _wrw(gy, x, KH, KW, stride, padding),
-                           lambda acc: _wrw(gy, x, KH, KW, stride, padding, out=acc), (x, gy))
-            if dw is None:
-                join_side_streams()
-                dw = _wrw(gy, x, KH, KW, stride, padding)
+            dw = _wrw_dispatch(weight, lambda: _wrw(gy, x, KH, KW, stride, padding),
+                               lambda acc: _wrw(gy, x, KH, KW, stride, padding, out=acc), (x, gy))
             gw = None if dw is False else dw.permute(3, 2, 0, 1)                               # [kh][kw][Cout][Cin] -> (Cin,Cout,kh,kw)
         if has_bias and ctx.needs_input_grad[2]:
             gb = _bias_grad(gy)

@@ -225,7 +225,8 @@ class GraphedStep:
     batch: the ~700 launches of a step are issued by the driver from one graph launch instead of by the Python host, which
     removes the host-issue gaps between the many small kernels (GPU busy 92 % -> 99 %).  The same
     kernels run on the same data in the same order -- results are those of the eager step (tests/test_gpu_steps.py).
-    What stays eager, after each replay: the optimizer step, whose learning rate, bias corrections and per-parameter step
+    Building the wrapper does not train: the warm-up and validation passes run forward + backward only and restore the
+    BatchNorm running statistics.  What stays eager, after each replay: the optimizer step, whose learning rate, bias corrections and per-parameter step
     counts are host state that changes from step to step.  Single-GPU (a step with a gradient all-reducer is refused).
     Requirements, as for any stream capture: static shapes (one graph per batch shape), no host decision inside the step
     (the occluder count of ``FinetuneStageStep`` is one -- that step is not graphable), batches are COPIED into the static
@@ -242,14 +243,25 @@ class GraphedStep:
                             "steps that draw their occluder count on the host cannot be captured")
         self.step = step
         self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in tgt.items()}
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                      # eager warm-up on a side stream: allocator, lazy tables, weight images
-            for _ in range(warmup):
-                step(self.static)
-        torch.cuda.current_stream().wait_stream(side)
         from .nn_norm import FusedBatchNorm2d
         self._bns = [m for m in step.net.modules() if isinstance(m, FusedBatchNorm2d)]
+        # eager warm-up on a side stream (allocator, lazy tables, weight images): forward + backward only -- no optimizer step --
+        # and the BatchNorm running statistics / batch counts are put back, so that building the wrapper does not train
+        bufs = [(b, b.clone()) for b in step.net.buffers()]
+        pend = [m._pending_batches for m in self._bns]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                step.forward_backward(self.static)
+            with torch.no_grad():
+                for b, c in bufs:
+                    b.copy_(c)
+        torch.cuda.current_stream().wait_stream(side)
+        for m, n in zip(self._bns, pend):
+            m._pending_batches = n
+            m.__dict__["_stats_epoch"] = m.__dict__.get("_stats_epoch", 0) + 1
+        del bufs
         before = [m._pending_batches for m in self._bns]
         self.graph = torch.cuda.CUDAGraph(keep_graph=True)
         with torch.cuda.graph(self.graph):
@@ -375,6 +387,8 @@ class _StepBase:
             for p in transfer_net.parameters():
                 p.requires_grad_(False)
             transfer_net.eval()
+            from . import nn_conv
+            nn_conv.manage_weights(transfer_net.parameters())       # frozen: its split weight images are kept across steps
 
     def draw(self, B, device, generator=None, host_rng=None, views=1, view_scale=1.0):
         return draw_augmentation(B, device, generator, host_rng, views=views, depth_range=self.render.depth_range,

@@ -30,6 +30,9 @@ class ConsisCycleGANStep:
             optimizers = (torch.optim.Adam(itertools.chain(netG_A.parameters(), netG_B.parameters()), lr=lr, betas=(beta1, 0.999)),
                           torch.optim.Adam(itertools.chain(netD_A.parameters(), netD_B.parameters()), lr=lr, betas=(beta1, 0.999)))
         self.opt_G, self.opt_D = optimizers
+        from . import nn_conv
+        # torch.optim writes the parameters in place (version counters bump): the split weight images may be kept between uses
+        nn_conv.manage_weights(itertools.chain(netG_A.parameters(), netG_B.parameters(), netD_A.parameters(), netD_B.parameters()))
 
     @staticmethod
     def _requires_grad(nets, flag):

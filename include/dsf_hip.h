@@ -472,7 +472,8 @@ int dsf_depth_augment_crop(const float* crop, const float* joints, const double*
  * when the library is loaded -- makes every launcher of this library bit-reproducible: the raster / point-face / collision
  * backward kernels accumulate in 64-bit fixed point (order-independent), the forward-type convolutions do not split
  * their reduction, backward-weights writes one partial tile per pixel split and adds them in ascending order
- * (dsf_conv_x6_wrw_ws with dsf_conv_x6_wrw_workspace_bytes(...) bytes of scratch; dsf_conv_x6_wrw refuses in this mode).
+ * (dsf_conv_x6_wrw_ws with dsf_conv_x6_wrw_workspace_bytes(...) bytes of scratch; dsf_conv_x6_wrw refuses in this mode;
+ * accumulate != 0 starts the ordered sum from what dW holds, as in the default mode).
  * Returns the previous setting.  Off (default): float atomics, results agree to ~1e-7 relative.
  * ---------------------------------------------------------------------------------- */
 int dsf_set_deterministic(int on);

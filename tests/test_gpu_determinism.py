@@ -179,10 +179,12 @@ def test_graphed_step_refuses_a_graph_with_memset_nodes(render):
 
 def test_backward_weights_side_stream_is_invisible(det_mode):
     """nn_conv runs dW of a convolution on a second stream when nothing can read that gradient before the backward pass ends
-    (leaf weight, one use in the graph, no gradient yet, no foreign hooks).  In deterministic mode every variant below must
+    (leaf weight in kernel layout, no gradient yet, no foreign hooks).  In deterministic mode every variant below must
     give BITWISE the gradients of the single-stream run: one use (side stream taken), a network applied to two batches (the
-    engine adds the two contributions on the main stream: side stream refused), accumulation over two backward calls, a
-    tensor hook on the weight, a non-leaf (merged) weight, and a create_graph pass followed by a second backward."""
+    engine adds the two contributions on the main stream: the second joins the streams first), accumulation over two
+    backward calls, a tensor hook on the weight, a non-leaf (merged) weight, a create_graph pass followed by a second
+    backward, a standard-layout leaf weight (AccumulateGrad would clone its dW on the main stream) and a
+    retained graph differentiated together with a new one (a forward-time use count under-counts there)."""
     from dsf_amd import nn_conv, nn_norm, _lib as L
     torch.manual_seed(2)
     net = torch.nn.Sequential(nn_conv.Conv2d(64, 128, 3, 1, 1, bias=False), nn_norm.FusedBatchNorm2d(128, fuse_relu=True),
@@ -242,7 +244,30 @@ def test_backward_weights_side_stream_is_invisible(det_mode):
         torch.cuda.synchronize()
         return [convs[0].weight.grad.clone(), convs[2].weight.grad.clone()]
 
-    for case in (one_use, two_uses, two_backwards, hooked, merged_weight, double_backward):
+    def standard_layout_weight():
+        # a leaf weight in torch's standard memory order handed straight to the Function: dW (kernel order) would not obey
+        # AccumulateGrad's layout contract, which then CLONES it on the main stream -- such a weight must stay on one stream
+        net.zero_grad(set_to_none=True)
+        w = convs[2].weight.detach().contiguous().clone().requires_grad_(True)
+        assert not w.permute(2, 3, 1, 0).is_contiguous()
+        y = net[:4](xa)
+        nn_conv.Conv2dFunction.apply(y, w, None, 1, (0, 0)).square().mean().backward()
+        torch.cuda.synchronize()
+        return [w.grad.clone()] + [p.grad.clone() for p in net[:4].parameters()]
+
+    def retained_plus_new_graph():
+        # one backward pass over a RETAINED graph and a new one: every weight receives two contributions in that pass although
+        # each forward saw it once -- decided per backward pass (nn_conv._wrw_dispatch), not from a forward-time count
+        net.zero_grad(set_to_none=True)
+        l1 = net(xa).square().mean()
+        l1.backward(retain_graph=True)
+        net.zero_grad(set_to_none=True)
+        l2 = net(xb).abs().mean()
+        (l1 + l2).backward()
+        return grads()
+
+    for case in (one_use, two_uses, two_backwards, hooked, merged_weight, double_backward, standard_layout_weight,
+                 retained_plus_new_graph):
         nn_conv.WRW_STREAM[0] = False
         try:
             ref = case()
@@ -291,6 +316,11 @@ def test_backward_weights_side_stream_is_invisible(det_mode):
         one_use()
         n_one = len(taken)
         two_uses()
+        n_two = len(taken) - n_one
+        standard_layout_weight()
+        n_std = len(taken) - n_one - n_two
     finally:
         nn_conv._on_side_stream = orig
-    assert n_one == 4 and len(taken) == n_one                                  # 3 convolutions + 1 transposed; none when the net is used twice
+    # 3 convolutions + 1 transposed; a net used twice (deterministic mode): each weight's first contribution only, the second
+    # joins the streams and runs on the main one; the standard-layout weight never (the two convolutions below it do)
+    assert n_one == 4 and n_two == 4 and n_std == 2

@@ -43,6 +43,37 @@ def test_gradient_penalty_double_backward_vs_torch(netD, norm):
     assert cos > 0.9995 and rel < 2e-2, (cos, rel)
 
 
+GP_CASES = (("basic", (1, 8, "basic", 3, "instance", "normal", 0.2), "mixed"), ("nl2", (1, 8, "n_layers", 2, "batch", "normal", 0.2), "mixed"),
+            ("pixel", (1, 8, "pixel", 3, "batch", "normal", 0.2), "mixed"),
+            ("basic_real", (1, 8, "basic", 3, "instance", "normal", 0.2), "real"),
+            ("basic_fake", (1, 8, "basic", 3, "instance", "normal", 0.2), "fake"))        # as tests/golden/make_golden_gp.py
+
+
+@pytest.mark.parametrize("case", range(5))
+def test_gradient_penalty_vs_reference_golden(case):
+    """The HIP discriminators through the product's ``cal_gradient_penalty`` against the REFERENCE's own call of its
+    ``cal_gradient_penalty`` (render_model/transfer.py:356-391; tests/golden/reference_gp.npz, mixing draw recorded):
+    value and returned input gradients within 2e-3, second-order parameter gradients cosine > 0.9995."""
+    import os
+    from dsf_amd.render_model.transfer import define_D, cal_gradient_penalty
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_gp.npz"))
+    tag, args, kind = GP_CASES[case]
+    _, gpu = _pair(lambda: define_D(*args), int(g["seed_net"]))
+    real, fake = torch.tensor(g["real"]).cuda(), torch.tensor(g["fake"]).cuda()
+    gp, grads = cal_gradient_penalty(gpu, real, fake, 'cuda', kind, 1.0, 10.0, alpha=torch.tensor(g[tag + "_alpha"]).cuda())
+    gp.backward()
+    ref = float(g[tag + "_gp"])
+    assert abs(float(gp) - ref) <= 2e-3 * abs(ref), (float(gp), ref)
+    gr = g[tag + "_grads"]
+    assert np.abs(grads.detach().cpu().numpy() - gr).max() <= 2e-3 * np.abs(gr).max()
+    if kind == "mixed":
+        a = torch.tensor(g[tag + "_param_grads"]).double()
+        b = torch.cat([p.grad.cpu().flatten().double() for p in gpu.parameters() if p.grad is not None])
+        assert a.numel() == b.numel()
+        cos, rel = float((a * b).sum() / (a.norm() * b.norm())), float((a - b).norm() / a.norm())
+        assert cos > 0.9995 and rel < 2e-2, (cos, rel)
+
+
 @pytest.mark.parametrize("gan_mode", ["lsgan", "wgangp"])
 def test_consis_cyclegan_step_vs_torch(gan_mode):
     from dsf_amd.render_model.transfer import define_G, define_D

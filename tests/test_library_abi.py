@@ -117,3 +117,26 @@ def test_torch_library_ops_are_registered_with_fake_kernels():
     with pytest.raises((NotImplementedError, RuntimeError)):             # CPU tensors: no kernel registered, no fallback
         torch.ops.dsf.point_face_dist_forward(torch.zeros(4, 3), torch.zeros(1, dtype=torch.int64), torch.zeros(2, 3, 3),
                                               torch.zeros(1, dtype=torch.int64), 4)
+
+
+def test_side_stream_capability_guard(monkeypatch):
+    """The weight-gradient side stream rests on private torch interfaces (graph task id, the engine's end-of-pass callback, the
+    tensor hook dictionaries): nn_conv probes them once and keeps everything on one stream when one is missing."""
+    from dsf_amd import nn_conv
+    assert nn_conv._side_api_ok() and nn_conv.SIDE_API                      # this torch has them all
+    monkeypatch.delattr(torch._C, "_current_graph_task_id")
+    assert not nn_conv._side_api_ok()
+    monkeypatch.undo()
+    monkeypatch.setattr(torch._C, "_current_graph_task_id", lambda: 0)      # present but not -1 outside a backward pass: unknown semantics
+    assert not nn_conv._side_api_ok()
+    monkeypatch.undo()
+    # with the interfaces reported missing no weight qualifies, whatever else holds
+    w = torch.nn.Parameter(torch.zeros(8, 8, 3, 3).permute(2, 3, 1, 0).contiguous().permute(3, 2, 0, 1))
+    assert w.permute(2, 3, 1, 0).is_contiguous()
+    monkeypatch.setattr(nn_conv, "WRW_STREAM", [False])
+    assert not nn_conv._side_ok(w)
+    monkeypatch.setattr(nn_conv, "WRW_STREAM", [True])
+    assert nn_conv._side_ok(w)
+    assert not nn_conv._side_ok(torch.nn.Parameter(torch.zeros(8, 8, 3, 3)))   # standard layout: AccumulateGrad would clone dW
+    nn_conv.no_side_stream([w])
+    assert not nn_conv._side_ok(w)

@@ -212,6 +212,41 @@ def test_discriminators_and_gan_loss_match_reference_golden():
         assert abs(float(L(pred, False)) - float(g["gan_%s_fake" % mode])) < 1e-6
 
 
+GP_CASES = (("basic", (1, 8, "basic", 3, "instance", "normal", 0.2), "mixed"), ("nl2", (1, 8, "n_layers", 2, "batch", "normal", 0.2), "mixed"),
+            ("pixel", (1, 8, "pixel", 3, "batch", "normal", 0.2), "mixed"),
+            ("basic_real", (1, 8, "basic", 3, "instance", "normal", 0.2), "real"),
+            ("basic_fake", (1, 8, "basic", 3, "instance", "normal", 0.2), "fake"))
+
+
+def test_gradient_penalty_matches_reference_golden():
+    """The product's ``cal_gradient_penalty`` formula (mixing, create_graph gradient, ``(||g + 1e-16|| - c)^2 * lambda``) on the
+    torch.nn twins == the reference's own ``cal_gradient_penalty`` (render_model/transfer.py:356-391) on its own ``define_D``,
+    recorded by tests/golden/make_golden_gp.py with the ``torch.rand`` draw of the mixing coefficients saved: value, the
+    returned input gradients and the penalty's gradient w.r.t. every discriminator parameter (second order)."""
+    import os
+    import torch
+    from dsf_amd.render_model import transfer as T
+    from oracle import nets
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_gp.npz"))
+    real, fake = torch.tensor(g["real"]), torch.tensor(g["fake"])
+    for tag, args, kind in GP_CASES:
+        torch.manual_seed(int(g["seed_net"]))
+        D = nets.build(T.define_D, *args)
+        assert list(D.state_dict().keys()) == list(g[tag + "_keys"])
+        sums = np.array([[float(v.double().sum()), float(v.double().abs().sum())] for v in D.state_dict().values()
+                         if v.dtype.is_floating_point])
+        assert np.array_equal(sums, g[tag + "_state_sums"])                     # same seeded weights as the reference's network
+        gp, grads = T.cal_gradient_penalty(D, real.clone(), fake.clone(), "cpu", kind, 1.0, 10.0, alpha=torch.tensor(g[tag + "_alpha"]))
+        gp.backward()
+        assert abs(float(gp) - float(g[tag + "_gp"])) <= 1e-6 * abs(float(g[tag + "_gp"]))
+        assert np.array_equal(grads.detach().numpy(), g[tag + "_grads"])
+        if kind == "mixed":
+            pg = np.concatenate([p.grad.flatten().numpy() for p in D.parameters() if p.grad is not None])
+            assert pg.shape == g[tag + "_param_grads"].shape
+            assert np.abs(pg - g[tag + "_param_grads"]).max() <= 1e-6 * np.abs(g[tag + "_param_grads"]).max()
+    assert T.cal_gradient_penalty(D, real, fake, "cpu", "mixed", 1.0, 0.0) == (0.0, None)
+
+
 def test_network_twins_are_bit_identical_to_the_reference(golden_nets):
     """Same seed, same builder code on torch.nn layers (oracle.nets) => the reference's state-dict keys, parameter
     counts and bit-identical outputs (tests/golden/reference_nets.npz was recorded from the imported reference)."""
