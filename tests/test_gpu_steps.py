@@ -224,9 +224,31 @@ def test_config3_mesh_loss_step_vs_oracle(render, orender):
 # ------------------------------------------------------------------------------------------------
 # Trainer.Pretrain and config 4 (multi-view, ResNet-50)
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("backbone,views,B,refine", [("ResNet_stage_18", 1, 2, True), ("ResNet_stage_50", 3, 2, False),
-                                                     ("ResNet_stage_50", 3, 2, True)])
-def test_pretrain_and_config4_multiview_step_vs_oracle(render, orender, backbone, views, B, refine):
+def _freeze_statistics(net_cpu, net_gpu, orender, p, cube, d, views, gen=None):
+    """Frozen-statistics BatchNorm for both twins: the running statistics become the batch statistics of ONE training-mode
+    pass of the CPU twin over the step's own images (momentum 1), then both networks go to evaluation mode.  The network is
+    then normalised as in training, but no BatchNorm couples the 6..24 samples of the batch any more -- the well-conditioned
+    variant of a case (the ill-conditioning of two-stage ResNet-50 at tiny batches is the batch statistics' Jacobian)."""
+    from oracle import step_ref
+    import torch.nn as nn
+    bns = [m for m in net_cpu.modules() if isinstance(m, nn.BatchNorm2d)]
+    saved = [m.momentum for m in bns]
+    for m in bns:
+        m.momentum = 1.0
+    with torch.no_grad():
+        pp, cc = (p.repeat_interleave(views, 0), cube.repeat_interleave(views, 0)) if views > 1 else (p, cube)
+        s_c = step_ref.synth_pass(orender, gen, pp, cc, d, True)
+        net_cpu.train()
+        net_cpu(s_c["img_t"], orender, s_c["center"], s_c["cube"])
+    for m, mom in zip(bns, saved):
+        m.momentum = mom
+    net_gpu.load_state_dict(net_cpu.state_dict())
+    net_cpu.eval(); net_gpu.eval()
+
+
+@pytest.mark.parametrize("backbone,views,B,refine,frozen", [("ResNet_stage_18", 1, 2, True, False), ("ResNet_stage_50", 3, 2, False, False),
+                                                            ("ResNet_stage_50", 3, 2, True, False), ("ResNet_stage_50", 3, 2, True, True)])
+def test_pretrain_and_config4_multiview_step_vs_oracle(render, orender, backbone, views, B, refine, frozen):
     """Trainer.Pretrain (views 1) and BASELINE config 4 (ResNet-50, 3 views per sample).  Strict bars for the two-stage
     ResNet-18 and for the ONE-stage ResNet-50 (Bottleneck trunk + multi-view render + loss list).  The two-stage ResNet-50 is
     compared through float64: besides being ill-conditioned (_Net64), its stage-2 input is a DISCONTINUOUS function of the
@@ -246,6 +268,10 @@ def test_pretrain_and_config4_multiview_step_vs_oracle(render, orender, backbone
     step = PretrainStep(net_gpu, render, gen_gpu, Config, views=views)
     p, _, cube = synthetic_batch(B, "cpu", seed=31)
     d = step.draw(B, "cpu", torch.Generator().manual_seed(32), np.random.default_rng(33))
+    if frozen:
+        # the WELL-CONDITIONED two-stage ResNet-50 multi-view case: same net, same images, BatchNorm with frozen statistics --
+        # held to the strict bars (loss 2e-3, gradient cosine 0.9995) below
+        _freeze_statistics(net_cpu, net_gpu, orender, p, cube, d, views, gen_cpu)
     assert d["aug_view"].shape == (B * views, 3) and (views == 1) == bool((d["aug_view"] == 0).all())
     rec = _Recording(orender)
     loss_c = step_ref.pretrain_loss(net_cpu, rec, gen_cpu, p, cube, d, Config, views=views)
@@ -268,7 +294,7 @@ def test_pretrain_and_config4_multiview_step_vs_oracle(render, orender, backbone
         pinned = PretrainStep(net_gpu, _PinnedBridge(render, rec.images), gen_gpu, Config, views=views, optimizer=step.opt)
         loss_g, _ = pinned.loss(p.cuda(), cube.cuda(), draws_to(d, "cuda"))
     loss_g.backward()
-    if backbone.endswith("18") or not refine:
+    if backbone.endswith("18") or not refine or frozen:
         _compare(loss_c, loss_g, net_cpu, net_gpu)
     else:
         # both fp32 paths against the float64 trunk (see the docstring)
@@ -465,3 +491,60 @@ def test_resnet50_bottleneck_vs_reference_golden():
     assert rel(xg.grad.cpu().numpy()[:, :, ::4, ::4], g["grad_x_sub"]) < (1e-1 if L.deterministic() else 5e-2)
     rm = net.layer4[2].bn3.running_mean.cpu().numpy()[:32]
     assert np.abs(rm - g["running_mean_layer4_2_bn3_head"]).max() < 1e-4 * max(1.0, np.abs(rm).max())
+# Render.forward: every output asserted directly (not only through a loss)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("views", [1, 3])
+def test_render_forward_all_eight_outputs_vs_oracle(render, orender, views):
+    """``Render.forward`` (mano_layer.py:983-1039) with every augmentation and the occluder mask, output by output against
+    ``OracleRender.forward`` on the same draws: perturbed centre / cube and the crop matrix ``M`` EXACT; joint / vertex uvd and
+    xyz within 1e-4 (north star); the image bit-exact when the rasteriser is handed the oracle's vertices, and -- end to end,
+    where the fused MANO kernel's vertices differ from torch's by ulps -- equal except for silhouette pixels, depths within
+    1e-4; the mask (:1326-1340) bit-equal on equal inputs."""
+    from oracle import step_ref, hand_ref as H
+    from dsf_amd.train_step import PretrainStep, synthetic_batch, draws_to, Config
+    B = 4
+    step = PretrainStep(None, render, None, Config, views=views, optimizer=object())
+    p, _, cube = synthetic_batch(B, "cpu", seed=61)
+    d = step.draw(B, "cpu", torch.Generator().manual_seed(62), np.random.default_rng(63))
+    if views > 1:
+        p, cube = p.repeat_interleave(views, 0), cube.repeat_interleave(views, 0)
+    dg = draws_to(d, "cuda")
+    md = (d["mask_joint_id"], d["mask_offset"], d["mask_radius"])
+    with torch.no_grad():
+        ref = orender.forward(p, d["center0"], cube, d["aug_view"], d["aug_shape"], d["aug_center"], d["aug_size"], None)
+        got = render(p.cuda(), dg["center0"], cube.cuda(), augmentView=dg["aug_view"], augmentShape=dg["aug_shape"],
+                     augmentCenter=dg["aug_center"], augmentSize=dg["aug_size"], mask=False)
+    img_c, juvd_c, vuvd_c, jxyz_c, vxyz_c, center_c, cube_c, M_c = ref
+    img_g, juvd_g, vuvd_g, jxyz_g, vxyz_g, center_g, cube_g, M_g = [t.cpu() for t in got]
+    assert torch.equal(center_g, center_c) and torch.equal(cube_g, cube_c)            # perturbed centre / cube: exact
+    assert torch.equal(M_g.float(), M_c.float())                                       # crop matrix: exact (integer bounds)
+    for name, a, b in (("joint_uvd", juvd_g, juvd_c), ("verts_uvd", vuvd_g, vuvd_c), ("joint_xyz", jxyz_g, jxyz_c),
+                       ("verts_xyz", vxyz_g, vxyz_c)):
+        assert a.shape == b.shape and (a - b).abs().max() < 1e-4, (name, float((a - b).abs().max()))
+    assert img_g.shape == img_c.shape == (B * views, 1, 128, 128)
+    diff = (img_g - img_c).abs()
+    fg = int((img_c < 0.99).sum())
+    assert fg > 200 * B * views
+    assert int((diff > 1e-4).sum()) <= max(2, fg // 200), (int((diff > 1e-4).sum()), fg)   # silhouette pixels only
+    # the SAME vertices through both rasterisers: bit-exact image (world vertices rebuilt exactly as :1001-1016 does)
+    with torch.no_grad():
+        beta = p[:, 48:58] + d["aug_shape"]
+        v, j = H.mano_vertices(orender.hm, p[:, :3], p[:, 3:48], beta, p[:, 58:62])
+        c = j.mean(dim=1, keepdim=True)
+        v = v - c + d["center0"].unsqueeze(1)
+        Rm = H.rodrigues(d["aug_view"]).unsqueeze(1)
+        c3 = d["center0"].unsqueeze(1)
+        v = torch.matmul(Rm, (v - c3).unsqueeze(-1)).squeeze(-1) + c3
+        img_same = render._depth_crop(v.cuda().contiguous(), center_c.cuda(), cube_c.cuda())[0].cpu()
+    assert torch.equal(img_same, img_c)
+    # mask_img on equal inputs: bit-equal, and it does occlude something
+    with torch.no_grad():
+        m_c = step_ref.mask_image(img_c, juvd_c, *md)
+        m_g = render.mask_img(img_c.cuda(), juvd_c.cuda(), 0.15, 0.3, draws=(dg["mask_joint_id"], dg["mask_offset"], dg["mask_radius"])).cpu()
+    assert torch.equal(m_g, m_c) and (m_c != img_c).any()
+    # forward(mask=True) draws its occluders itself (host numpy + torch, as the reference): it only ever sets pixels to 1.0
+    np.random.seed(5); torch.manual_seed(6)
+    with torch.no_grad():
+        full = render(p.cuda(), dg["center0"], cube.cuda(), augmentView=dg["aug_view"], augmentShape=dg["aug_shape"],
+                      augmentCenter=dg["aug_center"], augmentSize=dg["aug_size"], mask=True)[0].cpu()
+    assert full.shape == img_g.shape and ((full == img_g) | (full == 1.0)).all() and (full != img_g).any()

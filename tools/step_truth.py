@@ -1,6 +1,8 @@
 """Which fp32 path is closer to the float64 gradients of an ill-conditioned two-stage net?  (diagnostic for
 tests/test_gpu_steps.py::test_pretrain_and_config4_multiview_step_vs_oracle)
-  python tools/step_truth.py ResNet_stage_50 3 2      [DSF_CONV_MATH=f32] [DSF_FUSED_BN=0]"""
+  python tools/step_truth.py ResNet_stage_50 3 2 [frozen]     [DSF_CONV_MATH=f32] [DSF_FUSED_BN=0] [DSF_DETERMINISTIC=1]
+``frozen``: BatchNorm with frozen statistics (taken from one batch-statistics pass over the same images), the
+well-conditioned variant of the case."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -12,12 +14,15 @@ from dsf_amd.model.backbone import MANO_OCR_stage
 from dsf_amd.render_model.mano_layer import Render
 from dsf_amd.train_step import PretrainStep, synthetic_batch, draws_to, Config
 backbone, views, B = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+frozen = len(sys.argv) > 4 and sys.argv[4] == "frozen"
 render = Render("synthetic", "nyu", T.CAM, (640, 480)).cuda()
 orender = step_ref.OracleRender(build_synthetic_mano(0))
 net_cpu, net_gpu = T._twin_pair(MANO_OCR_stage, backbone, 21, True, seed=5)
 step = PretrainStep(net_gpu, render, None, Config, views=views)
 p, _, cube = synthetic_batch(B, "cpu", seed=31)
 d = step.draw(B, "cpu", torch.Generator().manual_seed(32), np.random.default_rng(33))
+if frozen:
+    T._freeze_statistics(net_cpu, net_gpu, orender, p, cube, d, views)
 rec = T._Recording(orender)
 step_ref.pretrain_loss(net_cpu, rec, None, p, cube, d, Config, views=views).backward()
 pinned = PretrainStep(net_gpu, T._PinnedBridge(render, rec.images), None, Config, views=views, optimizer=step.opt)
