@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(const float* __restric
 // Tiles: BN 128: 128 x 128 (2 x 2 waves of 64 x 64) or 64 x 128 (2 x 2 waves of 32 x 64: the 8x8 .. 32x32 maps);
 //        BN 64:  256 x 64  (4 x 1 waves of 64 x 64): the 64-channel layers get the 64 x 64 wave tile too.
 // ------------------------------------------------------------------------------------------------
-struct X6Ep { const float* scale; const float* shift; const float* residual; int relu; };   // output epilogue (all null: none)
+struct X6Ep { const float* scale; const float* shift; const float* residual; int relu; int stats_acc; };   // output epilogue (all null: none); stats_acc: see `stats`
 
 template <int BN, bool DIL2, int BMT>
 __global__ __launch_bounds__(256, 2) void igemm_x6b_kernel(const float* __restrict__ X, const uint4* __restrict__ Wimg,
@@ -613,7 +613,11 @@ __global__ __launch_bounds__(256, 2) void igemm_x6b_kernel(const float* __restri
             float tot = 0.f;
 #pragma unroll
             for (int w = 0; w < WAVES_M; ++w) tot += s_st[(BN == 128) ? (w * 2 + wcol) : w][which][lc];
-            stats[((int64_t)m_tile * 2 + which) * p.Co + n] = tot;
+            // ep.stats_acc == 0: partial row m_tile (folded in a fixed order by bn_finalize_kernel);  > 0: added into row
+            // (m_tile mod stats_acc) of a zeroed block of that many rows with float atomics (folded by the BatchNorm apply
+            // kernel's own prologue: dsf_bn_forward_acc) -- <= 32 adders per address, ~1 MB of atomics per launch
+            if (ep.stats_acc > 0) atomicAdd(&stats[((int64_t)(m_tile % ep.stats_acc) * 2 + which) * p.Co + n], tot);
+            else stats[((int64_t)m_tile * 2 + which) * p.Co + n] = tot;
         }
     }
 }
@@ -789,6 +793,197 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// igemm_wrw_x6b_kernel: backward-weights with the dY operand read STRAIGHT INTO THE MFMA FRAGMENT REGISTERS (round 3).
+//
+// Why: in igemm_wrw_x6_kernel BOTH operands are activations, so per 16-pixel chunk a wave splits 4 float4, writes 12
+// ds_write_b64 and issues 24 transposing LDS reads beside its 24 MFMAs -- twice the loader work of the forward kernels per
+// MFMA; and every dY element is loaded, split and transposed again by each of the K / 128 workgroups that share its
+// channels (35 times on the 488 -> 256 layer).  x6_split_dy_kernel does that work ONCE per element: it writes dY as an image
+// that is already the MFMA B fragment -- per (16-pixel chunk, n tile) three planes of [k-group 2][n BN] granules, a granule
+// = 8 consecutive PIXELS of one channel as bf16 -- exactly what the weight image is for the forward kernels (igemm_x6b).
+// Lane l of a wave then reads granule (k-group l >> 5, n) with one coalesced 16-byte buffer load, one chunk ahead, into
+// registers; the workgroups of an XCD that share the n tile walk the pixels in step, so these loads hit L2.  LDS carries the X
+// tile only: per chunk and wave 2 float4 loads, 2 splits, 6 ds_write_b64, 12 transposing reads -- the forward kernel's mix.
+// Cost: the image pass reads 4 and writes 6 bytes per dY element (memory-bound, on the weight-gradient stream).
+// ------------------------------------------------------------------------------------------------
+template <int BN>
+__global__ __launch_bounds__(256) void x6_split_dy_kernel(const float* __restrict__ dY, uint4* __restrict__ img, int M, int Co,
+                                                          int n_tiles) {
+    // one workgroup per (16-pixel chunk, n tile): thread -> (k-group kg, channel n): 8 pixels of one channel
+    const int t = threadIdx.x;
+    if (t >= 2 * BN) return;
+    const int chunk = blockIdx.x / n_tiles, n_tile = blockIdx.x % n_tiles;
+    const int nl = t % BN, kg = t / BN;
+    const int n = n_tile * BN + nl;
+    const int m0 = chunk * XBK + kg * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (n < Co && m0 + e < M) ? dY[(int64_t)(m0 + e) * Co + n] : 0.f;
+    uint2 h0, m0s, l0, h1, m1s, l1;
+    split4(__builtin_bit_cast(u32x4, (f32x4){v[0], v[1], v[2], v[3]}), h0, m0s, l0);
+    split4(__builtin_bit_cast(u32x4, (f32x4){v[4], v[5], v[6], v[7]}), h1, m1s, l1);
+    const int64_t base = (int64_t)blockIdx.x * (6 * BN) + kg * BN + nl;
+    img[base] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+    img[base + 2 * BN] = make_uint4(m0s.x, m0s.y, m1s.x, m1s.y);
+    img[base + 4 * BN] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+}
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void igemm_wrw_x6b_kernel(const float* __restrict__ X, const uint4* __restrict__ dYimg,
+                                                              float* __restrict__ dW, X6P p, int k_tiles, int n_tiles,
+                                                              int n_splits, int m_per_split, uint64_t magic_wo,
+                                                              uint64_t magic_ho, uint32_t x_bytes, uint32_t img_bytes,
+                                                              float* __restrict__ partial) {
+    constexpr int WM = (BN == 128) ? 64 : 32;
+    constexpr int TM = WM / 32, TN = 2, PLANE = 16 * 256;      // bytes per plane of the X tile
+    __shared__ __attribute__((aligned(16))) char As[2][3 * PLANE];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = (BN == 128) ? (wave >> 1) : wave, wn = (BN == 128) ? (wave & 1) : 0;
+    int tile = x6_xcd_contiguous(blockIdx.x, k_tiles * n_tiles * n_splits);
+    const int k_tile = tile % k_tiles; tile /= k_tiles;
+    const int n_tile = tile % n_tiles; const int split = tile / n_tiles;
+    const int k0 = k_tile * 128, n0 = n_tile * BN;
+    const int M = p.B * p.Ho * p.Wo, K = p.KH * p.KW * p.Ci;
+    const int m_begin = split * m_per_split, m_end = min(M, m_begin + m_per_split);
+    const __amdgpu_buffer_rsrc_t xbuf = x6_buffer(X, x_bytes), ybuf = x6_buffer(dYimg, img_bytes);
+
+    // X loader: thread -> (channel quad l_q of the tile's 128 k rows, pixel (t >> 5) + 8 i of the chunk)
+    const int l_q = t & 31, l_p = t >> 5;
+    const int a_k = k0 + l_q * 4;
+    const bool a_kok = a_k < K;
+    const int a_tap = min(a_k, K - 1) / p.Ci;
+    const int a_c = min(a_k, K - 1) % p.Ci, a_kh = a_tap / p.KW, a_kw = a_tap % p.KW;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    u32x4 ra[2][2];                                      // [set][px 0, px 8]: X loads, two chunks ahead
+    u32x4 rbf[2][3][TN];                                 // [set][plane][n block]: dY fragments as loaded, one chunk ahead
+    const uint32_t b_lane = (uint32_t)((lane >> 5) * BN + wn * 64 + (lane & 31)) * 16u;
+    auto load_a = [&](auto SET, int j, int mc) {
+        constexpr int S = decltype(SET)::value;
+        const int m = mc + l_p + 8 * j;
+        const uint32_t mm = (uint32_t)min(m, M - 1);
+        const uint32_t q = x6_fast_div(mm, magic_wo);
+        const int ox = (int)(mm - q * (uint32_t)p.Wo);
+        const uint32_t b = x6_fast_div(q, magic_ho);
+        const int oy = (int)(q - b * (uint32_t)p.Ho);
+        const int iy = oy * p.stride + a_kh - p.pad_h, ix = ox * p.stride + a_kw - p.pad_w;
+        const bool ok = a_kok & (m < m_end) & ((unsigned)iy < (unsigned)p.Hi) & ((unsigned)ix < (unsigned)p.Wi);
+        const uint32_t off = (uint32_t)((((int)b * p.Hi + iy) * p.Wi + ix) * p.Ci + a_c) * 4u;
+        ra[S][j] = x6_load16(xbuf, ok ? off : X_OOB);
+    };
+    auto load_b = [&](auto SET, int f, int mc) {
+        constexpr int S = decltype(SET)::value;
+        const int pl = f / TN, j = f % TN;
+        const uint32_t dead = (mc < m_end) ? 0u : X_OOB;                    // (offset | ~0) is the out-of-range offset: zeros
+        const uint32_t blk = (uint32_t)((mc >> 4) * n_tiles + n_tile);      // image block of (pixel chunk, n tile)
+        rbf[S][pl][j] = x6_load16(ybuf, (blk * (uint32_t)(6 * BN * 16) + (uint32_t)(pl * 2 * BN * 16 + j * 32 * 16) + b_lane) | dead);
+    };
+    const int st_off0 = x6_tr_off(l_p, l_q >> 1) + 8 * (l_q & 1), st_off1 = x6_tr_off(l_p + 8, l_q >> 1) + 8 * (l_q & 1);
+    auto stage_a = [&](auto SET, int buf, int j) {
+        constexpr int S = decltype(SET)::value;
+        uint2 h, m, l;
+        split4(ra[S][j], h, m, l);
+        char* base = As[buf] + (j ? st_off1 : st_off0);
+        *reinterpret_cast<uint2*>(base) = h;
+        *reinterpret_cast<uint2*>(base + PLANE) = m;
+        *reinterpret_cast<uint2*>(base + 2 * PLANE) = l;
+    };
+
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, 1>;
+    if (m_begin < m_end) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) load_a(Set0{}, j, m_begin);
+#pragma unroll
+        for (int f = 0; f < 3 * TN; ++f) load_b(Set0{}, f, m_begin);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) load_a(Set1{}, j, m_begin + XBK);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) stage_a(Set0{}, 0, j);
+    }
+    __syncthreads();
+
+    const int f_row = 8 * (lane >> 5) + ((lane & 15) >> 2);
+    const int f_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    auto frag_off = [&](int cbase, int r) {
+        const int c = cbase + f_col;
+        return x6_tr_off(f_row + 4 * r, c >> 3) + 2 * (c & 7);
+    };
+    int fa[TM][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { fa[i][0] = frag_off(wm * WM + i * 32, 0); fa[i][1] = frag_off(wm * WM + i * 32, 1); }
+    auto tr_read = [&](const char* base, int off0, int off1) {
+        struct { s16x4 lo, hi; } v;
+        v.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off0));
+        v.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off1));
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+    // chunk mc (parity SET): X fragments from LDS stage SET, dY fragments = register set SET.  Between its MFMAs: the dY fragment
+    // loads of chunk mc + 16 (set OTHER), the X loads of chunk mc + 32 (ra[SET], staged during chunk mc - 16), then the LDS
+    // stores of chunk mc + 16's X tile.
+    auto body = [&](auto SET, auto OTHER, int mc) {
+        constexpr int buf = decltype(SET)::value;
+        bf16x8 a[3][TM];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[pl][i] = tr_read(As[buf] + pl * PLANE, fa[i][0], fa[i][1]);
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};
+        constexpr int NM = 6 * TM * TN;
+        constexpr int NB = 3 * TN, NP = NB + 4;                           // pieces: 6 dY loads, 2 X loads, 2 X stores
+        int slot = 0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][i], __builtin_bit_cast(bf16x8, rbf[buf][PB[q]][j]),
+                                                                        acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int pc = 0; pc < NP; ++pc) {
+                        if (slot == (pc * NM) / NP) {
+                            if (pc < NB) load_b(OTHER, pc, mc + XBK);
+                            else if (pc < NB + 2) load_a(SET, pc - NB, mc + 2 * XBK);
+                            else stage_a(OTHER, buf ^ 1, pc - NB - 2);
+                        }
+                    }
+                    ++slot;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        __syncthreads();
+    };
+    for (int mc = m_begin; mc < m_end; mc += 2 * XBK) {         // chunks come in pairs: one past m_end is all zeros
+        body(Set0{}, Set1{}, mc);
+        body(Set1{}, Set0{}, mc + XBK);
+    }
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (n >= p.Co) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = k0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (k >= K) continue;
+                if (partial) partial[((int64_t)split * K + k) * p.Co + n] = acc[i][j][r];
+                else atomicAdd(dW + (int64_t)k * p.Co + n, acc[i][j][r]);
+            }
+        }
+}
+
 // dW[e] = sum over the pixel splits, ascending (deterministic mode)
 // (n is a multiple of 4: K * Co with Co % 4 == 0; four elements per lane, the splits still added one by one in ascending order)
 // accumulate != 0: the ordered sum starts from what dW holds (the launcher's `accumulate` contract; still one fixed order)
@@ -925,7 +1120,7 @@ static int x6_forward_impl(const float* X, const void* image, const float* bias,
     if (bn_rows) *bn_rows = stats ? m_tiles : 0;
     // the affine output epilogue has the same conditions (a split reduction meets in Y by atomics; the staged kernel has none)
     const bool ep_on = ep.scale && direct_pre && k_splits == 1;
-    if (!ep_on) ep = X6Ep{nullptr, nullptr, nullptr, 0};
+    if (!ep_on) ep = X6Ep{nullptr, nullptr, nullptr, 0, ep.stats_acc};
     if (ep_applied) *ep_applied = ep_on ? 1 : 0;
 #define DSF_LAUNCH_X6(KERNEL, BNv, DILv, BMv) hipLaunchKernelGGL((KERNEL<BNv, DILv, BMv>), grid, dim3(256), 0, (hipStream_t)stream, \
                                                        X, (const uint4*)image, bias, Y, p, m_tiles, n_tiles, k_splits,              \
@@ -968,7 +1163,7 @@ int dsf_conv_x6_forward(const float* X, const void* image, const float* bias, fl
                         int Wo, int Co, int KH, int KW, int stride, int dil, int pad_h, int pad_w, int k_splits,
                         dsf_stream_t stream) {
     return x6_forward_impl(X, image, bias, Y, B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, dil, pad_h, pad_w, k_splits, nullptr, nullptr,
-                           X6Ep{nullptr, nullptr, nullptr, 0}, nullptr, stream);
+                           X6Ep{nullptr, nullptr, nullptr, 0, 0}, nullptr, stream);
 }
 
 // partial rows a BatchNorm-statistics epilogue may write for an (M = B Ho Wo)-row output: one per 64 rows at most
@@ -979,7 +1174,23 @@ int dsf_conv_x6_forward_bn(const float* X, const void* image, float* Y, int B, i
                            dsf_stream_t stream) {
     DSF_CHECK_ARG(bn_stats && bn_rows);
     return x6_forward_impl(X, image, nullptr, Y, B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, dil, pad_h, pad_w, 0, bn_stats, bn_rows,
-                           X6Ep{nullptr, nullptr, nullptr, 0}, nullptr, stream);
+                           X6Ep{nullptr, nullptr, nullptr, 0, 0}, nullptr, stream);
+}
+
+// As dsf_conv_x6_forward_bn, but the tile sums are ADDED (float atomics) into the caller-zeroed block `acc` of
+// dsf_bn_acc_rows() rows [row][2][Co] that dsf_bn_forward_acc folds in its own prologue (no finalise launch).  *filled = 1
+// when the launch this shape takes wrote them (else Y is the plain convolution and `acc` is untouched).  Not in
+// deterministic mode (DSF_ERR_UNSUPPORTED).
+int dsf_conv_x6_forward_bn_acc(const float* X, const void* image, float* Y, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
+                               int KH, int KW, int stride, int dil, int pad_h, int pad_w, float* acc, int acc_rows, int* filled,
+                               dsf_stream_t stream) {
+    DSF_CHECK_ARG(acc && filled && acc_rows > 0);
+    if (dsf_deterministic()) return DSF_ERR_UNSUPPORTED;
+    int rows = 0;
+    const int rc = x6_forward_impl(X, image, nullptr, Y, B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, dil, pad_h, pad_w, 0, acc, &rows,
+                                   X6Ep{nullptr, nullptr, nullptr, 0, acc_rows}, nullptr, stream);
+    *filled = rows > 0 ? 1 : 0;
+    return rc;
 }
 
 // Convolution with a fused per-channel output epilogue: Y = act((conv + bias) * scale[c] + shift[c] (+ residual)), act = ReLU
@@ -993,7 +1204,18 @@ int dsf_conv_x6_forward_affine(const float* X, const void* image, const float* b
                                dsf_stream_t stream) {
     DSF_CHECK_ARG(scale && shift && applied);
     return x6_forward_impl(X, image, bias, Y, B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, dil, pad_h, pad_w, 0, nullptr, nullptr,
-                           X6Ep{scale, shift, residual, relu}, applied, stream);
+                           X6Ep{scale, shift, residual, relu, 0}, applied, stream);
+}
+
+// bytes of the dY image igemm_wrw_x6b_kernel reads (x6_split_dy_kernel writes it): ceil(M / 16) chunks x n tiles x 3 planes
+// x 2 BN granules of 16 bytes.  0: this shape stays on the LDS-staged kernel (tiny reductions).
+int64_t dsf_conv_x6_wrw_image_bytes(int B, int Ho, int Wo, int Co) {
+    static const int direct = [] { const char* e = getenv("DSF_X6_WRW_DIRECT"); return e ? atoi(e) : 1; }();
+    const int64_t M = (int64_t)B * Ho * Wo;
+    if (!direct || M < 64 || Co < 4) return 0;
+    const int bn = x6_bn(Co);
+    const int64_t bytes = ((M + XBK - 1) / XBK) * ((Co + bn - 1) / bn) * (int64_t)(6 * bn * 16);
+    return bytes < 0xFFFFFFF0ll ? bytes : 0;                              // (32-bit buffer offsets)
 }
 
 int64_t dsf_conv_x6_wrw_workspace_bytes(int B, int Ho, int Wo, int Ci, int Co, int KH, int KW) {
@@ -1003,8 +1225,26 @@ int64_t dsf_conv_x6_wrw_workspace_bytes(int B, int Ho, int Wo, int Ci, int Co, i
     return (int64_t)splits * KH * KW * Ci * Co * 4;
 }
 
+static int x6_wrw_impl(const float* X, const float* dY, float* dW, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
+                       int KW, int stride, int pad_h, int pad_w, int accumulate, float* workspace, void* dy_image, dsf_stream_t stream);
+
 int dsf_conv_x6_wrw_ws(const float* X, const float* dY, float* dW, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
                        int KW, int stride, int pad_h, int pad_w, int accumulate, float* workspace, dsf_stream_t stream) {
+    return x6_wrw_impl(X, dY, dW, B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad_h, pad_w, accumulate, workspace, nullptr, stream);
+}
+
+// dsf_conv_x6_wrw_ws with the dY operand pre-split into `dy_image` (dsf_conv_x6_wrw_image_bytes(...) bytes of scratch, written by
+// this call): two launches, x6_split_dy_kernel + igemm_wrw_x6b_kernel.  Same results as dsf_conv_x6_wrw_ws up to the order of
+// the float atomics (bitwise the same in deterministic mode: identical products, identical per-split sums).
+int dsf_conv_x6_wrw_direct(const float* X, const float* dY, float* dW, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
+                           int KW, int stride, int pad_h, int pad_w, int accumulate, float* workspace, void* dy_image,
+                           dsf_stream_t stream) {
+    DSF_CHECK_ARG(dy_image && dsf_conv_x6_wrw_image_bytes(B, Ho, Wo, Co) > 0);
+    return x6_wrw_impl(X, dY, dW, B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad_h, pad_w, accumulate, workspace, dy_image, stream);
+}
+
+static int x6_wrw_impl(const float* X, const float* dY, float* dW, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
+                       int KW, int stride, int pad_h, int pad_w, int accumulate, float* workspace, void* dy_image, dsf_stream_t stream) {
     DSF_CHECK_ARG(X && dY && dW && B >= 0 && Hi > 0 && Wi > 0 && Ci > 0 && Ho > 0 && Wo > 0 && Co > 0 && KH > 0 && KW > 0);
     DSF_CHECK_ARG(stride >= 1 && (Ci & 3) == 0 && (Co & 3) == 0);
     const int K = KH * KW * Ci;
@@ -1022,7 +1262,23 @@ int dsf_conv_x6_wrw_ws(const float* X, const float* dY, float* dW, int B, int Hi
     const int splits = x6_wrw_plan(B, Ho, Wo, Ci, Co, KH, KW, k_tiles, n_tiles, per);
     const uint64_t mwo = ((1ull << 40) + Wo - 1) / Wo, mho = ((1ull << 40) + Ho - 1) / Ho;
     float* partial = det ? workspace : nullptr;
-    if (bn == 128)
+    if (dy_image) {
+        const int64_t img_bytes = dsf_conv_x6_wrw_image_bytes(B, Ho, Wo, Co);
+        const int chunks = (int)((M + XBK - 1) / XBK);
+        if (bn == 128) {
+            hipLaunchKernelGGL(x6_split_dy_kernel<128>, dim3(chunks * n_tiles), dim3(256), 0, (hipStream_t)stream, dY, (uint4*)dy_image,
+                               (int)M, Co, n_tiles);
+            hipLaunchKernelGGL(igemm_wrw_x6b_kernel<128>, dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream, X,
+                               (const uint4*)dy_image, dW, p, k_tiles, n_tiles, splits, (int)per, mwo, mho, (uint32_t)x_bytes,
+                               (uint32_t)img_bytes, partial);
+        } else {
+            hipLaunchKernelGGL(x6_split_dy_kernel<64>, dim3(chunks * n_tiles), dim3(128), 0, (hipStream_t)stream, dY, (uint4*)dy_image,
+                               (int)M, Co, n_tiles);
+            hipLaunchKernelGGL(igemm_wrw_x6b_kernel<64>, dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream, X,
+                               (const uint4*)dy_image, dW, p, k_tiles, n_tiles, splits, (int)per, mwo, mho, (uint32_t)x_bytes,
+                               (uint32_t)img_bytes, partial);
+        }
+    } else if (bn == 128)
         hipLaunchKernelGGL(igemm_wrw_x6_kernel<128>, dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream, X, dY,
                            dW, p, k_tiles, n_tiles, splits, (int)per, mwo, mho, (uint32_t)x_bytes, (uint32_t)dy_bytes, partial);
     else

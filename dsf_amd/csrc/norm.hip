@@ -33,7 +33,11 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
                                                         const float* __restrict__ y, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int64_t M, int C, int relu,
-                                                        int rows_per_wg, float* __restrict__ part) {
+                                                        int rows_per_wg, float* __restrict__ part, int acc_rows) {
+    // acc_rows == 0: workgroup w stores partial row w (bn_finalize_kernel folds them in a fixed order: deterministic).
+    // acc_rows  > 0: the workgroup ADDS its partial row into row (w mod acc_rows) of a zeroed [acc_rows][2][C] block with
+    //                float atomics (8 adders per address at 256 workgroups); the apply kernels fold those few rows in their
+    //                own prologue, so that no finalise launch sits between the passes.
     // relu: 0 none, 1 mask from the saved output y (y > 0), 2 mask recomputed from x with the forward's own expression
     // (x - mean) * (invstd * gamma) + beta > 0 -- bit-identical to the forward, and y is not read (nor kept) at all
     __shared__ float s_part[2][256 * 4];
@@ -99,13 +103,13 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
     for (int k = 0; k < 4; ++k) { s_part[0][t * 4 + k] = a0[k]; s_part[1][t * 4 + k] = a1[k]; }
     __syncthreads();
     const int nv = 2 * C;
-    float* out = part + (int64_t)blockIdx.x * nv + blockIdx.y * c4b * 4;
+    float* out = part + (int64_t)(acc_rows ? (int)(blockIdx.x % acc_rows) : (int)blockIdx.x) * nv + blockIdx.y * c4b * 4;
     for (int ch = t; ch < c4b * 4; ch += 256) {
         const int cc = ch >> 2, kk = ch & 3;
         float d0 = 0.f, d1 = 0.f;
         for (int q = 0; q < rlanes; ++q) { d0 += s_part[0][(q * c4b + cc) * 4 + kk]; d1 += s_part[1][(q * c4b + cc) * 4 + kk]; }
-        out[ch] = d0;
-        out[C + ch] = d1;
+        if (acc_rows) { atomicAdd(out + ch, d0); atomicAdd(out + C + ch, d1); }
+        else { out[ch] = d0; out[C + ch] = d1; }
     }
 }
 
@@ -155,22 +159,72 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     }
 }
 
+// Sums of the `rows` accumulation rows [row][2][C] for channels c .. c + 3, in double, ascending row order (the order of the
+// rows is fixed; what is NOT is the order in which the float atomics built each row).  8 float4 loads in flight.
+__device__ __forceinline__ void bn_fold_rows(const float* __restrict__ rows, int n_rows, int C, int c, double (&s0)[4], double (&s1)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s0[k] = 0.0; s1[k] = 0.0; }
+    for (int r = 0; r < n_rows; r += 4) {
+        float4 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool ok = r + u < n_rows;
+            a[u] = ok ? *reinterpret_cast<const float4*>(rows + (int64_t)(r + u) * 2 * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            b[u] = ok ? *reinterpret_cast<const float4*>(rows + (int64_t)(r + u) * 2 * C + C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            s0[0] += (double)a[u].x; s0[1] += (double)a[u].y; s0[2] += (double)a[u].z; s0[3] += (double)a[u].w;
+            s1[0] += (double)b[u].x; s1[1] += (double)b[u].y; s1[2] += (double)b[u].z; s1[3] += (double)b[u].w;
+        }
+    }
+}
+
 // ---- pass 2 forward: y = (x - mean) * invstd * gamma + beta (+ residual) (relu) ---------------------
 // The grid stride is a multiple of the float4 column count, so a thread's channel quad is loop-invariant.
+// FOLD: mean / invstd are not read but COMPUTED in the prologue from the accumulation rows (every thread folds the rows of
+// its own four channels: <= 32 rows x 2 float4, L2-resident), with bn_finalize_kernel<0>'s arithmetic; the threads that hold
+// each channel quad first (i0 < C / 4) also store mean / invstd for the backward pass and update the running statistics.
+template <bool FOLD>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       int64_t n4, int C, int relu, float* __restrict__ y) {
+                                                       int64_t n4, int C, int relu, float* __restrict__ y,
+                                                       const float* __restrict__ rows, int n_rows, int64_t M, BnFinal fin) {
     const int c4n = C >> 2;
     const int64_t i0 = blockIdx.x * (int64_t)256 + threadIdx.x;
     const int c = (int)(i0 % c4n) * 4;
-    float sc[4], sh[4];
+    float sc[4], sh[4], mu[4];
+    if (FOLD) {
+        double s0[4], s1[4];
+        bn_fold_rows(rows, n_rows, C, c, s0, s1);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        sc[k] = invstd[c + k] * (gamma ? gamma[c + k] : 1.f);
-        sh[k] = beta ? beta[c + k] : 0.f;
+        for (int k = 0; k < 4; ++k) {
+            const double m = s0[k] / (double)M;
+            double var = s1[k] / (double)M - m * m;
+            if (var < 0.0) var = 0.0;
+            const float is = (float)(1.0 / sqrt(var + (double)fin.eps));
+            mu[k] = (float)m;
+            sc[k] = is * (gamma ? gamma[c + k] : 1.f);
+            sh[k] = beta ? beta[c + k] : 0.f;
+            if (i0 < c4n) {
+                fin.mean[c + k] = (float)m;
+                fin.invstd[c + k] = is;
+                if (fin.running_mean) {
+                    const double unbiased = (M > 1) ? var * (double)M / (double)(M - 1) : var;
+                    fin.running_mean[c + k] = (1.f - fin.momentum) * fin.running_mean[c + k] + fin.momentum * (float)m;
+                    fin.running_var[c + k] = (1.f - fin.momentum) * fin.running_var[c + k] + fin.momentum * (float)unbiased;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            sc[k] = invstd[c + k] * (gamma ? gamma[c + k] : 1.f);
+            sh[k] = beta ? beta[c + k] : 0.f;
+            mu[k] = mean[c + k];
+        }
     }
-    const float mu[4] = {mean[c], mean[c + 1], mean[c + 2], mean[c + 3]};
     for (int64_t i = i0; i < n4; i += (int64_t)gridDim.x * 256) {
         const float4 xv = reinterpret_cast<const float4*>(x)[i];
         const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
@@ -190,21 +244,36 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 }
 
 // ---- pass 2 backward: dx = gamma*invstd*(g - sum_g/M - xhat*sum_gx/M); dres = g -----------------------
+// FOLD: the two channel sums come from the accumulation rows (folded in the prologue, as in bn_apply_kernel<true>) instead of
+// the finalise launch's doubles; the threads that hold each channel quad first also store dgamma / dbeta.
+template <bool FOLD>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                            const float* __restrict__ y, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const double* __restrict__ acc,
                                                            int64_t M, int64_t n4, int C, int relu, float* __restrict__ dx,
-                                                           float* __restrict__ dres) {
+                                                           float* __restrict__ dres, const float* __restrict__ rows, int n_rows,
+                                                           BnFinal fin) {
     const int c4n = C >> 2;
     const float invM = 1.0f / (float)M;
     const int64_t i0 = blockIdx.x * (int64_t)256 + threadIdx.x;
     const int c = (int)(i0 % c4n) * 4;
     float mu[4], is[4], sg[4], sgx[4], gi[4], sc[4], sh[4];
+    double f0[4] = {0.0, 0.0, 0.0, 0.0}, f1[4] = {0.0, 0.0, 0.0, 0.0};
+    if (FOLD) {
+        bn_fold_rows(rows, n_rows, C, c, f0, f1);
+        if (i0 < c4n) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (fin.dbeta) fin.dbeta[c + k] = (float)f0[k];
+                if (fin.dgamma) fin.dgamma[c + k] = (float)f1[k];
+            }
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         mu[k] = mean[c + k]; is[k] = invstd[c + k];
-        sg[k] = (float)acc[c + k] * invM; sgx[k] = (float)acc[C + c + k] * invM;
+        sg[k] = (float)(FOLD ? f0[k] : acc[c + k]) * invM; sgx[k] = (float)(FOLD ? f1[k] : acc[C + c + k]) * invM;
         gi[k] = (gamma ? gamma[c + k] : 1.f) * is[k];
         sc[k] = is[k] * (gamma ? gamma[c + k] : 1.f);
         sh[k] = beta ? beta[c + k] : 0.f;
@@ -362,11 +431,11 @@ extern "C" int dsf_bn_forward(const float* x, const float* residual, const float
     const int wgs = (int)((M + rows - 1) / rows);
     BnFinal fin = {eps, momentum, save_mean, save_invstd, running_mean, running_var, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(wgs, bn_col_blocks(C)), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                       M, C, 0, rows, bn_ws_part(workspace, C));
+                       M, C, 0, rows, bn_ws_part(workspace, C), 0);
     hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3((C + 15) / 16), dim3(256), 0, st, bn_ws_part(workspace, C), wgs, M, C, fin);
     const int64_t n4 = M * (C >> 2);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_apply_grid(n4, C)), dim3(256), 0, st, x, residual, save_mean, save_invstd, gamma,
-                       beta, n4, C, relu, y);
+    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(bn_apply_grid(n4, C)), dim3(256), 0, st, x, residual, save_mean, save_invstd, gamma,
+                       beta, n4, C, relu, y, nullptr, 0, M, fin);
     return dsf_launch_status();
 }
 
@@ -382,8 +451,8 @@ extern "C" int dsf_bn_forward_from_stats(const float* x, const float* residual, 
     BnFinal fin = {eps, momentum, save_mean, save_invstd, running_mean, running_var, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3((C + 15) / 16), dim3(256), 0, st, part, rows, M, C, fin);
     const int64_t n4 = M * (C >> 2);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_apply_grid(n4, C)), dim3(256), 0, st, x, residual, save_mean, save_invstd, gamma,
-                       beta, n4, C, relu, y);
+    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(bn_apply_grid(n4, C)), dim3(256), 0, st, x, residual, save_mean, save_invstd, gamma,
+                       beta, n4, C, relu, y, nullptr, 0, M, fin);
     return dsf_launch_status();
 }
 
@@ -394,8 +463,9 @@ extern "C" int dsf_bn_apply(const float* x, const float* residual, const float* 
     DSF_CHECK_ARG(x && y && mean && invstd && M > 0);
     if (!bn_shape_ok(C)) return DSF_ERR_UNSUPPORTED;
     const int64_t n4 = M * (C >> 2);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_apply_grid(n4, C)), dim3(256), 0, (hipStream_t)stream, x, residual, mean, invstd,
-                       gamma, beta, n4, C, relu, y);
+    BnFinal fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(bn_apply_grid(n4, C)), dim3(256), 0, (hipStream_t)stream, x, residual, mean, invstd,
+                       gamma, beta, n4, C, relu, y, nullptr, 0, M, fin);
     return dsf_launch_status();
 }
 
@@ -411,11 +481,57 @@ extern "C" int dsf_bn_backward(const float* x, const float* grad_y, const float*
     const int wgs = (int)((M + rows - 1) / rows);
     BnFinal fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, workspace, grad_gamma, grad_beta};
     hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(wgs, bn_col_blocks(C)), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd, gamma, beta, M, C,
-                       relu, rows, bn_ws_part(workspace, C));
+                       relu, rows, bn_ws_part(workspace, C), 0);
     hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(256), 0, st, bn_ws_part(workspace, C), wgs, M, C, fin);
     const int64_t n4 = M * (C >> 2);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_apply_grid(n4, C)), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd,
-                       gamma, beta, workspace, M, n4, C, relu, grad_x, grad_residual);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(bn_apply_grid(n4, C)), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd,
+                       gamma, beta, workspace, M, n4, C, relu, grad_x, grad_residual, nullptr, 0, fin);
+    return dsf_launch_status();
+}
+
+// ---- the same passes WITHOUT the finalise launches (default, float-atomic mode) --------------------------------------
+// `acc` is a caller-zeroed block of dsf_bn_acc_rows() rows [row][2][C]: the statistics pass (here, or the producing
+// convolution's epilogue: dsf_conv_x6_forward_bn_acc) adds its per-workgroup sums into row (workgroup mod rows) with float
+// atomics, and the apply kernel folds the rows in its own prologue (in double, ascending) -- forward = 1 launch after a
+// convolution that filled the rows (2 otherwise), backward = 2, where the ordered-partials path above needs 2-3 and 3.
+// Results differ from that path by the float atomics' summation order only (~1e-7 relative on the statistics); in
+// deterministic mode these entry points return DSF_ERR_UNSUPPORTED and the caller uses the ordered path.
+constexpr int BN_ACC_ROWS = 32;
+extern "C" int dsf_bn_acc_rows(void) { return BN_ACC_ROWS; }
+
+extern "C" int dsf_bn_forward_acc(const float* x, const float* residual, const float* gamma, const float* beta, int64_t M, int C,
+                                  float eps, float momentum, int relu, float* running_mean, float* running_var, float* y,
+                                  float* save_mean, float* save_invstd, float* acc, int acc_filled, dsf_stream_t stream) {
+    DSF_CHECK_ARG(x && y && save_mean && save_invstd && acc && M > 0);
+    if (!bn_shape_ok(C) || dsf_deterministic()) return DSF_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    BnFinal fin = {eps, momentum, save_mean, save_invstd, running_mean, running_var, nullptr, nullptr, nullptr};
+    if (!acc_filled) {
+        const int rows = bn_rows_per_wg(M, C);
+        const int wgs = (int)((M + rows - 1) / rows);
+        hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(wgs, bn_col_blocks(C)), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr,
+                           nullptr, M, C, 0, rows, acc, BN_ACC_ROWS);
+    }
+    const int64_t n4 = M * (C >> 2);
+    hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(bn_apply_grid(n4, C)), dim3(256), 0, st, x, residual, nullptr, nullptr, gamma, beta,
+                       n4, C, relu, y, acc, BN_ACC_ROWS, M, fin);
+    return dsf_launch_status();
+}
+
+extern "C" int dsf_bn_backward_acc(const float* x, const float* grad_y, const float* y, const float* gamma, const float* beta,
+                                   const float* save_mean, const float* save_invstd, int64_t M, int C, int relu, float* grad_x,
+                                   float* grad_residual, float* grad_gamma, float* grad_beta, float* acc, dsf_stream_t stream) {
+    DSF_CHECK_ARG(x && grad_y && save_mean && save_invstd && grad_x && acc && M > 0 && relu >= 0 && relu <= 2 && (relu != 1 || y));
+    if (!bn_shape_ok(C) || dsf_deterministic()) return DSF_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int rows = bn_rows_per_wg(M, C);
+    const int wgs = (int)((M + rows - 1) / rows);
+    BnFinal fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, grad_gamma, grad_beta};
+    hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(wgs, bn_col_blocks(C)), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd, gamma, beta,
+                       M, C, relu, rows, acc, BN_ACC_ROWS);
+    const int64_t n4 = M * (C >> 2);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(bn_apply_grid(n4, C)), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd,
+                       gamma, beta, nullptr, M, n4, C, relu, grad_x, grad_residual, acc, BN_ACC_ROWS, fin);
     return dsf_launch_status();
 }
 

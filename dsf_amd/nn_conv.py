@@ -133,6 +133,7 @@ class StatsRequest:
     request, a bias-free conv_x6 forward also writes the per-tile partial rows of the BatchNorm batch statistics
     (dsf_conv_x6_forward_bn) and leaves them here; ``rows`` stays 0 when the launch it chose cannot (split K, ...)."""
     part, rows = None, 0
+    acc, filled = None, 0      # acc: a zeroed block of accumulation rows (nn_norm.stat_pool) -> the epilogue ADDS its tile sums there
 
 
 class AffineRequest:
@@ -165,7 +166,16 @@ def _fwd_x6(x, image, bias, out_hw, Co, KH, KW, stride, pad, dil=1):
                                                  ctypes.byref(done), stream_ptr()), "dsf_conv_x6_forward_affine")
         req.applied = bool(done.value)
         return y
-    if isinstance(req, StatsRequest) and bias is None and B > 0:
+    if isinstance(req, StatsRequest) and req.acc is not None and bias is None and B > 0:
+        import ctypes
+        filled = ctypes.c_int(0)
+        check(L.lib().dsf_conv_x6_forward_bn_acc(ptr_nhwc(x), ptr(image), ptr_nhwc(y), I(B), I(Hi), I(Wi), I(Ci), I(Ho), I(Wo), I(Co),
+                                                 I(KH), I(KW), I(stride), I(dil), I(pad[0]), I(pad[1]), ptr(req.acc),
+                                                 I(int(L.lib().dsf_bn_acc_rows())), ctypes.byref(filled), stream_ptr()),
+              "dsf_conv_x6_forward_bn_acc")
+        req.filled = filled.value
+        return y
+    if isinstance(req, StatsRequest) and req.acc is None and bias is None and B > 0:
         import ctypes
         rows_max = int(L.lib().dsf_conv_x6_bn_stats_rows(I(B), I(Ho), I(Wo)))
         part = torch.empty(rows_max * 2 * Co, device=x.device, dtype=torch.float32)
@@ -217,6 +227,9 @@ def _wrw_c1(x, gy, K, stride, pad):
     return dw
 
 
+WRW_DIRECT = [os.environ.get("DSF_X6_WRW_DIRECT", "1") == "1"]       # dY pre-split image + igemm_wrw_x6b_kernel (conv_x6.hip)
+
+
 def _wrw(x, gy, KH, KW, stride, pad, out=None):
     """-> dW [KH][KW][Ci][Co] for x (B,Ci,Hi,Wi), gy (B,Co,Ho,Wo), both channels_last; ``out``: add into this dW instead."""
     B, Ci, Hi, Wi = x.shape
@@ -230,6 +243,14 @@ def _wrw(x, gy, KH, KW, stride, pad, out=None):
     if _wrw_x6_ok(Ci, Co, x.numel(), gy.numel()):
         nws = int(L.lib().dsf_conv_x6_wrw_workspace_bytes(I(B), I(Ho), I(Wo), I(Ci), I(Co), I(KH), I(KW)))    # > 0: deterministic mode
         ws = torch.empty(nws // 4, device=x.device, dtype=torch.float32) if nws else None
+        nimg = int(L.lib().dsf_conv_x6_wrw_image_bytes(I(B), I(Ho), I(Wo), I(Co))) if WRW_DIRECT[0] else 0
+        if nimg:
+            # dY split once into an MFMA-fragment image (scratch of this call; stream-ordered reuse by the caching allocator)
+            img = torch.empty(nimg, device=x.device, dtype=torch.uint8)
+            check(L.lib().dsf_conv_x6_wrw_direct(ptr_nhwc(x), ptr_nhwc(gy), ptr(dw), I(B), I(Hi), I(Wi), I(Ci), I(Ho), I(Wo), I(Co),
+                                                 I(KH), I(KW), I(stride), I(pad[0]), I(pad[1]), I(1 if pooled else 0), ptr(ws),
+                                                 ptr(img), stream_ptr()), "dsf_conv_x6_wrw_direct")
+            return dw
         check(L.lib().dsf_conv_x6_wrw_ws(ptr_nhwc(x), ptr_nhwc(gy), ptr(dw), I(B), I(Hi), I(Wi), I(Ci), I(Ho), I(Wo), I(Co), I(KH),
                                          I(KW), I(stride), I(pad[0]), I(pad[1]), I(1 if pooled else 0), ptr(ws), stream_ptr()),
               "dsf_conv_x6_wrw_ws")
@@ -754,7 +775,8 @@ def kernel_name(rec):
             return "igemm_fwd_dil2_kernel<%d, %d, %s>" % (bn, 16 if (tiles >= 1024 and bn == 128) else 32, wt)
         return "igemm_fwd_kernel<%d, %s>" % (bn, "true" if (Ci < 32 and dil == 1) else "false")
     if _wrw_x6_ok(Ci, Co, B * Hi * Wi * Ci, M * Co):
-        return "igemm_wrw_x6_kernel<%d>" % (128 if Co > 64 else 64)
+        direct = WRW_DIRECT[0] and M >= 64 and ((M + 15) // 16) * ((Co + bn - 1) // bn) * 6 * bn * 16 < 0xFFFFFFF0
+        return "igemm_wrw_x6%s_kernel<%d>" % ("b" if direct else "", 128 if Co > 64 else 64)
     if vec:
         return "igemm_wrw_fast_kernel<%d, %d>" % (bn, 16 if M >= 32768 else 32)
     return "igemm_wrw_kernel<%d>" % bn

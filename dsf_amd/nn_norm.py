@@ -43,9 +43,59 @@ def _workspace(device, C):
     return ws
 
 
+# ---- accumulation rows of the finalise-free BatchNorm passes (dsf_bn_forward_acc / dsf_bn_backward_acc) ----------------
+# Each pass needs a ZEROED block of dsf_bn_acc_rows() x 2C floats.  ``with stat_pool(n_floats, device):`` around one forward +
+# backward of a step provides them from ONE zero fill (as nn_conv.grad_pool does for the weight gradients); without an open
+# pool, when it runs out, or in deterministic mode (float atomics build the rows) the layers take the ordered-partials path
+# with its finalise launches.  DSF_BN_ACC=0 switches the pool off.
+ACC = [os.environ.get("DSF_BN_ACC", "1") == "1"]
+_ACC_POOL = None         # [flat zeroed tensor, next offset]
+_ACC_ROWS = [0]
+
+
+class stat_pool:
+    def __init__(self, n_floats, device):
+        self.n, self.device = int(n_floats), device
+
+    def __enter__(self):
+        global _ACC_POOL
+        self.saved = _ACC_POOL
+        if _ACC_POOL is None and self.n > 0 and ACC[0] and torch.device(self.device).type == "cuda" and not L.deterministic():
+            _ACC_POOL = [torch.zeros(self.n, device=self.device, dtype=torch.float32), 0]
+        return self
+
+    def __exit__(self, *a):
+        global _ACC_POOL
+        _ACC_POOL = self.saved
+
+
+def acc_rows():
+    if not _ACC_ROWS[0]:
+        _ACC_ROWS[0] = int(L.lib().dsf_bn_acc_rows())
+    return _ACC_ROWS[0]
+
+
+def _acc_take(C, device):
+    """a zeroed [rows][2][C] block of the open pool, or None (no pool / exhausted / deterministic mode / unsupported C)"""
+    if _ACC_POOL is None or _ACC_POOL[0].device != device or not supported(C) or L.deterministic():
+        return None
+    n = acc_rows() * 2 * C
+    off = _ACC_POOL[1]
+    if off + n > _ACC_POOL[0].numel():
+        return None
+    _ACC_POOL[1] = off + n
+    return _ACC_POOL[0][off:off + n]
+
+
+def stat_floats(module, applications=1):
+    """pool size for ``applications`` forward + backward passes over ``module``: two blocks per fused BatchNorm and pass"""
+    return applications * sum(2 * acc_rows() * 2 * m.num_features for m in module.modules()
+                              if isinstance(m, FusedBatchNorm2d) and supported(m.num_features))
+
+
 class _BNFunction(Function):
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, eps, momentum, relu, part=None, rows=0):
+    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, eps, momentum, relu, part=None, rows=0, acc=None, acc_filled=0):
         x = x.contiguous(memory_format=CL)
         if residual is not None:
             residual = residual.contiguous(memory_format=CL)
@@ -54,7 +104,13 @@ class _BNFunction(Function):
         y = torch.empty_like(x, memory_format=CL)
         mean = torch.empty(C, device=x.device, dtype=torch.float32)
         invstd = torch.empty(C, device=x.device, dtype=torch.float32)
-        if part is not None and rows > 0:
+        if acc is not None:
+            # statistics rows accumulated by the producing convolution's epilogue (acc_filled) or by this call's own reduction;
+            # the apply kernel folds them in its prologue: no finalise launch
+            check(L.lib().dsf_bn_forward_acc(_p(x), _p(residual), _p(gamma), _p(beta), I64(M), I(C), CF(eps), CF(momentum),
+                                             I(int(relu)), _p(running_mean), _p(running_var), _p(y), _p(mean), _p(invstd), _p(acc),
+                                             I(int(acc_filled)), stream_ptr()), "dsf_bn_forward_acc")
+        elif part is not None and rows > 0:
             # the producing convolution's epilogue already reduced the tile sums (dsf_conv_x6_forward_bn): finalise + apply only
             check(L.lib().dsf_bn_forward_from_stats(_p(x), _p(residual), _p(gamma), _p(beta), I64(M), I(C), CF(eps), CF(momentum),
                                                     I(int(relu)), _p(running_mean), _p(running_var), _p(y), _p(mean), _p(invstd),
@@ -82,10 +138,15 @@ class _BNFunction(Function):
         gres = torch.empty_like(x, memory_format=CL) if has_res else None
         gg = torch.empty(C, device=x.device, dtype=torch.float32) if has_g else None
         gb = torch.empty(C, device=x.device, dtype=torch.float32) if has_b else None
-        ws = _workspace(x.device, C)
-        check(L.lib().dsf_bn_backward(_p(x), _p(gy), _p(y), _p(gamma), _p(beta), _p(mean), _p(invstd), I64(M), I(C), I(relu_mode), _p(gx),
-                                      _p(gres), _p(gg), _p(gb), _p(ws), stream_ptr()), "dsf_bn_backward")
-        return gx, gres, gg, gb, None, None, None, None, None, None, None
+        acc = _acc_take(C, x.device)
+        if acc is not None:
+            check(L.lib().dsf_bn_backward_acc(_p(x), _p(gy), _p(y), _p(gamma), _p(beta), _p(mean), _p(invstd), I64(M), I(C), I(relu_mode),
+                                              _p(gx), _p(gres), _p(gg), _p(gb), _p(acc), stream_ptr()), "dsf_bn_backward_acc")
+        else:
+            ws = _workspace(x.device, C)
+            check(L.lib().dsf_bn_backward(_p(x), _p(gy), _p(y), _p(gamma), _p(beta), _p(mean), _p(invstd), I64(M), I(C), I(relu_mode), _p(gx),
+                                          _p(gres), _p(gg), _p(gb), _p(ws), stream_ptr()), "dsf_bn_backward")
+        return gx, gres, gg, gb, None, None, None, None, None, None, None, None, None
 
 
 class FusedBatchNorm2d(nn.BatchNorm2d):
@@ -158,7 +219,13 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
                 mom = self.momentum
                 rm = self.running_mean if (self.training and self.track_running_stats) else None
                 rv = self.running_var if (self.training and self.track_running_stats) else None
+                if stats is not None and stats[0] == "acc":
+                    return _BNFunction.apply(x, residual, self.weight, self.bias, rm, rv, self.eps, mom, relu, None, 0, stats[1], stats[2])
                 part, rows = stats if stats is not None else (None, 0)
+                if part is None:
+                    acc = _acc_take(C, x.device)
+                    if acc is not None:
+                        return _BNFunction.apply(x, residual, self.weight, self.bias, rm, rv, self.eps, mom, relu, None, 0, acc, 0)
                 return _BNFunction.apply(x, residual, self.weight, self.bias, rm, rv, self.eps, mom, relu, part, rows)
             if torch.is_grad_enabled() and (x.requires_grad or (residual is not None and residual.requires_grad) or
                                             (self.weight is not None and self.weight.requires_grad) or
@@ -222,11 +289,14 @@ def conv_bn_act(conv, bn, x, residual=None, relu=None):
     if not fusable:
         return bn_act(bn, conv(x), residual, relu if relu is not None else getattr(bn, "fuse_relu", False))
     req = nn_conv.StatsRequest()
+    req.acc = _acc_take(bn.num_features, x.device)       # finalise-free path: the epilogue adds into these zeroed rows
     nn_conv.STATS = req
     try:
         y = conv(x)
     finally:
         nn_conv.STATS = None
+    if req.acc is not None:
+        return bn(y, residual, relu, stats=("acc", req.acc, req.filled))
     return bn(y, residual, relu, stats=(req.part, req.rows) if req.rows else None)
 
 

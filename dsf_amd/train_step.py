@@ -53,6 +53,17 @@ def synthetic_batch(B, device, seed=0, dtype=torch.float32):
     return p.to(device, dtype), center.to(device, dtype), cube.to(device, dtype)
 
 
+def _stat_pool(step, net, applications=1):
+    """The per-step pool of zeroed BatchNorm accumulation rows (nn_norm.stat_pool): one zero fill per step lets every fused
+    BatchNorm of ``net`` run without finalise launches; sized once per step object."""
+    from . import nn_norm
+    if not hasattr(step, "_stat_floats"):
+        dev = next(net.parameters()).device
+        step._stat_floats = nn_norm.stat_floats(net, applications) if dev.type == "cuda" else 0
+        step._stat_dev = dev
+    return nn_norm.stat_pool(step._stat_floats, step._stat_dev)
+
+
 def _default_adamw(params, lr, weight_decay):
     """AdamW as the reference builds it (train_render.py:131-139): the one-launch HIP version
     (dsf_amd.optim.FusedAdamW; DSF_FUSED_ADAMW=0 selects torch.optim.AdamW's multi-tensor kernels for A/B runs)."""
@@ -118,12 +129,13 @@ class RenderSupervisedStep:
         from . import nn_conv
         self.opt.zero_grad(set_to_none=True)
         self.render.mano_layer.clear_cache()                 # results of the previous step must not outlive its graph
-        loss, terms = self.loss(tgt)
         if not hasattr(self, "_pool_floats"):
             self._pool_floats = nn_conv.weight_grad_floats(self.net) + 64          # fused heads re-lay one merged weight
             self._pool_dev = next(self.net.parameters()).device
-        with nn_conv.grad_pool(self._pool_floats if self._pool_dev.type == "cuda" else 0, self._pool_dev):
-            loss.backward()
+        with _stat_pool(self, self.net):
+            loss, terms = self.loss(tgt)
+            with nn_conv.grad_pool(self._pool_floats if self._pool_dev.type == "cuda" else 0, self._pool_dev):
+                loss.backward()
         return loss.detach(), terms
 
     def __call__(self, tgt):
@@ -188,8 +200,9 @@ class MeshLossStep:
     def forward_backward(self, tgt):
         self.opt.zero_grad(set_to_none=True)
         self.render.mano_layer.clear_cache()                 # results of the previous step must not outlive its graph
-        loss, terms = self.loss(tgt)
-        loss.backward()
+        with _stat_pool(self, self.net):
+            loss, terms = self.loss(tgt)
+            loss.backward()
         return loss.detach(), terms
 
     def __call__(self, tgt):
@@ -500,8 +513,9 @@ class PretrainStep(_StepBase):
 
     def __call__(self, model_para, cube, draws=None):
         self._begin()
-        loss, terms = self.loss(model_para, cube, draws)
-        self._optimise(loss)
+        with _stat_pool(self, self.net):
+            loss, terms = self.loss(model_para, cube, draws)
+            self._optimise(loss)
         return loss.detach(), terms
 
 
@@ -551,8 +565,9 @@ class FinetuneStep(_StepBase):
 
     def __call__(self, model_para, cube, img_r, center_r, cube_r, M_r, draws=None):
         self._begin()
-        loss, terms = self.loss(model_para, cube, img_r, center_r, cube_r, M_r, draws)
-        self._optimise(loss)
+        with _stat_pool(self, self.net, applications=2):     # the network sees the synthetic and the real batch
+            loss, terms = self.loss(model_para, cube, img_r, center_r, cube_r, M_r, draws)
+            self._optimise(loss)
         return loss.detach(), terms
 
 
@@ -635,6 +650,7 @@ class FinetuneStageStep(_StepBase):
 
     def __call__(self, model_para, cube, img_r, center_r, cube_r, M_r, generator=None, draws=None):
         self._begin()
-        loss, terms = self.loss(model_para, cube, img_r, center_r, cube_r, M_r, generator, draws)
-        self._optimise(loss)
+        with _stat_pool(self, self.net, applications=2):     # the network sees the synthetic and the real batch
+            loss, terms = self.loss(model_para, cube, img_r, center_r, cube_r, M_r, generator, draws)
+            self._optimise(loss)
         return loss.detach(), terms

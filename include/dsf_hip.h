@@ -451,6 +451,28 @@ int dsf_bn_forward_from_stats(const float* x, const float* residual, const float
                               float* save_mean, float* save_invstd, const float* part, int rows, dsf_stream_t stream);
 
 /* ----------------------------------------------------------------------------------
+ * The same BatchNorm passes (reference model/resnet.py:18-98: conv -> BatchNorm2d (+ skip)(+ ReLU), training mode) WITHOUT the
+ * finalise launches -- the default, float-atomic mode.  `acc` is a caller-ZEROED block of dsf_bn_acc_rows() rows [row][2][C]
+ * floats: the statistics pass (dsf_bn_forward_acc's own reduction when acc_filled == 0, or the producing convolution's
+ * epilogue, dsf_conv_x6_forward_bn_acc, *filled = 1) adds per-workgroup sums into row (workgroup mod rows) with float
+ * atomics, and the apply kernel folds those rows in its own prologue (double, ascending), writes save_mean / save_invstd and
+ * updates the running statistics: forward = 1 launch after a convolution that filled the rows (else 2), backward = 2
+ * (dsf_bn_backward_acc: `acc` = a second zeroed block), against 2-3 and 3 on the ordered-partials path above.  The two paths
+ * differ by the atomics' summation order only.  All three return DSF_ERR_UNSUPPORTED in deterministic mode (callers then use
+ * dsf_bn_forward / dsf_bn_forward_from_stats / dsf_bn_backward, which are bit-reproducible).
+ * ---------------------------------------------------------------------------------- */
+int dsf_bn_acc_rows(void);
+int dsf_conv_x6_forward_bn_acc(const float* X, const void* image, float* Y, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
+                               int KH, int KW, int stride, int dil, int pad_h, int pad_w, float* acc, int acc_rows, int* filled,
+                               dsf_stream_t stream);
+int dsf_bn_forward_acc(const float* x, const float* residual, const float* gamma, const float* beta, int64_t M, int C, float eps,
+                       float momentum, int relu, float* running_mean, float* running_var, float* y, float* save_mean,
+                       float* save_invstd, float* acc, int acc_filled, dsf_stream_t stream);
+int dsf_bn_backward_acc(const float* x, const float* grad_y, const float* y, const float* gamma, const float* beta,
+                        const float* save_mean, const float* save_invstd, int64_t M, int C, int relu, float* grad_x,
+                        float* grad_residual, float* grad_gamma, float* grad_beta, float* acc, dsf_stream_t stream);
+
+/* ----------------------------------------------------------------------------------
  * Training-phase augmentation of cropped frames: `loader.augmentCrop`
  * (/root/reference/data/render_loader.py:653-695 = rotateHand :458-497 / moveCoM :427-456 / scaleHand :499-527 through
  * recropHand :403-424, then normalize_img :738-745) for a batch, replacing the cv2 / numpy DataLoader workers.
@@ -481,6 +503,15 @@ int dsf_get_deterministic(void);
 int64_t dsf_conv_x6_wrw_workspace_bytes(int B, int Ho, int Wo, int Ci, int Co, int KH, int KW);
 int dsf_conv_x6_wrw_ws(const float* X, const float* dY, float* dW, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
                        int KW, int stride, int pad_h, int pad_w, int accumulate, float* workspace, dsf_stream_t stream);
+/* Backward-weights with the dY operand pre-split ONCE into an image laid out as the MFMA fragment (round 3; replaces the
+ * weight-gradient GEMM cuDNN runs for every nn.Conv2d of the reference's backbones, model/resnet.py, model/backbone.py): two
+ * launches -- the image pass (4 bytes read, 6 written per dY element) and a kernel whose LDS carries the X tile only.
+ * dy_image: dsf_conv_x6_wrw_image_bytes(B, Ho, Wo, Co) bytes of scratch (0 = shape not served: use dsf_conv_x6_wrw_ws);
+ * workspace / accumulate / deterministic mode exactly as dsf_conv_x6_wrw_ws (same per-split sums, bitwise, in that mode). */
+int64_t dsf_conv_x6_wrw_image_bytes(int B, int Ho, int Wo, int Co);
+int dsf_conv_x6_wrw_direct(const float* X, const float* dY, float* dW, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
+                           int KW, int stride, int pad_h, int pad_w, int accumulate, float* workspace, void* dy_image,
+                           dsf_stream_t stream);
 
 /* ----------------------------------------------------------------------------------
  * NHWC max pooling (nn.MaxPool2d(kernel_size=3, stride=2, padding=1) of the backbone stem, reference

@@ -71,11 +71,27 @@ def test_conv_transpose2d_matches_torch_cpu(Ci, Co, K, s, p, op, H):
         assert _rel(a.cpu(), r) < 1e-4
 
 
+@pytest.mark.parametrize("acc", [False, True])
 @pytest.mark.parametrize("C,H,res,relu", [(64, 16, True, True), (256, 8, False, True), (512, 4, True, False), (8, 5, False, False),
                                           (1024, 3, True, True), (2048, 4, True, True), (2048, 3, False, False)])
-def test_fused_batchnorm_matches_torch_cpu(C, H, res, relu):
-    """bn(x) (+ residual) (relu) in training mode vs torch CPU: output, running stats, all gradients."""
+def test_fused_batchnorm_matches_torch_cpu(C, H, res, relu, acc):
+    """bn(x) (+ residual) (relu) in training mode vs torch CPU: output, running stats, all gradients -- on the ordered-partials
+    path (reduce, finalise, apply) and, ``acc``, on the finalise-free path (float-atomic accumulation rows from an open
+    ``stat_pool``, folded in the apply kernels' prologue: dsf_bn_forward_acc / dsf_bn_backward_acc)."""
+    from dsf_amd import nn_norm, _lib as L
     from dsf_amd.nn_norm import FusedBatchNorm2d
+    import contextlib
+    if acc and L.deterministic():
+        pytest.skip("deterministic mode keeps the ordered-partials path")
+    pool = nn_norm.stat_pool(2 * nn_norm.acc_rows() * 2 * C, "cuda") if acc else contextlib.nullcontext()
+    with pool:
+        _bn_case(C, H, res, relu, FusedBatchNorm2d)
+        if acc:
+            assert nn_norm._ACC_POOL is not None and nn_norm._ACC_POOL[1] == 2 * nn_norm.acc_rows() * 2 * C     # forward + backward blocks taken
+    assert nn_norm._ACC_POOL is None
+
+
+def _bn_case(C, H, res, relu, FusedBatchNorm2d):
     g = torch.Generator().manual_seed(C + H)
     B = 6
     x = (torch.randn(B, C, H, H, generator=g) * 2 + 0.5).requires_grad_(True)
@@ -261,7 +277,10 @@ def test_bn_statistics_from_the_conv_epilogue_equal_the_reduction_pass(kind, Ci,
             else nn_conv.ConvTranspose2d(Ci, Co, K, stride=s, padding=p, output_padding=0, bias=False)).cuda()
     nn_conv.weights_changed()
     outs = []
-    for fused in (True, False):
+    import contextlib
+    from dsf_amd import _lib as L_
+    variants = (True, False) if L_.deterministic() else (True, False, "acc")
+    for fused in variants:
         bn = nn_norm.FusedBatchNorm2d(Co, momentum=0.1).cuda()
         torch.manual_seed(7)
         with torch.no_grad():
@@ -273,9 +292,24 @@ def test_bn_statistics_from_the_conv_epilogue_equal_the_reduction_pass(kind, Ci,
             Ho = conv(x).shape[-1]
         r = torch.randn(B, Co, Ho, Ho, device="cuda").requires_grad_(True) if res else None
         conv.weight.grad = None
-        nn_norm.EPILOGUE_STATS[0] = fused
+        nn_norm.EPILOGUE_STATS[0] = bool(fused)
+        pool = nn_norm.stat_pool(2 * nn_norm.acc_rows() * 2 * Co, "cuda") if fused == "acc" else contextlib.nullcontext()
         try:
-            if fused:                                        # the request must be honoured, not silently dropped
+            if fused == "acc":                               # finalise-free path: the epilogue must fill the accumulation rows
+                with nn_norm.stat_pool(nn_norm.acc_rows() * 2 * Co, "cuda"):
+                    req = nn_conv.StatsRequest()
+                    req.acc = nn_norm._acc_take(Co, x.device)
+                    nn_conv.STATS = req
+                    try:
+                        with torch.no_grad():
+                            yc = conv(x)
+                    finally:
+                        nn_conv.STATS = None
+                    assert req.filled == 1 and req.acc is not None
+                    tot = req.acc.view(nn_norm.acc_rows(), 2, Co).double().sum(0)
+                    ref_s = torch.stack((yc.double().sum((0, 2, 3)), (yc.double() ** 2).sum((0, 2, 3))))
+                    assert ((tot - ref_s).abs() <= 1e-5 * ref_s.abs() + 1e-3).all()
+            elif fused:                                      # the request must be honoured, not silently dropped
                 req = nn_conv.StatsRequest()
                 nn_conv.STATS = req
                 try:
@@ -286,19 +320,24 @@ def test_bn_statistics_from_the_conv_epilogue_equal_the_reduction_pass(kind, Ci,
                 assert req.rows > 0 and req.part is not None
                 rows_max = nn_conv.L.lib().dsf_conv_x6_bn_stats_rows(B, Ho, Ho)
                 assert req.rows <= rows_max and req.part.numel() == rows_max * 2 * Co
-            y = nn_norm.conv_bn_act(conv, bn, x, residual=r, relu=True)
+            with pool:
+                y = nn_norm.conv_bn_act(conv, bn, x, residual=r, relu=True)
+                (y * torch.linspace(-1, 1, y.numel(), device="cuda").view_as(y)).sum().backward()
+                if fused == "acc":
+                    assert nn_norm._ACC_POOL[1] == 2 * nn_norm.acc_rows() * 2 * Co
         finally:
             nn_norm.EPILOGUE_STATS[0] = True
-        (y * torch.linspace(-1, 1, y.numel(), device="cuda").view_as(y)).sum().backward()
         outs.append((y.detach(), bn.running_mean.clone(), bn.running_var.clone(), x.grad.clone(), conv.weight.grad.clone(),
                      bn.weight.grad.clone(), bn.bias.grad.clone(), None if r is None else r.grad.clone(),
                      int(bn.num_batches_tracked)))
-    a, b = outs
+    a, b = outs[0], outs[1]
     assert a[8] == b[8] == 1
-    for i, (u, v) in enumerate(zip(a[:8], b[:8])):
-        if u is None:
-            continue
-        assert _rel(u, v) < 2e-5, (i, _rel(u, v))
+    for other in outs[1:]:
+        assert other[8] == 1
+        for i, (u, v) in enumerate(zip(a[:8], other[:8])):
+            if u is None:
+                continue
+            assert _rel(u, v) < 2e-5, (i, _rel(u, v))
     # and against float64 statistics of the convolution output itself
     with torch.no_grad():
         yc = conv(x).double()

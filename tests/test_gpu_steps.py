@@ -239,7 +239,7 @@ def _freeze_statistics(net_cpu, net_gpu, orender, p, cube, d, views, gen=None):
         pp, cc = (p.repeat_interleave(views, 0), cube.repeat_interleave(views, 0)) if views > 1 else (p, cube)
         s_c = step_ref.synth_pass(orender, gen, pp, cc, d, True)
         net_cpu.train()
-        net_cpu(s_c["img_t"], orender, s_c["center"], s_c["cube"])
+        step_ref.net_forward(net_cpu, s_c["img_t"], orender, s_c["center"], s_c["cube"])
     for m, mom in zip(bns, saved):
         m.momentum = mom
     net_gpu.load_state_dict(net_cpu.state_dict())

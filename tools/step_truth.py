@@ -15,6 +15,21 @@ from dsf_amd.render_model.mano_layer import Render
 from dsf_amd.train_step import PretrainStep, synthetic_batch, draws_to, Config
 backbone, views, B = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 frozen = len(sys.argv) > 4 and sys.argv[4] == "frozen"
+# TRUTH_DET=fwd|wrw: the deterministic (unsplit / ordered) form for the forward-type convolutions only, or for backward-weights only
+_det = os.environ.get("TRUTH_DET", "")
+if _det:
+    from dsf_amd import nn_conv, _lib as L
+    def _wrap(name):
+        inner = getattr(nn_conv, name)
+        def f(*a, **k):
+            old = L.set_deterministic(True)
+            try:
+                return inner(*a, **k)
+            finally:
+                L.set_deterministic(old)
+        setattr(nn_conv, name, f)
+    for nm in (("_fwd_x6", "_fwd", "_fwd_wt", "_bwd_data_s1") if _det == "fwd" else ("_wrw",)):
+        _wrap(nm)
 render = Render("synthetic", "nyu", T.CAM, (640, 480)).cuda()
 orender = step_ref.OracleRender(build_synthetic_mano(0))
 net_cpu, net_gpu = T._twin_pair(MANO_OCR_stage, backbone, 21, True, seed=5)
