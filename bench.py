@@ -64,23 +64,28 @@ def matrix_peak(kernel):
             "fp32-in/fp32-acc MFMA (v_mfma_f32_32x32x2_f32) dense peak 157.3 TFLOP/s; HBM traffic is not the bound")
 
 
+PMC_CONFIG = [2]          # which BASELINE config's committed PMC passes describe the running workload (set by main)
+
+
 def pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed PMC passes (profiles/r01_pmc_traffic.json, made by
+    """HBM-side bytes per launch of `kernel` from the committed PMC passes (profiles/rNN[_configK]_pmc_traffic.json, made by
     tools/pmc_summary.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this script;
     FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md).  A profiler cannot run inside the timed
     process, so the figure is read back from the profile of the same command; null when the file has no entry."""
     here = os.path.dirname(os.path.abspath(__file__))
-    for tag in ("r02", "r01"):                                   # the newest committed round that measured this kernel
+    mid = "" if PMC_CONFIG[0] == 2 else "_config%d" % PMC_CONFIG[0]
+    for tag in ("r03", "r02", "r01"):                            # the newest committed round that measured this kernel
+        name = "%s%s_pmc_traffic.json" % (tag, mid)
         try:
-            with open(os.path.join(here, "profiles", tag + "_pmc_traffic.json")) as f:
+            with open(os.path.join(here, "profiles", name)) as f:
                 e = json.load(f)["kernels"][kernel]
-            return {"traffic": e["hbm_bytes_per_launch"], "traffic_source": "profiles/%s_pmc_traffic.json (fetch x2 + write)" % tag}
+            return {"traffic": e["hbm_bytes_per_launch"], "traffic_source": "profiles/%s (fetch x2 + write)" % name}
         except (OSError, KeyError, ValueError):
             continue
     return {"traffic": None}
 
 
-def conv_kernel_roofline(step, tgt):
+def conv_kernel_roofline(step, run_once):
     """Roofline of the dominant kernel, igemm_fwd_kernel<128,false> (fp32 MFMA implicit-GEMM
     convolution: forward, backward-data and transposed-conv passes of every layer with Co > 64).
     One step is traced at the Python level, then every launch of that kernel is re-issued on the
@@ -90,7 +95,7 @@ def conv_kernel_roofline(step, tgt):
     nn_conv.RECORD = []
     if step.grad_sync is not None:
         step.grad_sync.enabled = False          # rank-0-only diagnostic step: no collectives
-    step(tgt)
+    run_once()
     if step.grad_sync is not None:
         step.grad_sync.enabled = True
     torch.cuda.synchronize()
@@ -280,17 +285,157 @@ def distributed_facts(world, dev, rccl_log):
     return facts
 
 
+def build_workload(args, dev, rank, world):
+    """The per-GPU share of a BASELINE config as: the step object, a zero-argument ``run`` (one optimizer step on
+    resident synthetic inputs), units per step and what a unit is, network FLOPs per unit, and the CPU-oracle leg."""
+    import numpy as np
+    from dsf_amd.parallel import GradAllReducer
+    from dsf_amd.render_model.mano_layer import Render
+    from dsf_amd.model.backbone import MANO_OCR_stage
+    from dsf_amd import ops
+    from dsf_amd.train_step import (RenderSupervisedStep, MeshLossStep, PretrainStep, FinetuneStageStep, synthetic_batch, Config)
+    cfg = args.config
+    B = args.batch or {2: 32, 3: 64, 4: 64, 5: 64}[cfg]
+    torch.manual_seed(0)                              # identical initial weights on every rank
+    render = Render("synthetic", "nyu", (588.03, 587.07, 320.0, 240.0), (640, 480)).to(dev)
+    p, c, cube = synthetic_batch(B, dev, seed=0 + rank)            # per-rank shard of the global batch
+    w = {"render": render, "units_per_step": B, "tgt": None}
+
+    def oracle_bits():
+        from dsf_amd.assets import build_synthetic_mano
+        from oracle import step_ref, nets                 # CPU oracle: the reported baseline leg only
+        return step_ref, nets, step_ref.OracleRender(build_synthetic_mano(0))
+
+    def timed_cpu(loss_fn, net_cpu, n_steps, units):
+        opt = torch.optim.AdamW(net_cpu.parameters(), lr=1e-3, weight_decay=0.01)
+        t0 = None
+        for it in range(1 + n_steps):
+            if it == 1:
+                t0 = time.perf_counter()
+            opt.zero_grad()
+            loss_fn().backward()
+            opt.step()
+        secs = time.perf_counter() - t0
+        return units * n_steps / secs, secs, units * n_steps
+
+    if cfg == 2:
+        backbone = args.backbone or "ResNet_stage_18"
+        net = MANO_OCR_stage(backbone, 21, True).to(dev)
+        sync = GradAllReducer(net.parameters()) if world > 1 else None
+        step = RenderSupervisedStep(net, render, Config, grad_sync=sync)
+        tgt = step.make_targets(p, c, cube, seed=1 + rank)
+        fl = 3 * 25.42e9 if backbone.endswith("18") else 3 * 37.84e9
+        w.update(step=step, tgt=tgt, run=lambda: step(tgt), run_diag=lambda: step(tgt), flops_per_unit=fl,
+                 flops_note="3 x %.2f GFLOP per image, fwd + bwd" % (fl / 3e9), unit_note="one image through one optimizer step",
+                 workload="BASELINE configs[1]: batch=%d/GPU %s 2-stage + MANO + depth rasteriser, single view" % (B, backbone))
+
+        def cpu(n_steps):
+            from dsf_amd.assets import build_synthetic_mano
+            from oracle import step_ref
+            n_steps = n_steps or 60
+            ips, secs, n = step_ref.timed_steps(build_synthetic_mano(0), B=2, steps=n_steps, warmup=1, backbone=backbone)
+            return ips, secs, n, "the same step (same net, losses, AdamW) at B=2 x %d steps" % n_steps
+        w["cpu"] = cpu
+    elif cfg == 3:
+        from dsf_amd.model.hourglass import PoseNetMANO
+        net = PoseNetMANO(2, 21).to(dev)
+        sync = GradAllReducer(net.parameters()) if world > 1 else None
+        step = MeshLossStep(net, render, Config, grad_sync=sync)
+        tgt = step.make_targets(p, c, cube, seed=1 + rank)
+        w.update(step=step, tgt=tgt, run=lambda: step(tgt), run_diag=lambda: step(tgt), flops_per_unit=3 * 4.58e9,
+                 flops_note="3 x 4.58 GFLOP per image, fwd + bwd (the geometry losses are not MFMA work)",
+                 unit_note="one image through one optimizer step",
+                 workload="BASELINE configs[2]: batch=%d/GPU hourglass-2-stack + MANO head, m2d + ICP + part ICP + sphere collision" % B)
+
+        def cpu(n_steps):
+            step_ref, nets, orender = oracle_bits()
+            n_steps = n_steps or 20
+            torch.manual_seed(0)
+            net_cpu = nets.build(PoseNetMANO, 2, 21)
+            pc, cc, cubec = synthetic_batch(2, "cpu", seed=0)
+            g = torch.Generator().manual_seed(1)
+            keys = [torch.randint(0, 2 ** 31 - 1, (2, 128 * 128), dtype=torch.int32, generator=g) for _ in range(2)]
+            tc = step_ref.mesh_targets(orender, pc, cc, cubec, keys[0], keys[1])
+            ips, secs, n = timed_cpu(lambda: step_ref.mesh_step_loss(net_cpu, orender, tc, Config)[0], net_cpu, n_steps, 2)
+            return ips, secs, n, "the same step (hourglass-2 + mesh losses, AdamW) at B=2 x %d steps" % n_steps
+        w["cpu"] = cpu
+    elif cfg == 4:
+        net = MANO_OCR_stage("ResNet_stage_50", 21, True).to(dev)
+        sync = GradAllReducer(net.parameters()) if world > 1 else None
+        step = PretrainStep(net, render, None, Config, grad_sync=sync, views=3)
+        d = step.draw(B, dev, torch.Generator(device=dev).manual_seed(4 + rank), np.random.default_rng(4 + rank))
+        w.update(step=step, run=lambda: step(p, cube, d), run_diag=lambda: step(p, cube, d), flops_per_unit=3 * 3 * 37.84e9,
+                 flops_note="3 views x 3 x 37.84 GFLOP per sample, fwd + bwd",
+                 unit_note="one SAMPLE (rendered from 3 augmentView rotations = 3 images through the network) through one optimizer step",
+                 workload="BASELINE configs[3], per-GPU share: %d samples x 3 synthetic camera views per GPU, ResNet-50 2-stage, "
+                          "Trainer.Pretrain step (Render.forward with view / shape / centre / size augmentation + occluders)" % B)
+
+        def cpu(n_steps):
+            step_ref, nets, orender = oracle_bits()
+            n_steps = n_steps or 4
+            torch.manual_seed(0)
+            net_cpu = nets.build(MANO_OCR_stage, "ResNet_stage_50", 21, True)
+            pc, _, cubec = synthetic_batch(2, "cpu", seed=0)
+            dc = step.draw(2, "cpu", torch.Generator().manual_seed(4), np.random.default_rng(4))
+            ips, secs, n = timed_cpu(lambda: step_ref.pretrain_loss(net_cpu, orender, None, pc, cubec, dc, Config, views=3), net_cpu, n_steps, 2)
+            return ips, secs, n, "the same step (ResNet-50 2-stage, 3 views per sample, AdamW) at 2 samples x %d steps" % n_steps
+        w["cpu"] = cpu
+    else:
+        from dsf_amd.render_model.transfer import define_G
+        net = MANO_OCR_stage("ResNet_stage_18", 21, True).to(dev)
+        with torch.no_grad():
+            for head in (net.mano_regress[2], net.mano_regress_s2[2]):
+                head.bias[58] = 1.0                    # unit global scale: non-degenerate hands from random-init heads
+        gen = define_G(1, 1, 64, 'resnet_9blocks', 'instance', False, 'xavier').to(dev)
+        sync = GradAllReducer(net.parameters()) if world > 1 else None
+        step = FinetuneStageStep(net, render, gen, Config, grad_sync=sync)
+        pr, cr, cube_r = synthetic_batch(B, dev, seed=100 + rank)
+        with torch.no_grad():
+            img_r = render.render(pr, cr, cube_r)[0]
+            _, M_r, _, _ = ops.crop_setup(cr, cube_r, render.cam, 128)
+        d = step.draw(B, dev, torch.Generator(device=dev).manual_seed(5 + rank), np.random.default_rng(5 + rank))
+        run = lambda: step(p, cube, img_r, cr, cube_r, M_r, draws=d)
+        w.update(step=step, run=run, run_diag=run, flops_per_unit=2 * 3 * 25.42e9 + 24.36e9,
+                 flops_note="2 images (synthetic + real) x 3 x 25.42 GFLOP + 24.36 GFLOP of the frozen transfer generator per pair",
+                 unit_note="one PAIR (synthetic + real image, the real batch counts: main_loader = trainLoader) through one optimizer step",
+                 workload="BASELINE configs[4], per-GPU share: %d synthetic + %d real images per GPU, full dual-branch self-boosting "
+                          "Trainer.FinetuneStage step with the frozen Consis-CycleGAN generator, ResNet-18 2-stage" % (B, B))
+
+        def cpu(n_steps):
+            step_ref, nets, orender = oracle_bits()
+            n_steps = n_steps or 8
+            torch.manual_seed(0)
+            net_cpu = nets.build(MANO_OCR_stage, "ResNet_stage_18", 21, True)
+            with torch.no_grad():
+                for head in (net_cpu.mano_regress[2], net_cpu.mano_regress_s2[2]):
+                    head.bias[58] = 1.0
+            gen_cpu = nets.build(define_G, 1, 1, 64, 'resnet_9blocks', 'instance', False, 'xavier').eval()
+            pc, _, cubec = synthetic_batch(2, "cpu", seed=0)
+            prc, crc, cube_rc = synthetic_batch(2, "cpu", seed=100)
+            with torch.no_grad():
+                img_rc = orender.render(prc, crc, cube_rc)[0]
+            dc = step.draw(2, "cpu", torch.Generator().manual_seed(5), np.random.default_rng(5))
+            fn = lambda: step_ref.finetune_stage_loss(net_cpu, orender, gen_cpu, pc, cubec, img_rc, crc, cube_rc, dc, Config)[0]
+            ips, secs, n = timed_cpu(fn, net_cpu, n_steps, 2)
+            return ips, secs, n, "the same step (FinetuneStage incl. the transfer generator, AdamW) at 2 pairs x %d steps" % n_steps
+        w["cpu"] = cpu
+    return w
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
-    ap.add_argument("--backbone", default="ResNet_stage_18")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5),
+                    help="BASELINE.json configs[n-1]: 2 (default, the headline) ResNet-18 two-stage + MANO + rasteriser, B=32; 3 hourglass-2 "
+                         "+ mesh losses, B=64; 4 ResNet-50 two-stage x 3 views, 64 samples per GPU; 5 FinetuneStage + transfer net, 64 pairs per GPU")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (weak scaling); 0 = the config's own (32 / 64 / 64 / 64)")
+    ap.add_argument("--backbone", default="", help="config 2 only: ResNet_stage_18 (default) / ResNet_stage_50")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay forward+backward from a HIP graph (train_step.GraphedStep; "
                     "single GPU): same kernels, no host issue -- pays below batch 16, where the step is host-bound")
-    ap.add_argument("--cpu-steps", type=int, default=60)
+    ap.add_argument("--cpu-steps", type=int, default=0, help="steps of the CPU baseline leg (0: sized per config to ~10-30 s)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -314,32 +459,23 @@ def main():
     # DSF_FUSED_BN=0 runs
     torch.backends.cudnn.benchmark = os.environ.get("DSF_MIOPEN_FIND", "0") == "1"   # reference :87 uses find mode; gfx950 ships no MIOpen find-db, find mode JIT-compiles every solver (hours)
 
-    from dsf_amd.render_model.mano_layer import Render
-    from dsf_amd.model.backbone import MANO_OCR_stage
-    from dsf_amd.train_step import RenderSupervisedStep, synthetic_batch, Config
-
-    torch.manual_seed(0)                              # identical initial weights on every rank
-    net = MANO_OCR_stage(args.backbone, 21, True).to(dev)
-    render = Render("synthetic", "nyu", (588.03, 587.07, 320.0, 240.0), (640, 480)).to(dev)
-    sync = GradAllReducer(net.parameters()) if world > 1 else None
-    step = RenderSupervisedStep(net, render, Config, grad_sync=sync)
-    p, c, cube = synthetic_batch(args.batch, dev, seed=0 + rank)           # per-rank shard of the global batch
-    tgt = step.make_targets(p, c, cube, seed=1 + rank)
-
-    run = step
+    PMC_CONFIG[0] = args.config
+    w = build_workload(args, dev, rank, world)
+    step, run = w["step"], w["run"]
     if args.graph:
-        if world > 1:
-            raise SystemExit("--graph is single-GPU (the bucketed all-reduce overlaps the eager backward)")
+        if world > 1 or args.config not in (2, 3):
+            raise SystemExit("--graph: single GPU, configs 2 and 3 (steps without a host decision)")
         from dsf_amd.train_step import GraphedStep
-        run = GraphedStep(step, tgt)
+        g = GraphedStep(step, w["tgt"])
+        run = lambda: g(w["tgt"])
     for _ in range(args.warmup):
-        run(tgt)
+        run()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, _ = run(tgt)
+        loss, _ = run()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -352,7 +488,8 @@ def main():
     facts = distributed_facts(world, dev, rccl_log)
 
     if rank == 0:
-        images = args.batch * world * args.steps
+        B = w["units_per_step"]
+        images = B * world * args.steps
         out = {
             "metric": "images/sec (fwd+bwd, 128x128 depth, MANO+render loss)",
             "value": round(images / dt, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
@@ -360,39 +497,35 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "conv_math": os.environ.get("DSF_CONV_MATH", "x6") + (": fp32 products as 6 bf16 MFMAs on exact 3-way operand splits, fp32 accumulate"
                                                                 if os.environ.get("DSF_CONV_MATH", "x6") == "x6" else ": fp32 MFMA"),
-            "config": {"workload": "BASELINE configs[1]: batch=%d/GPU %s 2-stage + MANO + depth rasteriser, single view"
-                                   % (args.batch, args.backbone),
-                       "global_batch": args.batch * world, "hip_graph": bool(args.graph),
+            "config": {"workload": w["workload"], "baseline_config": args.config, "unit_of_value": w["unit_note"],
+                       "global_batch": B * world, "hip_graph": bool(args.graph),
                        "weight_gradients_on_second_stream": os.environ.get("DSF_WRW_STREAM", "1") != "0", "crop": 128, "raster": 640, "parallelism": "dp%d" % world,
                        "mano_asset": "synthetic MANO-shaped hand (real MANO_RIGHT.pkl is license-gated)"},
             "final_loss": round(loss_val, 5),
             "distributed": facts,
         }
-        out["roofline"], out["conv_kernels"] = conv_kernel_roofline(step, tgt)
-        out["roofline_raster"] = crop_kernel_roofline(render, args.batch)
-        out["fp32_mfma_path"] = same_step_on_fp32_mfma(step, tgt, args.batch)
+        out["roofline"], out["conv_kernels"] = conv_kernel_roofline(step, w["run_diag"])
+        if args.config == 2:
+            out["roofline_raster"] = crop_kernel_roofline(w["render"], B)
+            out["fp32_mfma_path"] = same_step_on_fp32_mfma(step, w["tgt"], B)
         if "x6" in out["roofline"]["kernel"]:
             out["roofline"]["measured_mfma_ceiling"] = measured_mfma_ceiling()
             out["roofline"]["frac_of_measured_ceiling"] = round(
                 out["roofline"]["achieved"] / out["roofline"]["measured_mfma_ceiling"]["fp32_equivalent_TFLOP/s"], 4)
-        flops_per_img = 3 * 25.42e9 if args.backbone.endswith("18") else 3 * 37.84e9     # fwd+bwd ~ 3x fwd
-        tf = flops_per_img * images / dt / 1e12
-        out["whole_step_mfma"] = {"achieved": round(tf, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": round(tf / FP32_MATRIX_PEAK_TFLOPS, 4),
-                                  "note": "backbone FLOPs (3 x 25.42 GFLOP/img) / whole step time, all kernels included; the peak is the fp32 MFMA's "
-                                          "-- the split (x6) kernels run above it"}
+        tf = w["flops_per_unit"] * images / dt / 1e12
+        x6_peak = round(BF16_MATRIX_PEAK_TFLOPS / 6.0, 1)
+        out["whole_step_mfma"] = {"achieved": round(tf, 2), "peak": x6_peak, "unit": "TFLOP/s", "frac": round(tf / x6_peak, 4),
+                                  "frac_of_fp32_mfma_peak": round(tf / FP32_MATRIX_PEAK_TFLOPS, 4),
+                                  "note": "network FLOPs (%s) / whole step time, every kernel of the step included; peak = the split "
+                                          "(x6) kernels' 2500 / 6 fp32-equivalent TFLOP/s (the fp32 MFMA's own peak is 157.3)" % w["flops_note"]}
         if world == 1 and not args.no_cpu_baseline:
-            from dsf_amd.assets import build_synthetic_mano
-            from oracle import step_ref                       # CPU oracle: the reported baseline leg only
             cores = min(usable_cpus(), 32)
             torch.set_num_threads(cores)
             os.environ["OMP_NUM_THREADS"] = str(cores)
-            ips, secs, n = step_ref.timed_steps(build_synthetic_mano(0), B=2, steps=args.cpu_steps, warmup=1,
-                                                backbone=args.backbone)
+            ips, secs, n, what = w["cpu"](args.cpu_steps)
             out["cpu_baseline"] = {"value": round(ips, 3), "unit": "images/s", "cores": cores, "kind": "port",
-                                   "sample": "%d images: the same step (same net, losses, AdamW) at B=2 x %d steps through "
-                                             "the CPU oracle (torch-CPU trunk, C rasteriser, numpy crop chain), %.1f s"
-                                             % (n, args.cpu_steps, secs)}
+                                   "sample": "%d images: %s through the CPU oracle (torch-CPU trunk, C rasteriser / point-face "
+                                             "distances, numpy crop chain), %.1f s" % (n, what, secs)}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

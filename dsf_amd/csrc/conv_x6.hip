@@ -76,6 +76,24 @@ __device__ __forceinline__ void split4(const u32x4 raw, uint2& h, uint2& m, uint
     l.x = pk_bf16(r0 - pk_lo(m.x), r1 - pk_hi(m.x)); l.y = pk_bf16(r2 - pk_lo(m.y), r3 - pk_hi(m.y));
 }
 
+// split4 in four steps of ~5 VALU each (the loaders of the backward-weights kernels hand ONE step to each MFMA gap)
+struct Split4 { uint2 h, m, l; float r0, r1, r2, r3; };
+template <int STEP> __device__ __forceinline__ void split4_step(const u32x4 raw, Split4& s) {
+    const f32x4 v = __builtin_bit_cast(f32x4, raw);
+    if (STEP == 0) {
+        s.h.x = pk_bf16(v[0], v[1]); s.h.y = pk_bf16(v[2], v[3]);
+        s.r0 = v[0] - pk_lo(s.h.x); s.r1 = v[1] - pk_hi(s.h.x);
+    } else if (STEP == 1) {
+        s.r2 = v[2] - pk_lo(s.h.y); s.r3 = v[3] - pk_hi(s.h.y);
+        s.m.x = pk_bf16(s.r0, s.r1); s.m.y = pk_bf16(s.r2, s.r3);
+    } else if (STEP == 2) {
+        s.r0 -= pk_lo(s.m.x); s.r1 -= pk_hi(s.m.x); s.r2 -= pk_lo(s.m.y);
+    } else {
+        s.r3 -= pk_hi(s.m.y);
+        s.l.x = pk_bf16(s.r0, s.r1); s.l.y = pk_bf16(s.r2, s.r3);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Weight image.  mode 0 (forward): n = output channel, k = input channel, taps in order;  W is the kernel layout
 // [KH][KW][Ci][Co].  mode 1 (backward-data of a stride-1 convolution): n = input channel, k = output channel, taps
@@ -373,7 +391,8 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------------
 struct X6Ep { const float* scale; const float* shift; const float* residual; int relu; int stats_acc; };   // output epilogue (all null: none); stats_acc: see `stats`
 
-template <int BN, bool DIL2, int BMT>
+// SCHED 1: even spread of the loader over the MFMA gaps by group barriers (see igemm_wrw_x6_kernel)
+template <int BN, bool DIL2, int BMT, int SCHED = 0>
 __global__ __launch_bounds__(256, 2) void igemm_x6b_kernel(const float* __restrict__ X, const uint4* __restrict__ Wimg,
                                                           const float* __restrict__ bias, float* __restrict__ Y, X6P p,
                                                           int m_tiles, int n_tiles, int k_splits, uint32_t x_bytes,
@@ -525,10 +544,45 @@ __global__ __launch_bounds__(256, 2) void igemm_x6b_kernel(const float* __restri
 #pragma unroll
             for (int i = 0; i < TM; ++i)
                 a[pl][i] = __builtin_bit_cast(bf16x8, As[buf][pl * LA::SIZE + a_frag + i * 32]);
-        __builtin_amdgcn_sched_barrier(0);
         constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};
         constexpr int NM = 6 * TM * TN;                                   // MFMAs of the chunk: 24 or 12
         constexpr int NB = 3 * TN, NP = NB + 2 * APASS;                   // pieces: B loads, A loads, A stores
+        if (SCHED == 1) {
+#pragma unroll
+            for (int f = 0; f < NB; ++f) load_b(OTHER, f, live1);
+#pragma unroll
+            for (int i = 0; i < APASS; ++i) load_a(SET, i, live2);
+#pragma unroll
+            for (int i = 0; i < APASS; ++i) stage_piece(OTHER, buf ^ 1, i);
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][i], __builtin_bit_cast(bf16x8, rbf[buf][PB[q]][j]),
+                                                                            acc[i][j], 0, 0, 0);
+            // gaps 0 .. NB-1: a weight-fragment load each (two VALU of addressing); then the A loads behind their address
+            // arithmetic; the split arithmetic and the LDS stores of the previous chunk's A tile fill the rest
+            constexpr int G1 = NB + (NM - NB) / 3;                        // last A load
+            __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);           // plane-0 A fragments first
+#pragma unroll
+            for (int g = 0; g < NM; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (g < 2) __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);                 // planes 1, 2
+                if (g < NB) {
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x002, (NM == 24) ? 4 : 8, 0);
+                    if (g > NB && g <= G1 && (g - NB) % ((G1 - NB) / APASS) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            return;
+        }
+        __builtin_amdgcn_sched_barrier(0);
         int slot = 0;
 #pragma unroll
         for (int q = 0; q < 6; ++q)
@@ -638,7 +692,11 @@ __device__ __forceinline__ uint32_t x6_fast_div(uint32_t n, uint64_t magic) { re
 // byte offset of 16-byte chunk `ch` (0..15) of pixel row `row` (0..15) inside one plane of a [16][128] bf16 tile
 __device__ __forceinline__ int x6_tr_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
 
-template <int BN>
+// SCHED 1: the loader's ~120 VALU, 12 LDS stores and 4 buffer loads of a chunk are spread EVENLY over the 24 MFMA gaps by the
+// compiler's group-barrier pipeline (5 VALU per gap) instead of riding as whole pieces (one 22-instruction address decode or
+// split behind one MFMA, nothing behind the next): a 32-cycle MFMA hides ~6 single-issue instructions of its own wave, a clump of
+// 22 stalls the wave's next MFMA for ~90 cycles (MI355X_MICROARCH.md, "vector-instruction ISSUE cost").
+template <int BN, int SCHED = 0>
 __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __restrict__ X, const float* __restrict__ dY,
                                                              float* __restrict__ dW, X6P p, int k_tiles, int n_tiles,
                                                              int n_splits, int m_per_split, uint64_t magic_wo,
@@ -710,6 +768,48 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
         *reinterpret_cast<uint2*>(base + 2 * PLANE) = l;
     };
 
+    // The same two pieces cut into steps of ~5 VALU (SCHED 2): an X load = 4 steps (pixel decode by two multiply-shift
+    // divisions, tap offsets, range test + offset + the load), a dY load = 1, a stage = 4 (split4_step; the three LDS stores
+    // ride with the last).  One step per MFMA gap: a 32-cycle MFMA hides ~6 single-issue instructions of its own wave; whole
+    // pieces (22 VALU behind one MFMA, none behind the next) stalled the wave's next MFMA for ~90 cycles six times per chunk.
+    struct { uint32_t mm, q, b; int m, ox, iy, ix; } ad;
+    Split4 sp;
+    auto load_step = [&](auto SET, auto JC, auto STEPC, int mc) {
+        constexpr int S = decltype(SET)::value, j = decltype(JC)::value, STEP = decltype(STEPC)::value;
+        if (j >= 2) {                                                       // dY: one step
+            const int m = mc + l_p + 8 * (j & 1);
+            const bool ok = b_nok & (m < m_end);
+            rl[S][j] = x6_load16(ybuf, ok ? (uint32_t)(m * p.Co + b_n) * 4u : X_OOB);
+        } else if (STEP == 0) {                                             // (the empty asm statements pin each step's results to ITS gap:
+            ad.m = mc + l_p + 8 * j;                                        //  the optimiser otherwise sinks the arithmetic to its use in step 3)
+            ad.mm = (uint32_t)min(ad.m, M - 1);
+            ad.q = x6_fast_div(ad.mm, magic_wo);
+            asm volatile("" : "+v"(ad.q), "+v"(ad.mm));
+        } else if (STEP == 1) {
+            ad.ox = (int)(ad.mm - ad.q * (uint32_t)p.Wo);
+            ad.b = x6_fast_div(ad.q, magic_ho);
+            asm volatile("" : "+v"(ad.ox), "+v"(ad.b));
+        } else if (STEP == 2) {
+            const int oy = (int)(ad.q - ad.b * (uint32_t)p.Ho);
+            ad.iy = oy * p.stride + a_kh - p.pad_h; ad.ix = ad.ox * p.stride + a_kw - p.pad_w;
+            asm volatile("" : "+v"(ad.iy), "+v"(ad.ix));
+        } else {
+            const bool ok = a_kok & (ad.m < m_end) & ((unsigned)ad.iy < (unsigned)p.Hi) & ((unsigned)ad.ix < (unsigned)p.Wi);
+            const uint32_t off = (uint32_t)((((int)ad.b * p.Hi + ad.iy) * p.Wi + ad.ix) * p.Ci + a_c) * 4u;
+            rl[S][j] = x6_load16(xbuf, ok ? off : X_OOB);
+        }
+    };
+    auto stage_step = [&](auto SET, int buf, auto JC, auto STEPC) {
+        constexpr int S = decltype(SET)::value, j = decltype(JC)::value, STEP = decltype(STEPC)::value;
+        split4_step<STEP>(rl[S][j], sp);
+        if (STEP == 3) {
+            char* base = (j < 2 ? As[buf] : Bs[buf]) + ((j & 1) ? st_off1 : st_off0);
+            *reinterpret_cast<uint2*>(base) = sp.h;
+            *reinterpret_cast<uint2*>(base + PLANE) = sp.m;
+            *reinterpret_cast<uint2*>(base + 2 * PLANE) = sp.l;
+        }
+    };
+
     using Set0 = std::integral_constant<int, 0>;
     using Set1 = std::integral_constant<int, 1>;
     if (m_begin < m_end) {
@@ -752,8 +852,81 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
 #pragma unroll
             for (int j = 0; j < TN; ++j) b[pl][j] = tr_read(Bs[buf] + pl * PLANE, fb[j][0], fb[j][1]);
         }
-        __builtin_amdgcn_sched_barrier(0);
         constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};
+        if (SCHED == 2) {
+            // 24 gaps (BN 128): X load 0 (4 steps; dY load 0 with the first), X load 1 (4; dY load 1), then the four stages (4
+            // steps each).  12 gaps (BN 64): two steps per gap.
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int SPG = (TM == 2) ? 1 : 2;                          // steps per gap
+            auto step = [&](auto SC) {
+                constexpr int sidx = decltype(SC)::value;                   // 0 .. 23
+                using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>;
+                using C2 = std::integral_constant<int, 2>; using C3 = std::integral_constant<int, 3>;
+                using ST = std::integral_constant<int, sidx & 3>;
+                if (sidx < 4) { if (sidx == 0) load_step(SET, C2{}, C0{}, mc + 2 * XBK); load_step(SET, C0{}, ST{}, mc + 2 * XBK); }
+                else if (sidx < 8) { if (sidx == 4) load_step(SET, C3{}, C0{}, mc + 2 * XBK); load_step(SET, C1{}, ST{}, mc + 2 * XBK); }
+                else if (sidx < 12) stage_step(OTHER, buf ^ 1, C0{}, ST{});
+                else if (sidx < 16) stage_step(OTHER, buf ^ 1, C1{}, ST{});
+                else if (sidx < 20) stage_step(OTHER, buf ^ 1, C2{}, ST{});
+                else stage_step(OTHER, buf ^ 1, C3{}, ST{});
+            };
+            auto gap = [&](auto GC) {
+                constexpr int g = decltype(GC)::value;
+                step(std::integral_constant<int, g * SPG>{});
+                if (SPG == 2) step(std::integral_constant<int, g * SPG + 1>{});
+            };
+            int slot = 0;
+#define DSF_WRW_GAP(G) if (slot == G) gap(std::integral_constant<int, (G) < 24 / SPG ? (G) : 0>{});
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][i], b[PB[q]][j], acc[i][j], 0, 0, 0);
+                        DSF_WRW_GAP(0) DSF_WRW_GAP(1) DSF_WRW_GAP(2) DSF_WRW_GAP(3) DSF_WRW_GAP(4) DSF_WRW_GAP(5) DSF_WRW_GAP(6) DSF_WRW_GAP(7)
+                        DSF_WRW_GAP(8) DSF_WRW_GAP(9) DSF_WRW_GAP(10) DSF_WRW_GAP(11)
+                        if (SPG == 1) {
+                            DSF_WRW_GAP(12) DSF_WRW_GAP(13) DSF_WRW_GAP(14) DSF_WRW_GAP(15) DSF_WRW_GAP(16) DSF_WRW_GAP(17) DSF_WRW_GAP(18)
+                            DSF_WRW_GAP(19) DSF_WRW_GAP(20) DSF_WRW_GAP(21) DSF_WRW_GAP(22) DSF_WRW_GAP(23)
+                        }
+                        ++slot;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#undef DSF_WRW_GAP
+            __syncthreads();
+            return;
+        }
+        if (SCHED == 1) {
+            // program order: fragment reads, the whole loader, the MFMAs; the pipeline below interleaves them
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc) load_piece(SET, pc, mc + 2 * XBK);
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc) stage_piece(OTHER, buf ^ 1, pc);
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][i], b[PB[q]][j], acc[i][j], 0, 0, 0);
+            constexpr int NM = 6 * TM * TN;                              // 24 or 12 gaps
+            constexpr int VPG = (TM == 2) ? 5 : 10;                      // VALU per gap
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);           // plane-0 fragments first
+#pragma unroll
+            for (int g = 0; g < NM; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (g < 2 * (TM + TN)) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     // the other planes' fragments, two per gap
+                __builtin_amdgcn_sched_group_barrier(0x002, VPG, 0);
+                // the four buffer loads early (behind their address arithmetic, the first VALU in program order): they have the
+                // rest of this chunk and most of the next to land before the split arithmetic, which comes last, needs them
+                if (g == NM / 6 || g == NM / 3 || g == NM / 3 + 1 || g == NM / 3 + 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            return;
+        }
+        __builtin_amdgcn_sched_barrier(0);
         int slot = 0;
 #pragma unroll
         for (int q = 0; q < 6; ++q)
@@ -829,7 +1002,7 @@ __global__ __launch_bounds__(256) void x6_split_dy_kernel(const float* __restric
     img[base + 4 * BN] = make_uint4(l0.x, l0.y, l1.x, l1.y);
 }
 
-template <int BN>
+template <int BN, int SCHED = 0>
 __global__ __launch_bounds__(256, 2) void igemm_wrw_x6b_kernel(const float* __restrict__ X, const uint4* __restrict__ dYimg,
                                                               float* __restrict__ dW, X6P p, int k_tiles, int n_tiles,
                                                               int n_splits, int m_per_split, uint64_t magic_wo,
@@ -937,10 +1110,42 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6b_kernel(const float* __re
         for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
             for (int i = 0; i < TM; ++i) a[pl][i] = tr_read(As[buf] + pl * PLANE, fa[i][0], fa[i][1]);
-        __builtin_amdgcn_sched_barrier(0);
         constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};
         constexpr int NM = 6 * TM * TN;
         constexpr int NB = 3 * TN, NP = NB + 4;                           // pieces: 6 dY loads, 2 X loads, 2 X stores
+        if (SCHED == 1) {                                                 // even spread by group barriers (see igemm_wrw_x6_kernel)
+#pragma unroll
+            for (int f = 0; f < NB; ++f) load_b(OTHER, f, mc + XBK);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) load_a(SET, j, mc + 2 * XBK);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) stage_a(OTHER, buf ^ 1, j);
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][i], __builtin_bit_cast(bf16x8, rbf[buf][PB[q]][j]),
+                                                                            acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * TM, 0);       // plane-0 X fragments first
+#pragma unroll
+            for (int g = 0; g < NM; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (g < 2) __builtin_amdgcn_sched_group_barrier(0x100, 2 * TM, 0);             // planes 1, 2
+                if (g < NB) {                                                                  // the dY fragment loads of the NEXT chunk first
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x002, (NM == 24) ? 5 : 10, 0);
+                    if (g == NB + NM / 6 || g == NB + NM / 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // the X loads
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            return;
+        }
+        __builtin_amdgcn_sched_barrier(0);
         int slot = 0;
 #pragma unroll
         for (int q = 0; q < 6; ++q)
@@ -1076,6 +1281,16 @@ int dsf_conv_x6_split_weights_multi(const int64_t* jobs, int n_jobs, int64_t tot
     return dsf_launch_status();
 }
 
+// DSF_X6_SCHED (A/B): bit 0 = backward-weights kernels, bit 1 = forward-type igemm_x6b_kernel take the group-barrier loader
+// spread (SCHED = 1 instantiations); bit 2 = the staged backward-weights kernel with its loader cut into one step per MFMA gap
+// (SCHED = 2); 0 = the piece-per-gap placement everywhere
+static int x6_sched_mask() {
+    static const int v = [] { const char* e = getenv("DSF_X6_SCHED"); return e ? atoi(e) : 1; }();
+    return v;
+}
+static int x6_sched() { return x6_sched_mask() & 1; }
+static int x6_sched_fwd() { return x6_sched_mask() & 2; }
+
 // Ci / Co are the reduction / output channel counts of the IMAGE (mode 1: those of the backward-data GEMM).
 static int x6_forward_impl(const float* X, const void* image, const float* bias, float* Y, int B, int Hi, int Wi, int Ci, int Ho,
                            int Wo, int Co, int KH, int KW, int stride, int dil, int pad_h, int pad_w, int k_splits,
@@ -1125,9 +1340,11 @@ static int x6_forward_impl(const float* X, const void* image, const float* bias,
 #define DSF_LAUNCH_X6(KERNEL, BNv, DILv, BMv) hipLaunchKernelGGL((KERNEL<BNv, DILv, BMv>), grid, dim3(256), 0, (hipStream_t)stream, \
                                                        X, (const uint4*)image, bias, Y, p, m_tiles, n_tiles, k_splits,              \
                                                        (uint32_t)x_bytes, (uint32_t)w_bytes)
-#define DSF_LAUNCH_X6B(BNv, DILv, BMv) hipLaunchKernelGGL((igemm_x6b_kernel<BNv, DILv, BMv>), grid, dim3(256), 0, (hipStream_t)stream, \
-                                                       X, (const uint4*)image, bias, Y, p, m_tiles, n_tiles, k_splits,              \
-                                                       (uint32_t)x_bytes, (uint32_t)w_bytes, stats, ep)
+#define DSF_LAUNCH_X6B(BNv, DILv, BMv) do { if (x6_sched_fwd())                                                                      \
+        hipLaunchKernelGGL((igemm_x6b_kernel<BNv, DILv, BMv, 1>), grid, dim3(256), 0, (hipStream_t)stream, X, (const uint4*)image, bias, \
+                           Y, p, m_tiles, n_tiles, k_splits, (uint32_t)x_bytes, (uint32_t)w_bytes, stats, ep);                            \
+    else hipLaunchKernelGGL((igemm_x6b_kernel<BNv, DILv, BMv, 0>), grid, dim3(256), 0, (hipStream_t)stream, X, (const uint4*)image,      \
+                            bias, Y, p, m_tiles, n_tiles, k_splits, (uint32_t)x_bytes, (uint32_t)w_bytes, stats, ep); } while (0)
     // 64-row tiles with several n tiles (16x16x256, 8x8x512 maps): every wave of the many small tiles would pull its own copy of
     // the weight block from L2 -- the LDS-staged kernel is faster there (measured 136 / 139 vs 133 / 133 TFLOP/s)
     const bool direct = bdirect && !(bmt == 64 && n_tiles >= 2);
@@ -1208,14 +1425,24 @@ int dsf_conv_x6_forward_affine(const float* X, const void* image, const float* b
 }
 
 // bytes of the dY image igemm_wrw_x6b_kernel reads (x6_split_dy_kernel writes it): ceil(M / 16) chunks x n tiles x 3 planes
-// x 2 BN granules of 16 bytes.  0: this shape stays on the LDS-staged kernel (tiny reductions).
+// x 2 BN granules of 16 bytes (0: no image possible).  Whether a layer SHOULD take the image path: dsf_conv_x6_wrw_prefers_direct.
 int64_t dsf_conv_x6_wrw_image_bytes(int B, int Ho, int Wo, int Co) {
-    static const int direct = [] { const char* e = getenv("DSF_X6_WRW_DIRECT"); return e ? atoi(e) : 1; }();
     const int64_t M = (int64_t)B * Ho * Wo;
-    if (!direct || M < 64 || Co < 4) return 0;
+    if (M < 64 || Co < 4) return 0;
     const int bn = x6_bn(Co);
     const int64_t bytes = ((M + XBK - 1) / XBK) * ((Co + bn - 1) / bn) * (int64_t)(6 * bn * 16);
     return bytes < 0xFFFFFFF0ll ? bytes : 0;                              // (32-bit buffer offsets)
+}
+
+// The image pass costs 10 bytes of traffic per dY element and a launch; the kernel behind it saves the dY half of the loader
+// work once per 128 k rows.  Measured at B = 32 (tools/wrw_ab.py): it wins where >= 16 k tiles share the image and the pixel
+// count is large (488->256 at 64x64: 1619 -> 1507 us; 256->256 k4 s2: 401 -> 360; 256->64 at 64x64: 287 -> 263) and loses on
+// the short reductions (64->256 3x3: 224 -> 258 us; every 8x8 .. 32x32 map: +1 .. +12 %; 1x1 layers: +26 .. +96 %).
+int dsf_conv_x6_wrw_prefers_direct(int B, int Ho, int Wo, int Ci, int Co, int KH, int KW) {
+    static const int direct = [] { const char* e = getenv("DSF_X6_WRW_DIRECT"); return e ? atoi(e) : 1; }();   // 0 never, 2 always (A/B)
+    if (!direct || dsf_conv_x6_wrw_image_bytes(B, Ho, Wo, Co) == 0) return 0;
+    if (direct == 2) return 1;
+    return ((int64_t)KH * KW * Ci + 127) / 128 >= 16 && (int64_t)B * Ho * Wo >= 32768;
 }
 
 int64_t dsf_conv_x6_wrw_workspace_bytes(int B, int Ho, int Wo, int Ci, int Co, int KH, int KW) {
@@ -1268,17 +1495,40 @@ static int x6_wrw_impl(const float* X, const float* dY, float* dW, int B, int Hi
         if (bn == 128) {
             hipLaunchKernelGGL(x6_split_dy_kernel<128>, dim3(chunks * n_tiles), dim3(256), 0, (hipStream_t)stream, dY, (uint4*)dy_image,
                                (int)M, Co, n_tiles);
-            hipLaunchKernelGGL(igemm_wrw_x6b_kernel<128>, dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream, X,
-                               (const uint4*)dy_image, dW, p, k_tiles, n_tiles, splits, (int)per, mwo, mho, (uint32_t)x_bytes,
-                               (uint32_t)img_bytes, partial);
+            if (x6_sched())
+                hipLaunchKernelGGL((igemm_wrw_x6b_kernel<128, 1>), dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream, X,
+                                   (const uint4*)dy_image, dW, p, k_tiles, n_tiles, splits, (int)per, mwo, mho, (uint32_t)x_bytes,
+                                   (uint32_t)img_bytes, partial);
+            else
+                hipLaunchKernelGGL((igemm_wrw_x6b_kernel<128, 0>), dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream, X,
+                                   (const uint4*)dy_image, dW, p, k_tiles, n_tiles, splits, (int)per, mwo, mho, (uint32_t)x_bytes,
+                                   (uint32_t)img_bytes, partial);
         } else {
             hipLaunchKernelGGL(x6_split_dy_kernel<64>, dim3(chunks * n_tiles), dim3(128), 0, (hipStream_t)stream, dY, (uint4*)dy_image,
                                (int)M, Co, n_tiles);
-            hipLaunchKernelGGL(igemm_wrw_x6b_kernel<64>, dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream, X,
-                               (const uint4*)dy_image, dW, p, k_tiles, n_tiles, splits, (int)per, mwo, mho, (uint32_t)x_bytes,
-                               (uint32_t)img_bytes, partial);
+            if (x6_sched())
+                hipLaunchKernelGGL((igemm_wrw_x6b_kernel<64, 1>), dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream, X,
+                                   (const uint4*)dy_image, dW, p, k_tiles, n_tiles, splits, (int)per, mwo, mho, (uint32_t)x_bytes,
+                                   (uint32_t)img_bytes, partial);
+            else
+                hipLaunchKernelGGL((igemm_wrw_x6b_kernel<64, 0>), dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream, X,
+                                   (const uint4*)dy_image, dW, p, k_tiles, n_tiles, splits, (int)per, mwo, mho, (uint32_t)x_bytes,
+                                   (uint32_t)img_bytes, partial);
         }
-    } else if (bn == 128)
+    } else if (x6_sched_mask() & 4) {                                     // step-per-gap loader (SCHED 2)
+        if (bn == 128)
+            hipLaunchKernelGGL((igemm_wrw_x6_kernel<128, 2>), dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream, X, dY,
+                               dW, p, k_tiles, n_tiles, splits, (int)per, mwo, mho, (uint32_t)x_bytes, (uint32_t)dy_bytes, partial);
+        else
+            hipLaunchKernelGGL((igemm_wrw_x6_kernel<64, 2>), dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream, X, dY,
+                               dW, p, k_tiles, n_tiles, splits, (int)per, mwo, mho, (uint32_t)x_bytes, (uint32_t)dy_bytes, partial);
+    } else if (x6_sched() && bn == 128)
+        hipLaunchKernelGGL((igemm_wrw_x6_kernel<128, 1>), dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream, X, dY,
+                           dW, p, k_tiles, n_tiles, splits, (int)per, mwo, mho, (uint32_t)x_bytes, (uint32_t)dy_bytes, partial);
+    else if (x6_sched())
+        hipLaunchKernelGGL((igemm_wrw_x6_kernel<64, 1>), dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream, X, dY,
+                           dW, p, k_tiles, n_tiles, splits, (int)per, mwo, mho, (uint32_t)x_bytes, (uint32_t)dy_bytes, partial);
+    else if (bn == 128)
         hipLaunchKernelGGL(igemm_wrw_x6_kernel<128>, dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream, X, dY,
                            dW, p, k_tiles, n_tiles, splits, (int)per, mwo, mho, (uint32_t)x_bytes, (uint32_t)dy_bytes, partial);
     else

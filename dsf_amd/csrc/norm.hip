@@ -164,16 +164,17 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 __device__ __forceinline__ void bn_fold_rows(const float* __restrict__ rows, int n_rows, int C, int c, double (&s0)[4], double (&s1)[4]) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) { s0[k] = 0.0; s1[k] = 0.0; }
-    for (int r = 0; r < n_rows; r += 4) {
-        float4 a[4], b[4];
+    // all 2 x 8 loads of a batch of 8 rows are issued before the first add: ONE L2 round trip for BN_ACC_ROWS = 8
+    for (int r = 0; r < n_rows; r += 8) {
+        float4 a[8], b[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             const bool ok = r + u < n_rows;
             a[u] = ok ? *reinterpret_cast<const float4*>(rows + (int64_t)(r + u) * 2 * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
             b[u] = ok ? *reinterpret_cast<const float4*>(rows + (int64_t)(r + u) * 2 * C + C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             s0[0] += (double)a[u].x; s0[1] += (double)a[u].y; s0[2] += (double)a[u].z; s0[3] += (double)a[u].w;
             s1[0] += (double)b[u].x; s1[1] += (double)b[u].y; s1[2] += (double)b[u].z; s1[3] += (double)b[u].w;
         }
@@ -183,7 +184,7 @@ __device__ __forceinline__ void bn_fold_rows(const float* __restrict__ rows, int
 // ---- pass 2 forward: y = (x - mean) * invstd * gamma + beta (+ residual) (relu) ---------------------
 // The grid stride is a multiple of the float4 column count, so a thread's channel quad is loop-invariant.
 // FOLD: mean / invstd are not read but COMPUTED in the prologue from the accumulation rows (every thread folds the rows of
-// its own four channels: <= 32 rows x 2 float4, L2-resident), with bn_finalize_kernel<0>'s arithmetic; the threads that hold
+// its own four channels: 8 rows x 2 float4, L2-resident), with bn_finalize_kernel<0>'s arithmetic; the threads that hold
 // each channel quad first (i0 < C / 4) also store mean / invstd for the backward pass and update the running statistics.
 template <bool FOLD>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
@@ -496,7 +497,10 @@ extern "C" int dsf_bn_backward(const float* x, const float* grad_y, const float*
 // convolution that filled the rows (2 otherwise), backward = 2, where the ordered-partials path above needs 2-3 and 3.
 // Results differ from that path by the float atomics' summation order only (~1e-7 relative on the statistics); in
 // deterministic mode these entry points return DSF_ERR_UNSUPPORTED and the caller uses the ordered path.
-constexpr int BN_ACC_ROWS = 32;
+// 8 rows: the prologue fold is one batch of loads; 256 reduce workgroups = 32 adders per address, a 512-workgroup convolution
+// epilogue 64 -- a few hundred KB of atomics per launch, spread over its duration (measured with 32 rows: the 64-load fold cost
+// more than the finalise launch it replaced)
+constexpr int BN_ACC_ROWS = 8;
 extern "C" int dsf_bn_acc_rows(void) { return BN_ACC_ROWS; }
 
 extern "C" int dsf_bn_forward_acc(const float* x, const float* residual, const float* gamma, const float* beta, int64_t M, int C,

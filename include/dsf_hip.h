@@ -507,8 +507,10 @@ int dsf_conv_x6_wrw_ws(const float* X, const float* dY, float* dW, int B, int Hi
  * weight-gradient GEMM cuDNN runs for every nn.Conv2d of the reference's backbones, model/resnet.py, model/backbone.py): two
  * launches -- the image pass (4 bytes read, 6 written per dY element) and a kernel whose LDS carries the X tile only.
  * dy_image: dsf_conv_x6_wrw_image_bytes(B, Ho, Wo, Co) bytes of scratch (0 = shape not served: use dsf_conv_x6_wrw_ws);
+ * dsf_conv_x6_wrw_prefers_direct tells for which layers it pays (long reductions shared by >= 16 k tiles);
  * workspace / accumulate / deterministic mode exactly as dsf_conv_x6_wrw_ws (same per-split sums, bitwise, in that mode). */
 int64_t dsf_conv_x6_wrw_image_bytes(int B, int Ho, int Wo, int Co);
+int dsf_conv_x6_wrw_prefers_direct(int B, int Ho, int Wo, int Ci, int Co, int KH, int KW);   /* 1: this layer is faster through the image */
 int dsf_conv_x6_wrw_direct(const float* X, const float* dY, float* dW, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
                            int KW, int stride, int pad_h, int pad_w, int accumulate, float* workspace, void* dy_image,
                            dsf_stream_t stream);

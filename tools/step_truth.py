@@ -47,6 +47,15 @@ net64 = T._Net64(net_cpu)
 l64 = step_ref.pretrain_loss(net64, T._PinnedBridge(orender, rec.images), None, p, cube, d, Config, views=views)
 l64.backward()
 print("loss64 %.6f lossgpu %.6f" % (float(l64), float(lg)))
+# forward distance from the float64 trunk: stage-1 feature map and pixel heads, CPU fp32 and GPU
+with torch.no_grad():
+    pp, cc = (p.repeat_interleave(views, 0), cube.repeat_interleave(views, 0)) if views > 1 else (p, cube)
+    s_c = step_ref.synth_pass(orender, None, pp, cc, d, True)
+    f64 = net64._run_trunk(net64.pre(s_c["img_t"]), '')
+    f32 = net_cpu._run_trunk(net_cpu.pre(s_c["img_t"]), '')
+    fg = net_gpu._run_trunk(net_gpu.pre(s_c["img_t"].cuda()), '')
+    rel = lambda a, b: float((a.double().cpu() - b.double()).norm() / b.double().norm())
+    print("forward distance from float64 (feat, pix): cpu32 %.2e %.2e | gpu %.2e %.2e" % (rel(f32[1], f64[1]), rel(f32[2], f64[2]), rel(fg[1], f64[1]), rel(fg[2], f64[2])))
 print("cpu32 vs 64 (cos, rel):", T._grad_error(net64, net_cpu))
 print("gpu   vs 64 (cos, rel):", T._grad_error(net64, net_gpu))
 rows = []
