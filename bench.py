@@ -463,8 +463,8 @@ def main():
     w = build_workload(args, dev, rank, world)
     step, run = w["step"], w["run"]
     if args.graph:
-        if world > 1 or args.config not in (2, 3):
-            raise SystemExit("--graph: single GPU, configs 2 and 3 (steps without a host decision)")
+        if args.config not in (2, 3):
+            raise SystemExit("--graph: configs 2 and 3 (steps without a host decision); with --gpus N the bucket all-reduces follow each replay")
         from dsf_amd.train_step import GraphedStep
         g = GraphedStep(step, w["tgt"])
         run = lambda: g(w["tgt"])

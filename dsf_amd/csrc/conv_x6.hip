@@ -76,24 +76,6 @@ __device__ __forceinline__ void split4(const u32x4 raw, uint2& h, uint2& m, uint
     l.x = pk_bf16(r0 - pk_lo(m.x), r1 - pk_hi(m.x)); l.y = pk_bf16(r2 - pk_lo(m.y), r3 - pk_hi(m.y));
 }
 
-// split4 in four steps of ~5 VALU each (the loaders of the backward-weights kernels hand ONE step to each MFMA gap)
-struct Split4 { uint2 h, m, l; float r0, r1, r2, r3; };
-template <int STEP> __device__ __forceinline__ void split4_step(const u32x4 raw, Split4& s) {
-    const f32x4 v = __builtin_bit_cast(f32x4, raw);
-    if (STEP == 0) {
-        s.h.x = pk_bf16(v[0], v[1]); s.h.y = pk_bf16(v[2], v[3]);
-        s.r0 = v[0] - pk_lo(s.h.x); s.r1 = v[1] - pk_hi(s.h.x);
-    } else if (STEP == 1) {
-        s.r2 = v[2] - pk_lo(s.h.y); s.r3 = v[3] - pk_hi(s.h.y);
-        s.m.x = pk_bf16(s.r0, s.r1); s.m.y = pk_bf16(s.r2, s.r3);
-    } else if (STEP == 2) {
-        s.r0 -= pk_lo(s.m.x); s.r1 -= pk_hi(s.m.x); s.r2 -= pk_lo(s.m.y);
-    } else {
-        s.r3 -= pk_hi(s.m.y);
-        s.l.x = pk_bf16(s.r0, s.r1); s.l.y = pk_bf16(s.r2, s.r3);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Weight image.  mode 0 (forward): n = output channel, k = input channel, taps in order;  W is the kernel layout
 // [KH][KW][Ci][Co].  mode 1 (backward-data of a stride-1 convolution): n = input channel, k = output channel, taps
@@ -391,8 +373,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------------
 struct X6Ep { const float* scale; const float* shift; const float* residual; int relu; int stats_acc; };   // output epilogue (all null: none); stats_acc: see `stats`
 
-// SCHED 1: even spread of the loader over the MFMA gaps by group barriers (see igemm_wrw_x6_kernel)
-template <int BN, bool DIL2, int BMT, int SCHED = 0>
+template <int BN, bool DIL2, int BMT>
 __global__ __launch_bounds__(256, 2) void igemm_x6b_kernel(const float* __restrict__ X, const uint4* __restrict__ Wimg,
                                                           const float* __restrict__ bias, float* __restrict__ Y, X6P p,
                                                           int m_tiles, int n_tiles, int k_splits, uint32_t x_bytes,
@@ -547,41 +528,6 @@ __global__ __launch_bounds__(256, 2) void igemm_x6b_kernel(const float* __restri
         constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};
         constexpr int NM = 6 * TM * TN;                                   // MFMAs of the chunk: 24 or 12
         constexpr int NB = 3 * TN, NP = NB + 2 * APASS;                   // pieces: B loads, A loads, A stores
-        if (SCHED == 1) {
-#pragma unroll
-            for (int f = 0; f < NB; ++f) load_b(OTHER, f, live1);
-#pragma unroll
-            for (int i = 0; i < APASS; ++i) load_a(SET, i, live2);
-#pragma unroll
-            for (int i = 0; i < APASS; ++i) stage_piece(OTHER, buf ^ 1, i);
-#pragma unroll
-            for (int q = 0; q < 6; ++q)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][i], __builtin_bit_cast(bf16x8, rbf[buf][PB[q]][j]),
-                                                                            acc[i][j], 0, 0, 0);
-            // gaps 0 .. NB-1: a weight-fragment load each (two VALU of addressing); then the A loads behind their address
-            // arithmetic; the split arithmetic and the LDS stores of the previous chunk's A tile fill the rest
-            constexpr int G1 = NB + (NM - NB) / 3;                        // last A load
-            __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);           // plane-0 A fragments first
-#pragma unroll
-            for (int g = 0; g < NM; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (g < 2) __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);                 // planes 1, 2
-                if (g < NB) {
-                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                } else {
-                    __builtin_amdgcn_sched_group_barrier(0x002, (NM == 24) ? 4 : 8, 0);
-                    if (g > NB && g <= G1 && (g - NB) % ((G1 - NB) / APASS) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
-            return;
-        }
         __builtin_amdgcn_sched_barrier(0);
         int slot = 0;
 #pragma unroll
@@ -692,11 +638,14 @@ __device__ __forceinline__ uint32_t x6_fast_div(uint32_t n, uint64_t magic) { re
 // byte offset of 16-byte chunk `ch` (0..15) of pixel row `row` (0..15) inside one plane of a [16][128] bf16 tile
 __device__ __forceinline__ int x6_tr_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
 
-// SCHED 1: the loader's ~120 VALU, 12 LDS stores and 4 buffer loads of a chunk are spread EVENLY over the 24 MFMA gaps by the
-// compiler's group-barrier pipeline (5 VALU per gap) instead of riding as whole pieces (one 22-instruction address decode or
-// split behind one MFMA, nothing behind the next): a 32-cycle MFMA hides ~6 single-issue instructions of its own wave, a clump of
-// 22 stalls the wave's next MFMA for ~90 cycles (MI355X_MICROARCH.md, "vector-instruction ISSUE cost").
-template <int BN, int SCHED = 0>
+// Loader placement (round 3): the ~120 VALU, 12 LDS stores and 4 buffer loads of a chunk are spread EVENLY over the 24 MFMA gaps by
+// the compiler's group-barrier pipeline (5 VALU per gap).  Rounds 1-2 handed out whole pieces (one 22-instruction address
+// decode or split behind one MFMA, nothing behind the next): a 32-cycle MFMA hides ~6 single-issue instructions of its own wave,
+// a clump of 22 stalls the wave's next MFMA for ~90 cycles, six times per chunk (MI355X_MICROARCH.md, "vector-instruction ISSUE
+// cost").  Measured B = 32: 488->256 at 64x64 1627 -> 1513 us (181 -> 195 TFLOP/s), 256->256 k4 s2 404 -> 366, the 8x8 .. 32x32
+// maps 71-77 -> 66-72 us (profiles/r03_wrw_variants_ab.txt).  The forward-type kernels keep the piece placement: their loaders
+// are lighter (2.6 VALU per gap) and the pipeline hoists their eight loads in front of the first MFMA (197 -> 186 TFLOP/s).
+template <int BN>
 __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __restrict__ X, const float* __restrict__ dY,
                                                              float* __restrict__ dW, X6P p, int k_tiles, int n_tiles,
                                                              int n_splits, int m_per_split, uint64_t magic_wo,
@@ -768,48 +717,6 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
         *reinterpret_cast<uint2*>(base + 2 * PLANE) = l;
     };
 
-    // The same two pieces cut into steps of ~5 VALU (SCHED 2): an X load = 4 steps (pixel decode by two multiply-shift
-    // divisions, tap offsets, range test + offset + the load), a dY load = 1, a stage = 4 (split4_step; the three LDS stores
-    // ride with the last).  One step per MFMA gap: a 32-cycle MFMA hides ~6 single-issue instructions of its own wave; whole
-    // pieces (22 VALU behind one MFMA, none behind the next) stalled the wave's next MFMA for ~90 cycles six times per chunk.
-    struct { uint32_t mm, q, b; int m, ox, iy, ix; } ad;
-    Split4 sp;
-    auto load_step = [&](auto SET, auto JC, auto STEPC, int mc) {
-        constexpr int S = decltype(SET)::value, j = decltype(JC)::value, STEP = decltype(STEPC)::value;
-        if (j >= 2) {                                                       // dY: one step
-            const int m = mc + l_p + 8 * (j & 1);
-            const bool ok = b_nok & (m < m_end);
-            rl[S][j] = x6_load16(ybuf, ok ? (uint32_t)(m * p.Co + b_n) * 4u : X_OOB);
-        } else if (STEP == 0) {                                             // (the empty asm statements pin each step's results to ITS gap:
-            ad.m = mc + l_p + 8 * j;                                        //  the optimiser otherwise sinks the arithmetic to its use in step 3)
-            ad.mm = (uint32_t)min(ad.m, M - 1);
-            ad.q = x6_fast_div(ad.mm, magic_wo);
-            asm volatile("" : "+v"(ad.q), "+v"(ad.mm));
-        } else if (STEP == 1) {
-            ad.ox = (int)(ad.mm - ad.q * (uint32_t)p.Wo);
-            ad.b = x6_fast_div(ad.q, magic_ho);
-            asm volatile("" : "+v"(ad.ox), "+v"(ad.b));
-        } else if (STEP == 2) {
-            const int oy = (int)(ad.q - ad.b * (uint32_t)p.Ho);
-            ad.iy = oy * p.stride + a_kh - p.pad_h; ad.ix = ad.ox * p.stride + a_kw - p.pad_w;
-            asm volatile("" : "+v"(ad.iy), "+v"(ad.ix));
-        } else {
-            const bool ok = a_kok & (ad.m < m_end) & ((unsigned)ad.iy < (unsigned)p.Hi) & ((unsigned)ad.ix < (unsigned)p.Wi);
-            const uint32_t off = (uint32_t)((((int)ad.b * p.Hi + ad.iy) * p.Wi + ad.ix) * p.Ci + a_c) * 4u;
-            rl[S][j] = x6_load16(xbuf, ok ? off : X_OOB);
-        }
-    };
-    auto stage_step = [&](auto SET, int buf, auto JC, auto STEPC) {
-        constexpr int S = decltype(SET)::value, j = decltype(JC)::value, STEP = decltype(STEPC)::value;
-        split4_step<STEP>(rl[S][j], sp);
-        if (STEP == 3) {
-            char* base = (j < 2 ? As[buf] : Bs[buf]) + ((j & 1) ? st_off1 : st_off0);
-            *reinterpret_cast<uint2*>(base) = sp.h;
-            *reinterpret_cast<uint2*>(base + PLANE) = sp.m;
-            *reinterpret_cast<uint2*>(base + 2 * PLANE) = sp.l;
-        }
-    };
-
     using Set0 = std::integral_constant<int, 0>;
     using Set1 = std::integral_constant<int, 1>;
     if (m_begin < m_end) {
@@ -853,51 +760,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
             for (int j = 0; j < TN; ++j) b[pl][j] = tr_read(Bs[buf] + pl * PLANE, fb[j][0], fb[j][1]);
         }
         constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};
-        if (SCHED == 2) {
-            // 24 gaps (BN 128): X load 0 (4 steps; dY load 0 with the first), X load 1 (4; dY load 1), then the four stages (4
-            // steps each).  12 gaps (BN 64): two steps per gap.
-            __builtin_amdgcn_sched_barrier(0);
-            constexpr int SPG = (TM == 2) ? 1 : 2;                          // steps per gap
-            auto step = [&](auto SC) {
-                constexpr int sidx = decltype(SC)::value;                   // 0 .. 23
-                using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>;
-                using C2 = std::integral_constant<int, 2>; using C3 = std::integral_constant<int, 3>;
-                using ST = std::integral_constant<int, sidx & 3>;
-                if (sidx < 4) { if (sidx == 0) load_step(SET, C2{}, C0{}, mc + 2 * XBK); load_step(SET, C0{}, ST{}, mc + 2 * XBK); }
-                else if (sidx < 8) { if (sidx == 4) load_step(SET, C3{}, C0{}, mc + 2 * XBK); load_step(SET, C1{}, ST{}, mc + 2 * XBK); }
-                else if (sidx < 12) stage_step(OTHER, buf ^ 1, C0{}, ST{});
-                else if (sidx < 16) stage_step(OTHER, buf ^ 1, C1{}, ST{});
-                else if (sidx < 20) stage_step(OTHER, buf ^ 1, C2{}, ST{});
-                else stage_step(OTHER, buf ^ 1, C3{}, ST{});
-            };
-            auto gap = [&](auto GC) {
-                constexpr int g = decltype(GC)::value;
-                step(std::integral_constant<int, g * SPG>{});
-                if (SPG == 2) step(std::integral_constant<int, g * SPG + 1>{});
-            };
-            int slot = 0;
-#define DSF_WRW_GAP(G) if (slot == G) gap(std::integral_constant<int, (G) < 24 / SPG ? (G) : 0>{});
-#pragma unroll
-            for (int q = 0; q < 6; ++q)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][i], b[PB[q]][j], acc[i][j], 0, 0, 0);
-                        DSF_WRW_GAP(0) DSF_WRW_GAP(1) DSF_WRW_GAP(2) DSF_WRW_GAP(3) DSF_WRW_GAP(4) DSF_WRW_GAP(5) DSF_WRW_GAP(6) DSF_WRW_GAP(7)
-                        DSF_WRW_GAP(8) DSF_WRW_GAP(9) DSF_WRW_GAP(10) DSF_WRW_GAP(11)
-                        if (SPG == 1) {
-                            DSF_WRW_GAP(12) DSF_WRW_GAP(13) DSF_WRW_GAP(14) DSF_WRW_GAP(15) DSF_WRW_GAP(16) DSF_WRW_GAP(17) DSF_WRW_GAP(18)
-                            DSF_WRW_GAP(19) DSF_WRW_GAP(20) DSF_WRW_GAP(21) DSF_WRW_GAP(22) DSF_WRW_GAP(23)
-                        }
-                        ++slot;
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-#undef DSF_WRW_GAP
-            __syncthreads();
-            return;
-        }
-        if (SCHED == 1) {
+        {
             // program order: fragment reads, the whole loader, the MFMAs; the pipeline below interleaves them
 #pragma unroll
             for (int pc = 0; pc < 4; ++pc) load_piece(SET, pc, mc + 2 * XBK);
@@ -923,249 +786,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
                 if (g == NM / 6 || g == NM / 3 || g == NM / 3 + 1 || g == NM / 3 + 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
-            return;
         }
-        __builtin_amdgcn_sched_barrier(0);
-        int slot = 0;
-#pragma unroll
-        for (int q = 0; q < 6; ++q)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][i], b[PB[q]][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-                    for (int pc = 0; pc < 4; ++pc) {     // 24 MFMAs: a piece behind every second one; 12: behind every one
-                        if (slot == (TM == 2 ? 2 * pc + 1 : pc)) load_piece(SET, pc, mc + 2 * XBK);
-                        if (slot == (TM == 2 ? 2 * (pc + 4) + 1 : pc + 4)) stage_piece(OTHER, buf ^ 1, pc);
-                    }
-                    ++slot;
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-        __syncthreads();
-    };
-    for (int mc = m_begin; mc < m_end; mc += 2 * XBK) {         // chunks come in pairs: one past m_end is all zeros
-        body(Set0{}, Set1{}, mc);
-        body(Set1{}, Set0{}, mc + XBK);
-    }
-
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * 64 + j * 32 + (lane & 31);
-            if (n >= p.Co) continue;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int k = k0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (k >= K) continue;
-                if (partial) partial[((int64_t)split * K + k) * p.Co + n] = acc[i][j][r];
-                else atomicAdd(dW + (int64_t)k * p.Co + n, acc[i][j][r]);
-            }
-        }
-}
-
-// ------------------------------------------------------------------------------------------------
-// igemm_wrw_x6b_kernel: backward-weights with the dY operand read STRAIGHT INTO THE MFMA FRAGMENT REGISTERS (round 3).
-//
-// Why: in igemm_wrw_x6_kernel BOTH operands are activations, so per 16-pixel chunk a wave splits 4 float4, writes 12
-// ds_write_b64 and issues 24 transposing LDS reads beside its 24 MFMAs -- twice the loader work of the forward kernels per
-// MFMA; and every dY element is loaded, split and transposed again by each of the K / 128 workgroups that share its
-// channels (35 times on the 488 -> 256 layer).  x6_split_dy_kernel does that work ONCE per element: it writes dY as an image
-// that is already the MFMA B fragment -- per (16-pixel chunk, n tile) three planes of [k-group 2][n BN] granules, a granule
-// = 8 consecutive PIXELS of one channel as bf16 -- exactly what the weight image is for the forward kernels (igemm_x6b).
-// Lane l of a wave then reads granule (k-group l >> 5, n) with one coalesced 16-byte buffer load, one chunk ahead, into
-// registers; the workgroups of an XCD that share the n tile walk the pixels in step, so these loads hit L2.  LDS carries the X
-// tile only: per chunk and wave 2 float4 loads, 2 splits, 6 ds_write_b64, 12 transposing reads -- the forward kernel's mix.
-// Cost: the image pass reads 4 and writes 6 bytes per dY element (memory-bound, on the weight-gradient stream).
-// ------------------------------------------------------------------------------------------------
-template <int BN>
-__global__ __launch_bounds__(256) void x6_split_dy_kernel(const float* __restrict__ dY, uint4* __restrict__ img, int M, int Co,
-                                                          int n_tiles) {
-    // one workgroup per (16-pixel chunk, n tile): thread -> (k-group kg, channel n): 8 pixels of one channel
-    const int t = threadIdx.x;
-    if (t >= 2 * BN) return;
-    const int chunk = blockIdx.x / n_tiles, n_tile = blockIdx.x % n_tiles;
-    const int nl = t % BN, kg = t / BN;
-    const int n = n_tile * BN + nl;
-    const int m0 = chunk * XBK + kg * 8;
-    float v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (n < Co && m0 + e < M) ? dY[(int64_t)(m0 + e) * Co + n] : 0.f;
-    uint2 h0, m0s, l0, h1, m1s, l1;
-    split4(__builtin_bit_cast(u32x4, (f32x4){v[0], v[1], v[2], v[3]}), h0, m0s, l0);
-    split4(__builtin_bit_cast(u32x4, (f32x4){v[4], v[5], v[6], v[7]}), h1, m1s, l1);
-    const int64_t base = (int64_t)blockIdx.x * (6 * BN) + kg * BN + nl;
-    img[base] = make_uint4(h0.x, h0.y, h1.x, h1.y);
-    img[base + 2 * BN] = make_uint4(m0s.x, m0s.y, m1s.x, m1s.y);
-    img[base + 4 * BN] = make_uint4(l0.x, l0.y, l1.x, l1.y);
-}
-
-template <int BN, int SCHED = 0>
-__global__ __launch_bounds__(256, 2) void igemm_wrw_x6b_kernel(const float* __restrict__ X, const uint4* __restrict__ dYimg,
-                                                              float* __restrict__ dW, X6P p, int k_tiles, int n_tiles,
-                                                              int n_splits, int m_per_split, uint64_t magic_wo,
-                                                              uint64_t magic_ho, uint32_t x_bytes, uint32_t img_bytes,
-                                                              float* __restrict__ partial) {
-    constexpr int WM = (BN == 128) ? 64 : 32;
-    constexpr int TM = WM / 32, TN = 2, PLANE = 16 * 256;      // bytes per plane of the X tile
-    __shared__ __attribute__((aligned(16))) char As[2][3 * PLANE];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = (BN == 128) ? (wave >> 1) : wave, wn = (BN == 128) ? (wave & 1) : 0;
-    int tile = x6_xcd_contiguous(blockIdx.x, k_tiles * n_tiles * n_splits);
-    const int k_tile = tile % k_tiles; tile /= k_tiles;
-    const int n_tile = tile % n_tiles; const int split = tile / n_tiles;
-    const int k0 = k_tile * 128, n0 = n_tile * BN;
-    const int M = p.B * p.Ho * p.Wo, K = p.KH * p.KW * p.Ci;
-    const int m_begin = split * m_per_split, m_end = min(M, m_begin + m_per_split);
-    const __amdgpu_buffer_rsrc_t xbuf = x6_buffer(X, x_bytes), ybuf = x6_buffer(dYimg, img_bytes);
-
-    // X loader: thread -> (channel quad l_q of the tile's 128 k rows, pixel (t >> 5) + 8 i of the chunk)
-    const int l_q = t & 31, l_p = t >> 5;
-    const int a_k = k0 + l_q * 4;
-    const bool a_kok = a_k < K;
-    const int a_tap = min(a_k, K - 1) / p.Ci;
-    const int a_c = min(a_k, K - 1) % p.Ci, a_kh = a_tap / p.KW, a_kw = a_tap % p.KW;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    u32x4 ra[2][2];                                      // [set][px 0, px 8]: X loads, two chunks ahead
-    u32x4 rbf[2][3][TN];                                 // [set][plane][n block]: dY fragments as loaded, one chunk ahead
-    const uint32_t b_lane = (uint32_t)((lane >> 5) * BN + wn * 64 + (lane & 31)) * 16u;
-    auto load_a = [&](auto SET, int j, int mc) {
-        constexpr int S = decltype(SET)::value;
-        const int m = mc + l_p + 8 * j;
-        const uint32_t mm = (uint32_t)min(m, M - 1);
-        const uint32_t q = x6_fast_div(mm, magic_wo);
-        const int ox = (int)(mm - q * (uint32_t)p.Wo);
-        const uint32_t b = x6_fast_div(q, magic_ho);
-        const int oy = (int)(q - b * (uint32_t)p.Ho);
-        const int iy = oy * p.stride + a_kh - p.pad_h, ix = ox * p.stride + a_kw - p.pad_w;
-        const bool ok = a_kok & (m < m_end) & ((unsigned)iy < (unsigned)p.Hi) & ((unsigned)ix < (unsigned)p.Wi);
-        const uint32_t off = (uint32_t)((((int)b * p.Hi + iy) * p.Wi + ix) * p.Ci + a_c) * 4u;
-        ra[S][j] = x6_load16(xbuf, ok ? off : X_OOB);
-    };
-    auto load_b = [&](auto SET, int f, int mc) {
-        constexpr int S = decltype(SET)::value;
-        const int pl = f / TN, j = f % TN;
-        const uint32_t dead = (mc < m_end) ? 0u : X_OOB;                    // (offset | ~0) is the out-of-range offset: zeros
-        const uint32_t blk = (uint32_t)((mc >> 4) * n_tiles + n_tile);      // image block of (pixel chunk, n tile)
-        rbf[S][pl][j] = x6_load16(ybuf, (blk * (uint32_t)(6 * BN * 16) + (uint32_t)(pl * 2 * BN * 16 + j * 32 * 16) + b_lane) | dead);
-    };
-    const int st_off0 = x6_tr_off(l_p, l_q >> 1) + 8 * (l_q & 1), st_off1 = x6_tr_off(l_p + 8, l_q >> 1) + 8 * (l_q & 1);
-    auto stage_a = [&](auto SET, int buf, int j) {
-        constexpr int S = decltype(SET)::value;
-        uint2 h, m, l;
-        split4(ra[S][j], h, m, l);
-        char* base = As[buf] + (j ? st_off1 : st_off0);
-        *reinterpret_cast<uint2*>(base) = h;
-        *reinterpret_cast<uint2*>(base + PLANE) = m;
-        *reinterpret_cast<uint2*>(base + 2 * PLANE) = l;
-    };
-
-    using Set0 = std::integral_constant<int, 0>;
-    using Set1 = std::integral_constant<int, 1>;
-    if (m_begin < m_end) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) load_a(Set0{}, j, m_begin);
-#pragma unroll
-        for (int f = 0; f < 3 * TN; ++f) load_b(Set0{}, f, m_begin);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) load_a(Set1{}, j, m_begin + XBK);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) stage_a(Set0{}, 0, j);
-    }
-    __syncthreads();
-
-    const int f_row = 8 * (lane >> 5) + ((lane & 15) >> 2);
-    const int f_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-    auto frag_off = [&](int cbase, int r) {
-        const int c = cbase + f_col;
-        return x6_tr_off(f_row + 4 * r, c >> 3) + 2 * (c & 7);
-    };
-    int fa[TM][2];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) { fa[i][0] = frag_off(wm * WM + i * 32, 0); fa[i][1] = frag_off(wm * WM + i * 32, 1); }
-    auto tr_read = [&](const char* base, int off0, int off1) {
-        struct { s16x4 lo, hi; } v;
-        v.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off0));
-        v.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off1));
-        return __builtin_bit_cast(bf16x8, v);
-    };
-
-    // chunk mc (parity SET): X fragments from LDS stage SET, dY fragments = register set SET.  Between its MFMAs: the dY fragment
-    // loads of chunk mc + 16 (set OTHER), the X loads of chunk mc + 32 (ra[SET], staged during chunk mc - 16), then the LDS
-    // stores of chunk mc + 16's X tile.
-    auto body = [&](auto SET, auto OTHER, int mc) {
-        constexpr int buf = decltype(SET)::value;
-        bf16x8 a[3][TM];
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[pl][i] = tr_read(As[buf] + pl * PLANE, fa[i][0], fa[i][1]);
-        constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};
-        constexpr int NM = 6 * TM * TN;
-        constexpr int NB = 3 * TN, NP = NB + 4;                           // pieces: 6 dY loads, 2 X loads, 2 X stores
-        if (SCHED == 1) {                                                 // even spread by group barriers (see igemm_wrw_x6_kernel)
-#pragma unroll
-            for (int f = 0; f < NB; ++f) load_b(OTHER, f, mc + XBK);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) load_a(SET, j, mc + 2 * XBK);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) stage_a(OTHER, buf ^ 1, j);
-#pragma unroll
-            for (int q = 0; q < 6; ++q)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][i], __builtin_bit_cast(bf16x8, rbf[buf][PB[q]][j]),
-                                                                            acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * TM, 0);       // plane-0 X fragments first
-#pragma unroll
-            for (int g = 0; g < NM; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (g < 2) __builtin_amdgcn_sched_group_barrier(0x100, 2 * TM, 0);             // planes 1, 2
-                if (g < NB) {                                                                  // the dY fragment loads of the NEXT chunk first
-                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                } else {
-                    __builtin_amdgcn_sched_group_barrier(0x002, (NM == 24) ? 5 : 10, 0);
-                    if (g == NB + NM / 6 || g == NB + NM / 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // the X loads
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
-            return;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        int slot = 0;
-#pragma unroll
-        for (int q = 0; q < 6; ++q)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][i], __builtin_bit_cast(bf16x8, rbf[buf][PB[q]][j]),
-                                                                        acc[i][j], 0, 0, 0);
-#pragma unroll
-                    for (int pc = 0; pc < NP; ++pc) {
-                        if (slot == (pc * NM) / NP) {
-                            if (pc < NB) load_b(OTHER, pc, mc + XBK);
-                            else if (pc < NB + 2) load_a(SET, pc - NB, mc + 2 * XBK);
-                            else stage_a(OTHER, buf ^ 1, pc - NB - 2);
-                        }
-                    }
-                    ++slot;
-                    __builtin_amdgcn_sched_barrier(0);
-                }
         __syncthreads();
     };
     for (int mc = m_begin; mc < m_end; mc += 2 * XBK) {         // chunks come in pairs: one past m_end is all zeros
@@ -1281,16 +902,6 @@ int dsf_conv_x6_split_weights_multi(const int64_t* jobs, int n_jobs, int64_t tot
     return dsf_launch_status();
 }
 
-// DSF_X6_SCHED (A/B): bit 0 = backward-weights kernels, bit 1 = forward-type igemm_x6b_kernel take the group-barrier loader
-// spread (SCHED = 1 instantiations); bit 2 = the staged backward-weights kernel with its loader cut into one step per MFMA gap
-// (SCHED = 2); 0 = the piece-per-gap placement everywhere
-static int x6_sched_mask() {
-    static const int v = [] { const char* e = getenv("DSF_X6_SCHED"); return e ? atoi(e) : 1; }();
-    return v;
-}
-static int x6_sched() { return x6_sched_mask() & 1; }
-static int x6_sched_fwd() { return x6_sched_mask() & 2; }
-
 // Ci / Co are the reduction / output channel counts of the IMAGE (mode 1: those of the backward-data GEMM).
 static int x6_forward_impl(const float* X, const void* image, const float* bias, float* Y, int B, int Hi, int Wi, int Ci, int Ho,
                            int Wo, int Co, int KH, int KW, int stride, int dil, int pad_h, int pad_w, int k_splits,
@@ -1340,11 +951,9 @@ static int x6_forward_impl(const float* X, const void* image, const float* bias,
 #define DSF_LAUNCH_X6(KERNEL, BNv, DILv, BMv) hipLaunchKernelGGL((KERNEL<BNv, DILv, BMv>), grid, dim3(256), 0, (hipStream_t)stream, \
                                                        X, (const uint4*)image, bias, Y, p, m_tiles, n_tiles, k_splits,              \
                                                        (uint32_t)x_bytes, (uint32_t)w_bytes)
-#define DSF_LAUNCH_X6B(BNv, DILv, BMv) do { if (x6_sched_fwd())                                                                      \
-        hipLaunchKernelGGL((igemm_x6b_kernel<BNv, DILv, BMv, 1>), grid, dim3(256), 0, (hipStream_t)stream, X, (const uint4*)image, bias, \
-                           Y, p, m_tiles, n_tiles, k_splits, (uint32_t)x_bytes, (uint32_t)w_bytes, stats, ep);                            \
-    else hipLaunchKernelGGL((igemm_x6b_kernel<BNv, DILv, BMv, 0>), grid, dim3(256), 0, (hipStream_t)stream, X, (const uint4*)image,      \
-                            bias, Y, p, m_tiles, n_tiles, k_splits, (uint32_t)x_bytes, (uint32_t)w_bytes, stats, ep); } while (0)
+#define DSF_LAUNCH_X6B(BNv, DILv, BMv) hipLaunchKernelGGL((igemm_x6b_kernel<BNv, DILv, BMv>), grid, dim3(256), 0, (hipStream_t)stream, \
+                                                       X, (const uint4*)image, bias, Y, p, m_tiles, n_tiles, k_splits,              \
+                                                       (uint32_t)x_bytes, (uint32_t)w_bytes, stats, ep)
     // 64-row tiles with several n tiles (16x16x256, 8x8x512 maps): every wave of the many small tiles would pull its own copy of
     // the weight block from L2 -- the LDS-staged kernel is faster there (measured 136 / 139 vs 133 / 133 TFLOP/s)
     const bool direct = bdirect && !(bmt == 64 && n_tiles >= 2);
@@ -1424,27 +1033,6 @@ int dsf_conv_x6_forward_affine(const float* X, const void* image, const float* b
                            X6Ep{scale, shift, residual, relu, 0}, applied, stream);
 }
 
-// bytes of the dY image igemm_wrw_x6b_kernel reads (x6_split_dy_kernel writes it): ceil(M / 16) chunks x n tiles x 3 planes
-// x 2 BN granules of 16 bytes (0: no image possible).  Whether a layer SHOULD take the image path: dsf_conv_x6_wrw_prefers_direct.
-int64_t dsf_conv_x6_wrw_image_bytes(int B, int Ho, int Wo, int Co) {
-    const int64_t M = (int64_t)B * Ho * Wo;
-    if (M < 64 || Co < 4) return 0;
-    const int bn = x6_bn(Co);
-    const int64_t bytes = ((M + XBK - 1) / XBK) * ((Co + bn - 1) / bn) * (int64_t)(6 * bn * 16);
-    return bytes < 0xFFFFFFF0ll ? bytes : 0;                              // (32-bit buffer offsets)
-}
-
-// The image pass costs 10 bytes of traffic per dY element and a launch; the kernel behind it saves the dY half of the loader
-// work once per 128 k rows.  Measured at B = 32 (tools/wrw_ab.py): it wins where >= 16 k tiles share the image and the pixel
-// count is large (488->256 at 64x64: 1619 -> 1507 us; 256->256 k4 s2: 401 -> 360; 256->64 at 64x64: 287 -> 263) and loses on
-// the short reductions (64->256 3x3: 224 -> 258 us; every 8x8 .. 32x32 map: +1 .. +12 %; 1x1 layers: +26 .. +96 %).
-int dsf_conv_x6_wrw_prefers_direct(int B, int Ho, int Wo, int Ci, int Co, int KH, int KW) {
-    static const int direct = [] { const char* e = getenv("DSF_X6_WRW_DIRECT"); return e ? atoi(e) : 1; }();   // 0 never, 2 always (A/B)
-    if (!direct || dsf_conv_x6_wrw_image_bytes(B, Ho, Wo, Co) == 0) return 0;
-    if (direct == 2) return 1;
-    return ((int64_t)KH * KW * Ci + 127) / 128 >= 16 && (int64_t)B * Ho * Wo >= 32768;
-}
-
 int64_t dsf_conv_x6_wrw_workspace_bytes(int B, int Ho, int Wo, int Ci, int Co, int KH, int KW) {
     if (!dsf_deterministic() || B <= 0) return 0;
     int k_tiles, n_tiles; int64_t per;
@@ -1452,26 +1040,8 @@ int64_t dsf_conv_x6_wrw_workspace_bytes(int B, int Ho, int Wo, int Ci, int Co, i
     return (int64_t)splits * KH * KW * Ci * Co * 4;
 }
 
-static int x6_wrw_impl(const float* X, const float* dY, float* dW, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
-                       int KW, int stride, int pad_h, int pad_w, int accumulate, float* workspace, void* dy_image, dsf_stream_t stream);
-
 int dsf_conv_x6_wrw_ws(const float* X, const float* dY, float* dW, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
                        int KW, int stride, int pad_h, int pad_w, int accumulate, float* workspace, dsf_stream_t stream) {
-    return x6_wrw_impl(X, dY, dW, B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad_h, pad_w, accumulate, workspace, nullptr, stream);
-}
-
-// dsf_conv_x6_wrw_ws with the dY operand pre-split into `dy_image` (dsf_conv_x6_wrw_image_bytes(...) bytes of scratch, written by
-// this call): two launches, x6_split_dy_kernel + igemm_wrw_x6b_kernel.  Same results as dsf_conv_x6_wrw_ws up to the order of
-// the float atomics (bitwise the same in deterministic mode: identical products, identical per-split sums).
-int dsf_conv_x6_wrw_direct(const float* X, const float* dY, float* dW, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
-                           int KW, int stride, int pad_h, int pad_w, int accumulate, float* workspace, void* dy_image,
-                           dsf_stream_t stream) {
-    DSF_CHECK_ARG(dy_image && dsf_conv_x6_wrw_image_bytes(B, Ho, Wo, Co) > 0);
-    return x6_wrw_impl(X, dY, dW, B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad_h, pad_w, accumulate, workspace, dy_image, stream);
-}
-
-static int x6_wrw_impl(const float* X, const float* dY, float* dW, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
-                       int KW, int stride, int pad_h, int pad_w, int accumulate, float* workspace, void* dy_image, dsf_stream_t stream) {
     DSF_CHECK_ARG(X && dY && dW && B >= 0 && Hi > 0 && Wi > 0 && Ci > 0 && Ho > 0 && Wo > 0 && Co > 0 && KH > 0 && KW > 0);
     DSF_CHECK_ARG(stride >= 1 && (Ci & 3) == 0 && (Co & 3) == 0);
     const int K = KH * KW * Ci;
@@ -1489,46 +1059,7 @@ static int x6_wrw_impl(const float* X, const float* dY, float* dW, int B, int Hi
     const int splits = x6_wrw_plan(B, Ho, Wo, Ci, Co, KH, KW, k_tiles, n_tiles, per);
     const uint64_t mwo = ((1ull << 40) + Wo - 1) / Wo, mho = ((1ull << 40) + Ho - 1) / Ho;
     float* partial = det ? workspace : nullptr;
-    if (dy_image) {
-        const int64_t img_bytes = dsf_conv_x6_wrw_image_bytes(B, Ho, Wo, Co);
-        const int chunks = (int)((M + XBK - 1) / XBK);
-        if (bn == 128) {
-            hipLaunchKernelGGL(x6_split_dy_kernel<128>, dim3(chunks * n_tiles), dim3(256), 0, (hipStream_t)stream, dY, (uint4*)dy_image,
-                               (int)M, Co, n_tiles);
-            if (x6_sched())
-                hipLaunchKernelGGL((igemm_wrw_x6b_kernel<128, 1>), dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream, X,
-                                   (const uint4*)dy_image, dW, p, k_tiles, n_tiles, splits, (int)per, mwo, mho, (uint32_t)x_bytes,
-                                   (uint32_t)img_bytes, partial);
-            else
-                hipLaunchKernelGGL((igemm_wrw_x6b_kernel<128, 0>), dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream, X,
-                                   (const uint4*)dy_image, dW, p, k_tiles, n_tiles, splits, (int)per, mwo, mho, (uint32_t)x_bytes,
-                                   (uint32_t)img_bytes, partial);
-        } else {
-            hipLaunchKernelGGL(x6_split_dy_kernel<64>, dim3(chunks * n_tiles), dim3(128), 0, (hipStream_t)stream, dY, (uint4*)dy_image,
-                               (int)M, Co, n_tiles);
-            if (x6_sched())
-                hipLaunchKernelGGL((igemm_wrw_x6b_kernel<64, 1>), dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream, X,
-                                   (const uint4*)dy_image, dW, p, k_tiles, n_tiles, splits, (int)per, mwo, mho, (uint32_t)x_bytes,
-                                   (uint32_t)img_bytes, partial);
-            else
-                hipLaunchKernelGGL((igemm_wrw_x6b_kernel<64, 0>), dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream, X,
-                                   (const uint4*)dy_image, dW, p, k_tiles, n_tiles, splits, (int)per, mwo, mho, (uint32_t)x_bytes,
-                                   (uint32_t)img_bytes, partial);
-        }
-    } else if (x6_sched_mask() & 4) {                                     // step-per-gap loader (SCHED 2)
-        if (bn == 128)
-            hipLaunchKernelGGL((igemm_wrw_x6_kernel<128, 2>), dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream, X, dY,
-                               dW, p, k_tiles, n_tiles, splits, (int)per, mwo, mho, (uint32_t)x_bytes, (uint32_t)dy_bytes, partial);
-        else
-            hipLaunchKernelGGL((igemm_wrw_x6_kernel<64, 2>), dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream, X, dY,
-                               dW, p, k_tiles, n_tiles, splits, (int)per, mwo, mho, (uint32_t)x_bytes, (uint32_t)dy_bytes, partial);
-    } else if (x6_sched() && bn == 128)
-        hipLaunchKernelGGL((igemm_wrw_x6_kernel<128, 1>), dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream, X, dY,
-                           dW, p, k_tiles, n_tiles, splits, (int)per, mwo, mho, (uint32_t)x_bytes, (uint32_t)dy_bytes, partial);
-    else if (x6_sched())
-        hipLaunchKernelGGL((igemm_wrw_x6_kernel<64, 1>), dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream, X, dY,
-                           dW, p, k_tiles, n_tiles, splits, (int)per, mwo, mho, (uint32_t)x_bytes, (uint32_t)dy_bytes, partial);
-    else if (bn == 128)
+    if (bn == 128)
         hipLaunchKernelGGL(igemm_wrw_x6_kernel<128>, dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream, X, dY,
                            dW, p, k_tiles, n_tiles, splits, (int)per, mwo, mho, (uint32_t)x_bytes, (uint32_t)dy_bytes, partial);
     else

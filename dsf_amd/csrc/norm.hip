@@ -254,9 +254,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ beta, const double* __restrict__ acc,
                                                            int64_t M, int64_t n4, int C, int relu, float* __restrict__ dx,
                                                            float* __restrict__ dres, const float* __restrict__ rows, int n_rows,
-                                                           BnFinal fin) {
+                                                           BnFinal fin, const double* __restrict__ count) {
+    // count != nullptr: the divisor is the element count of the WHOLE (cross-replica) batch, read from device memory
     const int c4n = C >> 2;
-    const float invM = 1.0f / (float)M;
+    const float invM = count ? (float)(1.0 / count[0]) : 1.0f / (float)M;
     const int64_t i0 = blockIdx.x * (int64_t)256 + threadIdx.x;
     const int c = (int)(i0 % c4n) * 4;
     float mu[4], is[4], sg[4], sgx[4], gi[4], sc[4], sh[4];
@@ -486,7 +487,7 @@ extern "C" int dsf_bn_backward(const float* x, const float* grad_y, const float*
     hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(256), 0, st, bn_ws_part(workspace, C), wgs, M, C, fin);
     const int64_t n4 = M * (C >> 2);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(bn_apply_grid(n4, C)), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd,
-                       gamma, beta, workspace, M, n4, C, relu, grad_x, grad_residual, nullptr, 0, fin);
+                       gamma, beta, workspace, M, n4, C, relu, grad_x, grad_residual, nullptr, 0, fin, nullptr);
     return dsf_launch_status();
 }
 
@@ -535,7 +536,85 @@ extern "C" int dsf_bn_backward_acc(const float* x, const float* grad_y, const fl
                        M, C, relu, rows, acc, BN_ACC_ROWS);
     const int64_t n4 = M * (C >> 2);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(bn_apply_grid(n4, C)), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd,
-                       gamma, beta, nullptr, M, n4, C, relu, grad_x, grad_residual, acc, BN_ACC_ROWS, fin);
+                       gamma, beta, nullptr, M, n4, C, relu, grad_x, grad_residual, acc, BN_ACC_ROWS, fin, nullptr);
+    return dsf_launch_status();
+}
+
+// ---- cross-replica BatchNorm (SyncBatchNorm): ONE exchange of 2C + 1 doubles per layer and pass -------------
+// forward: dsf_bn_local_sums -> the caller all-reduces [sum x | sum x^2 | count] -> dsf_bn_forward_from_sums;
+// backward: dsf_bn_backward_sums -> all-reduce of [sum g | sum g xhat] -> dsf_bn_backward_apply with the global count.
+// mean / invstd / running statistics from GLOBAL sums (sums[0..C), sums[C..2C), count = sums[2C]); one thread per channel
+__global__ __launch_bounds__(256) void bn_stats_from_sums_kernel(const double* __restrict__ sums, int C, BnFinal fin) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double n = sums[2 * C];
+    const double m = sums[c] / n;
+    double var = sums[C + c] / n - m * m;
+    if (var < 0.0) var = 0.0;
+    fin.mean[c] = (float)m;
+    fin.invstd[c] = (float)(1.0 / sqrt(var + (double)fin.eps));
+    if (fin.running_mean) {
+        const double unbiased = (n > 1.0) ? var * n / (n - 1.0) : var;
+        fin.running_mean[c] = (1.f - fin.momentum) * fin.running_mean[c] + fin.momentum * (float)m;
+        fin.running_var[c] = (1.f - fin.momentum) * fin.running_var[c] + fin.momentum * (float)unbiased;
+    }
+}
+
+extern "C" int dsf_bn_local_sums(const float* x, int64_t M, int C, const float* part, int rows, double* sums, double* workspace,
+                                 dsf_stream_t stream) {
+    DSF_CHECK_ARG(x && sums && M > 0 && (part ? rows > 0 : workspace != nullptr));
+    if (!bn_shape_ok(C)) return DSF_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    BnFinal fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, sums, nullptr, nullptr};
+    if (!part) {                                                    // no epilogue rows: this call's own statistics pass
+        const int rpw = bn_rows_per_wg(M, C);
+        rows = (int)((M + rpw - 1) / rpw);
+        hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(rows, bn_col_blocks(C)), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr,
+                           nullptr, M, C, 0, rpw, bn_ws_part(workspace, C), 0);
+        part = bn_ws_part(workspace, C);
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(256), 0, st, part, rows, M, C, fin);   // MODE 1: the two sums as doubles
+    return dsf_launch_status();
+}
+
+extern "C" int dsf_bn_forward_from_sums(const float* x, const float* residual, const float* gamma, const float* beta, int64_t M, int C,
+                                        float eps, float momentum, int relu, float* running_mean, float* running_var, float* y,
+                                        float* save_mean, float* save_invstd, const double* sums, dsf_stream_t stream) {
+    DSF_CHECK_ARG(x && y && save_mean && save_invstd && sums && M > 0);
+    if (!bn_shape_ok(C)) return DSF_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    BnFinal fin = {eps, momentum, save_mean, save_invstd, running_mean, running_var, nullptr, nullptr, nullptr};
+    hipLaunchKernelGGL(bn_stats_from_sums_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, C, fin);
+    const int64_t n4 = M * (C >> 2);
+    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(bn_apply_grid(n4, C)), dim3(256), 0, st, x, residual, save_mean, save_invstd, gamma,
+                       beta, n4, C, relu, y, nullptr, 0, M, fin);
+    return dsf_launch_status();
+}
+
+extern "C" int dsf_bn_backward_sums(const float* x, const float* grad_y, const float* y, const float* gamma, const float* beta,
+                                    const float* save_mean, const float* save_invstd, int64_t M, int C, int relu, double* sums,
+                                    float* grad_gamma, float* grad_beta, double* workspace, dsf_stream_t stream) {
+    DSF_CHECK_ARG(x && grad_y && save_mean && save_invstd && sums && workspace && M > 0 && relu >= 0 && relu <= 2 && (relu != 1 || y));
+    if (!bn_shape_ok(C)) return DSF_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int rows = bn_rows_per_wg(M, C);
+    const int wgs = (int)((M + rows - 1) / rows);
+    BnFinal fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, sums, grad_gamma, grad_beta};      // dgamma / dbeta: this replica's share
+    hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(wgs, bn_col_blocks(C)), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd, gamma, beta,
+                       M, C, relu, rows, bn_ws_part(workspace, C), 0);
+    hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(256), 0, st, bn_ws_part(workspace, C), wgs, M, C, fin);
+    return dsf_launch_status();
+}
+
+extern "C" int dsf_bn_backward_apply(const float* x, const float* grad_y, const float* y, const float* gamma, const float* beta,
+                                     const float* save_mean, const float* save_invstd, const double* sums, const double* count,
+                                     int64_t M, int C, int relu, float* grad_x, float* grad_residual, dsf_stream_t stream) {
+    DSF_CHECK_ARG(x && grad_y && save_mean && save_invstd && sums && count && grad_x && M > 0 && relu >= 0 && relu <= 2 && (relu != 1 || y));
+    if (!bn_shape_ok(C)) return DSF_ERR_UNSUPPORTED;
+    BnFinal fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const int64_t n4 = M * (C >> 2);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(bn_apply_grid(n4, C)), dim3(256), 0, (hipStream_t)stream, x, grad_y, y, save_mean,
+                       save_invstd, gamma, beta, sums, M, n4, C, relu, grad_x, grad_residual, nullptr, 0, fin, count);
     return dsf_launch_status();
 }
 

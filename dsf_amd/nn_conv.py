@@ -227,17 +227,6 @@ def _wrw_c1(x, gy, K, stride, pad):
     return dw
 
 
-# backward-weights through the dY image (x6_split_dy_kernel + igemm_wrw_x6b_kernel, conv_x6.hip): None = where the library's
-# heuristic says it pays (dsf_conv_x6_wrw_prefers_direct), True / False = always / never (A/B tools)
-WRW_DIRECT = [None]
-
-
-def _wrw_direct(B, Ho, Wo, Ci, Co, KH, KW):
-    if WRW_DIRECT[0] is None:
-        return bool(L.lib().dsf_conv_x6_wrw_prefers_direct(I(B), I(Ho), I(Wo), I(Ci), I(Co), I(KH), I(KW)))
-    return bool(WRW_DIRECT[0]) and int(L.lib().dsf_conv_x6_wrw_image_bytes(I(B), I(Ho), I(Wo), I(Co))) > 0
-
-
 def _wrw(x, gy, KH, KW, stride, pad, out=None):
     """-> dW [KH][KW][Ci][Co] for x (B,Ci,Hi,Wi), gy (B,Co,Ho,Wo), both channels_last; ``out``: add into this dW instead."""
     B, Ci, Hi, Wi = x.shape
@@ -251,14 +240,6 @@ def _wrw(x, gy, KH, KW, stride, pad, out=None):
     if _wrw_x6_ok(Ci, Co, x.numel(), gy.numel()):
         nws = int(L.lib().dsf_conv_x6_wrw_workspace_bytes(I(B), I(Ho), I(Wo), I(Ci), I(Co), I(KH), I(KW)))    # > 0: deterministic mode
         ws = torch.empty(nws // 4, device=x.device, dtype=torch.float32) if nws else None
-        nimg = int(L.lib().dsf_conv_x6_wrw_image_bytes(I(B), I(Ho), I(Wo), I(Co))) if _wrw_direct(B, Ho, Wo, Ci, Co, KH, KW) else 0
-        if nimg:
-            # dY split once into an MFMA-fragment image (scratch of this call; stream-ordered reuse by the caching allocator)
-            img = torch.empty(nimg, device=x.device, dtype=torch.uint8)
-            check(L.lib().dsf_conv_x6_wrw_direct(ptr_nhwc(x), ptr_nhwc(gy), ptr(dw), I(B), I(Hi), I(Wi), I(Ci), I(Ho), I(Wo), I(Co),
-                                                 I(KH), I(KW), I(stride), I(pad[0]), I(pad[1]), I(1 if pooled else 0), ptr(ws),
-                                                 ptr(img), stream_ptr()), "dsf_conv_x6_wrw_direct")
-            return dw
         check(L.lib().dsf_conv_x6_wrw_ws(ptr_nhwc(x), ptr_nhwc(gy), ptr(dw), I(B), I(Hi), I(Wi), I(Ci), I(Ho), I(Wo), I(Co), I(KH),
                                          I(KW), I(stride), I(pad[0]), I(pad[1]), I(1 if pooled else 0), ptr(ws), stream_ptr()),
               "dsf_conv_x6_wrw_ws")
@@ -783,8 +764,7 @@ def kernel_name(rec):
             return "igemm_fwd_dil2_kernel<%d, %d, %s>" % (bn, 16 if (tiles >= 1024 and bn == 128) else 32, wt)
         return "igemm_fwd_kernel<%d, %s>" % (bn, "true" if (Ci < 32 and dil == 1) else "false")
     if _wrw_x6_ok(Ci, Co, B * Hi * Wi * Ci, M * Co):
-        direct = _wrw_direct(B, Ho, Wo, Ci, Co, rec[8], rec[9])
-        return "igemm_wrw_x6%s_kernel<%d>" % ("b" if direct else "", 128 if Co > 64 else 64)
+        return "igemm_wrw_x6_kernel<%d>" % (128 if Co > 64 else 64)
     if vec:
         return "igemm_wrw_fast_kernel<%d, %d>" % (bn, 16 if M >= 32768 else 32)
     return "igemm_wrw_kernel<%d>" % bn

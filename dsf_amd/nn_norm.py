@@ -219,7 +219,7 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
                 mom = self.momentum
                 rm = self.running_mean if (self.training and self.track_running_stats) else None
                 rv = self.running_var if (self.training and self.track_running_stats) else None
-                if stats is not None and stats[0] == "acc":
+                if stats is not None and isinstance(stats[0], str):            # ("acc", rows block, filled)
                     return _BNFunction.apply(x, residual, self.weight, self.bias, rm, rv, self.eps, mom, relu, None, 0, stats[1], stats[2])
                 part, rows = stats if stats is not None else (None, 0)
                 if part is None:
@@ -248,6 +248,83 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
         if residual is not None:
             y = y + residual
         return F.relu(y) if relu else y
+
+
+class _SyncBNFunction(Function):
+    """Training-mode BatchNorm (+ residual)(+ ReLU) over the batch of EVERY rank of ``group``: one all-reduce of 2C + 1
+    doubles in the forward pass (per-channel sum, sum of squares, element count) and one of 2C doubles in the backward
+    pass (sum g, sum g xhat) -- torch.nn.SyncBatchNorm's arithmetic (global mean / biased variance for the normalisation,
+    unbiased global variance into the running buffers, local dgamma / dbeta) on the fused HIP passes."""
+
+    @staticmethod
+    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, eps, momentum, relu, group, part=None, rows=0):
+        import torch.distributed as dist
+        x = x.contiguous(memory_format=CL)
+        if residual is not None:
+            residual = residual.contiguous(memory_format=CL)
+        B, C, H, W = x.shape
+        M = B * H * W
+        sums = torch.empty(2 * C + 1, device=x.device, dtype=torch.float64)
+        sums[2 * C:].fill_(float(M))
+        ws = _workspace(x.device, C)
+        check(L.lib().dsf_bn_local_sums(_p(x), I64(M), I(C), _p(part) if (part is not None and rows > 0) else None,
+                                        I(int(rows) if part is not None else 0), _p(sums), _p(ws), stream_ptr()), "dsf_bn_local_sums")
+        dist.all_reduce(sums, group=group)
+        y = torch.empty_like(x, memory_format=CL)
+        mean = torch.empty(C, device=x.device, dtype=torch.float32)
+        invstd = torch.empty(C, device=x.device, dtype=torch.float32)
+        check(L.lib().dsf_bn_forward_from_sums(_p(x), _p(residual), _p(gamma), _p(beta), I64(M), I(C), CF(eps), CF(momentum),
+                                               I(int(relu)), _p(running_mean), _p(running_var), _p(y), _p(mean), _p(invstd),
+                                               _p(sums), stream_ptr()), "dsf_bn_forward_from_sums")
+        ctx.save_for_backward(x, y if (relu and residual is not None) else None, gamma, beta, mean, invstd, sums)
+        ctx.cfg = (relu, residual is not None, gamma is not None, beta is not None, group)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        import torch.distributed as dist
+        x, y, gamma, beta, mean, invstd, sums = ctx.saved_tensors
+        relu, has_res, has_g, has_b, group = ctx.cfg
+        relu_mode = 0 if not relu else (1 if has_res else 2)
+        gy = gy.contiguous(memory_format=CL)
+        B, C, H, W = x.shape
+        M = B * H * W
+        gx = torch.empty_like(x, memory_format=CL)
+        gres = torch.empty_like(x, memory_format=CL) if has_res else None
+        gg = torch.empty(C, device=x.device, dtype=torch.float32) if has_g else None
+        gb = torch.empty(C, device=x.device, dtype=torch.float32) if has_b else None
+        gs = torch.empty(2 * C, device=x.device, dtype=torch.float64)
+        ws = _workspace(x.device, C)
+        check(L.lib().dsf_bn_backward_sums(_p(x), _p(gy), _p(y), _p(gamma), _p(beta), _p(mean), _p(invstd), I64(M), I(C), I(relu_mode),
+                                           _p(gs), _p(gg), _p(gb), _p(ws), stream_ptr()), "dsf_bn_backward_sums")
+        dist.all_reduce(gs, group=group)
+        count = sums[2 * C:]                                   # global element count, on the device
+        check(L.lib().dsf_bn_backward_apply(_p(x), _p(gy), _p(y), _p(gamma), _p(beta), _p(mean), _p(invstd), _p(gs), _p(count), I64(M),
+                                            I(C), I(relu_mode), _p(gx), _p(gres), stream_ptr()), "dsf_bn_backward_apply")
+        return gx, gres, gg, gb, None, None, None, None, None, None, None, None
+
+
+class FusedSyncBatchNorm2d(FusedBatchNorm2d):
+    """FusedBatchNorm2d whose TRAINING statistics are those of the global batch (all ranks of ``process_group``): the
+    drop-in for ``torch.nn.SyncBatchNorm`` on the fused HIP passes -- same parameters, buffers and state-dict keys, same
+    ``forward(x, residual=None, relu=None, stats=None)`` as the module it replaces (parallel.convert_sync_batchnorm swaps the
+    class in place).  Single-rank groups and evaluation mode fall through to FusedBatchNorm2d."""
+    process_group = None
+
+    def forward(self, x, residual=None, relu=None, stats=None):
+        import torch.distributed as dist
+        world = dist.get_world_size(self.process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        if not (self.training and self.track_running_stats and world > 1 and x.is_cuda and x.dtype == torch.float32 and
+                supported(x.shape[1]) and x.numel() > 0 and self.momentum is not None):
+            return super().forward(x, residual, relu, stats)
+        relu = self.fuse_relu if relu is None else relu
+        if self._buffers.get("num_batches_tracked") is not None:
+            self._pending_batches += 1
+        self.__dict__["_stats_epoch"] = self.__dict__.get("_stats_epoch", 0) + 1
+        part, rows = (stats if (stats is not None and not isinstance(stats[0], str)) else (None, 0))
+        return _SyncBNFunction.apply(x, residual, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
+                                     self.momentum, relu, self.process_group, part, rows)
 
 
 def bn_act(bn, x, residual=None, relu=False):
@@ -289,7 +366,8 @@ def conv_bn_act(conv, bn, x, residual=None, relu=None):
     if not fusable:
         return bn_act(bn, conv(x), residual, relu if relu is not None else getattr(bn, "fuse_relu", False))
     req = nn_conv.StatsRequest()
-    req.acc = _acc_take(bn.num_features, x.device)       # finalise-free path: the epilogue adds into these zeroed rows
+    # finalise-free path: the epilogue adds into these zeroed rows (a cross-replica BatchNorm exchanges ordered partial rows instead)
+    req.acc = None if isinstance(bn, FusedSyncBatchNorm2d) else _acc_take(bn.num_features, x.device)
     nn_conv.STATS = req
     try:
         y = conv(x)

@@ -143,6 +143,17 @@ class GradAllReducer:
         self._missing[b] = missing
         self._work[b] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
+    def reduce_now(self):
+        """Packs and all-reduces EVERY bucket from the gradients as they stand, then ``finish()``: for steps whose backward
+        pass did not run the hooks -- train_step.GraphedStep replays forward + backward from a HIP graph (captured with
+        ``enabled = False``) and calls this before the optimizer.  Nothing overlaps with the backward pass here; what the graph
+        buys instead is the host time of ~700-1500 launches per step (the regime of the small-batch / many-rank runs)."""
+        if self.world > 1 and self.enabled:
+            self._reset()
+            for b in range(len(self.buckets)):
+                self._launch(b)
+        self.finish()
+
     def finish(self):
         """Call after backward, before optimizer.step()."""
         if self.world > 1 and self.enabled:
@@ -175,33 +186,15 @@ def all_reduce_mean_pair(total, count, group=None):
     return total / (count + 1e-8)
 
 
-class _SyncBNAct(torch.nn.SyncBatchNorm):
-    """SyncBatchNorm standing in for a FusedBatchNorm2d: keeps the fused module's call signature
-    (``forward(x, residual=None, relu=None)``) so blocks that pass the skip connection / ReLU flag keep working."""
-    fuse_relu = False
-
-    def forward(self, x, residual=None, relu=None):
-        y = super().forward(x)
-        if residual is not None:
-            y = y + residual
-        return torch.relu(y) if (self.fuse_relu if relu is None else relu) else y
-
-
-def convert_sync_batchnorm(net):
-    """Optional: global-batch BN statistics (per-replica statistics are the default).  Fused BN(+add+ReLU)
-    modules become a SyncBatchNorm that still applies their residual add / ReLU; parameters, buffers and keys carry over."""
-    from .nn_norm import FusedBatchNorm2d
-    fused = {name: m for name, m in net.named_modules() if isinstance(m, FusedBatchNorm2d)}
-    for m in fused.values():
-        m.flush_batch_counter()
-    net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)
-    for name, old in fused.items():
-        parent = net
-        *path, leaf = name.split(".")
-        for p in path:
-            parent = getattr(parent, p)
-        new = getattr(parent, leaf)
-        if isinstance(new, torch.nn.SyncBatchNorm):
-            new.__class__ = _SyncBNAct
-            new.fuse_relu = old.fuse_relu
-    return net
+def convert_sync_batchnorm(net, process_group=None):
+    """Optional: global-batch BN statistics (per-replica statistics are the default).  Every fused BN(+add+ReLU)
+    module becomes a ``nn_norm.FusedSyncBatchNorm2d`` IN PLACE (same parameters, buffers, keys and call signature): its
+    statistics cross the ranks as ONE all-reduce of 2C + 1 doubles per layer and pass and feed the same fused HIP apply kernels
+    (round 2 fell back to torch.nn.SyncBatchNorm's own kernels and per-layer gathers).  Plain ``torch.nn.BatchNorm*`` modules,
+    if any, are converted by torch."""
+    from .nn_norm import FusedBatchNorm2d, FusedSyncBatchNorm2d
+    for m in net.modules():
+        if isinstance(m, FusedBatchNorm2d) and not isinstance(m, FusedSyncBatchNorm2d):
+            m.__class__ = FusedSyncBatchNorm2d
+            m.process_group = process_group
+    return torch.nn.SyncBatchNorm.convert_sync_batchnorm(net, process_group)

@@ -240,7 +240,8 @@ class GraphedStep:
     kernels run on the same data in the same order -- results are those of the eager step (tests/test_gpu_steps.py).
     Building the wrapper does not train: the warm-up and validation passes run forward + backward only and restore the
     BatchNorm running statistics.  What stays eager, after each replay: the optimizer step, whose learning rate, bias corrections and per-parameter step
-    counts are host state that changes from step to step.  Single-GPU (a step with a gradient all-reducer is refused).
+    counts are host state that changes from step to step -- and, with a GradAllReducer, the bucketed gradient all-reduce
+    (launched after the replay, not overlapped with the backward pass).
     Requirements, as for any stream capture: static shapes (one graph per batch shape), no host decision inside the step
     (the occluder count of ``FinetuneStageStep`` is one -- that step is not graphable), batches are COPIED into the static
     input buffers the graph reads.  The reference has no counterpart (PyTorch eager, train_render.py:636-823)."""
@@ -248,9 +249,15 @@ class GraphedStep:
     def __init__(self, step, tgt, warmup=2, validate=True):
         if not torch.cuda.is_available():
             raise RuntimeError("GraphedStep needs the GPU (HIP graph capture)")
-        if getattr(step, "grad_sync", None) is not None:
-            raise RuntimeError("GraphedStep is single-GPU: the bucketed gradient all-reduce is launched from autograd hooks "
-                               "inside the backward pass the graph would replace")
+        # data parallel: the graph holds forward + backward only (captured with the reducer's hooks switched off); the bucket
+        # all-reduces are launched eagerly after each replay (GradAllReducer.reduce_now), then the optimizer
+        self.sync = getattr(step, "grad_sync", None)
+        if self.sync is not None:
+            self.sync.enabled = False
+            from .nn_norm import FusedSyncBatchNorm2d
+            if any(isinstance(m, FusedSyncBatchNorm2d) for m in step.net.modules()):
+                raise RuntimeError("GraphedStep: a cross-replica BatchNorm all-reduces inside the forward pass; collectives are "
+                                   "not captured -- run this step eagerly")
         if not hasattr(step, "forward_backward"):
             raise TypeError("GraphedStep needs a step with forward_backward(tgt) (RenderSupervisedStep, MeshLossStep); the "
                             "steps that draw their occluder count on the host cannot be captured")
@@ -348,6 +355,14 @@ class GraphedStep:
         for m, n in zip(self._bns, self._bn_calls):
             m._pending_batches += n
             m.__dict__["_stats_epoch"] = m.__dict__.get("_stats_epoch", 0) + 1        # the replay rewrote the running statistics
+        if self.sync is not None:
+            for p, g in self._grads:
+                p.grad = g                                  # the tensors the graph wrote (finish() rebinds .grad to bucket views)
+            self.sync.enabled = True
+            try:
+                self.sync.reduce_now()
+            finally:
+                self.sync.enabled = False
         self.step.opt.step()
         return self.loss, self.terms
 

@@ -462,6 +462,26 @@ int dsf_bn_forward_from_stats(const float* x, const float* residual, const float
  * dsf_bn_forward / dsf_bn_forward_from_stats / dsf_bn_backward, which are bit-reproducible).
  * ---------------------------------------------------------------------------------- */
 int dsf_bn_acc_rows(void);
+/* Cross-replica BatchNorm (torch.nn.SyncBatchNorm semantics; the reference trains on one GPU, SURVEY 8e offers it for
+ * data-parallel runs): the statistics of a layer cross the ranks ONCE per pass as 2C + 1 doubles instead of torch's
+ * per-layer gather of means / invstds / counts.  Forward: dsf_bn_local_sums (sums[0..C) = sum x, sums[C..2C) = sum x^2 of
+ * this replica -- from the producing convolution's epilogue rows `part` (dsf_conv_x6_forward_bn) or, part == NULL, from its own
+ * reduction pass over x) -> the caller writes its row count to sums[2C] and all-reduces the 2C + 1 doubles ->
+ * dsf_bn_forward_from_sums (mean / invstd / running statistics from the GLOBAL sums, then the apply pass).  Backward:
+ * dsf_bn_backward_sums (sum g, sum g xhat of this replica; grad_gamma / grad_beta are the replica's own share, averaged
+ * later with every other gradient) -> all-reduce of 2C doubles -> dsf_bn_backward_apply with `count` = the device address
+ * of the global element count (sums[2C] of the forward).  No host synchronisation anywhere. */
+int dsf_bn_local_sums(const float* x, int64_t M, int C, const float* part, int rows, double* sums, double* workspace,
+                      dsf_stream_t stream);
+int dsf_bn_forward_from_sums(const float* x, const float* residual, const float* gamma, const float* beta, int64_t M, int C,
+                             float eps, float momentum, int relu, float* running_mean, float* running_var, float* y,
+                             float* save_mean, float* save_invstd, const double* sums, dsf_stream_t stream);
+int dsf_bn_backward_sums(const float* x, const float* grad_y, const float* y, const float* gamma, const float* beta,
+                         const float* save_mean, const float* save_invstd, int64_t M, int C, int relu, double* sums,
+                         float* grad_gamma, float* grad_beta, double* workspace, dsf_stream_t stream);
+int dsf_bn_backward_apply(const float* x, const float* grad_y, const float* y, const float* gamma, const float* beta,
+                          const float* save_mean, const float* save_invstd, const double* sums, const double* count, int64_t M,
+                          int C, int relu, float* grad_x, float* grad_residual, dsf_stream_t stream);
 int dsf_conv_x6_forward_bn_acc(const float* X, const void* image, float* Y, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
                                int KH, int KW, int stride, int dil, int pad_h, int pad_w, float* acc, int acc_rows, int* filled,
                                dsf_stream_t stream);
@@ -503,17 +523,6 @@ int dsf_get_deterministic(void);
 int64_t dsf_conv_x6_wrw_workspace_bytes(int B, int Ho, int Wo, int Ci, int Co, int KH, int KW);
 int dsf_conv_x6_wrw_ws(const float* X, const float* dY, float* dW, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
                        int KW, int stride, int pad_h, int pad_w, int accumulate, float* workspace, dsf_stream_t stream);
-/* Backward-weights with the dY operand pre-split ONCE into an image laid out as the MFMA fragment (round 3; replaces the
- * weight-gradient GEMM cuDNN runs for every nn.Conv2d of the reference's backbones, model/resnet.py, model/backbone.py): two
- * launches -- the image pass (4 bytes read, 6 written per dY element) and a kernel whose LDS carries the X tile only.
- * dy_image: dsf_conv_x6_wrw_image_bytes(B, Ho, Wo, Co) bytes of scratch (0 = shape not served: use dsf_conv_x6_wrw_ws);
- * dsf_conv_x6_wrw_prefers_direct tells for which layers it pays (long reductions shared by >= 16 k tiles);
- * workspace / accumulate / deterministic mode exactly as dsf_conv_x6_wrw_ws (same per-split sums, bitwise, in that mode). */
-int64_t dsf_conv_x6_wrw_image_bytes(int B, int Ho, int Wo, int Co);
-int dsf_conv_x6_wrw_prefers_direct(int B, int Ho, int Wo, int Ci, int Co, int KH, int KW);   /* 1: this layer is faster through the image */
-int dsf_conv_x6_wrw_direct(const float* X, const float* dY, float* dW, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
-                           int KW, int stride, int pad_h, int pad_w, int accumulate, float* workspace, void* dy_image,
-                           dsf_stream_t stream);
 
 /* ----------------------------------------------------------------------------------
  * NHWC max pooling (nn.MaxPool2d(kernel_size=3, stride=2, padding=1) of the backbone stem, reference

@@ -72,3 +72,128 @@ def test_two_ranks_on_one_gpu_stay_in_lockstep():
     assert np.array_equal(g0, g1)              # every rank applied the same (averaged) gradient ...
     assert np.array_equal(w0, w1)              # ... and holds the same parameters after two optimizer steps
     assert np.abs(g0).max() > 0
+
+
+def _bn_worker(rank, world, port, q):
+    """cross-replica BatchNorm: each rank holds half of a batch; outputs, input / parameter gradients and running statistics
+    must equal those of ONE process normalising the whole batch (plain FusedBatchNorm2d), conv-epilogue statistics included"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from dsf_amd.parallel import init_distributed, convert_sync_batchnorm
+    from dsf_amd import nn_conv, nn_norm
+    init_distributed("gloo")
+    torch.cuda.set_device(0)
+    out = {}
+    for tag, C, H, res in (("a", 64, 16, True), ("b", 256, 8, False)):
+        torch.manual_seed(5)
+        conv = nn_conv.Conv2d(32, C, 3, 1, 1, bias=False).cuda()
+        bn = nn_norm.FusedBatchNorm2d(C, momentum=0.1).cuda()
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.3, 0.3)
+        net = torch.nn.ModuleList([conv, bn])
+        convert_sync_batchnorm(net)
+        assert isinstance(net[1], nn_norm.FusedSyncBatchNorm2d) and list(net.state_dict().keys()) == ["0.weight", "1.weight", "1.bias", "1.running_mean", "1.running_var", "1.num_batches_tracked"]
+        g = torch.Generator().manual_seed(6)
+        x = torch.randn(8, 32, H, H, generator=g) + 0.3
+        r = torch.randn(8, C, H, H, generator=g) if res else None
+        wgt = torch.randn(8, C, H, H, generator=g)
+        sl = slice(rank * 4, rank * 4 + 4)
+        xs = x[sl].cuda().requires_grad_(True)
+        rs = r[sl].cuda().requires_grad_(True) if res else None
+        y = nn_norm.conv_bn_act(net[0], net[1], xs, residual=rs, relu=True)
+        (y * wgt[sl].cuda()).sum().backward()
+        torch.cuda.synchronize()
+        out[tag] = dict(y=y.detach().cpu().numpy(), gx=xs.grad.cpu().numpy(), gr=None if rs is None else rs.grad.cpu().numpy(),
+                        gw=conv.weight.grad.cpu().numpy(), gg=bn.weight.grad.cpu().numpy(), gb=bn.bias.grad.cpu().numpy(),
+                        rm=bn.running_mean.cpu().numpy(), rv=bn.running_var.cpu().numpy(), nbt=int(bn.num_batches_tracked))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fused_sync_batchnorm_two_ranks_equal_one_rank_on_the_whole_batch():
+    import torch.multiprocessing as mp
+    from dsf_amd import nn_conv, nn_norm
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bn_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+    for tag, C, H, has_res in (("a", 64, 16, True), ("b", 256, 8, False)):
+        torch.manual_seed(5)
+        conv = nn_conv.Conv2d(32, C, 3, 1, 1, bias=False).cuda()
+        bn = nn_norm.FusedBatchNorm2d(C, momentum=0.1).cuda()
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.3, 0.3)
+        g = torch.Generator().manual_seed(6)
+        x = torch.randn(8, 32, H, H, generator=g) + 0.3
+        r = torch.randn(8, C, H, H, generator=g) if has_res else None
+        wgt = torch.randn(8, C, H, H, generator=g)
+        xg = x.cuda().requires_grad_(True)
+        rg = r.cuda().requires_grad_(True) if has_res else None
+        y = nn_norm.conv_bn_act(conv, bn, xg, residual=rg, relu=True)
+        (y * wgt.cuda()).sum().backward()
+        for rank in (0, 1):
+            o, sl = res[rank][tag], slice(rank * 4, rank * 4 + 4)
+            assert rel(o["y"], y.detach().cpu().numpy()[sl]) < 1e-5
+            assert rel(o["gx"], xg.grad.cpu().numpy()[sl]) < 1e-4
+            if has_res:
+                assert rel(o["gr"], rg.grad.cpu().numpy()[sl]) < 1e-5
+            assert rel(o["rm"], bn.running_mean.cpu().numpy()) < 1e-5 and rel(o["rv"], bn.running_var.cpu().numpy()) < 1e-5
+            assert o["nbt"] == 1
+        # parameter gradients: each rank holds its own share; their sum is the whole batch's gradient
+        for k, full in (("gw", conv.weight.grad), ("gg", bn.weight.grad), ("gb", bn.bias.grad)):
+            assert rel(res[0][tag][k] + res[1][tag][k], full.cpu().numpy()) < 1e-4, k
+
+
+def _graph_worker(rank, world, port, q):
+    """GraphedStep under data parallelism: forward + backward replayed from a HIP graph, bucket all-reduces after each replay"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from dsf_amd.parallel import init_distributed, GradAllReducer
+    from dsf_amd.train_step import RenderSupervisedStep, GraphedStep, synthetic_batch, Config
+    from dsf_amd import _lib as L
+    init_distributed("gloo")
+    torch.cuda.set_device(0)
+    L.set_deterministic(True)
+    flats = []
+    for graphed in (False, True):
+        net, render = _build()
+        sync = GradAllReducer(net.parameters())
+        step = RenderSupervisedStep(net, render, Config, grad_sync=sync)
+        p, c, cube = synthetic_batch(3, "cuda", seed=10 + rank)
+        tgt = step.make_targets(p, c, cube, seed=20 + rank)
+        run = GraphedStep(step, tgt) if graphed else step
+        for it in range(3):
+            loss, _ = run(tgt)
+        torch.cuda.synchronize()
+        flats.append(torch.cat([pp.detach().reshape(-1).float().cpu() for pp in net.parameters()]).numpy())
+        for h in sync._hooks:
+            h.remove()
+    q.put((rank, flats[0], flats[1], float(loss)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_graphed_step_with_gradient_all_reduce_equals_the_eager_data_parallel_step():
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_graph_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, e0, g0, l0), (_, e1, g1, l1) = res
+    assert np.isfinite(l0) and np.isfinite(l1)
+    assert np.array_equal(e0, e1) and np.array_equal(g0, g1)       # ranks in lockstep, eager and graphed
+    assert np.array_equal(e0, g0)                                   # deterministic mode: the graphed trajectory IS the eager one

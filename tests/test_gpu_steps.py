@@ -269,8 +269,10 @@ def test_pretrain_and_config4_multiview_step_vs_oracle(render, orender, backbone
     p, _, cube = synthetic_batch(B, "cpu", seed=31)
     d = step.draw(B, "cpu", torch.Generator().manual_seed(32), np.random.default_rng(33))
     if frozen:
-        # the WELL-CONDITIONED two-stage ResNet-50 multi-view case: same net, same images, BatchNorm with frozen statistics --
-        # held to the strict bars (loss 2e-3, gradient cosine 0.9995) below
+        # the same case with FROZEN BatchNorm statistics.  Round 3 built it as the candidate "well-conditioned" two-stage ResNet-50
+        # case; it is not one: torch's own fp32 and fp64 CPU gradients still differ by 8.5 % (train mode 6.9 %, B = 8 x 3 11.4 %;
+        # DESIGN.md section 2) -- the batch statistics are not what makes this net's gradient sensitive, its ~110 ReLU / max-pool
+        # layers' discrete switches are.  It is therefore held to the float64-relative bar like the training-mode case.
         _freeze_statistics(net_cpu, net_gpu, orender, p, cube, d, views, gen_cpu)
     assert d["aug_view"].shape == (B * views, 3) and (views == 1) == bool((d["aug_view"] == 0).all())
     rec = _Recording(orender)
@@ -287,6 +289,7 @@ def test_pretrain_and_config4_multiview_step_vs_oracle(render, orender, backbone
         flips = _bridge_flips(net_cpu, net_gpu, orender, render, s_c["img_t"], s_c["center"], s_c["cube"])
         fg = int((rec.images[0] < 0.99).sum())
         assert flips <= max(2, fg // 100), (flips, fg)                  # a few silhouette pixels at most
+    pinned = None
     if flips:
         # the un-pinned step agrees as far as those pixels allow; the gradient comparison runs with the bridge image -- a
         # gradient-free input -- pinned to the oracle's
@@ -294,10 +297,15 @@ def test_pretrain_and_config4_multiview_step_vs_oracle(render, orender, backbone
         pinned = PretrainStep(net_gpu, _PinnedBridge(render, rec.images), gen_gpu, Config, views=views, optimizer=step.opt)
         loss_g, _ = pinned.loss(p.cuda(), cube.cuda(), draws_to(d, "cuda"))
     loss_g.backward()
-    if backbone.endswith("18") or not refine or frozen:
+    if backbone.endswith("18") or not refine:
         _compare(loss_c, loss_g, net_cpu, net_gpu)
     else:
-        # both fp32 paths against the float64 trunk (see the docstring)
+        # both fp32 paths against the float64 trunk (see the docstring).  Measured (round 3, tools/step_truth.py, DESIGN.md
+        # section 2): torch-CPU fp32 lands 0.069 from float64, the HIP path 0.16 with unsplit forward-type convolutions and 0.28
+        # with split-K ones -- independent of the convolution arithmetic (bf16x3 split or fp32 MFMA), of the BatchNorm kernels
+        # (fused or torch), of the backward-weights reduction (atomics or ordered) and of the second stream; the memory-side float
+        # atomics are exact round-to-nearest adds (tools/atomic_rounding.hip).  Bars: what was observed plus a margin.
+        from dsf_amd import _lib as L
         net64 = _Net64(net_cpu)
         loss_64 = step_ref.pretrain_loss(net64, _PinnedBridge(orender, rec.images), gen_cpu, p, cube, d, Config, views=views)
         loss_64.backward()
@@ -305,7 +313,22 @@ def test_pretrain_and_config4_multiview_step_vs_oracle(render, orender, backbone
         cos_c, rel_c = _grad_error(net64, net_cpu)
         cos_g, rel_g = _grad_error(net64, net_gpu)
         assert rel_c > 1e-2, "expected an ill-conditioned case (else use the strict bars)"
-        assert rel_g <= 6.0 * rel_c and cos_g > 0.9, ((cos_c, rel_c), (cos_g, rel_g))
+        print("two-stage ResNet-50 %s: cpu32 vs f64 (cos %.4f rel %.4f)  hip vs f64 (cos %.4f rel %.4f)" % ("frozen" if frozen else "train", cos_c, rel_c, cos_g, rel_g))
+        assert rel_g <= 5.0 * rel_c and cos_g > 0.95, ((cos_c, rel_c), (cos_g, rel_g))
+        # the same step with every forward-type convolution unsplit (deterministic mode): the closer of the two HIP evaluations
+        old = L.set_deterministic(True)
+        try:
+            for q in net_gpu.parameters():
+                q.grad = None
+            runner = pinned if flips else step
+            loss_d, _ = runner.loss(p.cuda(), cube.cuda(), draws_to(d, "cuda"))
+            loss_d.backward()
+        finally:
+            L.set_deterministic(old)
+        cos_d, rel_d = _grad_error(net64, net_gpu)
+        print("   unsplit convolutions (deterministic mode): hip vs f64 (cos %.4f rel %.4f)" % (cos_d, rel_d))
+        assert abs(float(loss_d) - float(loss_64)) <= 2e-3 * abs(float(loss_64))
+        assert rel_d <= 3.0 * rel_c and cos_d > 0.98, ((cos_c, rel_c), (cos_d, rel_d))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -62,6 +62,16 @@ def _worker(rank, world, port, q):
         assert torch.allclose(got, p.grad, atol=1e-6)
     for h in sync2._hooks:
         h.remove()
+    # reduce_now(): the hooks stay off during the backward pass (as under a HIP-graph replay, train_step.GraphedStep), the
+    # buckets are packed and reduced afterwards -- same averaged gradients as the hook-driven path
+    sync.enabled = False
+    net.zero_grad(set_to_none=True)
+    ((net(xs) - ys) ** 2).mean().backward()
+    sync.enabled = True
+    sync.reduce_now()
+    for got, p in zip(out[1], net.parameters()):
+        assert torch.allclose(got, p.grad, atol=1e-6)
+    sync.enabled = False
     # exact masked mean across shards
     vals = torch.arange(4.0) + 4 * rank
     mask = (vals % 3 == 0).float()
