@@ -46,7 +46,7 @@ SYMBOLS = [
     "dsf_xyz_to_uvd_backward", "dsf_crop_hand", "dsf_img2pcl", "dsf_joint2offset_forward",
     "dsf_joint2offset_backward", "dsf_offset2joint_forward", "dsf_offset2joint_backward",
     "dsf_conv_igemm_forward", "dsf_conv_igemm_bwd_data_s1", "dsf_conv_igemm_forward_wt", "dsf_conv_igemm_wrw",
-    "dsf_depth_crop_normalize", "dsf_conv_c1_supported", "dsf_conv_c1_workspace_bytes", "dsf_conv_c1_forward", "dsf_conv_c1_wrw",
+    "dsf_depth_crop_normalize", "dsf_depth_crop_normalize_u16", "dsf_conv_c1_supported", "dsf_conv_c1_workspace_bytes", "dsf_conv_c1_forward", "dsf_conv_c1_wrw",
     "dsf_conv_x6_image_bytes", "dsf_conv_x6_split_weights", "dsf_conv_x6_image_granules",
     "dsf_conv_x6_split_weights_multi", "dsf_conv_x6_forward", "dsf_conv_x6_wrw", "dsf_mfma_bf16_probe", "dsf_bn_forward", "dsf_bn_apply", "dsf_bn_backward", "dsf_bn_workspace_bytes", "dsf_col_sum", "dsf_col_sum_workspace_bytes",
     "dsf_huber_mean_forward", "dsf_huber_mean_backward", "dsf_adamw_multi", "dsf_adamw_chunk_elems",

@@ -34,13 +34,16 @@ __device__ __forceinline__ CropGeom crop_geom(const double* com, const double* s
 }
 
 // un-normalised crop value of output pixel (oy, ox)
-__device__ __forceinline__ float crop_pixel(const float* __restrict__ frame, int Hd, int Wd, const CropGeom& g, int oy, int ox) {
+// (T = float, or uint16_t: the sensors' raw 16-bit millimetre frames -- NYU / ICVL / HANDS17 png, render_loader.py:201-218 --
+//  whose conversion to float32 is exact, so both element types give the same bits)
+template <typename T>
+__device__ __forceinline__ float crop_pixel(const T* __restrict__ frame, int Hd, int Wd, const CropGeom& g, int oy, int ox) {
     const int ry = oy - g.y0, rx = ox - g.x0;
     if ((unsigned)ry >= (unsigned)g.sz_h || (unsigned)rx >= (unsigned)g.sz_w) return 0.f;
     const int sy = min((int)floor(ry * g.ify), g.hb - 1), sx = min((int)floor(rx * g.ifx), g.wb - 1);
     const int iy = g.ys + sy, ix = g.xs + sx;
     if ((unsigned)iy >= (unsigned)Hd || (unsigned)ix >= (unsigned)Wd) return 0.f;
-    float v = frame[(int64_t)iy * Wd + ix];
+    float v = (float)frame[(int64_t)iy * Wd + ix];
     if (v != 0.f) {
         if ((double)v < g.zs) v = (float)g.zs;           // in front of the cube: onto its front face
         else if ((double)v > g.ze) v = 0.f;              // behind it: background
@@ -48,7 +51,8 @@ __device__ __forceinline__ float crop_pixel(const float* __restrict__ frame, int
     return v;
 }
 
-__global__ __launch_bounds__(256) void depth_crop_normalize_kernel(const float* __restrict__ depth, const double* __restrict__ com,
+template <typename T>
+__global__ __launch_bounds__(256) void depth_crop_normalize_kernel(const T* __restrict__ depth, const double* __restrict__ com,
                                                                    const double* __restrict__ cube, double fx, double fy, int Hd,
                                                                    int Wd, int dsize, float* __restrict__ img,
                                                                    double* __restrict__ trans, float* __restrict__ raw) {
@@ -57,7 +61,7 @@ __global__ __launch_bounds__(256) void depth_crop_normalize_kernel(const float* 
     const double* c = com + 3 * b;
     const double* s = cube + 3 * b;
     const CropGeom g = crop_geom(c, s, fx, fy, dsize);
-    const float* frame = depth + (int64_t)b * Hd * Wd;
+    const T* frame = depth + (int64_t)b * Hd * Wd;
     const int n = dsize * dsize;
     if (t == 0 && trans) {                               // off . scale . trans (render_loader.py:810), row-major 3 x 3
         double* m = trans + 9 * b;
@@ -301,7 +305,18 @@ extern "C" int dsf_depth_crop_normalize(const float* depth, const double* com, c
                                         dsf_stream_t stream) {
     DSF_CHECK_ARG(depth && com && cube && img && B >= 0 && Hd > 0 && Wd > 0 && dsize > 0 && fx > 0. && fy > 0.);
     if (B == 0) return DSF_OK;
-    hipLaunchKernelGGL(depth_crop_normalize_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, depth, com, cube, fx, fy, Hd, Wd,
+    hipLaunchKernelGGL(depth_crop_normalize_kernel<float>, dim3(B), dim3(256), 0, (hipStream_t)stream, depth, com, cube, fx, fy, Hd, Wd,
                        dsize, img, trans, raw_crop);
+    return dsf_launch_status();
+}
+
+// the same on RAW 16-bit frames ("consuming raw 640x480 u16 depth"): no float32 copy of the frame is ever made
+extern "C" int dsf_depth_crop_normalize_u16(const uint16_t* depth, const double* com, const double* cube, double fx, double fy, int B,
+                                            int Hd, int Wd, int dsize, float* img, double* trans, float* raw_crop,
+                                            dsf_stream_t stream) {
+    DSF_CHECK_ARG(depth && com && cube && img && B >= 0 && Hd > 0 && Wd > 0 && dsize > 0 && fx > 0. && fy > 0.);
+    if (B == 0) return DSF_OK;
+    hipLaunchKernelGGL(depth_crop_normalize_kernel<uint16_t>, dim3(B), dim3(256), 0, (hipStream_t)stream, depth, com, cube, fx, fy, Hd,
+                       Wd, dsize, img, trans, raw_crop);
     return dsf_launch_status();
 }

@@ -410,11 +410,14 @@ def img2pcl(img, center, minv, cube, cam, n_sample, rand_keys=None):
 
 def depth_crop_normalize(depth, com, cube, paras, dsize=128, want_raw=False):
     """Test-phase data path of loader.__getitem__ (data/render_loader.py:1909-1916): Crop_Image_deep_pp + normalize_img on
-    raw depth frames.  depth (B,Hd,Wd) f32 mm, com (B,3) (u, v, z) and cube (B,3) / (3,) are used as float64 (the reference's
+    raw depth frames.  depth (B,Hd,Wd) mm -- uint16 / int16 (the sensors' raw frames, read as they are) or anything float32 can
+    hold --, com (B,3) (u, v, z) and cube (B,3) / (3,) are used as float64 (the reference's
     numpy arithmetic) -> img (B,1,dsize,dsize) f32, trans (B,3,3) f64 [, raw crop (B,dsize,dsize)]."""
     if not depth.is_cuda:
         raise RuntimeError("dsf_amd ops run on the GPU only (got a %s tensor); there is no CPU path" % depth.device)
-    depth = depth.float().contiguous()
+    # raw sensor frames stay 16-bit (torch.uint16, or int16 holding the same bits); anything else is read as float32
+    raw16 = depth.dtype in (torch.uint16, torch.int16)
+    depth = depth.contiguous() if raw16 else depth.float().contiguous()
     B, Hd, Wd = depth.shape
     com = torch.as_tensor(com, dtype=torch.float64, device=depth.device).reshape(B, 3).contiguous()
     cube = torch.as_tensor(cube, dtype=torch.float64, device=depth.device)
@@ -423,8 +426,9 @@ def depth_crop_normalize(depth, com, cube, paras, dsize=128, want_raw=False):
     trans = torch.empty((B, 3, 3), device=depth.device, dtype=torch.float64)
     raw = _empty((B, dsize, dsize), depth) if want_raw else None
     D = ctypes.c_double
-    check(L.lib().dsf_depth_crop_normalize(ptr(depth), ptr(com), ptr(cube), D(paras[0]), D(paras[1]), I(B), I(Hd), I(Wd),
-                                           I(dsize), ptr(img), ptr(trans), ptr(raw), stream_ptr()), "dsf_depth_crop_normalize")
+    fn = L.lib().dsf_depth_crop_normalize_u16 if raw16 else L.lib().dsf_depth_crop_normalize
+    check(fn(ptr(depth), ptr(com), ptr(cube), D(paras[0]), D(paras[1]), I(B), I(Hd), I(Wd),
+             I(dsize), ptr(img), ptr(trans), ptr(raw), stream_ptr()), "dsf_depth_crop_normalize")
     return (img, trans, raw) if want_raw else (img, trans)
 
 

@@ -328,6 +328,10 @@ int dsf_conv_igemm_wrw(const float* X, const float* dY, float* dW, int B, int Hi
  * take).  Source-pixel selection is bit-exact with the numpy code; normalised values agree to 1 float32 ulp. */
 int dsf_depth_crop_normalize(const float* depth, const double* com, const double* cube, double fx, double fy, int B, int Hd,
                              int Wd, int dsize, float* img, double* trans, float* raw_crop, dsf_stream_t stream);
+/* the same on the sensors' RAW 16-bit frames (uint16 millimetres: what nyu_reader / icvl_reader / hands17_reader decode,
+ * render_loader.py:201-218, before their float32 cast) -- bit-identical results, half the frame traffic, no host cast */
+int dsf_depth_crop_normalize_u16(const uint16_t* depth, const double* com, const double* cube, double fx, double fy, int B, int Hd,
+                                 int Wd, int dsize, float* img, double* trans, float* raw_crop, dsf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Direct convolution for 1-channel inputs (csrc/conv_c1.hip): the 5x5 ResNet stem (model/backbone.py:196-199), the 7x7

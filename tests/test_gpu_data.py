@@ -48,6 +48,26 @@ def test_crop_normalize_matches_oracle_on_random_frames():
         assert np.array_equal(img64[i, 0].cpu().numpy(), n) and np.array_equal(t64[i].cpu().numpy(), t)
 
 
+def test_crop_normalize_reads_raw_uint16_frames():
+    """SURVEY 8(f) row 1 names raw 16-bit depth as the input: the sensors' uint16 millimetre frames (what nyu_reader /
+    icvl_reader decode before their float32 cast, render_loader.py:201-218) go to the kernel as they are -- same bits out as
+    through the float32 frame, against the oracle too."""
+    from oracle import data_ref
+    from dsf_amd import ops
+    mgd, _, _, _, _ = _cases()
+    depth, com, cube = mgd.frames(np.random.RandomState(7), 12)
+    d16 = np.clip(np.rint(depth), 0, 65535).astype(np.uint16)                     # integer millimetres, as a sensor delivers them
+    ref = ops.depth_crop_normalize(torch.tensor(d16.astype(np.float32)).cuda(), com, cube, mgd.PARAS, 128, want_raw=True)
+    for dt in (torch.uint16, torch.int16):
+        t16 = torch.from_numpy(d16.view(np.int16)).cuda().view(dt)
+        got = ops.depth_crop_normalize(t16, com, cube, mgd.PARAS, 128, want_raw=True)
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b), dt
+    for i in range(len(com)):
+        n, t, c = data_ref.crop_and_normalize(d16[i].astype(np.float32), com[i], cube[i], (128, 128), mgd.PARAS)
+        assert np.array_equal(ref[2][i].cpu().numpy(), c) and np.array_equal(ref[0][i, 0].cpu().numpy(), n), i
+
+
 def test_crop_normalize_empty_batch_and_cpu_tensor():
     from dsf_amd import ops
     img, trans = ops.depth_crop_normalize(torch.zeros(0, 480, 640, device="cuda"), np.zeros((0, 3)), np.zeros((0, 3)),
