@@ -193,8 +193,23 @@ def convert_sync_batchnorm(net, process_group=None):
     (round 2 fell back to torch.nn.SyncBatchNorm's own kernels and per-layer gathers).  Plain ``torch.nn.BatchNorm*`` modules,
     if any, are converted by torch."""
     from .nn_norm import FusedBatchNorm2d, FusedSyncBatchNorm2d
-    for m in net.modules():
-        if isinstance(m, FusedBatchNorm2d) and not isinstance(m, FusedSyncBatchNorm2d):
-            m.__class__ = FusedSyncBatchNorm2d
-            m.process_group = process_group
-    return torch.nn.SyncBatchNorm.convert_sync_batchnorm(net, process_group)
+
+    def walk(mod):
+        for name, child in list(mod.named_children()):
+            if isinstance(child, FusedBatchNorm2d):
+                if not isinstance(child, FusedSyncBatchNorm2d):
+                    child.__class__ = FusedSyncBatchNorm2d
+                child.process_group = process_group
+            elif isinstance(child, torch.nn.modules.batchnorm._BatchNorm):
+                # (torch's converter would also turn OUR modules -- BatchNorm2d subclasses -- into its own: plain ones only)
+                setattr(mod, name, torch.nn.SyncBatchNorm.convert_sync_batchnorm(child, process_group))
+            else:
+                walk(child)
+    if isinstance(net, FusedBatchNorm2d):
+        net.__class__ = FusedSyncBatchNorm2d
+        net.process_group = process_group
+        return net
+    if isinstance(net, torch.nn.modules.batchnorm._BatchNorm):
+        return torch.nn.SyncBatchNorm.convert_sync_batchnorm(net, process_group)
+    walk(net)
+    return net

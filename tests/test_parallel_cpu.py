@@ -179,3 +179,18 @@ def test_rccl_log_summary_parses_what_it_can(tmp_path):
     s = bench.rccl_summary(str(f))["log"]
     assert s["ring_lines"] == 2 and s["tree_lines"] == 1 and s["channels"] == 16 and s["nranks_reported"] == [8]
     assert bench.rccl_summary(str(tmp_path / "absent.log")) == {"log": None}
+
+
+def test_convert_sync_batchnorm_keeps_the_fused_modules():
+    """parallel.convert_sync_batchnorm: fused BatchNorm modules become FusedSyncBatchNorm2d IN PLACE (class swap: parameters,
+    buffers, keys, call signature kept); plain torch BatchNorm modules go through torch's converter; nothing else changes."""
+    from dsf_amd.parallel import convert_sync_batchnorm
+    from dsf_amd import nn_norm
+    net = nn.ModuleList([nn.Conv2d(3, 4, 1), nn_norm.FusedBatchNorm2d(4, fuse_relu=True), nn.Sequential(nn.BatchNorm2d(4), nn_norm.FusedBatchNorm2d(8))])
+    keys = list(net.state_dict().keys())
+    fused = net[1]
+    out = convert_sync_batchnorm(net)
+    assert out is net and net[1] is fused and type(net[1]) is nn_norm.FusedSyncBatchNorm2d and net[1].fuse_relu
+    assert type(net[2][0]) is nn.SyncBatchNorm and type(net[2][1]) is nn_norm.FusedSyncBatchNorm2d
+    assert list(net.state_dict().keys()) == keys
+    assert type(convert_sync_batchnorm(nn_norm.FusedBatchNorm2d(4))) is nn_norm.FusedSyncBatchNorm2d
