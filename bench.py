@@ -197,13 +197,48 @@ def crop_kernel_roofline(render, B, launches=200):
     us = e0.elapsed_time(e1) * 1e3 / launches
     bytes_per_launch = B * (779 * 12 + 128 * 128 * 4 + 128 * 128 * 4)
     achieved = bytes_per_launch / (us * 1e-6) / 1e9
+    # VALU roofline (what actually bounds it): the kernel's work is one coverage evaluation per (crop pixel, face) pair whose
+    # raster pixel lies inside the face's bounding box -- counted here exactly, with the kernel's own pixel map and boxes --
+    # at ~25 lane-instructions for a rejected pair (3 edge functions, sign tests, loop) and ~65 for a covered one (3 IEEE
+    # divisions, depth, key, LDS atomic); peak = 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz lane-instructions per second.
+    with torch.no_grad():
+        W, H, S = 640.0, 480.0, 640
+        fxn, fyn = render.cam.fx / (W / 2), render.cam.fy / (H / 2)
+        X, Y, Z = verts.unbind(-1)
+        xn, yn = (-X * fxn) / Z, (-Y * fyn) / Z                                  # px' = py' = 0 for this camera (A.1)
+        fv = mano.faces_i32.long()
+        fx3, fy3 = xn[:, fv], yn[:, fv]                                          # (B,F,3)
+        box = lambda lo, hi: ((0.5 * (S * (1 - hi) - 1)).clamp(min=-4).ceil() - 1).clamp(min=0), ((0.5 * (S * (1 - lo) - 1)).clamp(max=S + 4).floor() + 1).clamp(max=S - 1)
+        xlo, xhi = box(fx3.amin(-1), fx3.amax(-1))
+        ylo, yhi = box(fy3.amin(-1), fy3.amax(-1))
+        jj, ii = torch.meshgrid(torch.arange(128.0, device=verts.device), torch.arange(128.0, device=verts.device), indexing="xy")
+        mi = minv.float()
+        sx = (mi[:, 0, 0, None, None] * jj + mi[:, 0, 1, None, None] * ii) + mi[:, 0, 2, None, None]
+        sy = (mi[:, 1, 0, None, None] * jj + mi[:, 1, 1, None, None] * ii) + mi[:, 1, 2, None, None]
+        fxp = torch.round(((sx / W) * 2 - 1 + 1) * (W / 2) - 0.5)
+        fyp = torch.round(((sy / H) * 2 - 1 + 1) * (H / 2) - 0.5)
+        ok = (fxp >= 0) & (fxp < W) & (fyp >= 0) & (fyp < H)
+        ry = render.resize_rowmap.long()[fyp.clamp(0, H - 1).long()].float()
+        evals = 0
+        for b in range(B):                                                       # (F, 16384) comparisons per sample
+            px, py, m = fxp[b].reshape(1, -1), ry[b].reshape(1, -1), ok[b].reshape(1, -1)
+            inside = m & (px >= xlo[b, :, None]) & (px <= xhi[b, :, None]) & (py >= ylo[b, :, None]) & (py <= yhi[b, :, None])
+            evals += int(inside.sum())
+        covered = int((run()[0] < 0.99).sum())
+    lane_ops = 25.0 * evals + 40.0 * covered
+    valu_peak = 256 * 4 * 32 * 2.4e9
     return {"kernel": "render_crop_fwd_kernel", "bound": "valu", "avg_launch_us": round(us, 2),
-            "images_per_s": round(B / (us * 1e-6), 1), "hbm_achieved": round(achieved, 2), "hbm_peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "achieved": round(lane_ops / (us * 1e-6) / 1e12, 3), "peak": round(valu_peak / 1e12, 1), "unit": "T lane-instructions/s",
+            "frac": round(lane_ops / (us * 1e-6) / valu_peak, 4),
+            "coverage_evaluations_per_launch": evals, "covered_pixels_per_launch": covered,
+            "images_per_s": round(B / (us * 1e-6), 1), "hbm_achieved": round(achieved, 2), "hbm_peak": HBM_PEAK_GBS,
             "hbm_frac": round(achieved / HBM_PEAK_GBS, 5), **pmc_traffic("render_crop_fwd_kernel"),
             "bytes_per_launch": bytes_per_launch,
-            "note": "VALU / latency-bound, not a bandwidth kernel: 4.5 MB of algorithmic traffic per launch; its time is the "
-                    "coverage tests of the heaviest 8x8 tile (one wave walks that tile's candidate faces) on top of a ~25 us "
-                    "floor (projection + face boxes per workgroup, empty-tile walks; tools/perf_crop.py); 2 launches per step"}
+            "note": "VALU / latency-bound, not a bandwidth kernel: 4.5 MB of algorithmic traffic per launch.  `frac` is a MODEL "
+                    "count (coverage evaluations x instructions per evaluation) over the VALU issue peak: the lanes of the "
+                    "face-parallel path walk boxes of different sizes (divergence), and ~25 us of the launch are the "
+                    "projection + face boxes every workgroup repeats and the walk over empty tiles (tools/perf_crop.py); "
+                    "2 launches per step = 0.8 % of it, 0.5 % of config 5: left as it is (DESIGN.md section 5)"}
 
 
 def self_launch(n):

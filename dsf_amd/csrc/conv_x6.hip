@@ -614,9 +614,11 @@ __global__ __launch_bounds__(256, 2) void igemm_x6b_kernel(const float* __restri
 #pragma unroll
             for (int w = 0; w < WAVES_M; ++w) tot += s_st[(BN == 128) ? (w * 2 + wcol) : w][which][lc];
             // ep.stats_acc == 0: partial row m_tile (folded in a fixed order by bn_finalize_kernel);  > 0: added into row
-            // (m_tile mod stats_acc) of a zeroed block of that many rows with float atomics (folded by the BatchNorm apply
-            // kernel's own prologue: dsf_bn_forward_acc) -- <= 32 adders per address, ~1 MB of atomics per launch
-            if (ep.stats_acc > 0) atomicAdd(&stats[((int64_t)(m_tile % ep.stats_acc) * 2 + which) * p.Co + n], tot);
+            // (m_tile mod stats_acc) of a zeroed block of that many rows of DOUBLES with global_atomic_add_f64 (folded by the
+            // BatchNorm apply kernel's own prologue: dsf_bn_forward_acc) -- ~1 MB of atomics per launch
+            if (ep.stats_acc > 0)
+                __hip_atomic_fetch_add(reinterpret_cast<double*>(stats) + ((int64_t)(m_tile % ep.stats_acc) * 2 + which) * p.Co + n, (double)tot,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else stats[((int64_t)m_tile * 2 + which) * p.Co + n] = tot;
         }
     }
@@ -1003,17 +1005,18 @@ int dsf_conv_x6_forward_bn(const float* X, const void* image, float* Y, int B, i
                            X6Ep{nullptr, nullptr, nullptr, 0, 0}, nullptr, stream);
 }
 
-// As dsf_conv_x6_forward_bn, but the tile sums are ADDED (float atomics) into the caller-zeroed block `acc` of
-// dsf_bn_acc_rows() rows [row][2][Co] that dsf_bn_forward_acc folds in its own prologue (no finalise launch).  *filled = 1
+// As dsf_conv_x6_forward_bn, but the tile sums are ADDED (double atomics) into the caller-zeroed block `acc` of
+// dsf_bn_acc_rows() rows [row][2][Co] of doubles that dsf_bn_forward_acc folds in its own prologue (no finalise launch).  *filled = 1
 // when the launch this shape takes wrote them (else Y is the plain convolution and `acc` is untouched).  Not in
 // deterministic mode (DSF_ERR_UNSUPPORTED).
 int dsf_conv_x6_forward_bn_acc(const float* X, const void* image, float* Y, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
-                               int KH, int KW, int stride, int dil, int pad_h, int pad_w, float* acc, int acc_rows, int* filled,
+                               int KH, int KW, int stride, int dil, int pad_h, int pad_w, double* acc, int acc_rows, int* filled,
                                dsf_stream_t stream) {
     DSF_CHECK_ARG(acc && filled && acc_rows > 0);
     if (dsf_deterministic()) return DSF_ERR_UNSUPPORTED;
     int rows = 0;
-    const int rc = x6_forward_impl(X, image, nullptr, Y, B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, dil, pad_h, pad_w, 0, acc, &rows,
+    const int rc = x6_forward_impl(X, image, nullptr, Y, B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, dil, pad_h, pad_w, 0,
+                                   reinterpret_cast<float*>(acc), &rows,
                                    X6Ep{nullptr, nullptr, nullptr, 0, acc_rows}, nullptr, stream);
     *filled = rows > 0 ? 1 : 0;
     return rc;

@@ -34,10 +34,13 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
                                                         const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int64_t M, int C, int relu,
                                                         int rows_per_wg, float* __restrict__ part, int acc_rows) {
+    // (with acc_rows > 0 `part` is really a double array: the accumulation rows are DOUBLES, see bn_fold_rows)
     // acc_rows == 0: workgroup w stores partial row w (bn_finalize_kernel folds them in a fixed order: deterministic).
-    // acc_rows  > 0: the workgroup ADDS its partial row into row (w mod acc_rows) of a zeroed [acc_rows][2][C] block with
-    //                float atomics (8 adders per address at 256 workgroups); the apply kernels fold those few rows in their
-    //                own prologue, so that no finalise launch sits between the passes.
+    // acc_rows  > 0: the workgroup ADDS its partial row into row (w mod acc_rows) of a zeroed [acc_rows][2][C] block of DOUBLES
+    //                with global_atomic_add_f64 (32 adders per address at 256 workgroups); the apply kernels fold those few
+    //                rows in their own prologue, so that no finalise launch sits between the passes.  Doubles: the float
+    //                partials are then summed exactly as bn_finalize_kernel does (a double sum of <= 1024 floats is order-
+    //                independent to ~1e-16), so the statistics match the ordered path to the last float bit almost always.
     // relu: 0 none, 1 mask from the saved output y (y > 0), 2 mask recomputed from x with the forward's own expression
     // (x - mean) * (invstd * gamma) + beta > 0 -- bit-identical to the forward, and y is not read (nor kept) at all
     __shared__ float s_part[2][256 * 4];
@@ -103,13 +106,16 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
     for (int k = 0; k < 4; ++k) { s_part[0][t * 4 + k] = a0[k]; s_part[1][t * 4 + k] = a1[k]; }
     __syncthreads();
     const int nv = 2 * C;
-    float* out = part + (int64_t)(acc_rows ? (int)(blockIdx.x % acc_rows) : (int)blockIdx.x) * nv + blockIdx.y * c4b * 4;
+    float* out = part + (int64_t)blockIdx.x * nv + blockIdx.y * c4b * 4;
+    double* acc = reinterpret_cast<double*>(part) + (int64_t)(acc_rows ? (int)(blockIdx.x % acc_rows) : 0) * nv + blockIdx.y * c4b * 4;
     for (int ch = t; ch < c4b * 4; ch += 256) {
         const int cc = ch >> 2, kk = ch & 3;
         float d0 = 0.f, d1 = 0.f;
         for (int q = 0; q < rlanes; ++q) { d0 += s_part[0][(q * c4b + cc) * 4 + kk]; d1 += s_part[1][(q * c4b + cc) * 4 + kk]; }
-        if (acc_rows) { atomicAdd(out + ch, d0); atomicAdd(out + C + ch, d1); }
-        else { out[ch] = d0; out[C + ch] = d1; }
+        if (acc_rows) {
+            __hip_atomic_fetch_add(acc + ch, (double)d0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(acc + C + ch, (double)d1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else { out[ch] = d0; out[C + ch] = d1; }
     }
 }
 
@@ -159,24 +165,26 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     }
 }
 
-// Sums of the `rows` accumulation rows [row][2][C] for channels c .. c + 3, in double, ascending row order (the order of the
-// rows is fixed; what is NOT is the order in which the float atomics built each row).  8 float4 loads in flight.
-__device__ __forceinline__ void bn_fold_rows(const float* __restrict__ rows, int n_rows, int C, int c, double (&s0)[4], double (&s1)[4]) {
+// Sums of the `rows` accumulation rows [row][2][C] (doubles) for channels c .. c + 3, ascending row order.
+__device__ __forceinline__ void bn_fold_rows(const double* __restrict__ rows, int n_rows, int C, int c, double (&s0)[4], double (&s1)[4]) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) { s0[k] = 0.0; s1[k] = 0.0; }
-    // all 2 x 8 loads of a batch of 8 rows are issued before the first add: ONE L2 round trip for BN_ACC_ROWS = 8
-    for (int r = 0; r < n_rows; r += 8) {
-        float4 a[8], b[8];
+    // all loads of a batch of 4 rows (16 x 16 bytes) are issued before the first add: two L2 round trips for BN_ACC_ROWS = 8
+    for (int r = 0; r < n_rows; r += 4) {
+        double2 a[4][2], b[4][2];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 4; ++u) {
             const bool ok = r + u < n_rows;
-            a[u] = ok ? *reinterpret_cast<const float4*>(rows + (int64_t)(r + u) * 2 * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            b[u] = ok ? *reinterpret_cast<const float4*>(rows + (int64_t)(r + u) * 2 * C + C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const double2* pa = reinterpret_cast<const double2*>(rows + (int64_t)(r + u) * 2 * C + c);
+            const double2* pb = reinterpret_cast<const double2*>(rows + (int64_t)(r + u) * 2 * C + C + c);
+            const double2 z = make_double2(0.0, 0.0);
+            a[u][0] = ok ? pa[0] : z; a[u][1] = ok ? pa[1] : z;
+            b[u][0] = ok ? pb[0] : z; b[u][1] = ok ? pb[1] : z;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            s0[0] += (double)a[u].x; s0[1] += (double)a[u].y; s0[2] += (double)a[u].z; s0[3] += (double)a[u].w;
-            s1[0] += (double)b[u].x; s1[1] += (double)b[u].y; s1[2] += (double)b[u].z; s1[3] += (double)b[u].w;
+        for (int u = 0; u < 4; ++u) {
+            s0[0] += a[u][0].x; s0[1] += a[u][0].y; s0[2] += a[u][1].x; s0[3] += a[u][1].y;
+            s1[0] += b[u][0].x; s1[1] += b[u][0].y; s1[2] += b[u][1].x; s1[3] += b[u][1].y;
         }
     }
 }
@@ -191,7 +199,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        int64_t n4, int C, int relu, float* __restrict__ y,
-                                                       const float* __restrict__ rows, int n_rows, int64_t M, BnFinal fin) {
+                                                       const double* __restrict__ rows, int n_rows, int64_t M, BnFinal fin) {
     const int c4n = C >> 2;
     const int64_t i0 = blockIdx.x * (int64_t)256 + threadIdx.x;
     const int c = (int)(i0 % c4n) * 4;
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const double* __restrict__ acc,
                                                            int64_t M, int64_t n4, int C, int relu, float* __restrict__ dx,
-                                                           float* __restrict__ dres, const float* __restrict__ rows, int n_rows,
+                                                           float* __restrict__ dres, const double* __restrict__ rows, int n_rows,
                                                            BnFinal fin, const double* __restrict__ count) {
     // count != nullptr: the divisor is the element count of the WHOLE (cross-replica) batch, read from device memory
     const int c4n = C >> 2;
@@ -492,21 +500,21 @@ extern "C" int dsf_bn_backward(const float* x, const float* grad_y, const float*
 }
 
 // ---- the same passes WITHOUT the finalise launches (default, float-atomic mode) --------------------------------------
-// `acc` is a caller-zeroed block of dsf_bn_acc_rows() rows [row][2][C]: the statistics pass (here, or the producing
-// convolution's epilogue: dsf_conv_x6_forward_bn_acc) adds its per-workgroup sums into row (workgroup mod rows) with float
-// atomics, and the apply kernel folds the rows in its own prologue (in double, ascending) -- forward = 1 launch after a
+// `acc` is a caller-zeroed block of dsf_bn_acc_rows() rows [row][2][C] of DOUBLES: the statistics pass (here, or the producing
+// convolution's epilogue: dsf_conv_x6_forward_bn_acc) adds its per-workgroup float sums into row (workgroup mod rows) with
+// double atomics, and the apply kernel folds the rows in its own prologue (in double, ascending) -- forward = 1 launch after a
 // convolution that filled the rows (2 otherwise), backward = 2, where the ordered-partials path above needs 2-3 and 3.
-// Results differ from that path by the float atomics' summation order only (~1e-7 relative on the statistics); in
+// Results differ from that path by the order of DOUBLE additions only (~1e-16 relative on the sums); in
 // deterministic mode these entry points return DSF_ERR_UNSUPPORTED and the caller uses the ordered path.
-// 8 rows: the prologue fold is one batch of loads; 256 reduce workgroups = 32 adders per address, a 512-workgroup convolution
-// epilogue 64 -- a few hundred KB of atomics per launch, spread over its duration (measured with 32 rows: the 64-load fold cost
-// more than the finalise launch it replaced)
+// 8 rows of doubles: the prologue fold is two batches of loads; 256 reduce workgroups = 32 adders per address, a 512-workgroup
+// convolution epilogue 64 -- a few hundred KB of atomics per launch, spread over its duration (measured with 32 float rows: the
+// 64-load fold cost more than the finalise launch it replaced)
 constexpr int BN_ACC_ROWS = 8;
 extern "C" int dsf_bn_acc_rows(void) { return BN_ACC_ROWS; }
 
 extern "C" int dsf_bn_forward_acc(const float* x, const float* residual, const float* gamma, const float* beta, int64_t M, int C,
                                   float eps, float momentum, int relu, float* running_mean, float* running_var, float* y,
-                                  float* save_mean, float* save_invstd, float* acc, int acc_filled, dsf_stream_t stream) {
+                                  float* save_mean, float* save_invstd, double* acc, int acc_filled, dsf_stream_t stream) {
     DSF_CHECK_ARG(x && y && save_mean && save_invstd && acc && M > 0);
     if (!bn_shape_ok(C) || dsf_deterministic()) return DSF_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
@@ -515,7 +523,7 @@ extern "C" int dsf_bn_forward_acc(const float* x, const float* residual, const f
         const int rows = bn_rows_per_wg(M, C);
         const int wgs = (int)((M + rows - 1) / rows);
         hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(wgs, bn_col_blocks(C)), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr,
-                           nullptr, M, C, 0, rows, acc, BN_ACC_ROWS);
+                           nullptr, M, C, 0, rows, reinterpret_cast<float*>(acc), BN_ACC_ROWS);
     }
     const int64_t n4 = M * (C >> 2);
     hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(bn_apply_grid(n4, C)), dim3(256), 0, st, x, residual, nullptr, nullptr, gamma, beta,
@@ -525,7 +533,7 @@ extern "C" int dsf_bn_forward_acc(const float* x, const float* residual, const f
 
 extern "C" int dsf_bn_backward_acc(const float* x, const float* grad_y, const float* y, const float* gamma, const float* beta,
                                    const float* save_mean, const float* save_invstd, int64_t M, int C, int relu, float* grad_x,
-                                   float* grad_residual, float* grad_gamma, float* grad_beta, float* acc, dsf_stream_t stream) {
+                                   float* grad_residual, float* grad_gamma, float* grad_beta, double* acc, dsf_stream_t stream) {
     DSF_CHECK_ARG(x && grad_y && save_mean && save_invstd && grad_x && acc && M > 0 && relu >= 0 && relu <= 2 && (relu != 1 || y));
     if (!bn_shape_ok(C) || dsf_deterministic()) return DSF_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
@@ -533,7 +541,7 @@ extern "C" int dsf_bn_backward_acc(const float* x, const float* grad_y, const fl
     const int wgs = (int)((M + rows - 1) / rows);
     BnFinal fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, grad_gamma, grad_beta};
     hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(wgs, bn_col_blocks(C)), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd, gamma, beta,
-                       M, C, relu, rows, acc, BN_ACC_ROWS);
+                       M, C, relu, rows, reinterpret_cast<float*>(acc), BN_ACC_ROWS);
     const int64_t n4 = M * (C >> 2);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(bn_apply_grid(n4, C)), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd,
                        gamma, beta, nullptr, M, n4, C, relu, grad_x, grad_residual, acc, BN_ACC_ROWS, fin, nullptr);

@@ -385,7 +385,7 @@ class Conv2dFunction(Function):
             if ctx.needs_input_grad[1]:
                 join_side_streams()                      # a main-stream contribution: see _wrw_dispatch
                 if SIDE_API:
-                    weight.__dict__["_dsf_pass"] = (torch._C._current_graph_task_id(), None, 0)
+                    weight.__dict__["_dsf_pass"] = (torch._C._current_graph_task_id(), None)
                 gw = _WeightGradFunction.apply(x, gy, (KH, KW), stride, padding)
             if has_bias and ctx.needs_input_grad[2]:
                 gb = gy.sum((0, 2, 3))
@@ -464,9 +464,7 @@ def _side_api_ok():
 SIDE_API = _side_api_ok()
 WRW_STREAM = [os.environ.get("DSF_WRW_STREAM", "1") == "1" and SIDE_API]
 WRW_PRIORITY = int(os.environ.get("DSF_WRW_PRIORITY", "0"))          # priority of the side stream (lower number = higher priority)
-WRW_STREAMS = int(os.environ.get("DSF_WRW_STREAMS", "2"))           # how many weight-gradient streams take turns
 _SIDE = {}
-_RR, _LAST_IDX = [0], [0]
 _JOIN_QUEUED = [-1]
 _PENDING = [False]
 _HELD = []
@@ -487,17 +485,17 @@ def _wrw_dispatch(weight, fn_new, fn_add, held):
     if _side_ok(weight) and task >= 0:
         if first:
             dw = _on_side_stream(fn_new, held)
-            weight.__dict__["_dsf_pass"] = (task, dw, _LAST_IDX[0])
+            weight.__dict__["_dsf_pass"] = (task, dw)
             return dw
         if rec[1] is not None and fn_add is not None and not L.deterministic() and MATH == "x6":
             acc = rec[1]
-            _on_side_stream(lambda: fn_add(acc), held, idx=rec[2])      # same stream as the launch that created the buffer
+            _on_side_stream(lambda: fn_add(acc), held)
             return False
     # main stream: whatever reads this gradient next (the engine's add of two contributions, AccumulateGrad's add into an
     # existing .grad) may also read a pending one of the side stream
     join_side_streams()
     if task >= 0:
-        weight.__dict__["_dsf_pass"] = (task, None, 0)    # the rest of this pass stays on the main stream for this weight
+        weight.__dict__["_dsf_pass"] = (task, None)    # the rest of this pass stays on the main stream for this weight
     return fn_new()
 
 
@@ -521,18 +519,13 @@ def _side_ok(weight):
     return True
 
 
-def _on_side_stream(fn, inputs, idx=None):
-    """Runs ``fn`` on one of the weight-gradient streams (round robin over WRW_STREAMS of them: consecutive launches are
-    independent, so the tail of one -- the last workgroups and their atomics -- overlaps the start of the next; ``idx`` pins the
-    stream, for launches that add into a buffer an earlier launch created)."""
+def _on_side_stream(fn, inputs):
+    # (ONE weight-gradient stream: taking turns over two or three of them, so that one launch's tail overlaps the next one's
+    #  start, measured 20.17 / 20.02 ms per step against 19.83-19.91 with one -- the launches then compete with each other)
     cur = torch.cuda.current_stream()
-    pool = _SIDE.get(cur.device)
-    if pool is None:
-        pool = _SIDE[cur.device] = [torch.cuda.Stream(device=cur.device, priority=WRW_PRIORITY) for _ in range(max(1, WRW_STREAMS))]
-    if idx is None:
-        idx = _RR[0] = (_RR[0] + 1) % len(pool)
-    _LAST_IDX[0] = idx
-    side = pool[idx % len(pool)]
+    side = _SIDE.get(cur.device)
+    if side is None:
+        side = _SIDE[cur.device] = torch.cuda.Stream(device=cur.device, priority=WRW_PRIORITY)
     side.wait_stream(cur)
     with torch.cuda.stream(side):
         out = fn()
@@ -559,9 +552,8 @@ def join_side_streams():
     """Orders the current stream(s) behind every backward-weights launch still running on the side stream."""
     if _PENDING[0]:
         _PENDING[0] = False
-        for dev, pool in _SIDE.items():
-            for side in pool:
-                torch.cuda.current_stream(dev).wait_stream(side)
+        for dev, side in _SIDE.items():
+            torch.cuda.current_stream(dev).wait_stream(side)
         del _HELD[:]
 
 

@@ -44,7 +44,7 @@ def _workspace(device, C):
 
 
 # ---- accumulation rows of the finalise-free BatchNorm passes (dsf_bn_forward_acc / dsf_bn_backward_acc) ----------------
-# Each pass needs a ZEROED block of dsf_bn_acc_rows() x 2C floats.  ``with stat_pool(n_floats, device):`` around one forward +
+# Each pass needs a ZEROED block of dsf_bn_acc_rows() x 2C doubles.  ``with stat_pool(n_floats, device):`` around one forward +
 # backward of a step provides them from ONE zero fill (as nn_conv.grad_pool does for the weight gradients); without an open
 # pool, when it runs out, or in deterministic mode (float atomics build the rows) the layers take the ordered-partials path
 # with its finalise launches.  DSF_BN_ACC=0 switches the pool off.
@@ -61,7 +61,7 @@ class stat_pool:
         global _ACC_POOL
         self.saved = _ACC_POOL
         if _ACC_POOL is None and self.n > 0 and ACC[0] and torch.device(self.device).type == "cuda" and not L.deterministic():
-            _ACC_POOL = [torch.zeros(self.n, device=self.device, dtype=torch.float32), 0]
+            _ACC_POOL = [torch.zeros(self.n, device=self.device, dtype=torch.float64), 0]
         return self
 
     def __exit__(self, *a):
@@ -88,7 +88,7 @@ def _acc_take(C, device):
 
 
 def stat_floats(module, applications=1):
-    """pool size for ``applications`` forward + backward passes over ``module``: two blocks per fused BatchNorm and pass"""
+    """pool size (in doubles) for ``applications`` forward + backward passes over ``module``: two blocks per fused BatchNorm and pass"""
     return applications * sum(2 * acc_rows() * 2 * m.num_features for m in module.modules()
                               if isinstance(m, FusedBatchNorm2d) and supported(m.num_features))
 

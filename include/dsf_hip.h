@@ -456,13 +456,13 @@ int dsf_bn_forward_from_stats(const float* x, const float* residual, const float
 
 /* ----------------------------------------------------------------------------------
  * The same BatchNorm passes (reference model/resnet.py:18-98: conv -> BatchNorm2d (+ skip)(+ ReLU), training mode) WITHOUT the
- * finalise launches -- the default, float-atomic mode.  `acc` is a caller-ZEROED block of dsf_bn_acc_rows() rows [row][2][C]
- * floats: the statistics pass (dsf_bn_forward_acc's own reduction when acc_filled == 0, or the producing convolution's
- * epilogue, dsf_conv_x6_forward_bn_acc, *filled = 1) adds per-workgroup sums into row (workgroup mod rows) with float
- * atomics, and the apply kernel folds those rows in its own prologue (double, ascending), writes save_mean / save_invstd and
+ * finalise launches -- the default mode.  `acc` is a caller-ZEROED block of dsf_bn_acc_rows() rows [row][2][C]
+ * DOUBLES: the statistics pass (dsf_bn_forward_acc's own reduction when acc_filled == 0, or the producing convolution's
+ * epilogue, dsf_conv_x6_forward_bn_acc, *filled = 1) adds per-workgroup float sums into row (workgroup mod rows) with
+ * global_atomic_add_f64, and the apply kernel folds those rows in its own prologue (double, ascending), writes save_mean / save_invstd and
  * updates the running statistics: forward = 1 launch after a convolution that filled the rows (else 2), backward = 2
  * (dsf_bn_backward_acc: `acc` = a second zeroed block), against 2-3 and 3 on the ordered-partials path above.  The two paths
- * differ by the atomics' summation order only.  All three return DSF_ERR_UNSUPPORTED in deterministic mode (callers then use
+ * differ by the order of double additions only (~1e-16 on the sums).  All three return DSF_ERR_UNSUPPORTED in deterministic mode (callers then use
  * dsf_bn_forward / dsf_bn_forward_from_stats / dsf_bn_backward, which are bit-reproducible).
  * ---------------------------------------------------------------------------------- */
 int dsf_bn_acc_rows(void);
@@ -487,14 +487,14 @@ int dsf_bn_backward_apply(const float* x, const float* grad_y, const float* y, c
                           const float* save_mean, const float* save_invstd, const double* sums, const double* count, int64_t M,
                           int C, int relu, float* grad_x, float* grad_residual, dsf_stream_t stream);
 int dsf_conv_x6_forward_bn_acc(const float* X, const void* image, float* Y, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
-                               int KH, int KW, int stride, int dil, int pad_h, int pad_w, float* acc, int acc_rows, int* filled,
+                               int KH, int KW, int stride, int dil, int pad_h, int pad_w, double* acc, int acc_rows, int* filled,
                                dsf_stream_t stream);
 int dsf_bn_forward_acc(const float* x, const float* residual, const float* gamma, const float* beta, int64_t M, int C, float eps,
                        float momentum, int relu, float* running_mean, float* running_var, float* y, float* save_mean,
-                       float* save_invstd, float* acc, int acc_filled, dsf_stream_t stream);
+                       float* save_invstd, double* acc, int acc_filled, dsf_stream_t stream);
 int dsf_bn_backward_acc(const float* x, const float* grad_y, const float* y, const float* gamma, const float* beta,
                         const float* save_mean, const float* save_invstd, int64_t M, int C, int relu, float* grad_x,
-                        float* grad_residual, float* grad_gamma, float* grad_beta, float* acc, dsf_stream_t stream);
+                        float* grad_residual, float* grad_gamma, float* grad_beta, double* acc, dsf_stream_t stream);
 
 /* ----------------------------------------------------------------------------------
  * Training-phase augmentation of cropped frames: `loader.augmentCrop`

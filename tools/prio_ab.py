@@ -38,7 +38,7 @@ def run(variant, n):
     nn_conv.join_side_streams(); torch.cuda.synchronize()
     nn_conv._SIDE.clear()
     if variant == "e" and low_ext is not None:
-        nn_conv._SIDE[torch.device("cuda", torch.cuda.current_device())] = [low_ext]
+        nn_conv._SIDE[torch.device("cuda", torch.cuda.current_device())] = low_ext
     nn_conv.WRW_STREAM[0] = variant != "d"
     nn_conv.WRW_PRIORITY = lo if variant == "b" else 0
     ctx = torch.cuda.stream(high) if variant == "c" else torch.cuda.stream(torch.cuda.current_stream())
