@@ -208,7 +208,8 @@ def crop_kernel_roofline(render, B, launches=200):
         xn, yn = (-X * fxn) / Z, (-Y * fyn) / Z                                  # px' = py' = 0 for this camera (A.1)
         fv = mano.faces_i32.long()
         fx3, fy3 = xn[:, fv], yn[:, fv]                                          # (B,F,3)
-        box = lambda lo, hi: ((0.5 * (S * (1 - hi) - 1)).clamp(min=-4).ceil() - 1).clamp(min=0), ((0.5 * (S * (1 - lo) - 1)).clamp(max=S + 4).floor() + 1).clamp(max=S - 1)
+        box = lambda lo, hi: (((0.5 * (S * (1 - hi) - 1)).clamp(min=-4).ceil() - 1).clamp(min=0),
+                              ((0.5 * (S * (1 - lo) - 1)).clamp(max=S + 4).floor() + 1).clamp(max=S - 1))
         xlo, xhi = box(fx3.amin(-1), fx3.amax(-1))
         ylo, yhi = box(fy3.amin(-1), fy3.amax(-1))
         jj, ii = torch.meshgrid(torch.arange(128.0, device=verts.device), torch.arange(128.0, device=verts.device), indexing="xy")
@@ -503,18 +504,24 @@ def main():
         from dsf_amd.train_step import GraphedStep
         g = GraphedStep(step, w["tgt"])
         run = lambda: g(w["tgt"])
-    for _ in range(args.warmup):
-        run()
-    if world > 1:
-        dist.barrier()
+    # DSF_MAIN_PRIORITY=-1 (A/B aid): the training loop on a HIGH-priority stream, so that the weight-gradient stream is the lower one
+    import contextlib
+    prio = int(os.environ.get("DSF_MAIN_PRIORITY", "0"))
+    loop_stream = torch.cuda.stream(torch.cuda.Stream(priority=prio)) if prio else contextlib.nullcontext()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, _ = run()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    with loop_stream:
+        for _ in range(args.warmup):
+            run()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss, _ = run()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -45,6 +45,10 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
     // (x - mean) * (invstd * gamma) + beta > 0 -- bit-identical to the forward, and y is not read (nor kept) at all
     __shared__ float s_part[2][256 * 4];
     const int t = threadIdx.x;
+    // blockIdx.z: independent (M, C) matrices stacked in memory, each with its own accumulation block (instance
+    // normalisation: one per sample; 1 for BatchNorm)
+    x += (int64_t)blockIdx.z * M * C;
+    if (acc_rows) part += (int64_t)blockIdx.z * acc_rows * 2 * C * 2;         // (doubles: two floats each)
     // float4 columns: a workgroup covers a block of c4b <= 256 of them (blockIdx.y: C > 1024 takes several blocks)
     const int c4b = min(C >> 2, 256);             // 256 % c4b == 0
     const int lcol = t % c4b, rl = t / c4b;
@@ -204,6 +208,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     const int64_t i0 = blockIdx.x * (int64_t)256 + threadIdx.x;
     const int c = (int)(i0 % c4n) * 4;
     float sc[4], sh[4], mu[4];
+    if (FOLD && gridDim.y > 1) {                               // blockIdx.y: stacked matrices of n4 float4 each (instance normalisation)
+        x += (int64_t)blockIdx.y * n4 * 4; y += (int64_t)blockIdx.y * n4 * 4;
+        if (res) res += (int64_t)blockIdx.y * n4 * 4;
+        rows += (int64_t)blockIdx.y * n_rows * 2 * C;
+    }
     if (FOLD) {
         double s0[4], s1[4];
         bn_fold_rows(rows, n_rows, C, c, s0, s1);
@@ -216,7 +225,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
             mu[k] = (float)m;
             sc[k] = is * (gamma ? gamma[c + k] : 1.f);
             sh[k] = beta ? beta[c + k] : 0.f;
-            if (i0 < c4n) {
+            if (i0 < c4n && fin.mean) {
                 fin.mean[c + k] = (float)m;
                 fin.invstd[c + k] = is;
                 if (fin.running_mean) {
@@ -623,6 +632,72 @@ extern "C" int dsf_bn_backward_apply(const float* x, const float* grad_y, const 
     const int64_t n4 = M * (C >> 2);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(bn_apply_grid(n4, C)), dim3(256), 0, (hipStream_t)stream, x, grad_y, y, save_mean,
                        save_invstd, gamma, beta, sums, M, n4, C, relu, grad_x, grad_residual, nullptr, 0, fin, count);
+    return dsf_launch_status();
+}
+
+// ---- InstanceNorm2d (affine = False, no running statistics) (+ residual) (+ ReLU) on NHWC, inference ------------------------
+// (the frozen Consis-CycleGAN generator, reference render_model/transfer.py:393-448: 23 of them per 128x128 image).  x (B, HW, C):
+// one statistics pass with the sample as a grid dimension (per-sample sums added into acc [B][1][2][C] doubles, caller-zeroed)
+// and one apply pass that turns them into mean / invstd in its prologue.  torch runs it as batch_norm over a (1, B C, H, W) view:
+// two kernels plus two layout copies around them, ~10x the time.
+extern "C" int dsf_instnorm_forward(const float* x, const float* residual, int B, int64_t HW, int C, float eps, int relu, float* y,
+                                    double* acc, dsf_stream_t stream) {
+    DSF_CHECK_ARG(x && y && acc && B >= 0 && HW > 0);
+    if (!bn_shape_ok(C) || B > 65535) return DSF_ERR_UNSUPPORTED;
+    if (B == 0) return DSF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int rows = bn_rows_per_wg(HW, C);
+    const int wgs = (int)((HW + rows - 1) / rows);
+    hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(wgs, bn_col_blocks(C), B), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr,
+                       nullptr, HW, C, 0, rows, reinterpret_cast<float*>(acc), 1);
+    BnFinal fin = {eps, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const int64_t n4 = HW * (C >> 2);
+    hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(bn_apply_grid(n4, C), B), dim3(256), 0, st, x, residual, nullptr, nullptr, nullptr,
+                       nullptr, n4, C, relu, y, acc, 1, HW, fin);
+    return dsf_launch_status();
+}
+
+// ---- nn.ReflectionPad2d on NHWC (the generator's padding, transfer.py:409,428-444): y (B, H + 2p, W + 2p, C) ---------------------
+__global__ __launch_bounds__(256) void reflect_pad_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C4,
+                                                          int pad, int64_t n4) {
+    const int Ho = H + 2 * pad, Wo = W + 2 * pad;
+    for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        int64_t q = i / C4;
+        const int ox = (int)(q % Wo); q /= Wo;
+        const int oy = (int)(q % Ho); const int64_t b = q / Ho;
+        int iy = oy - pad, ix = ox - pad;
+        iy = iy < 0 ? -iy : (iy >= H ? 2 * H - 2 - iy : iy);
+        ix = ix < 0 ? -ix : (ix >= W ? 2 * W - 2 - ix : ix);
+        reinterpret_cast<float4*>(y)[i] = reinterpret_cast<const float4*>(x)[((b * H + iy) * W + ix) * C4 + c];
+    }
+}
+__global__ __launch_bounds__(256) void reflect_pad_scalar_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C,
+                                                                 int pad, int64_t n) {
+    const int Ho = H + 2 * pad, Wo = W + 2 * pad;
+    for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        int64_t q = i / C;
+        const int ox = (int)(q % Wo); q /= Wo;
+        const int oy = (int)(q % Ho); const int64_t b = q / Ho;
+        int iy = oy - pad, ix = ox - pad;
+        iy = iy < 0 ? -iy : (iy >= H ? 2 * H - 2 - iy : iy);
+        ix = ix < 0 ? -ix : (ix >= W ? 2 * W - 2 - ix : ix);
+        y[i] = x[((b * H + iy) * W + ix) * C + c];
+    }
+}
+extern "C" int dsf_reflect_pad_nhwc(const float* x, float* y, int B, int H, int W, int C, int pad, dsf_stream_t stream) {
+    DSF_CHECK_ARG(x && y && B >= 0 && H > 0 && W > 0 && C > 0 && pad >= 0 && pad < H && pad < W);
+    if (B == 0) return DSF_OK;
+    const int64_t n = (int64_t)B * (H + 2 * pad) * (W + 2 * pad) * C;
+    if ((C & 3) == 0) {
+        const int64_t n4 = n / 4;
+        hipLaunchKernelGGL(reflect_pad_kernel, dim3((unsigned)((n4 + 1023) / 1024 > 8192 ? 8192 : (n4 + 1023) / 1024)), dim3(256), 0,
+                           (hipStream_t)stream, x, y, H, W, C >> 2, pad, n4);
+    } else {
+        hipLaunchKernelGGL(reflect_pad_scalar_kernel, dim3((unsigned)((n + 1023) / 1024 > 8192 ? 8192 : (n + 1023) / 1024)), dim3(256), 0,
+                           (hipStream_t)stream, x, y, H, W, C, pad, n);
+    }
     return dsf_launch_status();
 }
 

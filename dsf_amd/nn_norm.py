@@ -327,6 +327,28 @@ class FusedSyncBatchNorm2d(FusedBatchNorm2d):
                                      self.momentum, relu, self.process_group, part, rows)
 
 
+def instance_norm_act(x, residual=None, relu=False, eps=1e-5):
+    """``nn.InstanceNorm2d(affine=False, track_running_stats=False)(x)`` (+ residual) (+ ReLU) on the HIP passes, inference only
+    (no autograd): the frozen transfer generator's normalisation.  x (B,C,H,W) channels_last."""
+    x = x.contiguous(memory_format=CL)
+    B, C, H, W = x.shape
+    res = residual.contiguous(memory_format=CL) if residual is not None else None
+    y = torch.empty_like(x, memory_format=CL)
+    acc = torch.zeros(B * 2 * C, device=x.device, dtype=torch.float64)
+    check(L.lib().dsf_instnorm_forward(_p(x), _p(res), I(B), I64(H * W), I(C), CF(eps), I(int(relu)), _p(y), _p(acc), stream_ptr()),
+          "dsf_instnorm_forward")
+    return y
+
+
+def reflect_pad(x, pad):
+    """``nn.ReflectionPad2d(pad)`` on a channels_last tensor, staying channels_last (torch's kernel is NCHW: two layout copies)"""
+    x = x.contiguous(memory_format=CL)
+    B, C, H, W = x.shape
+    y = torch.empty((B, C, H + 2 * pad, W + 2 * pad), device=x.device, dtype=torch.float32, memory_format=CL)
+    check(L.lib().dsf_reflect_pad_nhwc(_p(x), _p(y), I(B), I(H), I(W), I(C), I(pad), stream_ptr()), "dsf_reflect_pad_nhwc")
+    return y
+
+
 def bn_act(bn, x, residual=None, relu=False):
     """bn(x) (+ residual) (relu) for either the fused module or a plain nn.BatchNorm2d (CPU twin)."""
     if isinstance(bn, FusedBatchNorm2d):

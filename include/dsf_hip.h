@@ -475,6 +475,14 @@ int dsf_bn_acc_rows(void);
  * dsf_bn_backward_sums (sum g, sum g xhat of this replica; grad_gamma / grad_beta are the replica's own share, averaged
  * later with every other gradient) -> all-reduce of 2C doubles -> dsf_bn_backward_apply with `count` = the device address
  * of the global element count (sums[2C] of the forward).  No host synchronisation anywhere. */
+/* Inference-time pieces of the frozen Consis-CycleGAN generator (reference render_model/transfer.py:393-448, the network
+ * Trainer.Pretrain / FinetuneStage push every synthetic image through, train_render.py:428-435, 633-639), NHWC:
+ * dsf_instnorm_forward = nn.InstanceNorm2d(affine=False, track_running_stats=False)(x) (+ residual) (+ ReLU); x, y, residual
+ * (B, HW, C) f32, acc = B x 2C doubles of caller-zeroed scratch (per-sample sums); biased variance, eps as torch.
+ * dsf_reflect_pad_nhwc = nn.ReflectionPad2d(pad): x (B,H,W,C) -> y (B,H+2pad,W+2pad,C), pad < H, W. */
+int dsf_instnorm_forward(const float* x, const float* residual, int B, int64_t HW, int C, float eps, int relu, float* y,
+                         double* acc, dsf_stream_t stream);
+int dsf_reflect_pad_nhwc(const float* x, float* y, int B, int H, int W, int C, int pad, dsf_stream_t stream);
 int dsf_bn_local_sums(const float* x, int64_t M, int C, const float* part, int rows, double* sums, double* workspace,
                       dsf_stream_t stream);
 int dsf_bn_forward_from_sums(const float* x, const float* residual, const float* gamma, const float* beta, int64_t M, int C,

@@ -321,6 +321,8 @@ def test_pretrain_and_config4_multiview_step_vs_oracle(render, orender, backbone
             for q in net_gpu.parameters():
                 q.grad = None
             runner = pinned if flips else step
+            if flips:
+                pinned.render.__dict__["calls"] = 0                     # replay the pinned bridge images from the first
             loss_d, _ = runner.loss(p.cuda(), cube.cuda(), draws_to(d, "cuda"))
             loss_d.backward()
         finally:

@@ -120,3 +120,45 @@ def test_consis_cyclegan_step_vs_torch(gan_mode):
         loss, terms = sg(real_A.cuda(), real_B.cuda(), (alphas[0].cuda(), alphas[1].cuda()))
     assert torch.isfinite(loss) and all(torch.isfinite(v) for v in terms.values())
     assert any((p.detach() != q).any() for p, q in zip(nets_g[0].parameters(), before))
+
+
+@pytest.mark.parametrize("B,C,H,pad,res,relu", [(3, 64, 32, 3, False, True), (2, 256, 16, 1, True, False), (5, 128, 24, 1, False, False),
+                                                (2, 1, 20, 3, False, False), (1, 1024, 6, 2, True, True)])
+def test_instance_norm_and_reflect_pad_kernels_vs_torch(B, C, H, pad, res, relu):
+    """dsf_instnorm_forward / dsf_reflect_pad_nhwc (the frozen generator's inference passes, reference transfer.py:393-448)
+    against torch's InstanceNorm2d / ReflectionPad2d on the CPU."""
+    from dsf_amd import nn_norm
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(B, C, H, H + 3, generator=g) * 2 + 0.7
+    r = torch.randn(B, C, H, H + 3, generator=g) if res else None
+    assert torch.equal(nn_norm.reflect_pad(x.cuda(), pad).cpu(), torch.nn.ReflectionPad2d(pad)(x))        # a gather: bit-equal
+    if C >= 4:
+        ref = torch.nn.InstanceNorm2d(C)(x)
+        if res:
+            ref = ref + r
+        if relu:
+            ref = torch.relu(ref)
+        got = nn_norm.instance_norm_act(x.cuda(), r.cuda() if res else None, relu).cpu()
+        assert (got - ref).abs().max() < 1e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_frozen_generator_fused_inference_equals_the_module_path():
+    """The no-grad pass of the transfer generator (what Trainer.Pretrain / FinetuneStage run, train_render.py:428-435) on the
+    HIP padding / instance-norm passes against the same network through torch's modules, and against the CPU twin."""
+    from dsf_amd.render_model import transfer as T
+    cpu, gpu = _pair(lambda: T.define_G(1, 1, 64, 'resnet_9blocks', 'instance', False, 'xavier'), 8)
+    cpu.eval(); gpu.eval()
+    x = torch.rand(3, 1, 128, 128, generator=torch.Generator().manual_seed(9)) * 2 - 1
+    with torch.no_grad():
+        ref = cpu(x)
+        fused = gpu(x.cuda()).cpu()
+        T.FUSED_INFERENCE[0] = False
+        try:
+            plain = gpu(x.cuda()).cpu()
+        finally:
+            T.FUSED_INFERENCE[0] = True
+    assert fused.shape == ref.shape == (3, 1, 128, 128)
+    assert (fused - plain).abs().max() < 2e-4 and (fused - ref).abs().max() < 2e-3
+    # with autograd on the generator runs through the modules (its training step, ConsisCycleGANStep, needs the backward pass)
+    y = gpu(x.cuda().requires_grad_(True))
+    y.mean().backward()
