@@ -471,6 +471,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay forward+backward from a HIP graph (train_step.GraphedStep; "
                     "single GPU): same kernels, no host issue -- pays below batch 16, where the step is host-bound")
+    ap.add_argument("--no-graph", action="store_true", help="config 3 only: the eager step instead of its default HIP-graph replay")
     ap.add_argument("--cpu-steps", type=int, default=0, help="steps of the CPU baseline leg (0: sized per config to ~10-30 s)")
     args = ap.parse_args()
 
@@ -498,6 +499,9 @@ def main():
     PMC_CONFIG[0] = args.config
     w = build_workload(args, dev, rank, world)
     step, run = w["step"], w["run"]
+    # config 3 is host-bound in eager mode (1,400+ launches of 10-60 us kernels per step): its default is the HIP-graph replay
+    if args.config == 3 and not args.no_graph:
+        args.graph = True
     if args.graph:
         if args.config not in (2, 3):
             raise SystemExit("--graph: configs 2 and 3 (steps without a host decision); with --gpus N the bucket all-reduces follow each replay")
