@@ -51,15 +51,15 @@ def _rotmat(rot):
 
 def RotationPoints(verts, joints, center3d, rot):
     """Rotate about ``center3d`` (reference :874-884)."""
-    R = _rotmat(rot).unsqueeze(1)
+    # (B, V, 3) x (B, 3, 3)^T as ONE batched product per tensor: the reference's broadcast form, matmul((B,1,3,3), (B,V,3,1)), is a
+    # bmm over B*V 3x3 matrices -- 149,568 of them at config 4's 192 meshes, 1.07 ms per call in hipBLASLt (round-2 profile)
+    Rt = _rotmat(rot).transpose(1, 2)
     c = center3d.unsqueeze(1)
-    rv = torch.matmul(R, (verts - c).unsqueeze(-1)).squeeze(-1)
-    rj = torch.matmul(R, (joints - c).unsqueeze(-1)).squeeze(-1)
-    return rv + c, rj + c
+    return torch.bmm(verts - c, Rt) + c, torch.bmm(joints - c, Rt) + c
 
 
 def RotationNormalPoints(points, rot):
-    return torch.matmul(_rotmat(rot).unsqueeze(1), points.unsqueeze(-1)).squeeze(-1)
+    return torch.bmm(points, _rotmat(rot).transpose(1, 2))
 
 
 def _collision_mask():
