@@ -96,7 +96,7 @@ def conv_kernel_roofline(step, run_once):
     if step.grad_sync is not None:
         step.grad_sync.enabled = False          # rank-0-only diagnostic step: no collectives
     run_once()
-    if step.grad_sync is not None:
+    if step.grad_sync is not None and dist.is_initialized():
         step.grad_sync.enabled = True
     torch.cuda.synchronize()
     recs, nn_conv.RECORD = nn_conv.RECORD, None
@@ -162,7 +162,7 @@ def same_step_on_fp32_mfma(step, tgt, B, steps=10, warmup=3):
         dt = (time.perf_counter() - t0) / steps
     finally:
         nn_conv.MATH = "x6"
-        if step.grad_sync is not None:
+        if step.grad_sync is not None and dist.is_initialized():
             step.grad_sync.enabled = True
     return {"value": round(B / dt, 2), "unit": "images/s per GPU", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
             "note": "same step, convolutions on the fp32 MFMA kernels (peak 157.3 TFLOP/s); both paths agree with float64 to "
@@ -532,6 +532,14 @@ def main():
         dt = float(tmax.item())
     loss_val = float(loss)
     facts = distributed_facts(world, dev, rccl_log)
+    if world > 1:
+        # every rank leaves the process group HERE, together: rank 0's single-rank diagnostics below (kernel replays, the fp32-MFMA
+        # comparison step: ~10 s, no collectives, the reducer switched off) must not run while the other ranks wait inside a
+        # collective teardown under RCCL's watchdog
+        if step.grad_sync is not None:
+            step.grad_sync.enabled = False
+        dist.barrier()
+        dist.destroy_process_group()
 
     if rank == 0:
         B = w["units_per_step"]
@@ -573,8 +581,6 @@ def main():
                                    "sample": "%d images: %s through the CPU oracle (torch-CPU trunk, C rasteriser / point-face "
                                              "distances, numpy crop chain), %.1f s" % (n, what, secs)}
         print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
