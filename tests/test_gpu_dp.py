@@ -197,3 +197,24 @@ def test_graphed_step_with_gradient_all_reduce_equals_the_eager_data_parallel_st
     assert np.isfinite(l0) and np.isfinite(l1)
     assert np.array_equal(e0, e1) and np.array_equal(g0, g1)       # ranks in lockstep, eager and graphed
     assert np.array_equal(e0, g0)                                   # deterministic mode: the graphed trajectory IS the eager one
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_bench_two_ranks_on_one_gpu_flow(graph):
+    """`bench.py --gpus 2` under torch.distributed.run, both ranks on the one GPU of the test box (gloo transport): the ranks time
+    the step together, leave the process group together, rank 0 alone runs its diagnostics and prints ONE JSON line with
+    n_gpus 2; with --graph the forward + backward pass is replayed from a HIP graph and the bucket all-reduces follow it."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DSF_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "4", "--no-cpu-baseline"] + (["--graph"] if graph else [])
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 8 and j["config"]["hip_graph"] == graph
+    assert j["distributed"]["world_size_observed"] == 2 and j["value"] > 0 and "roofline" in j
