@@ -22,7 +22,8 @@ class _Factory:
 
 
 _L = _Factory()
-FUSED_INFERENCE = [True]       # the no-grad generator pass on the HIP padding / instance-norm kernels (False: torch modules)
+import os
+FUSED_INFERENCE = [os.environ.get("DSF_GEN_FUSED", "1") == "1"]    # the no-grad generator pass on the HIP padding / instance-norm kernels (False: torch modules)
 
 
 class ResnetBlock(nn.Module):
