@@ -327,14 +327,16 @@ class FusedSyncBatchNorm2d(FusedBatchNorm2d):
                                      self.momentum, relu, self.process_group, part, rows)
 
 
-def instance_norm_act(x, residual=None, relu=False, eps=1e-5):
+def instance_norm_act(x, residual=None, relu=False, eps=1e-5, acc=None):
     """``nn.InstanceNorm2d(affine=False, track_running_stats=False)(x)`` (+ residual) (+ ReLU) on the HIP passes, inference only
-    (no autograd): the frozen transfer generator's normalisation.  x (B,C,H,W) channels_last."""
+    (no autograd): the frozen transfer generator's normalisation.  x (B,C,H,W) channels_last; ``acc``: B * 2C zeroed doubles of
+    scratch (a slice of one buffer zeroed for the whole network pass), allocated here when None."""
     x = x.contiguous(memory_format=CL)
     B, C, H, W = x.shape
     res = residual.contiguous(memory_format=CL) if residual is not None else None
     y = torch.empty_like(x, memory_format=CL)
-    acc = torch.zeros(B * 2 * C, device=x.device, dtype=torch.float64)
+    if acc is None:
+        acc = torch.zeros(B * 2 * C, device=x.device, dtype=torch.float64)
     check(L.lib().dsf_instnorm_forward(_p(x), _p(res), I(B), I64(H * W), I(C), CF(eps), I(int(relu)), _p(y), _p(acc), stream_ptr()),
           "dsf_instnorm_forward")
     return y

@@ -41,7 +41,7 @@ def _fusable_norm(m):
     return isinstance(m, nn.InstanceNorm2d) and not m.affine and not m.track_running_stats
 
 
-def _fused_inference(seq, x, residual=None):
+def _fused_inference(seq, x, residual=None, pool=None):
     """``seq(x)`` (+ residual behind its last layer) for a stack of [ReflectionPad2d, conv, InstanceNorm2d, ReLU, ResnetBlock, Tanh]
     layers on the HIP inference passes: padding and instance normalisation (+ skip)(+ ReLU) stay channels_last and run as one and
     two launches (nn_norm.reflect_pad / instance_norm_act) where torch needs NCHW kernels between channels_last convolutions
@@ -49,6 +49,16 @@ def _fused_inference(seq, x, residual=None):
     requires a gradient (the generator is frozen inside the trainer steps, train_render.py:428-435); same arithmetic, fp32."""
     from .. import nn_norm
     mods = list(seq)
+    if pool is None:
+        # one zero fill for the per-sample statistics of every instance norm of the pass (B x 2C doubles each; <= 256 channels here)
+        n_norm = sum(1 for m in seq.modules() if _fusable_norm(m))
+        pool = [torch.zeros(n_norm * x.shape[0] * 2 * 256, device=x.device, dtype=torch.float64), 0]
+
+    def take(n):
+        if pool[1] + n > pool[0].numel():
+            return None
+        pool[1] += n
+        return pool[0][pool[1] - n:pool[1]]
     i = 0
     while i < len(mods):
         m = mods[i]
@@ -58,12 +68,12 @@ def _fused_inference(seq, x, residual=None):
         elif _fusable_norm(m) and nn_norm.supported(x.shape[1]):
             relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
             tail = last or (relu and i + 2 == len(mods))
-            x = nn_norm.instance_norm_act(x, residual if tail else None, relu, m.eps)
+            x = nn_norm.instance_norm_act(x, residual if tail else None, relu, m.eps, acc=take(x.shape[0] * 2 * x.shape[1]))
             if tail:
                 residual = None
             i += 1 if relu else 0
         elif isinstance(m, ResnetBlock):
-            x = _fused_inference(m.conv_block, x, residual=x)
+            x = _fused_inference(m.conv_block, x, residual=x, pool=pool)
         else:
             x = m(x)
         i += 1
