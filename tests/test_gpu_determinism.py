@@ -324,3 +324,31 @@ def test_backward_weights_side_stream_is_invisible(det_mode):
     # 3 convolutions + 1 transposed; a net used twice (deterministic mode): each weight's first contribution only, the second
     # joins the streams and runs on the main one; the standard-layout weight never (the two convolutions below it do)
     assert n_one == 4 and n_two == 4 and n_std == 2
+
+
+def test_backward_on_a_worker_thread_matches_the_main_thread(det_mode):
+    """The weight-gradient stream's bookkeeping (module-level lists, the per-pass record on the weight, the engine callback) is
+    driven from whichever thread runs the backward pass: a backward pass started on a worker thread -- autograd then runs the
+    device's nodes on its own engine thread -- gives bitwise the gradients of the main-thread run, repeatedly."""
+    import threading
+    from dsf_amd import nn_conv, nn_norm
+    torch.manual_seed(4)
+    net = torch.nn.Sequential(nn_conv.Conv2d(32, 64, 3, 1, 1, bias=False), nn_norm.FusedBatchNorm2d(64, fuse_relu=True),
+                              nn_conv.Conv2d(64, 64, 3, 2, 1, bias=True), nn_conv.ConvTranspose2d(64, 32, 4, stride=2, padding=1, bias=False)).cuda()
+    nn_conv.weights_changed()
+    x = torch.randn(6, 32, 24, 24, device="cuda")
+
+    def run(out):
+        net.zero_grad(set_to_none=True)
+        net(x).square().mean().backward()
+        torch.cuda.synchronize()
+        out.append([p.grad.clone() for p in net.parameters()])
+    ref = []
+    run(ref)
+    for _ in range(3):
+        got = []
+        th = threading.Thread(target=run, args=(got,))
+        th.start(); th.join(timeout=120)
+        assert got, "the worker thread did not finish"
+        for a, b in zip(ref[0], got[0]):
+            assert torch.equal(a, b)
