@@ -677,8 +677,12 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
     const bool a_kok = a_k < K;
     const int a_tap = min(a_k, K - 1) / p.Ci;
     const int a_c = min(a_k, K - 1) % p.Ci, a_kh = a_tap / p.KW, a_kw = a_tap % p.KW;
-    const int b_n = n0 + l_q * 4;
-    const bool b_nok = b_n < p.Co && l_q * 4 < BN;
+    // dY tile: BN 128: as the X tile (channel quad l_q, pixels l_p and l_p + 8: two pieces);  BN 64: the tile holds 16 x 16 float4,
+    // exactly one per thread (channel quad t & 15, pixel t >> 4: ONE piece -- round 2 issued two half-masked ones and split both)
+    constexpr int NPC = (BN == 128) ? 4 : 3;             // loader pieces per chunk
+    const int b_q = (BN == 128) ? l_q : (t & 15), b_p = (BN == 128) ? l_p : (t >> 4);
+    const int b_n = n0 + b_q * 4;
+    const bool b_nok = b_n < p.Co;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -691,7 +695,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
     u32x4 rl[2][4];                                      // [set][A px 0, A px 8, B px 0, B px 8]
     auto load_piece = [&](auto SET, int j, int mc) {     // rows past m_end get the out-of-range offset (zeros)
         constexpr int S = decltype(SET)::value;
-        const int m = mc + l_p + 8 * (j & 1);
+        const int m = (j < 2) ? mc + l_p + 8 * j : mc + b_p + 8 * (j - 2);
         if (j < 2) {
             const uint32_t mm = (uint32_t)min(m, M - 1);
             const uint32_t q = x6_fast_div(mm, magic_wo);
@@ -709,11 +713,12 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
         }
     };
     const int st_off0 = x6_tr_off(l_p, l_q >> 1) + 8 * (l_q & 1), st_off1 = x6_tr_off(l_p + 8, l_q >> 1) + 8 * (l_q & 1);
+    const int st_offb0 = x6_tr_off(b_p, b_q >> 1) + 8 * (b_q & 1), st_offb1 = x6_tr_off((b_p + 8) & 15, b_q >> 1) + 8 * (b_q & 1);
     auto stage_piece = [&](auto SET, int buf, int j) {
         constexpr int S = decltype(SET)::value;
         uint2 h, m, l;
         split4(rl[S][j], h, m, l);
-        char* base = (j < 2 ? As[buf] : Bs[buf]) + ((j & 1) ? st_off1 : st_off0);
+        char* base = (j < 2) ? As[buf] + (j ? st_off1 : st_off0) : Bs[buf] + ((j - 2) ? st_offb1 : st_offb0);
         *reinterpret_cast<uint2*>(base) = h;
         *reinterpret_cast<uint2*>(base + PLANE) = m;
         *reinterpret_cast<uint2*>(base + 2 * PLANE) = l;
@@ -723,11 +728,11 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
     using Set1 = std::integral_constant<int, 1>;
     if (m_begin < m_end) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) load_piece(Set0{}, j, m_begin);
+        for (int j = 0; j < NPC; ++j) load_piece(Set0{}, j, m_begin);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) load_piece(Set1{}, j, m_begin + XBK);
+        for (int j = 0; j < NPC; ++j) load_piece(Set1{}, j, m_begin + XBK);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) stage_piece(Set0{}, 0, j);
+        for (int j = 0; j < NPC; ++j) stage_piece(Set0{}, 0, j);
     }
     __syncthreads();
 
@@ -765,9 +770,9 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
         {
             // program order: fragment reads, the whole loader, the MFMAs; the pipeline below interleaves them
 #pragma unroll
-            for (int pc = 0; pc < 4; ++pc) load_piece(SET, pc, mc + 2 * XBK);
+            for (int pc = 0; pc < NPC; ++pc) load_piece(SET, pc, mc + 2 * XBK);
 #pragma unroll
-            for (int pc = 0; pc < 4; ++pc) stage_piece(OTHER, buf ^ 1, pc);
+            for (int pc = 0; pc < NPC; ++pc) stage_piece(OTHER, buf ^ 1, pc);
 #pragma unroll
             for (int q = 0; q < 6; ++q)
 #pragma unroll
@@ -776,7 +781,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][i], b[PB[q]][j], acc[i][j], 0, 0, 0);
             constexpr int NM = 6 * TM * TN;                              // 24 or 12 gaps
-            constexpr int VPG = (TM == 2) ? 5 : 10;                      // VALU per gap
+            constexpr int VPG = (TM == 2) ? 5 : 8;                       // VALU per gap
             __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);           // plane-0 fragments first
 #pragma unroll
             for (int g = 0; g < NM; ++g) {
