@@ -12,7 +12,7 @@ tot = sum(float(r["TotalDurationNs"]) for r in rows)
 j = json.loads(open("$O/${TAG}_bench_config$c.json").read().strip().splitlines()[-1])
 print("config $c: %s" % j["config"]["workload"])
 print("bench line: %.2f %s, %.3f ms per step; roofline %s frac %.4f; cpu_baseline %s" % (j["value"], j["unit"], j["ms_per_step"], j["roofline"]["kernel"], j["roofline"]["frac"], json.dumps(j.get("cpu_baseline"))))
-print("rocprofv3 --kernel-trace --stats of `bench.py --config $c --steps 6 --warmup 3 --no-cpu-baseline` (whole process: warm-up, timed steps, roofline replays), top 40 of %d kernels, %.1f ms of kernel time:" % (len(rows), tot / 1e6))
+print("rocprofv3 --kernel-trace --stats of bench.py --config $c --steps 6 --warmup 3 --no-cpu-baseline (whole process: warm-up, timed steps, roofline replays), top 40 of %d kernels, %.1f ms of kernel time:" % (len(rows), tot / 1e6))
 for r in rows[:40]:
     print("%6d x %9.1f us = %8.1f ms (%4.1f%%)  %s" % (int(r["Calls"]), float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6, 100 * float(r["TotalDurationNs"]) / tot, r["Name"][:120]))
 PY
