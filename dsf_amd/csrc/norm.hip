@@ -28,7 +28,7 @@ struct BnFinal {
     double* sums; float* dgamma; float* dbeta;
 };
 
-template <int MODE>
+template <int MODE, bool YMASK = false>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                         const float* __restrict__ y, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, const float* __restrict__ gamma,
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
     // (with acc_rows > 0 `part` is really a double array: the accumulation rows are DOUBLES, see bn_fold_rows)
     // acc_rows == 0: workgroup w stores partial row w (bn_finalize_kernel folds them in a fixed order: deterministic).
     // acc_rows  > 0: the workgroup ADDS its partial row into row (w mod acc_rows) of a zeroed [acc_rows][2][C] block of DOUBLES
-    //                with global_atomic_add_f64 (32 adders per address at 256 workgroups); the apply kernels fold those few
+    //                with global_atomic_add_f64 (64 adders per address at 512 workgroups); the apply kernels fold those few
     //                rows in their own prologue, so that no finalise launch sits between the passes.  Doubles: the float
     //                partials are then summed exactly as bn_finalize_kernel does (a double sum of <= 1024 floats is order-
     //                independent to ~1e-16), so the statistics match the ordered path to the last float bit almost always.
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
             for (int k = 0; k < 4; ++k) { a0[k] += xe[k]; a1[k] = fmaf(xe[k], xe[k], a1[k]); }
         } else {
             float ge[4] = {gv.x, gv.y, gv.z, gv.w};
-            if (relu == 1) {
+            if (YMASK) {                     // (YMASK <=> relu == 1: the launchers pick the instantiation)
                 const float ye[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) ge[k] = (ye[k] > 0.f) ? ge[k] : 0.f;
@@ -85,26 +85,24 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
             for (int k = 0; k < 4; ++k) { a0[k] += ge[k]; a1[k] = fmaf(ge[k], (xe[k] - mu[k]) * is[k], a1[k]); }
         }
     };
+    // U rows per lane in flight (forward 8 x 16 bytes of x; backward 4 of x, of gy, and of y with a saved-output mask): with one workgroup per CU
+    // the pass is latency-bound on what a wave keeps outstanding (4 rows: 2.8 TB/s on a 34 MB tensor).  Rows past r1 load
+    // nothing and add zeros.
+    constexpr int U = (MODE == 0) ? 8 : 4;      // backward: 2-3 tensors per row, and the wave has to fit beside the backward-weights kernels
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    int64_t r = r0 + rl;
-    for (; r + 3 * rlanes < r1; r += 4 * rlanes) {
-        float4 xv[4], gv[4], yv[4];
+    for (int64_t r = r0 + rl; r < r1; r += (int64_t)U * rlanes) {
+        float4 xv[U], gv[U], yv[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t o = (r + u * rlanes) * C + col * 4;
-            xv[u] = *reinterpret_cast<const float4*>(x + o);
-            gv[u] = (MODE == 1) ? *reinterpret_cast<const float4*>(gy + o) : z4;
-            yv[u] = (MODE == 1 && relu == 1) ? *reinterpret_cast<const float4*>(y + o) : z4;
+        for (int u = 0; u < U; ++u) {
+            const int64_t rr = r + (int64_t)u * rlanes;
+            const bool ok = rr < r1;
+            const int64_t o = (ok ? rr : r) * C + col * 4;
+            xv[u] = ok ? *reinterpret_cast<const float4*>(x + o) : z4;
+            gv[u] = (MODE == 1 && ok) ? *reinterpret_cast<const float4*>(gy + o) : z4;
+            yv[u] = (YMASK && ok) ? *reinterpret_cast<const float4*>(y + o) : z4;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) accumulate(xv[u], gv[u], yv[u]);
-    }
-    for (; r < r1; r += rlanes) {
-        const int64_t o = r * C + col * 4;
-        const float4 xv = *reinterpret_cast<const float4*>(x + o);
-        const float4 gv = (MODE == 1) ? *reinterpret_cast<const float4*>(gy + o) : z4;
-        const float4 yv = (MODE == 1 && relu == 1) ? *reinterpret_cast<const float4*>(y + o) : z4;
-        accumulate(xv, gv, yv);
+        for (int u = 0; u < U; ++u) accumulate(xv[u], gv[u], yv[u]);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) { s_part[0][t * 4 + k] = a0[k]; s_part[1][t * 4 + k] = a1[k]; }
@@ -169,103 +167,159 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     }
 }
 
-// Sums of the `rows` accumulation rows [row][2][C] (doubles) for channels c .. c + 3, ascending row order.
-__device__ __forceinline__ void bn_fold_rows(const double* __restrict__ rows, int n_rows, int C, int c, double (&s0)[4], double (&s1)[4]) {
+// ---- per-workgroup channel parameters of the apply passes ---------------------------------------------------------------------
+// A workgroup's 256 threads hold only nq = min(C / 4, 256) distinct channel quads (thread t: quad (blockIdx.x * 256 + t) mod C/4).
+// Rounds 1-3 let EVERY thread fold the accumulation rows and load the per-channel vectors of its quad: 512 bytes of loads per
+// thread, 1 MB per CU through the vector L1 at 8 workgroups -- a third of the pass on the 34 MB layers.  Now the 256 / nq threads
+// that share a quad split its rows, the partial sums meet in LDS, the first nq threads ("owners") finish the arithmetic and
+// publish NP float4 per quad, and everybody reads its own.  C >= 1024: one quad per thread, nothing to share.
+constexpr int BN_FOLD_LDS = 256 * 8;               // doubles: one 8-double partial per thread; reused for the published float4s
+
+// the two folded sums of quad `c` for the owner threads (t < nq); rows [row][2][C] doubles; all threads must call
+__device__ __forceinline__ void bn_fold_rows_wg(const double* __restrict__ rows, int n_rows, int C, int nq, int c, double* s_buf,
+                                                double (&s0)[4], double (&s1)[4]) {
+    const int t = threadIdx.x, dup = 256 / nq, j = t / nq;
+    double p[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+    for (int r = j; r < n_rows; r += dup) {
+        const double2* pa = reinterpret_cast<const double2*>(rows + (int64_t)r * 2 * C + c);
+        const double2* pb = reinterpret_cast<const double2*>(rows + (int64_t)r * 2 * C + C + c);
+        const double2 a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];
+        p[0] += a0.x; p[1] += a0.y; p[2] += a1.x; p[3] += a1.y;
+        p[4] += b0.x; p[5] += b0.y; p[6] += b1.x; p[7] += b1.y;
+    }
+    const int helpers = min(dup, n_rows);
+    if (j < helpers) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s_buf[k * 256 + t] = p[k];          // [value][thread]: conflict-free
+    }
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < 4; ++k) { s0[k] = 0.0; s1[k] = 0.0; }
-    // all loads of a batch of 4 rows (16 x 16 bytes) are issued before the first add: two L2 round trips for BN_ACC_ROWS = 8
-    for (int r = 0; r < n_rows; r += 4) {
-        double2 a[4][2], b[4][2];
+    if (t < nq) {
+        for (int h = 0; h < helpers; ++h) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const bool ok = r + u < n_rows;
-            const double2* pa = reinterpret_cast<const double2*>(rows + (int64_t)(r + u) * 2 * C + c);
-            const double2* pb = reinterpret_cast<const double2*>(rows + (int64_t)(r + u) * 2 * C + C + c);
-            const double2 z = make_double2(0.0, 0.0);
-            a[u][0] = ok ? pa[0] : z; a[u][1] = ok ? pa[1] : z;
-            b[u][0] = ok ? pb[0] : z; b[u][1] = ok ? pb[1] : z;
+            for (int k = 0; k < 4; ++k) { s0[k] += s_buf[k * 256 + h * nq + t]; s1[k] += s_buf[(4 + k) * 256 + h * nq + t]; }
         }
+    }
+    __syncthreads();                                                     // s_buf is free again
+}
+
+// owners publish par[NP][4] for their quad; every thread of the quad reads it back
+template <int NP>
+__device__ __forceinline__ void bn_share_params(int nq, float (&par)[NP][4], double* s_buf) {
+    float4* s_par = reinterpret_cast<float4*>(s_buf);                    // NP * nq float4 <= 6 * 128 * 16 bytes < 16 KB
+    const int t = threadIdx.x;
+    if (t < nq) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            s0[0] += a[u][0].x; s0[1] += a[u][0].y; s0[2] += a[u][1].x; s0[3] += a[u][1].y;
-            s1[0] += b[u][0].x; s1[1] += b[u][0].y; s1[2] += b[u][1].x; s1[3] += b[u][1].y;
-        }
+        for (int q = 0; q < NP; ++q) s_par[q * nq + t] = make_float4(par[q][0], par[q][1], par[q][2], par[q][3]);
+    }
+    __syncthreads();
+    const int o = t % nq;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const float4 v = s_par[q * nq + o];
+        par[q][0] = v.x; par[q][1] = v.y; par[q][2] = v.z; par[q][3] = v.w;
     }
 }
 
 // ---- pass 2 forward: y = (x - mean) * invstd * gamma + beta (+ residual) (relu) ---------------------
 // The grid stride is a multiple of the float4 column count, so a thread's channel quad is loop-invariant.
-// FOLD: mean / invstd are not read but COMPUTED in the prologue from the accumulation rows (every thread folds the rows of
-// its own four channels: 8 rows x 2 float4, L2-resident), with bn_finalize_kernel<0>'s arithmetic; the threads that hold
-// each channel quad first (i0 < C / 4) also store mean / invstd for the backward pass and update the running statistics.
+// FOLD: mean / invstd are not read but COMPUTED in the prologue from the accumulation rows (folded once per workgroup, see
+// above), with bn_finalize_kernel<0>'s arithmetic; the owners of the first workgroup(s) (i0 < C / 4) also store mean / invstd
+// for the backward pass and update the running statistics.
+// Four float4 of x (and of the residual) are in flight per thread, and the first batch is issued BEFORE the prologue (no register
+// double buffer: the passes share the CUs with the backward-weights kernels of the second stream, which leave ~150 VGPRs per SIMD).
 template <bool FOLD>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        int64_t n4, int C, int relu, float* __restrict__ y,
                                                        const double* __restrict__ rows, int n_rows, int64_t M, BnFinal fin) {
-    const int c4n = C >> 2;
+    __shared__ double s_buf[BN_FOLD_LDS];
+    constexpr int U = 4;
+    const int c4n = C >> 2, nq = min(c4n, 256);
     const int64_t i0 = blockIdx.x * (int64_t)256 + threadIdx.x;
+    const int64_t S = (int64_t)gridDim.x * 256;
     const int c = (int)(i0 % c4n) * 4;
-    float sc[4], sh[4], mu[4];
+    const bool owner = (int)threadIdx.x < nq;
     if (FOLD && gridDim.y > 1) {                               // blockIdx.y: stacked matrices of n4 float4 each (instance normalisation)
         x += (int64_t)blockIdx.y * n4 * 4; y += (int64_t)blockIdx.y * n4 * 4;
         if (res) res += (int64_t)blockIdx.y * n4 * 4;
         rows += (int64_t)blockIdx.y * n_rows * 2 * C;
     }
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 xv[U], rv[U];
+    auto fetch = [&](int64_t i) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t j = i + u * S;
+            const bool ok = j < n4;
+            xv[u] = ok ? reinterpret_cast<const float4*>(x)[j] : z4;
+            rv[u] = (res && ok) ? reinterpret_cast<const float4*>(res)[j] : z4;
+        }
+    };
+    fetch(i0);
+    float par[3][4];                                           // mean, scale = invstd * gamma, shift = beta
     if (FOLD) {
         double s0[4], s1[4];
-        bn_fold_rows(rows, n_rows, C, c, s0, s1);
+        bn_fold_rows_wg(rows, n_rows, C, nq, c, s_buf, s0, s1);
+        if (owner) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const double m = s0[k] / (double)M;
-            double var = s1[k] / (double)M - m * m;
-            if (var < 0.0) var = 0.0;
-            const float is = (float)(1.0 / sqrt(var + (double)fin.eps));
-            mu[k] = (float)m;
-            sc[k] = is * (gamma ? gamma[c + k] : 1.f);
-            sh[k] = beta ? beta[c + k] : 0.f;
-            if (i0 < c4n && fin.mean) {
-                fin.mean[c + k] = (float)m;
-                fin.invstd[c + k] = is;
-                if (fin.running_mean) {
-                    const double unbiased = (M > 1) ? var * (double)M / (double)(M - 1) : var;
-                    fin.running_mean[c + k] = (1.f - fin.momentum) * fin.running_mean[c + k] + fin.momentum * (float)m;
-                    fin.running_var[c + k] = (1.f - fin.momentum) * fin.running_var[c + k] + fin.momentum * (float)unbiased;
+            for (int k = 0; k < 4; ++k) {
+                const double m = s0[k] / (double)M;
+                double var = s1[k] / (double)M - m * m;
+                if (var < 0.0) var = 0.0;
+                const float is = (float)(1.0 / sqrt(var + (double)fin.eps));
+                par[0][k] = (float)m;
+                par[1][k] = is * (gamma ? gamma[c + k] : 1.f);
+                par[2][k] = beta ? beta[c + k] : 0.f;
+                if (i0 < c4n && fin.mean) {
+                    fin.mean[c + k] = (float)m;
+                    fin.invstd[c + k] = is;
+                    if (fin.running_mean) {
+                        const double unbiased = (M > 1) ? var * (double)M / (double)(M - 1) : var;
+                        fin.running_mean[c + k] = (1.f - fin.momentum) * fin.running_mean[c + k] + fin.momentum * (float)m;
+                        fin.running_var[c + k] = (1.f - fin.momentum) * fin.running_var[c + k] + fin.momentum * (float)unbiased;
+                    }
                 }
             }
         }
-    } else {
+    } else if (owner) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            sc[k] = invstd[c + k] * (gamma ? gamma[c + k] : 1.f);
-            sh[k] = beta ? beta[c + k] : 0.f;
-            mu[k] = mean[c + k];
+            par[0][k] = mean[c + k];
+            par[1][k] = invstd[c + k] * (gamma ? gamma[c + k] : 1.f);
+            par[2][k] = beta ? beta[c + k] : 0.f;
         }
     }
-    for (int64_t i = i0; i < n4; i += (int64_t)gridDim.x * 256) {
-        const float4 xv = reinterpret_cast<const float4*>(x)[i];
-        const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
-        float o[4];
+    if (nq < 256) bn_share_params<3>(nq, par, s_buf);
+    for (int64_t i = i0; i < n4;) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = (xe[k] - mu[k]) * sc[k] + sh[k];
-        if (res) {
-            const float4 rv = reinterpret_cast<const float4*>(res)[i];
-            o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w;
-        }
-        if (relu) {
+        for (int u = 0; u < U; ++u) {
+            const int64_t j = i + u * S;
+            if (j >= n4) break;
+            const float xe[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+            float o[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = fmaxf(o[k], 0.f);
+            for (int k = 0; k < 4; ++k) o[k] = (xe[k] - par[0][k]) * par[1][k] + par[2][k];
+            if (res) { o[0] += rv[u].x; o[1] += rv[u].y; o[2] += rv[u].z; o[3] += rv[u].w; }
+            if (relu) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = fmaxf(o[k], 0.f);
+            }
+            reinterpret_cast<float4*>(y)[j] = make_float4(o[0], o[1], o[2], o[3]);
         }
-        reinterpret_cast<float4*>(y)[i] = make_float4(o[0], o[1], o[2], o[3]);
+        i += U * S;
+        if (i < n4) fetch(i);
     }
 }
 
 // ---- pass 2 backward: dx = gamma*invstd*(g - sum_g/M - xhat*sum_gx/M); dres = g -----------------------
-// FOLD: the two channel sums come from the accumulation rows (folded in the prologue, as in bn_apply_kernel<true>) instead of
-// the finalise launch's doubles; the threads that hold each channel quad first also store dgamma / dbeta.
+// FOLD: the two channel sums come from the accumulation rows (folded once per workgroup, as in bn_apply_kernel<true>) instead of
+// the finalise launch's doubles; the owners of the first workgroup(s) also store dgamma / dbeta.
 template <bool FOLD>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+__global__ __launch_bounds__(256, 6) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                            const float* __restrict__ y, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const double* __restrict__ acc,
@@ -273,15 +327,30 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            float* __restrict__ dres, const double* __restrict__ rows, int n_rows,
                                                            BnFinal fin, const double* __restrict__ count) {
     // count != nullptr: the divisor is the element count of the WHOLE (cross-replica) batch, read from device memory
-    const int c4n = C >> 2;
-    const float invM = count ? (float)(1.0 / count[0]) : 1.0f / (float)M;
+    __shared__ double s_buf[BN_FOLD_LDS];
+    constexpr int U = 2;                                      // (the wave has to fit beside the backward-weights kernels: ~150 VGPRs per SIMD)
+    const int c4n = C >> 2, nq = min(c4n, 256);
     const int64_t i0 = blockIdx.x * (int64_t)256 + threadIdx.x;
+    const int64_t S = (int64_t)gridDim.x * 256;
     const int c = (int)(i0 % c4n) * 4;
-    float mu[4], is[4], sg[4], sgx[4], gi[4], sc[4], sh[4];
+    const bool owner = (int)threadIdx.x < nq;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 xv[U], gv[U], yv[U];
+    auto fetch = [&](int64_t i) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t j = i + u * S;
+            const bool ok = j < n4;
+            xv[u] = ok ? reinterpret_cast<const float4*>(x)[j] : z4;
+            gv[u] = ok ? reinterpret_cast<const float4*>(gy)[j] : z4;
+            yv[u] = (relu == 1 && ok) ? reinterpret_cast<const float4*>(y)[j] : z4;
+        }
+    };
+    fetch(i0);
     double f0[4] = {0.0, 0.0, 0.0, 0.0}, f1[4] = {0.0, 0.0, 0.0, 0.0};
     if (FOLD) {
-        bn_fold_rows(rows, n_rows, C, c, f0, f1);
-        if (i0 < c4n) {
+        bn_fold_rows_wg(rows, n_rows, C, nq, c, s_buf, f0, f1);
+        if (owner && i0 < c4n) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (fin.dbeta) fin.dbeta[c + k] = (float)f0[k];
@@ -289,36 +358,44 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             }
         }
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        mu[k] = mean[c + k]; is[k] = invstd[c + k];
-        sg[k] = (float)(FOLD ? f0[k] : acc[c + k]) * invM; sgx[k] = (float)(FOLD ? f1[k] : acc[C + c + k]) * invM;
-        gi[k] = (gamma ? gamma[c + k] : 1.f) * is[k];
-        sc[k] = is[k] * (gamma ? gamma[c + k] : 1.f);
-        sh[k] = beta ? beta[c + k] : 0.f;
-    }
-    for (int64_t i = i0; i < n4; i += (int64_t)gridDim.x * 256) {
-        const float4 xv = reinterpret_cast<const float4*>(x)[i];
-        const float4 gv = reinterpret_cast<const float4*>(gy)[i];
-        const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
-        float ge[4] = {gv.x, gv.y, gv.z, gv.w};
-        if (relu == 1) {
-            const float4 yv = reinterpret_cast<const float4*>(y)[i];
-            const float ye[4] = {yv.x, yv.y, yv.z, yv.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) ge[k] = (ye[k] > 0.f) ? ge[k] : 0.f;
-        } else if (relu == 2) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) ge[k] = ((xe[k] - mu[k]) * sc[k] + sh[k] > 0.f) ? ge[k] : 0.f;
-        }
-        float o[4];
+    float par[6][4];                                           // mean, invstd, sum_g / M, sum_gx / M, invstd * gamma, beta
+    if (owner) {
+        const float invM = count ? (float)(1.0 / count[0]) : 1.0f / (float)M;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float xh = (xe[k] - mu[k]) * is[k];
-            o[k] = gi[k] * (ge[k] - sg[k] - xh * sgx[k]);
+            par[0][k] = mean[c + k]; par[1][k] = invstd[c + k];
+            par[2][k] = (float)(FOLD ? f0[k] : acc[c + k]) * invM; par[3][k] = (float)(FOLD ? f1[k] : acc[C + c + k]) * invM;
+            par[4][k] = (gamma ? gamma[c + k] : 1.f) * par[1][k];
+            par[5][k] = beta ? beta[c + k] : 0.f;
         }
-        reinterpret_cast<float4*>(dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
-        if (dres) reinterpret_cast<float4*>(dres)[i] = make_float4(ge[0], ge[1], ge[2], ge[3]);
+    }
+    if (nq < 256) bn_share_params<6>(nq, par, s_buf);
+    for (int64_t i = i0; i < n4;) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t j = i + u * S;
+            if (j >= n4) break;
+            const float xe[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+            float ge[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+            if (relu == 1) {
+                const float ye[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ge[k] = (ye[k] > 0.f) ? ge[k] : 0.f;
+            } else if (relu == 2) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ge[k] = ((xe[k] - par[0][k]) * par[4][k] + par[5][k] > 0.f) ? ge[k] : 0.f;
+            }
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float xh = (xe[k] - par[0][k]) * par[1][k];
+                o[k] = par[4][k] * (ge[k] - par[2][k] - xh * par[3][k]);
+            }
+            reinterpret_cast<float4*>(dx)[j] = make_float4(o[0], o[1], o[2], o[3]);
+            if (dres) reinterpret_cast<float4*>(dres)[j] = make_float4(ge[0], ge[1], ge[2], ge[3]);
+        }
+        i += U * S;
+        if (i < n4) fetch(i);
     }
 }
 
@@ -416,10 +493,11 @@ inline bool bn_shape_ok(int C) {
 inline int bn_col_blocks(int C) { return ((C >> 2) + 255) / 256; }
 
 constexpr int BN_MAX_WGS = 256;
-inline int bn_rows_per_wg(int64_t M, int C) {
+constexpr int BN_ACC_WGS = 512;                                 // reduction workgroups when they meet by atomics (no partial rows to size; 1024 / 2048 measured equal)
+inline int bn_rows_per_wg(int64_t M, int C, int max_wgs = BN_MAX_WGS) {
     const int rlanes = 256 / min(C >> 2, 256);
-    int64_t r = (M + BN_MAX_WGS - 1) / BN_MAX_WGS;
-    if (r < (int64_t)rlanes * 4) r = (int64_t)rlanes * 4;      // at least one unrolled trip per row-lane
+    int64_t r = (M + max_wgs - 1) / max_wgs;
+    if (r < (int64_t)rlanes * 8) r = (int64_t)rlanes * 8;      // at least one full batch of loads per row-lane
     return (int)r;
 }
 inline int bn_apply_grid(int64_t n4, int C) {
@@ -449,7 +527,7 @@ extern "C" int dsf_bn_forward(const float* x, const float* residual, const float
     const int rows = bn_rows_per_wg(M, C);
     const int wgs = (int)((M + rows - 1) / rows);
     BnFinal fin = {eps, momentum, save_mean, save_invstd, running_mean, running_var, nullptr, nullptr, nullptr};
-    hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(wgs, bn_col_blocks(C)), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+    hipLaunchKernelGGL((bn_reduce_kernel<0, false>), dim3(wgs, bn_col_blocks(C)), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                        M, C, 0, rows, bn_ws_part(workspace, C), 0);
     hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3((C + 15) / 16), dim3(256), 0, st, bn_ws_part(workspace, C), wgs, M, C, fin);
     const int64_t n4 = M * (C >> 2);
@@ -499,8 +577,13 @@ extern "C" int dsf_bn_backward(const float* x, const float* grad_y, const float*
     const int rows = bn_rows_per_wg(M, C);
     const int wgs = (int)((M + rows - 1) / rows);
     BnFinal fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, workspace, grad_gamma, grad_beta};
-    hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(wgs, bn_col_blocks(C)), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd, gamma, beta, M, C,
-                       relu, rows, bn_ws_part(workspace, C), 0);
+    if (relu == 1) {
+        hipLaunchKernelGGL((bn_reduce_kernel<1, true>), dim3(wgs, bn_col_blocks(C)), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd, gamma, beta, M, C,
+                           relu, rows, bn_ws_part(workspace, C), 0);
+    } else {
+        hipLaunchKernelGGL((bn_reduce_kernel<1, false>), dim3(wgs, bn_col_blocks(C)), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd, gamma, beta, M, C,
+                           relu, rows, bn_ws_part(workspace, C), 0);
+    }
     hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(256), 0, st, bn_ws_part(workspace, C), wgs, M, C, fin);
     const int64_t n4 = M * (C >> 2);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(bn_apply_grid(n4, C)), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd,
@@ -515,8 +598,7 @@ extern "C" int dsf_bn_backward(const float* x, const float* grad_y, const float*
 // convolution that filled the rows (2 otherwise), backward = 2, where the ordered-partials path above needs 2-3 and 3.
 // Results differ from that path by the order of DOUBLE additions only (~1e-16 relative on the sums); in
 // deterministic mode these entry points return DSF_ERR_UNSUPPORTED and the caller uses the ordered path.
-// 8 rows of doubles: the prologue fold is two batches of loads; 256 reduce workgroups = 32 adders per address, a 512-workgroup
-// convolution epilogue 64 -- a few hundred KB of atomics per launch, spread over its duration (measured with 32 float rows: the
+// 8 rows of doubles: 512 reduce workgroups = 64 adders per address, as a 512-workgroup convolution epilogue -- a few hundred KB of atomics per launch, spread over its duration (measured with 32 float rows: the
 // 64-load fold cost more than the finalise launch it replaced)
 constexpr int BN_ACC_ROWS = 8;
 extern "C" int dsf_bn_acc_rows(void) { return BN_ACC_ROWS; }
@@ -529,9 +611,9 @@ extern "C" int dsf_bn_forward_acc(const float* x, const float* residual, const f
     hipStream_t st = (hipStream_t)stream;
     BnFinal fin = {eps, momentum, save_mean, save_invstd, running_mean, running_var, nullptr, nullptr, nullptr};
     if (!acc_filled) {
-        const int rows = bn_rows_per_wg(M, C);
+        const int rows = bn_rows_per_wg(M, C, BN_ACC_WGS);
         const int wgs = (int)((M + rows - 1) / rows);
-        hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(wgs, bn_col_blocks(C)), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr,
+        hipLaunchKernelGGL((bn_reduce_kernel<0, false>), dim3(wgs, bn_col_blocks(C)), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr,
                            nullptr, M, C, 0, rows, reinterpret_cast<float*>(acc), BN_ACC_ROWS);
     }
     const int64_t n4 = M * (C >> 2);
@@ -546,11 +628,16 @@ extern "C" int dsf_bn_backward_acc(const float* x, const float* grad_y, const fl
     DSF_CHECK_ARG(x && grad_y && save_mean && save_invstd && grad_x && acc && M > 0 && relu >= 0 && relu <= 2 && (relu != 1 || y));
     if (!bn_shape_ok(C) || dsf_deterministic()) return DSF_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    const int rows = bn_rows_per_wg(M, C);
+    const int rows = bn_rows_per_wg(M, C, BN_ACC_WGS);
     const int wgs = (int)((M + rows - 1) / rows);
     BnFinal fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, grad_gamma, grad_beta};
-    hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(wgs, bn_col_blocks(C)), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd, gamma, beta,
-                       M, C, relu, rows, reinterpret_cast<float*>(acc), BN_ACC_ROWS);
+    if (relu == 1) {
+        hipLaunchKernelGGL((bn_reduce_kernel<1, true>), dim3(wgs, bn_col_blocks(C)), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd, gamma, beta,
+                           M, C, relu, rows, reinterpret_cast<float*>(acc), BN_ACC_ROWS);
+    } else {
+        hipLaunchKernelGGL((bn_reduce_kernel<1, false>), dim3(wgs, bn_col_blocks(C)), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd, gamma, beta,
+                           M, C, relu, rows, reinterpret_cast<float*>(acc), BN_ACC_ROWS);
+    }
     const int64_t n4 = M * (C >> 2);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(bn_apply_grid(n4, C)), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd,
                        gamma, beta, nullptr, M, n4, C, relu, grad_x, grad_residual, acc, BN_ACC_ROWS, fin, nullptr);
@@ -586,7 +673,7 @@ extern "C" int dsf_bn_local_sums(const float* x, int64_t M, int C, const float* 
     if (!part) {                                                    // no epilogue rows: this call's own statistics pass
         const int rpw = bn_rows_per_wg(M, C);
         rows = (int)((M + rpw - 1) / rpw);
-        hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(rows, bn_col_blocks(C)), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr,
+        hipLaunchKernelGGL((bn_reduce_kernel<0, false>), dim3(rows, bn_col_blocks(C)), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr,
                            nullptr, M, C, 0, rpw, bn_ws_part(workspace, C), 0);
         part = bn_ws_part(workspace, C);
     }
@@ -617,8 +704,13 @@ extern "C" int dsf_bn_backward_sums(const float* x, const float* grad_y, const f
     const int rows = bn_rows_per_wg(M, C);
     const int wgs = (int)((M + rows - 1) / rows);
     BnFinal fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, sums, grad_gamma, grad_beta};      // dgamma / dbeta: this replica's share
-    hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(wgs, bn_col_blocks(C)), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd, gamma, beta,
-                       M, C, relu, rows, bn_ws_part(workspace, C), 0);
+    if (relu == 1) {
+        hipLaunchKernelGGL((bn_reduce_kernel<1, true>), dim3(wgs, bn_col_blocks(C)), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd, gamma, beta,
+                           M, C, relu, rows, bn_ws_part(workspace, C), 0);
+    } else {
+        hipLaunchKernelGGL((bn_reduce_kernel<1, false>), dim3(wgs, bn_col_blocks(C)), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd, gamma, beta,
+                           M, C, relu, rows, bn_ws_part(workspace, C), 0);
+    }
     hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(256), 0, st, bn_ws_part(workspace, C), wgs, M, C, fin);
     return dsf_launch_status();
 }
@@ -648,7 +740,7 @@ extern "C" int dsf_instnorm_forward(const float* x, const float* residual, int B
     hipStream_t st = (hipStream_t)stream;
     const int rows = bn_rows_per_wg(HW, C);
     const int wgs = (int)((HW + rows - 1) / rows);
-    hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(wgs, bn_col_blocks(C), B), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr,
+    hipLaunchKernelGGL((bn_reduce_kernel<0, false>), dim3(wgs, bn_col_blocks(C), B), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr,
                        nullptr, HW, C, 0, rows, reinterpret_cast<float*>(acc), 1);
     BnFinal fin = {eps, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     const int64_t n4 = HW * (C >> 2);

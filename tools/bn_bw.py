@@ -37,13 +37,14 @@ def timed(fn, sets, n=30):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sets", type=int, default=12)
+    ap.add_argument("--only", type=int, default=-1, help="index of the one shape to run")
     a = ap.parse_args()
     lib = L.lib()
     dev = torch.device("cuda:0")
     rows = int(lib.dsf_bn_acc_rows())
     p, st = L.ptr, L.stream_ptr
     print("%-16s %-9s %10s %8s %10s %8s" % ("M x C (MB)", "call", "cache us", "TB/s", "hbm us", "TB/s"))
-    for M, C in SHAPES:
+    for M, C in (SHAPES if a.only < 0 else SHAPES[a.only:a.only + 1]):
         mb = M * C * 4 / 1e6
         nset = max(2, min(a.sets, int(3000 // (5 * mb))))
         T = [[torch.randn(M, C, device=dev) for _ in range(5)] for _ in range(nset)]     # x, res / gy, y, gx, gres
