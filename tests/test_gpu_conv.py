@@ -73,7 +73,9 @@ def test_conv_transpose2d_matches_torch_cpu(Ci, Co, K, s, p, op, H):
 
 @pytest.mark.parametrize("acc", [False, True])
 @pytest.mark.parametrize("C,H,res,relu", [(64, 16, True, True), (256, 8, False, True), (512, 4, True, False), (8, 5, False, False),
-                                          (1024, 3, True, True), (2048, 4, True, True), (2048, 3, False, False)])
+                                          (1024, 3, True, True), (2048, 4, True, True), (2048, 3, False, False),
+                                          # one channel quad shared by all 256 threads; ragged row batches; > 2 M float4 (several batches per thread)
+                                          (4, 7, True, True), (128, 37, False, True), (64, 153, True, True)])
 def test_fused_batchnorm_matches_torch_cpu(C, H, res, relu, acc):
     """bn(x) (+ residual) (relu) in training mode vs torch CPU: output, running stats, all gradients -- on the ordered-partials
     path (reduce, finalise, apply) and, ``acc``, on the finalise-free path (float-atomic accumulation rows from an open
