@@ -140,3 +140,16 @@ def test_side_stream_capability_guard(monkeypatch):
     assert not nn_conv._side_ok(torch.nn.Parameter(torch.zeros(8, 8, 3, 3)))   # standard layout: AccumulateGrad would clone dW
     nn_conv.no_side_stream([w])
     assert not nn_conv._side_ok(w)
+
+
+def test_integration_index_lists_every_declared_symbol():
+    """INTEGRATION.md section 5 (tools/abi_index.py) names every entry point the header declares."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "dsf_hip.h")).read()
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    index = doc[doc.index("## 5. Entry-point index"):]
+    declared = re.findall(r"^(?:int|int64_t|const char\*) (dsf_[a-z0-9_]+)\(", hdr, re.M)
+    assert len(declared) >= 70
+    missing = [s for s in declared if "| `%s` |" % s not in index]
+    assert not missing, missing
