@@ -167,7 +167,7 @@ def _grad_error(ref_net, other_net):
 
 def _terms_close(tc, tg, rtol=5e-3, atol=2e-5):
     for k in tc:
-        a, b = float(tc[k]), float(tg[k])
+        a, b = (float(v.detach()) if torch.is_tensor(v) else float(v) for v in (tc[k], tg[k]))
         assert abs(a - b) <= rtol * abs(a) + atol, (k, a, b)
 
 
