@@ -2,6 +2,7 @@
 // (round 3: three small-grid kernels of libdsf_hip.so did not, under two concurrent bench.py processes; this is the same
 // arithmetic as xyz_to_uvd_kernel in a stand-alone program: no torch, no library, default hipcc flags unless given)
 //   hipcc --offload-arch=gfx950 -O3 tiny_kernel_soak.hip -o tiny_kernel_soak && ./tiny_kernel_soak 20000
+//   (-DNO_VCC_DIVISION: the same kernel with reciprocal multiplications instead of IEEE divisions, as a control)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -17,10 +18,19 @@ __global__ void k(const float* __restrict__ xyz, const float* __restrict__ cente
     const int b = (int)(i / N);
     const float* m = M + b * 9; const float* c = center + b * 3; const float* cb = cube + b * 3;
     float wx = xyz[i * 3], wy = xyz[i * 3 + 1], wz = xyz[i * 3 + 2];
-    wx = wx * cb[0] / 2.0f + c[0]; wy = wy * cb[1] / 2.0f + c[1]; wz = wz * cb[2] / 2.0f + c[2];
+    wx = wx * cb[0] * 0.5f + c[0]; wy = wy * cb[1] * 0.5f + c[1]; wz = wz * cb[2] * 0.5f + c[2];      // (exact: a power of two)
+#ifdef NO_VCC_DIVISION          // control: v_rcp_f32 * numerator instead of the div_scale / div_fmas / div_fixup sequence (not IEEE-exact)
+    const float U = wx * cam.fx * __builtin_amdgcn_rcpf(wz + 1e-8f) + cam.px, V = wy * cam.fy * __builtin_amdgcn_rcpf(wz) + cam.py;
+#else
     const float U = wx * cam.fx / (wz + 1e-8f) + cam.px, V = wy * cam.fy / wz + cam.py;
+#endif
     const float u = (m[0] * U + m[1] * V) + m[2], v = (m[3] * U + m[4] * V) + m[5];
+    #ifdef NO_VCC_DIVISION
+    const float r = __builtin_amdgcn_rcpf(img_size);
+    uvd[i * 3] = u * r * 2.0f - 1.0f; uvd[i * 3 + 1] = v * r * 2.0f - 1.0f; uvd[i * 3 + 2] = (wz - c[2]) * __builtin_amdgcn_rcpf(cb[2] * 0.5f);
+#else
     uvd[i * 3] = u / img_size * 2.0f - 1.0f; uvd[i * 3 + 1] = v / img_size * 2.0f - 1.0f; uvd[i * 3 + 2] = (wz - c[2]) / (cb[2] / 2.0f);
+#endif
 }
 
 int main(int argc, char** argv) {
