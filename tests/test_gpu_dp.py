@@ -227,6 +227,7 @@ def test_graphed_step_with_gradient_all_reduce_equals_the_eager_data_parallel_st
 
 
 @pytest.mark.parametrize("graph", [False, True])
+@_shared_gpu_retry()
 def test_bench_two_ranks_on_one_gpu_flow(graph):
     """`bench.py --gpus 2` under torch.distributed.run, both ranks on the one GPU of the test box (gloo transport): the ranks time
     the step together, leave the process group together, rank 0 alone runs its diagnostics and prints ONE JSON line with
