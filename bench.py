@@ -74,7 +74,7 @@ def pmc_traffic(kernel):
     process, so the figure is read back from the profile of the same command; null when the file has no entry."""
     here = os.path.dirname(os.path.abspath(__file__))
     mid = "" if PMC_CONFIG[0] == 2 else "_config%d" % PMC_CONFIG[0]
-    for tag in ("r03", "r02", "r01"):                            # the newest committed round that measured this kernel
+    for tag in ("r04", "r03", "r02", "r01"):                     # the newest committed round that measured this kernel
         name = "%s%s_pmc_traffic.json" % (tag, mid)
         try:
             with open(os.path.join(here, "profiles", name)) as f:
@@ -567,11 +567,14 @@ def main():
             out["roofline"]["frac_of_measured_ceiling"] = round(
                 out["roofline"]["achieved"] / out["roofline"]["measured_mfma_ceiling"]["fp32_equivalent_TFLOP/s"], 4)
         tf = w["flops_per_unit"] * images / dt / 1e12
-        x6_peak = round(BF16_MATRIX_PEAK_TFLOPS / 6.0, 1)
-        out["whole_step_mfma"] = {"achieved": round(tf, 2), "peak": x6_peak, "unit": "TFLOP/s", "frac": round(tf / x6_peak, 4),
+        from dsf_amd import nn_conv as _nc
+        step_peak, _ = matrix_peak("x6" if _nc.MATH == "x6" else "fp32")         # the matrix pipe the step's convolutions ran on
+        out["whole_step_mfma"] = {"achieved": round(tf, 2), "peak": step_peak, "unit": "TFLOP/s", "frac": round(tf / step_peak, 4),
                                   "frac_of_fp32_mfma_peak": round(tf / FP32_MATRIX_PEAK_TFLOPS, 4),
-                                  "note": "network FLOPs (%s) / whole step time, every kernel of the step included; peak = the split "
-                                          "(x6) kernels' 2500 / 6 fp32-equivalent TFLOP/s (the fp32 MFMA's own peak is 157.3)" % w["flops_note"]}
+                                  "note": "network FLOPs (%s) / whole step time, every kernel of the step included; peak = that of "
+                                          "the active convolution math (DSF_CONV_MATH=%s): 2500 / 6 = 416.7 fp32-equivalent TFLOP/s for "
+                                          "the split (x6) kernels, 157.3 for the fp32 MFMA (rounds 1-2 quoted frac against 157.3)"
+                                          % (w["flops_note"], _nc.MATH)}
         if world == 1 and not args.no_cpu_baseline:
             cores = min(usable_cpus(), 32)
             torch.set_num_threads(cores)

@@ -179,7 +179,45 @@ __global__ void pfd_packed_bwd_kernel(const float* __restrict__ points, const fl
 }
 
 // ---- fused batched (sample, part) form --------------------------------------------------------
-constexpr int LIST_CAP = 4096;      // points per workgroup range
+// Round 4: a conservative cull in front of the per-pair arithmetic (which stays the oracle's).
+//
+// Every triangle gets a bounding sphere (centre c, radius R) of the region whose points the reference can report at
+// distance t^2 (plane distance): its `inside` test divides by denom + 1e-8, so the barycentrics it sees are the true
+// ones times s = denom_true / (denom_true + 1e-8), i.e. `inside` holds on the triangle SCALED about v0 by k = 1 / s
+// (>= 1; 1.01 for cube-normalised hands); the plane distance it reports is the true one times |n| = nn / (nn + 1e-8).
+// The three segment distances of the other branch are distances to points of the triangle itself.  Hence, for every
+// point p,  computed_dist2(p, tri) >= (max(0, |p - c| - R) * nn / (nn + 1e-8))^2  up to float rounding, and a lane whose
+// current minimum is `best` may skip a triangle when  |p - c| * (1 - m) > R * (1 + m) + sqrt(best) * (1 + m) * 1.0011
+// (m = 1e-4 covers the rounding of every quantity involved; triangles with nn / (nn + 1e-8) < 1 / 1.001 or an unbounded k
+// get R = inf and are never skipped).  The inequality is STRICT, so a skipped triangle's distance is larger than the
+// minimum: ties (ubiquitous on shared edges) are still decided among all minimisers, by the lowest index -- the update
+// rule compares indices, so the order in which triangles are visited no longer matters.  That allows (1) a seed: each
+// lane first finds the sphere centre nearest to its point (9 operations per pair) and evaluates that triangle, which puts
+// `best` within a small factor of the minimum before the scan starts; (2) points taken in a spatially coherent order (a
+// counting sort of the sample's cloud by 9-bit Morton cell, rebuilt by every workgroup of the sample in LDS), so that
+// the 64 lanes of a wave skip the same triangles -- a triangle is evaluated when ANY live lane needs it.
+constexpr int LIST_CAP = 4096;      // points per workgroup range (uint16 list entries)
+constexpr int SPH_CAP = 2048;       // triangles per (sample, part) range the cull holds spheres for (MANO: 1554)
+constexpr float CULL_M = 1e-4f;
+
+__device__ __forceinline__ float4 tri_sphere(const TriRec& r) {
+    const f3 v0 = mk3(r.v0x, r.v0y, r.v0z), q0 = mk3(r.v1x, r.v1y, r.v1z) - v0, q1 = mk3(r.v2x, r.v2y, r.v2z) - v0;
+    float k = 1.0f;
+    bool bounded = true;
+    if (r.nn > kEps) {                                  // the plane branch exists for this triangle
+        const float dt = r.denom - kEps;                // ~ denom_true
+        bounded = dt > 0.0f && (r.nn + kEps) <= 1.001f * r.nn;
+        k = bounded ? r.denom / dt : 1.0f;
+        bounded = bounded && k < 64.0f;
+    }
+    const f3 a = k * q0, b = k * q1;                    // scaled triangle: v0, v0 + a, v0 + b
+    const f3 cc = (1.0f / 3.0f) * (a + b);              // centroid - v0
+    const f3 d1 = a - cc, d2 = b - cc;
+    const float r2 = fmaxf(dot(cc, cc), fmaxf(dot(d1, d1), dot(d2, d2)));
+    const f3 c = v0 + cc;
+    const float R = bounded ? sqrtf(r2) * ((1.0f + 2.0f * CULL_M) / (1.0f - CULL_M)) : INFINITY;
+    return make_float4(c.x, c.y, c.z, R);
+}
 
 __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __restrict__ verts,
                                                              const float* __restrict__ points,
@@ -189,41 +227,134 @@ __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __rest
                                                              int splits, float* __restrict__ dists,
                                                              int32_t* __restrict__ idxs) {
     __shared__ TriRec s_tri[CHUNK];
+    __shared__ float4 s_sph[SPH_CAP];
     __shared__ uint16_t s_list[LIST_CAP];
-    __shared__ int s_n;
-    const int t = threadIdx.x;
+    __shared__ int s_hist[512];
+    __shared__ float s_box[4 * 6];
+    __shared__ int s_n, s_wsum[4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     int w = blockIdx.x;
     const int split = w % splits; w /= splits;
     const int part = w % n_parts;
     const int b = w / n_parts;
-    const int per = (P + splits - 1) / splits;
-    const int pbeg = split * per, pend = min(P, pbeg + per);
     const float* vb = verts + (int64_t)b * V * 3;
     const float* pb = points + (int64_t)b * P * 3;
+    const int f0 = part_first[part], f1 = part_first[part + 1];
+    const bool cull = (f1 - f0) <= SPH_CAP;
 
-    if (t == 0) s_n = 0;
-    __syncthreads();
-    for (int p = pbeg + t; p < pend; p += 256) {
-        bool mine = true;
-        if (seg) {
+    int pbeg, n_mine;                  // this workgroup's points: s_list[0 .. n_mine) + pbeg, or the plain range when !listed
+    bool listed = true;
+    if (seg) {
+        const int per = (P + splits - 1) / splits;
+        pbeg = split * per;
+        const int pend = min(P, pbeg + per);
+        if (t == 0) s_n = 0;
+        __syncthreads();
+        for (int p = pbeg + t; p < pend; p += 256) {
             const int64_t lab = seg[(int64_t)b * P + p];
-            mine = (lab == part + 1);
-            if (part == 0 && (lab < 1 || lab > n_parts)) {          // no part: the reference's masked-out zeros
+            if (part == 0 && (lab < 1 || lab > n_parts)) {              // no part: the reference's masked-out zeros
                 dists[(int64_t)b * P + p] = 0.f;
                 idxs[(int64_t)b * P + p] = -1;
             }
+            if (lab == part + 1) s_list[atomicAdd(&s_n, 1)] = (uint16_t)(p - pbeg);
         }
-        if (mine) s_list[atomicAdd(&s_n, 1)] = (uint16_t)(p - pbeg);
+        __syncthreads();
+        n_mine = s_n;
+    } else if (P <= LIST_CAP) {
+        // the whole cloud of the sample in Morton-cell order (every workgroup of the sample builds the same cells; the order
+        // inside a cell is whatever the LDS atomics give -- results do not depend on it), this workgroup takes 256 of them
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int p = t; p < P; p += 256) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { const float x = pb[p * 3 + c]; lo[c] = fminf(lo[c], x); hi[c] = fmaxf(hi[c], x); }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { lo[c] = fminf(lo[c], __shfl_xor(lo[c], o, 64)); hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], o, 64)); }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { s_box[wave * 6 + c] = lo[c]; s_box[wave * 6 + 3 + c] = hi[c]; }
+        }
+        for (int i = t; i < 512; i += 256) s_hist[i] = 0;
+        __syncthreads();
+        float sc[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            lo[c] = fminf(fminf(s_box[c], s_box[6 + c]), fminf(s_box[12 + c], s_box[18 + c]));
+            hi[c] = fmaxf(fmaxf(s_box[3 + c], s_box[9 + c]), fmaxf(s_box[15 + c], s_box[21 + c]));
+            const float ext = hi[c] - lo[c];
+            sc[c] = (ext > 0.f && ext < INFINITY) ? 8.0f / ext : 0.f;
+        }
+        auto cell = [&](int p) {
+            int k = 0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float u = (pb[p * 3 + c] - lo[c]) * sc[c];
+                const int q = (u >= 0.f) ? min(7, (int)u) : 0;            // (NaN / inf coordinates land in cell 0)
+                k |= ((q & 1) << c) | ((q & 2) << (c + 2)) | ((q & 4) << (c + 4));
+            }
+            return k;
+        };
+        for (int p = t; p < P; p += 256) atomicAdd(&s_hist[cell(p)], 1);
+        __syncthreads();
+        {                                                               // exclusive scan of the 512 cell counts
+            const int a0 = s_hist[2 * t], a1 = s_hist[2 * t + 1];
+            int v = a0 + a1;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(v, o, 64); if (lane >= o) v += u; }
+            if (lane == 63) s_wsum[wave] = v;
+            __syncthreads();
+            int base = 0;
+            for (int q = 0; q < wave; ++q) base += s_wsum[q];
+            const int excl = base + v - (a0 + a1);
+            s_hist[2 * t] = excl; s_hist[2 * t + 1] = excl + a0;
+        }
+        __syncthreads();
+        for (int p = t; p < P; p += 256) s_list[atomicAdd(&s_hist[cell(p)], 1)] = (uint16_t)p;
+        __syncthreads();
+        pbeg = 0;
+        n_mine = 0;                                                     // handled below through `sorted`
+    } else {
+        listed = false;
+        pbeg = 0; n_mine = 0;
     }
-    __syncthreads();
-    const int n_mine = s_n;
-    const int f0 = part_first[part], f1 = part_first[part + 1];
-    for (int g = 0; g < n_mine; g += 256) {
-        const bool live = g + t < n_mine;
-        const int p = live ? pbeg + s_list[g + t] : 0;
+    const bool sorted = !seg && listed;
+    // the groups of 256 points this workgroup walks: (seg) its compacted list; (no seg) ONE group: slots split*256 + t
+    const int n_groups = seg ? (n_mine + 255) / 256 : 1;
+
+    if (cull) {                                                         // spheres of the whole triangle range, once
+        for (int f = f0 + t; f < f1; f += 256) {
+            const int32_t* fc = faces + f * 3;
+            s_sph[f - f0] = tri_sphere(make_tri(ld3(vb + fc[0] * 3), ld3(vb + fc[1] * 3), ld3(vb + fc[2] * 3), 0));
+        }
+    }
+    for (int g = 0; g < n_groups; ++g) {
+        bool live;
+        int p;
+        if (seg) { live = g * 256 + t < n_mine; p = live ? pbeg + s_list[g * 256 + t] : 0; }
+        else { const int slot = split * 256 + t; live = slot < P; p = live ? (sorted ? (int)s_list[slot] : slot) : 0; }
         const f3 pt = live ? ld3(pb + p * 3) : mk3(0.f, 0.f, 0.f);
-        float best = INFINITY;
+        float best = INFINITY, thr = INFINITY;          // thr = sqrt(best) * (1 + m) * 1.0011 / (1 - m), refreshed with best
         int bi = -1;
+        __syncthreads();                                 // s_sph complete (first group) / previous group done with s_tri
+        if (cull && live && f1 > f0) {
+            // seed: the triangle whose sphere centre is nearest
+            float dmin = INFINITY;
+            int smin = 0;
+            for (int q = 0; q < f1 - f0; ++q) {
+                const float4 s = s_sph[q];
+                const float dx = pt.x - s.x, dy = pt.y - s.y, dz = pt.z - s.z;
+                const float d2 = dx * dx + dy * dy + dz * dz;
+                if (d2 < dmin) { dmin = d2; smin = q; }
+            }
+            const int32_t* fc = faces + (f0 + smin) * 3;
+            const TriRec r = make_tri(ld3(vb + fc[0] * 3), ld3(vb + fc[1] * 3), ld3(vb + fc[2] * 3), 0);
+            best = point_tri_dist2(pt, r);
+            bi = f0 + smin;
+            thr = sqrtf(best) * ((1.0f + CULL_M) * 1.0011f / (1.0f - CULL_M));
+        }
         for (int base = f0; base < f1; base += CHUNK) {
             __syncthreads();
             if (base + t < f1) {
@@ -232,10 +363,22 @@ __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __rest
             }
             __syncthreads();
             const int cnt = min(CHUNK, f1 - base);
-            if (live) {
-                for (int q = 0; q < cnt; ++q) {
+            for (int q = 0; q < cnt; ++q) {
+                bool need = live;
+                if (cull) {
+                    const float4 s = s_sph[base - f0 + q];
+                    const float dx = pt.x - s.x, dy = pt.y - s.y, dz = pt.z - s.z;
+                    const float lim = s.w + thr;
+                    need = live && !(dx * dx + dy * dy + dz * dz > lim * lim);      // (NaN distances are never skipped)
+                    if (!__any(need)) continue;                                    // wave-uniform: nobody needs this triangle
+                }
+                if (need) {
                     const float d = point_tri_dist2(pt, s_tri[q]);
-                    if (d < best || bi < 0) { best = d; bi = base + q; }
+                    const int id = base + q;
+                    if (bi < 0 || d < best || (d == best && id < bi)) {
+                        best = d; bi = id;
+                        thr = sqrtf(best) * ((1.0f + CULL_M) * 1.0011f / (1.0f - CULL_M));
+                    }
                 }
             }
         }

@@ -12,7 +12,8 @@ from torch.autograd.function import once_differentiable
 from . import _lib as L
 from ._lib import F, I, I64, ptr, f32, check, stream_ptr
 
-SAVE_FLOATS = 5248
+SAVE_FLOATS = 5248            # DSF_MANO_SAVE_FLOATS
+BWD_SCRATCH_FLOATS = 2560     # DSF_MANO_BWD_SCRATCH_FLOATS
 
 
 def _empty(shape, ref, dtype=torch.float32):
@@ -33,8 +34,7 @@ class ManoFunction(Function):
         verts = _empty((B, 779, 3), beta)
         joints = _empty((B, 21, 3), beta)
         Rs = _empty((B, 15, 3, 3), beta)
-        need_grad = any(ctx.needs_input_grad[1:5])
-        save = _empty((B, SAVE_FLOATS), beta) if need_grad else None
+        save = _empty((B, SAVE_FLOATS), beta)          # staging between the two forward launches + state of the backward pass
         check(L.lib().dsf_mano_forward(ctypes.byref(model.c_struct), ptr(beta), ptr(theta), ptr(rot), ptr(cam), I(B),
                                        I(ncomp), I(rot_dim), I(0), F(k1), F(k2), ptr(verts), ptr(joints), ptr(Rs),
                                        ptr(save), stream_ptr()), "dsf_mano_forward")
@@ -58,8 +58,8 @@ class ManoFunction(Function):
         k1, k2 = ctx.k
         check(L.lib().dsf_mano_backward(ctypes.byref(ctx.model.c_struct), ptr(theta), ptr(rot), ptr(cam), ptr(save),
                                         ptr(g_verts), ptr(g_joints), I(B), I(ncomp), I(rot_dim), I(0), F(k1), F(k2),
-                                        ptr(g_beta), ptr(g_theta), ptr(g_rot), ptr(g_cam), stream_ptr()),
-              "dsf_mano_backward")
+                                        ptr(g_beta), ptr(g_theta), ptr(g_rot), ptr(g_cam),
+                                        ptr(_empty((B, BWD_SCRATCH_FLOATS), theta)), stream_ptr()), "dsf_mano_backward")
         return None, g_beta, g_theta, g_rot, g_cam, None, None
 
 
@@ -76,7 +76,7 @@ class ManoPackedFunction(Function):
         assert rot_dim in (3, 4)
         verts = _empty((B, 779, 3), paras)
         joints = _empty((B, 21, 3), paras)
-        save = _empty((B, SAVE_FLOATS), paras) if ctx.needs_input_grad[1] else None
+        save = _empty((B, SAVE_FLOATS), paras)
         col = lambda c: ctypes.c_void_p((paras.data_ptr() if B else L._dummy(paras.device).data_ptr()) + 4 * c)
         check(L.lib().dsf_mano_forward(ctypes.byref(model.c_struct), col(rot_dim + 45), col(rot_dim), col(0), col(rot_dim + 55),
                                        I(B), I(45), I(rot_dim), I(W), F(k1), F(k2), ptr(verts), ptr(joints), ptr(None),
@@ -99,7 +99,8 @@ class ManoPackedFunction(Function):
         check(L.lib().dsf_mano_backward(ctypes.byref(ctx.model.c_struct), base(paras, rot_dim), base(paras, 0),
                                         base(paras, rot_dim + 55), ptr(save), ptr(g_verts), ptr(g_joints), I(B), I(45),
                                         I(rot_dim), I(W), F(k1), F(k2), base(g, rot_dim + 45), base(g, rot_dim), base(g, 0),
-                                        base(g, rot_dim + 55), stream_ptr()), "dsf_mano_backward")
+                                        base(g, rot_dim + 55), ptr(_empty((B, BWD_SCRATCH_FLOATS), paras)), stream_ptr()),
+              "dsf_mano_backward")
         return None, g, None, None
 
 

@@ -227,54 +227,61 @@ def define_D(input_nc, ndf, netD, n_layers_D=3, norm='batch', init_type='normal'
 
 
 class GANLoss(nn.Module):
-    """reference :287-353: lsgan (MSE), vanilla (BCE with logits), wgangp (+-mean) against broadcast labels."""
+    """The three adversarial objectives of the reference's ``GANLoss`` (:287-353) behind its call signature
+    ``criterion(prediction, target_is_real)``: 'lsgan' = mean squared error against the label, 'vanilla' = binary cross
+    entropy on logits against the label, 'wgangp' = the critic's signed mean.  The labels are buffers ``real_label`` /
+    ``fake_label`` (they follow ``.to(device)`` and appear in the state dict in that order, as in the reference)."""
+
+    _CRITERIA = {'lsgan': nn.MSELoss, 'vanilla': nn.BCEWithLogitsLoss, 'wgangp': None}
 
     def __init__(self, gan_mode, target_real_label=1.0, target_fake_label=0.0):
         super().__init__()
-        self.register_buffer('real_label', torch.tensor(target_real_label))
-        self.register_buffer('fake_label', torch.tensor(target_fake_label))
-        self.gan_mode = gan_mode
-        if gan_mode == 'lsgan':
-            self.loss = nn.MSELoss()
-        elif gan_mode == 'vanilla':
-            self.loss = nn.BCEWithLogitsLoss()
-        elif gan_mode == 'wgangp':
-            self.loss = None
-        else:
+        if gan_mode not in self._CRITERIA:
             raise NotImplementedError('gan mode %s not implemented' % gan_mode)
+        for name, value in (('real_label', target_real_label), ('fake_label', target_fake_label)):
+            self.register_buffer(name, torch.tensor(value))
+        self.gan_mode = gan_mode
+        criterion = self._CRITERIA[gan_mode]
+        self.loss = criterion() if criterion is not None else None
 
     def get_target_tensor(self, prediction, target_is_real):
         return (self.real_label if target_is_real else self.fake_label).expand_as(prediction)
 
     def __call__(self, prediction, target_is_real):
-        if self.gan_mode in ('lsgan', 'vanilla'):
-            return self.loss(prediction, self.get_target_tensor(prediction, target_is_real))
-        return -prediction.mean() if target_is_real else prediction.mean()
+        if self.loss is None:                                           # wgangp: maximise the critic on real, minimise on fake
+            return prediction.mean() * (-1.0 if target_is_real else 1.0)
+        return self.loss(prediction, self.get_target_tensor(prediction, target_is_real))
+
+
+def _penalty_points(real_data, fake_data, kind, alpha, device):
+    """where the critic's input gradient is taken: the real batch, the fake batch, or one random point per sample on the
+    segment between them (``alpha`` (B,1) in [0,1): the weight of the real sample)"""
+    if kind == 'real':
+        return real_data
+    if kind == 'fake':
+        return fake_data
+    if kind != 'mixed':
+        raise NotImplementedError('{} not implemented'.format(kind))
+    n = real_data.shape[0]
+    w = torch.rand(n, 1, device=device) if alpha is None else alpha
+    w = w.reshape((n,) + (1,) * (real_data.dim() - 1))                  # one weight per sample, broadcast over its elements
+    return w * real_data + (1 - w) * fake_data
 
 
 def cal_gradient_penalty(netD, real_data, fake_data, device, type='mixed', constant=1.0, lambda_gp=10.0, alpha=None):
-    """WGAN-GP gradient penalty (reference :356-391): ``(||d netD(x) / d x||_2 - constant)^2 * lambda_gp`` at real / fake /
-    mixed samples, built with ``create_graph=True`` -- the HIP convolutions provide the backward of their backward
-    (``nn_conv.Conv2dFunction.backward`` re-expresses itself through differentiable Functions when autograd asks).
-    ``alpha`` (B,1): the mixing draw of type 'mixed' as an explicit input; drawn here when None."""
-    if lambda_gp > 0.0:
-        if type == 'real':
-            interpolatesv = real_data
-        elif type == 'fake':
-            interpolatesv = fake_data
-        elif type == 'mixed':
-            if alpha is None:
-                alpha = torch.rand(real_data.shape[0], 1, device=device)
-            alpha = alpha.expand(real_data.shape[0], real_data.nelement() // real_data.shape[0]).contiguous().view(*real_data.shape)
-            interpolatesv = alpha * real_data + ((1 - alpha) * fake_data)
-        else:
-            raise NotImplementedError('{} not implemented'.format(type))
-        interpolatesv.requires_grad_(True)
-        disc_interpolates = netD(interpolatesv)
-        gradients = torch.autograd.grad(outputs=disc_interpolates, inputs=interpolatesv,
-                                        grad_outputs=torch.ones(disc_interpolates.size()).to(device),
-                                        create_graph=True, retain_graph=True, only_inputs=True)
-        gradients = gradients[0].reshape(real_data.size(0), -1)
-        gradient_penalty = (((gradients + 1e-16).norm(2, dim=1) - constant) ** 2).mean() * lambda_gp
-        return gradient_penalty, gradients
-    return 0.0, None
+    """WGAN-GP gradient penalty with the reference's signature and return pair (:356-391):
+    ``lambda_gp * mean_b (||d netD(x_b) / d x_b + 1e-16||_2 - constant)^2`` at real / fake / mixed points, and the per-sample
+    gradients ``(B, -1)``; ``(0.0, None)`` when ``lambda_gp <= 0``.  The input gradient is taken with ``create_graph=True`` so
+    that the penalty can be differentiated with respect to the critic's parameters -- the HIP convolutions provide the
+    backward of their backward (``nn_conv.Conv2dFunction.backward`` re-expresses itself through differentiable Functions
+    when autograd asks).  ``alpha`` (B,1): the mixing draw of type 'mixed' as an explicit input; drawn here
+    when None.  Pinned to the reference's own call by tests/golden/reference_gp.npz."""
+    if not lambda_gp > 0.0:
+        return 0.0, None
+    x = _penalty_points(real_data, fake_data, type, alpha, device)
+    x.requires_grad_(True)
+    score = netD(x)
+    grad_x, = torch.autograd.grad(score, x, grad_outputs=torch.ones_like(score), create_graph=True, retain_graph=True)
+    per_sample = grad_x.reshape(real_data.size(0), -1)
+    excess = torch.linalg.vector_norm(per_sample + 1e-16, ord=2, dim=1) - constant
+    return (excess * excess).mean() * lambda_gp, per_sample

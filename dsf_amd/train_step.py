@@ -6,6 +6,7 @@ so a whole step can be enqueued asynchronously (and captured in a HIP graph).
 Loss lists, weights, detach points and thresholds follow the reference; each block cites its
 lines.  TensorBoard / cv2 drawing / ``xyz2error`` host metrics are out of scope.
 """
+import contextlib
 import math
 
 import numpy as np
@@ -251,22 +252,41 @@ class GraphedStep:
             raise RuntimeError("GraphedStep needs the GPU (HIP graph capture)")
         # data parallel: the graph holds forward + backward only (captured with the reducer's hooks switched off); the bucket
         # all-reduces are launched eagerly after each replay (GradAllReducer.reduce_now), then the optimizer
+        # every refusal below is checked BEFORE the reducer is touched: a caller that catches the error and steps eagerly must find
+        # its GradAllReducer as it left it (hooks on), else the replicas would train without any all-reduce
+        if not hasattr(step, "forward_backward"):
+            raise TypeError("GraphedStep needs a step with forward_backward(tgt) (RenderSupervisedStep, MeshLossStep); the "
+                            "steps that draw their occluder count on the host cannot be captured")
         self.sync = getattr(step, "grad_sync", None)
         if self.sync is not None:
-            self.sync.enabled = False
             from .nn_norm import FusedSyncBatchNorm2d
             if any(isinstance(m, FusedSyncBatchNorm2d) for m in step.net.modules()):
                 raise RuntimeError("GraphedStep: a cross-replica BatchNorm all-reduces inside the forward pass; collectives are "
                                    "not captured -- run this step eagerly")
-        if not hasattr(step, "forward_backward"):
-            raise TypeError("GraphedStep needs a step with forward_backward(tgt) (RenderSupervisedStep, MeshLossStep); the "
-                            "steps that draw their occluder count on the host cannot be captured")
         self.step = step
         self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in tgt.items()}
         from .nn_norm import FusedBatchNorm2d
         self._bns = [m for m in step.net.modules() if isinstance(m, FusedBatchNorm2d)]
         # eager warm-up on a side stream (allocator, lazy tables, weight images): forward + backward only -- no optimizer step --
         # and the BatchNorm running statistics / batch counts are put back, so that building the wrapper does not train
+        with self._hooks_off():
+            self._build(step, warmup, validate)
+
+    @contextlib.contextmanager
+    def _hooks_off(self):
+        """GradAllReducer hooks off for GraphedStep's own passes (warm-up, capture, validation: forward + backward without a
+        collective), whatever happens inside; the reducer's ``enabled`` flag is the caller's everywhere else."""
+        if self.sync is None:
+            yield
+            return
+        was = self.sync.enabled
+        self.sync.enabled = False
+        try:
+            yield
+        finally:
+            self.sync.enabled = was
+
+    def _build(self, step, warmup, validate):
         bufs = [(b, b.clone()) for b in step.net.buffers()]
         pend = [m._pending_batches for m in self._bns]
         side = torch.cuda.Stream()
@@ -358,11 +378,12 @@ class GraphedStep:
         if self.sync is not None:
             for p, g in self._grads:
                 p.grad = g                                  # the tensors the graph wrote (finish() rebinds .grad to bucket views)
-            self.sync.enabled = True
+            was = self.sync.enabled
+            self.sync.enabled = True                        # reduce_now is a no-op on a disabled reducer
             try:
                 self.sync.reduce_now()
             finally:
-                self.sync.enabled = False
+                self.sync.enabled = was                     # the wrapped step stays usable eagerly (its hooks as the caller set them)
         self.step.opt.step()
         return self.loss, self.terms
 

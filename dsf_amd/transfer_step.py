@@ -30,9 +30,13 @@ class ConsisCycleGANStep:
             optimizers = (torch.optim.Adam(itertools.chain(netG_A.parameters(), netG_B.parameters()), lr=lr, betas=(beta1, 0.999)),
                           torch.optim.Adam(itertools.chain(netD_A.parameters(), netD_B.parameters()), lr=lr, betas=(beta1, 0.999)))
         self.opt_G, self.opt_D = optimizers
-        from . import nn_conv
-        # torch.optim writes the parameters in place (version counters bump): the split weight images may be kept between uses
-        nn_conv.manage_weights(itertools.chain(netG_A.parameters(), netG_B.parameters(), netD_A.parameters(), netD_B.parameters()))
+        from . import nn_conv, optim as _optim
+        # torch.optim and FusedAdamW announce their writes (in-place ops bump the version counters / the write epoch): the split
+        # weight images may be kept between uses.  Any other optimizer object (a `.data`-style update, an EMA wrapper) could
+        # write behind torch's back and be served stale images, so its parameters stay unmanaged (re-split per use); such a
+        # caller can opt in with nn_conv.manage_weights(...) + nn_conv.weights_changed() after its writes
+        if all(isinstance(o, (torch.optim.Optimizer, _optim.FusedAdamW)) for o in optimizers):
+            nn_conv.manage_weights(itertools.chain(netG_A.parameters(), netG_B.parameters(), netD_A.parameters(), netD_B.parameters()))
 
     @staticmethod
     def _requires_grad(nets, flag):

@@ -26,7 +26,8 @@ extern "C" {
 #define DSF_MANO_VERTS 779      /* 778 + wrist cap vertex (render_model/mano_layer.py:636-637) */
 #define DSF_MANO_JOINTS 21
 #define DSF_MANO_FACES 1554
-#define DSF_MANO_SAVE_FLOATS 5248   /* per-sample forward state kept for the backward kernel */
+#define DSF_MANO_SAVE_FLOATS 5248   /* per-sample forward state: staging between the two forward kernels, kept for the backward pass */
+#define DSF_MANO_BWD_SCRATCH_FLOATS 2560   /* per-sample staging between the two backward kernels */
 #define DSF_N_SPHERES 66
 
 typedef void* dsf_stream_t;     /* hipStream_t */
@@ -61,8 +62,9 @@ typedef struct dsf_mano_model {
  * coefficients, ncomp <= 45; beta: (B,10); cam: (B,4) = scale|trans or NULL.
  * out = ((raw * k1) * k2) * cam[0] + cam[1:4]   (k1 = 1000, k2 = global_scale in get_mano_vertices;
  * k1 = k2 = 1 and cam = NULL reproduce MANO_SMPL.forward).
- * verts (B,779,3), joints (B,21,3), Rs (B,15,3,3) (may be NULL), save (B,DSF_MANO_SAVE_FLOATS)
- * (may be NULL when no backward is needed).
+ * verts (B,779,3), joints (B,21,3), Rs (B,15,3,3) (may be NULL), save (B,DSF_MANO_SAVE_FLOATS): REQUIRED since ABI 2 --
+ * the blendshape launch (8 samples x 256 columns per workgroup) hands v_posed and the pose state to the per-sample
+ * skinning launch through it, and dsf_mano_backward reads it.
  * param_stride: floats between consecutive samples of beta / theta / rot / cam; 0 = each array tightly packed.  With
  * param_stride = 62 the four pointers can be column offsets into the network's (B,62) output row
  * [rot 3 | theta 45 | beta 10 | cam 4] (Render._split, mano_layer.py:1071-1076): no slicing copies. */
@@ -73,12 +75,15 @@ int dsf_mano_forward(const dsf_mano_model* m, const float* beta, const float* th
 /* grad_verts (B,779,3) / grad_joints (B,21,3): either may be NULL (= zeros).
  * Outputs (all written, not accumulated): grad_beta (B,10), grad_theta (B,ncomp),
  * grad_rot (B,rot_dim), grad_cam (B,4) or NULL; param_stride applies to the inputs and to the four gradients
- * (column offsets into one (B,62) gradient row). */
+ * (column offsets into one (B,62) gradient row).
+ * scratch (B,DSF_MANO_BWD_SCRATCH_FLOATS), since ABI 2: staging between the per-sample skinning / chain launch and the
+ * blendshape-reduction launch; contents undefined before and after the call, `save` is left untouched (a retained graph
+ * can be differentiated again). */
 int dsf_mano_backward(const dsf_mano_model* m, const float* theta, const float* rot, const float* cam,
                       const float* save, const float* grad_verts, const float* grad_joints,
                       int B, int ncomp, int rot_dim, int param_stride, float k1, float k2,
                       float* grad_beta, float* grad_theta, float* grad_rot, float* grad_cam,
-                      dsf_stream_t stream);
+                      float* scratch, dsf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * K1/K2  Mesh rasteriser (pytorch3d==0.4.0 semantics).

@@ -196,8 +196,9 @@ def net_forward(net, img, render, center, cube):
         return [[pix, mano]]
     mano_img, mano_uvd, _, _ = render.render(mano, center, cube)
     remap = I.joints_to_offset_maps(mano_uvd, mano_img, 0.8, 64)
-    # (one dtype for the concatenation: the tests also run this with a float64 trunk around the fp32 geometry)
-    _, _, pix2, mano2 = net._run_trunk(net.fusion(torch.cat([t.to(c0.dtype) for t in (c0, feat, pix, remap)], dim=1)), '_s2')
+    # (one dtype and device for the concatenation: the tests also run this with a float64 trunk, or with the torch twin on
+    #  the GPU, around the fp32 CPU geometry)
+    _, _, pix2, mano2 = net._run_trunk(net.fusion(torch.cat([t.to(device=c0.device, dtype=c0.dtype) for t in (c0, feat, pix, remap)], dim=1)), '_s2')
     return [[pix, mano], [pix2, mano2]]
 
 

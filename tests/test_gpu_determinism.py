@@ -172,9 +172,17 @@ def test_graphed_step_refuses_a_graph_with_memset_nodes(render):
     step = MeshLossStep(net, render, Config, n_points=512)
     p, c, cube = synthetic_batch(4, "cuda", seed=2)
     tgt = step.make_targets(p, c, cube)
+    # a data-parallel caller that catches the refusal and steps eagerly must find its reducer as it left it (ADVICE r3:
+    # the hooks used to stay switched off, so the fallback trained without any all-reduce)
+    import types
+    step.grad_sync = types.SimpleNamespace(enabled=True, finish=lambda: None)
     with pytest.raises(RuntimeError, match="memset node"):
         GraphedStep(step, tgt, warmup=1)
+    assert step.grad_sync.enabled is True
     step(tgt)                                                        # the step itself is untouched and still runs eagerly
+    with pytest.raises(TypeError, match="forward_backward"):
+        GraphedStep(types.SimpleNamespace(grad_sync=step.grad_sync, net=net), tgt)
+    assert step.grad_sync.enabled is True
 
 
 def test_backward_weights_side_stream_is_invisible(det_mode):

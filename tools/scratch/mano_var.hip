@@ -13,7 +13,7 @@
 //
 // Reference: MANO_SMPL.forward / get_mano_vertices / batch_rodrigues / quat2mat /
 // batch_global_rigid_transformation, render_model/mano_layer.py:573-770.
-#include "common.h"
+#include "../../dsf_amd/csrc/common.h"
 
 namespace {
 
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(NT, 3) void mano_skin_kernel(dsf_mano_model m, cons
             const float w[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                if (w[u] != 0.f) {
+                if (VAR == 1 || w[u] != 0.f) {
                     const float* A = s_A + (q * 4 + u) * 12;
 #pragma unroll
                     for (int k = 0; k < 12; ++k) T[k] = fmaf(w[u], A[k], T[k]);
@@ -358,11 +358,11 @@ __global__ __launch_bounds__(NT, 3) void mano_skin_bwd_kernel(dsf_mano_model m, 
         for (int k = 0; k < 9; ++k) T[k] = 0.f;
         for (int i = 0; i < 16; ++i) {
             const float w = m.weights[v * 16 + i];
-            if (w != 0.f) {
+            if (VAR == 1 || w != 0.f) {
 #pragma unroll
                 for (int r = 0; r < 3; ++r)
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) T[r * 3 + c] = fmaf(w, s_G[i * 12 + r * 4 + c], T[r * 3 + c]);
+                    for (int c = 0; c < 3; ++c) T[r * 3 + c] = fmaf(w, (VAR == 2 ? ((volatile float*)s_G)[i * 12 + r * 4 + c] : s_G[i * 12 + r * 4 + c]), T[r * 3 + c]);
             }
         }
         const float g0 = s_gv[v * 3], g1 = s_gv[v * 3 + 1], g2 = s_gv[v * 3 + 2];
@@ -551,7 +551,7 @@ static_assert(64 * BB_SB <= NT && 16 * BB_SB <= NT, "one launch covers the per-s
 
 }  // namespace
 
-extern "C" int dsf_mano_forward(const dsf_mano_model* m, const float* beta, const float* theta, const float* rot,
+extern "C" int dsf_mano_forward_var(const dsf_mano_model* m, const float* beta, const float* theta, const float* rot,
                                 const float* cam, int B, int ncomp, int rot_dim, int param_stride, float k1, float k2,
                                 float* verts, float* joints, float* Rs, float* save, dsf_stream_t stream) {
     DSF_CHECK_ARG(m && beta && theta && rot && verts && joints && save);
@@ -564,7 +564,7 @@ extern "C" int dsf_mano_forward(const dsf_mano_model* m, const float* beta, cons
     return dsf_launch_status();
 }
 
-extern "C" int dsf_mano_backward(const dsf_mano_model* m, const float* theta, const float* rot, const float* cam,
+extern "C" int dsf_mano_backward_var(const dsf_mano_model* m, const float* theta, const float* rot, const float* cam,
                                  const float* save, const float* grad_verts, const float* grad_joints, int B,
                                  int ncomp, int rot_dim, int param_stride, float k1, float k2, float* grad_beta,
                                  float* grad_theta, float* grad_rot, float* grad_cam, float* scratch, dsf_stream_t stream) {
