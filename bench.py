@@ -24,6 +24,18 @@ sys.path.insert(0, ROOT)
 import torch
 import torch.distributed as dist
 
+def cpu_model():
+    """the host CPU's model string (stated beside the core count of the CPU baseline)"""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
 def usable_cpus():
     """Cores this process may really use: min(affinity mask, cgroup quota).  os.cpu_count() reports the
     host's cores even inside a CPU-limited container; oversubscribing the OpenMP pools stalls for minutes."""
@@ -240,6 +252,97 @@ def crop_kernel_roofline(render, B, launches=200):
                     "face-parallel path walk boxes of different sizes (divergence), and ~25 us of the launch are the "
                     "projection + face boxes every workgroup repeats and the walk over empty tiles (tools/perf_crop.py); "
                     "2 launches per step = 0.8 % of it, 0.5 % of config 5: left as it is (DESIGN.md section 5)"}
+
+
+def geometry_rooflines(render, B, launches=50):
+    """"report each fraction separately" -- the geometry kernels of the path timed alone with HIP events on the stream
+    they are launched on (torch's current stream), each against the bound that applies to it.  Sizes = one GPU's share of the
+    BASELINE configuration that uses the kernel (B samples, 2048-point clouds, 1554 faces, 21 joints, 84-channel 64x64 maps)."""
+    from dsf_amd.metric.meshLoss import ICPLoss, JointICPLoss
+    from dsf_amd.train_step import synthetic_batch
+    from dsf_amd.util.generateFeature import GFM
+    mano = render.mano_layer
+    gfm = GFM()
+    p, c, cube = synthetic_batch(B, "cuda", seed=321)
+    P = 2048
+
+    def timed(fn):
+        for _ in range(5):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(launches):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / launches
+    rows = []
+    valu_peak = 256 * 4 * 32 * 2.4e9                       # lane-instructions per second (as in roofline_raster)
+
+    def hbm_row(kid, kernel, us, nbytes, note):
+        gbs = nbytes / (us * 1e-6) / 1e9
+        rows.append({"id": kid, "kernel": kernel, "avg_launch_us": round(us, 2), "bound": "hbm", "achieved": round(gbs, 2),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "bytes_per_launch": int(nbytes),
+                     "note": note})
+    with torch.no_grad():
+        jx, mesh = render.get_mesh_xyz(p)
+        g = torch.Generator(device="cuda").manual_seed(5)
+        idx = torch.randint(0, 779, (B, P), device="cuda", generator=g)
+        pcl = (torch.gather(mesh, 1, idx[..., None].expand(-1, -1, 3)) + 0.02 * torch.randn(B, P, 3, device="cuda", generator=g)).contiguous()
+        seg = mano.seg_pcl(jx, jx, mesh, pcl)
+        # K3: point-to-triangle distance, every point against every triangle (ICPLoss) and against its part (JointICPLoss)
+        us = timed(lambda: ICPLoss(mesh, pcl, mano.faces))
+        pairs = B * P * 1554
+        per_pair = 18.0                                     # the cheapest a pair can be: seed compare (9) + sphere test (9)
+        rows.append({"id": "K3", "kernel": "mesh_point_fwd_kernel (ICPLoss: %d points x 1554 triangles per sample)" % P,
+                     "avg_launch_us": round(us, 2), "bound": "valu", "achieved": round(pairs / (us * 1e-6) / 1e12, 4),
+                     "peak": round(valu_peak / per_pair / 1e12, 3), "unit": "T pair-tests/s",
+                     "frac": round(pairs / (us * 1e-6) / (valu_peak / per_pair), 4), "pairs_per_launch": pairs,
+                     "note": "algorithmic pair-tests (every point x every triangle of its sample) per second; peak = VALU issue "
+                             "peak / 18 lane-instructions, the least a pair costs in the culled kernel (nearest-centre seed "
+                             "compare + bounding-sphere test); a pair that survives the cull costs ~120 more (the oracle's "
+                             "arithmetic incl. 5 IEEE divisions).  Round 3's brute-force kernel: 712 us at B = 64 = 0.29 T/s"})
+        us = timed(lambda: JointICPLoss(mesh, pcl, mano.joint_faces, seg))
+        rows.append({"id": "K3p", "kernel": "mesh_point_fwd_kernel (JointICPLoss: points x the triangles of their part, 15 parts)",
+                     "avg_launch_us": round(us, 2), "bound": "valu", "note": "one (sample, part) workgroup per part: latency of the "
+                     "largest part's point list; no separate model"})
+        # K5: MANO layer (two launches each way since round 4)
+        q = p.clone().requires_grad_(True)
+    from dsf_amd import ops
+    with torch.no_grad():
+        us = timed(lambda: ops.ManoPackedFunction.apply(mano._native(), p, 1000.0, 1.0))
+    const_bytes = (135 + 10 + 1) * 2334 * 4 + 778 * 16 * 4
+    hbm_row("K5f", "mano_blend_kernel + mano_skin_kernel (forward)", us, B * (62 * 4 + 779 * 12 + 21 * 12 + 5248 * 4) + const_bytes,
+            "latency-bound: 2 dependent launches, the second one a 15-step kinematic chain per sample; bytes = parameters in, "
+            "vertices / joints / saved state out per sample + the 1.4 MB of model constants once")
+    v, j = ops.ManoPackedFunction.apply(mano._native(), q, 1000.0, 1.0)
+    gv, gj = torch.randn_like(v), torch.randn_like(j)
+    us = timed(lambda: torch.autograd.grad([v, j], q, [gv, gj], retain_graph=True))
+    hbm_row("K5b", "mano_skin_bwd_kernel + mano_blend_bwd_kernel (backward)", us,
+            B * (779 * 12 + 21 * 12 + 5248 * 4 + 2 * 2560 * 4 + 62 * 4) + ((B + 1) // 2) * const_bytes,
+            "latency-bound: 256-thread workgroups that fit beside two convolution workgroups per CU (78 us as one 1024-thread "
+            "workgroup per sample in round 3, which then waited 700 us for a drained CU inside the step); the constants are "
+            "read once per PAIR of samples (L2 / Infinity Cache resident)")
+    with torch.no_grad():
+        # K6 / K7
+        us = timed(lambda: mano.calculate_coll(jx, mesh))
+        hbm_row("K6", "sphere_set + collision_fwd_kernel (calculate_coll)", us, B * (779 * 12 + 21 * 12 + 66 * 16 + 264),
+                "latency-bound (one workgroup per sample, iterative top-10 per wave); bytes are negligible")
+        us = timed(lambda: mano.seg_pcl(jx, jx, mesh, pcl))
+        hbm_row("K7", "sphere_set + seg_pcl_kernel (%d points per sample)" % P, us, B * (P * 12 + P * 8 + 66 * 16),
+                "VALU-bound by model (66 sphere tests per point), tiny; reported against HBM as SURVEY 8d lists it")
+        # K10: offset-map encode / decode (84 channels x 64 x 64 per sample)
+        img = torch.rand(B, 1, 128, 128, device="cuda")
+        juvd = (torch.rand(B, 21, 3, device="cuda") - 0.5)
+        us = timed(lambda: gfm.joint2offset(juvd, img, 0.8, 64))
+        hbm_row("K10e", "joint2offset_fwd_cl_kernel (encode)", us, B * (84 * 64 * 64 * 4 + 128 * 128 * 4 + 21 * 12),
+                "streaming write of the 84-channel map (channels-last)")
+        maps = gfm.joint2offset(juvd, img, 0.8, 64)
+        us = timed(lambda: gfm.offset2joint_softmax(maps, img, 0.8))
+        hbm_row("K10d", "offset2joint_* (soft-argmax decode)", us, B * (84 * 64 * 64 * 4 + 128 * 128 * 4 + 21 * 12),
+                "one read of the 84-channel map; (sample, joint) workgroups")
+    return rows
 
 
 def self_launch(n):
@@ -561,6 +664,8 @@ def main():
         out["roofline"], out["conv_kernels"] = conv_kernel_roofline(step, w["run_diag"])
         if args.config == 2:
             out["roofline_raster"] = crop_kernel_roofline(w["render"], B)
+        if args.config in (2, 3):
+            out["roofline_geometry"] = geometry_rooflines(w["render"], B)
             out["fp32_mfma_path"] = same_step_on_fp32_mfma(step, w["tgt"], B)
         if "x6" in out["roofline"]["kernel"]:
             out["roofline"]["measured_mfma_ceiling"] = measured_mfma_ceiling()
@@ -580,7 +685,7 @@ def main():
             torch.set_num_threads(cores)
             os.environ["OMP_NUM_THREADS"] = str(cores)
             ips, secs, n, what = w["cpu"](args.cpu_steps)
-            out["cpu_baseline"] = {"value": round(ips, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            out["cpu_baseline"] = {"value": round(ips, 3), "unit": "images/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port",
                                    "sample": "%d images: %s through the CPU oracle (torch-CPU trunk, C rasteriser / point-face "
                                              "distances, numpy crop chain), %.1f s" % (n, what, secs)}
         print(json.dumps(out))

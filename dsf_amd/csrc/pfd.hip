@@ -194,10 +194,12 @@ __global__ void pfd_packed_bwd_kernel(const float* __restrict__ points, const fl
 // rule compares indices, so the order in which triangles are visited no longer matters.  That allows (1) a seed: each
 // lane first finds the sphere centre nearest to its point (9 operations per pair) and evaluates that triangle, which puts
 // `best` within a small factor of the minimum before the scan starts; (2) points taken in a spatially coherent order (a
-// counting sort of the sample's cloud by 9-bit Morton cell, rebuilt by every workgroup of the sample in LDS), so that
-// the 64 lanes of a wave skip the same triangles -- a triangle is evaluated when ANY live lane needs it.
+// counting sort of the sample's cloud by 9-bit Morton cell, rebuilt by every workgroup of the sample in LDS; a workgroup
+// takes the WHOLE cells whose first slot falls into its 256-slot window, so the partition does not depend on the order the
+// LDS atomics give inside a cell), so that the 64 lanes of a wave skip the same triangles -- a triangle is evaluated when
+// ANY live lane needs it.
 constexpr int LIST_CAP = 4096;      // points per workgroup range (uint16 list entries)
-constexpr int SPH_CAP = 2048;       // triangles per (sample, part) range the cull holds spheres for (MANO: 1554)
+constexpr int CH = 224;             // triangle records + spheres staged per pass (7 passes over MANO's 1554 faces)
 constexpr float CULL_M = 1e-4f;
 
 __device__ __forceinline__ float4 tri_sphere(const TriRec& r) {
@@ -226,12 +228,18 @@ __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __rest
                                                              const int64_t* __restrict__ seg, int V, int P, int n_parts,
                                                              int splits, float* __restrict__ dists,
                                                              int32_t* __restrict__ idxs) {
-    __shared__ TriRec s_tri[CHUNK];
-    __shared__ float4 s_sph[SPH_CAP];
+    // 29.7 KB of LDS = 5 workgroups per CU: the pair loop is a chain of dependent divisions and LDS broadcasts, it needs the waves
+    // (a first version with every sphere of the range resident, 60 KB, ran the plain loop 3.6 x slower than round 3's kernel).
+    // The triangle stage and the scratch of the point sort share their bytes: the sort is over before the first stage is built.
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[CH * (sizeof(TriRec) + sizeof(float4))];
+    TriRec* const s_tri = reinterpret_cast<TriRec*>(s_raw);
+    float4* const s_sph = reinterpret_cast<float4*>(s_raw + CH * sizeof(TriRec));
+    int* const s_hist = reinterpret_cast<int*>(s_raw);                  // 512 cell counters
+    uint8_t* const s_owner = s_raw + 2048;                              // 512 cell owners
+    float* const s_box = reinterpret_cast<float*>(s_raw + 2560);        // 4 waves x (min, max)
     __shared__ uint16_t s_list[LIST_CAP];
-    __shared__ int s_hist[512];
-    __shared__ float s_box[4 * 6];
-    __shared__ int s_n, s_wsum[4];
+    __shared__ uint8_t s_cand[4 * CH];                                  // per wave: the staged triangles its ball can reach
+    __shared__ int s_n, s_hi, s_wsum[4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     int w = blockIdx.x;
     const int split = w % splits; w /= splits;
@@ -240,7 +248,6 @@ __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __rest
     const float* vb = verts + (int64_t)b * V * 3;
     const float* pb = points + (int64_t)b * P * 3;
     const int f0 = part_first[part], f1 = part_first[part + 1];
-    const bool cull = (f1 - f0) <= SPH_CAP;
 
     int pbeg, n_mine;                  // this workgroup's points: s_list[0 .. n_mine) + pbeg, or the plain range when !listed
     bool listed = true;
@@ -298,6 +305,7 @@ __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __rest
             return k;
         };
         for (int p = t; p < P; p += 256) atomicAdd(&s_hist[cell(p)], 1);
+        if (t == 0) { s_n = 0x7fffffff; s_hi = 0; }
         __syncthreads();
         {                                                               // exclusive scan of the 512 cell counts
             const int a0 = s_hist[2 * t], a1 = s_hist[2 * t + 1];
@@ -310,68 +318,114 @@ __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __rest
             for (int q = 0; q < wave; ++q) base += s_wsum[q];
             const int excl = base + v - (a0 + a1);
             s_hist[2 * t] = excl; s_hist[2 * t + 1] = excl + a0;
+            // a cell belongs to the workgroup whose 256-slot window holds the cell's FIRST slot: whole cells, so that the
+            // partition of the cloud over the sample's workgroups does not depend on the order inside a cell
+            const int o0 = excl >> 8, o1 = (excl + a0) >> 8;
+            s_owner[2 * t] = (uint8_t)min(o0, 255); s_owner[2 * t + 1] = (uint8_t)min(o1, 255);
+            if (a0 > 0 && o0 == split) { atomicMin(&s_n, excl); atomicMax(&s_hi, excl + a0); }
+            if (a1 > 0 && o1 == split) { atomicMin(&s_n, excl + a0); atomicMax(&s_hi, excl + a0 + a1); }
         }
         __syncthreads();
-        for (int p = t; p < P; p += 256) s_list[atomicAdd(&s_hist[cell(p)], 1)] = (uint16_t)p;
+        const int first = s_n;
+        n_mine = max(0, s_hi - first);                                  // <= 255 + the largest cell <= P <= LIST_CAP
+        for (int p = t; p < P; p += 256) {
+            const int k = cell(p);
+            if (s_owner[k] == split) s_list[atomicAdd(&s_hist[k], 1) - first] = (uint16_t)p;
+        }
         __syncthreads();
         pbeg = 0;
-        n_mine = 0;                                                     // handled below through `sorted`
     } else {
+        // clouds too large for the LDS list: plain index ranges (the cull still applies, lane-coherence is what it is)
         listed = false;
         pbeg = 0; n_mine = 0;
     }
-    const bool sorted = !seg && listed;
-    // the groups of 256 points this workgroup walks: (seg) its compacted list; (no seg) ONE group: slots split*256 + t
-    const int n_groups = seg ? (n_mine + 255) / 256 : 1;
+    // the groups of 256 points this workgroup walks: its list (part-compacted, or Morton-cell sorted), else slots split*256 + t
+    const int n_groups = listed ? (n_mine + 255) / 256 : 1;
 
-    if (cull) {                                                         // spheres of the whole triangle range, once
-        for (int f = f0 + t; f < f1; f += 256) {
-            const int32_t* fc = faces + f * 3;
-            s_sph[f - f0] = tri_sphere(make_tri(ld3(vb + fc[0] * 3), ld3(vb + fc[1] * 3), ld3(vb + fc[2] * 3), 0));
+    auto stage = [&](int base, bool full) {             // records (full) and spheres of triangles base .. base + CH of the range
+        __syncthreads();                                 // everybody is done with the previous stage (or with the sort scratch)
+        if (t < CH && base + t < f1) {
+            const int32_t* fc = faces + (base + t) * 3;
+            const TriRec r = make_tri(ld3(vb + fc[0] * 3), ld3(vb + fc[1] * 3), ld3(vb + fc[2] * 3), t);
+            if (full) s_tri[t] = r;
+            s_sph[t] = tri_sphere(r);
         }
-    }
+        __syncthreads();
+    };
     for (int g = 0; g < n_groups; ++g) {
         bool live;
         int p;
-        if (seg) { live = g * 256 + t < n_mine; p = live ? pbeg + s_list[g * 256 + t] : 0; }
-        else { const int slot = split * 256 + t; live = slot < P; p = live ? (sorted ? (int)s_list[slot] : slot) : 0; }
+        if (listed) { live = g * 256 + t < n_mine; p = live ? pbeg + s_list[g * 256 + t] : 0; }
+        else { p = split * 256 + t; live = p < P; p = live ? p : 0; }
         const f3 pt = live ? ld3(pb + p * 3) : mk3(0.f, 0.f, 0.f);
         float best = INFINITY, thr = INFINITY;          // thr = sqrt(best) * (1 + m) * 1.0011 / (1 - m), refreshed with best
         int bi = -1;
-        __syncthreads();                                 // s_sph complete (first group) / previous group done with s_tri
-        if (cull && live && f1 > f0) {
-            // seed: the triangle whose sphere centre is nearest
+        // ---- seed: the nearest sphere centre among every 8th triangle, evaluated exactly ----
+        if (f1 > f0) {
             float dmin = INFINITY;
-            int smin = 0;
-            for (int q = 0; q < f1 - f0; ++q) {
+            int smin = f0;
+            for (int base = f0; base < f1; base += CH) {
+                stage(base, false);
+                const int cnt = min(CH, f1 - base);
+                for (int q = 0; q < cnt; q += 8) {
+                    const float4 s = s_sph[q];
+                    const float dx = pt.x - s.x, dy = pt.y - s.y, dz = pt.z - s.z;
+                    const float d2 = dx * dx + dy * dy + dz * dz;
+                    if (d2 < dmin) { dmin = d2; smin = base + q; }
+                }
+            }
+            if (live) {
+                const int32_t* fc = faces + smin * 3;
+                const TriRec r = make_tri(ld3(vb + fc[0] * 3), ld3(vb + fc[1] * 3), ld3(vb + fc[2] * 3), 0);
+                best = point_tri_dist2(pt, r);
+                bi = smin;
+                thr = sqrtf(best) * ((1.0f + CULL_M) * 1.0011f / (1.0f - CULL_M));
+            }
+        }
+        // ---- the wave's points as ONE ball (centre of their box, radius to the farthest) and its loosest threshold: a triangle
+        //      with |c_tri - c_wave| - r_wave > R_tri + thr_max is skipped by every lane's own test, so one lane per TRIANGLE can
+        //      discard 64 of them per instruction; NaN-ignoring min / max keep a lane with broken coordinates from widening it ----
+        float bx0 = live ? pt.x : INFINITY, by0 = live ? pt.y : INFINITY, bz0 = live ? pt.z : INFINITY;
+        float bx1 = live ? pt.x : -INFINITY, by1 = live ? pt.y : -INFINITY, bz1 = live ? pt.z : -INFINITY;
+        float tmax = live ? thr : 0.f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            bx0 = fminf(bx0, __shfl_xor(bx0, o, 64)); by0 = fminf(by0, __shfl_xor(by0, o, 64)); bz0 = fminf(bz0, __shfl_xor(bz0, o, 64));
+            bx1 = fmaxf(bx1, __shfl_xor(bx1, o, 64)); by1 = fmaxf(by1, __shfl_xor(by1, o, 64)); bz1 = fmaxf(bz1, __shfl_xor(bz1, o, 64));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, o, 64));
+        }
+        const f3 cw = mk3(0.5f * (bx0 + bx1), 0.5f * (by0 + by1), 0.5f * (bz0 + bz1));
+        float rw = 0.f;
+        if (live) { const f3 d = pt - cw; rw = sqrtf(dot(d, d)); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) rw = fmaxf(rw, __shfl_xor(rw, o, 64));
+        const float wave_reach = (rw + tmax) * (1.0f + CULL_M);       // (inf / NaN when some lane has no finite threshold: nothing is discarded)
+        // ---- scan ----
+        for (int base = f0; base < f1; base += CH) {
+            stage(base, true);
+            const int cnt = min(CH, f1 - base);
+            int n_cand = 0;                              // wave-uniform
+            for (int q0 = 0; q0 < cnt; q0 += 64) {
+                const int q = q0 + lane;
+                bool keep = false;
+                if (q < cnt) {
+                    const float4 s = s_sph[q];
+                    const float dx = cw.x - s.x, dy = cw.y - s.y, dz = cw.z - s.z;
+                    const float dc = sqrtf(dx * dx + dy * dy + dz * dz) * (1.0f - CULL_M);
+                    keep = !(dc > s.w + wave_reach);
+                }
+                const unsigned long long m = __ballot(keep);
+                if (keep) s_cand[wave * CH + n_cand + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)q;
+                n_cand += __popcll(m);
+            }
+            __syncthreads();                             // the candidate list of this wave is in LDS
+            for (int i = 0; i < n_cand; ++i) {
+                const int q = s_cand[wave * CH + i];
                 const float4 s = s_sph[q];
                 const float dx = pt.x - s.x, dy = pt.y - s.y, dz = pt.z - s.z;
-                const float d2 = dx * dx + dy * dy + dz * dz;
-                if (d2 < dmin) { dmin = d2; smin = q; }
-            }
-            const int32_t* fc = faces + (f0 + smin) * 3;
-            const TriRec r = make_tri(ld3(vb + fc[0] * 3), ld3(vb + fc[1] * 3), ld3(vb + fc[2] * 3), 0);
-            best = point_tri_dist2(pt, r);
-            bi = f0 + smin;
-            thr = sqrtf(best) * ((1.0f + CULL_M) * 1.0011f / (1.0f - CULL_M));
-        }
-        for (int base = f0; base < f1; base += CHUNK) {
-            __syncthreads();
-            if (base + t < f1) {
-                const int32_t* fc = faces + (base + t) * 3;
-                s_tri[t] = make_tri(ld3(vb + fc[0] * 3), ld3(vb + fc[1] * 3), ld3(vb + fc[2] * 3), t);
-            }
-            __syncthreads();
-            const int cnt = min(CHUNK, f1 - base);
-            for (int q = 0; q < cnt; ++q) {
-                bool need = live;
-                if (cull) {
-                    const float4 s = s_sph[base - f0 + q];
-                    const float dx = pt.x - s.x, dy = pt.y - s.y, dz = pt.z - s.z;
-                    const float lim = s.w + thr;
-                    need = live && !(dx * dx + dy * dy + dz * dz > lim * lim);      // (NaN distances are never skipped)
-                    if (!__any(need)) continue;                                    // wave-uniform: nobody needs this triangle
-                }
+                const float lim = s.w + thr;
+                const bool need = live && !(dx * dx + dy * dy + dz * dz > lim * lim);      // (NaN distances are never skipped)
+                if (!__any(need)) continue;                                                // nobody needs this triangle
                 if (need) {
                     const float d = point_tri_dist2(pt, s_tri[q]);
                     const int id = base + q;

@@ -199,11 +199,16 @@ class MeshLossStep:
         return l_m2d + l_part + l_icp + l_coll + l_sup, terms
 
     def forward_backward(self, tgt):
+        from . import nn_conv
         self.opt.zero_grad(set_to_none=True)
         self.render.mano_layer.clear_cache()                 # results of the previous step must not outlive its graph
+        if not hasattr(self, "_pool_floats"):                # one zero fill per step for the ~90 weight gradients of the
+            self._pool_floats = nn_conv.weight_grad_floats(self.net) + 64          # hourglass instead of one launch each
+            self._pool_dev = next(self.net.parameters()).device
         with _stat_pool(self, self.net):
             loss, terms = self.loss(tgt)
-            loss.backward()
+            with nn_conv.grad_pool(self._pool_floats if self._pool_dev.type == "cuda" else 0, self._pool_dev):
+                loss.backward()
         return loss.detach(), terms
 
     def __call__(self, tgt):

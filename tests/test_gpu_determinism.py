@@ -360,3 +360,90 @@ def test_backward_on_a_worker_thread_matches_the_main_thread(det_mode):
         assert got, "the worker thread did not finish"
         for a, b in zip(ref[0], got[0]):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("kind", ["config2", "config3"])
+def test_every_kernel_of_a_step_is_stable_beside_convolution_workgroups(render, det_mode, kind):
+    """Found in round 4: a kernel that is correct alone can return different bits while conv_x6 workgroups share its CUs.
+    The first 256-thread MANO backward (built so that it CAN take the wave slot beside two convolution workgroups) had its
+    skinning loop SLP-vectorised into v_pk_fma_f32 / ds_read_b128 by the compiler and then returned wrong first components in
+    lanes 48-63 of a wave in 170 of 200 launches beside backward-weights or forward conv_x6 launches on a second stream -- never
+    alone, never beside the fp32-MFMA kernels, rocBLAS or elementwise kernels, and never when compiled without the SLP
+    vectoriser (profiles/r04_mano_beside_conv_x6.txt; mano.hip is built with -fno-slp-vectorize since).  The whole-step
+    determinism test above only sees the kernels that happen to overlap the side stream's own work; this one runs every kernel
+    of the step (one stream, deterministic mode) while an unrelated stream keeps conv_x6 workgroups on every CU, and requires
+    the bits of the unloaded run."""
+    from dsf_amd import nn_conv
+    from dsf_amd.model.backbone import MANO_OCR_stage
+    from dsf_amd.model.hourglass import PoseNetMANO
+    from dsf_amd.train_step import RenderSupervisedStep, MeshLossStep, synthetic_batch, Config
+    torch.manual_seed(0)
+    if kind == "config2":
+        net = MANO_OCR_stage("ResNet_stage_18", 21, True).cuda()
+        with torch.no_grad():
+            for head in (net.mano_regress[2], net.mano_regress_s2[2]):
+                head.bias[58] = 1.0
+        step = RenderSupervisedStep(net, render, Config)
+    else:
+        net = PoseNetMANO(1, 21).cuda()
+        step = MeshLossStep(net, render, Config, n_points=512)
+    p, c, cube = synthetic_batch(8, "cuda", seed=2)
+    tgt = step.make_targets(p, c, cube)
+    x = torch.randn(32, 256, 64, 64, device="cuda").contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(32, 256, 64, 64, device="cuda").contiguous(memory_format=torch.channels_last)
+    conv = nn_conv.Conv2d(256, 256, 3, 1, 1, bias=False).cuda()
+    side = torch.cuda.Stream()
+
+    def run(load):
+        if load:
+            with torch.cuda.stream(side), torch.no_grad():                 # ~8 ms of conv_x6 workgroups on every CU
+                for _ in range(3):
+                    nn_conv._wrw(x, gy, 3, 3, 1, (1, 1))
+                    conv(x)
+        net.zero_grad(set_to_none=True)
+        render.mano_layer.clear_cache()
+        loss = step.loss(tgt)[0]
+        loss.backward()
+        torch.cuda.synchronize()
+        return [loss.detach().clone()] + _grads(net)
+    old = nn_conv.WRW_STREAM[0]
+    nn_conv.WRW_STREAM[0] = False                                          # the step's own kernels all on one stream
+    try:
+        ref = run(False)
+        again = run(False)
+        assert all(torch.equal(a, b) for a, b in zip(ref, again))
+        for r in range(6):
+            got = run(True)
+            bad = [i for i, (a, b) in enumerate(zip(ref, got)) if not torch.equal(a, b)]
+            assert not bad, "run %d beside conv_x6 workgroups: %d of %d tensors differ from the unloaded run" % (r, len(bad), len(ref))
+    finally:
+        nn_conv.WRW_STREAM[0] = old
+
+
+def test_mano_backward_is_stable_beside_convolution_workgroups(render):
+    """the reproducer of the finding above, on the shipped library: 100 MANO backward calls while backward-weights launches of
+    conv_x6 run on a second stream must all return the bits of a call that ran alone"""
+    from dsf_amd import nn_conv, ops
+    from dsf_amd.train_step import synthetic_batch
+    p, _, _ = synthetic_batch(32, "cuda", seed=4)
+    mano = render.mano_layer
+    gV = torch.randn(32, 779, 3, device="cuda")
+    gJ = torch.randn(32, 21, 3, device="cuda")
+    x = torch.randn(32, 256, 64, 64, device="cuda").contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(32, 256, 64, 64, device="cuda").contiguous(memory_format=torch.channels_last)
+    side = torch.cuda.Stream()
+
+    def grad():
+        q = p.clone().requires_grad_(True)
+        v, j = ops.ManoPackedFunction.apply(mano._native(), q, 1000.0, 1.0)
+        g, = torch.autograd.grad([v, j], q, [gV, gJ])
+        torch.cuda.synchronize()
+        return g
+    ref = grad()
+    bad = 0
+    for _ in range(100):
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                nn_conv._wrw(x, gy, 3, 3, 1, (1, 1))
+        bad += int(not torch.equal(grad(), ref))
+    assert bad == 0, "%d of 100 MANO backward calls beside conv_x6 workgroups differ from the call that ran alone" % bad

@@ -14,25 +14,32 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+_RETRIED = []          # (test name, attempt) of every comparison that had to be repeated in this session
+
+
 def _shared_gpu_retry(attempts=4):
-    """These tests put TWO processes on the ONE GPU of the test box.  On this pool a GPU that is time-sliced between busy
-    processes occasionally returns wrong bits from kernels that contain an IEEE float division: a stand-alone HIP program
-    (tools/platform/tiny_kernel_soak.hip -- no torch, no libdsf_hip.so, constant inputs, a ten-line elementwise kernel) gets
-    ~1.3 % of its launches wrong while two other processes load the GPU and none of 30,000 when it has the GPU to itself
-    (profiles/r03_gpu_sharing.txt; the damage is always the quotient of the lanes 48-63 of a wave, as if the upper half of VCC
-    were lost between v_div_scale and v_div_fmas when the wave is switched out).  One process per GPU -- the deployment, and
-    every single-process test of this suite -- never shows it (deterministic-mode soaks: 40 x 3 steps bitwise equal).  So a
-    comparison that fails here is repeated: a defect of the data-parallel logic fails every attempt, the platform's
-    corruption (observed in 2 of 6 runs of the graphed-step test) almost never fails four in a row."""
+    """These tests put TWO processes on the ONE GPU of the test box, so kernels of the two ranks share CUs.  On this pool a
+    kernel that is correct on a GPU of its own can then return wrong bits in lanes 48-63 of a wave: round 3 saw it in kernels
+    with IEEE divisions beside other processes (profiles/r03_gpu_sharing.txt, stand-alone reproducer
+    tools/platform/tiny_kernel_soak.hip), round 4 in a packed-FP32 loop beside conv_x6 workgroups of the SAME process
+    (tools/platform/mano_beside_conv_x6.py; that kernel is built without the SLP vectoriser since).  One process per GPU -- the
+    deployment, and every single-process test of this suite -- does not show it (deterministic-mode soaks bitwise equal,
+    tests/test_gpu_determinism.py::test_every_kernel_of_a_step_is_stable_beside_convolution_workgroups).  So a comparison that
+    fails here is repeated -- a defect of the data-parallel logic fails every attempt -- but NOT silently: every repeat is
+    recorded and warned about, and the session fails if more than one test needed one (test_zz_retries_stayed_rare)."""
     def deco(fn):
         @functools.wraps(fn)
         def wrapped(*a, **k):
             for i in range(attempts):
                 try:
                     return fn(*a, **k)
-                except AssertionError:
+                except AssertionError as e:
                     if i == attempts - 1:
                         raise
+                    _RETRIED.append((fn.__name__, i + 1))
+                    import warnings
+                    warnings.warn("%s: attempt %d failed a comparison (%s); repeating -- two processes share this GPU"
+                                  % (fn.__name__, i + 1, str(e).splitlines()[0][:200] if str(e) else "assert"))
         return wrapped
     return deco
 
@@ -196,6 +203,7 @@ def _graph_worker(rank, world, port, q):
         p, c, cube = synthetic_batch(3, "cuda", seed=10 + rank)
         tgt = step.make_targets(p, c, cube, seed=20 + rank)
         run = GraphedStep(step, tgt) if graphed else step
+        assert sync.enabled is True                    # building the graph leaves the reducer's hooks as they were
         for it in range(3):
             loss, _ = run(tgt)
         torch.cuda.synchronize()
@@ -246,3 +254,79 @@ def test_bench_two_ranks_on_one_gpu_flow(graph):
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 8 and j["config"]["hip_graph"] == graph
     assert j["distributed"]["world_size_observed"] == 2 and j["value"] > 0 and "roofline" in j
+
+
+def _whole_batch_targets(step, seed=40):
+    from dsf_amd.train_step import synthetic_batch
+    p, c, cube = synthetic_batch(6, "cuda", seed=seed)
+    return step.make_targets(p, c, cube, seed=seed + 1)
+
+
+def _syncbn_worker(rank, world, port, q):
+    """the real step with cross-replica BatchNorm, deterministic mode: rank r trains on rows [3r, 3r + 3) of ONE batch of 6"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from dsf_amd.parallel import init_distributed, GradAllReducer, convert_sync_batchnorm
+    from dsf_amd.train_step import RenderSupervisedStep, Config
+    from dsf_amd import _lib as L
+    init_distributed("gloo")
+    torch.cuda.set_device(0)
+    L.set_deterministic(True)
+    net, render = _build()
+    convert_sync_batchnorm(net)
+    sync = GradAllReducer(net.parameters())
+    step = RenderSupervisedStep(net, render, Config, grad_sync=sync)
+    tgt = {k: v[rank * 3:rank * 3 + 3].contiguous() for k, v in _whole_batch_targets(step).items()}
+    loss, _ = step.forward_backward(tgt)
+    sync.finish()
+    torch.cuda.synchronize()
+    g = torch.cat([pp.grad.detach().reshape(-1).float().cpu() if pp.grad is not None else torch.zeros(pp.numel()) for pp in net.parameters()])
+    q.put((rank, g.numpy(), float(loss)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@_shared_gpu_retry()
+def test_two_rank_gradient_equals_the_single_process_gradient_of_the_whole_batch():
+    """What the lockstep test above cannot see (both ranks could agree on a WRONG average): with cross-replica BatchNorm two
+    ranks on half a batch each compute the function one process computes on the whole batch, so the gradient every rank
+    applies must be the whole-batch gradient -- here for the real two-stage step on the GPU, all 154 parameter tensors, against
+    a single-process run (plain fused BatchNorm, no reducer) on the same 6 samples.  Not bitwise: the two sides sum in different
+    orders (per-rank partial sums, then the all-reduce)."""
+    import torch.multiprocessing as mp
+    from dsf_amd.train_step import RenderSupervisedStep, Config
+    from dsf_amd import _lib as L
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, g0, l0), (_, g1, l1) = res
+    assert np.array_equal(g0, g1)                                          # both ranks hold the same averaged gradient
+    old = L.set_deterministic(True)
+    try:
+        net, render = _build()
+        step = RenderSupervisedStep(net, render, Config)
+        loss, _ = step.forward_backward(_whole_batch_targets(step))
+        torch.cuda.synchronize()
+    finally:
+        L.set_deterministic(old)
+    ref = torch.cat([pp.grad.detach().reshape(-1).float().cpu() if pp.grad is not None else torch.zeros(pp.numel()) for pp in net.parameters()]).numpy().astype(np.float64)
+    got = g0.astype(np.float64)
+    rel = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+    cos = float(got @ ref / (np.linalg.norm(got) * np.linalg.norm(ref)))
+    print("two ranks + cross-replica BN vs one process on the whole batch: loss %.6f / %.6f vs %.6f, gradient rel %.2e cos %.7f" % (l0, l1, float(loss), rel, cos))
+    assert abs(0.5 * (l0 + l1) - float(loss)) <= 1e-4 * abs(float(loss))   # mean of the shard losses = the whole-batch loss
+    assert rel < 2e-3 and cos > 0.99999, (rel, cos)
+
+
+def test_zz_retries_stayed_rare():
+    """runs last in this file: the repeats _shared_gpu_retry allowed are counted, and more than one test needing one is a failure
+    (a race in the reducer / stream ordering would show up across tests, the platform's corruption was seen in ~1 run of 3)"""
+    names = sorted({n for n, _ in _RETRIED})
+    assert len(names) <= 1, "comparisons had to be repeated in %d tests: %s" % (len(names), _RETRIED)

@@ -300,12 +300,15 @@ def test_pretrain_and_config4_multiview_step_vs_oracle(render, orender, backbone
     if backbone.endswith("18") or not refine:
         _compare(loss_c, loss_g, net_cpu, net_gpu)
     else:
-        # both fp32 paths against the float64 trunk (see the docstring).  Measured (round 3, tools/step_truth.py, DESIGN.md
-        # section 2): torch-CPU fp32 lands 0.07-0.11 from float64 whatever the batch size or BatchNorm mode; the HIP path
-        # 0.16-0.41, independent of the convolution arithmetic (bf16x3 split or fp32 MFMA), of the BatchNorm kernels (fused or
-        # torch), of the backward-weights reduction (atomics or ordered) and of the second stream, and NOT monotone in anything
-        # found (unsplit vs split-K forward convolutions: 0.16 vs 0.28 without the generator, 0.41 vs 0.37 with it); the memory-
-        # side float atomics are exact round-to-nearest adds (tools/atomic_rounding.hip).  Bars: what was observed plus a margin.
+        # both fp32 paths against the float64 trunk (see the docstring).  Round 4 closed the question of WHY the HIP path lands
+        # further from float64 than torch-CPU fp32 here (0.16-0.41 against 0.07-0.11 in round 3) with three controls
+        # (profiles/r04_r50_controls_*.txt, r04_r50_noise.txt): (a) the torch twin on the same GPU lands at
+        # 0.087 (torch's native kernels) and 0.149 (MIOpen); (b) teacher-forced, block by block, the HIP path's backward is as
+        # close to float64 as torch-CPU's (medians 3e-7, test_two_stage_resnet50_teacher_forced_blocks); (c) torch-CPU fp32 ITSELF,
+        # with 1e-7 relative noise on its block outputs (half of its own rounding), lands at 0.07 in 6 of 15 draws, at 0.27 in 6
+        # and at 0.15 in 3: the whole-step error is decided by ONE discrete switch that carries a quarter of the gradient norm,
+        # and every fp32 evaluation is a draw from those levels.  The bar below therefore stays what a draw can give (5 x the
+        # CPU draw = 0.35 > 0.27 + margin); what guards the arithmetic is the per-block test.
         from dsf_amd import _lib as L
         net64 = _Net64(net_cpu)
         loss_64 = step_ref.pretrain_loss(net64, _PinnedBridge(orender, rec.images), gen_cpu, p, cube, d, Config, views=views)
@@ -334,6 +337,143 @@ def test_pretrain_and_config4_multiview_step_vs_oracle(render, orender, backbone
         # (a second SAMPLE of the same sensitivity, not a better path: on the generator-free variant of this case the unsplit
         #  evaluation lands at 0.16 and the split-K one at 0.28; here it is the other way round, 0.41 vs 0.37)
         assert rel_d <= 5.0 * rel_c and cos_d > 0.9, ((cos_c, rel_c), (cos_d, rel_d))
+
+
+# ------------------------------------------------------------------------------------------------
+# teacher-forced blocks: per-block arithmetic of the two-stage ResNet-50 without the chaotic amplification
+# ------------------------------------------------------------------------------------------------
+def _block_names(net):
+    """the trunk cut into blocks: stem, every residual block, the transposed-convolution stages, MANO heads, fusion layer"""
+    names = ["pre"]
+    for suffix in ("", "_s2"):
+        for l in range(1, 5):
+            layer = getattr(net, "layer%d%s" % (l, suffix), None)
+            if layer is not None:
+                names += ["layer%d%s.%d" % (l, suffix, i) for i in range(len(layer))]
+        for n in ("deconv_layer4", "deconv_layer3", "deconv_layer2", "mano_regress"):
+            if hasattr(net, n + suffix):
+                names.append(n + suffix)
+    if hasattr(net, "fusion"):
+        names.append("fusion")
+    return names
+
+
+def _sub(net, name):
+    m = net
+    for part in name.split("."):
+        m = m[int(part)] if part.isdigit() else getattr(m, part)
+    return m
+
+
+def _record_blocks(net):
+    """forward / full-backward hooks on every block of ``net`` (and on the two pixel heads): -> {name: {x, y, gy, gx}}"""
+    cap = {}
+
+    def hook(name, mod):
+        def fwd(m, inp, out):
+            cap.setdefault(name, {})["x"] = inp[0].detach().clone()
+            cap[name]["y"] = out.detach().clone()
+
+        def bwd(m, gin, gout):
+            cap[name]["gy"] = gout[0].detach().clone()
+            cap[name]["gx"] = None if gin[0] is None else gin[0].detach().clone()
+        mod.register_forward_hook(fwd)
+        mod.register_full_backward_hook(bwd)
+    for n in _block_names(net):
+        hook(n, _sub(net, n))
+    for suffix in ("", "_s2"):
+        for i, h in enumerate(getattr(net, "finals" + suffix, [])):
+            hook("finals%s.%d" % (suffix, i), h)
+    return cap
+
+
+def _teacher_forced_rows(net_cpu, net_gpu, net64, cap):
+    """Every block run ALONE on the float64 run's own input and differentiated against the float64 run's own upstream
+    gradient (both cast to fp32), on the torch-CPU fp32 twin and on the HIP modules: -> [(name, (err_y, err_gx, err_gW) of the
+    CPU twin, the same of the HIP path)], relative L2 errors against float64 (nan where there is nothing to compare)."""
+    from dsf_amd import nn_conv
+
+    def rel(a, ref):
+        ref = ref.double().cpu()
+        return float((a.double().cpu() - ref).norm() / (ref.norm() + 1e-300))
+
+    def pgrads(mod):
+        g = [q.grad.double().cpu().flatten() for q in mod.parameters() if q.grad is not None]
+        return torch.cat(g) if g else torch.zeros(0, dtype=torch.float64)
+
+    def run(mod, x64, gy64, dev, call=None):
+        for q in mod.parameters():
+            q.grad = None
+        x = x64.float().to(dev).requires_grad_(True)
+        y = (call or mod)(x)
+        y.backward(gy64.float().to(dev))
+        if dev == "cuda":
+            torch.cuda.synchronize()
+        return y.detach(), x.grad, pgrads(mod)
+    jobs = [(n, _sub(net_cpu, n), _sub(net_gpu, n), None, None) for n in _block_names(net_cpu)]
+    for suffix in ("", "_s2"):
+        if not hasattr(net_cpu, "finals" + suffix):
+            continue
+        hc, hg = getattr(net_cpu, "finals" + suffix), getattr(net_gpu, "finals" + suffix)
+        a, b = cap["finals%s.0" % suffix], cap["finals%s.1" % suffix]
+        cap["finals" + suffix] = {"x": a["x"], "y": torch.cat([a["y"], b["y"]], 1), "gy": torch.cat([a["gy"], b["gy"]], 1),
+                                  "gx": a["gx"] + b["gx"]}
+        jobs.append(("finals" + suffix, hc, hg, (lambda x, h=hc: torch.cat([m(x) for m in h], 1)),
+                     (lambda x, h=hg: nn_conv.fused_heads(x, h))))
+    rows = []
+    for n, mc, mg, call_c, call_g in jobs:
+        c = cap[n]
+        p64 = pgrads(_sub(net64.net, n))
+        nan = float("nan")
+
+        def errs(y, gx, gw):
+            return (rel(y, c["y"]), rel(gx, c["gx"]) if (gx is not None and c["gx"] is not None) else nan,
+                    rel(gw, p64) if p64.numel() else nan)
+        rows.append((n, errs(*run(mc, c["x"], c["gy"], "cpu", call_c)), errs(*run(mg, c["x"], c["gy"], "cuda", call_g))))
+    return rows
+
+
+def test_two_stage_resnet50_teacher_forced_blocks(render, orender):
+    """The per-block form of the config-4 comparison, which a discrete switch cannot dominate.  The whole-step gradient of
+    the two-stage ResNet-50 is decided by a handful of ReLU / max-pool switches (tools/r50_noise.py: torch's own CPU fp32
+    evaluation with 1e-7 relative noise on its block outputs lands at 0.07 OR at 0.27 from float64), so
+    the whole-step bar is loose by nature.  Here every block (stem, 32 Bottlenecks, 6 transposed-convolution stages, fusion
+    layer, MANO and pixel heads) is run alone on the float64 run's input and upstream gradient: errors cannot travel, and
+    each block's forward output, input gradient and parameter gradients are held against float64 next to torch-CPU fp32's.
+    Measured (round 4): both paths 2e-7 .. 1e-6 on 35-39 of the 44 blocks; a block that holds an activation within rounding
+    of zero shows one switch, 1e-4 .. 5e-3, on either path (9 such blocks for torch-CPU, 8 for HIP, mostly different ones)."""
+    import numpy as _np
+    from oracle import step_ref
+    from dsf_amd.model.backbone import MANO_OCR_stage
+    from dsf_amd.train_step import PretrainStep, synthetic_batch, Config
+    views, B = 3, 2
+    net_cpu, net_gpu = _twin_pair(MANO_OCR_stage, "ResNet_stage_50", 21, True, seed=5)
+    step = PretrainStep(net_gpu, render, None, Config, views=views)
+    p, _, cube = synthetic_batch(B, "cpu", seed=31)
+    d = step.draw(B, "cpu", torch.Generator().manual_seed(32), np.random.default_rng(33))
+    net64 = _Net64(net_cpu)
+    cap = _record_blocks(net64.net)
+    step_ref.pretrain_loss(net64, orender, None, p, cube, d, Config, views=views).backward()
+    rows = _teacher_forced_rows(net_cpu, net_gpu, net64, cap)
+    assert len(rows) == 44                  # stem, 2 x (16 Bottlenecks + 3 transposed-convolution stages + MANO head + pixel heads), fusion
+    fwd = _np.array([r[2][0] for r in rows])
+    gx = _np.array([r[2][1] for r in rows if r[2][1] == r[2][1]])
+    gw = _np.array([r[2][2] for r in rows if r[2][2] == r[2][2]])
+    gx_c = _np.array([r[1][1] for r in rows if r[1][1] == r[1][1]])
+    gw_c = _np.array([r[1][2] for r in rows if r[1][2] == r[1][2]])
+    worst = sorted(rows, key=lambda r: -max(v for v in r[2][1:] if v == v))[:3]
+    print("teacher-forced blocks (HIP): forward max %.2e; input-gradient median %.2e max %.2e; parameter-gradient median %.2e max %.2e; "
+          "blocks above 1e-5: HIP %d, torch-CPU %d of %d; worst %s" % (fwd.max(), _np.median(gx), gx.max(), _np.median(gw), gw.max(),
+          int((gx > 1e-5).sum()), int((gx_c > 1e-5).sum()), len(gx), [(r[0], "%.1e" % max(v for v in r[2][1:] if v == v)) for r in worst]))
+    # forward: no switch can show in a block's own output (observed <= 1.2e-6, torch-CPU <= 1.1e-6)
+    assert fwd.max() < 5e-6, [(r[0], r[2][0]) for r in rows if r[2][0] >= 5e-6]
+    # backward: the typical block is at rounding level (observed medians 3.1e-7 / 4.6e-7; torch-CPU 3.3e-7 / 5.5e-7) ...
+    assert _np.median(gx) < 2e-6 and _np.median(gw) < 3e-6, (_np.median(gx), _np.median(gw))
+    assert _np.median(gx) <= 2.0 * _np.median(gx_c) and _np.median(gw) <= 2.0 * _np.median(gw_c)
+    # ... a minority of blocks holds a switch (observed 8 of 44, torch-CPU 9), and a switch is small (observed <= 4.5e-3):
+    # a wrong backward formula in any op would put its blocks at >= 1e-1
+    assert int((gx > 1e-5).sum()) <= len(gx) // 3, int((gx > 1e-5).sum())
+    assert gx.max() < 3e-2 and gw.max() < 3e-2, (gx.max(), gw.max())
 
 
 # ------------------------------------------------------------------------------------------------
@@ -509,6 +649,7 @@ def test_resnet50_bottleneck_vs_reference_golden():
     assert rel(pix.detach().cpu().numpy()[:, :, ::8, ::8], g["train_pix_sub"]) < bar
     assert rel(par.detach().cpu().numpy(), g["train_par"]) < bar
     named = dict(net.named_parameters())
+    head_l2 = []
     for i, n in enumerate(g["probe_names"]):
         got = named[str(n)].grad.detach().cpu().numpy()
         norm = float(np.sqrt((got.astype(np.float64) ** 2).sum()))
@@ -520,6 +661,11 @@ def test_resnet50_bottleneck_vs_reference_golden():
         # with the order of the float atomics), and once above 0.05 in the runs of round 3; the norms (2e-2) and the forward
         # outputs (5e-3) above never moved past 0.002 / 1.1e-4
         assert np.abs(got.reshape(-1)[:64] - ref).max() <= 1e-1 * max(np.abs(ref).max(), 1e-12), n
+        head_l2.append(float(np.linalg.norm(got.reshape(-1)[:64] - ref) / max(np.linalg.norm(ref), 1e-30)))
+    print("R50 golden: per-probe relative L2 error of the 64-entry gradient heads: max %.4f median %.4f" % (max(head_l2), float(np.median(head_l2))))
+    # a statistic one switch cannot flip: the MEDIAN over the 12 probed tensors (one activation switch of the B = 2 batch moves a
+    # few entries of a few tensors: it decides the maximum above, which is why that bar is loose, but not the median)
+    assert float(np.median(head_l2)) <= 2e-2, head_l2
     assert rel(xg.grad.cpu().numpy()[:, :, ::4, ::4], g["grad_x_sub"]) < 1e-1
     rm = net.layer4[2].bn3.running_mean.cpu().numpy()[:32]
     assert np.abs(rm - g["running_mean_layer4_2_bn3_head"]).max() < 1e-4 * max(1.0, np.abs(rm).max())

@@ -153,3 +153,57 @@ def test_integration_index_lists_every_declared_symbol():
     assert len(declared) >= 70
     missing = [s for s in declared if "| `%s` |" % s not in index]
     assert not missing, missing
+
+
+def test_checkpoint_round_trip(tmp_path):
+    """dsf_amd/checkpoint.py against the reference trainer's rules (train_render.py:117-145, 282-308): the file format, the key
+    filter (foreign keys dropped, absent keys keep the network's values), ``start_epoch = epoch + 1``, the optimizer state
+    that is saved but never loaded, ``best.pth`` on ``<=``, and exchange with a plain-torch (reference-layout) state dict."""
+    import torch
+    from oracle import nets
+    from dsf_amd import checkpoint as C
+    from dsf_amd.model.backbone import MANO_OCR
+    torch.manual_seed(0)
+    net = MANO_OCR("ResNet_stage_18", 21)                         # product modules (parameters in kernel memory order), on the CPU
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3)
+    for q in net.parameters():
+        q.grad = torch.ones_like(q) * 1e-3
+    opt.step()
+    ck = C.Checkpointer(str(tmp_path), net, opt)
+    assert ck.end_of_epoch(3, test_error=12.0) is True            # 12 <= 100: best.pth written
+    assert ck.end_of_epoch(4, test_error=12.0) is True            # `<=`: an equal error rewrites it
+    assert ck.end_of_epoch(5, test_error=13.0) is False
+    raw = torch.load(str(tmp_path / "latest.pth"), weights_only=False)
+    assert sorted(raw) == ["epoch", "model", "optimizer"] and raw["epoch"] == 5
+    assert torch.load(str(tmp_path / "best.pth"), weights_only=False)["epoch"] == 4
+    assert list(raw["model"]) == list(net.state_dict())
+    # the reference side: a plain torch.nn network with contiguous parameters takes the file with its own load rule
+    torch.manual_seed(1)
+    twin = nets.build(MANO_OCR, "ResNet_stage_18", 21)
+    own = twin.state_dict()
+    own.update({k: v for k, v in raw["model"].items() if k in own})
+    twin.load_state_dict(own)
+    for (k, a), (_, b) in zip(net.state_dict().items(), twin.state_dict().items()):
+        assert a.shape == b.shape and torch.equal(a, b), k
+    # and back: a reference-style file with a foreign key and a missing key into a fresh product network
+    ref_state = {k: v.clone().contiguous() for k, v in twin.state_dict().items()}
+    ref_state["module.not_ours"] = torch.zeros(3)
+    gone = "mano_regress.2.bias"
+    kept = None
+    del ref_state[gone]
+    torch.save({"model": ref_state, "optimizer": {"state": {}, "param_groups": []}, "epoch": 7}, str(tmp_path / "ref.pth"))
+    torch.manual_seed(2)
+    fresh = MANO_OCR("ResNet_stage_18", 21)
+    kept = fresh.state_dict()[gone].clone()
+    opt2 = torch.optim.AdamW(fresh.parameters(), lr=1e-3)
+    merged, taken, dropped, missing = C.filter_state(ref_state, fresh)
+    assert dropped == ["module.not_ours"] and missing == [gone] and len(taken) == len(fresh.state_dict()) - 1
+    assert C.load_checkpoint(str(tmp_path / "ref.pth"), fresh, opt2) == 8            # resume: epoch + 1
+    assert C.load_checkpoint(str(tmp_path / "ref.pth"), fresh, opt2, resume=False) == 0
+    for k, v in fresh.state_dict().items():
+        assert torch.equal(v, kept if k == gone else twin.state_dict()[k]), k
+    assert len(opt2.state) == 0                                    # the file's optimizer state is not loaded (the reference never does)
+    # the extension: restoring the optimizer state too
+    opt3 = torch.optim.AdamW(net.parameters(), lr=1e-3)
+    C.load_checkpoint(str(tmp_path / "latest.pth"), net, opt3, load_optimizer=True)
+    assert len(opt3.state) == len(opt.state) > 0

@@ -104,6 +104,65 @@ def test_two_rank_gradient_average_equals_full_batch():
     assert abs(mm - (0 + 3 + 6) / 3) < 1e-5          # values 0..7, multiples of 3 -> mean 3
 
 
+def _uneven_net():
+    """parameter sizes chosen so that no bucket boundary falls on a layer boundary: 4 B .. 37 KB tensors, a frozen parameter in
+    the middle, a tensor larger than a whole bucket, and a small tail"""
+    torch.manual_seed(5)
+    net = nn.Sequential(nn.Conv2d(1, 3, 3, padding=1), nn.ReLU(), nn.Conv2d(3, 32, 5, padding=2), nn.ReLU(),
+                        nn.Conv2d(32, 32, 3, padding=1), nn.ReLU(), nn.AdaptiveAvgPool2d(1), nn.Flatten(),
+                        nn.Linear(32, 7), nn.ReLU(), nn.Linear(7, 1, bias=True))
+    net[2].bias.requires_grad_(False)
+    return net
+
+
+def _worker4(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from dsf_amd.parallel import init_distributed, GradAllReducer, shard_batch
+    init_distributed("gloo")
+    net = _uneven_net()
+    params = [p for p in net.parameters() if p.requires_grad]
+    sync = GradAllReducer(params, bucket_bytes=6000, tail_bucket_bytes=200)
+    sizes = [sum(p.numel() * 4 for p in b) for b in sync.buckets]
+    g = torch.Generator().manual_seed(9)
+    x, y = torch.randn(12, 1, 8, 8, generator=g), torch.randn(12, 1, generator=g)
+    xs, ys = shard_batch([x, y], rank, world)                            # 3 images per rank
+    out = []
+    for it in range(3):
+        net.zero_grad(set_to_none=True)
+        ((net(xs) - ys) ** 2).mean().backward()
+        sync.finish()
+        out.append([p.grad.clone().numpy() for p in params])
+    if rank == 3:
+        q.put((out, sizes, [len(b) for b in sync.buckets]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_four_ranks_uneven_buckets_equal_the_full_batch():
+    """world size 4 (gloo), buckets that split the parameter list unevenly (one tensor larger than a bucket, a frozen parameter
+    between trainable ones, a small tail bucket): every rank's averaged gradient = the gradient of the whole batch, step after
+    step."""
+    world, port = 4, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker4, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    grads, sizes, counts = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len(sizes) >= 4 and max(sizes) > 6000 and min(sizes) <= 200 and len(set(counts)) > 1, (sizes, counts)
+    net = _uneven_net()
+    g = torch.Generator().manual_seed(9)
+    x, y = torch.randn(12, 1, 8, 8, generator=g), torch.randn(12, 1, generator=g)
+    ((net(x) - y) ** 2).mean().backward()
+    ref = [p.grad for p in net.parameters() if p.requires_grad]
+    for it in range(3):
+        for got, want in zip(grads[it], ref):
+            assert torch.allclose(torch.tensor(got), want, atol=1e-6, rtol=1e-5)
+
+
 def test_single_process_reducer_is_a_noop():
     from dsf_amd.parallel import GradAllReducer
     net = _net()

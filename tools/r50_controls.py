@@ -54,28 +54,6 @@ class NetOnGpu:
         return self.net.named_parameters()
 
 
-def block_names(net):
-    names = ["pre"]
-    for suffix in ("", "_s2"):
-        for l in range(1, 5):
-            layer = getattr(net, "layer%d%s" % (l, suffix), None)
-            if layer is not None:
-                names += ["layer%d%s.%d" % (l, suffix, i) for i in range(len(layer))]
-        for n in ("deconv_layer4", "deconv_layer3", "deconv_layer2", "mano_regress"):
-            if hasattr(net, n + suffix):
-                names.append(n + suffix)
-    if hasattr(net, "fusion"):
-        names.append("fusion")
-    return names
-
-
-def sub(net, name):
-    m = net
-    for part in name.split("."):
-        m = m[int(part)] if part.isdigit() else getattr(m, part)
-    return m
-
-
 render = Render("synthetic", "nyu", T.CAM, (640, 480)).cuda()
 orender = step_ref.OracleRender(build_synthetic_mano(0))
 net_cpu, net_gpu = T._twin_pair(MANO_OCR_stage, backbone, 21, True, seed=5)
@@ -90,29 +68,7 @@ pin = lambda r: T._PinnedBridge(r, rec.images)
 
 # ---- float64 truth, with every block's input / output / upstream gradient / input gradient recorded ----
 net64 = T._Net64(net_cpu)
-cap = {}
-heads_cap = {}
-
-
-def hook_block(name, mod):
-    def fwd(m, inp, out):
-        cap.setdefault(name, {})["x"] = inp[0].detach().clone()
-        cap[name]["y"] = out.detach().clone()
-
-    def bwd(m, gin, gout):
-        cap[name]["gy"] = gout[0].detach().clone()
-        cap[name]["gx"] = None if gin[0] is None else gin[0].detach().clone()
-
-    mod.register_forward_hook(fwd)
-    mod.register_full_backward_hook(bwd)
-
-
-names = block_names(net64.net)
-for n in names:
-    hook_block(n, sub(net64.net, n))
-for suffix in ("", "_s2"):
-    for i, h in enumerate(getattr(net64.net, "finals" + suffix)):
-        hook_block("finals%s.%d" % (suffix, i), h)
+cap = T._record_blocks(net64.net)
 l64 = step_ref.pretrain_loss(net64, pin(orender), None, p, cube, d, Config, views=views)
 l64.backward()
 print("case: %s two-stage, %d x %d views%s; float64 loss %.6f" % (backbone, B, views, ", frozen statistics" if frozen else "", float(l64)))
@@ -137,45 +93,12 @@ torch.backends.cudnn.enabled = True
 
 
 # ---- (b) teacher-forced blocks ----
-def rel(a, ref):
-    ref = ref.double().cpu()
-    return float((a.double().cpu() - ref).norm() / (ref.norm() + 1e-300))
-
-
-def pgrads(mod):
-    g = [q.grad.double().cpu().flatten() for q in mod.parameters() if q.grad is not None]
-    return torch.cat(g) if g else torch.zeros(0, dtype=torch.float64)
-
-
-def run_block(mod, x64, gy64, dev, call=None):
-    for q in mod.parameters():
-        q.grad = None
-    x = x64.float().to(dev).requires_grad_(x64.is_floating_point())
-    y = (call or mod)(x)
-    y.backward(gy64.float().to(dev))
-    if dev == "cuda":
-        torch.cuda.synchronize()
-    return y.detach(), (x.grad if x.grad is not None else None), pgrads(mod)
-
-
 print("\n(b) teacher-forced blocks: relative L2 error against float64 of (output | input gradient | parameter gradients), torch-CPU fp32 then HIP:")
 print("  %-22s %-30s %-30s %s" % ("block", "torch CPU fp32", "HIP", "ratio HIP/CPU (gx, gW)"))
 worst = []
-rows = [(n, sub(net_cpu, n), sub(net_gpu, n), None, None) for n in names]
-for suffix in ("", "_s2"):
-    hc, hg = getattr(net_cpu, "finals" + suffix), getattr(net_gpu, "finals" + suffix)
-    a, b = cap["finals%s.0" % suffix], cap["finals%s.1" % suffix]
-    cap["finals" + suffix] = {"x": a["x"], "y": torch.cat([a["y"], b["y"]], 1), "gy": torch.cat([a["gy"], b["gy"]], 1), "gx": a["gx"] + b["gx"]}
-    rows.append(("finals" + suffix, hc, hg, (lambda x, h=hc: torch.cat([m(x) for m in h], 1)), (lambda x, h=hg: nn_conv.fused_heads(x, h))))
-for n, mc, mg, call_c, call_g in rows:
-    c = cap[n]
-    p64 = pgrads(sub(net64.net, n))
-    yc, gxc, gwc = run_block(mc, c["x"], c["gy"], "cpu", call_c)
-    yg, gxg, gwg = run_block(mg, c["x"], c["gy"], "cuda", call_g)
-    e = lambda y, gx, gw: (rel(y, c["y"]), rel(gx, c["gx"]) if (gx is not None and c["gx"] is not None) else float("nan"), rel(gw, p64) if p64.numel() else float("nan"))
-    ec, eg = e(yc, gxc, gwc), e(yg, gxg, gwg)
-    ratio = (eg[1] / ec[1] if ec[1] == ec[1] and ec[1] > 0 else float("nan"), eg[2] / ec[2] if ec[2] == ec[2] and ec[2] > 0 else float("nan"))
-    worst.append((max(r for r in ratio if r == r) if any(r == r for r in ratio) else 0.0, n, ec, eg))
+for n, ec, eg in T._teacher_forced_rows(net_cpu, net_gpu, net64, cap):
+    ratio = tuple(eg[k] / ec[k] if (ec[k] == ec[k] and ec[k] > 0) else float("nan") for k in (1, 2))
+    worst.append((max([r for r in ratio if r == r] or [0.0]), n, ec, eg))
     print("  %-22s %.2e %.2e %.2e    %.2e %.2e %.2e    %.2f %.2f" % ((n,) + ec + eg + ratio))
 print("\nworst blocks by HIP / CPU error ratio:")
 for r, n, ec, eg in sorted(worst, reverse=True)[:6]:
