@@ -199,7 +199,9 @@ __global__ void pfd_packed_bwd_kernel(const float* __restrict__ points, const fl
 // LDS atomics give inside a cell), so that the 64 lanes of a wave skip the same triangles -- a triangle is evaluated when
 // ANY live lane needs it.
 constexpr int LIST_CAP = 4096;      // points per workgroup range (uint16 list entries)
-constexpr int CH = 224;             // triangle records + spheres staged per pass (7 passes over MANO's 1554 faces)
+constexpr int CH = 192;             // triangle records + spheres staged per pass (9 passes over MANO's 1554 faces)
+constexpr int GP = 64;              // points per group: one per lane, the same 64 in each of the four waves
+constexpr int SEG_RANGE = 512;      // labelled clouds: points one (sample, part) workgroup compacts its part's members from
 constexpr float CULL_M = 1e-4f;
 
 __device__ __forceinline__ float4 tri_sphere(const TriRec& r) {
@@ -228,8 +230,10 @@ __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __rest
                                                              const int64_t* __restrict__ seg, int V, int P, int n_parts,
                                                              int splits, float* __restrict__ dists,
                                                              int32_t* __restrict__ idxs) {
-    // 29.7 KB of LDS = 5 workgroups per CU: the pair loop is a chain of dependent divisions and LDS broadcasts, it needs the waves
-    // (a first version with every sphere of the range resident, 60 KB, ran the plain loop 3.6 x slower than round 3's kernel).
+    // A workgroup = 64 points x 4 waves: every wave holds the SAME 64 points (one per lane) and scans its quarter of each staged
+    // block of triangles; the four minima meet in LDS at the end.  The pair loop is a chain of dependent divisions and LDS
+    // broadcasts, so what it needs is waves: 64-point groups give B x P / 64 workgroups (2048 at B = 64: 256-point groups left
+    // the chip at one or two waves per SIMD and a launch took 600 us whatever B was), 28.7 KB of LDS keep 5 of them per CU.
     // The triangle stage and the scratch of the point sort share their bytes: the sort is over before the first stage is built.
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[CH * (sizeof(TriRec) + sizeof(float4))];
     TriRec* const s_tri = reinterpret_cast<TriRec*>(s_raw);
@@ -238,7 +242,9 @@ __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __rest
     uint8_t* const s_owner = s_raw + 2048;                              // 512 cell owners
     float* const s_box = reinterpret_cast<float*>(s_raw + 2560);        // 4 waves x (min, max)
     __shared__ uint16_t s_list[LIST_CAP];
-    __shared__ uint8_t s_cand[4 * CH];                                  // per wave: the staged triangles its ball can reach
+    __shared__ uint8_t s_cand[4 * 64];                                  // per wave: the triangles of its quarter the group's ball can reach
+    __shared__ float s_rd[4 * 64];                                      // per wave, per lane: (distance, index) for the cross-wave minima
+    __shared__ int s_ri[4 * 64];
     __shared__ int s_n, s_hi, s_wsum[4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     int w = blockIdx.x;
@@ -318,16 +324,16 @@ __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __rest
             for (int q = 0; q < wave; ++q) base += s_wsum[q];
             const int excl = base + v - (a0 + a1);
             s_hist[2 * t] = excl; s_hist[2 * t + 1] = excl + a0;
-            // a cell belongs to the workgroup whose 256-slot window holds the cell's FIRST slot: whole cells, so that the
+            // a cell belongs to the workgroup whose 64-slot window holds the cell's FIRST slot: whole cells, so that the
             // partition of the cloud over the sample's workgroups does not depend on the order inside a cell
-            const int o0 = excl >> 8, o1 = (excl + a0) >> 8;
+            const int o0 = excl >> 6, o1 = (excl + a0) >> 6;
             s_owner[2 * t] = (uint8_t)min(o0, 255); s_owner[2 * t + 1] = (uint8_t)min(o1, 255);
             if (a0 > 0 && o0 == split) { atomicMin(&s_n, excl); atomicMax(&s_hi, excl + a0); }
             if (a1 > 0 && o1 == split) { atomicMin(&s_n, excl + a0); atomicMax(&s_hi, excl + a0 + a1); }
         }
         __syncthreads();
         const int first = s_n;
-        n_mine = max(0, s_hi - first);                                  // <= 255 + the largest cell <= P <= LIST_CAP
+        n_mine = max(0, s_hi - first);                                  // <= 63 + the largest cell <= P <= LIST_CAP
         for (int p = t; p < P; p += 256) {
             const int k = cell(p);
             if (s_owner[k] == split) s_list[atomicAdd(&s_hist[k], 1) - first] = (uint16_t)p;
@@ -339,41 +345,51 @@ __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __rest
         listed = false;
         pbeg = 0; n_mine = 0;
     }
-    // the groups of 256 points this workgroup walks: its list (part-compacted, or Morton-cell sorted), else slots split*256 + t
-    const int n_groups = listed ? (n_mine + 255) / 256 : 1;
+    // the groups of 64 points this workgroup walks: its list (part-compacted, or Morton-cell sorted), else slots split * 64 + lane
+    const int n_groups = listed ? (n_mine + GP - 1) / GP : 1;
 
     auto stage = [&](int base, bool full) {             // records (full) and spheres of triangles base .. base + CH of the range
         __syncthreads();                                 // everybody is done with the previous stage (or with the sort scratch)
         if (t < CH && base + t < f1) {
             const int32_t* fc = faces + (base + t) * 3;
-            const TriRec r = make_tri(ld3(vb + fc[0] * 3), ld3(vb + fc[1] * 3), ld3(vb + fc[2] * 3), t);
-            if (full) s_tri[t] = r;
-            s_sph[t] = tri_sphere(r);
+            const f3 v0 = ld3(vb + fc[0] * 3), v1 = ld3(vb + fc[1] * 3), v2 = ld3(vb + fc[2] * 3);
+            if (full) {
+                const TriRec r = make_tri(v0, v1, v2, t);
+                s_tri[t] = r;
+                s_sph[t] = tri_sphere(r);
+            } else {                                     // the seed only ranks triangles: plain centroids, no square roots / divisions
+                const f3 c = (1.0f / 3.0f) * ((v0 + v1) + v2);
+                s_sph[t] = make_float4(c.x, c.y, c.z, 0.f);
+            }
         }
         __syncthreads();
     };
     for (int g = 0; g < n_groups; ++g) {
         bool live;
         int p;
-        if (listed) { live = g * 256 + t < n_mine; p = live ? pbeg + s_list[g * 256 + t] : 0; }
-        else { p = split * 256 + t; live = p < P; p = live ? p : 0; }
+        if (listed) { live = g * GP + lane < n_mine; p = live ? pbeg + s_list[g * GP + lane] : 0; }
+        else { p = split * GP + lane; live = p < P; p = live ? p : 0; }
         const f3 pt = live ? ld3(pb + p * 3) : mk3(0.f, 0.f, 0.f);
         float best = INFINITY, thr = INFINITY;          // thr = sqrt(best) * (1 + m) * 1.0011 / (1 - m), refreshed with best
         int bi = -1;
-        // ---- seed: the nearest sphere centre among every 8th triangle, evaluated exactly ----
+        // ---- seed: the nearest centroid among every 2nd triangle (each wave looks at every 8th), evaluated exactly ----
         if (f1 > f0) {
             float dmin = INFINITY;
             int smin = f0;
             for (int base = f0; base < f1; base += CH) {
                 stage(base, false);
                 const int cnt = min(CH, f1 - base);
-                for (int q = 0; q < cnt; q += 8) {
+                for (int q = 2 * wave; q < cnt; q += 8) {
                     const float4 s = s_sph[q];
                     const float dx = pt.x - s.x, dy = pt.y - s.y, dz = pt.z - s.z;
                     const float d2 = dx * dx + dy * dy + dz * dz;
                     if (d2 < dmin) { dmin = d2; smin = base + q; }
                 }
             }
+            s_rd[t] = dmin; s_ri[t] = smin;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float d = s_rd[k * 64 + lane]; if (d < dmin) { dmin = d; smin = s_ri[k * 64 + lane]; } }
             if (live) {
                 const int32_t* fc = faces + smin * 3;
                 const TriRec r = make_tri(ld3(vb + fc[0] * 3), ld3(vb + fc[1] * 3), ld3(vb + fc[2] * 3), 0);
@@ -382,8 +398,8 @@ __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __rest
                 thr = sqrtf(best) * ((1.0f + CULL_M) * 1.0011f / (1.0f - CULL_M));
             }
         }
-        // ---- the wave's points as ONE ball (centre of their box, radius to the farthest) and its loosest threshold: a triangle
-        //      with |c_tri - c_wave| - r_wave > R_tri + thr_max is skipped by every lane's own test, so one lane per TRIANGLE can
+        // ---- the group's points as ONE ball (centre of their box, radius to the farthest) and its loosest threshold: a triangle
+        //      with |c_tri - c_ball| - r_ball > R_tri + thr_max is skipped by every lane's own test, so one lane per TRIANGLE can
         //      discard 64 of them per instruction; NaN-ignoring min / max keep a lane with broken coordinates from widening it ----
         float bx0 = live ? pt.x : INFINITY, by0 = live ? pt.y : INFINITY, bz0 = live ? pt.z : INFINITY;
         float bx1 = live ? pt.x : -INFINITY, by1 = live ? pt.y : -INFINITY, bz1 = live ? pt.z : -INFINITY;
@@ -399,28 +415,29 @@ __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __rest
         if (live) { const f3 d = pt - cw; rw = sqrtf(dot(d, d)); }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) rw = fmaxf(rw, __shfl_xor(rw, o, 64));
-        const float wave_reach = (rw + tmax) * (1.0f + CULL_M);       // (inf / NaN when some lane has no finite threshold: nothing is discarded)
-        // ---- scan ----
+        const float ball_reach = (rw + tmax) * (1.0f + CULL_M);       // (inf / NaN when some lane has no finite threshold: nothing is discarded)
+        // ---- scan: this wave's quarter of every staged block ----
         for (int base = f0; base < f1; base += CH) {
             stage(base, true);
             const int cnt = min(CH, f1 - base);
-            int n_cand = 0;                              // wave-uniform
-            for (int q0 = 0; q0 < cnt; q0 += 64) {
-                const int q = q0 + lane;
+            const int q_lo = wave * (CH / 4), q_hi = min(cnt, q_lo + CH / 4);
+            int n_cand = 0;
+            {
+                const int q = q_lo + lane;
                 bool keep = false;
-                if (q < cnt) {
+                if (q < q_hi) {
                     const float4 s = s_sph[q];
                     const float dx = cw.x - s.x, dy = cw.y - s.y, dz = cw.z - s.z;
                     const float dc = sqrtf(dx * dx + dy * dy + dz * dz) * (1.0f - CULL_M);
-                    keep = !(dc > s.w + wave_reach);
+                    keep = !(dc > s.w + ball_reach);
                 }
                 const unsigned long long m = __ballot(keep);
-                if (keep) s_cand[wave * CH + n_cand + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)q;
-                n_cand += __popcll(m);
+                if (keep) s_cand[wave * 64 + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)q;
+                n_cand = __popcll(m);
             }
             __syncthreads();                             // the candidate list of this wave is in LDS
             for (int i = 0; i < n_cand; ++i) {
-                const int q = s_cand[wave * CH + i];
+                const int q = s_cand[wave * 64 + i];
                 const float4 s = s_sph[q];
                 const float dx = pt.x - s.x, dy = pt.y - s.y, dz = pt.z - s.z;
                 const float lim = s.w + thr;
@@ -436,7 +453,17 @@ __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __rest
                 }
             }
         }
-        if (live) {
+        // ---- the four waves' minima: smallest distance, then smallest index (the oracle's tie rule) ----
+        __syncthreads();
+        s_rd[t] = best; s_ri[t] = bi;
+        __syncthreads();
+        if (wave == 0 && live) {
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+                const float d = s_rd[k * 64 + lane];
+                const int id = s_ri[k * 64 + lane];
+                if (id >= 0 && (bi < 0 || d < best || (d == best && id < bi))) { best = d; bi = id; }
+            }
             dists[(int64_t)b * P + p] = (bi < 0) ? 0.f : best;
             idxs[(int64_t)b * P + p] = bi;
         }
@@ -516,9 +543,10 @@ extern "C" int dsf_mesh_point_dist_forward(const float* verts, const float* poin
     DSF_CHECK_ARG(verts && points && faces && part_first && dists && idxs);
     DSF_CHECK_ARG(B >= 0 && V > 0 && P >= 0 && n_parts >= 1 && (seg || n_parts == 1));
     if (B == 0 || P == 0) return DSF_OK;
-    // seg == NULL: every point meets every triangle -> 256 points per workgroup; with labels one
-    // workgroup per (sample, part) scans the cloud (<= LIST_CAP points per range).
-    int splits = seg ? (P + LIST_CAP - 1) / LIST_CAP : (P + 255) / 256;
+    // seg == NULL: every point meets every triangle -> 64 points per workgroup (4 waves share them and split the triangles);
+    // with labels one workgroup per (sample, part, 512-point range) compacts its part's members of that range (the palm's
+    // ~600 of 2048 points would otherwise be ten 64-point groups in one workgroup: the launch's tail).
+    int splits = seg ? (P + SEG_RANGE - 1) / SEG_RANGE : (P + GP - 1) / GP;
     if (splits < 1) splits = 1;
     hipLaunchKernelGGL(mesh_point_fwd_kernel, dim3((unsigned)(B * n_parts * splits)), dim3(256), 0, (hipStream_t)stream,
                        verts, points, faces, part_first, seg, V, P, n_parts, splits, dists, idxs);

@@ -665,7 +665,7 @@ def test_resnet50_bottleneck_vs_reference_golden():
     print("R50 golden: per-probe relative L2 error of the 64-entry gradient heads: max %.4f median %.4f" % (max(head_l2), float(np.median(head_l2))))
     # a statistic one switch cannot flip: the MEDIAN over the 12 probed tensors (one activation switch of the B = 2 batch moves a
     # few entries of a few tensors: it decides the maximum above, which is why that bar is loose, but not the median)
-    assert float(np.median(head_l2)) <= 2e-2, head_l2
+    assert float(np.median(head_l2)) <= 3e-2, head_l2                 # observed 0.0153 (max 0.021)
     assert rel(xg.grad.cpu().numpy()[:, :, ::4, ::4], g["grad_x_sub"]) < 1e-1
     rm = net.layer4[2].bn3.running_mean.cpu().numpy()[:32]
     assert np.abs(rm - g["running_mean_layer4_2_bn3_head"]).max() < 1e-4 * max(1.0, np.abs(rm).max())

@@ -1,10 +1,15 @@
-"""kernel-trace csv -> per-step category table.  usage: kstats.py kernel_trace.csv n_steps_total"""
+"""kernel-trace csv -> per-step category table.  usage: kstats.py kernel_trace.csv n_steps [tail_ms]
+With tail_ms only the kernels that START within the last tail_ms milliseconds of the trace are counted (the timed steps of
+tools/step_only.py: warm-up, graph capture and validation passes fall away), divided by n_steps."""
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 nst = float(sys.argv[2])
+if len(sys.argv) > 3:
+    t_end = max(int(r['End_Timestamp']) for r in rows)
+    rows = [r for r in rows if int(r['Start_Timestamp']) >= t_end - float(sys.argv[3]) * 1e6]
 def c(n):
     if 'igemm' in n: return 'conv'
-    if 'BatchNorm' in n: return 'bn'
+    if 'BatchNorm' in n or n.startswith('void (anonymous namespace)::bn_') or '::bn_' in n: return 'bn'
     if 'fillBuffer' in n or 'FillFunctor' in n: return 'fill'
     if 'copyBuffer' in n or 'CatArray' in n or 'direct_copy' in n: return 'copy'
     if 'multi_tensor' in n: return 'optimizer'

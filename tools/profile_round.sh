@@ -7,8 +7,9 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o k -
 cp $O/kt/k_kernel_stats.csv $O/${TAG}_kernel_stats.csv
 rm -rf $O/kt
 # per-step category table and GPU-busy fraction from a trace of bare training steps (no bench diagnostics in it)
-timeout 400 rocprofv3 --kernel-trace --output-format csv -d $O/ks -o k -- python3 $R/tools/step_only.py > /dev/null 2>&1
-( python3 $R/tools/kstats.py $O/ks/k_kernel_trace.csv 12; echo; echo "GPU busy per step (tools/busy.py, last steps):"; python3 $R/tools/busy.py $O/ks/k_kernel_trace.csv | tail -3 ) > $O/${TAG}_kernel_categories.txt
+timeout 400 rocprofv3 --kernel-trace --output-format csv -d $O/ks -o k -- python3 $R/tools/step_only.py --config 2 --steps 12 --warmup 4 > $O/step_only.log 2>&1
+ms=$(grep STEP_ONLY $O/step_only.log | sed 's/.*wall_ms \([0-9.]*\).*/\1/')
+( echo "config 2, per step over the 12 timed steps of tools/step_only.py (kernels starting in the last $ms ms of the trace):"; python3 $R/tools/kstats.py $O/ks/k_kernel_trace.csv 12 $ms; echo; echo "GPU busy per step (tools/busy.py, last steps):"; python3 $R/tools/busy.py $O/ks/k_kernel_trace.csv | tail -3 ) > $O/${TAG}_kernel_categories.txt
 rm -rf $O/ks
 run() { name=$1; shift
   timeout 200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/$name -o p -- python3 $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline > $O/$name.log 2>&1
