@@ -201,7 +201,8 @@ __global__ void pfd_packed_bwd_kernel(const float* __restrict__ points, const fl
 constexpr int LIST_CAP = 4096;      // points per workgroup range (uint16 list entries)
 constexpr int CH = 192;             // triangle records + spheres staged per pass (9 passes over MANO's 1554 faces)
 constexpr int GP = 64;              // points per group: one per lane, the same 64 in each of the four waves
-constexpr int SEG_RANGE = 512;      // labelled clouds: points one (sample, part) workgroup compacts its part's members from
+constexpr int SEG_RANGE = LIST_CAP;  // labelled clouds: points one (sample, part) workgroup compacts its part's members from (512-point
+                                     // ranges = 4 x the workgroups, each staging the part's triangles again: 217 us against 175)
 constexpr float CULL_M = 1e-4f;
 
 __device__ __forceinline__ float4 tri_sphere(const TriRec& r) {
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __rest
         const f3 pt = live ? ld3(pb + p * 3) : mk3(0.f, 0.f, 0.f);
         float best = INFINITY, thr = INFINITY;          // thr = sqrt(best) * (1 + m) * 1.0011 / (1 - m), refreshed with best
         int bi = -1;
-        // ---- seed: the nearest centroid among every 2nd triangle (each wave looks at every 8th), evaluated exactly ----
+        // ---- seed: the nearest centroid among every 2nd triangle (each wave looks at every 8th; every 4th: 484 us against 442) ----
         if (f1 > f0) {
             float dmin = INFINITY;
             int smin = f0;
@@ -544,8 +545,8 @@ extern "C" int dsf_mesh_point_dist_forward(const float* verts, const float* poin
     DSF_CHECK_ARG(B >= 0 && V > 0 && P >= 0 && n_parts >= 1 && (seg || n_parts == 1));
     if (B == 0 || P == 0) return DSF_OK;
     // seg == NULL: every point meets every triangle -> 64 points per workgroup (4 waves share them and split the triangles);
-    // with labels one workgroup per (sample, part, 512-point range) compacts its part's members of that range (the palm's
-    // ~600 of 2048 points would otherwise be ten 64-point groups in one workgroup: the launch's tail).
+    // with labels one workgroup per (sample, part) compacts its part's members of the cloud (<= LIST_CAP points per range)
+    // and walks them in groups of 64.
     int splits = seg ? (P + SEG_RANGE - 1) / SEG_RANGE : (P + GP - 1) / GP;
     if (splits < 1) splits = 1;
     hipLaunchKernelGGL(mesh_point_fwd_kernel, dim3((unsigned)(B * n_parts * splits)), dim3(256), 0, (hipStream_t)stream,

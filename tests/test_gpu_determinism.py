@@ -362,7 +362,7 @@ def test_backward_on_a_worker_thread_matches_the_main_thread(det_mode):
             assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("kind", ["config2", "config3"])
+@pytest.mark.parametrize("kind", ["config2", "config3", "config5"])
 def test_every_kernel_of_a_step_is_stable_beside_convolution_workgroups(render, det_mode, kind):
     """Found in round 4: a kernel that is correct alone can return different bits while conv_x6 workgroups share its CUs.
     The first 256-thread MANO backward (built so that it CAN take the wave slot beside two convolution workgroups) had its
@@ -376,19 +376,34 @@ def test_every_kernel_of_a_step_is_stable_beside_convolution_workgroups(render, 
     from dsf_amd import nn_conv
     from dsf_amd.model.backbone import MANO_OCR_stage
     from dsf_amd.model.hourglass import PoseNetMANO
-    from dsf_amd.train_step import RenderSupervisedStep, MeshLossStep, synthetic_batch, Config
+    from dsf_amd.train_step import RenderSupervisedStep, MeshLossStep, FinetuneStageStep, synthetic_batch, draws_to, Config
     torch.manual_seed(0)
-    if kind == "config2":
+    p, c, cube = synthetic_batch(8, "cuda", seed=2)
+    if kind in ("config2", "config5"):
         net = MANO_OCR_stage("ResNet_stage_18", 21, True).cuda()
         with torch.no_grad():
             for head in (net.mano_regress[2], net.mano_regress_s2[2]):
                 head.bias[58] = 1.0
+    if kind == "config2":
         step = RenderSupervisedStep(net, render, Config)
-    else:
+        tgt = step.make_targets(p, c, cube)
+        loss_fn = lambda: step.loss(tgt)[0]
+    elif kind == "config3":
         net = PoseNetMANO(1, 21).cuda()
         step = MeshLossStep(net, render, Config, n_points=512)
-    p, c, cube = synthetic_batch(8, "cuda", seed=2)
-    tgt = step.make_targets(p, c, cube)
+        tgt = step.make_targets(p, c, cube)
+        loss_fn = lambda: step.loss(tgt)[0]
+    else:                                                                  # the self-boosting step incl. the frozen generator
+        from dsf_amd import ops
+        from dsf_amd.render_model.transfer import define_G
+        gen = define_G(1, 1, 64, 'resnet_9blocks', 'instance', False, 'xavier').cuda()
+        step = FinetuneStageStep(net, render, gen, Config)
+        pr, cr, cube_r = synthetic_batch(8, "cuda", seed=3)
+        with torch.no_grad():
+            img_r = render.render(pr, cr, cube_r)[0]
+            _, M_r, _, _ = ops.crop_setup(cr, cube_r, render.cam, 128)
+        d = draws_to(step.draw(8, "cpu", torch.Generator().manual_seed(7), np.random.default_rng(8)), "cuda")
+        loss_fn = lambda: step.loss(p, cube, img_r, cr, cube_r, M_r, draws=d)[0]
     x = torch.randn(32, 256, 64, 64, device="cuda").contiguous(memory_format=torch.channels_last)
     gy = torch.randn(32, 256, 64, 64, device="cuda").contiguous(memory_format=torch.channels_last)
     conv = nn_conv.Conv2d(256, 256, 3, 1, 1, bias=False).cuda()
@@ -402,7 +417,7 @@ def test_every_kernel_of_a_step_is_stable_beside_convolution_workgroups(render, 
                     conv(x)
         net.zero_grad(set_to_none=True)
         render.mano_layer.clear_cache()
-        loss = step.loss(tgt)[0]
+        loss = loss_fn()
         loss.backward()
         torch.cuda.synchronize()
         return [loss.detach().clone()] + _grads(net)
