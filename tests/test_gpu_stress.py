@@ -104,3 +104,81 @@ def test_crop_render_bit_exact_on_triangle_soups(seed):
     assert (exp_f >= 0).mean() > 0.2
     assert np.array_equal(p2f.cpu().numpy(), exp_f)
     assert np.array_equal(img.cpu().numpy(), exp_img)
+
+
+def _mesh_soup(rng, V, F, scale, snap):
+    """vertex pool + faces (not a manifold): lattice-snapped vertices (exactly equal distances), duplicated faces (ties -> the
+    lowest index), degenerate faces, slivers; ``scale`` shrinks the whole thing -- at 0.02 the reference's `+ 1e-8` terms are no
+    longer negligible against the triangles' Gram determinants (its `inside` region grows by up to tens of per cent), which
+    is the regime the cull's scaled bounding spheres exist for"""
+    verts = rng.normal(size=(V, 3)).astype(np.float32)
+    if snap:
+        verts = np.round(verts * 4.0) / 4.0
+    verts = (verts * scale).astype(np.float32)
+    # faces from nearby vertices (small triangles, so that the cull has something to skip) + some arbitrary ones
+    order = np.argsort(verts[:, 0] + 0.37 * verts[:, 1])
+    near = np.stack([order[np.clip(np.arange(F) % (V - 8) + rng.integers(0, 8, F), 0, V - 1)] for _ in range(3)], 1)
+    faces = near.astype(np.int32)
+    wild = rng.integers(0, F, F // 10)
+    faces[wild] = rng.integers(0, V, (F // 10, 3))
+    faces[F // 7:F // 7 + 10] = faces[:10]                        # duplicates
+    faces[F // 5, 2] = faces[F // 5, 1]                           # degenerate: two equal vertices
+    faces[F // 4] = faces[F // 4, 0]                              # degenerate: a point
+    return verts, faces
+
+
+@pytest.mark.parametrize("seed,scale,snap,P", [(21, 1.0, True, 2048), (22, 1.0, False, 3000), (23, 0.02, False, 2048),
+                                               (24, 0.02, True, 1000), (25, 0.004, False, 777), (26, 1.0, True, 5000)])
+def test_culled_point_to_mesh_kernel_bit_exact_on_soups(seed, scale, snap, P):
+    """`dsf_mesh_point_dist_forward` (ICPLoss / JointICPLoss) since round 4 skips triangles whose bounding sphere cannot hold a
+    minimiser, visits points in Morton-cell order and triangles per wave quarter: distances AND argmin indices must still be
+    those of the exhaustive scan in index order (the C oracle), on geometry built to break a cull -- exact ties between
+    duplicated / lattice triangles, degenerate triangles, tiny triangles where the reference's epsilon terms enlarge the
+    `inside` region, points on vertices / edges / inside faces / far away, clouds above the LDS list capacity (P = 5000: plain
+    index ranges), and a labelled (per-part) run over a random partition of the faces."""
+    from dsf_amd import ops
+    from oracle import p3d
+    rng = np.random.default_rng(seed)
+    B, V, F = 3, 600, 1554
+    soups = [_mesh_soup(rng, V, F, scale, snap) for _ in range(B)]
+    faces = soups[0][1]                                           # one face table for the batch (as MANO's)
+    verts = np.stack([s[0] for s in soups])
+    pts = (rng.normal(size=(B, P, 3)) * scale).astype(np.float32)
+    for b in range(B):
+        tri = verts[b][faces]                                     # (F,3,3)
+        k = P // 5
+        pts[b, :k] = tri[rng.integers(0, F, k), rng.integers(0, 3, k)]                       # exactly on vertices
+        e = rng.integers(0, F, k)
+        pts[b, k:2 * k] = (tri[e, 0] + tri[e, 1]) / 2                                        # on edges
+        f = rng.integers(0, F, k)
+        pts[b, 2 * k:3 * k] = tri[f].mean(1) + (0.05 * scale) * rng.normal(size=(k, 3)).astype(np.float32)   # near faces
+        g = rng.integers(0, F, k)
+        w = rng.uniform(-0.2, 1.2, (k, 2)).astype(np.float32)                                # in the plane, just outside edges
+        pts[b, 3 * k:4 * k] = tri[g, 0] + w[:, :1] * (tri[g, 1] - tri[g, 0]) + w[:, 1:] * (tri[g, 2] - tri[g, 0])
+    pts[:, -1] = 50.0 * scale                                      # far away
+    T = lambda a: torch.tensor(a, device="cuda")
+    first = torch.tensor([0, F], dtype=torch.int32, device="cuda")
+    dis, idx = ops.MeshPointDistance.apply(T(verts), T(pts), T(faces), first, None, 1)
+    dis, idx = dis.cpu().numpy(), idx.cpu().numpy()
+    for b in range(B):
+        d_o, i_o = p3d.point_face_dist_forward(pts[b], np.array([0], np.int64), verts[b][faces], np.array([0], np.int64))
+        assert np.array_equal(idx[b], i_o.astype(np.int32)), (b, int((idx[b] != i_o).sum()))
+        assert np.array_equal(dis[b], d_o), b
+    # labelled form: a random partition of the faces into 7 parts, labels 0 (no part) .. 7
+    n_parts = 7
+    cut = np.sort(rng.choice(np.arange(1, F), n_parts - 1, replace=False))
+    pfirst = np.concatenate([[0], cut, [F]]).astype(np.int32)
+    seg = rng.integers(0, n_parts + 1, (B, P)).astype(np.int64)
+    dis, idx = ops.MeshPointDistance.apply(T(verts), T(pts), T(faces), T(pfirst), T(seg), n_parts)
+    dis, idx = dis.cpu().numpy(), idx.cpu().numpy()
+    for b in range(B):
+        for part in range(n_parts):
+            sel = np.nonzero(seg[b] == part + 1)[0]
+            if sel.size == 0:
+                continue
+            f0, f1 = int(pfirst[part]), int(pfirst[part + 1])
+            d_o, i_o = p3d.point_face_dist_forward(pts[b][sel], np.array([0], np.int64), verts[b][faces[f0:f1]], np.array([0], np.int64))
+            assert np.array_equal(idx[b][sel], (i_o + f0).astype(np.int32)), (b, part)
+            assert np.array_equal(dis[b][sel], d_o), (b, part)
+        none = seg[b] == 0
+        assert (idx[b][none] == -1).all() and (dis[b][none] == 0).all()
