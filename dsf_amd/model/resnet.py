@@ -32,12 +32,8 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        if self.downsample is None:
-            # the skip connection takes the convolution's alias of x: its gradient is then added inside conv1's backward-data launch
-            y, identity = conv_bn_act(self.conv1, self.bn1, x, relu=True, fork=True)
-        else:
-            y = conv_bn_act(self.conv1, self.bn1, x, relu=True)                   # (BN statistics from the conv epilogue)
-            identity = self.downsample(x)
+        y = conv_bn_act(self.conv1, self.bn1, x, relu=True)                       # (BN statistics from the conv epilogue)
+        identity = x if self.downsample is None else self.downsample(x)
         return conv_bn_act(self.conv2, self.bn2, y, residual=identity, relu=True)    # bn + skip + relu in one pass
 
 
@@ -57,10 +53,7 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        if self.downsample is None:
-            y, identity = conv_bn_act(self.conv1, self.bn1, x, relu=True, fork=True)      # (see BasicBlock)
-        else:
-            y = conv_bn_act(self.conv1, self.bn1, x, relu=True)
-            identity = self.downsample(x)
+        y = conv_bn_act(self.conv1, self.bn1, x, relu=True)
         y = conv_bn_act(self.conv2, self.bn2, y, relu=True)
+        identity = x if self.downsample is None else self.downsample(x)
         return conv_bn_act(self.conv3, self.bn3, y, residual=identity, relu=True)

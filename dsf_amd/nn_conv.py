@@ -400,19 +400,9 @@ class Conv2dFunction(Function):
         Co, Ci, KH, KW = weight.shape
         gy = _nhwc(gy)
         gx = gw = gb = None
-        skip = SKIP_GRAD[0]                               # Conv2dForkFunction: the skip path's gradient, to be added to gx
-        SKIP_GRAD[0] = None
         if ctx.needs_input_grad[0] and stride == 1 and _x6_ok(Co, gy.numel()):
-            req = None
-            if skip is not None and STATS is None and skip.shape == x.shape and skip.dtype == torch.float32:
-                # dX = conv^T(dY) + d(skip) in the backward-data convolution's own output epilogue (the affine epilogue of the
-                # evaluation path with scale 1, shift 0: x * 1 + 0 + r rounds once, as the separate add does)
-                one, zero = _unit_affine(Ci, gy.device)
-                req = AffineRequest(one, zero, _nhwc(skip), False)
-            gx = _under_request(req, lambda: _fwd_x6(gy, _x6_image(weight, wk, 1), None, (x.shape[2], x.shape[3]), Ci, KH, KW, 1,
-                                                    (KH - 1 - padding[0], KW - 1 - padding[1])))
-            if req is not None and req.applied:
-                skip = None                               # added inside the launch
+            gx = _fwd_x6(gy, _x6_image(weight, wk, 1), None, (x.shape[2], x.shape[3]), Ci, KH, KW, 1,
+                         (KH - 1 - padding[0], KW - 1 - padding[1]))
         elif ctx.needs_input_grad[0] and stride == 1 and Co >= 32 and Co % 4 == 0 and Ci % 4 == 0:
             gx = _bwd_data_s1(gy, wk, (x.shape[2], x.shape[3]), Ci, KH, KW, padding)
         elif ctx.needs_input_grad[0] and _x6_dil_ok(Co, x.shape[2], x.shape[3], stride, gy.numel()):
@@ -434,61 +424,7 @@ class Conv2dFunction(Function):
             gw = None if dw is False else dw.permute(3, 2, 0, 1)
         if has_bias and ctx.needs_input_grad[2]:
             gb = _bias_grad(gy)
-        if skip is not None and gx is not None:
-            gx.add_(skip)                                 # this launch could not carry it (split reduction / staged kernel / other path)
         return gx, gw, gb, None, None
-
-
-def _under_request(req, fn):
-    """fn() with ``req`` in the side channel the forward-type launches consult (STATS); None: plain call"""
-    global STATS
-    if req is None:
-        return fn()
-    STATS = req
-    try:
-        return fn()
-    finally:
-        STATS = None
-
-
-SKIP_GRAD = [None]
-SKIP_EPILOGUE = [os.environ.get("DSF_SKIP_EPILOGUE", "1") == "1"]     # 0: residual blocks leave their fan-in add to autograd (A/B aid)
-_UNIT = {}
-
-
-def _unit_affine(C, device):
-    hit = _UNIT.get((C, device.index))
-    if hit is None:
-        hit = _UNIT[(C, device.index)] = (torch.ones(C, device=device), torch.zeros(C, device=device))
-    return hit
-
-
-class Conv2dForkFunction(Function):
-    """``y = conv(x)`` together with an ALIAS of ``x`` for the block's skip connection.  The alias exists for the backward pass: the
-    gradient of the skip path then arrives at THIS node as a second upstream gradient instead of meeting the convolution's input
-    gradient in one of autograd's add kernels (three passes over the tensor: 11.9 ms of config 4's 178.9 ms step), and the
-    backward-data convolution adds it in its output epilogue (one extra read).  Residual blocks without a downsample branch use it
-    (model/resnet.py; reference model/resnet.py:38-52, 79-98: ``out += identity``)."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding):
-        y = Conv2dFunction.forward(ctx, x, weight, bias, stride, padding)
-        return y, x.view_as(x)
-
-    @staticmethod
-    def backward(ctx, gy, g_skip):
-        if g_skip is None:
-            return Conv2dFunction.backward(ctx, gy)
-        if gy is None:                                    # only the skip path was used
-            return g_skip, None, None, None, None
-        if torch.is_grad_enabled():                       # double backward: the plain composition
-            gx, gw, gb, _, _ = Conv2dFunction.backward(ctx, gy)
-            return (gx + g_skip if gx is not None else None), gw, gb, None, None
-        SKIP_GRAD[0] = g_skip
-        try:
-            return Conv2dFunction.backward(ctx, gy)
-        finally:
-            SKIP_GRAD[0] = None
 
 
 # ------------------------------------------------------------------------------------------------
@@ -714,16 +650,6 @@ class Conv2d(nn.Conv2d):
         if x.is_cuda and not self.weight.permute(2, 3, 1, 0).is_contiguous():
             kernel_layout_(self.weight, (2, 3, 1, 0))             # once: memory order [KH][KW][Ci][Co]
         return Conv2dFunction.apply(x, self.weight, self.bias, s[0], _pair(self.padding))
-
-    def fork(self, x):
-        """-> (conv(x), alias of x for a skip connection): see Conv2dForkFunction"""
-        if not (SKIP_EPILOGUE[0] and x.is_cuda and x.requires_grad and torch.is_grad_enabled()):
-            return self.forward(x), x
-        assert self.groups == 1 and _pair(self.dilation) == (1, 1) and self.padding_mode == 'zeros'
-        s = _pair(self.stride)
-        if not self.weight.permute(2, 3, 1, 0).is_contiguous():
-            kernel_layout_(self.weight, (2, 3, 1, 0))
-        return Conv2dForkFunction.apply(x, self.weight, self.bias, s[0], _pair(self.padding))
 
 
 class ConvTranspose2d(nn.ConvTranspose2d):

@@ -366,29 +366,11 @@ EPILOGUE_STATS = [os.environ.get("DSF_BN_EPILOGUE", "1") == "1"]
 EPILOGUE_AFFINE = [os.environ.get("DSF_BN_EPILOGUE", "1") == "1"]
 
 
-def conv_bn_act(conv, bn, x, residual=None, relu=None, fork=False):
-    """``bn(conv(x))`` (+ residual) (relu).  ``fork=True`` -> ``(result, alias of x)``: the alias is what a residual block hands to
-    its skip connection, so that the skip gradient is added inside this convolution's backward-data launch (nn_conv.Conv2dForkFunction).
-    Both this package's HIP layers, training mode: the BatchNorm batch statistics
+def conv_bn_act(conv, bn, x, residual=None, relu=None):
+    """``bn(conv(x))`` (+ residual) (relu).  Both this package's HIP layers, training mode: the BatchNorm batch statistics
     come from the convolution's epilogue (one pass over the convolution output less, two launches instead of three).
     Evaluation mode without autograd: the whole frozen-statistics BatchNorm (+ residual)(+ ReLU) rides in the convolution's
     output epilogue -- one launch, no second pass.  Any other combination is the plain composition."""
-    from . import nn_conv
-    if fork:
-        alias = [x]
-        inner = conv
-
-        def conv(t):                                     # the one convolution call below, through the fork
-            if isinstance(inner, nn_conv.Conv2d):
-                y_, alias[0] = inner.fork(t)
-                return y_
-            return inner(t)
-        out = _conv_bn_act(inner, conv, bn, x, residual, relu)
-        return out, alias[0]
-    return _conv_bn_act(conv, conv, bn, x, residual, relu)
-
-
-def _conv_bn_act(conv, call, bn, x, residual, relu):
     from . import nn_conv
     ours = isinstance(bn, FusedBatchNorm2d) and isinstance(conv, (nn_conv.Conv2d, nn_conv.ConvTranspose2d)) and x.is_cuda
     if (ours and EPILOGUE_AFFINE[0] and not bn.training and bn.track_running_stats and supported(bn.num_features) and
@@ -399,20 +381,20 @@ def _conv_bn_act(conv, call, bn, x, residual, relu):
         req = nn_conv.AffineRequest(scale, shift, res, r)
         nn_conv.STATS = req
         try:
-            y = call(x)
+            y = conv(x)
         finally:
             nn_conv.STATS = None
         return y if req.applied else bn(y, residual, r)
     fusable = (EPILOGUE_STATS[0] and isinstance(bn, FusedBatchNorm2d) and isinstance(conv, (nn_conv.Conv2d, nn_conv.ConvTranspose2d)) and bn.training and
                bn.track_running_stats and conv.bias is None and x.is_cuda and supported(bn.num_features) and nn_conv.STATS is None)
     if not fusable:
-        return bn_act(bn, call(x), residual, relu if relu is not None else getattr(bn, "fuse_relu", False))
+        return bn_act(bn, conv(x), residual, relu if relu is not None else getattr(bn, "fuse_relu", False))
     req = nn_conv.StatsRequest()
     # finalise-free path: the epilogue adds into these zeroed rows (a cross-replica BatchNorm exchanges ordered partial rows instead)
     req.acc = None if isinstance(bn, FusedSyncBatchNorm2d) else _acc_take(bn.num_features, x.device)
     nn_conv.STATS = req
     try:
-        y = call(x)
+        y = conv(x)
     finally:
         nn_conv.STATS = None
     if req.acc is not None:
