@@ -40,7 +40,14 @@ gV, gJ = torch.randn(B, 779, 3, device="cuda", generator=g), torch.randn(B, 21, 
 x = torch.randn(32, 256, 64, 64, device="cuda").contiguous(memory_format=torch.channels_last)
 gy = torch.randn(32, 256, 64, 64, device="cuda").contiguous(memory_format=torch.channels_last)
 a_mm = torch.randn(8192, 8192, device="cuda")
+mf_ops = (torch.randint(0, 256, (4096,), device="cuda", dtype=torch.int32) | 0x3f00)
+mf_ops = (mf_ops | (mf_ops.roll(1) << 16)).contiguous()
+mf_out = torch.empty(512 * 256, device="cuda")
 conv = nn_conv.Conv2d(256, 256, 3, 1, 1, bias=False).cuda()
+big = torch.nn.Sequential(*[nn_conv.Conv2d(512, 512, 3, 1, 1, bias=False) for _ in range(8)]).cuda()
+nn_conv.manage_weights(big.parameters())
+with torch.no_grad():
+    big(torch.randn(1, 512, 8, 8, device="cuda").contiguous(memory_format=torch.channels_last))      # creates the cached images
 side = torch.cuda.Stream()
 
 
@@ -56,6 +63,11 @@ def side_load(kind):
         dw = torch.zeros(3, 3, 256, 256, device="cuda")
         for _ in range(2):
             assert L.lib().dsf_conv_igemm_wrw(nn_conv.ptr_nhwc(x), nn_conv.ptr_nhwc(gy), ptr(dw), I(32), I(64), I(64), I(256), I(64), I(64), I(256), I(3), I(3), I(1), I(1), I(1), I(1), stream_ptr()) == 0
+    elif kind == "conv_x6 weight split (no MFMA, no LDS)":
+        for _ in range(40):
+            nn_conv.refresh_images(big.parameters(), owner=big)
+    elif kind == "bare bf16 MFMA loop":
+        assert L.lib().dsf_mfma_bf16_probe(ctypes.c_void_p(mf_ops.data_ptr()), ctypes.c_void_p(mf_out.data_ptr()), ctypes.c_int(512), ctypes.c_int(3000), stream_ptr()) > 0
     elif kind == "rocBLAS GEMM":
         torch.mm(a_mm, a_mm)
     elif kind == "elementwise":
@@ -71,7 +83,7 @@ for tag, lib in libs.items():
         return gp, scratch[:, :2334].clone()
     ref, ref_s = bwd()
     print("build: %s" % tag)
-    for kind in ("none", "conv_x6 backward-weights", "conv_x6 forward", "fp32-MFMA backward-weights", "rocBLAS GEMM", "elementwise"):
+    for kind in ("none", "conv_x6 backward-weights", "conv_x6 forward", "conv_x6 weight split (no MFMA, no LDS)", "bare bf16 MFMA loop", "fp32-MFMA backward-weights", "rocBLAS GEMM", "elementwise"):
         bad, lanes, comps = 0, set(), set()
         for it in range(200):
             if kind != "none":

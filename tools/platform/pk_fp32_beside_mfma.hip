@@ -23,6 +23,18 @@ extern "C" __global__ __launch_bounds__(256, 3) void pk_victim(float* __restrict
         asm volatile("v_pk_fma_f32 %0, %1, %0, %2 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(a), "v"(b));
         asm volatile("v_fma_f32 %0, %1, %0, %2" : "+v"(p0) : "v"(a.x), "v"(b.x));
         asm volatile("v_fma_f32 %0, %1, %0, %2" : "+v"(p1) : "v"(a.x), "v"(b.y));
+#elif MODE == 3    // as MODE 1, the packed operand coming from a broadcast ds_read_b128 (every lane the same LDS address)
+        {
+            __shared__ float4 s_g[16];
+            if (i == 0) { if (t < 16) s_g[t] = make_float4(0.0005f * t, -0.0003f * t, 0.0002f * t, 0.0001f * t); __syncthreads(); }
+            float4 g4;
+            const unsigned addr = (unsigned)(uintptr_t)(s_g + (i & 15));
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(g4) : "v"(addr) : "memory");
+            const v2f g = {g4.x, g4.y};
+            asm volatile("v_pk_fma_f32 %0, %1, %0, %2 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(a), "v"(g));
+            asm volatile("v_fma_f32 %0, %1, %0, %2" : "+v"(p0) : "v"(a.x), "v"(g4.x));
+            asm volatile("v_fma_f32 %0, %1, %0, %2" : "+v"(p1) : "v"(a.x), "v"(g4.y));
+        }
 #else              // packed multiply + packed add with op_sel, as in the skinning epilogue
         v2f m = acc;
         asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(m) : "v"(a));
