@@ -1,20 +1,22 @@
 // K3/K4: point -> triangle squared distance (pytorch3d==0.4.0 semantics, SURVEY.md
 // Appendix A.4) for gfx950.
 //
-// One lane owns one point; the triangles of the point's mesh are staged through LDS in
-// chunks of 256 records (one record built per lane: vertices, unit normal and the
-// Gram-matrix invariants, computed once per workgroup instead of once per pair) and read
-// back as wave-uniform broadcasts.  The kernel is VALU-bound (about 120 flops and five
-// IEEE divisions per pair), not HBM-bound.
+// One lane owns one point; triangle records (vertices, unit normal and the Gram-matrix
+// invariants, computed once per workgroup instead of once per pair) are staged through LDS
+// and read back as wave-uniform broadcasts.  The kernels are VALU-bound (about 120 flops and
+// five IEEE divisions per pair), not HBM-bound.
 //
 // Argmin ties (ubiquitous: a point nearest to a shared edge sees the same distance from
 // both triangles) resolve to the lowest triangle index, as in the oracle; for that the
 // per-pair arithmetic below is the oracle's, operation for operation (-ffp-contract=off).
 //
-// The fused batched form used by ICPLoss / JointICPLoss tests each point only against the
-// triangles of its own part: the point list of a (sample, part) workgroup is compacted in
-// LDS first, so all lanes stay busy (the reference replicates the cloud 15x and throws
-// 14/15 of the results away, metric/meshLoss.py:377-395).
+// Two forward forms: the packed one (pytorch3d._C's argument lists: every point of a mesh
+// against every triangle of it, 256-record chunks, exhaustive) and the fused batched one
+// behind ICPLoss / JointICPLoss (mesh_point_fwd_kernel), which tests each point only against
+// the triangles of its own part -- the point list of a (sample, part) workgroup is compacted
+// in LDS first (the reference replicates the cloud 15x and throws 14/15 of the results away,
+// metric/meshLoss.py:377-395) -- and, since round 4, only against triangles whose bounding
+// sphere can hold a minimiser (the cull described above that kernel).
 #include "common.h"
 
 namespace {
