@@ -200,11 +200,11 @@ __global__ void pfd_packed_bwd_kernel(const float* __restrict__ points, const fl
 // takes the WHOLE cells whose first slot falls into its 256-slot window, so the partition does not depend on the order the
 // LDS atomics give inside a cell), so that the 64 lanes of a wave skip the same triangles -- a triangle is evaluated when
 // ANY live lane needs it.
-constexpr int LIST_CAP = 4096;      // points per workgroup range (uint16 list entries)
-constexpr int CH = 192;             // triangle records + spheres staged per pass (9 passes over MANO's 1554 faces)
+constexpr int LIST_CAP = 2560;      // points per workgroup range (uint16 list entries; 5 KB: the kernel stays under 32 KB of LDS = 5 workgroups per CU)
+constexpr int CH = 256;             // triangle records + spheres staged per pass: 64 per wave, each wave its own (7 passes over MANO's 1554 faces)
 constexpr int GP = 64;              // points per group: one per lane, the same 64 in each of the four waves
 constexpr int SEG_RANGE = LIST_CAP;  // labelled clouds: points one (sample, part) workgroup compacts its part's members from (512-point
-                                     // ranges = 4 x the workgroups, each staging the part's triangles again: 217 us against 175)
+                                     // ranges = 4 x the workgroups, each staging the part's triangles again: 223 us against 171)
 constexpr float CULL_M = 1e-4f;
 
 __device__ __forceinline__ float4 tri_sphere(const TriRec& r) {
@@ -236,7 +236,9 @@ __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __rest
     // A workgroup = 64 points x 4 waves: every wave holds the SAME 64 points (one per lane) and scans its quarter of each staged
     // block of triangles; the four minima meet in LDS at the end.  The pair loop is a chain of dependent divisions and LDS
     // broadcasts, so what it needs is waves: 64-point groups give B x P / 64 workgroups (2048 at B = 64: 256-point groups left
-    // the chip at one or two waves per SIMD and a launch took 600 us whatever B was), 28.7 KB of LDS keep 5 of them per CU.
+    // the chip at one or two waves per SIMD and a launch took 600 us whatever B was).  Every wave stages ITS OWN 64 triangles of a
+    // block (one record per lane) and reads only those, so the scan needs no workgroup barrier at all -- a first version staged
+    // 192 triangles cooperatively behind 45 barriers per group and spent most of its time waiting at them.
     // The triangle stage and the scratch of the point sort share their bytes: the sort is over before the first stage is built.
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[CH * (sizeof(TriRec) + sizeof(float4))];
     TriRec* const s_tri = reinterpret_cast<TriRec*>(s_raw);
@@ -245,7 +247,6 @@ __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __rest
     uint8_t* const s_owner = s_raw + 2048;                              // 512 cell owners
     float* const s_box = reinterpret_cast<float*>(s_raw + 2560);        // 4 waves x (min, max)
     __shared__ uint16_t s_list[LIST_CAP];
-    __shared__ uint8_t s_cand[4 * 64];                                  // per wave: the triangles of its quarter the group's ball can reach
     __shared__ float s_rd[4 * 64];                                      // per wave, per lane: (distance, index) for the cross-wave minima
     __shared__ int s_ri[4 * 64];
     __shared__ int s_n, s_hi, s_wsum[4];
@@ -351,22 +352,33 @@ __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __rest
     // the groups of 64 points this workgroup walks: its list (part-compacted, or Morton-cell sorted), else slots split * 64 + lane
     const int n_groups = listed ? (n_mine + GP - 1) / GP : 1;
 
-    auto stage = [&](int base, bool full) {             // records (full) and spheres of triangles base .. base + CH of the range
-        __syncthreads();                                 // everybody is done with the previous stage (or with the sort scratch)
-        if (t < CH && base + t < f1) {
-            const int32_t* fc = faces + (base + t) * 3;
+    TriRec* const w_tri = s_tri + wave * 64;            // this wave's stage: 64 records + spheres, written and read by this wave only
+    float4* const w_sph = s_sph + wave * 64;
+    // wave w takes the triangle blocks w, w + 4, w + 8, ... of 64: its stage for block k holds triangles f0 + k * 64 ...
+    constexpr int bs = 64;                               // (32-triangle blocks for the ~100-triangle hand parts: no faster)
+    auto stage = [&](int k, bool full) -> int {
+        const int first = f0 + k * bs;
+        const int cnt = min(bs, f1 - first);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // (this wave's earlier reads of the stage are done)
+        __builtin_amdgcn_wave_barrier();
+        if (lane < cnt) {
+            const int32_t* fc = faces + (first + lane) * 3;
             const f3 v0 = ld3(vb + fc[0] * 3), v1 = ld3(vb + fc[1] * 3), v2 = ld3(vb + fc[2] * 3);
             if (full) {
-                const TriRec r = make_tri(v0, v1, v2, t);
-                s_tri[t] = r;
-                s_sph[t] = tri_sphere(r);
+                const TriRec r = make_tri(v0, v1, v2, lane);
+                w_tri[lane] = r;
+                w_sph[lane] = tri_sphere(r);
             } else {                                     // the seed only ranks triangles: plain centroids, no square roots / divisions
                 const f3 c = (1.0f / 3.0f) * ((v0 + v1) + v2);
-                s_sph[t] = make_float4(c.x, c.y, c.z, 0.f);
+                w_sph[lane] = make_float4(c.x, c.y, c.z, 0.f);
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // LDS operations of one wave execute in order: the stage is
+        __builtin_amdgcn_wave_barrier();                                // written before any lane of this wave reads it
+        return cnt;
     };
+    const int n_blocks = (f1 - f0 + bs - 1) / bs;
+    __syncthreads();                                     // the sort scratch (which shares the stage's bytes) is dead
     for (int g = 0; g < n_groups; ++g) {
         bool live;
         int p;
@@ -375,20 +387,21 @@ __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __rest
         const f3 pt = live ? ld3(pb + p * 3) : mk3(0.f, 0.f, 0.f);
         float best = INFINITY, thr = INFINITY;          // thr = sqrt(best) * (1 + m) * 1.0011 / (1 - m), refreshed with best
         int bi = -1;
-        // ---- seed: the nearest centroid among every 2nd triangle (each wave looks at every 8th; every 4th: 484 us against 442) ----
+        // ---- seed: the nearest centroid among every 2nd triangle of this wave's blocks; the four waves' candidates meet in LDS
+        //      and every wave evaluates the winner exactly ----
         if (f1 > f0) {
             float dmin = INFINITY;
             int smin = f0;
-            for (int base = f0; base < f1; base += CH) {
-                stage(base, false);
-                const int cnt = min(CH, f1 - base);
-                for (int q = 2 * wave; q < cnt; q += 8) {
-                    const float4 s = s_sph[q];
+            for (int k = wave; k < n_blocks; k += 4) {
+                const int cnt = stage(k, false);
+                for (int q = 0; q < cnt; q += 2) {
+                    const float4 s = w_sph[q];
                     const float dx = pt.x - s.x, dy = pt.y - s.y, dz = pt.z - s.z;
                     const float d2 = dx * dx + dy * dy + dz * dz;
-                    if (d2 < dmin) { dmin = d2; smin = base + q; }
+                    if (d2 < dmin) { dmin = d2; smin = f0 + k * bs + q; }
                 }
             }
+            __syncthreads();                             // (the previous group's final exchange is over)
             s_rd[t] = dmin; s_ri[t] = smin;
             __syncthreads();
 #pragma unroll
@@ -419,36 +432,28 @@ __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __rest
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) rw = fmaxf(rw, __shfl_xor(rw, o, 64));
         const float ball_reach = (rw + tmax) * (1.0f + CULL_M);       // (inf / NaN when some lane has no finite threshold: nothing is discarded)
-        // ---- scan: this wave's quarter of every staged block ----
-        for (int base = f0; base < f1; base += CH) {
-            stage(base, true);
-            const int cnt = min(CH, f1 - base);
-            const int q_lo = wave * (CH / 4), q_hi = min(cnt, q_lo + CH / 4);
-            int n_cand = 0;
-            {
-                const int q = q_lo + lane;
-                bool keep = false;
-                if (q < q_hi) {
-                    const float4 s = s_sph[q];
-                    const float dx = cw.x - s.x, dy = cw.y - s.y, dz = cw.z - s.z;
-                    const float dc = sqrtf(dx * dx + dy * dy + dz * dz) * (1.0f - CULL_M);
-                    keep = !(dc > s.w + ball_reach);
-                }
-                const unsigned long long m = __ballot(keep);
-                if (keep) s_cand[wave * 64 + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)q;
-                n_cand = __popcll(m);
+        // ---- scan: this wave's blocks, no workgroup barrier ----
+        for (int k = wave; k < n_blocks; k += 4) {
+            const int cnt = stage(k, true);
+            bool keep = false;
+            if (lane < cnt) {
+                const float4 s = w_sph[lane];
+                const float dx = cw.x - s.x, dy = cw.y - s.y, dz = cw.z - s.z;
+                const float dc = sqrtf(dx * dx + dy * dy + dz * dz) * (1.0f - CULL_M);
+                keep = !(dc > s.w + ball_reach);
             }
-            __syncthreads();                             // the candidate list of this wave is in LDS
-            for (int i = 0; i < n_cand; ++i) {
-                const int q = s_cand[wave * 64 + i];
-                const float4 s = s_sph[q];
+            unsigned long long cand = __ballot(keep);    // the triangles of this block the group's ball can reach, lowest first
+            while (cand) {
+                const int q = __builtin_ctzll(cand);
+                cand &= cand - 1;
+                const float4 s = w_sph[q];
                 const float dx = pt.x - s.x, dy = pt.y - s.y, dz = pt.z - s.z;
                 const float lim = s.w + thr;
                 const bool need = live && !(dx * dx + dy * dy + dz * dz > lim * lim);      // (NaN distances are never skipped)
                 if (!__any(need)) continue;                                                // nobody needs this triangle
                 if (need) {
-                    const float d = point_tri_dist2(pt, s_tri[q]);
-                    const int id = base + q;
+                    const float d = point_tri_dist2(pt, w_tri[q]);
+                    const int id = f0 + k * bs + q;
                     if (bi < 0 || d < best || (d == best && id < bi)) {
                         best = d; bi = id;
                         thr = sqrtf(best) * ((1.0f + CULL_M) * 1.0011f / (1.0f - CULL_M));
