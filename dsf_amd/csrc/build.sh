@@ -8,26 +8,24 @@ set -e
 cd "$(dirname "$0")"
 OUT=../lib
 mkdir -p $OUT
-FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function"   # (+ per-file EXTRA below)
+# -fno-slp-vectorize, for the whole library.  Found with mano.hip in round 4: its SLP-vectorised skinning loops (v_pk_fma_f32 on
+# ds_read_b128 broadcasts) returned wrong bits in lanes 48-63 whenever conv_x6 workgroups shared the CU, the scalar form never did
+# (profiles/r04_mano_beside_conv_x6.txt, tools/platform/mano_beside_conv_x6.py,
+# tests/test_gpu_determinism.py::test_mano_backward_is_stable_beside_convolution_workgroups).  The trigger was not isolated beyond
+# "SLP-vectorised code beside conv_x6", and every kernel of a step runs beside the conv_x6 workgroups of the weight-gradient stream,
+# so every kernel gets the form that never failed.  It costs nothing: the non-convolution sources +0.03 ms of a 19.5 ms step, the
+# convolution sources -0.1 ... -0.2 ms (same box, alternating: 20.22 / 20.24 / 20.26 ms with, 20.15 / 20.12 / 20.07 without).
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wall -Wno-unused-function"
 SRCS="api mano raster pfd hand_geom image_ops data_ops conv conv_x6 conv_c1 norm loss optim pool volume"
-if [ "$(cat $OUT/.flags 2>/dev/null)" != "$FLAGS noslp-v2" ]; then
+if [ "$(cat $OUT/.flags 2>/dev/null)" != "$FLAGS" ]; then
   rm -f $OUT/*.o
-  echo "$FLAGS noslp-v2" > $OUT/.flags
+  echo "$FLAGS" > $OUT/.flags
 fi
 pids=()
 for f in $SRCS; do
   if [ ! -f $OUT/$f.o ] || [ $f.hip -nt $OUT/$f.o ] || [ common.h -nt $OUT/$f.o ] || [ ../../include/dsf_hip.h -nt $OUT/$f.o ]; then
     rm -f $OUT/$f.o
-    # Everything but the convolution kernels is built WITHOUT the SLP vectoriser.  Found with mano.hip in round 4: its vectorised
-    # skinning loops (v_pk_fma_f32 on ds_read_b128 broadcasts) returned wrong bits in lanes 48-63 whenever conv_x6 workgroups shared
-    # the CU, the scalar form never did (profiles/r04_mano_beside_conv_x6.txt, tools/platform/mano_beside_conv_x6.py,
-    # tests/test_gpu_determinism.py::test_mano_backward_is_stable_beside_convolution_workgroups).  The trigger was not isolated beyond
-    # "SLP-vectorised code beside conv_x6", every kernel of a step runs beside conv_x6 workgroups of the weight-gradient stream, and
-    # the scalar builds cost 0.03 ms of a 19.5 ms step (same box, alternating: 19.52 / 19.49 vs 19.56 / 19.53) -- so all of them get
-    # the form that never failed.  The convolution kernels keep it (their packed adds are part of the tuned loaders; they are checked
-    # against float64 and bitwise against themselves while sharing CUs with each other all the time).
-    EXTRA="-fno-slp-vectorize"; case $f in conv|conv_x6|conv_c1) EXTRA="";; esac
-    /opt/rocm/bin/hipcc $FLAGS $EXTRA -c $f.hip -o $OUT/$f.o &
+    /opt/rocm/bin/hipcc $FLAGS -c $f.hip -o $OUT/$f.o &
     pids+=($!)
   fi
 done

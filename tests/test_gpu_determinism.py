@@ -369,7 +369,7 @@ def test_every_kernel_of_a_step_is_stable_beside_convolution_workgroups(render, 
     skinning loop SLP-vectorised into v_pk_fma_f32 / ds_read_b128 by the compiler and then returned wrong first components in
     lanes 48-63 of a wave in 170 of 200 launches beside backward-weights or forward conv_x6 launches on a second stream -- never
     alone, never beside the fp32-MFMA kernels, rocBLAS or elementwise kernels, and never when compiled without the SLP
-    vectoriser (profiles/r04_mano_beside_conv_x6.txt; every non-convolution source is built with -fno-slp-vectorize since).  The whole-step
+    vectoriser (profiles/r04_mano_beside_conv_x6.txt; the whole library is built with -fno-slp-vectorize since).  The whole-step
     determinism test above only sees the kernels that happen to overlap the side stream's own work; this one runs every kernel
     of the step (one stream, deterministic mode) while an unrelated stream keeps conv_x6 workgroups on every CU, and requires
     the bits of the unloaded run."""
