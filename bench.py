@@ -320,10 +320,10 @@ def geometry_rooflines(render, B, launches=50):
     gv, gj = torch.randn_like(v), torch.randn_like(j)
     us = timed(lambda: torch.autograd.grad([v, j], q, [gv, gj], retain_graph=True))
     hbm_row("K5b", "mano_skin_bwd_kernel + mano_blend_bwd_kernel (backward)", us,
-            B * (779 * 12 + 21 * 12 + 5248 * 4 + 2 * 2560 * 4 + 62 * 4) + ((B + 1) // 2) * const_bytes,
+            B * (779 * 12 + 21 * 12 + 5248 * 4 + 2 * 2560 * 4 + 62 * 4 + const_bytes),
             "latency-bound: 256-thread workgroups that fit beside two convolution workgroups per CU (78 us as one 1024-thread "
             "workgroup per sample in round 3, which then waited 700 us for a drained CU inside the step); the constants are "
-            "read once per PAIR of samples (L2 / Infinity Cache resident)")
+            "L2 / Infinity Cache resident")
     with torch.no_grad():
         # K6 / K7
         us = timed(lambda: mano.calculate_coll(jx, mesh))

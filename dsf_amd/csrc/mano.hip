@@ -7,7 +7,7 @@
 // The blendshapes are BATCHED: v_posed = v_template + beta.shapedirs + pose_feature.posedirs is a (B x 145) . (145 x 2334)
 // product, so a workgroup owns 256 columns for 8 samples and reads each 148 KB column block of the 1.4 MB constants
 // once per 8 samples (one workgroup per sample read all of them per sample); its transpose in the backward pass,
-// g_pose_feature = g_v_posed . posedirs^T, walks the rows once per pair of samples.  Skinning, the kinematic chain
+// g_pose_feature = g_v_posed . posedirs^T, walks the rows once per sample (per pair of samples above 512).  Skinning, the kinematic chain
 // (12 lanes per joint) and joint regression stay per sample with everything in LDS.  Per output the order of the float
 // operations is the one of the 1024-thread kernels: forward results are bit-identical to theirs.
 //
@@ -84,7 +84,6 @@ __device__ __forceinline__ void rodrigues_bwd(const float* th, const float* G, f
 
 constexpr int NT = 256;             // threads of every workgroup here
 constexpr int BL_SB = 8;            // samples per blendshape workgroup (forward)
-constexpr int BB_SB = 2;            // samples per blendshape-reduction workgroup (backward)
 // backward scratch per sample: d/d(v_posed) | d/dR of the 16 joints from the chain (blendshape part not yet added) | d/dJ
 constexpr int SC_GVP = 0, SC_GR = 2334, SC_GJ = 2478;
 static_assert(SC_GJ + 48 <= DSF_MANO_BWD_SCRATCH_FLOATS, "scratch layout");
@@ -445,10 +444,11 @@ __global__ __launch_bounds__(NT, 3) void mano_skin_bwd_kernel(dsf_mano_model m, 
 }
 
 // ---- backward 2/2: blendshape reductions g_pf[j] = <posedirs_j, g_vp>, g_beta[k] = <shapedirs_k, g_vp> for BB_SB samples
-// per workgroup (every row of the constants is read once per BB_SB samples), then the Rodrigues / quaternion backward and the
+// per workgroup (every row of the constants is read once per BB_SB samples; the per-sample arithmetic does not depend on BB_SB), then the Rodrigues / quaternion backward and the
 // PCA projection of those samples.  Per row: KPT products per thread, a wave sum, the four waves added in order.
 constexpr int BB_KPT = (NE + NT - 1) / NT, BB_ROWS = 145, BB_JB = 5, BB_NBLK = BB_ROWS / BB_JB;
 static_assert(BB_ROWS % BB_JB == 0, "row blocking");
+template <int BB_SB>      // samples per workgroup: 1 (a workgroup per sample: the shortest launch while B workgroups fit the chip), or 2
 __global__ __launch_bounds__(NT, 3) void mano_blend_bwd_kernel(dsf_mano_model m, const float* __restrict__ rot,
                                                             const float* __restrict__ save, const float* __restrict__ scratch,
                                                             int B, int ncomp, int rot_dim, int ps,
@@ -547,7 +547,6 @@ __global__ __launch_bounds__(NT, 3) void mano_blend_bwd_kernel(dsf_mano_model m,
         }
     }
 }
-static_assert(64 * BB_SB <= NT && 16 * BB_SB <= NT, "one launch covers the per-sample tails");
 
 }  // namespace
 
@@ -575,7 +574,13 @@ extern "C" int dsf_mano_backward(const dsf_mano_model* m, const float* theta, co
     if (B == 0) return DSF_OK;
     hipLaunchKernelGGL(mano_skin_bwd_kernel, dim3(B), dim3(NT), 0, (hipStream_t)stream, *m, cam, save, grad_verts,
                        grad_joints, param_stride, k1, k2, grad_cam, scratch);
-    hipLaunchKernelGGL(mano_blend_bwd_kernel, dim3((B + BB_SB - 1) / BB_SB), dim3(NT), 0, (hipStream_t)stream, *m, rot, save,
-                       scratch, B, ncomp, rot_dim, param_stride, grad_beta, grad_theta, grad_rot);
+    // one sample per workgroup up to 512 samples (the backward pair alone at B = 32: 123 -> 90 us; each workgroup streams the
+    // L2-resident constants once), pairs beyond
+    if (B <= 512)
+        hipLaunchKernelGGL(mano_blend_bwd_kernel<1>, dim3(B), dim3(NT), 0, (hipStream_t)stream, *m, rot, save, scratch, B, ncomp,
+                           rot_dim, param_stride, grad_beta, grad_theta, grad_rot);
+    else
+        hipLaunchKernelGGL(mano_blend_bwd_kernel<2>, dim3((B + 1) / 2), dim3(NT), 0, (hipStream_t)stream, *m, rot, save, scratch, B,
+                           ncomp, rot_dim, param_stride, grad_beta, grad_theta, grad_rot);
     return dsf_launch_status();
 }
