@@ -9,6 +9,7 @@ from torch import nn
 
 from .. import nn_conv
 from ..nn_norm import FusedBatchNorm2d
+from ..streams import fork
 
 
 def _bn_relu(c, relu=True):
@@ -72,7 +73,15 @@ class Hourglass(nn.Module):
         self.up2 = nn.Upsample(scale_factor=2, mode='nearest')
 
     def forward(self, x):
-        return self.up1(x) + self.up2(self.low3(self.low2(self.low1(self.pool1(x)))))
+        # the two arms are independent between x and the add: ``up1`` works on this level's own (large) maps, the other arm on
+        # maps a quarter of that size and smaller (8 x 8 ... 2 x 2: 32 ... 2 tiles for 256 CUs) -- a stream per level for ``up1``, so
+        # that the chain of small launches runs beside the large ones instead of between them (streams.py; config 3 +5 %)
+        f = fork(x.device, params=True)
+        with f.branch(self.n):
+            up = self.up1(x)
+        low = self.up2(self.low3(self.low2(self.low1(self.pool1(x)))))
+        f.join()
+        return up + low
 
 
 class Merge(nn.Module):

@@ -420,7 +420,8 @@ class Conv2dFunction(Function):
                 dw = _wrw_dispatch(weight, lambda: _wrw_c1(x, gy, KH, stride, padding[0]), None, (x, gy))
             else:
                 dw = _wrw_dispatch(weight, lambda: _wrw(x, gy, KH, KW, stride, padding),
-                                   lambda acc: _wrw(x, gy, KH, KW, stride, padding, out=acc), (x, gy))
+                                   lambda acc: _wrw(x, gy, KH, KW, stride, padding, out=acc), (x, gy),
+                                   work=2.0 * gy.numel() * Ci * KH * KW)
             gw = None if dw is False else dw.permute(3, 2, 0, 1)
         if has_bias and ctx.needs_input_grad[2]:
             gb = _bias_grad(gy)
@@ -463,6 +464,7 @@ def _side_api_ok():
 
 SIDE_API = _side_api_ok()
 WRW_STREAM = [os.environ.get("DSF_WRW_STREAM", "1") == "1" and SIDE_API]
+WRW_MIN_WORK = [float(os.environ.get("DSF_WRW_MIN_GFLOP", "8")) * 1e9]   # below: the layer's dW stays on the chain's stream
 WRW_PRIORITY = int(os.environ.get("DSF_WRW_PRIORITY", "0"))          # priority of the side stream (lower number = higher priority)
 _SIDE = {}
 _JOIN_QUEUED = [-1]
@@ -476,12 +478,19 @@ def no_side_stream(params, flag=True):
         p.__dict__["_dsf_no_side"] = bool(flag)
 
 
-def _wrw_dispatch(weight, fn_new, fn_add, held):
+def _wrw_dispatch(weight, fn_new, fn_add, held, work=None):
     """One node's weight-gradient launch -> dW (handed to autograd) or False (added into the dW an earlier node of this
     backward pass handed over; autograd gets None).  ``fn_new()`` -> dW;  ``fn_add(acc)`` adds into acc (None: this kernel cannot)."""
     task = torch._C._current_graph_task_id() if SIDE_API else -1
     rec = weight.__dict__.get("_dsf_pass")
     first = task < 0 or rec is None or rec[0] != task
+    if first and task >= 0 and work is not None and work < WRW_MIN_WORK[0]:
+        # a small layer (< DSF_WRW_MIN_GFLOP, default 8): the fork and the join cost more than its launch hides.  Config 3 under
+        # the HIP-graph replay, same box: 17.9 ms per step with all 96 layers on the side stream, 17.0 with none, 16.3-17.3 with
+        # the threshold at 8, 16.7-16.8 at 32; config 2: 18.8 ms at 0, 2 and 8, 19.6 at 32.  First contribution of the pass, so
+        # nothing of this weight is pending on the side stream: no join either
+        weight.__dict__["_dsf_pass"] = (task, None)
+        return fn_new()
     if _side_ok(weight) and task >= 0:
         if first:
             dw = _on_side_stream(fn_new, held)
@@ -629,7 +638,8 @@ class ConvTranspose2dFunction(Function):
                 gx = _fwd(gy, wd, None, (x.shape[2], x.shape[3]), Cin, KH, KW, stride, 1, padding)
         if ctx.needs_input_grad[1]:
             dw = _wrw_dispatch(weight, lambda: _wrw(gy, x, KH, KW, stride, padding),
-                               lambda acc: _wrw(gy, x, KH, KW, stride, padding, out=acc), (x, gy))
+                               lambda acc: _wrw(gy, x, KH, KW, stride, padding, out=acc), (x, gy),
+                               work=2.0 * x.numel() * Cout * KH * KW)
             gw = None if dw is False else dw.permute(3, 2, 0, 1)                               # [kh][kw][Cout][Cin] -> (Cin,Cout,kh,kw)
         if has_bias and ctx.needs_input_grad[2]:
             gb = _bias_grad(gy)

@@ -1,0 +1,61 @@
+"""Fork / join of independent launch chains over HIP streams.
+
+A chain of small launches (the 8 x 8 ... 2 x 2 levels of an hourglass at 2 ... 32 tiles each, the geometry losses after the MANO
+layer) is latency: issued one after the other on one stream it leaves most of the 256 CUs idle.  Where the data flow forks,
+the arms are issued on different streams -- ``fork(device)`` hands out branch streams that start behind the current one and
+``join()`` orders the current one behind them again -- so that the GPU runs them beside each other; autograd replays every
+backward node on the stream of its forward and orders the streams itself, and a captured HIP graph (train_step.GraphedStep)
+keeps the fork as independent dependency chains.
+
+Allocator safety without Tensor.record_stream (whose event-deferred frees made the caching allocator fall back to hipMalloc,
+nn_conv._on_side_stream): a branch stream only ever works between a fork (``wait_stream(current)``) and the join that follows,
+so a block of its pool that is freed after the join is re-used behind everything the forking stream had queued by the
+next fork, and what a branch reads from the forking stream is held by the caller until the join.  Gradients that cross
+streams in the backward pass are recorded by the autograd engine itself.
+
+DSF_BRANCHES=0 keeps everything on one stream.  Off in a multi-rank process group for chains that produce parameter
+gradients (``params=True``): GradAllReducer packs a bucket on the stream its last gradient arrives on.
+"""
+import contextlib
+import os
+
+import torch
+
+ENABLED = [os.environ.get("DSF_BRANCHES", "1") == "1"]
+SLOTS = 4
+_STREAMS = {}
+
+
+def _stream(device, slot):
+    key = (device.index if device.index is not None else torch.cuda.current_device(), slot % SLOTS)
+    s = _STREAMS.get(key)
+    if s is None:
+        s = _STREAMS[key] = torch.cuda.Stream(device=device)
+    return s
+
+
+class fork:
+    """``f = fork(x.device); with f.branch(0): a = g(x); b = h(x); f.join(); a + b``  (a no-op on the CPU or when switched off)"""
+
+    def __init__(self, device, params=False):
+        device = torch.device(device)
+        self.on = ENABLED[0] and device.type == "cuda"
+        if self.on and params and torch.distributed.is_available() and torch.distributed.is_initialized() \
+                and torch.distributed.get_world_size() > 1:
+            self.on = False
+        self.device, self.used = device, []
+        self.cur = torch.cuda.current_stream(device) if self.on else None
+
+    def branch(self, slot):
+        if not self.on:
+            return contextlib.nullcontext()
+        s = _stream(self.device, slot)
+        if s not in self.used:
+            s.wait_stream(self.cur)
+            self.used.append(s)
+        return torch.cuda.stream(s)
+
+    def join(self):
+        for s in self.used:
+            self.cur.wait_stream(s)
+        self.used = []

@@ -16,6 +16,7 @@ from . import ops
 from .metric.losses import SmoothL1Loss
 from .metric.meshLoss import ICPLoss, JointICPLoss
 from .render_model.render_loss import m2d_loss
+from .streams import fork
 from .util.generateFeature import GFM
 from .data.render_loader import loader as TensorUtils
 
@@ -189,12 +190,19 @@ class MeshLossStep:
         mano_layer = self.render.mano_layer
         _, mano_pd = self.net(tgt["img"])
         img_pd, juvd, jxyz, mesh = self.render.render(mano_pd, tgt["center"], tgt["cube"])
-        crop_pd = self.utils.crop_hand(img_pd, tgt["joint_xyz"], tgt["center"], tgt["M"], tgt["cube"])
-        l_m2d = m2d_loss(tgt["crop"], crop_pd) * cfg.model_weight
-        l_part = JointICPLoss(mesh, tgt["joint_pcl"], mano_layer.joint_faces, tgt["seg"]).mean(-1).mean(-1) * cfg.partICP_weight
+        # four independent chains behind the MANO layer (streams.py): the point-to-triangle search fills the chip, the others
+        # are a few short launches each -- beside it instead of behind it, forward and backward
+        f = fork(mesh.device)
+        with f.branch(0):
+            crop_pd = self.utils.crop_hand(img_pd, tgt["joint_xyz"], tgt["center"], tgt["M"], tgt["cube"])
+            l_m2d = m2d_loss(tgt["crop"], crop_pd) * cfg.model_weight
+        with f.branch(1):
+            l_part = JointICPLoss(mesh, tgt["joint_pcl"], mano_layer.joint_faces, tgt["seg"]).mean(-1).mean(-1) * cfg.partICP_weight
+        with f.branch(2):
+            l_coll = mano_layer.calculate_coll(jxyz, mesh.detach()) * cfg.coll_weight
+            l_sup = (self.L1(jxyz, tgt["joint_xyz"]) + self.L1(mesh, tgt["mesh_xyz"])) * cfg.coord_weight
         l_icp = ICPLoss(mesh, tgt["pcl"], mano_layer.faces).mean(-1) * cfg.model_weight
-        l_coll = mano_layer.calculate_coll(jxyz, mesh.detach()) * cfg.coll_weight
-        l_sup = (self.L1(jxyz, tgt["joint_xyz"]) + self.L1(mesh, tgt["mesh_xyz"])) * cfg.coord_weight
+        f.join()
         terms = {"m2d": l_m2d, "pd2m": l_part, "d2m": l_icp, "coll": l_coll, "sup": l_sup}
         return l_m2d + l_part + l_icp + l_coll + l_sup, terms
 
