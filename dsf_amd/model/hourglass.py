@@ -146,12 +146,34 @@ class PoseNet(nn.Module):
         return preds_all, hg
 
 
+class _GlobalAvgPoolFunction(torch.autograd.Function):
+    """the two single-pass sums below with a CHANNELS_LAST gradient: autograd's own backward of ``sum`` expands the pooled
+    gradient in torch's standard order, and that order then travels down every skip connection of the last hourglass (each
+    add takes it over, each upsampling backward runs its strided path: 4 x 55 us at 2 ... 128 workgroups) until a HIP kernel
+    converts it.  Same values."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = x.shape
+        return (x.sum(3).sum(2) * (1.0 / (x.shape[2] * x.shape[3]))).reshape(x.shape[0], x.shape[1], 1, 1)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        B, C, H, W = ctx.shape
+        gx = torch.empty((B, C, H, W), device=g.device, dtype=g.dtype, memory_format=torch.channels_last)
+        gx.copy_((g.reshape(B, C, 1, 1) * (1.0 / (H * W))).expand(B, C, H, W))
+        return gx
+
+
 class GlobalAvgPool2d(nn.Module):
     """nn.AdaptiveAvgPool2d(1) as two single-pass sums (over W, then over H).  torch's one-shot mean over a large H x W
     to B x C outputs is a multi-block reduction whose semaphores are zeroed by a hipMemsetAsync -- a node a captured HIP
     graph does not replay correctly on ROCm 7.2 (train_step.GraphedStep refuses such graphs)."""
 
     def forward(self, x):
+        if x.is_cuda and x.dim() == 4:
+            return _GlobalAvgPoolFunction.apply(x)
         return (x.sum(3).sum(2) * (1.0 / (x.shape[2] * x.shape[3]))).reshape(x.shape[0], x.shape[1], 1, 1)
 
 

@@ -185,7 +185,7 @@ def test_graphed_step_refuses_a_graph_with_memset_nodes(render):
     assert step.grad_sync.enabled is True
 
 
-def test_backward_weights_side_stream_is_invisible(det_mode):
+def test_backward_weights_side_stream_is_invisible(det_mode, monkeypatch):
     """nn_conv runs dW of a convolution on a second stream when nothing can read that gradient before the backward pass ends
     (leaf weight in kernel layout, no gradient yet, no foreign hooks).  In deterministic mode every variant below must
     give BITWISE the gradients of the single-stream run: one use (side stream taken), a network applied to two batches (the
@@ -194,6 +194,7 @@ def test_backward_weights_side_stream_is_invisible(det_mode):
     backward, a standard-layout leaf weight (AccumulateGrad would clone its dW on the main stream) and a
     retained graph differentiated together with a new one (a forward-time use count under-counts there)."""
     from dsf_amd import nn_conv, nn_norm, _lib as L
+    monkeypatch.setattr(nn_conv, "WRW_MIN_WORK", [0.0])          # (these layers are below the default size threshold of the side stream)
     torch.manual_seed(2)
     net = torch.nn.Sequential(nn_conv.Conv2d(64, 128, 3, 1, 1, bias=False), nn_norm.FusedBatchNorm2d(128, fuse_relu=True),
                               nn_conv.Conv2d(128, 128, 3, 2, 1, bias=True), nn_norm.FusedBatchNorm2d(128, fuse_relu=True),
@@ -332,14 +333,33 @@ def test_backward_weights_side_stream_is_invisible(det_mode):
     # 3 convolutions + 1 transposed; a net used twice (deterministic mode): each weight's first contribution only, the second
     # joins the streams and runs on the main one; the standard-layout weight never (the two convolutions below it do)
     assert n_one == 4 and n_two == 4 and n_std == 2
+    # the size threshold (DSF_WRW_MIN_GFLOP): a layer below it keeps its dW on the chain's stream -- same bits, nothing forked
+    monkeypatch.setattr(nn_conv, "WRW_MIN_WORK", [1e30])
+    ref = one_use()
+    taken = []
+    nn_conv._on_side_stream = lambda fn, inputs: taken.append(1) or orig(fn, inputs)
+    try:
+        got = one_use() + two_uses()
+    finally:
+        nn_conv._on_side_stream = orig
+    assert not taken and all(torch.equal(a, b) for a, b in zip(ref, got))
+    monkeypatch.setattr(nn_conv, "WRW_MIN_WORK", [2.0 * 8 * 128 * 32 * 32 * 64 * 9])       # the first layer's own work: it and nothing smaller forks
+    taken = []
+    nn_conv._on_side_stream = lambda fn, inputs: taken.append(1) or orig(fn, inputs)
+    try:
+        got = one_use()
+    finally:
+        nn_conv._on_side_stream = orig
+    assert len(taken) == 1 and all(torch.equal(a, b) for a, b in zip(ref, got))
 
 
-def test_backward_on_a_worker_thread_matches_the_main_thread(det_mode):
+def test_backward_on_a_worker_thread_matches_the_main_thread(det_mode, monkeypatch):
     """The weight-gradient stream's bookkeeping (module-level lists, the per-pass record on the weight, the engine callback) is
     driven from whichever thread runs the backward pass: a backward pass started on a worker thread -- autograd then runs the
     device's nodes on its own engine thread -- gives bitwise the gradients of the main-thread run, repeatedly."""
     import threading
     from dsf_amd import nn_conv, nn_norm
+    monkeypatch.setattr(nn_conv, "WRW_MIN_WORK", [0.0])
     torch.manual_seed(4)
     net = torch.nn.Sequential(nn_conv.Conv2d(32, 64, 3, 1, 1, bias=False), nn_norm.FusedBatchNorm2d(64, fuse_relu=True),
                               nn_conv.Conv2d(64, 64, 3, 2, 1, bias=True), nn_conv.ConvTranspose2d(64, 32, 4, stride=2, padding=1, bias=False)).cuda()
