@@ -909,19 +909,9 @@ int dsf_conv_x6_split_weights_multi(const int64_t* jobs, int n_jobs, int64_t tot
     return dsf_launch_status();
 }
 
-// Ci / Co are the reduction / output channel counts of the IMAGE (mode 1: those of the backward-data GEMM).
-static int x6_forward_impl(const float* X, const void* image, const float* bias, float* Y, int B, int Hi, int Wi, int Ci, int Ho,
-                           int Wo, int Co, int KH, int KW, int stride, int dil, int pad_h, int pad_w, int k_splits,
-                           float* bn_stats, int* bn_rows, X6Ep ep, int* ep_applied, dsf_stream_t stream) {
-    if (bn_rows) *bn_rows = 0;
-    DSF_CHECK_ARG(X && image && Y && B >= 0 && Hi > 0 && Wi > 0 && Ci > 0 && Ho > 0 && Wo > 0 && Co > 0 && KH > 0 && KW > 0);
-    DSF_CHECK_ARG(stride >= 1 && (Ci & 3) == 0 && (dil == 1 || (dil == 2 && stride == 1)));
-    if (dil == 2 && ((Ho | Wo) & 1)) return DSF_ERR_UNSUPPORTED;
-    if (B == 0) return DSF_OK;
-    X6P p = {B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad_h, pad_w};
-    const int64_t M = (int64_t)B * Ho * Wo;
-    const int64_t x_bytes = (int64_t)B * Hi * Wi * Ci * 4, w_bytes = dsf_conv_x6_image_bytes(KH, KW, Ci, Co);
-    DSF_CHECK_ARG(M < (1ll << 31) && x_bytes < 0xFFFFFFF0ll && w_bytes < 0xFFFFFFF0ll);
+// Tiling of one forward launch: tile rows, tile counts and the number of K splits (k_splits < 1: chosen here).
+struct X6Plan { int bn, n_tiles, bdirect, bmt, m_tiles, k_splits; };
+static X6Plan x6_forward_plan(int64_t M, int Ci, int Co, int KH, int KW, int dil, int k_splits) {
     const int bn = x6_bn(Co);
     const int n_tiles = (Co + bn - 1) / bn;
     // DSF_X6_BDIRECT=0: the first-generation kernels (both operands through LDS); default: igemm_x6b_kernel (B operand straight
@@ -944,7 +934,27 @@ static int x6_forward_impl(const float* X, const void* image, const float* bias,
     }
     if (k_splits > n_chunks) k_splits = n_chunks > 0 ? n_chunks : 1;
     if (dsf_deterministic()) k_splits = 1;                               // no float atomics in the epilogue
-    if (k_splits > 1 &&
+    return X6Plan{bn, n_tiles, bdirect, bmt, m_tiles, k_splits};
+}
+
+// Ci / Co are the reduction / output channel counts of the IMAGE (mode 1: those of the backward-data GEMM).
+static int x6_forward_impl(const float* X, const void* image, const float* bias, float* Y, int B, int Hi, int Wi, int Ci, int Ho,
+                           int Wo, int Co, int KH, int KW, int stride, int dil, int pad_h, int pad_w, int k_splits,
+                           float* bn_stats, int* bn_rows, X6Ep ep, int* ep_applied, dsf_stream_t stream, bool y_ready = false) {
+    if (bn_rows) *bn_rows = 0;
+    DSF_CHECK_ARG(X && image && Y && B >= 0 && Hi > 0 && Wi > 0 && Ci > 0 && Ho > 0 && Wo > 0 && Co > 0 && KH > 0 && KW > 0);
+    DSF_CHECK_ARG(stride >= 1 && (Ci & 3) == 0 && (dil == 1 || (dil == 2 && stride == 1)));
+    if (dil == 2 && ((Ho | Wo) & 1)) return DSF_ERR_UNSUPPORTED;
+    if (B == 0) return DSF_OK;
+    X6P p = {B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad_h, pad_w};
+    const int64_t M = (int64_t)B * Ho * Wo;
+    const int64_t x_bytes = (int64_t)B * Hi * Wi * Ci * 4, w_bytes = dsf_conv_x6_image_bytes(KH, KW, Ci, Co);
+    DSF_CHECK_ARG(M < (1ll << 31) && x_bytes < 0xFFFFFFF0ll && w_bytes < 0xFFFFFFF0ll);
+    const X6Plan plan = x6_forward_plan(M, Ci, Co, KH, KW, dil, k_splits);
+    const int bn = plan.bn, n_tiles = plan.n_tiles, bdirect = plan.bdirect, bmt = plan.bmt, m_tiles = plan.m_tiles;
+    k_splits = plan.k_splits;
+    if (y_ready && k_splits < 2) return DSF_ERR_UNSUPPORTED;             // only the split launches ADD into Y
+    if (k_splits > 1 && !y_ready &&
         dsf_zero_async(Y, sizeof(float) * (size_t)M * Co, (hipStream_t)stream) != hipSuccess) return DSF_ERR_LAUNCH;
     const dim3 grid(m_tiles * n_tiles * k_splits);
     // BatchNorm statistics in the epilogue: only the B-direct kernels, unsplit, without a bias
@@ -997,6 +1007,23 @@ int dsf_conv_x6_forward(const float* X, const void* image, const float* bias, fl
                         dsf_stream_t stream) {
     return x6_forward_impl(X, image, bias, Y, B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, dil, pad_h, pad_w, k_splits, nullptr, nullptr,
                            X6Ep{nullptr, nullptr, nullptr, 0, 0}, nullptr, stream);
+}
+
+// The K splits dsf_conv_x6_forward would choose for this shape (1: an unsplit launch that stores Y).
+int dsf_conv_x6_forward_splits(int B, int Ho, int Wo, int Ci, int Co, int KH, int KW, int dil) {
+    if (B <= 0 || Ho <= 0 || Wo <= 0 || Ci <= 0 || Co <= 0 || KH <= 0 || KW <= 0 || (dil != 1 && dil != 2)) return 1;
+    return x6_forward_plan((int64_t)B * Ho * Wo, Ci, Co, KH, KW, dil, 0).k_splits;
+}
+
+// dsf_conv_x6_forward as a split launch that ADDS into a Y the caller has initialised (zeros from one pooled fill instead of a
+// fill per layer, or a residual): k_splits >= 2 as reported by dsf_conv_x6_forward_splits; DSF_ERR_UNSUPPORTED otherwise and in
+// deterministic mode (which never splits).
+int dsf_conv_x6_forward_into(const float* X, const void* image, const float* bias, float* Y, int B, int Hi, int Wi, int Ci, int Ho,
+                             int Wo, int Co, int KH, int KW, int stride, int dil, int pad_h, int pad_w, int k_splits,
+                             dsf_stream_t stream) {
+    if (k_splits < 2) return DSF_ERR_UNSUPPORTED;
+    return x6_forward_impl(X, image, bias, Y, B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, dil, pad_h, pad_w, k_splits, nullptr, nullptr,
+                           X6Ep{nullptr, nullptr, nullptr, 0, 0}, nullptr, stream, true);
 }
 
 // partial rows a BatchNorm-statistics epilogue may write for an (M = B Ho Wo)-row output: one per 64 rows at most

@@ -462,6 +462,41 @@ __global__ __launch_bounds__(256) void col_sum_combine_kernel(const float* __res
     if (pl == 0 && c < C) out[c] = (s[cl] + s[64 + cl]) + (s[128 + cl] + s[192 + cl]);
 }
 
+// Small inputs (<= 1 M elements: bias gradients on the 8 x 8 ... 2 x 2 maps of an hourglass, where a launch costs more than the
+// sum): ONE launch, a workgroup per 16 columns (4 float4 lanes x 64 row lanes), fixed-order fold.
+__global__ __launch_bounds__(256) void col_sum_small_kernel(const float* __restrict__ x, int M, int C, float* __restrict__ out) {
+    __shared__ float4 s[256];
+    const int t = threadIdx.x, cl = t & 3, rl = t >> 2;
+    const int C4 = C >> 2, c4 = blockIdx.x * 4 + cl;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c4 < C4) {
+        const float4* base = reinterpret_cast<const float4*>(x) + c4;
+        int r = rl;
+        for (; r + 7 * 64 < M; r += 8 * 64) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = base[(int64_t)(r + u * 64) * C4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        }
+        for (; r < M; r += 64) {
+            const float4 v = base[(int64_t)r * C4];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    s[t] = acc;
+    __syncthreads();
+    for (int st = 32; st > 0; st >>= 1) {
+        if (rl < st) {
+            const float4 v = s[(rl + st) * 4 + cl];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            s[t] = acc;
+        }
+        __syncthreads();
+    }
+    if (rl == 0 && c4 < C4) reinterpret_cast<float4*>(out)[c4] = acc;
+}
+
 // scalar-column variant for channel counts that are not a multiple of 4
 __global__ __launch_bounds__(256) void col_sum_scalar_kernel(const float* __restrict__ x, int64_t M, int C, int cpad,
                                                              int rows_per_wg, float* __restrict__ out) {
@@ -799,6 +834,11 @@ extern "C" int64_t dsf_col_sum_workspace_bytes(int C) { return (int64_t)COLSUM_M
 extern "C" int dsf_col_sum(const float* x, int64_t M, int C, float* out, float* workspace, dsf_stream_t stream) {
     DSF_CHECK_ARG(x && out && M > 0 && C > 0);
     hipStream_t st = (hipStream_t)stream;
+    static const int small_on = [] { const char* e = getenv("DSF_COLSUM_SMALL"); return e ? atoi(e) : 1; }();     // tuning aid
+    if (small_on && (C & 3) == 0 && M * C <= (1 << 20) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+        hipLaunchKernelGGL(col_sum_small_kernel, dim3((C / 4 + 3) / 4), dim3(256), 0, st, x, (int)M, C, out);
+        return dsf_launch_status();
+    }
     if (workspace && (C & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0) {
         int c4n = 1;
         while (c4n < (C >> 2) && c4n < 256) c4n <<= 1;        // float4 column groups per pass (power of two <= 256)

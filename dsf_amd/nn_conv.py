@@ -186,10 +186,65 @@ def _fwd_x6(x, image, bias, out_hw, Co, KH, KW, stride, pad, dil=1):
         if rows.value > 0:
             req.part, req.rows = part, rows.value
         return y
+    if _ZERO is not None and B > 0 and y.numel() * 4 <= ZERO_POOL_MAX_BYTES:
+        # a small layer that the launcher splits along K (partial sums meet in Y by float atomics): Y from the step's pooled zero
+        # fill instead of a fill launch of its own in front of every such layer
+        splits = int(L.lib().dsf_conv_x6_forward_splits(I(B), I(Ho), I(Wo), I(Ci), I(Co), I(KH), I(KW), I(dil)))
+        off = _zero_take(B * Ho * Wo * Co, x.device) if splits > 1 else None
+        if off is not None:
+            # (a tensor of its own on the pool's storage, not a view of the pool: views share ONE version counter, and an
+            #  in-place op on any pooled output would then invalidate every other one that autograd has saved)
+            y = torch.empty(0, device=x.device, dtype=torch.float32).set_(_ZERO[0].untyped_storage(), off, (B, Co, Ho, Wo),
+                                                                          (Ho * Wo * Co, 1, Wo * Co, Co))
+            check(L.lib().dsf_conv_x6_forward_into(ptr_nhwc(x), ptr(image), ptr(bias), ptr_nhwc(y), I(B), I(Hi), I(Wi), I(Ci), I(Ho),
+                                                   I(Wo), I(Co), I(KH), I(KW), I(stride), I(dil), I(pad[0]), I(pad[1]), I(splits),
+                                                   stream_ptr()), "dsf_conv_x6_forward_into")
+            return y
     check(L.lib().dsf_conv_x6_forward(ptr_nhwc(x), ptr(image), ptr(bias), ptr_nhwc(y), I(B), I(Hi), I(Wi), I(Ci), I(Ho), I(Wo),
                                       I(Co), I(KH), I(KW), I(stride), I(dil), I(pad[0]), I(pad[1]), I(0), stream_ptr()),
           "dsf_conv_x6_forward")
     return y
+
+
+# ---- zero pool: one fill per step for the outputs of the small split-K layers -----------------------------------------
+# ``with zero_pool(owner, device):`` around one forward + backward of a step.  The pool is as large as the demand the PREVIOUS
+# pass under the same owner recorded (the first pass records only and every layer fills its own Y); outputs above
+# ZERO_POOL_MAX_BYTES keep their own fill (a pooled fill of the 16 x 16 maps' outputs costs what it saves).  The slices are
+# views of one tensor: it lives as long as any of them (activations saved for the backward pass included).
+ZERO_POOL = [os.environ.get("DSF_ZERO_POOL", "1") == "1"]
+ZERO_POOL_MAX_BYTES = int(os.environ.get("DSF_ZERO_POOL_MAX_MB", "4")) << 20
+_ZERO = None         # [flat zeroed tensor or None, next offset, demand of this pass]
+
+
+class zero_pool:
+    def __init__(self, owner, device):
+        self.owner, self.device = owner, torch.device(device)
+
+    def __enter__(self):
+        global _ZERO
+        self.saved = _ZERO
+        if ZERO_POOL[0] and self.device.type == "cuda" and not L.deterministic():
+            n = int(self.owner.__dict__.get("_zero_pool_floats", 0))
+            _ZERO = [torch.zeros(n, device=self.device, dtype=torch.float32) if n > 0 else None, 0, 0]
+        else:
+            _ZERO = None
+        return self
+
+    def __exit__(self, *a):
+        global _ZERO
+        if _ZERO is not None:
+            self.owner.__dict__["_zero_pool_floats"] = _ZERO[2]
+        _ZERO = self.saved
+
+
+def _zero_take(n, device):
+    n = (n + 3) & ~3
+    _ZERO[2] += n
+    buf, off = _ZERO[0], _ZERO[1]
+    if buf is None or buf.device != device or off + n > buf.numel():
+        return None
+    _ZERO[1] = off + n
+    return off
 
 
 def _x6_dil_ok(Ck, Ho, Wo, dil, n_in=0):

@@ -56,14 +56,18 @@ def synthetic_batch(B, device, seed=0, dtype=torch.float32):
 
 
 def _stat_pool(step, net, applications=1):
-    """The per-step pool of zeroed BatchNorm accumulation rows (nn_norm.stat_pool): one zero fill per step lets every fused
-    BatchNorm of ``net`` run without finalise launches; sized once per step object."""
-    from . import nn_norm
+    """The per-step pools around one forward + backward: zeroed BatchNorm accumulation rows (nn_norm.stat_pool: one zero fill
+    per step lets every fused BatchNorm of ``net`` run without finalise launches; sized once per step object) and the zeroed
+    outputs of the small split-K convolutions (nn_conv.zero_pool: sized by the previous step's demand)."""
+    from . import nn_norm, nn_conv
     if not hasattr(step, "_stat_floats"):
         dev = next(net.parameters()).device
         step._stat_floats = nn_norm.stat_floats(net, applications) if dev.type == "cuda" else 0
         step._stat_dev = dev
-    return nn_norm.stat_pool(step._stat_floats, step._stat_dev)
+    stack = contextlib.ExitStack()
+    stack.enter_context(nn_norm.stat_pool(step._stat_floats, step._stat_dev))
+    stack.enter_context(nn_conv.zero_pool(step, step._stat_dev))
+    return stack
 
 
 def _default_adamw(params, lr, weight_decay):

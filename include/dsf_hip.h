@@ -379,6 +379,15 @@ int dsf_conv_x6_split_weights_multi(const int64_t* jobs, int n_jobs, int64_t tot
 int dsf_conv_x6_forward(const float* X, const void* image, const float* bias, float* Y, int B, int Hi, int Wi, int Ci, int Ho,
                         int Wo, int Co, int KH, int KW, int stride, int dil, int pad_h, int pad_w, int k_splits,
                         dsf_stream_t stream);
+/* dsf_conv_x6_forward_splits: the K splits dsf_conv_x6_forward (k_splits <= 0) chooses for this shape; 1 = an unsplit launch
+ * that stores Y.  A split launch first zero-fills Y -- one more launch in front of every small layer.
+ * dsf_conv_x6_forward_into: the split launch WITHOUT that fill: it ADDS the convolution (+ bias) into a Y the caller has
+ * initialised -- zeros taken from one pooled fill per step (dsf_amd/nn_conv.py: zero_pool), or a residual.  k_splits >= 2 as
+ * reported by dsf_conv_x6_forward_splits, else DSF_ERR_UNSUPPORTED (also in deterministic mode, which never splits). */
+int dsf_conv_x6_forward_splits(int B, int Ho, int Wo, int Ci, int Co, int KH, int KW, int dil);
+int dsf_conv_x6_forward_into(const float* X, const void* image, const float* bias, float* Y, int B, int Hi, int Wi, int Ci, int Ho,
+                             int Wo, int Co, int KH, int KW, int stride, int dil, int pad_h, int pad_w, int k_splits,
+                             dsf_stream_t stream);
 /* Measurement aid for bench.py: launches a bare v_mfma_f32_32x32x16_bf16 loop (no memory traffic) on `workgroups` x 4 waves,
  * `iters` x 24 MFMAs each, operands = 16 KiB of bf16 pairs; returns the number of MFMAs issued (each 2*32*32*16 flop), -1 on error.
  * Timed by the caller: the matrix-pipe rate the chip sustains at the clock it holds under that load. */

@@ -439,3 +439,67 @@ def test_eval_mode_batchnorm_rides_in_the_conv_epilogue(kind, Ci, Co, K, s, p, H
     y = nn_norm.conv_bn_act(conv, bn, xg, relu=True)
     y.sum().backward()
     assert xg.grad is not None and torch.isfinite(xg.grad).all()
+
+
+@pytest.mark.parametrize("Ci,Co,K,H,B", [(128, 128, 3, 4, 16), (256, 128, 1, 2, 64), (256, 256, 3, 8, 8)])
+def test_split_launch_adds_into_a_pooled_zero_output(Ci, Co, K, H, B):
+    """A small layer is split along K and its partial sums meet in Y by float atomics: Y comes from the step's pooled zero fill
+    (nn_conv.zero_pool -> dsf_conv_x6_forward_into) instead of a fill launch per layer.  Same result as the self-filling launch up
+    to atomic order, forward and through the backward-data pass; the first pass under an owner only records the demand."""
+    import ctypes
+    from dsf_amd import nn_conv, _lib as L
+    if nn_conv.MATH != "x6":
+        pytest.skip("DSF_CONV_MATH=f32")
+    I = ctypes.c_int
+    assert int(L.lib().dsf_conv_x6_forward_splits(I(B), I(H), I(H), I(Ci), I(Co), I(K), I(K), I(1))) > 1
+    bwd_split = int(L.lib().dsf_conv_x6_forward_splits(I(B), I(H), I(H), I(Co), I(Ci), I(K), I(K), I(1))) > 1    # the backward-data launch
+    g = torch.Generator().manual_seed(Ci + Co + K + H)
+    x = torch.randn(B, Ci, H, H, generator=g).cuda().requires_grad_(True)
+    w = (torch.randn(Co, Ci, K, K, generator=g) / (Ci * K * K) ** 0.5).cuda().requires_grad_(True)
+    b = torch.randn(Co, generator=g).cuda().requires_grad_(True)
+    gy = torch.randn(B, Co, H, H, generator=g).cuda()
+
+    def run():
+        y = nn_conv.Conv2dFunction.apply(x, w, b, 1, (K // 2, K // 2))
+        gx, = torch.autograd.grad((y * gy).sum(), [x])
+        return y.detach(), gx
+
+    y0, gx0 = run()
+
+    class Owner:
+        pass
+    owner = Owner()
+    with nn_conv.zero_pool(owner, x.device):
+        y1, gx1 = run()                                          # records the demand, fills per layer
+        assert nn_conv._ZERO[0] is None
+    want = y0.numel() + (gx0.numel() if bwd_split else 0)
+    assert owner._zero_pool_floats == want
+    with nn_conv.zero_pool(owner, x.device):
+        pool = nn_conv._ZERO[0]
+        y2, gx2 = run()
+        assert nn_conv._ZERO[1] == want                          # every split launch took its output from the pool
+    lo, hi = pool.data_ptr(), pool.data_ptr() + pool.numel() * 4
+    assert lo <= y2.data_ptr() < hi and (lo <= gx2.data_ptr() < hi) == bwd_split and not (lo <= y1.data_ptr() < hi)
+    ref = F.conv2d(x.detach().double().cpu(), w.detach().double().cpu(), b.detach().double().cpu(), padding=K // 2)
+    for y in (y0, y1, y2):
+        assert _rel(y.double().cpu(), ref) < 2e-6
+    assert _rel(gx2, gx0) < 2e-6 and _rel(gx1, gx0) < 2e-6
+    # an unsplit request is refused: the unsplit kernels store Y
+    out = torch.zeros_like(y0)
+    rc = L.lib().dsf_conv_x6_forward_into(nn_conv.ptr_nhwc(x.detach().contiguous(memory_format=torch.channels_last)), None,
+                                          None, nn_conv.ptr_nhwc(out), I(B), I(H), I(H), I(Ci), I(H), I(H), I(Co), I(K), I(K), I(1),
+                                          I(1), I(K // 2), I(K // 2), I(1), None)
+    assert rc != 0
+
+
+@pytest.mark.parametrize("M,C", [(256, 128), (4096, 256), (1000, 12), (64, 256), (3, 64), (16384, 64), (5000, 128)])
+def test_bias_gradient_column_sums(M, C):
+    """dsf_col_sum: per-channel sums of an (M, C) matrix -- the one-launch kernel for small inputs, the two-launch form above
+    1 M elements -- against float64, and bitwise run to run (fixed-order folds)."""
+    from dsf_amd import nn_conv
+    g = torch.Generator().manual_seed(M + C)
+    gy = (torch.randn(1, M, 1, C, generator=g) * 3 + 0.5).cuda().permute(0, 3, 1, 2)          # (1, C, M, 1), channels_last memory
+    out = nn_conv._bias_grad(gy)
+    ref = gy.double().sum((0, 2, 3))
+    assert (out.double() - ref).abs().max().item() < 1e-6 * gy.abs().double().sum((0, 2, 3)).max().item()
+    assert torch.equal(out, nn_conv._bias_grad(gy))
