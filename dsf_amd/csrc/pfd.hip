@@ -433,6 +433,9 @@ __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __rest
         for (int o = 32; o > 0; o >>= 1) rw = fmaxf(rw, __shfl_xor(rw, o, 64));
         const float ball_reach = (rw + tmax) * (1.0f + CULL_M);       // (inf / NaN when some lane has no finite threshold: nothing is discarded)
         // ---- scan: this wave's blocks, no workgroup barrier ----
+        const int n_live = __popcll(__ballot(live));
+        bool dense = false;
+        int since = 0;
         for (int k = wave; k < n_blocks; k += 4) {
             const int cnt = stage(k, true);
             bool keep = false;
@@ -443,6 +446,27 @@ __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __rest
                 keep = !(dc > s.w + ball_reach);
             }
             unsigned long long cand = __ballot(keep);    // the triangles of this block the group's ball can reach, lowest first
+            if (dense && ++since < 4) {
+                // the last tested block was evaluated almost whole (a mesh beside the cloud, or collapsed to a blob as a freshly
+                // initialised network predicts it: every triangle is then a near-minimiser of every point): the per-triangle tests
+                // only cost -- the plain loop over the stage, whose LDS reads the compiler runs ahead of the arithmetic (the
+                // candidate loop cannot: 2.0 ms per launch in config 5's first steps against 0.9 for the brute-force kernel of round
+                // 3).  Evaluating a triangle the cull would have skipped never changes the result: it cannot hold a minimiser.
+                // Every 4th block is tested again.
+                if (live) {
+                    const float was = best;
+                    for (int q = 0; q < cnt; ++q) {
+                        const float d = point_tri_dist2(pt, w_tri[q]);
+                        const int id = f0 + k * bs + q;
+                        if (bi < 0 || d < best || (d == best && id < bi)) { best = d; bi = id; }
+                    }
+                    if (best != was) thr = sqrtf(best) * ((1.0f + CULL_M) * 1.0011f / (1.0f - CULL_M));
+                }
+                continue;
+            }
+            since = 0;
+            const int n_cand = __popcll(cand);
+            int evals = 0;
             while (cand) {
                 const int q = __builtin_ctzll(cand);
                 cand &= cand - 1;
@@ -450,7 +474,9 @@ __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __rest
                 const float dx = pt.x - s.x, dy = pt.y - s.y, dz = pt.z - s.z;
                 const float lim = s.w + thr;
                 const bool need = live && !(dx * dx + dy * dy + dz * dz > lim * lim);      // (NaN distances are never skipped)
-                if (!__any(need)) continue;                                                // nobody needs this triangle
+                const unsigned long long who = __ballot(need);
+                if (!who) continue;                                                        // nobody needs this triangle
+                evals += __popcll(who);
                 if (need) {
                     const float d = point_tri_dist2(pt, w_tri[q]);
                     const int id = f0 + k * bs + q;
@@ -460,6 +486,7 @@ __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __rest
                     }
                 }
             }
+            dense = n_cand * 2 > cnt && evals * 2 > n_cand * n_live;
         }
         // ---- the four waves' minima: smallest distance, then smallest index (the oracle's tie rule) ----
         __syncthreads();

@@ -127,15 +127,20 @@ def _mesh_soup(rng, V, F, scale, snap):
     return verts, faces
 
 
-@pytest.mark.parametrize("seed,scale,snap,P", [(21, 1.0, True, 2048), (22, 1.0, False, 3000), (23, 0.02, False, 2048),
-                                               (24, 0.02, True, 1000), (25, 0.004, False, 777), (26, 1.0, True, 5000)])
-def test_culled_point_to_mesh_kernel_bit_exact_on_soups(seed, scale, snap, P):
+@pytest.mark.parametrize("seed,scale,snap,P,mode", [(21, 1.0, True, 2048, "mixed"), (22, 1.0, False, 3000, "mixed"),
+                                                    (23, 0.02, False, 2048, "mixed"), (24, 0.02, True, 1000, "mixed"),
+                                                    (25, 0.004, False, 777, "mixed"), (26, 1.0, True, 5000, "mixed"),
+                                                    (27, 1.0, True, 2048, "far"), (28, 1.0, False, 2048, "blob"),
+                                                    (29, 0.02, True, 3000, "blob")])
+def test_culled_point_to_mesh_kernel_bit_exact_on_soups(seed, scale, snap, P, mode):
     """`dsf_mesh_point_dist_forward` (ICPLoss / JointICPLoss) since round 4 skips triangles whose bounding sphere cannot hold a
     minimiser, visits points in Morton-cell order and triangles per wave quarter: distances AND argmin indices must still be
     those of the exhaustive scan in index order (the C oracle), on geometry built to break a cull -- exact ties between
     duplicated / lattice triangles, degenerate triangles, tiny triangles where the reference's epsilon terms enlarge the
     `inside` region, points on vertices / edges / inside faces / far away, clouds above the LDS list capacity (P = 5000: plain
-    index ranges), and a labelled (per-part) run over a random partition of the faces."""
+    index ranges), and a labelled (per-part) run over a random partition of the faces.  ``far``: the cloud sits beside the soup;
+    ``blob``: the soup is collapsed to 1 % of the cloud's size (what a freshly initialised MANO head predicts) -- every triangle
+    is then a near-minimiser of every point, whole blocks survive the cull and the kernel takes its plain loop over them."""
     from dsf_amd import ops
     from oracle import p3d
     rng = np.random.default_rng(seed)
@@ -156,6 +161,10 @@ def test_culled_point_to_mesh_kernel_bit_exact_on_soups(seed, scale, snap, P):
         w = rng.uniform(-0.2, 1.2, (k, 2)).astype(np.float32)                                # in the plane, just outside edges
         pts[b, 3 * k:4 * k] = tri[g, 0] + w[:, :1] * (tri[g, 1] - tri[g, 0]) + w[:, 1:] * (tri[g, 2] - tri[g, 0])
     pts[:, -1] = 50.0 * scale                                      # far away
+    if mode == "far":
+        pts[:, :, 0] += np.float32(6.0 * scale)
+    elif mode == "blob":
+        verts = (verts * np.float32(0.01)).astype(np.float32)
     T = lambda a: torch.tensor(a, device="cuda")
     first = torch.tensor([0, F], dtype=torch.int32, device="cuda")
     dis, idx = ops.MeshPointDistance.apply(T(verts), T(pts), T(faces), first, None, 1)
