@@ -499,7 +499,8 @@ __global__ __launch_bounds__(256) void col_sum_small_kernel(const float* __restr
 
 // scalar-column variant for channel counts that are not a multiple of 4
 __global__ __launch_bounds__(256) void col_sum_scalar_kernel(const float* __restrict__ x, int64_t M, int C, int cpad,
-                                                             int rows_per_wg, float* __restrict__ out) {
+                                                             int rows_per_wg, float* __restrict__ out, float* __restrict__ part) {
+    // part != nullptr: one partial row per workgroup for col_sum_combine_kernel (fixed order); else float atomics into a zeroed out
     __shared__ float s[256];
     const int t = threadIdx.x;
     const int c = t % cpad, rl = t / cpad, rlanes = 256 / cpad;
@@ -514,7 +515,8 @@ __global__ __launch_bounds__(256) void col_sum_scalar_kernel(const float* __rest
         if (rl == 0 && cb + c < C) {
             float tot = 0.f;
             for (int q = 0; q < rlanes; ++q) tot += s[q * cpad + c];
-            atomicAdd(out + cb + c, tot);
+            if (part) part[(int64_t)blockIdx.x * C + cb + c] = tot;
+            else atomicAdd(out + cb + c, tot);
         }
         __syncthreads();
     }
@@ -851,12 +853,20 @@ extern "C" int dsf_col_sum(const float* x, int64_t M, int C, float* out, float* 
         hipLaunchKernelGGL(col_sum_combine_kernel, dim3((C + 63) / 64), dim3(256), 0, st, workspace, wgs, C, out);
         return dsf_launch_status();
     }
-    if (dsf_zero_async(out, sizeof(float) * C, st) != hipSuccess) return DSF_ERR_LAUNCH;
     int cpad = 1;
     while (cpad < C && cpad < 256) cpad <<= 1;         // columns handled per pass (power of two <= 256)
     int64_t rows = (M + 255) / 256;
     if (rows < 64) rows = 64;
-    const int wgs = (int)((M + rows - 1) / rows);
-    hipLaunchKernelGGL(col_sum_scalar_kernel, dim3(wgs), dim3(256), 0, st, x, M, C, cpad, (int)rows, out);
+    int wgs = (int)((M + rows - 1) / rows);            // <= 256 = COLSUM_MAX_WGS partial rows
+    if (workspace) {
+        // partial rows + the fixed-order fold, as above (float atomics from the workgroups gave sums that depended on their
+        // order -- the heads' 63- and 21-channel bias gradients differed between a one-stream and a forked-stream run of config 3)
+        hipLaunchKernelGGL(col_sum_scalar_kernel, dim3(wgs), dim3(256), 0, st, x, M, C, cpad, (int)rows, out, workspace);
+        hipLaunchKernelGGL(col_sum_combine_kernel, dim3((C + 63) / 64), dim3(256), 0, st, workspace, wgs, C, out);
+        return dsf_launch_status();
+    }
+    if (dsf_deterministic()) { rows = M; wgs = 1; }    // no workspace: one workgroup walks every row in deterministic mode
+    if (dsf_zero_async(out, sizeof(float) * C, st) != hipSuccess) return DSF_ERR_LAUNCH;
+    hipLaunchKernelGGL(col_sum_scalar_kernel, dim3(wgs), dim3(256), 0, st, x, M, C, cpad, (int)rows, out, (float*)nullptr);
     return dsf_launch_status();
 }

@@ -425,7 +425,8 @@ int dsf_bn_backward(const float* x, const float* grad_y, const float* y, const f
 
 /* out[c] = sum_m x[m][c] of a row-major (M, C) matrix (bias gradient of an NHWC convolution output:
  * the `gy.sum((0,2,3))` of nn.Conv2d's backward).  workspace: dsf_col_sum_workspace_bytes(C) bytes of 16-byte
- * aligned scratch (partial rows; deterministic two-launch reduction), or NULL (single launch with float atomics). */
+ * aligned scratch (partial rows; deterministic two-launch reduction), or NULL (single launch with float atomics; ONE workgroup in
+ * deterministic mode).  Inputs of up to 2^20 elements with C % 4 == 0 take one launch with a fixed-order fold either way. */
 int64_t dsf_col_sum_workspace_bytes(int C);
 int dsf_col_sum(const float* x, int64_t M, int C, float* out, float* workspace, dsf_stream_t stream);
 

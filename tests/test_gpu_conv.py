@@ -492,7 +492,8 @@ def test_split_launch_adds_into_a_pooled_zero_output(Ci, Co, K, H, B):
     assert rc != 0
 
 
-@pytest.mark.parametrize("M,C", [(256, 128), (4096, 256), (1000, 12), (64, 256), (3, 64), (16384, 64), (5000, 128)])
+@pytest.mark.parametrize("M,C", [(256, 128), (4096, 256), (1000, 12), (64, 256), (3, 64), (16384, 64), (5000, 128), (4096, 63),
+                                 (70000, 21), (100, 7)])
 def test_bias_gradient_column_sums(M, C):
     """dsf_col_sum: per-channel sums of an (M, C) matrix -- the one-launch kernel for small inputs, the two-launch form above
     1 M elements -- against float64, and bitwise run to run (fixed-order folds)."""

@@ -161,6 +161,48 @@ def test_graphed_step_equals_the_eager_step_bitwise(render, det_mode, kind):
         assert torch.equal(a, p.grad)
 
 
+def test_forked_streams_are_invisible(render, det_mode):
+    """Config 3 issues the two arms of every hourglass level and the four loss chains behind the MANO layer on forked streams
+    (dsf_amd/streams.py).  In deterministic mode the trajectory of the eager step -- losses, every gradient, parameters, BatchNorm
+    buffers -- is BITWISE that of the single-stream run, over several steps and a change of batch, and repeated passes from one
+    state reproduce themselves (a missing stream dependency shows up as a difference here)."""
+    from dsf_amd import streams
+    from dsf_amd.model.hourglass import PoseNetMANO
+    from dsf_amd.train_step import MeshLossStep, synthetic_batch, Config
+
+    def make():
+        torch.manual_seed(0)
+        return MeshLossStep(PoseNetMANO(2, 21).cuda(), render, Config, n_points=512)
+    one, forked = make(), make()
+    tgts = []
+    for seed in (3, 8):
+        p, c, cube = synthetic_batch(4, "cuda", seed=seed)
+        tgts.append(one.make_targets(p, c, cube))
+    assert streams.ENABLED[0]
+    for t in (tgts[0], tgts[1], tgts[0]):
+        streams.ENABLED[0] = False
+        try:
+            l1, terms1 = one(t)
+        finally:
+            streams.ENABLED[0] = True
+        l2, terms2 = forked(t)
+        assert len(streams._STREAMS) >= 4                                   # the forks really happened
+        assert torch.equal(l1, l2) and all(torch.equal(terms1[k], terms2[k]) for k in terms1)
+        for (n, a), b in zip(one.net.named_parameters(), forked.net.parameters()):
+            assert (a.grad is None) == (b.grad is None) and (a.grad is None or torch.equal(a.grad, b.grad)), n
+    for (n, a), (_, b) in zip(one.net.state_dict().items(), forked.net.state_dict().items()):
+        assert torch.equal(a, b), n
+    # repeated forward + backward passes from one state: the same gradients every time
+    first = None
+    for _ in range(4):
+        forked.forward_backward(tgts[1])
+        torch.cuda.synchronize()
+        g = [q.grad.clone() for q in forked.net.parameters() if q.grad is not None]
+        if first is None:
+            first = g
+        assert all(torch.equal(a, b) for a, b in zip(first, g))
+
+
 def test_graphed_step_refuses_a_graph_with_memset_nodes(render):
     """A step holding a torch multi-block reduction (here: a one-shot global mean over a channels-last map) captures a
     hipMemsetAsync node; GraphedStep must refuse it rather than replay wrong numbers at some later step."""
