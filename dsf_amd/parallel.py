@@ -112,6 +112,7 @@ class GradAllReducer:
         self.buckets.append(list(plist))
 
     def _reset(self):
+        self._streams = [set() for _ in self.buckets]     # streams the bucket's gradients arrived on (forked chains: streams.py)
         self._arrived = [0] * len(self.buckets)
         self._flat = [None] * len(self.buckets)
         self._work = [None] * len(self.buckets)
@@ -121,6 +122,8 @@ class GradAllReducer:
         if not self.enabled:
             return
         b = self._bucket_of[p]
+        if p.is_cuda:
+            self._streams[b].add(torch.cuda.current_stream(p.device))
         self._arrived[b] += 1
         if self._arrived[b] == len(self.buckets[b]) and self._flat[b] is None:
             self._launch(b)
@@ -130,6 +133,12 @@ class GradAllReducer:
         if plist and plist[0].is_cuda:
             from . import nn_conv
             nn_conv.join_side_streams()        # weight gradients still being written on the backward-weights stream
+            # gradients of the bucket that arrived on OTHER streams (the forked arms of an hourglass level run their backward
+            # nodes, AccumulateGrad included, on their own streams): the pack below reads them on this one
+            cur = torch.cuda.current_stream(plist[0].device)
+            for st in self._streams[b]:
+                if st != cur:
+                    cur.wait_stream(st)
         missing = [p.grad is None for p in plist]
         parts = [_flat(p.grad if p.grad is not None and p.grad.stride() == p.stride() else
                        (torch.zeros_like(p) if p.grad is None else torch.empty_like(p).copy_(p.grad))) for p in plist]

@@ -13,8 +13,10 @@ so a block of its pool that is freed after the join is re-used behind everything
 next fork, and what a branch reads from the forking stream is held by the caller until the join.  Gradients that cross
 streams in the backward pass are recorded by the autograd engine itself.
 
-DSF_BRANCHES=0 keeps everything on one stream.  Off in a multi-rank process group for chains that produce parameter
-gradients (``params=True``): GradAllReducer packs a bucket on the stream its last gradient arrives on.
+DSF_BRANCHES=0 keeps everything on one stream.  In a multi-rank process group a chain that produces parameter gradients
+(``params=<module>``) forks only when every parameter of the module is managed by parallel.GradAllReducer, which notes the
+stream each gradient arrives on and orders its bucket pack behind them; any other data-parallel wrapper reads gradients on
+streams this module cannot know.
 """
 import contextlib
 import os
@@ -37,12 +39,16 @@ def _stream(device, slot):
 class fork:
     """``f = fork(x.device); with f.branch(0): a = g(x); b = h(x); f.join(); a + b``  (a no-op on the CPU or when switched off)"""
 
-    def __init__(self, device, params=False):
+    def __init__(self, device, params=None):
         device = torch.device(device)
         self.on = ENABLED[0] and device.type == "cuda"
-        if self.on and params and torch.distributed.is_available() and torch.distributed.is_initialized() \
+        if self.on and params is not None and torch.distributed.is_available() and torch.distributed.is_initialized() \
                 and torch.distributed.get_world_size() > 1:
-            self.on = False
+            ok = params.__dict__.get("_dsf_fork_ok")
+            if ok is None:                                  # decided once per module, at its first multi-rank forward
+                ok = all(bool(p.__dict__.get("_dsf_hooks_join")) for p in params.parameters() if p.requires_grad)
+                params.__dict__["_dsf_fork_ok"] = ok
+            self.on = ok
         self.device, self.used = device, []
         self.cur = torch.cuda.current_stream(device) if self.on else None
 

@@ -329,6 +329,84 @@ def test_two_rank_gradient_equals_the_single_process_gradient_of_the_whole_batch
     assert rel < 2e-2 and cos > 0.9999, (rel, cos)
 
 
+def _mesh_net_and_targets():
+    from dsf_amd.render_model.mano_layer import Render
+    from dsf_amd.model.hourglass import PoseNetMANO
+    from dsf_amd.train_step import MeshLossStep, synthetic_batch, Config
+    torch.manual_seed(0)
+    net = PoseNetMANO(1, 21).cuda()
+    render = Render("synthetic", "nyu", (588.03, 587.07, 320.0, 240.0), (640, 480)).cuda()
+    return net, render, MeshLossStep, synthetic_batch, Config
+
+
+def _mesh_worker(rank, world, port, q):
+    """config 3's step (hourglass arms and loss chains on forked streams) under GradAllReducer, deterministic mode; both ranks
+    hold the SAME batch, so the averaged gradient must be the single-process gradient of that batch bit for bit"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from dsf_amd.parallel import init_distributed, GradAllReducer
+    from dsf_amd import _lib as L, streams
+    init_distributed("gloo")
+    torch.cuda.set_device(0)
+    L.set_deterministic(True)
+    net, render, MeshLossStep, synthetic_batch, Config = _mesh_net_and_targets()
+    sync = GradAllReducer(net.parameters(), bucket_bytes=1 << 20)          # several buckets, so that some are packed mid-backward
+    step = MeshLossStep(net, render, Config, grad_sync=sync, n_points=512)
+    p, c, cube = synthetic_batch(4, "cuda", seed=50)
+    tgt = step.make_targets(p, c, cube, seed=51)
+    outs = []
+    for _ in range(3):                                                     # repeated passes: a missing stream dependency is a race
+        loss, _ = step.forward_backward(tgt)
+        sync.finish()
+        torch.cuda.synchronize()
+        outs.append(torch.cat([pp.grad.detach().reshape(-1).float().cpu() if pp.grad is not None else torch.zeros(pp.numel())
+                               for pp in net.parameters()]).numpy())
+    forked = bool(net.body.hgs[0].__dict__.get("_dsf_fork_ok")) and len(streams._STREAMS) >= 4 and len(sync.buckets) >= 3
+    q.put((rank, outs, float(loss), forked))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@_shared_gpu_retry()
+def test_forked_streams_under_gradient_all_reduce():
+    """The hourglass arms fork under data parallelism only because GradAllReducer notes the stream each gradient arrives on and
+    orders its bucket pack behind them: two ranks on the same batch must hold, after the all-reduce, bitwise the gradient one
+    process computes for that batch on ONE stream -- on every one of three passes."""
+    import torch.multiprocessing as mp
+    from dsf_amd import _lib as L, streams
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_mesh_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    old = L.set_deterministic(True)
+    was = streams.ENABLED[0]
+    streams.ENABLED[0] = False
+    try:
+        net, render, MeshLossStep, synthetic_batch, Config = _mesh_net_and_targets()
+        step = MeshLossStep(net, render, Config, n_points=512)
+        p, c, cube = synthetic_batch(4, "cuda", seed=50)
+        loss, _ = step.forward_backward(step.make_targets(p, c, cube, seed=51))
+        torch.cuda.synchronize()
+    finally:
+        streams.ENABLED[0] = was
+        L.set_deterministic(old)
+    ref = torch.cat([pp.grad.detach().reshape(-1).float().cpu() if pp.grad is not None else torch.zeros(pp.numel())
+                     for pp in net.parameters()]).numpy()
+    assert np.abs(ref).max() > 0
+    for rank, outs, l, forked in res:
+        assert forked, "the worker did not fork (or had a single bucket)"
+        assert abs(l - float(loss)) <= 1e-6 * abs(float(loss))
+        for i, g in enumerate(outs):
+            # (g / 2 + g / 2 is g itself except where halving underflows)
+            assert float(np.abs(g - ref).max()) < 1e-30, (rank, i, float(np.abs(g - ref).max()))
+
+
 def test_zz_retries_stayed_rare():
     """runs last in this file: the repeats _shared_gpu_retry allowed are counted, and more than one test needing one is a failure
     (a race in the reducer / stream ordering would show up across tests, the platform's corruption was seen in ~1 run of 3)"""
