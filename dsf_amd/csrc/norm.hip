@@ -399,6 +399,171 @@ __global__ __launch_bounds__(256, 6) void bn_bwd_apply_kernel(const float* __res
     }
 }
 
+// ---- small maps: statistics AND apply in one launch -------------------------------------------------------------------------
+// On the 4 x 4 and 2 x 2 levels of an hourglass (M = B H W <= 1024 rows) a launch costs more than the pass: the reduce + apply
+// pair is 12 us of which a few are work, and it sits on the step's critical chain 36 times per direction (config 3).  Here ONE
+// workgroup owns a channel quad (one float4 column): its 256 threads hold the column's rows in registers (R = 1 or 4 float4 each,
+// M <= 256 R), fold the two sums in double through shuffles and LDS -- a fixed order: the kernels serve the deterministic mode too
+// -- and apply from the registers.  The arithmetic per element is the two-launch path's, operation for operation; the sums differ
+// from it in summation order only.
+__device__ __forceinline__ void bn_small_fold(double (&v)[8], double* s_red) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o, 64);
+    }
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s_red[wave * 8 + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (s_red[k] + s_red[8 + k]) + (s_red[16 + k] + s_red[24 + k]);
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, int M,
+                                                           int C, int relu, float* __restrict__ y, BnFinal fin) {
+    __shared__ double s_red[32];
+    const int t = threadIdx.x, C4 = C >> 2, c4 = blockIdx.x, c = c4 * 4;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 xv[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        const int r = t + u * 256;
+        xv[u] = z4;                                                       // (not a select: it would pick between POINTERS, with z4 in scratch)
+        if (r < M) xv[u] = reinterpret_cast<const float4*>(x)[(int64_t)r * C4 + c4];
+    }
+    float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        const float xe[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a0[k] += xe[k]; a1[k] = fmaf(xe[k], xe[k], a1[k]); }
+    }
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = (double)a0[k]; v[4 + k] = (double)a1[k]; }
+    bn_small_fold(v, s_red);
+    float par[3][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double m = v[k] / (double)M;
+        double var = v[4 + k] / (double)M - m * m;
+        if (var < 0.0) var = 0.0;
+        const float is = (float)(1.0 / sqrt(var + (double)fin.eps));
+        par[0][k] = (float)m;
+        par[1][k] = is * (gamma ? gamma[c + k] : 1.f);
+        par[2][k] = beta ? beta[c + k] : 0.f;
+        if (t == 0 && fin.mean) {
+            fin.mean[c + k] = (float)m;
+            fin.invstd[c + k] = is;
+            if (fin.running_mean) {
+                const double unbiased = (M > 1) ? var * (double)M / (double)(M - 1) : var;
+                fin.running_mean[c + k] = (1.f - fin.momentum) * fin.running_mean[c + k] + fin.momentum * (float)m;
+                fin.running_var[c + k] = (1.f - fin.momentum) * fin.running_var[c + k] + fin.momentum * (float)unbiased;
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        const int r = t + u * 256;
+        if (r < M) {
+            const int64_t j = (int64_t)r * C4 + c4;
+            const float xe[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = (xe[k] - par[0][k]) * par[1][k] + par[2][k];
+            if (res) { const float4 rv = reinterpret_cast<const float4*>(res)[j]; o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w; }
+            if (relu) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = fmaxf(o[k], 0.f);
+            }
+            reinterpret_cast<float4*>(y)[j] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                           const float* __restrict__ y, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int M, int C, int relu,
+                                                           float* __restrict__ dx, float* __restrict__ dres, BnFinal fin) {
+    __shared__ double s_red[32];
+    const int t = threadIdx.x, C4 = C >> 2, c4 = blockIdx.x, c = c4 * 4;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float mu[4], is[4], sc[4], sh[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        mu[k] = mean[c + k]; is[k] = invstd[c + k];
+        sc[k] = is[k] * (gamma ? gamma[c + k] : 1.f);
+        sh[k] = beta ? beta[c + k] : 0.f;
+    }
+    float4 xv[R], gv[R];
+    float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        const int r = t + u * 256;
+        const bool ok = r < M;
+        const int64_t j = (int64_t)(ok ? r : 0) * C4 + c4;
+        xv[u] = ok ? reinterpret_cast<const float4*>(x)[j] : z4;
+        gv[u] = ok ? reinterpret_cast<const float4*>(gy)[j] : z4;
+        const float xe[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+        float ge[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+        if (relu == 1) {
+            const float4 yv = ok ? reinterpret_cast<const float4*>(y)[j] : z4;
+            const float ye[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ge[k] = (ye[k] > 0.f) ? ge[k] : 0.f;
+        } else if (relu == 2) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ge[k] = ((xe[k] - mu[k]) * sc[k] + sh[k] > 0.f) ? ge[k] : 0.f;
+        }
+        gv[u] = make_float4(ge[0], ge[1], ge[2], ge[3]);                  // (the masked gradient: what both passes use)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a0[k] += ge[k]; a1[k] = fmaf(ge[k], (xe[k] - mu[k]) * is[k], a1[k]); }
+    }
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = (double)a0[k]; v[4 + k] = (double)a1[k]; }
+    bn_small_fold(v, s_red);
+    float m0[4], m1[4];
+    const float invM = 1.0f / (float)M;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (t == 0) {
+            if (fin.dbeta) fin.dbeta[c + k] = (float)v[k];
+            if (fin.dgamma) fin.dgamma[c + k] = (float)v[4 + k];
+        }
+        m0[k] = (float)v[k] * invM; m1[k] = (float)v[4 + k] * invM;
+    }
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        const int r = t + u * 256;
+        if (r < M) {
+            const int64_t j = (int64_t)r * C4 + c4;
+            const float xe[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+            const float ge[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float xh = (xe[k] - mu[k]) * is[k];
+                o[k] = sc[k] * (ge[k] - m0[k] - xh * m1[k]);
+            }
+            reinterpret_cast<float4*>(dx)[j] = make_float4(o[0], o[1], o[2], o[3]);
+            if (dres) reinterpret_cast<float4*>(dres)[j] = gv[u];
+        }
+    }
+}
+
+constexpr int BN_SMALL_MAX_ROWS = 1024;      // (16 float4 per thread, M <= 4096, was built and measured: 19-30 us forward, 37-49 backward against ~12 for the pair --
+                                             //  a thread per ROW of a 1-4 MB column block is an uncoalesced walk; 4 per thread breaks even, 1 per thread halves the time)
+static const int bn_small_on = [] { const char* e = getenv("DSF_BN_SMALL"); return e ? atoi(e) : 1; }();     // tuning aid
+inline bool bn_small_ok(int64_t M, int C) { return bn_small_on && M <= BN_SMALL_MAX_ROWS && C >= 4 && (C & 3) == 0; }
+
 // Per-channel sums of an (M rows, C channels) row-major matrix (bias gradients of NHWC activations).
 // Each lane owns one float4 column group, the 256 / (C/4) row-lanes of a workgroup walk rows_per_wg rows with 8
 // independent 16-byte loads in flight per lane; row-lanes fold through LDS and the workgroup writes one partial row
@@ -549,6 +714,20 @@ inline int bn_apply_grid(int64_t n4, int C) {
 // partials.  No state survives a call.
 inline float* bn_ws_part(double* ws, int C) { return reinterpret_cast<float*>(ws + 2 * C); }
 
+inline void bn_small_forward(const float* x, const float* residual, const float* gamma, const float* beta, int64_t M, int C, int relu,
+                             float* y, const BnFinal& fin, hipStream_t st) {
+    const dim3 grid(C >> 2);
+    if (M <= 256) hipLaunchKernelGGL(bn_small_fwd_kernel<1>, grid, dim3(256), 0, st, x, residual, gamma, beta, (int)M, C, relu, y, fin);
+    else hipLaunchKernelGGL(bn_small_fwd_kernel<4>, grid, dim3(256), 0, st, x, residual, gamma, beta, (int)M, C, relu, y, fin);
+}
+inline void bn_small_backward(const float* x, const float* grad_y, const float* y, const float* save_mean, const float* save_invstd,
+                              const float* gamma, const float* beta, int64_t M, int C, int relu, float* grad_x, float* grad_residual,
+                              const BnFinal& fin, hipStream_t st) {
+    const dim3 grid(C >> 2);
+    if (M <= 256) hipLaunchKernelGGL(bn_small_bwd_kernel<1>, grid, dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd, gamma, beta, (int)M, C, relu, grad_x, grad_residual, fin);
+    else hipLaunchKernelGGL(bn_small_bwd_kernel<4>, grid, dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd, gamma, beta, (int)M, C, relu, grad_x, grad_residual, fin);
+}
+
 }  // namespace
 
 extern "C" int64_t dsf_bn_workspace_bytes(int C) {
@@ -561,6 +740,11 @@ extern "C" int dsf_bn_forward(const float* x, const float* residual, const float
     DSF_CHECK_ARG(x && y && save_mean && save_invstd && workspace && M > 0);
     if (!bn_shape_ok(C)) return DSF_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
+    if (bn_small_ok(M, C)) {                                         // small maps: one launch, fixed-order sums
+        BnFinal fin = {eps, momentum, save_mean, save_invstd, running_mean, running_var, nullptr, nullptr, nullptr};
+        bn_small_forward(x, residual, gamma, beta, M, C, relu, y, fin, st);
+        return dsf_launch_status();
+    }
     const int rows = bn_rows_per_wg(M, C);
     const int wgs = (int)((M + rows - 1) / rows);
     BnFinal fin = {eps, momentum, save_mean, save_invstd, running_mean, running_var, nullptr, nullptr, nullptr};
@@ -614,6 +798,10 @@ extern "C" int dsf_bn_backward(const float* x, const float* grad_y, const float*
     const int rows = bn_rows_per_wg(M, C);
     const int wgs = (int)((M + rows - 1) / rows);
     BnFinal fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, workspace, grad_gamma, grad_beta};
+    if (bn_small_ok(M, C)) {
+        bn_small_backward(x, grad_y, y, save_mean, save_invstd, gamma, beta, M, C, relu, grad_x, grad_residual, fin, st);
+        return dsf_launch_status();
+    }
     if (relu == 1) {
         hipLaunchKernelGGL((bn_reduce_kernel<1, true>), dim3(wgs, bn_col_blocks(C)), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd, gamma, beta, M, C,
                            relu, rows, bn_ws_part(workspace, C), 0);
@@ -647,6 +835,10 @@ extern "C" int dsf_bn_forward_acc(const float* x, const float* residual, const f
     if (!bn_shape_ok(C) || dsf_deterministic()) return DSF_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     BnFinal fin = {eps, momentum, save_mean, save_invstd, running_mean, running_var, nullptr, nullptr, nullptr};
+    if (!acc_filled && bn_small_ok(M, C)) {                          // statistics + apply in one launch (`acc` stays untouched)
+        bn_small_forward(x, residual, gamma, beta, M, C, relu, y, fin, st);
+        return dsf_launch_status();
+    }
     if (!acc_filled) {
         const int rows = bn_rows_per_wg(M, C, BN_ACC_WGS);
         const int wgs = (int)((M + rows - 1) / rows);
@@ -668,6 +860,10 @@ extern "C" int dsf_bn_backward_acc(const float* x, const float* grad_y, const fl
     const int rows = bn_rows_per_wg(M, C, BN_ACC_WGS);
     const int wgs = (int)((M + rows - 1) / rows);
     BnFinal fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, grad_gamma, grad_beta};
+    if (bn_small_ok(M, C)) {                                         // both sums + apply in one launch (`acc` stays untouched)
+        bn_small_backward(x, grad_y, y, save_mean, save_invstd, gamma, beta, M, C, relu, grad_x, grad_residual, fin, st);
+        return dsf_launch_status();
+    }
     if (relu == 1) {
         hipLaunchKernelGGL((bn_reduce_kernel<1, true>), dim3(wgs, bn_col_blocks(C)), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd, gamma, beta,
                            M, C, relu, rows, reinterpret_cast<float*>(acc), BN_ACC_ROWS);

@@ -93,11 +93,27 @@ def test_fused_batchnorm_matches_torch_cpu(C, H, res, relu, acc):
     assert nn_norm._ACC_POOL is None
 
 
-def _bn_case(C, H, res, relu, FusedBatchNorm2d):
+@pytest.mark.parametrize("acc", [False, True])
+@pytest.mark.parametrize("M,C,res,relu", [(255, 64, True, True), (256, 4, False, True), (257, 64, True, False), (1024, 128, False, True),
+                                          (1025, 8, True, True), (600, 256, True, True), (17, 2048, False, False)])
+def test_small_map_batchnorm_one_launch(M, C, res, relu, acc):
+    """Maps of up to 1024 rows take ONE launch per pass (a workgroup per channel quad holds the column in registers: 1 or 4 float4
+    per thread): the boundaries of the two instantiations and the first size beyond them, against torch CPU."""
+    from dsf_amd import nn_norm, _lib as L
+    from dsf_amd.nn_norm import FusedBatchNorm2d
+    import contextlib
+    if acc and L.deterministic():
+        pytest.skip("deterministic mode keeps the ordered-partials path")
+    with (nn_norm.stat_pool(2 * nn_norm.acc_rows() * 2 * C, "cuda") if acc else contextlib.nullcontext()):
+        _bn_case(C, M, res, relu, FusedBatchNorm2d, shape=(1, C, 1, M))
+
+
+def _bn_case(C, H, res, relu, FusedBatchNorm2d, shape=None):
     g = torch.Generator().manual_seed(C + H)
     B = 6
-    x = (torch.randn(B, C, H, H, generator=g) * 2 + 0.5).requires_grad_(True)
-    r = torch.randn(B, C, H, H, generator=g).requires_grad_(True) if res else None
+    shape = shape or (B, C, H, H)
+    x = (torch.randn(shape, generator=g) * 2 + 0.5).requires_grad_(True)
+    r = torch.randn(shape, generator=g).requires_grad_(True) if res else None
     ref = torch.nn.BatchNorm2d(C, momentum=0.1)
     with torch.no_grad():
         ref.weight.copy_(torch.randn(C, generator=g)); ref.bias.copy_(torch.randn(C, generator=g))
