@@ -407,6 +407,8 @@ int dsf_conv_x6_wrw(const float* X, const float* dY, float* dW, int B, int Hi, i
  * workspace: dsf_bn_workspace_bytes(C) bytes, 8-byte aligned scratch; one buffer can serve every layer of a stream
  * because calls on a stream are ordered.  The reduction is deterministic (fixed partials, fixed order, double combine).
  * running_mean / running_var (may be NULL) are updated in place with `momentum` (unbiased variance).
+ * Maps of up to 1024 rows (M) take ONE launch per pass on every BatchNorm entry point of this header -- a workgroup per channel
+ * quad holds its column in registers; fixed-order sums, the workspace / accumulation rows stay untouched (DSF_BN_SMALL=0: off).
  * ---------------------------------------------------------------------------------- */
 int64_t dsf_bn_workspace_bytes(int C);
 int dsf_bn_forward(const float* x, const float* residual, const float* gamma, const float* beta, int64_t M,
