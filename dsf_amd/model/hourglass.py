@@ -77,7 +77,7 @@ class Hourglass(nn.Module):
         # maps a quarter of that size and smaller (8 x 8 ... 2 x 2: 32 ... 2 tiles for 256 CUs) -- a stream per level for ``up1``, so
         # that the chain of small launches runs beside the large ones instead of between them (streams.py; config 3 +5 %)
         f = fork(x.device, params=self)
-        with f.branch(self.n):
+        with f.branch(self.n, x):
             up = self.up1(x)
         low = self.up2(self.low3(self.low2(self.low1(self.pool1(x)))))
         f.join()

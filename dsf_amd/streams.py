@@ -7,11 +7,14 @@ the arms are issued on different streams -- ``fork(device)`` hands out branch st
 backward node on the stream of its forward and orders the streams itself, and a captured HIP graph (train_step.GraphedStep)
 keeps the fork as independent dependency chains.
 
-Allocator safety without Tensor.record_stream (whose event-deferred frees made the caching allocator fall back to hipMalloc,
-nn_conv._on_side_stream): a branch stream only ever works between a fork (``wait_stream(current)``) and the join that follows,
-so a block of its pool that is freed after the join is re-used behind everything the forking stream had queued by the
-next fork, and what a branch reads from the forking stream is held by the caller until the join.  Gradients that cross
-streams in the backward pass are recorded by the autograd engine itself.
+Allocator safety: a branch stream only ever works between a fork (``wait_stream(current)``) and the join that follows, so a
+block of ITS pool that is freed after the join is re-used behind everything the forking stream had queued by the next fork.
+What a branch READS from the forking stream is named in ``branch(slot, *reads)`` and recorded on the branch stream
+(``Tensor.record_stream``: a handful of tensors per step -- per layer, as nn_conv._on_side_stream would have needed it, its
+event-deferred frees made the caching allocator fall back to hipMalloc): autograd saves such a tensor for a backward node that
+runs on the branch stream and drops it as soon as that node has been ISSUED, and without the record its block would go straight
+back to the forking stream's pool while the node's kernel may still be reading it.  Gradients that cross streams in the backward
+pass are recorded by the autograd engine itself.
 
 DSF_BRANCHES=0 keeps everything on one stream.  In a multi-rank process group a chain that produces parameter gradients
 (``params=<module>``) forks only when every parameter of the module is managed by parallel.GradAllReducer, which notes the
@@ -37,7 +40,7 @@ def _stream(device, slot):
 
 
 class fork:
-    """``f = fork(x.device); with f.branch(0): a = g(x); b = h(x); f.join(); a + b``  (a no-op on the CPU or when switched off)"""
+    """``f = fork(x.device); with f.branch(0, x): a = g(x); b = h(x); f.join(); a + b``  (a no-op on the CPU or when switched off)"""
 
     def __init__(self, device, params=None):
         device = torch.device(device)
@@ -52,13 +55,16 @@ class fork:
         self.device, self.used = device, []
         self.cur = torch.cuda.current_stream(device) if self.on else None
 
-    def branch(self, slot):
+    def branch(self, slot, *reads):
         if not self.on:
             return contextlib.nullcontext()
         s = _stream(self.device, slot)
         if s not in self.used:
             s.wait_stream(self.cur)
             self.used.append(s)
+        for t in reads:
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(s)
         return torch.cuda.stream(s)
 
     def join(self):

@@ -197,12 +197,12 @@ class MeshLossStep:
         # four independent chains behind the MANO layer (streams.py): the point-to-triangle search fills the chip, the others
         # are a few short launches each -- beside it instead of behind it, forward and backward
         f = fork(mesh.device)
-        with f.branch(0):
+        with f.branch(0, img_pd):
             crop_pd = self.utils.crop_hand(img_pd, tgt["joint_xyz"], tgt["center"], tgt["M"], tgt["cube"])
             l_m2d = m2d_loss(tgt["crop"], crop_pd) * cfg.model_weight
-        with f.branch(1):
+        with f.branch(1, mesh):
             l_part = JointICPLoss(mesh, tgt["joint_pcl"], mano_layer.joint_faces, tgt["seg"]).mean(-1).mean(-1) * cfg.partICP_weight
-        with f.branch(2):
+        with f.branch(2, mesh, jxyz):
             l_coll = mano_layer.calculate_coll(jxyz, mesh.detach()) * cfg.coll_weight
             l_sup = (self.L1(jxyz, tgt["joint_xyz"]) + self.L1(mesh, tgt["mesh_xyz"])) * cfg.coord_weight
         l_icp = ICPLoss(mesh, tgt["pcl"], mano_layer.faces).mean(-1) * cfg.model_weight
@@ -385,15 +385,9 @@ class GraphedStep:
 
     def __call__(self, tgt=None):
         if tgt is not None and tgt is not self.static:
-            # the new batch into the captured step's input buffers: ONE multi-tensor launch per dtype pair (a copy_ each was ten
-            # launch-bound copies, 100-160 us, in front of every replay of config 3)
-            pairs = [(self.static[k], v) for k, v in tgt.items() if torch.is_tensor(v) and v is not self.static[k]]
-            same = [(d, s) for d, s in pairs if d.dtype == s.dtype and d.device == s.device and d.shape == s.shape]
-            if same:
-                torch._foreach_copy_([d for d, _ in same], [s for _, s in same], non_blocking=True)
-            for d, s in pairs:
-                if not (d.dtype == s.dtype and d.device == s.device and d.shape == s.shape):
-                    d.copy_(s, non_blocking=True)
+            for k, v in tgt.items():
+                if torch.is_tensor(v):
+                    self.static[k].copy_(v, non_blocking=True)
         self.graph.replay()
         for m, n in zip(self._bns, self._bn_calls):
             m._pending_batches += n
