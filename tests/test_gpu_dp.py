@@ -234,19 +234,20 @@ def test_graphed_step_with_gradient_all_reduce_equals_the_eager_data_parallel_st
     assert np.array_equal(e0, g0)                                   # deterministic mode: the graphed trajectory IS the eager one
 
 
-@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("graph,config", [(False, 2), (True, 2), (True, 3)])
 @_shared_gpu_retry()
-def test_bench_two_ranks_on_one_gpu_flow(graph):
+def test_bench_two_ranks_on_one_gpu_flow(graph, config):
     """`bench.py --gpus 2` under torch.distributed.run, both ranks on the one GPU of the test box (gloo transport): the ranks time
     the step together, leave the process group together, rank 0 alone runs its diagnostics and prints ONE JSON line with
-    n_gpus 2; with --graph the forward + backward pass is replayed from a HIP graph and the bucket all-reduces follow it."""
+    n_gpus 2; with --graph the forward + backward pass is replayed from a HIP graph and the bucket all-reduces follow it.  Config 3:
+    the hourglass step, whose graph holds the forked arms (they fork under GradAllReducer: all parameters are managed by it)."""
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, DSF_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--batch", "4", "--no-cpu-baseline"] + (["--graph"] if graph else [])
+           "--batch", "4", "--no-cpu-baseline", "--config", str(config)] + (["--graph"] if graph else [])
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
