@@ -17,6 +17,9 @@ from .resnet import BasicBlock, Bottleneck
 from .. import nn_conv
 from ..nn_norm import FusedBatchNorm2d, ConvBN
 from ..util.generateFeature import joint2offset, offset2joint_softmax
+from ..streams import fork
+
+_BRIDGE_FORK = [os.environ.get("DSF_BRIDGE_FORK", "1") == "1"]
 
 BN_MOMENTUM = 0.1
 resnet = {18: (BasicBlock, [2, 2, 2, 2]), 50: (Bottleneck, [3, 4, 6, 3]), 101: (Bottleneck, [3, 4, 23, 3]),
@@ -165,12 +168,27 @@ class MANO_OCR_stage(_TwoBranchNet):
 
     def forward(self, img, render=None, center=None, cube=None, M=None):
         c0 = self.pre(img)
-        _, feat, pix, mano = self._run_trunk(c0, '')
         if not self.refine:
+            _, feat, pix, mano = self._run_trunk(c0, '')
             return [[pix, mano]]
-        # stage-2 bridge: render the stage-1 MANO estimate, re-encode it as an offset map (HIP kernels)
-        mano_img, mano_uvd, _, _ = render.render(mano, center, cube)
-        remap = joint2offset(mano_uvd, mano_img, 0.8, 64)
+        if _BRIDGE_FORK[0]:
+            # the stage-2 bridge (MANO head -> MANO layer -> rasteriser -> offset map: a chain of short, latency-bound launches,
+            # forward and backward) needs only c4; the decoder (three transposed convolutions + heads: large launches) needs
+            # nothing of it until the stage-2 `cat` -- beside each other on forked streams (streams.py)
+            c4 = self.layer4(self.layer3(self.layer2(self.layer1(c0))))
+            f = fork(c4.device, params=self)
+            with f.branch(0, c4):
+                mano = self.mano_regress(c4)
+                mano_img, mano_uvd, _, _ = render.render(mano, center, cube)
+                remap = joint2offset(mano_uvd, mano_img, 0.8, 64)
+            feat = self.deconv_layer2(self.deconv_layer3(self.deconv_layer4(c4)))
+            pix = nn_conv.fused_heads(feat, self.finals)
+            f.join()
+        else:
+            _, feat, pix, mano = self._run_trunk(c0, '')
+            # stage-2 bridge: render the stage-1 MANO estimate, re-encode it as an offset map (HIP kernels)
+            mano_img, mano_uvd, _, _ = render.render(mano, center, cube)
+            remap = joint2offset(mano_uvd, mano_img, 0.8, 64)
         _, _, pix2, mano2 = self._run_trunk(self.fusion(torch.cat((c0, feat, pix, remap), dim=1)), '_s2')
         return [[pix, mano], [pix2, mano2]]
 

@@ -5,6 +5,9 @@ import torch.nn as nn
 
 from ..nn_conv import Conv2d as _HipConv2d
 from ..nn_norm import FusedBatchNorm2d, conv_bn_act
+from ..streams import fork
+import os
+_DS_FORK = [os.environ.get("DSF_DS_FORK", "1") == "1"]
 
 _CONV = [_HipConv2d]      # layer factory of the network under construction (set by model/backbone.py::_Layers)
 _FUSED_BN = [False]       # fused BN+add+ReLU kernels (see model/backbone.py::_Layers)
@@ -32,6 +35,13 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        if self.downsample is not None and _DS_FORK[0]:
+            f = fork(x.device, params=self)
+            with f.branch(0, x):
+                identity = self.downsample(x)
+            y = conv_bn_act(self.conv1, self.bn1, x, relu=True)
+            f.join()
+            return conv_bn_act(self.conv2, self.bn2, y, residual=identity, relu=True)
         y = conv_bn_act(self.conv1, self.bn1, x, relu=True)                       # (BN statistics from the conv epilogue)
         identity = x if self.downsample is None else self.downsample(x)
         return conv_bn_act(self.conv2, self.bn2, y, residual=identity, relu=True)    # bn + skip + relu in one pass
@@ -53,6 +63,14 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        if self.downsample is not None and _DS_FORK[0]:
+            f = fork(x.device, params=self)
+            with f.branch(0, x):
+                identity = self.downsample(x)
+            y = conv_bn_act(self.conv1, self.bn1, x, relu=True)
+            y = conv_bn_act(self.conv2, self.bn2, y, relu=True)
+            f.join()
+            return conv_bn_act(self.conv3, self.bn3, y, residual=identity, relu=True)
         y = conv_bn_act(self.conv1, self.bn1, x, relu=True)
         y = conv_bn_act(self.conv2, self.bn2, y, relu=True)
         identity = x if self.downsample is None else self.downsample(x)

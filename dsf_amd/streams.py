@@ -16,6 +16,10 @@ runs on the branch stream and drops it as soon as that node has been ISSUED, and
 back to the forking stream's pool while the node's kernel may still be reading it.  Gradients that cross streams in the backward
 pass are recorded by the autograd engine itself.
 
+Eager steps keep to ONE branch stream (slot 0) beside the current one and the weight-gradient stream: HIP maps streams onto
+GPU_MAX_HW_QUEUES = 4 hardware queues, and with five streams two of them shared a queue in some runs -- config 2 then ran
+whole benchmark runs at 20.2-20.9 ms instead of 18.9-19.4 (2 of 8 runs; 0 of 8 with one branch stream).  A replayed HIP graph has
+its own queue assignment: the hourglass levels and the loss chains of config 3 use a stream each.
 DSF_BRANCHES=0 keeps everything on one stream.  In a multi-rank process group a chain that produces parameter gradients
 (``params=<module>``) forks only when every parameter of the module is managed by parallel.GradAllReducer, which notes the
 stream each gradient arrives on and orders its bucket pack behind them; any other data-parallel wrapper reads gradients on
@@ -37,6 +41,17 @@ def _stream(device, slot):
     if s is None:
         s = _STREAMS[key] = torch.cuda.Stream(device=device)
     return s
+
+
+class disabled:
+    """``with streams.disabled():`` keeps everything inside on one stream (a step whose chains do not pay: measured per step class)"""
+
+    def __enter__(self):
+        self.was, ENABLED[0] = ENABLED[0], False
+        return self
+
+    def __exit__(self, *a):
+        ENABLED[0] = self.was
 
 
 class fork:

@@ -16,6 +16,7 @@ from . import ops
 from .metric.losses import SmoothL1Loss
 from .metric.meshLoss import ICPLoss, JointICPLoss
 from .render_model.render_loss import m2d_loss
+from . import streams
 from .streams import fork
 from .util.generateFeature import GFM
 from .data.render_loader import loader as TensorUtils
@@ -111,22 +112,30 @@ class RenderSupervisedStep:
         img, center, cube = tgt["img"], tgt["center"], tgt["cube"]
         outputs = self.net(img, self.render, center, cube)
         terms = {}
-        for s, (pixel_pd, mano_pd) in enumerate(outputs):
+        # the model branch (MANO layer, rasteriser: short latency-bound launches, forward and backward) beside the pixel branch:
+        # the decoder's backward pass only waits for the pixel terms (streams.py)
+        f = fork(img.device)
+        with f.branch(0, *[mano_pd for _, mano_pd in outputs]):
+            for s, (_, mano_pd) in enumerate(outputs):
+                # model branch (:459-466)
+                jxyz_pd, mesh_pd = self.render.get_mesh_xyz(mano_pd)
+                terms["joint%d" % s] = self.L1(jxyz_pd, tgt["joint_xyz"], weight=cfg.coord_weight)
+                terms["vert%d" % s] = self.L1(mesh_pd, tgt["mesh_xyz"], weight=cfg.coord_weight)
+                terms["beta%d" % s] = torch.mean(torch.pow(mano_pd[:, 48:58], 2)) * (cfg.coord_weight * 10)
+                terms["scale%d" % s] = torch.mean(torch.abs(torch.clamp(mano_pd[:, 58], max=0.0))) * 0.1
+            # render loss on the final estimate (:719, :728-732, :745)
+            img_pd, _, _, _ = self.render.render(outputs[-1][1], center, cube)
+            terms["m2d"] = m2d_loss(img, img_pd) * cfg.model_weight
+        for s, (pixel_pd, _) in enumerate(outputs):
             S = pixel_pd.size(-1)
             # pixel-wise branch (:451-456); loss weights are folded into the fused Huber kernels
             pixel_gt = self.gfm.joint2feature(tgt["joint_uvd"], img, cfg.feature_para, S, cfg.feature_type)
             juvd_pd = self.gfm.feature2joint(img, pixel_pd, cfg.feature_type, cfg.feature_para)
             terms["pix%d" % s] = self.L1(pixel_pd, pixel_gt, weight=cfg.deconv_weight)
             terms["coord%d" % s] = self.L1(juvd_pd, tgt["joint_uvd"], weight=cfg.coord_weight)
-            # model branch (:459-466)
-            jxyz_pd, mesh_pd = self.render.get_mesh_xyz(mano_pd)
-            terms["joint%d" % s] = self.L1(jxyz_pd, tgt["joint_xyz"], weight=cfg.coord_weight)
-            terms["vert%d" % s] = self.L1(mesh_pd, tgt["mesh_xyz"], weight=cfg.coord_weight)
-            terms["beta%d" % s] = torch.mean(torch.pow(mano_pd[:, 48:58], 2)) * (cfg.coord_weight * 10)
-            terms["scale%d" % s] = torch.mean(torch.abs(torch.clamp(mano_pd[:, 58], max=0.0))) * 0.1
-        # render loss on the final estimate (:719, :728-732, :745)
-        img_pd, _, _, _ = self.render.render(outputs[-1][1], center, cube)
-        terms["m2d"] = m2d_loss(img, img_pd) * cfg.model_weight
+        f.join()
+        order = [k % s for s in range(len(outputs)) for k in ("pix%d", "coord%d", "joint%d", "vert%d", "beta%d", "scale%d")] + ["m2d"]
+        terms = {k: terms[k] for k in order}                 # (the reference's order: the sum below is order-sensitive in its last bits)
         # one stack + one sum instead of a chain of scalar adds (and their backward kernels)
         return torch.stack(list(terms.values())).sum(), terms
 
@@ -703,7 +712,9 @@ class FinetuneStageStep(_StepBase):
 
     def __call__(self, model_para, cube, img_r, center_r, cube_r, M_r, generator=None, draws=None):
         self._begin()
-        with _stat_pool(self, self.net, applications=2):     # the network sees the synthetic and the real batch
+        # (the forked chains of the network -- downsample arms, stage-2 bridge -- do not pay in this step, whose network runs twice per
+        #  pass beside the frozen generator: 87.3 ms with them off, 88.0 on, three alternating runs each)
+        with _stat_pool(self, self.net, applications=2), streams.disabled():     # the network sees the synthetic and the real batch
             loss, terms = self.loss(model_para, cube, img_r, center_r, cube_r, M_r, generator, draws)
             self._optimise(loss)
         return loss.detach(), terms

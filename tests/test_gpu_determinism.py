@@ -161,18 +161,28 @@ def test_graphed_step_equals_the_eager_step_bitwise(render, det_mode, kind):
         assert torch.equal(a, p.grad)
 
 
-def test_forked_streams_are_invisible(render, det_mode):
+@pytest.mark.parametrize("kind", ["config3", "config2", "config2_r50"])
+def test_forked_streams_are_invisible(render, det_mode, kind):
     """Config 3 issues the two arms of every hourglass level and the four loss chains behind the MANO layer on forked streams
-    (dsf_amd/streams.py).  In deterministic mode the trajectory of the eager step -- losses, every gradient, parameters, BatchNorm
-    buffers -- is BITWISE that of the single-stream run, over several steps and a change of batch, and repeated passes from one
-    state reproduce themselves (a missing stream dependency shows up as a difference here)."""
+    (dsf_amd/streams.py); the two-stage ResNet step its downsample arms, the stage-2 bridge (MANO head -> MANO layer -> rasteriser
+    -> offset map) beside the decoder, and the model branch of the loss beside the pixel branch.  In deterministic mode the
+    trajectory of the eager step -- losses, every gradient, parameters, BatchNorm buffers -- is BITWISE that of the single-stream
+    run, over several steps and a change of batch, and repeated passes from one state reproduce themselves (a missing stream
+    dependency shows up as a difference here)."""
     from dsf_amd import streams
     from dsf_amd.model.hourglass import PoseNetMANO
-    from dsf_amd.train_step import MeshLossStep, synthetic_batch, Config
+    from dsf_amd.model.backbone import MANO_OCR_stage
+    from dsf_amd.train_step import MeshLossStep, RenderSupervisedStep, synthetic_batch, Config
 
     def make():
         torch.manual_seed(0)
-        return MeshLossStep(PoseNetMANO(2, 21).cuda(), render, Config, n_points=512)
+        if kind == "config3":
+            return MeshLossStep(PoseNetMANO(2, 21).cuda(), render, Config, n_points=512)
+        net = MANO_OCR_stage("ResNet_stage_18" if kind == "config2" else "ResNet_stage_50", 21, True).cuda()
+        with torch.no_grad():
+            for head in (net.mano_regress[2], net.mano_regress_s2[2]):
+                head.bias[58] = 1.0
+        return RenderSupervisedStep(net, render, Config)
     one, forked = make(), make()
     tgts = []
     for seed in (3, 8):
@@ -186,7 +196,7 @@ def test_forked_streams_are_invisible(render, det_mode):
         finally:
             streams.ENABLED[0] = True
         l2, terms2 = forked(t)
-        assert len(streams._STREAMS) >= 4                                   # the forks really happened
+        assert len(streams._STREAMS) >= (4 if kind == "config3" else 1)     # the forks really happened
         assert torch.equal(l1, l2) and all(torch.equal(terms1[k], terms2[k]) for k in terms1)
         for (n, a), b in zip(one.net.named_parameters(), forked.net.parameters()):
             assert (a.grad is None) == (b.grad is None) and (a.grad is None or torch.equal(a.grad, b.grad)), n
