@@ -560,17 +560,23 @@ class PretrainStep(_StepBase):
         img = s["img"]
         outputs = self.net(s["img_t"], R, s["center"], s["cube"])
         terms = {}
-        for i, (pixel_pd, mano_pd) in enumerate(outputs):
+        f = fork(img.device)                                  # the model branch beside the pixel branch, as in RenderSupervisedStep.loss
+        with f.branch(0, *[mano_pd for _, mano_pd in outputs]):
+            for i, (_, mano_pd) in enumerate(outputs):
+                jxyz_pd, mesh_pd = R.get_mesh_xyz(mano_pd)
+                terms["joint%d" % i] = L1(jxyz_pd, s["joint_xyz"], weight=cfg.coord_weight)
+                terms["vert%d" % i] = L1(mesh_pd, s["mesh_xyz"], weight=cfg.coord_weight)
+                terms["beta%d" % i] = torch.mean(torch.pow(mano_pd[:, 48:58], 2)) * (cfg.coord_weight * 10)
+                terms["scale%d" % i] = torch.mean(torch.abs(torch.clamp(mano_pd[:, 58], max=0.0))) * 0.1
+        for i, (pixel_pd, _) in enumerate(outputs):
             S = pixel_pd.size(-1)
             pixel_gt = gfm.joint2feature(s["joint_uvd"], img, cfg.feature_para, S, cfg.feature_type)
             juvd_pd = gfm.feature2joint(img, pixel_pd, cfg.feature_type, cfg.feature_para)
             terms["pix%d" % i] = L1(pixel_pd, pixel_gt, weight=cfg.deconv_weight)
             terms["coord%d" % i] = L1(juvd_pd, s["joint_uvd"], weight=cfg.coord_weight)
-            jxyz_pd, mesh_pd = R.get_mesh_xyz(mano_pd)
-            terms["joint%d" % i] = L1(jxyz_pd, s["joint_xyz"], weight=cfg.coord_weight)
-            terms["vert%d" % i] = L1(mesh_pd, s["mesh_xyz"], weight=cfg.coord_weight)
-            terms["beta%d" % i] = torch.mean(torch.pow(mano_pd[:, 48:58], 2)) * (cfg.coord_weight * 10)
-            terms["scale%d" % i] = torch.mean(torch.abs(torch.clamp(mano_pd[:, 58], max=0.0))) * 0.1
+        f.join()
+        order = [k % i for i in range(len(outputs)) for k in ("pix%d", "coord%d", "joint%d", "vert%d", "beta%d", "scale%d")]
+        terms = {k: terms[k] for k in order}                 # (the reference's order: the sum below is order-sensitive in its last bits)
         return torch.stack(list(terms.values())).sum(), terms
 
     def __call__(self, model_para, cube, draws=None):
