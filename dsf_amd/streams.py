@@ -19,7 +19,7 @@ pass are recorded by the autograd engine itself.
 Eager steps keep to ONE branch stream (slot 0) beside the current one and the weight-gradient stream: HIP maps streams onto
 GPU_MAX_HW_QUEUES = 4 hardware queues, and with five streams two of them shared a queue in some runs -- config 2 then ran
 whole benchmark runs at 20.2-20.9 ms instead of 18.9-19.4 (2 of 8 runs; 0 of 8 with one branch stream).  A replayed HIP graph has
-its own queue assignment: the hourglass levels and the loss chains of config 3 use a stream each.
+its own queue assignment: inside a capture the hourglass levels and the loss chains of config 3 use a stream each (``slot``).
 DSF_BRANCHES=0 keeps everything on one stream.  In a multi-rank process group a chain that produces parameter gradients
 (``params=<module>``) forks only when every parameter of the module is managed by parallel.GradAllReducer, which notes the
 stream each gradient arrives on and orders its bucket pack behind them; any other data-parallel wrapper reads gradients on
@@ -36,7 +36,9 @@ _STREAMS = {}
 
 
 def _stream(device, slot):
-    key = (device.index if device.index is not None else torch.cuda.current_device(), slot % SLOTS)
+    # eager: ONE branch stream (see above); inside a stream capture the slots are distinct streams = independent chains of the graph
+    slot = slot % SLOTS if torch.cuda.is_current_stream_capturing() else 0
+    key = (device.index if device.index is not None else torch.cuda.current_device(), slot)
     s = _STREAMS.get(key)
     if s is None:
         s = _STREAMS[key] = torch.cuda.Stream(device=device)

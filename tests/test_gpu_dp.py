@@ -362,7 +362,7 @@ def _mesh_worker(rank, world, port, q):
         torch.cuda.synchronize()
         outs.append(torch.cat([pp.grad.detach().reshape(-1).float().cpu() if pp.grad is not None else torch.zeros(pp.numel())
                                for pp in net.parameters()]).numpy())
-    forked = bool(net.body.hgs[0].__dict__.get("_dsf_fork_ok")) and len(streams._STREAMS) >= 4 and len(sync.buckets) >= 3
+    forked = bool(net.body.hgs[0].__dict__.get("_dsf_fork_ok")) and len(streams._STREAMS) >= 1 and len(sync.buckets) >= 3
     q.put((rank, outs, float(loss), forked))
     dist.barrier()
     dist.destroy_process_group()
