@@ -207,3 +207,33 @@ def test_checkpoint_round_trip(tmp_path):
     opt3 = torch.optim.AdamW(net.parameters(), lr=1e-3)
     C.load_checkpoint(str(tmp_path / "latest.pth"), net, opt3, load_optimizer=True)
     assert len(opt3.state) == len(opt.state) > 0
+
+
+def test_forked_stream_helpers_are_no_ops_without_a_gpu():
+    """dsf_amd/streams.py on CPU tensors (the oracle twins run the product's module classes on the CPU): ``fork`` hands out
+    null contexts and joins nothing; ``disabled()`` restores the switch; the zero pool of nn_conv stays closed."""
+    import torch
+    from dsf_amd import streams, nn_conv
+    f = streams.fork("cpu")
+    assert not f.on
+    x = torch.ones(3)
+    with f.branch(0, x):
+        y = x + 1
+    with f.branch(2):
+        z = y * 2
+    f.join()
+    assert float(z.sum()) == 12.0
+    was = streams.ENABLED[0]
+    with streams.disabled():
+        assert streams.ENABLED[0] is False
+        with streams.disabled():
+            pass
+        assert streams.ENABLED[0] is False
+    assert streams.ENABLED[0] == was
+
+    class Owner:
+        pass
+    o = Owner()
+    with nn_conv.zero_pool(o, "cpu"):
+        assert nn_conv._ZERO is None
+    assert "_zero_pool_floats" not in o.__dict__
