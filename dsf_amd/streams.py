@@ -17,8 +17,8 @@ back to the forking stream's pool while the node's kernel may still be reading i
 pass are recorded by the autograd engine itself.
 
 Eager steps keep to ONE branch stream (slot 0) beside the current one and the weight-gradient stream: HIP maps streams onto
-GPU_MAX_HW_QUEUES = 4 hardware queues, and with five streams two of them shared a queue in some runs -- config 2 then ran
-whole benchmark runs at 20.2-20.9 ms instead of 18.9-19.4 (2 of 8 runs; 0 of 8 with one branch stream).  A replayed HIP graph has
+GPU_MAX_HW_QUEUES = 4 hardware queues, and with five streams config 2 ran whole benchmark runs at 20.2-20.9 ms instead of
+18.9-19.4 (2 of 10 runs; 0 of 8 with one branch stream) -- two streams sharing a queue is the likely cause, not an isolated one.  A replayed HIP graph has
 its own queue assignment: inside a capture the hourglass levels and the loss chains of config 3 use a stream each (``slot``).
 DSF_BRANCHES=0 keeps everything on one stream.  In a multi-rank process group a chain that produces parameter gradients
 (``params=<module>``) forks only when every parameter of the module is managed by parallel.GradAllReducer, which notes the
