@@ -237,3 +237,37 @@ def test_forked_stream_helpers_are_no_ops_without_a_gpu():
     with nn_conv.zero_pool(o, "cpu"):
         assert nn_conv._ZERO is None
     assert "_zero_pool_floats" not in o.__dict__
+
+
+def test_lanes_tool_accounts_for_every_nanosecond(tmp_path, capsys):
+    """tools/lanes.py on a hand-made kernel trace: idle + one + two (+ more) kernels in flight = the step's wall time, the alone-in-
+    flight time goes to the right workgroup bucket, gaps are counted (the config-3 work of round 4 was steered by this tool)."""
+    import csv, importlib.util, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("lanes", os.path.join(root, "tools", "lanes.py"))
+    lanes = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lanes)
+    ms = 1000000
+    rows = [  # start, end (ms), name, queue, workgroups  (one step between the two optimizer marks)
+        (0, 1, "adamw_multi_kernel(x)", 1, 10),
+        (2, 12, "void (anonymous namespace)::big_kernel<4>(float*)", 1, 512),      # alone 2-5 and 9-12
+        (5, 9, "void (anonymous namespace)::side_kernel(float*)", 2, 8),           # overlaps the big one entirely
+        (15, 16, "void (anonymous namespace)::tiny_kernel(float*)", 1, 2),          # alone, after a 3 ms gap
+        (20, 21, "adamw_multi_kernel(x)", 1, 10),
+    ]
+    rows = [(s_ * ms, e_ * ms, n, q, g) for s_, e_, n, q, g in rows]
+    path = tmp_path / "k.csv"
+    with open(path, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Start_Timestamp", "End_Timestamp", "Kernel_Name", "Queue_Id", "Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z",
+                    "Workgroup_Size_X", "Workgroup_Size_Y", "Workgroup_Size_Z"])
+        for s, e, n, q, g in rows:
+            w.writerow([s, e, n, q, g * 256, 1, 1, 256, 1, 1])
+    lanes.main(str(path), 1)
+    out = capsys.readouterr().out
+    # the step runs from the first mark's end (1 ms) to the second's end (21 ms); kernels inside: big, side, tiny, adamw
+    assert "step 20.00 ms, 4 kernels: idle 8.00 ms, one kernel in flight 8.00, two 4.00, three or more 0.00; kernel time 16.00 ms" in out
+    assert "1: 3 launches 12.00 ms, 2: 1 launches 4.00 ms" in out
+    assert "alone in flight, by workgroup count: 1+: 2.00 ms, 16+: 0.00 ms, 64+: 0.00 ms, 256+: 6.00 ms, 1024+: 0.00 ms" in out
+    assert "alone    6.00 ms in    2 intervals  big_kernel<4>" in out
+    assert "2 idle gaps, 7.00 ms in total, median 4000.0 us, 2 above 10 us" in out
