@@ -31,7 +31,7 @@ import os
 import torch
 
 ENABLED = [os.environ.get("DSF_BRANCHES", "1") == "1"]
-SLOTS = 4
+SLOTS = int(os.environ.get("DSF_BRANCH_SLOTS", "4"))           # distinct branch streams inside a capture
 _STREAMS = {}
 
 
