@@ -318,8 +318,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 // ---- pass 2 backward: dx = gamma*invstd*(g - sum_g/M - xhat*sum_gx/M); dres = g -----------------------
 // FOLD: the two channel sums come from the accumulation rows (folded once per workgroup, as in bn_apply_kernel<true>) instead of
 // the finalise launch's doubles; the owners of the first workgroup(s) also store dgamma / dbeta.
+// (launch bound 5, not 6: the same 80 VGPRs, but bound 6 made the allocator spill three dwords that the main loop reloaded per
+//  iteration; config 4 172.0 -> 170.9 ms, config 2 unchanged)
 template <bool FOLD>
-__global__ __launch_bounds__(256, 6) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+__global__ __launch_bounds__(256, 5) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                            const float* __restrict__ y, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const double* __restrict__ acc,
