@@ -11,6 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdsf_hip.so")
+EXPECTED_ABI = 2            # dsf_abi_version() of the library these bindings were written for (csrc/api.hip)
 
 c_float_p = ctypes.c_void_p
 _lib = None
@@ -66,7 +67,12 @@ def lib():
             raise MissingNativeLibrary(
                 "libdsf_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(dsf_amd has no CPU fallback)" % LIB_PATH)
-        _lib = ctypes.CDLL(LIB_PATH)
+        cand = ctypes.CDLL(LIB_PATH)
+        cand.dsf_abi_version.restype = ctypes.c_int
+        if cand.dsf_abi_version() != EXPECTED_ABI:                  # a stale build: argument lists differ, pointers would shift
+            raise MissingNativeLibrary("%s has ABI version %d, this package needs %d -- rebuild it with "
+                                       "`python -c 'import __graft_entry__ as g; g.build()'`" % (LIB_PATH, cand.dsf_abi_version(), EXPECTED_ABI))
+        _lib = cand
         _lib.dsf_status_string.restype = ctypes.c_char_p
         _lib.dsf_conv_x6_image_bytes.restype = ctypes.c_int64
         _lib.dsf_mfma_bf16_probe.restype = ctypes.c_int64

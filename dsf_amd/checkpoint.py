@@ -31,10 +31,12 @@ def filter_state(model_state, net):
     return merged, list(taken), dropped, missing
 
 
-def load_checkpoint(path, net, optimizer=None, resume=True, load_optimizer=False, map_location="cpu"):
+def load_checkpoint(path, net, optimizer=None, resume=True, load_optimizer=False, map_location="cpu", trusted=False):
     """Loads ``path`` into ``net`` with the reference's key filter.  -> ``start_epoch`` (``checkpoint["epoch"] + 1`` when
-    resuming, 0 for a fine-tune start).  ``load_optimizer``: also restore the optimizer state (the reference never does)."""
-    ckpt = torch.load(path, map_location=map_location, weights_only=False)
+    resuming, 0 for a fine-tune start).  ``load_optimizer``: also restore the optimizer state (the reference never does).
+    The reference's files hold tensors, ints and the optimizer's param_groups only, so they load with ``weights_only=True``;
+    ``trusted=True`` falls back to the full unpickler (arbitrary code execution: only for files you wrote yourself)."""
+    ckpt = torch.load(path, map_location=map_location, weights_only=not trusted)
     merged, _, _, _ = filter_state(ckpt["model"], net)
     net.load_state_dict(merged)
     from . import nn_conv
@@ -53,7 +55,7 @@ def load_checkpoint(path, net, optimizer=None, resume=True, load_optimizer=False
 def save_checkpoint(path, net, optimizer, epoch):
     """``torch.save({"model", "optimizer", "epoch"}, path)`` (:282-296), written through a temporary file so that an
     interrupted save cannot leave a truncated ``latest.pth``."""
-    tmp = path + ".tmp"
+    tmp = "%s.%d.tmp" % (path, os.getpid())             # data-parallel ranks / two Checkpointers on one path do not share it
     torch.save({"model": net.state_dict(), "optimizer": optimizer.state_dict(), "epoch": int(epoch)}, tmp)
     os.replace(tmp, path)
 

@@ -8,14 +8,16 @@ set -e
 cd "$(dirname "$0")"
 OUT=../lib
 mkdir -p $OUT
-# -fno-slp-vectorize, for the whole library.  Found with mano.hip in round 4: its SLP-vectorised skinning loops (v_pk_fma_f32 on
-# ds_read_b128 broadcasts) returned wrong bits in lanes 48-63 whenever conv_x6 workgroups shared the CU, the scalar form never did
-# (profiles/r04_mano_beside_conv_x6.txt, tools/platform/mano_beside_conv_x6.py,
-# tests/test_gpu_determinism.py::test_mano_backward_is_stable_beside_convolution_workgroups).  The trigger was not isolated beyond
-# "SLP-vectorised code beside conv_x6", and every kernel of a step runs beside the conv_x6 workgroups of the weight-gradient stream,
-# so every kernel gets the form that never failed.  It costs nothing: the non-convolution sources +0.03 ms of a 19.5 ms step, the
-# convolution sources -0.1 ... -0.2 ms (same box, alternating: 20.22 / 20.24 / 20.26 ms with, 20.15 / 20.12 / 20.07 without).
-FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wall -Wno-unused-function"
+# -fno-slp-vectorize -fno-vectorize, for the whole library: no auto-vectorised packed-FP32 arithmetic in any kernel.
+# Round 4 found the SLP-vectorised MANO backward returning wrong bits in lanes 48-63 whenever conv_x6 workgroups shared the CU;
+# round 5 bisected it to a platform erratum (tools/platform/pk_opsel_beside_mfma_lds.hip, profiles/r05_pk_opsel_erratum.txt): a
+# v_pk_{mul,fma,add}_f32 whose low result selects (source 0 low, source 1 HIGH) -- op_sel:[0,1] -- reads source 1 as 0.0 in lanes
+# 48-63 while a wave issuing bf16 MFMAs runs on the same SIMD.  Which selects the vectorisers pick is not under this source's
+# control and every kernel of a step runs beside the conv_x6 workgroups of the weight-gradient stream, so neither vectoriser
+# runs (round 4 disabled only the SLP one and the loop vectoriser still packed four kernels, the crop rasteriser among them).
+# isa_lint.py below disassembles the linked library and fails the build on any packed-FP32 or scratch instruction.
+# Cost: none measurable (round 4: non-convolution sources +0.03 ms of a 19.5 ms step, the convolution sources -0.1 ... -0.2 ms).
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fno-vectorize -Wall -Wno-unused-function"
 SRCS="api mano raster pfd hand_geom image_ops data_ops conv conv_x6 conv_c1 norm loss optim pool volume"
 if [ "$(cat $OUT/.flags 2>/dev/null)" != "$FLAGS" ]; then
   rm -f $OUT/*.o
@@ -40,4 +42,5 @@ fi
 OBJS=""
 for f in $SRCS; do OBJS="$OBJS $OUT/$f.o"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libdsf_hip.so $OBJS
+python3 isa_lint.py $OUT/libdsf_hip.so
 echo built $OUT/libdsf_hip.so

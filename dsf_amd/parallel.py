@@ -16,12 +16,13 @@ import torch
 import torch.distributed as dist
 
 
-def init_distributed(backend=None):
-    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env (torch.distributed.run)."""
+def init_distributed(backend=None, force=False):
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env (torch.distributed.run).  ``force``: create the process
+    group even at world size 1 (a one-rank RCCL communicator: tests/test_gpu_rccl.py drives the collective path through it)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -67,8 +68,11 @@ class GradAllReducer:
     for ResNet-18 two-stage).
     """
 
-    def __init__(self, params, bucket_bytes=32 << 20, group=None, tail_bucket_bytes=2 << 20):
+    def __init__(self, params, bucket_bytes=32 << 20, group=None, tail_bucket_bytes=2 << 20, force=False):
+        """``force``: hooks, packing and the collective also run at world size 1 (they are skipped there otherwise: a
+        one-rank average is the identity) -- the way to exercise RCCL's asynchronous semantics on a one-GPU box."""
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (bool(force) and dist.is_initialized())
         self.group = group
         self.params = [p for p in params if p.requires_grad]
         self.buckets = []            # lists of params
@@ -101,10 +105,24 @@ class GradAllReducer:
         self._reset()
         self.enabled = True          # False: hooks and finish() do nothing (single-rank diagnostic steps)
         self._hooks = []
-        if self.world > 1:
+        self._present = {}           # (bucket, missing pattern) -> device row, see _launch
+        if self.active:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
                 p.__dict__["_dsf_hooks_join"] = True     # (nn_conv._side_ok: this hook joins the side stream before it reads)
+        from . import streams
+        streams.DP_EPOCH[0] += 1     # every module's cached "may this level fork under data parallelism" answer is stale now
+
+    def detach(self):
+        """Removes the hooks and the per-parameter marks (the parameters go back to plain autograd accumulation)."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        for p in self.params:
+            p.__dict__.pop("_dsf_hooks_join", None)
+        self.active = False
+        from . import streams
+        streams.DP_EPOCH[0] += 1
 
     def _seal(self, plist):
         for p in plist:
@@ -144,8 +162,14 @@ class GradAllReducer:
                        (torch.zeros_like(p) if p.grad is None else torch.empty_like(p).copy_(p.grad))) for p in plist]
         # presence row: one float per parameter, 1 where this rank produced a gradient.  After the sum it tells which
         # parameters got a gradient on NO rank: those keep ``grad = None`` (as in a single-GPU run, where AdamW then skips
-        # them -- no weight decay, no moment decay), see finish()
-        present = torch.tensor([0.0 if m else float(self.world) for m in missing], dtype=parts[0].dtype).to(parts[0].device, non_blocking=True)
+        # them -- no weight decay, no moment decay), see finish().  The row lives on the device: built ONCE per (bucket,
+        # pattern of missing gradients) -- the pattern is a property of the step, the same every iteration -- so the hook
+        # issues no host-to-device copy (round 4 built it from pageable memory per bucket per step: a host-blocking copy in
+        # the middle of the backward pass, which gloo hides and an overlapped RCCL collective does not)
+        key = (b, tuple(missing))
+        present = self._present.get(key)
+        if present is None:
+            present = self._present[key] = torch.tensor([0.0 if m else float(self.world) for m in missing], dtype=parts[0].dtype).to(parts[0].device)
         flat = torch.cat(parts + [present])
         flat.div_(self.world)
         self._flat[b] = flat
@@ -157,7 +181,7 @@ class GradAllReducer:
         pass did not run the hooks -- train_step.GraphedStep replays forward + backward from a HIP graph (captured with
         ``enabled = False``) and calls this before the optimizer.  Nothing overlaps with the backward pass here; what the graph
         buys instead is the host time of ~700-1500 launches per step (the regime of the small-batch / many-rank runs)."""
-        if self.world > 1 and self.enabled:
+        if self.active and self.enabled:
             self._reset()
             for b in range(len(self.buckets)):
                 self._launch(b)
@@ -165,7 +189,7 @@ class GradAllReducer:
 
     def finish(self):
         """Call after backward, before optimizer.step()."""
-        if self.world > 1 and self.enabled:
+        if self.active and self.enabled:
             for b in range(len(self.buckets)):
                 if self._flat[b] is None:                # some parameter of the bucket got no gradient this step
                     self._launch(b)

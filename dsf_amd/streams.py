@@ -33,6 +33,7 @@ import torch
 ENABLED = [os.environ.get("DSF_BRANCHES", "1") == "1"]
 SLOTS = int(os.environ.get("DSF_BRANCH_SLOTS", "4"))           # distinct branch streams inside a capture
 _STREAMS = {}
+DP_EPOCH = [0]                 # bumped whenever a GradAllReducer is attached or detached (parallel.py): invalidates fork()'s per-module cache
 
 
 def _stream(device, slot):
@@ -64,11 +65,11 @@ class fork:
         self.on = ENABLED[0] and device.type == "cuda"
         if self.on and params is not None and torch.distributed.is_available() and torch.distributed.is_initialized() \
                 and torch.distributed.get_world_size() > 1:
-            ok = params.__dict__.get("_dsf_fork_ok")
-            if ok is None:                                  # decided once per module, at its first multi-rank forward
+            cached = params.__dict__.get("_dsf_fork_ok")
+            if cached is None or cached[0] != DP_EPOCH[0]:  # decided once per module and per set of attached reducers
                 ok = all(bool(p.__dict__.get("_dsf_hooks_join")) for p in params.parameters() if p.requires_grad)
-                params.__dict__["_dsf_fork_ok"] = ok
-            self.on = ok
+                params.__dict__["_dsf_fork_ok"] = cached = (DP_EPOCH[0], ok)
+            self.on = cached[1]
         self.device, self.used = device, []
         self.cur = torch.cuda.current_stream(device) if self.on else None
 

@@ -534,3 +534,72 @@ def test_mano_backward_is_stable_beside_convolution_workgroups(render):
                 nn_conv._wrw(x, gy, 3, 3, 1, (1, 1))
         bad += int(not torch.equal(grad(), ref))
     assert bad == 0, "%d of 100 MANO backward calls beside conv_x6 workgroups differ from the call that ran alone" % bad
+
+
+def test_geometry_kernels_are_stable_beside_convolution_workgroups(render):
+    """Round 5: the four kernels in which round 4's build still had packed-FP32 instructions (the loop vectoriser's, which
+    -fno-slp-vectorize does not stop) -- the crop rasteriser forward (the kernel whose face / pixel indices must be bit-exact),
+    its backward, Img2pcl and the Huber backward -- 200 times each while conv_x6 backward-weights launches (bf16 MFMAs, the
+    aggressor of tools/platform/pk_opsel_beside_mfma_lds.hip) run on a second stream of the same process, exactly as the
+    weight-gradient stream does in every step; bitwise against the call that ran alone.  The static side of the same
+    guarantee is tests/test_isa_lint.py (no packed-FP32 instruction in any shipped code object)."""
+    from dsf_amd import nn_conv, ops
+    from dsf_amd.data.render_loader import loader
+    from dsf_amd.metric.losses import SmoothL1Loss
+    from dsf_amd.train_step import synthetic_batch
+    B = 32
+    p, c, cube = synthetic_batch(B, "cuda", seed=6)
+    _, M, _, _ = ops.crop_setup(c, cube, render.cam, 128)
+    L1, ld = SmoothL1Loss(), loader()
+    gimg = torch.randn(B, 1, 128, 128, device="cuda")
+    keys = torch.randint(0, 2 ** 31 - 1, (B, 128 * 128), device="cuda", dtype=torch.int32)
+    tgt = torch.randn(B, 84, 64, 64, device="cuda") * 0.02
+    pred0 = torch.randn(B, 84, 64, 64, device="cuda") * 0.02
+    x = torch.randn(32, 256, 64, 64, device="cuda").contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(32, 256, 64, 64, device="cuda").contiguous(memory_format=torch.channels_last)
+    side = torch.cuda.Stream()
+
+    def crop():                                             # render_crop_fwd_kernel + render_crop_bwd_kernel (+ the MANO pair)
+        render.mano_layer.clear_cache()
+        q = p.clone().requires_grad_(True)
+        verts, _ = render.mano_layer.get_mano_vertices_packed(q[:, :62], global_scale=1 / 125)
+        verts = verts * cube.unsqueeze(1) / 2 + c.unsqueeze(1)
+        center2d, M_auto, _, minv_c = ops.crop_setup(c, cube, render.cam, 128)
+        minv = render._inverse(M_auto, minv_c)
+        img, p2f = ops.RenderCropFunction.apply(verts, render.mano_layer.faces_i32, minv, render.resize_rowmap, center2d[:, 2].contiguous(),
+                                                cube[:, 2].contiguous(), render.cam, 640, 128)
+        g, = torch.autograd.grad(img, q, gimg)
+        assert (p2f >= 0).float().mean() > 0.02
+        return [img.detach(), p2f, g]
+
+    def pcl():                                              # img2pcl_kernel, the random branch with explicit keys
+        with torch.no_grad():
+            img = render.render(p, c, cube)[0]
+            return [ld.Img2pcl(img, 128, c, M, cube, 1024, rand_keys=keys)]
+
+    def huber():                                            # huber_partial / final / bwd kernels
+        pr = pred0.clone().requires_grad_(True)
+        loss = L1(pr, tgt, weight=3.0)
+        g, = torch.autograd.grad(loss, pr)
+        return [loss.detach(), g]
+
+    from dsf_amd import _lib as L
+    old = L.set_deterministic(True)                         # the raster backward's float atomics would differ between runs by themselves
+    try:
+        for name, fn in (("crop rasteriser forward + backward", crop), ("Img2pcl", pcl), ("Huber forward + backward", huber)):
+            ref = fn()
+            torch.cuda.synchronize()
+            again = fn()
+            torch.cuda.synchronize()
+            assert all(torch.equal(a, b) for a, b in zip(ref, again)), name + ": not reproducible even alone"
+            bad = 0
+            for _ in range(200):
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        nn_conv._wrw(x, gy, 3, 3, 1, (1, 1))
+                got = fn()
+                torch.cuda.synchronize()
+                bad += int(not all(torch.equal(a, b) for a, b in zip(ref, got)))
+            assert bad == 0, "%s: %d of 200 calls beside conv_x6 backward-weights differ from the call that ran alone" % (name, bad)
+    finally:
+        L.set_deterministic(old)

@@ -7,11 +7,12 @@ for c in $CONFIGS; do
   timeout 900 python3 $R/bench.py --config $c > $O/${TAG}_bench_config$c.json 2> $O/bench_config$c.err
   rm -rf $O/kc; timeout 900 rocprofv3 --kernel-trace --output-format csv -d $O/kc -o k -- python3 $R/tools/step_only.py --config $c --steps 8 --warmup 3 > $O/step_only_$c.log 2>&1
   ms=$(grep STEP_ONLY $O/step_only_$c.log | sed 's/.*wall_ms \([0-9.]*\).*/\1/')
+  if [ -z "$ms" ]; then echo "config $c: step_only.py printed no STEP_ONLY line (see $O/step_only_$c.log): skipped" >&2; continue; fi
   ( echo "config $c, per step over the 8 timed steps of tools/step_only.py (kernels starting in the last $ms ms of the trace; under the tracer a step takes $(grep STEP_ONLY $O/step_only_$c.log | sed 's/.*ms_per_step //') ms):"; python3 $R/tools/kstats.py $O/kc/k_kernel_trace.csv 8 $ms ) > $O/${TAG}_config${c}_kernel_categories.txt
   python3 $R/tools/lanes.py $O/kc/k_kernel_trace.csv 2 > $O/${TAG}_config${c}_lanes.txt 2>&1
   rm -rf $O/kc
   for ctr in FETCH_SIZE WRITE_SIZE; do
-    rm -rf $O/pm; timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pm -o p -- python3 $R/bench.py --config $c --steps 2 --warmup 2 --no-cpu-baseline > $O/pmc_$c_$ctr.log 2>&1
+    rm -rf $O/pm; timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pm -o p -- python3 $R/bench.py --config $c --steps 2 --warmup 2 --no-cpu-baseline > $O/pmc_${c}_${ctr}.log 2>&1
     python3 $R/tools/pmc_summary.py $O/${TAG}_config${c}_pmc_$ctr.json $O/pm/p_counter_collection.csv; rm -rf $O/pm
   done
   python3 - <<PY
