@@ -439,6 +439,23 @@ def build_workload(args, dev, rank, world):
     render = Render("synthetic", "nyu", (588.03, 587.07, 320.0, 240.0), (640, 480)).to(dev)
     p, c, cube = synthetic_batch(B, dev, seed=0 + rank)            # per-rank shard of the global batch
     w = {"render": render, "units_per_step": B, "tgt": None}
+    fit = None
+    if args.init == "fitted":
+        # one pose, B small perturbations of it (tests/test_gpu_steps.py::_selfsup_setup's fitted case at batch size)
+        fit = synthetic_batch(1, "cpu", seed=23)[0][0]
+        noise = 0.003 * torch.randn(B, 62, generator=torch.Generator().manual_seed(2 + rank))
+        noise[:, 58:] = 0.0
+        p = (fit[None] + noise).to(dev)
+
+    def fit_heads(net):
+        if fit is None:
+            return
+        with torch.no_grad():
+            for name in ("mano_regress", "mano_regress_s2"):
+                head = getattr(net, name, None)
+                if head is not None:
+                    head[2].bias.copy_(fit.to(head[2].bias.device))
+                    head[2].weight.mul_(0.05)              # the head stays within ~0.01 of the pose for any input
 
     def oracle_bits():
         from dsf_amd.assets import build_synthetic_mano
@@ -460,6 +477,7 @@ def build_workload(args, dev, rank, world):
     if cfg == 2:
         backbone = args.backbone or "ResNet_stage_18"
         net = MANO_OCR_stage(backbone, 21, True).to(dev)
+        fit_heads(net)
         sync = GradAllReducer(net.parameters()) if world > 1 else None
         step = RenderSupervisedStep(net, render, Config, grad_sync=sync)
         tgt = step.make_targets(p, c, cube, seed=1 + rank)
@@ -478,6 +496,7 @@ def build_workload(args, dev, rank, world):
     elif cfg == 3:
         from dsf_amd.model.hourglass import PoseNetMANO
         net = PoseNetMANO(2, 21).to(dev)
+        fit_heads(net)
         sync = GradAllReducer(net.parameters()) if world > 1 else None
         step = MeshLossStep(net, render, Config, grad_sync=sync)
         tgt = step.make_targets(p, c, cube, seed=1 + rank)
@@ -500,6 +519,7 @@ def build_workload(args, dev, rank, world):
         w["cpu"] = cpu
     elif cfg == 4:
         net = MANO_OCR_stage("ResNet_stage_50", 21, True).to(dev)
+        fit_heads(net)
         sync = GradAllReducer(net.parameters()) if world > 1 else None
         step = PretrainStep(net, render, None, Config, grad_sync=sync, views=3)
         d = step.draw(B, dev, torch.Generator(device=dev).manual_seed(4 + rank), np.random.default_rng(4 + rank))
@@ -525,10 +545,14 @@ def build_workload(args, dev, rank, world):
         with torch.no_grad():
             for head in (net.mano_regress[2], net.mano_regress_s2[2]):
                 head.bias[58] = 1.0                    # unit global scale: non-degenerate hands from random-init heads
+        fit_heads(net)
         gen = define_G(1, 1, 64, 'resnet_9blocks', 'instance', False, 'xavier').to(dev)
         sync = GradAllReducer(net.parameters()) if world > 1 else None
         step = FinetuneStageStep(net, render, gen, Config, grad_sync=sync)
         pr, cr, cube_r = synthetic_batch(B, dev, seed=100 + rank)
+        if fit is not None:                            # the real images show the pose the heads reproduce
+            pr = (fit[None] + 0.003 * torch.randn(B, 62, generator=torch.Generator().manual_seed(7 + rank))).to(dev)
+            pr[:, 58:] = fit[58:].to(dev)
         with torch.no_grad():
             img_r = render.render(pr, cr, cube_r)[0]
             _, M_r, _, _ = ops.crop_setup(cr, cube_r, render.cam, 128)
@@ -572,6 +596,11 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (weak scaling); 0 = the config's own (32 / 64 / 64 / 64)")
     ap.add_argument("--backbone", default="", help="config 2 only: ResNet_stage_18 (default) / ResNet_stage_50")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--init", default="fresh", choices=("fresh", "fitted"),
+                    help="fresh: random-init network (the default and the contract's workload).  fitted: the steady state a trained "
+                         "estimate is in (train_render.py:735-739, 777-781 run the mesh losses on one): every sample of the batch is a "
+                         "small perturbation of one pose and the MANO heads reproduce that pose, so that the predicted mesh lies on "
+                         "the data -- the state in which the point-to-triangle cull works; reported as config.init")
     ap.add_argument("--graph", action="store_true", help="replay forward+backward from a HIP graph (train_step.GraphedStep; "
                     "single GPU): same kernels, no host issue -- pays below batch 16, where the step is host-bound")
     ap.add_argument("--no-graph", action="store_true", help="config 3 only: the eager step instead of its default HIP-graph replay")
@@ -655,7 +684,7 @@ def main():
             "conv_math": os.environ.get("DSF_CONV_MATH", "x6") + (": fp32 products as 6 bf16 MFMAs on exact 3-way operand splits, fp32 accumulate"
                                                                 if os.environ.get("DSF_CONV_MATH", "x6") == "x6" else ": fp32 MFMA"),
             "config": {"workload": w["workload"], "baseline_config": args.config, "unit_of_value": w["unit_note"],
-                       "global_batch": B * world, "hip_graph": bool(args.graph),
+                       "global_batch": B * world, "hip_graph": bool(args.graph), "init": args.init,
                        "weight_gradients_on_second_stream": os.environ.get("DSF_WRW_STREAM", "1") != "0", "crop": 128, "raster": 640, "parallelism": "dp%d" % world,
                        "mano_asset": "synthetic MANO-shaped hand (real MANO_RIGHT.pkl is license-gated)"},
             "final_loss": round(loss_val, 5),

@@ -328,17 +328,57 @@ __device__ __forceinline__ bool crop_to_raster(const float* mi, const int32_t* _
     return ry >= 0;
 }
 
-constexpr int CROP_MAX_ROWS = 1024;
-constexpr int CAND_CAP = 512;                   // candidate faces per tile handled by the face-parallel path
+// per-face conservative bbox in raster pixel indices (column rx has x_ndc = 1 - (2rx+1)/S); lo = 1 > hi = 0: the face covers nothing
+__device__ __forceinline__ uint2 crop_face_box(float x0, float y0, float z0, float x1, float y1, float z1, float x2, float y2, float z2, int S) {
+    const float zmax = max3(z0, z1, z2);
+    const float face_area = edge_fn(x0, y0, x1, y1, x2, y2);
+    const bool degenerate = (face_area <= kEps && face_area >= -kEps);
+    uint2 box = make_uint2(1u, 1u);
+    if (!(zmax < 0.0f) && !degenerate) {
+        const float xmin = min3(x0, x1, x2), xmax = max3(x0, x1, x2);
+        const float ymin = min3(y0, y1, y2), ymax = max3(y0, y1, y2);
+        const float fxlo = 0.5f * ((float)S * (1.0f - xmax) - 1.0f), fxhi = 0.5f * ((float)S * (1.0f - xmin) - 1.0f);
+        const float fylo = 0.5f * ((float)S * (1.0f - ymax) - 1.0f), fyhi = 0.5f * ((float)S * (1.0f - ymin) - 1.0f);
+        if (fxhi > -2.0f && fyhi > -2.0f && fxlo < (float)S + 1.0f && fylo < (float)S + 1.0f) {
+            const int xlo = max(0, (int)ceilf(fmaxf(fxlo, -4.0f)) - 1), xhi = min(S - 1, (int)floorf(fminf(fxhi, (float)S + 4.0f)) + 1);
+            const int ylo = max(0, (int)ceilf(fmaxf(fylo, -4.0f)) - 1), yhi = min(S - 1, (int)floorf(fminf(fyhi, (float)S + 4.0f)) + 1);
+            if (xlo <= xhi && ylo <= yhi)
+                box = make_uint2((uint32_t)xlo | ((uint32_t)xhi << 16), (uint32_t)ylo | ((uint32_t)yhi << 16));
+        }
+    }
+    return box;
+}
 
-// One wave per 8x8 crop tile, one lane per crop pixel.  LDS per workgroup: projected vertices
-// (<=10 KB), packed 16-bit face indices (13 KB), per-face raster-pixel bboxes (13 KB) and the
-// resize row table (2 KB) -> ~38 KB, four workgroups per CU.  A wave ballots the bbox-vs-tile test
-// over 64 faces at a time and walks the set bits (ascending face index, so a strict `<` on z keeps
-// the lowest face on exact ties, as the naive pytorch3d path does).  Lanes whose edge functions do
-// not all share the sign of the face area cannot be covered (w_i > 0 is a sign statement), so the
-// three IEEE divisions are only executed for the surviving lanes -- the accepted arithmetic is
-// still the oracle's, operation for operation.
+constexpr int CROP_MAX_ROWS = 1024;
+constexpr int BIN_TILES = 8;                    // tiles a workgroup bins faces for at a time: two per wave
+constexpr int CBIN_CAP = 320;                   // candidate faces per tile list (a fuller tile takes the pixel-parallel scan)
+constexpr int HEAVY = 64;                       // tiles with more candidates are shared by the four waves
+
+// Crop mode, forward (round 5).  A workgroup owns tiles spread over the crop (8x8 crop pixels each, one lane per pixel) and
+// handles them BIN_TILES at a time:
+//   1. each wave maps its (up to two) tiles to raster pixels (the two nearest-neighbour maps of resize + crop warp) and
+//      publishes the tile's raster bounding box;
+//   2. all 256 threads bin the sample's faces into the tiles' candidate lists in LDS (face box vs tile box, LDS-atomic
+//      append) -- "LDS staging of per-tile triangle bins";
+//   3. a wave gives every candidate of its tile a lane, which walks the tile pixels inside its face's box and merges
+//      (z bits << 32 | face) keys into the tile's 64 keys with 64-bit LDS atomic-min: exactly "strict < on z, lowest face
+//      index wins exact ties", whatever the order of the list;
+//   4. tiles with more than HEAVY candidates (fingers on top of each other: 200-300) are left to the end of the batch and
+//      shared by all four waves, 64 list entries each per round.
+// Lanes whose edge functions do not all share the sign of the face area cannot be covered (w_i > 0 is a sign statement), so
+// the three IEEE divisions are only executed for the surviving lanes -- the accepted arithmetic is still the oracle's,
+// operation for operation.
+// Why this shape (tools/crop_stamps.py: s_memtime stamps per tile in a diagnostic build): rounds 1-4 gave every wave two
+// tiles and had it scan all 1554 face boxes per tile, 64 at a time.  Of a 78 us launch at B = 32 the mean wave needed 13 us;
+// a tile with three candidates still cost 12 k cycles (the 25 dependent ballot rounds over the face boxes), the wave that
+// owned the heaviest tile 110 k cycles = 51 us; the per-workgroup prologue 700 cycles -- the "25 us floor of projection +
+// face boxes" that rounds 2-4 reported was the host's launch overhead inside the timing loop, and a pre-pass launch that
+// hoisted the prologue changed nothing (79.0 against 79.5 us).
+// LDS: projected vertices 10 KB, face boxes 13 KB, row table 2 KB, lists 5 KB, keys 4 KB -> 35 KB, four workgroups per CU
+// (the packed face indices of rounds 1-4, 13 KB, are read from L2 now: three dwords per candidate).
+#ifdef CROP_STAMP       // diagnostic build only (tools/crop_stamps.py): per-tile s_memtime stamps of the wave that writes the tile
+__device__ unsigned long long* crop_stamp_buf = nullptr;
+#endif
 __global__ __launch_bounds__(256) void render_crop_fwd_kernel(const float* __restrict__ verts,
                                                               const int32_t* __restrict__ faces,
                                                               const float* __restrict__ minv,
@@ -348,15 +388,16 @@ __global__ __launch_bounds__(256) void render_crop_fwd_kernel(const float* __res
                                                               int F, int S, int crop, int wg_per_sample,
                                                               float* __restrict__ img, int32_t* __restrict__ p2f) {
     __shared__ float s_pv[CROP_MAX_V * 3];          // projected verts (x_ndc, y_ndc, z_view)
-    __shared__ uint2 s_fidx[CROP_MAX_F];             // x = v0 | v1<<16, y = v2
     __shared__ uint2 s_box[CROP_MAX_F];              // x = lo_x | hi_x<<16, y = lo_y | hi_y<<16 (raster pixels); lo>hi = never
     __shared__ uint16_t s_rows[CROP_MAX_ROWS];
     __shared__ float s_mi[6];
-    // per-wave scratch of the face-parallel tile path
-    __shared__ unsigned long long s_key[4][64];     // (z bits << 32 | face) per tile pixel
-    __shared__ unsigned short s_cand[4][CAND_CAP];   // compacted candidate faces of the tile
-    __shared__ short s_colrx[4][8], s_rowry[4][8];  // raster column of tile column j / raster row of tile row i (-1: padding)
-    __shared__ float s_colx[4][8], s_rowy[4][8];    // their NDC coordinates
+    __shared__ unsigned long long s_key[BIN_TILES][64];      // (z bits << 32 | face) per tile pixel
+    __shared__ unsigned short s_bin[BIN_TILES][CBIN_CAP];      // candidate faces per tile
+    __shared__ int s_bcnt[BIN_TILES];                         // list lengths (may exceed CBIN_CAP: the tile then scans all faces)
+    __shared__ int s_tbox[BIN_TILES][4];                      // raster box of the tile (x0, x1, y0, y1); x1 < x0: nothing is binned for it
+    __shared__ int s_state[BIN_TILES];                        // 0 done / nothing to do, 1 heavy: waits for the cooperative pass
+    __shared__ short s_colrx[BIN_TILES][8], s_rowry[BIN_TILES][8];   // raster column of tile column j / raster row of tile row i (-1: padding)
+    __shared__ float s_colx[BIN_TILES][8], s_rowy[BIN_TILES][8];     // their NDC coordinates
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int b = blockIdx.x / wg_per_sample, part = blockIdx.x % wg_per_sample;
     const CamN k = cam_ndc(cam);
@@ -371,33 +412,11 @@ __global__ __launch_bounds__(256) void render_crop_fwd_kernel(const float* __res
         s_pv[v * 3] = xn; s_pv[v * 3 + 1] = yn; s_pv[v * 3 + 2] = zv;
     }
     __syncthreads();
-
-    // per-face conservative bbox in raster pixel indices: column rx has x_ndc = 1 - (2rx+1)/S
     for (int f = t; f < F; f += 256) {
         const int a = faces[f * 3], c1 = faces[f * 3 + 1], c2 = faces[f * 3 + 2];
-        s_fidx[f] = make_uint2((uint32_t)a | ((uint32_t)c1 << 16), (uint32_t)c2);
-        const float x0 = s_pv[a * 3], y0 = s_pv[a * 3 + 1], z0 = s_pv[a * 3 + 2];
-        const float x1 = s_pv[c1 * 3], y1 = s_pv[c1 * 3 + 1], z1 = s_pv[c1 * 3 + 2];
-        const float x2 = s_pv[c2 * 3], y2 = s_pv[c2 * 3 + 1], z2 = s_pv[c2 * 3 + 2];
-        const float zmax = max3(z0, z1, z2);
-        const float face_area = edge_fn(x0, y0, x1, y1, x2, y2);
-        const bool degenerate = (face_area <= kEps && face_area >= -kEps);
-        uint2 box = make_uint2(1u, 1u);                        // lo = 1 > hi = 0
-        if (!(zmax < 0.0f) && !degenerate) {
-            const float xmin = min3(x0, x1, x2), xmax = max3(x0, x1, x2);
-            const float ymin = min3(y0, y1, y2), ymax = max3(y0, y1, y2);
-            const float fxlo = 0.5f * ((float)S * (1.0f - xmax) - 1.0f), fxhi = 0.5f * ((float)S * (1.0f - xmin) - 1.0f);
-            const float fylo = 0.5f * ((float)S * (1.0f - ymax) - 1.0f), fyhi = 0.5f * ((float)S * (1.0f - ymin) - 1.0f);
-            if (fxhi > -2.0f && fyhi > -2.0f && fxlo < (float)S + 1.0f && fylo < (float)S + 1.0f) {
-                const int xlo = max(0, (int)ceilf(fmaxf(fxlo, -4.0f)) - 1), xhi = min(S - 1, (int)floorf(fminf(fxhi, (float)S + 4.0f)) + 1);
-                const int ylo = max(0, (int)ceilf(fmaxf(fylo, -4.0f)) - 1), yhi = min(S - 1, (int)floorf(fminf(fyhi, (float)S + 4.0f)) + 1);
-                if (xlo <= xhi && ylo <= yhi)
-                    box = make_uint2((uint32_t)xlo | ((uint32_t)xhi << 16), (uint32_t)ylo | ((uint32_t)yhi << 16));
-            }
-        }
-        s_box[f] = box;
+        s_box[f] = crop_face_box(s_pv[a * 3], s_pv[a * 3 + 1], s_pv[a * 3 + 2], s_pv[c1 * 3], s_pv[c1 * 3 + 1], s_pv[c1 * 3 + 2],
+                                 s_pv[c2 * 3], s_pv[c2 * 3 + 1], s_pv[c2 * 3 + 2], S);
     }
-    __syncthreads();
 
     const bool normalise = (center_z != nullptr);
     const float cz = normalise ? center_z[b] : 0.f;
@@ -405,65 +424,166 @@ __global__ __launch_bounds__(256) void render_crop_fwd_kernel(const float* __res
     const float zmin_c = cz - half, zmax_c = cz + half;
     const int tiles_axis = crop >> 3;
     const int n_tiles = tiles_axis * tiles_axis;
-    const int waves_total = wg_per_sample * 4;
-    for (int tile = part * 4 + wave; tile < n_tiles; tile += waves_total) {
-        const int ty = tile / tiles_axis, tx = tile % tiles_axis;
-        const int i = ty * 8 + (lane >> 3), j = tx * 8 + (lane & 7);
-        // crop pixel -> source pixel of the resized image -> raster pixel (zero padding outside)
-        int ry = 0, rx = 0;
-        bool valid;
-        {
-            const float x = (float)j, y = (float)i;
-            const float sx = (s_mi[0] * x + s_mi[1] * y) + s_mi[2];       // torch CPU matmul order: mul, mul, add, add
-            const float sy = (s_mi[3] * x + s_mi[4] * y) + s_mi[5];
-            const float gx = (sx / cam.img_w) * 2.0f - 1.0f;
-            const float gy = (sy / cam.img_h) * 2.0f - 1.0f;
-            const float fx = rintf((gx + 1.0f) * (cam.img_w / 2.0f) - 0.5f);   // grid_sample unnormalize + nearbyint
-            const float fy = rintf((gy + 1.0f) * (cam.img_h / 2.0f) - 0.5f);
-            valid = fx >= 0.0f && fx < cam.img_w && fy >= 0.0f && fy < cam.img_h;
-            if (valid) {
-                rx = (int)fx;
-                const int sy_i = (int)fy;
-                ry = (sy_i < CROP_MAX_ROWS) ? (int)s_rows[sy_i] : rowmap[sy_i];
-            }
-        }
-        const float xf = pix_to_ndc(S - 1 - rx, S), yf = pix_to_ndc(S - 1 - ry, S);
-        float bz = INFINITY;
-        int bf = -1;
-        // raster-pixel bbox of the 64 sample points of this tile (wave reduction)
-        int t_x0 = valid ? rx : 0x7fffffff, t_x1 = valid ? rx : -1, t_y0 = valid ? ry : 0x7fffffff, t_y1 = valid ? ry : -1;
+#ifdef CROP_STAMP
+    const uint64_t stamp_k0 = __builtin_amdgcn_s_memtime();
+#endif
+    // tile m of this workgroup.  128-pixel crops (16 x 16 tiles): the workgroup id is the LOW bits of the tile's Morton code and
+    // m the high bits, so a workgroup's tiles are spread over the whole crop (the heavy tiles -- overlapping fingers -- sit
+    // together); other sizes: part + m * workgroups per sample
+    const int tiles_per_wg = (n_tiles + wg_per_sample - 1) / wg_per_sample;
+    const bool morton = tiles_axis == 16 && (wg_per_sample & (wg_per_sample - 1)) == 0 && wg_per_sample <= 256;
+    const int wg_bits = 31 - __clz(max(wg_per_sample, 1));
+    auto tile_of = [&](int m) -> int {
+        if (m >= tiles_per_wg) return -1;
+        if (!morton) { const int tl = part + m * wg_per_sample; return tl < n_tiles ? tl : -1; }
+        const unsigned code = (unsigned)part | ((unsigned)m << wg_bits);
+        if (code >= 256u) return -1;
+        const unsigned tx = (code & 1u) | ((code >> 1) & 2u) | ((code >> 2) & 4u) | ((code >> 3) & 8u);
+        const unsigned ty = ((code >> 1) & 1u) | ((code >> 2) & 2u) | ((code >> 3) & 4u) | ((code >> 4) & 8u);
+        return (int)(ty * 16u + tx);
+    };
+    // one candidate face, one lane: the tile pixels inside its raster box, merged into the tile's keys
+    auto face_lane = [&](const int f, const int q) {
+        const uint2 box = s_box[f];
+        const int xlo = (int)(box.x & 0xFFFF), xhi = (int)(box.x >> 16), ylo = (int)(box.y & 0xFFFF), yhi = (int)(box.y >> 16);
+        int j0 = 8, j1 = -1, i0 = 8, i1 = -1;            // pixel sub-rectangle [i0,i1] x [j0,j1] of the tile inside the face's box
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            t_x0 = min(t_x0, __shfl_xor(t_x0, o, 64)); t_x1 = max(t_x1, __shfl_xor(t_x1, o, 64));
-            t_y0 = min(t_y0, __shfl_xor(t_y0, o, 64)); t_y1 = max(t_y1, __shfl_xor(t_y1, o, 64));
+        for (int u = 0; u < 8; ++u) {
+            const int cx = s_colrx[q][u], cy = s_rowry[q][u];
+            if (cx >= xlo && cx <= xhi) { j0 = min(j0, u); j1 = max(j1, u); }
+            if (cy >= ylo && cy <= yhi) { i0 = min(i0, u); i1 = max(i1, u); }
         }
-        const int f_end = (t_x1 < 0) ? 0 : F;                    // whole tile reads the zero padding
+        if (j0 > j1 || i0 > i1) return;
+        const int a = faces[f * 3] * 3, c1 = faces[f * 3 + 1] * 3, c2 = faces[f * 3 + 2] * 3;
+        const float x0 = s_pv[a], y0 = s_pv[a + 1], z0 = s_pv[a + 2];
+        const float x1 = s_pv[c1], y1 = s_pv[c1 + 1], z1 = s_pv[c1 + 2];
+        const float x2 = s_pv[c2], y2 = s_pv[c2 + 1], z2 = s_pv[c2 + 2];
+        const float xmin = min3(x0, x1, x2), xmax = max3(x0, x1, x2);
+        const float ymin = min3(y0, y1, y2), ymax = max3(y0, y1, y2);
+        const float area = edge_fn(x2, y2, x0, y0, x1, y1) + kEps;
+        for (int pi = i0; pi <= i1; ++pi) {
+            const float py = s_rowy[q][pi];
+            if (s_rowry[q][pi] < 0 || py > ymax || py < ymin) continue;
+            for (int pj = j0; pj <= j1; ++pj) {
+                const float px = s_colx[q][pj];
+                if (s_colrx[q][pj] < 0 || px > xmax || px < xmin) continue;
+                const float e0 = edge_fn(px, py, x1, y1, x2, y2);
+                const float e1 = edge_fn(px, py, x2, y2, x0, y0);
+                const float e2 = edge_fn(px, py, x0, y0, x1, y1);
+                // exact pre-test: e/area > 0 needs equal, non-zero signs (area == 0: leave it to the division)
+                if (area > 0.0f) { if (!(e0 > 0.0f && e1 > 0.0f && e2 > 0.0f)) continue; }
+                else if (area < 0.0f) { if (!(e0 < 0.0f && e1 < 0.0f && e2 < 0.0f)) continue; }
+                const float w0 = e0 / area, w1 = e1 / area, w2 = e2 / area;
+                const float pz = w0 * z0 + w1 * z1 + w2 * z2;
+                if (pz < 0.0f) continue;
+                if (!(w0 > 0.0f && w1 > 0.0f && w2 > 0.0f)) continue;
+                // (z bits, face) ordered lexicographically == strict < on z with lowest-face ties
+                const unsigned long long key = ((unsigned long long)__float_as_uint(pz + 0.0f) << 32) | (unsigned)f;
+                atomicMin(&s_key[q][pi * 8 + pj], key);
+            }
+        }
+    };
 
-        // Is the tile a separable grid (raster column depends on j only, raster row on i only)?  It is
-        // unless the ~1e-7 off-diagonal LAPACK noise of M^-1 flips a rounding; then fall back below.
-        const int col_rx = __shfl(valid ? rx : -1, lane & 7, 64), col_ok = __shfl((int)valid, lane & 7, 64);
-        const int row_ry = __shfl(valid ? ry : -1, lane & 56, 64), row_ok = __shfl((int)valid, lane & 56, 64);
-        const bool sep_lane = valid ? (rx == col_rx && ry == row_ry && col_ok && row_ok) : !(col_ok && row_ok);
-        bool separable = __all(sep_lane);
-        if (separable && f_end > 0) {
-            // ---- face-parallel path: candidates (face bbox meets the tile's raster bbox) are compacted CAND_CAP at a
-            //      time; one lane per candidate face walks only the tile pixels inside its face's raster bbox and merges
-            //      (z, face) keys with 64-bit LDS atomic min.  Any number of candidates is handled in rounds, so a mesh
-            //      that collapses into one tile (early training: a hand a few pixels wide) stays on this path. ----
-            unsigned long long* keys = s_key[wave];
-            keys[lane] = ~0ull;
-            if (lane < 8) {
-                s_colrx[wave][lane] = (short)(col_ok ? rx : -1);                         // lane j: row 0, column j
-                s_colx[wave][lane] = xf;
+    for (int m0 = 0; m0 < tiles_per_wg; m0 += BIN_TILES) {
+        // ---- 1. this wave's tiles of the batch: slots q = wave and wave + 4 ----
+        int tl[2], rx_[2], ry_[2];
+        bool valid_[2], sep_[2], scan_[2];
+        float xf_[2], yf_[2];
+#ifdef CROP_STAMP
+        uint64_t stamp_t0[2];
+        int stamp_n[2] = {0, 0}, stamp_coop[2] = {0, 0};
+#endif
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int q = wave + 4 * h;
+            const int tile = tile_of(m0 + q);
+            tl[h] = tile; rx_[h] = 0; ry_[h] = 0; valid_[h] = false; sep_[h] = false; scan_[h] = false; xf_[h] = 0.f; yf_[h] = 0.f;
+#ifdef CROP_STAMP
+            stamp_t0[h] = __builtin_amdgcn_s_memtime();
+#endif
+            if (lane == 0) { s_bcnt[q] = 0; s_state[q] = 0; s_tbox[q][0] = 0; s_tbox[q][1] = -1; s_tbox[q][2] = 0; s_tbox[q][3] = -1; }
+            if (tile < 0) continue;
+            s_key[q][lane] = ~0ull;
+            const int ty = tile / tiles_axis, tx = tile % tiles_axis;
+            const int i = ty * 8 + (lane >> 3), j = tx * 8 + (lane & 7);
+            // crop pixel -> source pixel of the resized image -> raster pixel (zero padding outside)
+            int ry = 0, rx = 0;
+            bool valid;
+            {
+                const float x = (float)j, y = (float)i;
+                const float sx = (s_mi[0] * x + s_mi[1] * y) + s_mi[2];       // torch CPU matmul order: mul, mul, add, add
+                const float sy = (s_mi[3] * x + s_mi[4] * y) + s_mi[5];
+                const float gx = (sx / cam.img_w) * 2.0f - 1.0f;
+                const float gy = (sy / cam.img_h) * 2.0f - 1.0f;
+                const float fx = rintf((gx + 1.0f) * (cam.img_w / 2.0f) - 0.5f);   // grid_sample unnormalize + nearbyint
+                const float fy = rintf((gy + 1.0f) * (cam.img_h / 2.0f) - 0.5f);
+                valid = fx >= 0.0f && fx < cam.img_w && fy >= 0.0f && fy < cam.img_h;
+                if (valid) {
+                    rx = (int)fx;
+                    const int sy_i = (int)fy;
+                    ry = (sy_i < CROP_MAX_ROWS) ? (int)s_rows[sy_i] : rowmap[sy_i];
+                }
             }
-            if ((lane & 7) == 0) {
-                s_rowry[wave][lane >> 3] = (short)(row_ok ? ry : -1);                    // lane 8i: row i, column 0
-                s_rowy[wave][lane >> 3] = yf;
+            const float xf = pix_to_ndc(S - 1 - rx, S), yf = pix_to_ndc(S - 1 - ry, S);
+            // raster-pixel bbox of the 64 sample points of this tile (wave reduction)
+            int t_x0 = valid ? rx : 0x7fffffff, t_x1 = valid ? rx : -1, t_y0 = valid ? ry : 0x7fffffff, t_y1 = valid ? ry : -1;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                t_x0 = min(t_x0, __shfl_xor(t_x0, o, 64)); t_x1 = max(t_x1, __shfl_xor(t_x1, o, 64));
+                t_y0 = min(t_y0, __shfl_xor(t_y0, o, 64)); t_y1 = max(t_y1, __shfl_xor(t_y1, o, 64));
             }
-            int base = 0;
-            while (base < f_end) {
-                int n_cand = 0;
-                for (; base < f_end && n_cand <= CAND_CAP - 64; base += 64) {
+            // Is the tile a separable grid (raster column depends on j only, raster row on i only)?  It is
+            // unless the ~1e-7 off-diagonal LAPACK noise of M^-1 flips a rounding; then the pixel-parallel scan below.
+            const int col_rx = __shfl(valid ? rx : -1, lane & 7, 64), col_ok = __shfl((int)valid, lane & 7, 64);
+            const int row_ry = __shfl(valid ? ry : -1, lane & 56, 64), row_ok = __shfl((int)valid, lane & 56, 64);
+            const bool sep_lane = valid ? (rx == col_rx && ry == row_ry && col_ok && row_ok) : !(col_ok && row_ok);
+            const bool separable = __all(sep_lane);
+            const bool any_px = t_x1 >= 0;                        // else the whole tile reads the zero padding
+            if (separable && any_px) {
+                if (lane < 8) { s_colrx[q][lane] = (short)(col_ok ? rx : -1); s_colx[q][lane] = xf; }                      // lane j: row 0, column j
+                if ((lane & 7) == 0) { s_rowry[q][lane >> 3] = (short)(row_ok ? ry : -1); s_rowy[q][lane >> 3] = yf; }   // lane 8i: row i, column 0
+                if (lane == 0) { s_tbox[q][0] = t_x0; s_tbox[q][1] = t_x1; s_tbox[q][2] = t_y0; s_tbox[q][3] = t_y1; }
+            }
+            rx_[h] = rx; ry_[h] = ry; valid_[h] = valid; xf_[h] = xf; yf_[h] = yf; sep_[h] = separable && any_px; scan_[h] = !separable && any_px;
+        }
+        __syncthreads();                                 // face boxes (first batch), tile boxes, zeroed counters and keys are in LDS
+        // ---- 2. bin the faces: every thread its faces against the batch's tile boxes ----
+        {
+            int bx0[BIN_TILES], bx1[BIN_TILES], by0[BIN_TILES], by1[BIN_TILES];
+#pragma unroll
+            for (int q = 0; q < BIN_TILES; ++q) { bx0[q] = s_tbox[q][0]; bx1[q] = s_tbox[q][1]; by0[q] = s_tbox[q][2]; by1[q] = s_tbox[q][3]; }
+            for (int f = t; f < F; f += 256) {
+                const uint2 box = s_box[f];
+                const int xlo = (int)(box.x & 0xFFFF), xhi = (int)(box.x >> 16), ylo = (int)(box.y & 0xFFFF), yhi = (int)(box.y >> 16);
+                if (xlo > xhi) continue;
+#pragma unroll
+                for (int q = 0; q < BIN_TILES; ++q) {
+                    if (bx0[q] <= bx1[q] && xlo <= bx1[q] && xhi >= bx0[q] && ylo <= by1[q] && yhi >= by0[q]) {
+                        const int pos = atomicAdd(&s_bcnt[q], 1);
+                        if (pos < CBIN_CAP) s_bin[q][pos] = (unsigned short)f;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- 3. this wave's tiles: light ones now, heavy ones are left to pass 4 ----
+        auto write_tile = [&](const int h, const int q) {
+            float bz = INFINITY;
+            int bf = -1;
+            if (sep_[h]) {
+                const unsigned long long kmin = s_key[q][lane];
+                if (kmin != ~0ull) { bz = __uint_as_float((unsigned)(kmin >> 32)); bf = (int)(kmin & 0xFFFFFFFFu); }
+            } else if (scan_[h]) {
+                // ---- pixel-parallel scan (a tile that is not a separable grid, or whose list overflowed): every lane z-tests its
+                //      own pixel against each face whose box meets the tile, in ascending face order ----
+                int t_x0 = valid_[h] ? rx_[h] : 0x7fffffff, t_x1 = valid_[h] ? rx_[h] : -1, t_y0 = valid_[h] ? ry_[h] : 0x7fffffff, t_y1 = valid_[h] ? ry_[h] : -1;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    t_x0 = min(t_x0, __shfl_xor(t_x0, o, 64)); t_x1 = max(t_x1, __shfl_xor(t_x1, o, 64));
+                    t_y0 = min(t_y0, __shfl_xor(t_y0, o, 64)); t_y1 = max(t_y1, __shfl_xor(t_y1, o, 64));
+                }
+                const float xf = xf_[h], yf = yf_[h];
+                for (int base = 0; base < F; base += 64) {
                     const int fme = base + lane;
                     bool hit = false;
                     if (fme < F) {
@@ -471,113 +591,91 @@ __global__ __launch_bounds__(256) void render_crop_fwd_kernel(const float* __res
                         const int xlo = (int)(box.x & 0xFFFF), xhi = (int)(box.x >> 16), ylo = (int)(box.y & 0xFFFF), yhi = (int)(box.y >> 16);
                         hit = xlo <= xhi && xlo <= t_x1 && xhi >= t_x0 && ylo <= t_y1 && yhi >= t_y0;
                     }
-                    const unsigned long long mask = __ballot(hit);
-                    if (hit) s_cand[wave][n_cand + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)fme;
-                    n_cand += __popcll(mask);
-                }
-                __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): the wave's own LDS writes have landed
-                __builtin_amdgcn_wave_barrier();
-                for (int c0 = 0; c0 < n_cand; c0 += 64) {
-                    if (c0 + lane < n_cand) {
-                        const int f = s_cand[wave][c0 + lane];
-                        const uint2 box = s_box[f];
-                        const int xlo = (int)(box.x & 0xFFFF), xhi = (int)(box.x >> 16), ylo = (int)(box.y & 0xFFFF), yhi = (int)(box.y >> 16);
-                        // pixel sub-rectangle [i0,i1] x [j0,j1] of the tile inside the face's raster bbox
-                        int j0 = 8, j1 = -1, i0 = 8, i1 = -1;
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            const int cx = s_colrx[wave][q], cy = s_rowry[wave][q];
-                            if (cx >= xlo && cx <= xhi) { j0 = min(j0, q); j1 = max(j1, q); }
-                            if (cy >= ylo && cy <= yhi) { i0 = min(i0, q); i1 = max(i1, q); }
-                        }
-                        if (j0 <= j1 && i0 <= i1) {
-                            const uint2 fi = s_fidx[f];
-                            const int a = (int)(fi.x & 0xFFFF) * 3, c1 = (int)(fi.x >> 16) * 3, c2 = (int)fi.y * 3;
-                            const float x0 = s_pv[a], y0 = s_pv[a + 1], z0 = s_pv[a + 2];
-                            const float x1 = s_pv[c1], y1 = s_pv[c1 + 1], z1 = s_pv[c1 + 2];
-                            const float x2 = s_pv[c2], y2 = s_pv[c2 + 1], z2 = s_pv[c2 + 2];
-                            const float xmin = min3(x0, x1, x2), xmax = max3(x0, x1, x2);
-                            const float ymin = min3(y0, y1, y2), ymax = max3(y0, y1, y2);
-                            const float area = edge_fn(x2, y2, x0, y0, x1, y1) + kEps;
-                            for (int pi = i0; pi <= i1; ++pi) {
-                                const float py = s_rowy[wave][pi];
-                                if (s_rowry[wave][pi] < 0 || py > ymax || py < ymin) continue;
-                                for (int pj = j0; pj <= j1; ++pj) {
-                                    const float px = s_colx[wave][pj];
-                                    if (s_colrx[wave][pj] < 0 || px > xmax || px < xmin) continue;
-                                    const float e0 = edge_fn(px, py, x1, y1, x2, y2);
-                                    const float e1 = edge_fn(px, py, x2, y2, x0, y0);
-                                    const float e2 = edge_fn(px, py, x0, y0, x1, y1);
-                                    if (area > 0.0f) { if (!(e0 > 0.0f && e1 > 0.0f && e2 > 0.0f)) continue; }
-                                    else if (area < 0.0f) { if (!(e0 < 0.0f && e1 < 0.0f && e2 < 0.0f)) continue; }
-                                    const float w0 = e0 / area, w1 = e1 / area, w2 = e2 / area;
-                                    const float pz = w0 * z0 + w1 * z1 + w2 * z2;
-                                    if (pz < 0.0f) continue;
-                                    if (!(w0 > 0.0f && w1 > 0.0f && w2 > 0.0f)) continue;
-                                    // (z bits, face) ordered lexicographically == strict < on z with lowest-face ties
-                                    const unsigned long long key = ((unsigned long long)__float_as_uint(pz + 0.0f) << 32) | (unsigned)f;
-                                    atomicMin(&keys[pi * 8 + pj], key);
-                                }
-                            }
-                        }
+                    unsigned long long mask = __ballot(hit);
+                    while (mask) {
+                        const int bit = __ffsll((long long)mask) - 1;
+                        mask &= mask - 1;
+                        const int f = base + bit;
+                        const int a = faces[f * 3] * 3, c1 = faces[f * 3 + 1] * 3, c2 = faces[f * 3 + 2] * 3;     // wave-uniform
+                        const float x0 = s_pv[a], y0 = s_pv[a + 1], x1 = s_pv[c1], y1 = s_pv[c1 + 1], x2 = s_pv[c2], y2 = s_pv[c2 + 1];
+                        const float xmin = min3(x0, x1, x2), xmax = max3(x0, x1, x2);
+                        const float ymin = min3(y0, y1, y2), ymax = max3(y0, y1, y2);
+                        if (!valid_[h] || xf > xmax || xf < xmin || yf > ymax || yf < ymin) continue;
+                        const float area = edge_fn(x2, y2, x0, y0, x1, y1) + kEps;
+                        const float e0 = edge_fn(xf, yf, x1, y1, x2, y2);
+                        const float e1 = edge_fn(xf, yf, x2, y2, x0, y0);
+                        const float e2 = edge_fn(xf, yf, x0, y0, x1, y1);
+                        if (area > 0.0f) { if (!(e0 > 0.0f && e1 > 0.0f && e2 > 0.0f)) continue; }
+                        else if (area < 0.0f) { if (!(e0 < 0.0f && e1 < 0.0f && e2 < 0.0f)) continue; }
+                        const float w0 = e0 / area, w1 = e1 / area, w2 = e2 / area;
+                        const float z0 = s_pv[a + 2], z1 = s_pv[c1 + 2], z2 = s_pv[c2 + 2];
+                        const float pz = w0 * z0 + w1 * z1 + w2 * z2;
+                        if (pz < 0.0f) continue;
+                        if (!(w0 > 0.0f && w1 > 0.0f && w2 > 0.0f)) continue;
+                        if (bf < 0 || pz < bz) { bz = pz; bf = f; }      // faces visited in ascending order: ties keep the lowest
                     }
                 }
-                __builtin_amdgcn_s_waitcnt(0xc07f);               // this round's reads of s_cand are done before it is refilled
-                __builtin_amdgcn_wave_barrier();
             }
-            const unsigned long long k = keys[lane];
-            if (k != ~0ull) { bz = __uint_as_float((unsigned)(k >> 32)); bf = (int)(k & 0xFFFFFFFFu); }
-        } else if (!separable) {
-        // ---- pixel-parallel path (non-separable tile): every lane z-tests its own pixel against each candidate ----
-        for (int base = 0; base < f_end; base += 64) {
-            const int fme = base + lane;
-            bool hit = false;
-            if (fme < F) {
-                const uint2 box = s_box[fme];
-                const int xlo = (int)(box.x & 0xFFFF), xhi = (int)(box.x >> 16), ylo = (int)(box.y & 0xFFFF), yhi = (int)(box.y >> 16);
-                hit = xlo <= xhi && xlo <= t_x1 && xhi >= t_x0 && ylo <= t_y1 && yhi >= t_y0;
+            // zbuf -> background 0 (:1085) -> zero-padded nearest crop -> normalize_img (:1289-1299)
+            float d = (bf >= 0) ? bz : -1.0f;
+            if (d <= 0.0f) d = 0.0f;
+            if (!valid_[h]) d = 0.0f;
+            float o = d;
+            if (normalise) {
+                if (o == -1.0f || o == 0.0f) o = zmax_c;
+                if (o > zmax_c) o = zmax_c;
+                if (o < zmin_c) o = zmin_c;
+                o = (o - cz) / half;
             }
-            unsigned long long mask = __ballot(hit);
-            while (mask) {
-                const int bit = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                const int f = base + bit;
-                const uint2 fi = s_fidx[f];                       // wave-uniform address: LDS broadcast
-                const int a = (int)(fi.x & 0xFFFF) * 3, c1 = (int)(fi.x >> 16) * 3, c2 = (int)fi.y * 3;
-                const float x0 = s_pv[a], y0 = s_pv[a + 1], x1 = s_pv[c1], y1 = s_pv[c1 + 1], x2 = s_pv[c2], y2 = s_pv[c2 + 1];
-                const float xmin = min3(x0, x1, x2), xmax = max3(x0, x1, x2);
-                const float ymin = min3(y0, y1, y2), ymax = max3(y0, y1, y2);
-                if (!valid || xf > xmax || xf < xmin || yf > ymax || yf < ymin) continue;
-                const float area = edge_fn(x2, y2, x0, y0, x1, y1) + kEps;
-                const float e0 = edge_fn(xf, yf, x1, y1, x2, y2);
-                const float e1 = edge_fn(xf, yf, x2, y2, x0, y0);
-                const float e2 = edge_fn(xf, yf, x0, y0, x1, y1);
-                // exact pre-test: e/area > 0 needs equal, non-zero signs (area == 0: leave it to the division)
-                if (area > 0.0f) { if (!(e0 > 0.0f && e1 > 0.0f && e2 > 0.0f)) continue; }
-                else if (area < 0.0f) { if (!(e0 < 0.0f && e1 < 0.0f && e2 < 0.0f)) continue; }
-                const float w0 = e0 / area, w1 = e1 / area, w2 = e2 / area;
-                const float z0 = s_pv[a + 2], z1 = s_pv[c1 + 2], z2 = s_pv[c2 + 2];
-                const float pz = w0 * z0 + w1 * z1 + w2 * z2;
-                if (pz < 0.0f) continue;
-                if (!(w0 > 0.0f && w1 > 0.0f && w2 > 0.0f)) continue;
-                if (bf < 0 || pz < bz) { bz = pz; bf = f; }      // faces visited in ascending order: ties keep the lowest
+            const int tile = tl[h];
+            const int i = (tile / tiles_axis) * 8 + (lane >> 3), j = (tile % tiles_axis) * 8 + (lane & 7);
+            const int64_t idx = ((int64_t)b * crop + i) * crop + j;
+            img[idx] = o;
+            if (p2f) p2f[idx] = (valid_[h] && bf >= 0 && bz > 0.0f) ? bf : -1;
+#ifdef CROP_STAMP
+            if (lane == 0 && crop_stamp_buf) {
+                unsigned long long* st = crop_stamp_buf + ((size_t)b * n_tiles + tile) * 4;
+                st[0] = __builtin_amdgcn_s_memtime() - stamp_t0[h]; st[1] = (unsigned long long)stamp_n[h]; st[2] = (unsigned long long)stamp_coop[h]; st[3] = stamp_t0[h] - stamp_k0;
+            }
+#endif
+        };
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int q = wave + 4 * h;
+            if (tl[h] < 0) continue;
+            const int n = sep_[h] ? s_bcnt[q] : 0;
+#ifdef CROP_STAMP
+            stamp_n[h] = n;
+#endif
+            if (n > CBIN_CAP) { sep_[h] = false; scan_[h] = true; }          // the list overflowed: scan all faces instead
+            if (sep_[h] && n > HEAVY) {
+                if (lane == 0) s_state[q] = 1;
+#ifdef CROP_STAMP
+                stamp_coop[h] = 1;
+#endif
+                continue;
+            }
+            if (sep_[h])
+                for (int c0 = 0; c0 < n; c0 += 64)
+                    if (c0 + lane < n) face_lane((int)s_bin[q][c0 + lane], q);
+            write_tile(h, q);                            // (LDS operations of one wave execute in order: its atomics precede its reads)
+        }
+        __syncthreads();
+        // ---- 4. the heavy tiles of the batch, all four waves on each; the owner writes it ----
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                    // (h stays a compile-time index of the per-tile registers)
+#pragma unroll 1
+            for (int r = 0; r < 4; ++r) {
+                const int q = r + 4 * h;
+                if (s_state[q] == 0) continue;           // (the same value for every wave: written before the barrier above)
+                const int n = min(s_bcnt[q], CBIN_CAP);
+                for (int c0 = wave * 64; c0 < n; c0 += 256)
+                    if (c0 + lane < n) face_lane((int)s_bin[q][c0 + lane], q);
+                __syncthreads();
+                if (r == wave) write_tile(h, q);
             }
         }
-        }
-        // zbuf -> background 0 (:1085) -> zero-padded nearest crop -> normalize_img (:1289-1299)
-        float d = (bf >= 0) ? bz : -1.0f;
-        if (d <= 0.0f) d = 0.0f;
-        if (!valid) d = 0.0f;
-        float o = d;
-        if (normalise) {
-            if (o == -1.0f || o == 0.0f) o = zmax_c;
-            if (o > zmax_c) o = zmax_c;
-            if (o < zmin_c) o = zmin_c;
-            o = (o - cz) / half;
-        }
-        const int64_t idx = ((int64_t)b * crop + i) * crop + j;
-        img[idx] = o;
-        if (p2f) p2f[idx] = (valid && bf >= 0 && bz > 0.0f) ? bf : -1;
+        __syncthreads();                                 // the next batch reuses the lists, counters and keys
     }
 }
 
@@ -662,7 +760,7 @@ inline int crop_wg_per_sample(int B, int tiles) {
     // ~2 workgroups per CU on the 256-CU chip (each re-stages the sample's vertices / face boxes),
     // at least one tile per wave
     int g = 1;
-    int target = 1024;
+    int target = (B > 32) ? 2048 : 1024;       // measured at B = 32 / 64 / 128: 1024 -> 49.8 / 118.9 / 171.3 us, 2048 -> 59.3 / 111.8 / 133.3 us
     if (const char* e = getenv("DSF_CROP_WG_TARGET")) target = atoi(e);
     while (g < tiles / 4 && B * g < target) g *= 2;
     return g;
@@ -742,6 +840,13 @@ extern "C" int dsf_render_crop_forward(const float* verts, const int32_t* faces,
                        resize_rowmap, center_z, cube_z, *cam, V, F, raster_size, crop, g, img, pix_to_face);
     return dsf_launch_status();
 }
+
+#ifdef CROP_STAMP
+extern "C" int dsf_crop_stamp_buffer(void* p) {
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+    return hipMemcpyToSymbol(HIP_SYMBOL(crop_stamp_buf), &q, sizeof(q)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int dsf_render_crop_backward(const float* verts, const int32_t* faces, const float* minv,
                                         const int32_t* resize_rowmap, const float* center_z, const float* cube_z,
