@@ -18,6 +18,7 @@
 // metric/meshLoss.py:377-395) -- and, since round 4, only against triangles whose bounding
 // sphere can hold a minimiser (the cull described above that kernel).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -340,7 +341,14 @@ __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __rest
         }
     }
     int w = blockIdx.x;
-    const int split = w % splits; w /= splits;
+    int split;
+    if (seg) {
+        // labelled clouds: the split index varies SLOWEST.  Workgroups are dealt round-robin over the 8 XCDs, and the groups of a
+        // part are dealt to splits 0, 1, ...: with `split = id % 8` every non-empty workgroup of a launch whose parts have one or
+        // two groups each landed on XCDs 0 and 1 (a quarter of the chip: 361 us against 118 for one workgroup per part)
+        const int per_split = (int)gridDim.x / splits;
+        split = w / per_split; w %= per_split;
+    } else { split = w % splits; w /= splits; }
     const int part = w % n_parts;
     const int b = w / n_parts;
     const float* vb = verts + (int64_t)b * V * 3;
@@ -349,7 +357,48 @@ __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __rest
 
     int pbeg, n_mine;                  // this workgroup's points: s_list[0 .. n_mine) + pbeg, or the plain range when !listed
     bool listed = true;
-    if (seg) {
+    int g_first = 0, g_step = 1;       // the groups of 64 listed points this workgroup walks: g_first, g_first + g_step, ...
+    if (seg && P <= LIST_CAP) {
+        // Labelled cloud (JointICPLoss): EVERY workgroup of a (sample, part) compacts the part's members of the whole cloud, in
+        // index order (each wave a contiguous quarter: count, exchange, write -- no LDS atomics, so all `splits` workgroups hold
+        // the same list), and takes every splits-th group of 64 of them.  Round 4 cut the cloud into index ranges instead, one
+        // workgroup each: with the labels of a real depth crop (most points on the palm and two or three fingers; uniform
+        // labels only in the synthetic timing scenario) one workgroup then owned ~20 groups and the launch was its latency --
+        // 1.4 ms per launch in the first steps of config 5, 0.38 ms in its fitted state, against 0.2 / 0.14 ms with the groups
+        // dealt out.  Which workgroup evaluates a point does not change its result.
+        const int quarter = ((P + 255) / 256) * 64;                     // points per wave, a multiple of 64
+        const int w0 = wave * quarter, w1 = min(P, w0 + quarter);
+        constexpr int LAB_IT = LIST_CAP / 256;                          // <= 10 labels per lane, all loads in flight at once
+        bool mine[LAB_IT];
+        int cnt = 0;
+#pragma unroll
+        for (int it = 0; it < LAB_IT; ++it) {
+            const int p = w0 + it * 64 + lane;
+            const bool in = it * 64 < quarter && p < w1;
+            const int64_t lab = in ? seg[(int64_t)b * P + p] : 0;
+            if (in && part == 0 && split == 0 && (lab < 1 || lab > n_parts)) {          // no part: the reference's masked-out zeros
+                dists[(int64_t)b * P + p] = 0.f;
+                idxs[(int64_t)b * P + p] = -1;
+            }
+            mine[it] = in && lab == part + 1;
+        }
+#pragma unroll
+        for (int it = 0; it < LAB_IT; ++it) cnt += __popcll(__ballot(mine[it]));
+        if (lane == 0) s_wsum[wave] = cnt;
+        __syncthreads();
+        int off = 0;
+        for (int q = 0; q < wave; ++q) off += s_wsum[q];
+        n_mine = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+#pragma unroll
+        for (int it = 0; it < LAB_IT; ++it) {
+            const unsigned long long mask = __ballot(mine[it]);
+            if (mine[it]) s_list[off + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)(w0 + it * 64 + lane);
+            off += __popcll(mask);
+        }
+        __syncthreads();
+        pbeg = 0;
+        g_first = split; g_step = splits;
+    } else if (seg) {
         const int per = (P + splits - 1) / splits;
         pbeg = split * per;
         const int pend = min(P, pbeg + per);
@@ -467,7 +516,7 @@ __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __rest
     };
     const int n_blocks = (f1 - f0 + bs - 1) / bs;
     __syncthreads();                                     // the sort scratch (which shares the stage's bytes) is dead
-    for (int g = 0; g < n_groups; ++g) {
+    for (int g = g_first; g < n_groups; g += g_step) {
         bool live;
         int p;
         if (listed) { live = g * GP + lane < n_mine; p = live ? pbeg + s_list[g * GP + lane] : 0; }
@@ -669,7 +718,10 @@ extern "C" int dsf_mesh_point_dist_forward(const float* verts, const float* poin
     // seg == NULL: every point meets every triangle -> 64 points per workgroup (4 waves share them and split the triangles);
     // with labels one workgroup per (sample, part) compacts its part's members of the cloud (<= LIST_CAP points per range)
     // and walks them in groups of 64.
-    int splits = seg ? (P + SEG_RANGE - 1) / SEG_RANGE : (P + GP - 1) / GP;
+    // labelled clouds that fit the LDS list: 8 workgroups per (sample, part) deal out the part's groups of 64 members between them
+    // (one per 256 points of the cloud); larger clouds: one workgroup per SEG_RANGE points
+    int splits = seg ? (P <= LIST_CAP ? (P + 255) / 256 : (P + SEG_RANGE - 1) / SEG_RANGE) : (P + GP - 1) / GP;
+    if (const char* e = getenv("DSF_PFD_SPLITS")) { const int v = atoi(e); if (seg && P <= LIST_CAP && v >= 1 && v <= 64) splits = v; }
     if (splits < 1) splits = 1;
     // unlabelled clouds: B * splits culled workgroups + B * ceil(P / 256) exhaustive ones; per sample one of the two sets exits at once
     const int culled = B * n_parts * splits;

@@ -47,3 +47,13 @@ def scenario(name, mesh):
 scenario("cloud on the mesh", mesh)
 scenario("mesh shifted by half its size", mesh + 0.5 * (mesh.amax(1, keepdim=True) - mesh.amin(1, keepdim=True)))
 scenario("mesh collapsed to 1 %", mesh.mean(1, keepdim=True) + 0.01 * (mesh - mesh.mean(1, keepdim=True)))
+
+# the labelled launch (JointICPLoss's kernel call alone) under three label distributions: the workgroups of a (sample, part) deal
+# the part's groups of 64 member points out between them (round 5; round 4 gave each index range of the cloud one workgroup, and
+# the labels of a real depth crop -- most points on the palm -- made the launch the latency of one workgroup: 1.4 ms in config 5)
+from dsf_amd import ops
+from dsf_amd.metric.meshLoss import _cached_parts
+cat, first = _cached_parts(list(mano.joint_faces), mesh.device)
+with torch.no_grad():
+    for name, lab in (("labels of seg_pcl (cloud sampled from the vertices)", seg), ("every point in part 13", torch.full_like(seg, 13)), ("no labelled point", torch.zeros_like(seg))):
+        print("labelled launch, %s: %.0f us" % (name, timed(lambda: ops.MeshPointDistance.apply(mesh, pcl, cat, first, lab, 15))))
