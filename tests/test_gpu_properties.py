@@ -154,3 +154,91 @@ def test_img2pcl_and_gfm_round_trip_full_size(render, batch):
     seen = (maps[:, 63:] > 0).flatten(2).any(-1)                     # joints with heat support
     assert seen.float().mean() > 0.5
     assert (back - juvd)[seen].abs().max() < 0.06
+
+
+def test_crop_kernel_is_independent_of_its_launch_shape(render, batch, monkeypatch):
+    """Round 5: the crop rasteriser bins faces per tile, BIN_TILES tiles of a workgroup at a time, tiles spread over the
+    workgroups by Morton code, heavy tiles shared by four waves.  Every launch shape -- 4, 8, 16, 32, 64, 256 tiles per
+    workgroup (one to 32 batches), the Morton and the linear tile order, a batch whose samples are rendered four at a time --
+    must give the bits of every other: the image and the face index of each pixel depend on its sample only."""
+    from dsf_amd import ops
+    p, c, cube, v, j = batch
+    mano = render.mano_layer
+    verts = (v * cube.unsqueeze(1) / 2 + c.unsqueeze(1)).contiguous()
+    c2, M, _, _ = ops.crop_setup(c, cube, render.cam, 128)
+    minv = torch.linalg.inv_ex(M)[0].contiguous()
+    cz, cbz = c2[:, 2].contiguous(), cube[:, 2].contiguous()
+
+    def run(sl=slice(None)):
+        return ops.RenderCropFunction.apply(verts[sl].contiguous(), mano.faces_i32, minv[sl].contiguous(), render.resize_rowmap,
+                                            cz[sl].contiguous(), cbz[sl].contiguous(), render.cam, 640, 128)
+    monkeypatch.delenv("DSF_CROP_WG_TARGET", raising=False)
+    img, p2f = run()
+    assert (p2f >= 0).float().mean() > 0.03
+    for target in ("64", "128", "256", "512", "1024", "4096", "16384"):       # 1 ... 64 workgroups per sample at B = 64
+        monkeypatch.setenv("DSF_CROP_WG_TARGET", target)
+        a, f = run()
+        assert torch.equal(a, img) and torch.equal(f, p2f), target
+    monkeypatch.delenv("DSF_CROP_WG_TARGET")
+    for b0 in range(0, B, 4):                                                  # 4 samples per launch: 64 workgroups per sample
+        a, f = run(slice(b0, b0 + 4))
+        assert torch.equal(a, img[b0:b0 + 4]) and torch.equal(f, p2f[b0:b0 + 4]), b0
+    a, f = run(slice(5, 8))                                                    # 3 samples: a workgroup count that is no power of two
+    assert torch.equal(a, img[5:8]) and torch.equal(f, p2f[5:8])
+
+
+def test_crop_sizes_other_than_128_agree_with_the_full_raster(render, batch):
+    """64- and 256-pixel crops take the linear tile order (the Morton order is for 16 x 16 tiles): every (face, depth) pair
+    the crop kernel produces must exist in the full raster of the same mesh, and a repeat must be bitwise equal."""
+    from dsf_amd import ops
+    p, c, cube, v, j = batch
+    mano = render.mano_layer
+    sl = slice(0, 6)
+    verts = (v * cube.unsqueeze(1) / 2 + c.unsqueeze(1))[sl].contiguous()
+    fr = render.rasterizer(verts)
+    for crop in (64, 256):
+        c2, M, _, _ = ops.crop_setup(c[sl].contiguous(), cube[sl].contiguous(), render.cam, crop)
+        minv = torch.linalg.inv_ex(M)[0].contiguous()
+        img, p2f = ops.RenderCropFunction.apply(verts, mano.faces_i32, minv, render.resize_rowmap, None, None, render.cam, 640, crop)
+        img2, p2f2 = ops.RenderCropFunction.apply(verts, mano.faces_i32, minv, render.resize_rowmap, None, None, render.cam, 640, crop)
+        assert img.shape == (6, 1, crop, crop) and torch.equal(img, img2) and torch.equal(p2f, p2f2)
+        assert (p2f >= 0).float().mean() > 0.03
+        for b_ in range(6):
+            covered = p2f[b_] >= 0
+            zfull = fr.zbuf[b_, ..., 0]
+            ffull = fr.pix_to_face[b_, ..., 0] - b_ * 1554
+            vals = set(zip(ffull[ffull >= 0].tolist(), zfull[ffull >= 0].tolist()))
+            assert set(zip(p2f[b_][covered].tolist(), img[b_, 0][covered].tolist())) <= vals, (crop, b_)
+
+
+def test_labelled_point_to_mesh_is_independent_of_how_groups_are_dealt(render, batch, monkeypatch):
+    """Round 5: the workgroups of a (sample, part) deal the part's 64-point groups out between them.  One, three, eight or
+    sixteen workgroups per part, labels concentrated in one part, spread evenly, or absent: same distances, same indices."""
+    from dsf_amd import ops
+    from dsf_amd.metric.meshLoss import _cached_parts
+    p, c, cube, v, j = batch
+    mano = render.mano_layer
+    jx, mesh = render.get_mesh_xyz(p)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    for P in (2048, 1000, 130):
+        idx = torch.randint(0, 779, (B, P), device="cuda", generator=g)
+        pcl = (torch.gather(mesh, 1, idx[..., None].expand(-1, -1, 3)) + 0.03 * torch.randn(B, P, 3, device="cuda", generator=g)).contiguous()
+        seg = mano.seg_pcl(jx, jx, mesh, pcl)
+        cat, first = _cached_parts(list(mano.joint_faces), mesh.device)
+        labs = {"seg_pcl": seg, "one part": torch.full_like(seg, 13), "none": torch.zeros_like(seg),
+                "uniform": torch.randint(0, 16, seg.shape, device="cuda", generator=g).to(seg.dtype)}
+        for name, lab in labs.items():
+            monkeypatch.setenv("DSF_PFD_SPLITS", "1")
+            d1, i1 = ops.MeshPointDistance.apply(mesh, pcl, cat, first, lab, 15)
+            for s_ in ("3", "8", "16"):
+                monkeypatch.setenv("DSF_PFD_SPLITS", s_)
+                d, i = ops.MeshPointDistance.apply(mesh, pcl, cat, first, lab, 15)
+                assert torch.equal(d, d1) and torch.equal(i, i1), (P, name, s_)
+            monkeypatch.delenv("DSF_PFD_SPLITS")
+            d, i = ops.MeshPointDistance.apply(mesh, pcl, cat, first, lab, 15)
+            assert torch.equal(d, d1) and torch.equal(i, i1), (P, name)
+            if name == "none":
+                assert (i1 == -1).all() and (d1 == 0).all()
+            if name == "one part":
+                lo, hi = int(first[12]), int(first[13])
+                assert ((i1 >= lo) & (i1 < hi)).all()
