@@ -181,6 +181,47 @@ def same_step_on_fp32_mfma(step, tgt, B, steps=10, warmup=3):
                     "5e-7 of the largest output (tests/test_gpu_conv.py)"}
 
 
+def gpu_time_per_call_us(fn, launches, warmup=5, capture=True):
+    """GPU time per call of ``fn`` (every kernel it issues, layout copies included) WITHOUT the host: ``launches`` calls are
+    captured into one HIP graph on a side stream and the replay is bracketed by events.  Rounds 1-4 timed eager loops, which for
+    a 20-50 us operation measure the Python call (torch.empty, ctypes, autograd.Function: 30-70 us) -- the crop rasteriser's
+    "25 us floor" and the 71 us soft-argmax decode of the round-4 tables were that.  Falls back to the eager loop for an
+    operation that cannot be captured (a host synchronisation inside)."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    try:
+        if not capture:                                  # (an autograd backward pass inside a capture crashes this runtime: eager)
+            raise RuntimeError("eager")
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                for _ in range(launches):
+                    fn()
+            graph.replay()
+            side.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(side)
+            graph.replay()
+            e1.record(side)
+            side.synchronize()
+        torch.cuda.current_stream().wait_stream(side)
+        us = e0.elapsed_time(e1) * 1e3 / launches
+        del graph
+        return us, "graph replay of %d calls" % launches
+    except Exception:
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(launches):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / launches, "eager loop of %d calls (host time included)" % launches
+
+
 def crop_kernel_roofline(render, B, launches=200):
     """Live timing of the fused crop rasteriser (dsf_render_crop_forward) with HIP events on the stream
     it is launched on.  Algorithmic bytes per image (SURVEY 8d, K1 crop mode): read verts 779*12 = 9,348 B,
@@ -197,16 +238,7 @@ def crop_kernel_roofline(render, B, launches=200):
         cz, cbz = c2[:, 2].contiguous(), cube[:, 2].contiguous()
         run = lambda: ops.RenderCropFunction.apply(verts, mano.faces_i32, minv, render.resize_rowmap, cz, cbz,
                                                    render.cam, 640, 128)
-        for _ in range(10):
-            run()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(launches):
-            run()
-        e1.record()
-        torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / launches
+        us, how = gpu_time_per_call_us(run, launches, warmup=10)
     bytes_per_launch = B * (779 * 12 + 128 * 128 * 4 + 128 * 128 * 4)
     achieved = bytes_per_launch / (us * 1e-6) / 1e9
     # VALU roofline (what actually bounds it): the kernel's work is one coverage evaluation per (crop pixel, face) pair whose
@@ -247,17 +279,18 @@ def crop_kernel_roofline(render, B, launches=200):
             "images_per_s": round(B / (us * 1e-6), 1), "hbm_achieved": round(achieved, 2), "hbm_peak": HBM_PEAK_GBS,
             "hbm_frac": round(achieved / HBM_PEAK_GBS, 5), **pmc_traffic("render_crop_fwd_kernel"),
             "bytes_per_launch": bytes_per_launch,
+            "timed_as": how,
             "note": "VALU / latency-bound, not a bandwidth kernel: 4.5 MB of algorithmic traffic per launch.  `frac` is a MODEL "
-                    "count (coverage evaluations x instructions per evaluation) over the VALU issue peak: the lanes of the "
-                    "face-parallel path walk boxes of different sizes (divergence), and ~25 us of the launch are the "
-                    "projection + face boxes every workgroup repeats and the walk over empty tiles (tools/perf_crop.py); "
-                    "2 launches per step = 0.8 % of it, 0.5 % of config 5: left as it is (DESIGN.md section 5)"}
+                    "count (coverage evaluations x instructions per evaluation) over the VALU issue peak.  Round 5: faces binned "
+                    "into per-tile LDS lists by the whole workgroup, heavy tiles shared by four waves, tiles Morton-interleaved "
+                    "over the workgroups (78 -> 48 us at B = 32; tools/crop_stamps.py shows where a launch's cycles go)"}
 
 
 def geometry_rooflines(render, B, launches=50):
     """"report each fraction separately" -- the geometry kernels of the path timed alone with HIP events on the stream
     they are launched on (torch's current stream), each against the bound that applies to it.  Sizes = one GPU's share of the
-    BASELINE configuration that uses the kernel (B samples, 2048-point clouds, 1554 faces, 21 joints, 84-channel 64x64 maps)."""
+    BASELINE configuration that uses the kernel (B samples, 2048-point clouds, 1554 faces, 21 joints, 84-channel 64x64 maps).
+    Timed host-free (gpu_time_per_call_us): a row is the GPU time of the whole API call, layout copies and small helper kernels included."""
     from dsf_amd.metric.meshLoss import ICPLoss, JointICPLoss
     from dsf_amd.train_step import synthetic_batch
     from dsf_amd.util.generateFeature import GFM
@@ -266,17 +299,8 @@ def geometry_rooflines(render, B, launches=50):
     p, c, cube = synthetic_batch(B, "cuda", seed=321)
     P = 2048
 
-    def timed(fn):
-        for _ in range(5):
-            fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(launches):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) * 1e3 / launches
+    def timed(fn, capture=True):
+        return gpu_time_per_call_us(fn, launches, capture=capture)[0]
     rows = []
     valu_peak = 256 * 4 * 32 * 2.4e9                       # lane-instructions per second (as in roofline_raster)
 
@@ -305,8 +329,8 @@ def geometry_rooflines(render, B, launches=50):
                              "arithmetic incl. 5 IEEE divisions).  Round 3's brute-force kernel: 712 us at B = 64 = 0.29 T/s"})
         us = timed(lambda: JointICPLoss(mesh, pcl, mano.joint_faces, seg))
         rows.append({"id": "K3p", "kernel": "mesh_point_fwd_kernel (JointICPLoss: points x the triangles of their part, 15 parts)",
-                     "avg_launch_us": round(us, 2), "bound": "valu", "note": "one (sample, part) workgroup per part: latency of the "
-                     "largest part's point list; no separate model"})
+                     "avg_launch_us": round(us, 2), "bound": "valu", "note": "eight workgroups per (sample, part) deal the part's "
+                     "64-point groups out between them (round 5); includes the masked per-part means around the kernel; no separate model"})
         # K5: MANO layer (two launches each way since round 4)
         q = p.clone().requires_grad_(True)
     from dsf_amd import ops
@@ -318,7 +342,7 @@ def geometry_rooflines(render, B, launches=50):
             "vertices / joints / saved state out per sample + the 1.4 MB of model constants once")
     v, j = ops.ManoPackedFunction.apply(mano._native(), q, 1000.0, 1.0)
     gv, gj = torch.randn_like(v), torch.randn_like(j)
-    us = timed(lambda: torch.autograd.grad([v, j], q, [gv, gj], retain_graph=True))
+    us = timed(lambda: torch.autograd.grad([v, j], q, [gv, gj], retain_graph=True), capture=False)
     hbm_row("K5b", "mano_skin_bwd_kernel + mano_blend_bwd_kernel (backward)", us,
             B * (779 * 12 + 21 * 12 + 5248 * 4 + 2 * 2560 * 4 + 62 * 4 + const_bytes),
             "latency-bound: 256-thread workgroups that fit beside two convolution workgroups per CU (78 us as one 1024-thread "
