@@ -21,8 +21,8 @@ def _shared_gpu_retry(attempts=4):
     """These tests put TWO processes on the ONE GPU of the test box, so kernels of the two ranks share CUs.  On this pool a
     kernel that is correct on a GPU of its own can then return wrong bits in lanes 48-63 of a wave: round 3 saw it in kernels
     with IEEE divisions beside other processes (profiles/r03_gpu_sharing.txt, stand-alone reproducer
-    tools/platform/tiny_kernel_soak.hip), round 4 in a packed-FP32 loop beside conv_x6 workgroups of the SAME process
-    (tools/platform/mano_beside_conv_x6.py; that kernel is built without the SLP vectoriser since).  One process per GPU -- the
+    tools/platform/tiny_kernel_soak.hip), round 4 in packed-FP32 code beside conv_x6 workgroups of the SAME process (round 5:
+    an op_sel:[0,1] packed instruction beside bf16 MFMAs, tools/platform/pk_opsel_beside_mfma_lds.hip; no shipped kernel has one).  One process per GPU -- the
     deployment, and every single-process test of this suite -- does not show it (deterministic-mode soaks bitwise equal,
     tests/test_gpu_determinism.py::test_every_kernel_of_a_step_is_stable_beside_convolution_workgroups).  So a comparison that
     fails here is repeated -- a defect of the data-parallel logic fails every attempt -- but NOT silently: every repeat is
