@@ -86,7 +86,7 @@ def pmc_traffic(kernel):
     process, so the figure is read back from the profile of the same command; null when the file has no entry."""
     here = os.path.dirname(os.path.abspath(__file__))
     mid = "" if PMC_CONFIG[0] == 2 else "_config%d" % PMC_CONFIG[0]
-    for tag in ("r04", "r03", "r02", "r01"):                     # the newest committed round that measured this kernel
+    for tag in ("r05", "r04", "r03", "r02", "r01"):              # the newest committed round that measured this kernel
         name = "%s%s_pmc_traffic.json" % (tag, mid)
         try:
             with open(os.path.join(here, "profiles", name)) as f:
@@ -464,7 +464,7 @@ def build_workload(args, dev, rank, world):
     p, c, cube = synthetic_batch(B, dev, seed=0 + rank)            # per-rank shard of the global batch
     w = {"render": render, "units_per_step": B, "tgt": None}
     fit = None
-    if args.init == "fitted":
+    if getattr(args, "init", "fresh") == "fitted":
         # one pose, B small perturbations of it (tests/test_gpu_steps.py::_selfsup_setup's fitted case at batch size)
         fit = synthetic_batch(1, "cpu", seed=23)[0][0]
         noise = 0.003 * torch.randn(B, 62, generator=torch.Generator().manual_seed(2 + rank))
