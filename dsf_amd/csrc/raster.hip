@@ -351,7 +351,7 @@ __device__ __forceinline__ uint2 crop_face_box(float x0, float y0, float z0, flo
 
 constexpr int CROP_MAX_ROWS = 1024;
 constexpr int BIN_TILES = 8;                    // tiles a workgroup bins faces for at a time: two per wave
-constexpr int CBIN_CAP = 320;                   // candidate faces per tile list (a fuller tile takes the pixel-parallel scan)
+constexpr int CBIN_CAP = 320;                   // candidate faces per tile list (a fuller tile is scanned by the four waves directly)
 constexpr int HEAVY = 64;                       // tiles with more candidates are shared by the four waves
 
 // Crop mode, forward (round 5).  A workgroup owns tiles spread over the crop (8x8 crop pixels each, one lane per pixel) and
@@ -395,7 +395,8 @@ __global__ __launch_bounds__(256) void render_crop_fwd_kernel(const float* __res
     __shared__ unsigned short s_bin[BIN_TILES][CBIN_CAP];      // candidate faces per tile
     __shared__ int s_bcnt[BIN_TILES];                         // list lengths (may exceed CBIN_CAP: the tile then scans all faces)
     __shared__ int s_tbox[BIN_TILES][4];                      // raster box of the tile (x0, x1, y0, y1); x1 < x0: nothing is binned for it
-    __shared__ int s_state[BIN_TILES];                        // 0 done / nothing to do, 1 heavy: waits for the cooperative pass
+    __shared__ int s_state[BIN_TILES];                        // 0 done / nothing to do, 1 heavy: waits for the cooperative pass, 2 heavy + list overflowed
+    __shared__ unsigned short s_cand[4][128];                 // per-wave candidates of an overflowed tile
     __shared__ short s_colrx[BIN_TILES][8], s_rowry[BIN_TILES][8];   // raster column of tile column j / raster row of tile row i (-1: padding)
     __shared__ float s_colx[BIN_TILES][8], s_rowy[BIN_TILES][8];     // their NDC coordinates
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -647,9 +648,10 @@ __global__ __launch_bounds__(256) void render_crop_fwd_kernel(const float* __res
 #ifdef CROP_STAMP
             stamp_n[h] = n;
 #endif
-            if (n > CBIN_CAP) { sep_[h] = false; scan_[h] = true; }          // the list overflowed: scan all faces instead
+            // a list that overflowed (a mesh collapsed into one or two tiles -- what a freshly initialised MANO head predicts: all
+            // 1554 faces in one tile) is not used: the four waves scan the face boxes themselves in pass 4, 64 at a time each
             if (sep_[h] && n > HEAVY) {
-                if (lane == 0) s_state[q] = 1;
+                if (lane == 0) s_state[q] = (n > CBIN_CAP) ? 2 : 1;
 #ifdef CROP_STAMP
                 stamp_coop[h] = 1;
 #endif
@@ -667,10 +669,39 @@ __global__ __launch_bounds__(256) void render_crop_fwd_kernel(const float* __res
 #pragma unroll 1
             for (int r = 0; r < 4; ++r) {
                 const int q = r + 4 * h;
-                if (s_state[q] == 0) continue;           // (the same value for every wave: written before the barrier above)
-                const int n = min(s_bcnt[q], CBIN_CAP);
-                for (int c0 = wave * 64; c0 < n; c0 += 256)
-                    if (c0 + lane < n) face_lane((int)s_bin[q][c0 + lane], q);
+                const int state = s_state[q];            // (the same value for every wave: written before the barrier above)
+                if (state == 0) continue;
+                if (state == 1) {
+                    const int n = s_bcnt[q];
+                    for (int c0 = wave * 64; c0 < n; c0 += 256)
+                        if (c0 + lane < n) face_lane((int)s_bin[q][c0 + lane], q);
+                } else {
+                    // overflowed list: this wave's blocks of 64 faces (wave, wave + 4, ...), candidates compacted 128 at a time
+                    const int bx0 = s_tbox[q][0], bx1 = s_tbox[q][1], by0 = s_tbox[q][2], by1 = s_tbox[q][3];
+                    int n_cand = 0;
+                    for (int base = wave * 64; base < F || n_cand > 0; base += 256) {
+                        const int fme = base + lane;
+                        bool hit = false;
+                        if (base < F && fme < F) {
+                            const uint2 box = s_box[fme];
+                            const int xlo = (int)(box.x & 0xFFFF), xhi = (int)(box.x >> 16), ylo = (int)(box.y & 0xFFFF), yhi = (int)(box.y >> 16);
+                            hit = xlo <= xhi && xlo <= bx1 && xhi >= bx0 && ylo <= by1 && yhi >= by0;
+                        }
+                        const unsigned long long mask = __ballot(hit);
+                        if (hit) s_cand[wave][n_cand + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)fme;
+                        n_cand += __popcll(mask);
+                        if (n_cand > 64 || base + 256 >= F) {            // flush (LDS operations of one wave execute in order)
+                            __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0): the wave's own LDS writes have landed
+                            __builtin_amdgcn_wave_barrier();
+                            for (int c0 = 0; c0 < n_cand; c0 += 64)
+                                if (c0 + lane < n_cand) face_lane((int)s_cand[wave][c0 + lane], q);
+                            __builtin_amdgcn_s_waitcnt(0xc07f);           // this round's reads of s_cand are done before it is refilled
+                            __builtin_amdgcn_wave_barrier();
+                            n_cand = 0;
+                        }
+                        if (base >= F) break;
+                    }
+                }
                 __syncthreads();
                 if (r == wave) write_tile(h, q);
             }

@@ -19,6 +19,8 @@ lib = ctypes.CDLL(so)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 render = Render("synthetic", "nyu", (588.03, 587.07, 320.0, 240.0), (640, 480)).cuda()
 p, c, cube = synthetic_batch(B, "cuda", seed=123)
+if os.environ.get("CROP_STAMP_POSE") == "rest":            # what a freshly initialised MANO head predicts: rest pose, no rotation, unit scale
+    p = torch.zeros_like(p); p[:, 58] = 1.0
 mano = render.mano_layer
 with torch.no_grad():
     v, _ = mano.get_mano_vertices(p[:, :3], p[:, 3:48], p[:, 48:58], p[:, 58:62], 1 / 125)
