@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __rest
                                                              const int32_t* __restrict__ faces,
                                                              const int32_t* __restrict__ part_first,
                                                              const int64_t* __restrict__ seg, int V, int P, int n_parts,
-                                                             int splits, int ex_first, float* __restrict__ dists,
+                                                             int splits, float* __restrict__ dists,
                                                              int32_t* __restrict__ idxs) {
     // A workgroup = 64 points x 4 waves: every wave holds the SAME 64 points (one per lane) and scans its quarter of each staged
     // block of triangles; the four minima meet in LDS at the end.  The pair loop is a chain of dependent divisions and LDS
@@ -255,91 +255,10 @@ __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __rest
     __shared__ int s_ri[4 * 64];
     __shared__ int s_n, s_hi, s_wsum[4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    // ---- two roles per sample (unlabelled clouds only: ex_first < gridDim.x).  Workgroups below ex_first are the culled scan
-    //      described above (64 points each); workgroups from ex_first on are the EXHAUSTIVE scan of round 3 (256 points each,
-    //      one per thread, 256 staged triangle records per pass, every pair evaluated).  Every workgroup of a sample takes the
-    //      same decision from the same 64 sampled triangles and the role that is not wanted exits at once: when most triangles
-    //      of the mesh are too small for a bounding sphere (their Gram determinants are dominated by the reference's 1e-8 terms,
-    //      tri_sphere's R = inf) nothing may be culled and the exhaustive form is the fast one -- the state a freshly
-    //      initialised network is in (a MANO head that predicts a scale near zero: the mesh collapsed to a blob; 1.86 ms per
-    //      launch with the culled structure against 0.9 for this loop at B = 64).  Both forms evaluate the oracle's arithmetic
-    //      per pair and resolve ties to the lowest index: the results are bit for bit the same. ----
-    const bool ex_role = (int)blockIdx.x >= ex_first;
-    if (ex_first < (int)gridDim.x) {
-        const int per_b_ex = (P + 255) / 256;
-        const int bb = ex_role ? ((int)blockIdx.x - ex_first) / per_b_ex : (int)blockIdx.x / splits;
-        const float* vbb = verts + (int64_t)bb * V * 3;
-        const int F = part_first[1] - part_first[0];
-        if (wave == 0) {
-            // 64 evenly spaced triangles and 64 evenly spaced points of the sample.  The cull cannot work (a) when most triangles
-            // have no bounding sphere, or (b) when the whole mesh is smaller than the band of distances the cull has to keep --
-            // a point at distance d keeps every triangle within ~0.12 % of d (the rounding margin of the test): a mesh of radius rm
-            // with 0.0013 d > 2 rm survives whole (a mesh collapsed to a point, as a scale of 0 gives)
-            const int nf = min(F, 64), np = min(P, 64);
-            bool u = false;
-            float4 sp = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (lane < nf) {
-                const int32_t* fc = faces + (part_first[0] + (int)(((int64_t)lane * F) / 64)) * 3;
-                const TriRec r = make_tri(ld3(vbb + fc[0] * 3), ld3(vbb + fc[1] * 3), ld3(vbb + fc[2] * 3), 0);
-                sp = tri_sphere(r);
-                u = !(sp.w < INFINITY);
-            }
-            const int unb = __popcll(__ballot(u));
-            float mx = (lane < nf) ? sp.x : 0.f, my = (lane < nf) ? sp.y : 0.f, mz = (lane < nf) ? sp.z : 0.f;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { mx += __shfl_xor(mx, o, 64); my += __shfl_xor(my, o, 64); mz += __shfl_xor(mz, o, 64); }
-            const float inv = 1.0f / (float)max(nf, 1);
-            mx *= inv; my *= inv; mz *= inv;
-            float rm = 0.f;
-            if (lane < nf) { const float dx = sp.x - mx, dy = sp.y - my, dz = sp.z - mz; rm = sqrtf(dx * dx + dy * dy + dz * dz) + (u ? 0.f : sp.w); }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) rm = fmaxf(rm, __shfl_xor(rm, o, 64));
-            bool farp = false;
-            if (lane < np) {
-                const float* q = points + ((int64_t)bb * P + (int)(((int64_t)lane * P) / 64)) * 3;
-                const float dx = q[0] - mx, dy = q[1] - my, dz = q[2] - mz;
-                farp = 0.0013f * sqrtf(dx * dx + dy * dy + dz * dz) > 2.0f * rm;            // (NaN: false)
-            }
-            const int nfar = __popcll(__ballot(farp));
-            if (lane == 0) s_n = (unb * 2 > nf || nfar * 2 > np) ? 1 : 0;
-        }
-        __syncthreads();
-        const bool degenerate = s_n != 0;
-        __syncthreads();
-        if (degenerate != ex_role) return;
-        if (ex_role) {
-            TriRec* const e_tri = reinterpret_cast<TriRec*>(s_raw);            // 256 records = 20 KB of the 24.5 KB stage
-            const int w_ex = (int)blockIdx.x - ex_first;
-            const int chunk = w_ex % per_b_ex;
-            const float* pbb = points + (int64_t)bb * P * 3;
-            const int p = chunk * 256 + t;
-            const bool live = p < P;
-            const f3 pt = live ? ld3(pbb + p * 3) : mk3(0.f, 0.f, 0.f);
-            float best = INFINITY;
-            int bi = -1;
-            const int f0e = part_first[0], f1e = part_first[1];
-            for (int base = f0e; base < f1e; base += 256) {
-                __syncthreads();
-                if (base + t < f1e) {
-                    const int32_t* fc = faces + (base + t) * 3;
-                    e_tri[t] = make_tri(ld3(vbb + fc[0] * 3), ld3(vbb + fc[1] * 3), ld3(vbb + fc[2] * 3), t);
-                }
-                __syncthreads();
-                const int cnt = min(256, f1e - base);
-                if (live) {
-                    for (int q = 0; q < cnt; ++q) {
-                        const float d = point_tri_dist2(pt, e_tri[q]);
-                        if (d < best || bi < 0) { best = d; bi = base + q; }           // ascending order: the lowest index keeps a tie
-                    }
-                }
-            }
-            if (live) {
-                dists[(int64_t)bb * P + p] = (bi < 0) ? 0.f : best;
-                idxs[(int64_t)bb * P + p] = bi;
-            }
-            return;
-        }
-    }
+    // (Round 5 measured an EXHAUSTIVE role for meshes the cull cannot work on -- 256 points per workgroup, every pair, chosen per
+    //  sample inside the launch from 64 sampled triangles and points -- as the round-4 brief asked: 1610-1850 us against 1862 for the
+    //  adaptive loop below on the mesh collapsed to 1 % at B = 64, and SLOWER inside the steps that are in that state (config 3's
+    //  first steps: 532-840 us per launch against 495): removed again.  What those steps really paid for was the labelled form.)
     int w = blockIdx.x;
     int split;
     if (seg) {
@@ -723,11 +642,8 @@ extern "C" int dsf_mesh_point_dist_forward(const float* verts, const float* poin
     int splits = seg ? (P <= LIST_CAP ? (P + 255) / 256 : (P + SEG_RANGE - 1) / SEG_RANGE) : (P + GP - 1) / GP;
     if (const char* e = getenv("DSF_PFD_SPLITS")) { const int v = atoi(e); if (seg && P <= LIST_CAP && v >= 1 && v <= 64) splits = v; }
     if (splits < 1) splits = 1;
-    // unlabelled clouds: B * splits culled workgroups + B * ceil(P / 256) exhaustive ones; per sample one of the two sets exits at once
-    const int culled = B * n_parts * splits;
-    const int extra = (!seg && n_parts == 1) ? B * ((P + 255) / 256) : 0;
-    hipLaunchKernelGGL(mesh_point_fwd_kernel, dim3((unsigned)(culled + extra)), dim3(256), 0, (hipStream_t)stream,
-                       verts, points, faces, part_first, seg, V, P, n_parts, splits, extra ? culled : 0x7fffffff, dists, idxs);
+    hipLaunchKernelGGL(mesh_point_fwd_kernel, dim3((unsigned)(B * n_parts * splits)), dim3(256), 0, (hipStream_t)stream,
+                       verts, points, faces, part_first, seg, V, P, n_parts, splits, dists, idxs);
     return dsf_launch_status();
 }
 
