@@ -258,7 +258,8 @@ __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __rest
     // (Round 5 measured an EXHAUSTIVE role for meshes the cull cannot work on -- 256 points per workgroup, every pair, chosen per
     //  sample inside the launch from 64 sampled triangles and points -- as the round-4 brief asked: 1610-1850 us against 1862 for the
     //  adaptive loop below on the mesh collapsed to 1 % at B = 64, and SLOWER inside the steps that are in that state (config 3's
-    //  first steps: 532-840 us per launch against 495): removed again.  What those steps really paid for was the labelled form.)
+    //  first steps: 532-840 us per launch against 495; whole steps of configs 3 and 5 with and without it: no difference): removed
+    //  again.  What those steps really paid for was the labelled form.)
     int w = blockIdx.x;
     int split;
     if (seg) {
