@@ -420,7 +420,7 @@ def rccl_summary(path):
                   "tree_lines": sum(1 for l in lines if re.search(r"\bTrees? ", l)),
                   "channels": max([int(m.group(1)) for l in lines for m in [re.search(r"(\d+) coll channels", l)] if m] or [0]),
                   "nranks_reported": sorted({int(m.group(1)) for l in lines for m in [re.search(r"nranks (\d+)", l)] if m}),
-                  "version": next((l.split("version", 1)[1].strip() for l in lines if "NCCL version" in l or "RCCL version" in l), None)}
+                  "version": next((l.split("version", 1)[1].strip(" :") for l in lines if "NCCL version" in l or "RCCL version" in l), None)}
     return out
 
 

@@ -323,7 +323,9 @@ extern "C" int dsf_seg_pcl(const float* centres, const float* radii, const float
                            dsf_stream_t stream) {
     DSF_CHECK_ARG(centres && radii && pcl && labels && B >= 0 && P >= 0);
     if (B == 0 || P == 0) return DSF_OK;
-    int g = (P + 1023) / 1024;               // 4 points per lane
+    // one point per lane: 66 sphere tests with an IEEE square root each are a ~2600-instruction chain per point; four points per
+    // lane (rounds 1-4) left the chip at one wave per SIMD on half of its SIMDs (B = 64, P = 2048: 42 us)
+    int g = (P + 255) / 256;
     if (g < 1) g = 1;
     hipLaunchKernelGGL(seg_pcl_kernel, dim3(B * g), dim3(256), 0, (hipStream_t)stream, centres, radii, pcl, P, g, labels);
     return dsf_launch_status();

@@ -168,6 +168,12 @@ def test_gradient_all_reduce_on_rccl_at_world_size_one(tmp_path):
         for k, v in res.items():
             fh.write("  %-48s %s\n" % (k, v))
         fh.write("RCCL's own log (NCCL_DEBUG=INFO, INIT):\n" + "\n".join("  " + l for l in rccl_lines) + "\n")
+    # bench.py's reader of RCCL's own log, on what RCCL really wrote here (round 4: "an untested guess")
+    sys.path.insert(0, REPO)
+    import bench
+    facts = bench.rccl_summary(str(nccl_log))["log"]
+    assert facts and facts["lines"] > 0 and facts["nranks_reported"] == [1], facts
+    assert facts["version"] and facts["version"][0].isdigit(), facts
     assert res["backend"] == "nccl"
     assert res["eager_r18_buckets"] > 8 and res["eager_r18_collectives_launched_from_hooks"] >= 3 * (res["eager_r18_buckets"] - 1), res
     assert res["eager_r18_gradients_bitwise"] and res["eager_r18_parameters_bitwise_after_3_steps"], res

@@ -253,3 +253,25 @@ def test_convert_sync_batchnorm_keeps_the_fused_modules():
     assert type(net[2][0]) is nn.SyncBatchNorm and type(net[2][1]) is nn_norm.FusedSyncBatchNorm2d
     assert list(net.state_dict().keys()) == keys
     assert type(convert_sync_batchnorm(nn_norm.FusedBatchNorm2d(4))) is nn_norm.FusedSyncBatchNorm2d
+
+
+
+def test_rccl_log_reader_on_lines_rccl_wrote(tmp_path):
+    """bench.rccl_summary on the init lines RCCL 2.26.6 itself wrote on an MI355X box (profiles/r05_rccl_world1.log, round 5) plus
+    the graph lines of a multi-rank communicator in RCCL's wording: ranks, channels, rings / trees, version."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    log = tmp_path / "rccl.log"
+    log.write_text("\n".join([
+        "runc:293:553 [0] NCCL INFO RCCL version : 2.26.6-HEAD:64f48b6",
+        "runc:293:555 [0] NCCL INFO ncclCommInitRankConfig_impl comm 0x7e795ed6b370 rank 0 nranks 8 cudaDev 0 nvmlDev 0 busId a4000 commId 0xf88f353abe2ebc93 - Init START",
+        "runc:293:555 [0] NCCL INFO comm 0x7e795ed6b370 rank 0 nRanks 8 nNodes 1 localRanks 8 localRank 0 MNNVL 0",
+        "runc:293:555 [0] NCCL INFO Ring 00 : 7 -> 0 -> 1 comm 0x7e795ed6b370 nRanks 08 busId a4000",
+        "runc:293:555 [0] NCCL INFO Ring 01 : 7 -> 0 -> 1 comm 0x7e795ed6b370 nRanks 08 busId a4000",
+        "runc:293:555 [0] NCCL INFO Trees [0] 1/-1/-1->0->-1 [1] 1/-1/-1->0->-1 comm 0x7e795ed6b370 nRanks 08 busId a4000",
+        "runc:293:555 [0] NCCL INFO 32 coll channels, 32 collnet channels, 0 nvls channels, 32 p2p channels, 2 p2p channels per peer",
+        "runc:293:555 [0] NCCL INFO ncclCommInitRankConfig_impl comm 0x7e795ed6b370 rank 0 nranks 8 cudaDev 0 nvmlDev 0 busId a4000 commId 0xf88f353abe2ebc93 - Init COMPLETE"]))
+    f = bench.rccl_summary(str(log))["log"]
+    assert f == {"lines": 8, "ring_lines": 2, "tree_lines": 1, "channels": 32, "nranks_reported": [8], "version": "2.26.6-HEAD:64f48b6"}
+    assert bench.rccl_summary(str(tmp_path / "absent.log")) == {"log": None}
