@@ -390,12 +390,24 @@ def _record_blocks(net):
 def _teacher_forced_rows(net_cpu, net_gpu, net64, cap):
     """Every block run ALONE on the float64 run's own input and differentiated against the float64 run's own upstream
     gradient (both cast to fp32), on the torch-CPU fp32 twin and on the HIP modules: -> [(name, (err_y, err_gx, err_gW) of the
-    CPU twin, the same of the HIP path)], relative L2 errors against float64 (nan where there is nothing to compare)."""
+    CPU twin, the same of the HIP path)], relative L2 errors against float64 (nan where there is nothing to compare); a fourth
+    entry err_gx_trimmed = the input-gradient error without its largest differences (0.5 %, at least 25 pixels' worth of channels)."""
     from dsf_amd import nn_conv
 
     def rel(a, ref):
         ref = ref.double().cpu()
         return float((a.double().cpu() - ref).norm() / (ref.norm() + 1e-300))
+
+    def rel_trimmed(a, ref, frac=0.005):
+        """relative L2 error with the `frac` largest differences left out: a ReLU / max-pool switch changes a gradient through
+        ONE activation, i.e. in the few elements of its receptive field (plus a 1 / M share through the BatchNorm sums), while a
+        wrong formula is wrong everywhere -- the trimmed error separates the two"""
+        channels = ref.shape[1] if ref.dim() == 4 else 1
+        ref = ref.double().cpu().flatten()
+        d = (a.double().cpu().flatten() - ref).abs()
+        k = max(1, int(frac * d.numel()), 25 * channels)          # at least a 5 x 5 pixel neighbourhood of every channel (the 8 x 8 maps)
+        kept = d.topk(d.numel() - k, largest=False).values if d.numel() > k else d[:0]
+        return float(kept.norm() / (ref.norm() + 1e-300))
 
     def pgrads(mod):
         g = [q.grad.double().cpu().flatten() for q in mod.parameters() if q.grad is not None]
@@ -428,7 +440,8 @@ def _teacher_forced_rows(net_cpu, net_gpu, net64, cap):
 
         def errs(y, gx, gw):
             return (rel(y, c["y"]), rel(gx, c["gx"]) if (gx is not None and c["gx"] is not None) else nan,
-                    rel(gw, p64) if p64.numel() else nan)
+                    rel(gw, p64) if p64.numel() else nan,
+                    rel_trimmed(gx, c["gx"]) if (gx is not None and c["gx"] is not None) else nan)
         rows.append((n, errs(*run(mc, c["x"], c["gy"], "cpu", call_c)), errs(*run(mg, c["x"], c["gy"], "cuda", call_g))))
     return rows
 
@@ -461,10 +474,19 @@ def test_two_stage_resnet50_teacher_forced_blocks(render, orender):
     gw = _np.array([r[2][2] for r in rows if r[2][2] == r[2][2]])
     gx_c = _np.array([r[1][1] for r in rows if r[1][1] == r[1][1]])
     gw_c = _np.array([r[1][2] for r in rows if r[1][2] == r[1][2]])
-    worst = sorted(rows, key=lambda r: -max(v for v in r[2][1:] if v == v))[:3]
+    gxt = _np.array([r[2][3] for r in rows if r[2][3] == r[2][3]])
+    gxt_c = _np.array([r[1][3] for r in rows if r[1][3] == r[1][3]])
+    print("teacher-forced blocks, input-gradient error WITHOUT its 0.5 %% largest differences: HIP median %.2e max %.2e; torch-CPU median %.2e max %.2e; "
+          "blocks whose full error is above 1e-5: %s" % (_np.median(gxt), gxt.max(), _np.median(gxt_c), gxt_c.max(),
+          [(r[0], "%.1e -> %.1e" % (r[2][1], r[2][3])) for r in rows if r[2][1] == r[2][1] and r[2][1] > 1e-5]))
+    # the switch discriminator (round 5): with the few largest differences left out every block is back near rounding level
+    # (observed: HIP median 2.8e-7, the ten flagged blocks 5.7e-4 -> 8.2e-6 ... 1.6e-3 -> 2.0e-5, worst 2.0e-3 -> 1.2e-4 on an
+    # 8 x 8 map; torch-CPU median 2.9e-7, max 3.5e-5) -- a formula that is wrong by 0.3 % stays at 3e-3 whatever is trimmed
+    assert _np.median(gxt) < 2e-6 and gxt.max() < 5e-4, (float(_np.median(gxt)), float(gxt.max()))
+    worst = sorted(rows, key=lambda r: -max(v for v in r[2][1:3] if v == v))[:3]
     print("teacher-forced blocks (HIP): forward max %.2e; input-gradient median %.2e max %.2e; parameter-gradient median %.2e max %.2e; "
           "blocks above 1e-5: HIP %d, torch-CPU %d of %d; worst %s" % (fwd.max(), _np.median(gx), gx.max(), _np.median(gw), gw.max(),
-          int((gx > 1e-5).sum()), int((gx_c > 1e-5).sum()), len(gx), [(r[0], "%.1e" % max(v for v in r[2][1:] if v == v)) for r in worst]))
+          int((gx > 1e-5).sum()), int((gx_c > 1e-5).sum()), len(gx), [(r[0], "%.1e" % max(v for v in r[2][1:3] if v == v)) for r in worst]))
     # forward: no switch can show in a block's own output (observed <= 1.2e-6, torch-CPU <= 1.1e-6)
     assert fwd.max() < 5e-6, [(r[0], r[2][0]) for r in rows if r[2][0] >= 5e-6]
     # backward: the typical block is at rounding level (observed medians 3.1e-7 / 4.6e-7; torch-CPU 3.3e-7 / 5.5e-7) ...
