@@ -625,6 +625,224 @@ __global__ __launch_bounds__(256, 2) void igemm_x6b_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// igemm_x6p_kernel: igemm_x6b_kernel for the 3 x 3, stride 1, pad 1 layers on W-wide maps, with the A operand staged as a PATCH.
+//
+// Why: igemm_x6b_kernel gathers, splits and stores the A tile once per (tap, chunk): every input value of a 3 x 3 layer crosses
+// the loader nine times (~22 VALU + 3 ds_write per float4 each time), and on the 64-channel layers that work is amortised over
+// only 24 MFMAs -- the kernel is issue-bound at 0.35-0.68 MFMA utilisation.  A tile of BMT = R W output pixels (R whole rows of
+// one image) needs the (R + 2) x (W + 2) input pixels around it; this kernel loads and splits THAT once per 16-channel chunk
+// ([plane][k-group][patch pixel] granules, pixel pitch W + 2) and reads all nine taps' fragments out of it: the fragment of tap
+// (kh, kw) is the same ds_read_b128 moved by the constant kh (W + 2) + kw granules.  Loader work per output tile falls
+// (9 BMT) / ((R + 2)(W + 2)) = 5.8x (R = 4) / 4.4x (R = 2); barriers fall 9x.  The reduction order (taps of one chunk, then the
+// next chunk; the six products of a step in the same order) is igemm_x6b_kernel's, so results are bit-identical to it.
+// One LDS stage = 3 planes x 2 k-groups x KGS granules (38.8 KB at R = 4): two stages as dynamic LDS (77.6 KB, 2 workgroups per
+// CU); the B fragments alternate between two register sets per tap; the A loads of chunk c + 1 are issued during taps 0-2 of
+// chunk c and split / stored during taps 5-8; the fragments of tap t + 1 are read during tap t.
+// ------------------------------------------------------------------------------------------------
+template <int BMT, int W> struct X6Patch {
+    static constexpr int R = BMT / W, PW = W + 2, NPIX = (R + 2) * PW;
+    static constexpr int KGS = ((NPIX + 11) / 16) * 16 + 4;               // k-group pitch = 4 mod 16 granules: see LdsPlane
+    static constexpr int PLANE = 2 * KGS, STAGE = 3 * PLANE;             // granules
+    static constexpr int NPASS = (NPIX + 63) / 64;                       // float4 loads of the patch per thread
+    static constexpr int LDS_BYTES = 2 * STAGE * 16;
+};
+
+template <int BN, int BMT, int W>
+__global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restrict__ X, const uint4* __restrict__ Wimg,
+                                                          const float* __restrict__ bias, float* __restrict__ Y, X6P p, int m_tiles,
+                                                          int n_tiles, uint32_t x_bytes, uint32_t w_bytes, float* __restrict__ stats,
+                                                          X6Ep ep) {
+    static_assert((BN == 128 && BMT == 128) || (BN == 64 && BMT == 256), "tile shapes");
+    static_assert(BMT % W == 0 && W % 32 == 0, "a 32-row fragment block lies in one image row");
+    using PT = X6Patch<BMT, W>;
+    constexpr int WM = 64, TM = 2, TN = 2;               // wave sub-tile 64 x 64: 2 x 2 waves (BN 128) or 4 x 1 (BN 64)
+    constexpr int NPASS = PT::NPASS;
+    constexpr int B_GRANULES = 2 * BN;
+    extern __shared__ uint4 x6p_lds[];                   // [stage 2][plane 3][k-group 2][KGS]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = (BN == 128) ? (wave >> 1) : wave, wn = (BN == 128) ? (wave & 1) : 0;
+    int tile = x6_xcd_contiguous(blockIdx.x, m_tiles * n_tiles);
+    const int n_tile = tile % n_tiles; const int m_tile = tile / n_tiles;
+    const int m0 = m_tile * BMT, n0 = n_tile * BN;
+    const int M = p.B * p.Ho * p.Wo;                     // a multiple of BMT (launcher)
+    const __amdgpu_buffer_rsrc_t xbuf = x6_buffer(X, x_bytes), wbuf = x6_buffer(Wimg, w_bytes);
+
+    // patch pixel pidx = py PW + px  <->  input pixel (y0 - 1 + py, px - 1) of image b
+    const int img = m0 / (p.Hi * W), y0 = (m0 % (p.Hi * W)) / W;
+    const int a_q = t & 3, a_k4 = a_q * 4, a_r = t >> 2;
+    int a_off[NPASS];                                    // element offset of (pixel, channel quad) at chunk 0; -1: zeros
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+        const int pidx = a_r + 64 * i;
+        const int py = pidx / PT::PW, px = pidx % PT::PW;
+        const int y = y0 - 1 + py, x = px - 1;
+        const bool ok = pidx < PT::NPIX && (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)W;
+        a_off[i] = ok ? ((img * p.Hi + y) * W + x) * p.Ci + a_k4 : -1;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int n_chunks = (p.Ci + XBK - 1) / XBK;
+    u32x4 ra[NPASS];
+    u32x4 rbf[2][3][TN];                                 // [set][plane][n block]: B fragments as loaded
+    bf16x8 af[2][3][TM];                                 // [set][plane][m block]: A fragments of the current / next tap
+    const uint32_t b_lane = (uint32_t)((lane >> 5) * BN + wn * 64 + (lane & 31)) * 16u;
+    auto load_a = [&](int i, int chunk) {                // pass i of the patch of `chunk` (past the end: zeros)
+        const bool ok = a_off[i] >= 0 && chunk < n_chunks && chunk * XBK + a_k4 < p.Ci;
+        ra[i] = x6_load16(xbuf, ok ? (uint32_t)(a_off[i] + chunk * XBK) * 4u : X_OOB);
+    };
+    auto stage_piece = [&](int buf, int i) {
+        if (NPASS * 64 > PT::KGS && a_r + 64 * i >= PT::KGS) return;     // the tail of the last pass: past the k-group
+        uint2 h, m, l;
+        split4(ra[i], h, m, l);
+        uint2* dst = reinterpret_cast<uint2*>(&x6p_lds[buf * PT::STAGE + (a_q >> 1) * PT::KGS + a_r + 64 * i]) + (a_q & 1);
+        dst[0] = h; dst[2 * PT::PLANE] = m; dst[4 * PT::PLANE] = l;
+    };
+    auto load_b = [&](auto SET, int f, int tap, int chunk) {             // fragment f of step (chunk, tap) (past the end: zeros)
+        constexpr int S = decltype(SET)::value;
+        const int pl = f / TN, j = f % TN;
+        const uint32_t dead = chunk < n_chunks ? 0u : X_OOB;
+        const int blk = tap * n_chunks + chunk;
+        rbf[S][pl][j] = x6_load16(wbuf, ((uint32_t)(blk * n_tiles + n_tile) * (uint32_t)(3 * B_GRANULES * 16) +
+                                         (uint32_t)(pl * B_GRANULES * 16 + j * 32 * 16) + b_lane) | dead);
+    };
+    // this lane's granule of output row block i at tap (0, 0): rows wm WM + 32 i + (lane & 31) of the tile
+    int a_frag[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int ml = wm * WM + i * 32 + (lane & 31);
+        a_frag[i] = (lane >> 5) * PT::KGS + (ml / W) * PT::PW + (ml % W);
+    }
+    auto read_frag = [&](auto SET, int buf, int tap, int pl, int i) {
+        constexpr int S = decltype(SET)::value;
+        af[S][pl][i] = __builtin_bit_cast(bf16x8, x6p_lds[buf * PT::STAGE + pl * PT::PLANE + a_frag[i] + (tap / 3) * PT::PW + tap % 3]);
+    };
+
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, 1>;
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) load_a(i, 0);
+#pragma unroll
+    for (int f = 0; f < 3 * TN; ++f) load_b(Set0{}, f, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) stage_piece(0, i);
+    __syncthreads();
+
+    // chunk c (parity PAR): A fragments from LDS stage PAR; tap t uses B register set and fragment set (PAR + t) & 1 (nine taps:
+    // the next chunk starts on the other set).  Handed out between the 24 MFMAs of a tap: the B loads of the next step, the A
+    // fragment reads of the next tap, and this chunk's share of the patch of chunk c + 1 (loads in taps 0-2, stores in taps 5-8).
+    auto body = [&](auto PARITY, int chunk) {
+        constexpr int PAR = decltype(PARITY)::value;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if (PAR) read_frag(Set1{}, PAR, 0, pl, i); else read_frag(Set0{}, PAR, 0, pl, i);
+            }
+        constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int S = (PAR + tap) & 1;
+            __builtin_amdgcn_sched_barrier(0);
+            int slot = 0;
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[S][PA[q]][i], __builtin_bit_cast(bf16x8, rbf[S][PB[q]][j]),
+                                                                            acc[i][j], 0, 0, 0);
+                        // B fragments of the next step: behind MFMAs 0, 4, .. 20
+                        if ((slot & 3) == 0) {
+                            const int f = slot >> 2, ntap = tap == 8 ? 0 : tap + 1, nchunk = tap == 8 ? chunk + 1 : chunk;
+                            if (S) load_b(Set0{}, f, ntap, nchunk); else load_b(Set1{}, f, ntap, nchunk);
+                        }
+                        // A fragments of the next tap: behind MFMAs 1, 5, .. 21 (the planes in the order the MFMAs want them)
+                        if ((slot & 3) == 1 && tap < 8) {
+                            const int f = slot >> 2, pl = f / TM, i = f % TM;
+                            if (S) read_frag(Set0{}, PAR, tap + 1, pl, i); else read_frag(Set1{}, PAR, tap + 1, pl, i);
+                        }
+                        // the patch of chunk + 1: three loads per tap in taps 0-2, two stores per tap in taps 5-8
+                        if (tap < 3 && (slot == 2 || slot == 10 || slot == 18)) {
+                            const int i = tap * 3 + (slot - 2) / 8;
+                            if (i < NPASS) load_a(i, chunk + 1);
+                        }
+                        if (tap >= 5 && (slot == 6 || slot == 18)) {
+                            const int i = (tap - 5) * 2 + (slot == 18);
+                            if (i < NPASS) stage_piece(PAR ^ 1, i);
+                        }
+                        ++slot;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+        }
+        __syncthreads();
+    };
+    for (int chunk = 0; chunk < n_chunks; chunk += 2) {
+        body(Set0{}, chunk);
+        if (chunk + 1 < n_chunks) body(Set1{}, chunk + 1);
+    }
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (n >= p.Co) continue;
+            const float bv = bias ? bias[n] : 0.f;
+            const bool affine = ep.scale != nullptr;     // the output epilogue of igemm_x6b_kernel
+            const float es = affine ? ep.scale[n] : 1.f, et = affine ? ep.shift[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row >= M) continue;
+                if (affine) {
+                    float v = fmaf(acc[i][j][r] + bv, es, et);
+                    if (ep.residual) v += ep.residual[row * p.Co + n];
+                    Y[row * p.Co + n] = ep.relu ? fmaxf(v, 0.f) : v;
+                } else Y[row * p.Co + n] = acc[i][j][r] + bv;
+            }
+        }
+
+    // BatchNorm batch statistics of this tile: as in igemm_x6b_kernel (the partial sums meet in the first 2 KB of the stage)
+    if (stats) {
+        float (*s_st)[2][64] = reinterpret_cast<float (*)[2][64]>(x6p_lds);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float su = 0.f, sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { su += acc[i][j][r]; sq = fmaf(acc[i][j][r], acc[i][j][r], sq); }
+            su += __shfl_xor(su, 32, 64); sq += __shfl_xor(sq, 32, 64);
+            if (lane < 32) { s_st[wave][0][j * 32 + lane] = su; s_st[wave][1][j * 32 + lane] = sq; }
+        }
+        __syncthreads();
+        constexpr int WAVES_M = (BN == 128) ? 2 : 4;
+        for (int e = t; e < 2 * BN; e += 256) {
+            const int which = e / BN, c = e % BN;
+            const int n = n0 + c;
+            if (n >= p.Co) continue;
+            const int wcol = (BN == 128) ? (c >> 6) : 0, lc = c & 63;
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES_M; ++w) tot += s_st[(BN == 128) ? (w * 2 + wcol) : w][which][lc];
+            if (ep.stats_acc > 0)
+                __hip_atomic_fetch_add(reinterpret_cast<double*>(stats) + ((int64_t)(m_tile % ep.stats_acc) * 2 + which) * p.Co + n, (double)tot,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else stats[((int64_t)m_tile * 2 + which) * p.Co + n] = tot;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Backward-weights:  dW[(tap, ci)][co] += sum_{m in split} X[pixel(m) + tap][ci] * dY[m][co]
 // The reduction runs over pixels, so an MFMA lane needs 8 consecutive PIXELS of one channel, while HBM (and the loader's
 // float4) hold consecutive CHANNELS of one pixel.  Both tiles are therefore staged as loaded -- [pixel 16][channel 128]
@@ -937,6 +1155,17 @@ static X6Plan x6_forward_plan(int64_t M, int Ci, int Co, int KH, int KW, int dil
     return X6Plan{bn, n_tiles, bdirect, bmt, m_tiles, k_splits};
 }
 
+// igemm_x6p_kernel's conditions: 3 x 3, stride 1, pad 1 on 64-wide maps, unsplit, tiles of whole image rows inside one image.
+// DSF_X6_PATCH=0 switches it off; read per call (tests/test_gpu_conv.py compares both kernels in one process).
+static bool x6_patch_applies(const X6Plan& plan, int Hi, int Wi, int Ho, int Wo, int KH, int KW, int stride, int dil, int pad_h,
+                             int pad_w) {
+    const char* e = getenv("DSF_X6_PATCH");
+    if (e && atoi(e) == 0) return false;
+    const bool direct = plan.bdirect && !(plan.bmt == 64 && plan.n_tiles >= 2);
+    return direct && dil == 1 && KH == 3 && KW == 3 && stride == 1 && pad_h == 1 && pad_w == 1 && Ho == Hi && Wo == Wi && Wi == 64 &&
+           plan.k_splits == 1 && (plan.bn == 64 ? plan.bmt == 256 : plan.bmt == 128) && (Hi * Wi) % plan.bmt == 0;
+}
+
 // Ci / Co are the reduction / output channel counts of the IMAGE (mode 1: those of the backward-data GEMM).
 static int x6_forward_impl(const float* X, const void* image, const float* bias, float* Y, int B, int Hi, int Wi, int Ci, int Ho,
                            int Wo, int Co, int KH, int KW, int stride, int dil, int pad_h, int pad_w, int k_splits,
@@ -974,6 +1203,20 @@ static int x6_forward_impl(const float* X, const void* image, const float* bias,
     // 64-row tiles with several n tiles (16x16x256, 8x8x512 maps): every wave of the many small tiles would pull its own copy of
     // the weight block from L2 -- the LDS-staged kernel is faster there (measured 136 / 139 vs 133 / 133 TFLOP/s)
     const bool direct = bdirect && !(bmt == 64 && n_tiles >= 2);
+    if (x6_patch_applies(plan, Hi, Wi, Ho, Wo, KH, KW, stride, dil, pad_h, pad_w)) {
+#define DSF_LAUNCH_X6P(BNv, BMv)                                                                                                  \
+    do {                                                                                                                          \
+        using PT = X6Patch<BMv, 64>;                                                                                              \
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_x6p_kernel<BNv, BMv, 64>),        \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, PT::LDS_BYTES);            \
+        if (attr != hipSuccess) return DSF_ERR_LAUNCH;                                                                            \
+        hipLaunchKernelGGL((igemm_x6p_kernel<BNv, BMv, 64>), grid, dim3(256), PT::LDS_BYTES, (hipStream_t)stream, X,              \
+                           (const uint4*)image, bias, Y, p, m_tiles, n_tiles, (uint32_t)x_bytes, (uint32_t)w_bytes, stats, ep);   \
+    } while (0)
+        if (bn == 64) DSF_LAUNCH_X6P(64, 256); else DSF_LAUNCH_X6P(128, 128);
+#undef DSF_LAUNCH_X6P
+        return dsf_launch_status();
+    }
     if (direct) {
         if (dil == 2) { if (bn == 64) DSF_LAUNCH_X6B(64, true, 256); else if (bmt == 64) DSF_LAUNCH_X6B(128, true, 64); else DSF_LAUNCH_X6B(128, true, 128); }
         else { if (bn == 64) DSF_LAUNCH_X6B(64, false, 256); else if (bmt == 64) DSF_LAUNCH_X6B(128, false, 64); else DSF_LAUNCH_X6B(128, false, 128); }
@@ -1013,6 +1256,16 @@ int dsf_conv_x6_forward(const float* X, const void* image, const float* bias, fl
 int dsf_conv_x6_forward_splits(int B, int Ho, int Wo, int Ci, int Co, int KH, int KW, int dil) {
     if (B <= 0 || Ho <= 0 || Wo <= 0 || Ci <= 0 || Co <= 0 || KH <= 0 || KW <= 0 || (dil != 1 && dil != 2)) return 1;
     return x6_forward_plan((int64_t)B * Ho * Wo, Ci, Co, KH, KW, dil, 0).k_splits;
+}
+
+// Which kernel dsf_conv_x6_forward (k_splits <= 0) launches for this shape: 0 igemm_x6_kernel (both operands through LDS),
+// 1 igemm_x6b_kernel (weights straight into the fragment registers), 2 igemm_x6p_kernel (the same with a patch-staged input).
+int dsf_conv_x6_forward_variant(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int dil, int pad_h,
+                                int pad_w) {
+    if (B <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || Ci <= 0 || Co <= 0 || KH <= 0 || KW <= 0 || (dil != 1 && dil != 2)) return -1;
+    const X6Plan plan = x6_forward_plan((int64_t)B * Ho * Wo, Ci, Co, KH, KW, dil, 0);
+    if (x6_patch_applies(plan, Hi, Wi, Ho, Wo, KH, KW, stride, dil, pad_h, pad_w)) return 2;
+    return (plan.bdirect && !(plan.bmt == 64 && plan.n_tiles >= 2)) ? 1 : 0;
 }
 
 // dsf_conv_x6_forward as a split launch that ADDS into a Y the caller has initialised (zeros from one pooled fill instead of a

@@ -1,0 +1,50 @@
+"""Whole-step A/B of an environment switch the library reads per call (e.g. DSF_X6_PATCH), on ONE box and in ONE process:
+blocks of steps alternate between the values, so clock / box differences cancel.
+
+  python tools/ab_env.py --config 2 --var DSF_X6_PATCH --values 0 1 [--block 10] [--rounds 6]
+
+Config 3 replays a HIP graph: one GraphedStep is captured per value."""
+import argparse, os, sys, time, types
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--config", type=int, default=2)
+ap.add_argument("--var", required=True)
+ap.add_argument("--values", nargs="+", required=True)
+ap.add_argument("--block", type=int, default=10)
+ap.add_argument("--rounds", type=int, default=6)
+ap.add_argument("--init", default="fresh")
+a = ap.parse_args()
+args = types.SimpleNamespace(config=a.config, batch=0, backbone="", graph=False, no_graph=False, cpu_steps=0, init=a.init)
+dev = torch.device("cuda", 0)
+os.environ[a.var] = a.values[0]
+w = bench.build_workload(args, dev, 0, 1)
+runs = {}
+for v in a.values:
+    os.environ[a.var] = v
+    if a.config == 3:
+        from dsf_amd.train_step import GraphedStep
+        g = GraphedStep(w["step"], w["tgt"])
+        runs[v] = (lambda g_: (lambda: g_(w["tgt"])))(g)
+    else:
+        runs[v] = w["run"]
+    for _ in range(4):
+        runs[v]()
+torch.cuda.synchronize()
+tot = {v: [] for v in a.values}
+for r in range(a.rounds):
+    for v in (a.values if r % 2 == 0 else a.values[::-1]):
+        os.environ[a.var] = v
+        runs[v]()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.block):
+            runs[v]()
+        torch.cuda.synchronize()
+        tot[v].append((time.perf_counter() - t0) * 1e3 / a.block)
+for v in a.values:
+    xs = sorted(tot[v])
+    print("AB config %d %s=%s: median %.3f ms/step  min %.3f  max %.3f  (%d blocks of %d)" %
+          (a.config, a.var, v, xs[len(xs) // 2], xs[0], xs[-1], len(xs), a.block))
