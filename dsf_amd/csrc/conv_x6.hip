@@ -640,8 +640,10 @@ __global__ __launch_bounds__(256, 2) void igemm_x6b_kernel(const float* __restri
 // chunk c and split / stored during taps 5-8; the fragments of tap t + 1 are read during tap t.
 // ------------------------------------------------------------------------------------------------
 template <int BMT, int W> struct X6Patch {
-    static constexpr int R = BMT / W, PW = W + 2, NPIX = (R + 2) * PW;
-    static constexpr int KGS = ((NPIX + 11) / 16) * 16 + 4;               // k-group pitch = 4 mod 16 granules: see LdsPlane
+    // pixel pitch of a patch row: W + 2; 8-wide maps 24 (a 32-row fragment block spans four image rows: the 16-lane halves of
+    // the ds_read_b128 then land on disjoint bank halves)
+    static constexpr int R = BMT / W, PW = (W == 8) ? 24 : W + 2, NPIX = (R + 2) * (W + 2);
+    static constexpr int KGS = (((R + 2) * PW + 11) / 16) * 16 + 4;       // k-group pitch = 4 mod 16 granules: see LdsPlane
     static constexpr int PLANE = 2 * KGS, STAGE = 3 * PLANE;             // granules
     static constexpr int NPASS = (NPIX + 63) / 64;                       // float4 loads of the patch per thread
     static constexpr int LDS_BYTES = 2 * STAGE * 16;
@@ -650,34 +652,38 @@ template <int BMT, int W> struct X6Patch {
 template <int BN, int BMT, int W>
 __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restrict__ X, const uint4* __restrict__ Wimg,
                                                           const float* __restrict__ bias, float* __restrict__ Y, X6P p, int m_tiles,
-                                                          int n_tiles, uint32_t x_bytes, uint32_t w_bytes, float* __restrict__ stats,
-                                                          X6Ep ep) {
-    static_assert((BN == 128 && BMT == 128) || (BN == 64 && BMT == 256), "tile shapes");
-    static_assert(BMT % W == 0 && W % 32 == 0, "a 32-row fragment block lies in one image row");
+                                                          int n_tiles, int k_splits, uint32_t x_bytes, uint32_t w_bytes,
+                                                          float* __restrict__ stats, X6Ep ep) {
+    static_assert((BN == 128 && (BMT == 128 || BMT == 64)) || (BN == 64 && BMT == 256), "tile shapes");
+    static_assert(BMT % W == 0 && (W % 32 == 0 || 32 % W == 0), "fragment blocks are whole image rows or lie in one");
     using PT = X6Patch<BMT, W>;
-    constexpr int WM = 64, TM = 2, TN = 2;               // wave sub-tile 64 x 64: 2 x 2 waves (BN 128) or 4 x 1 (BN 64)
+    constexpr int WM = (BN == 128) ? BMT / 2 : 64;       // wave sub-tile WM x 64: 2 x 2 waves (BN 128) or 4 x 1 (BN 64)
+    constexpr int TM = WM / 32, TN = 2;
     constexpr int NPASS = PT::NPASS;
     constexpr int B_GRANULES = 2 * BN;
     extern __shared__ uint4 x6p_lds[];                   // [stage 2][plane 3][k-group 2][KGS]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = (BN == 128) ? (wave >> 1) : wave, wn = (BN == 128) ? (wave & 1) : 0;
-    int tile = x6_xcd_contiguous(blockIdx.x, m_tiles * n_tiles);
-    const int n_tile = tile % n_tiles; const int m_tile = tile / n_tiles;
+    int tile = x6_xcd_contiguous(blockIdx.x, m_tiles * n_tiles * k_splits);
+    const int n_tile = tile % n_tiles; tile /= n_tiles;
+    const int m_tile = tile % m_tiles; const int ks = tile / m_tiles;
     const int m0 = m_tile * BMT, n0 = n_tile * BN;
     const int M = p.B * p.Ho * p.Wo;                     // a multiple of BMT (launcher)
     const __amdgpu_buffer_rsrc_t xbuf = x6_buffer(X, x_bytes), wbuf = x6_buffer(Wimg, w_bytes);
 
-    // patch pixel pidx = py PW + px  <->  input pixel (y0 - 1 + py, px - 1) of image b
+    // patch pixel (py, px), LDS granule py PW + px  <->  input pixel (y0 - 1 + py, px - 1) of image `img`
     const int img = m0 / (p.Hi * W), y0 = (m0 % (p.Hi * W)) / W;
     const int a_q = t & 3, a_k4 = a_q * 4, a_r = t >> 2;
     int a_off[NPASS];                                    // element offset of (pixel, channel quad) at chunk 0; -1: zeros
+    int a_lds[NPASS];                                    // granule of the pixel in k-group 0; -1: no such pixel
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
         const int pidx = a_r + 64 * i;
-        const int py = pidx / PT::PW, px = pidx % PT::PW;
+        const int py = pidx / (W + 2), px = pidx % (W + 2);
         const int y = y0 - 1 + py, x = px - 1;
         const bool ok = pidx < PT::NPIX && (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)W;
         a_off[i] = ok ? ((img * p.Hi + y) * W + x) * p.Ci + a_k4 : -1;
+        a_lds[i] = pidx < PT::NPIX ? py * PT::PW + px : -1;
     }
 
     f32x16 acc[TM][TN];
@@ -688,26 +694,28 @@ __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restri
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int n_chunks = (p.Ci + XBK - 1) / XBK;
+    const int n_chunks = (p.Ci + XBK - 1) / XBK;       // K splits are ranges of channel chunks (all nine taps of each)
+    const int per_split = (n_chunks + k_splits - 1) / k_splits;
+    const int chunk_lo = ks * per_split, chunk_hi = min(n_chunks, chunk_lo + per_split);
     u32x4 ra[NPASS];
     u32x4 rbf[2][3][TN];                                 // [set][plane][n block]: B fragments as loaded
     bf16x8 af[2][3][TM];                                 // [set][plane][m block]: A fragments of the current / next tap
     const uint32_t b_lane = (uint32_t)((lane >> 5) * BN + wn * 64 + (lane & 31)) * 16u;
     auto load_a = [&](int i, int chunk) {                // pass i of the patch of `chunk` (past the end: zeros)
-        const bool ok = a_off[i] >= 0 && chunk < n_chunks && chunk * XBK + a_k4 < p.Ci;
+        const bool ok = a_off[i] >= 0 && chunk < chunk_hi && chunk * XBK + a_k4 < p.Ci;
         ra[i] = x6_load16(xbuf, ok ? (uint32_t)(a_off[i] + chunk * XBK) * 4u : X_OOB);
     };
     auto stage_piece = [&](int buf, int i) {
-        if (NPASS * 64 > PT::KGS && a_r + 64 * i >= PT::KGS) return;     // the tail of the last pass: past the k-group
+        if (NPASS * 64 > PT::NPIX && a_lds[i] < 0) return;               // the tail of the last pass
         uint2 h, m, l;
         split4(ra[i], h, m, l);
-        uint2* dst = reinterpret_cast<uint2*>(&x6p_lds[buf * PT::STAGE + (a_q >> 1) * PT::KGS + a_r + 64 * i]) + (a_q & 1);
+        uint2* dst = reinterpret_cast<uint2*>(&x6p_lds[buf * PT::STAGE + (a_q >> 1) * PT::KGS + a_lds[i]]) + (a_q & 1);
         dst[0] = h; dst[2 * PT::PLANE] = m; dst[4 * PT::PLANE] = l;
     };
     auto load_b = [&](auto SET, int f, int tap, int chunk) {             // fragment f of step (chunk, tap) (past the end: zeros)
         constexpr int S = decltype(SET)::value;
         const int pl = f / TN, j = f % TN;
-        const uint32_t dead = chunk < n_chunks ? 0u : X_OOB;
+        const uint32_t dead = chunk < chunk_hi ? 0u : X_OOB;
         const int blk = tap * n_chunks + chunk;
         rbf[S][pl][j] = x6_load16(wbuf, ((uint32_t)(blk * n_tiles + n_tile) * (uint32_t)(3 * B_GRANULES * 16) +
                                          (uint32_t)(pl * B_GRANULES * 16 + j * 32 * 16) + b_lane) | dead);
@@ -727,16 +735,16 @@ __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restri
     using Set0 = std::integral_constant<int, 0>;
     using Set1 = std::integral_constant<int, 1>;
 #pragma unroll
-    for (int i = 0; i < NPASS; ++i) load_a(i, 0);
+    for (int i = 0; i < NPASS; ++i) load_a(i, chunk_lo);
 #pragma unroll
-    for (int f = 0; f < 3 * TN; ++f) load_b(Set0{}, f, 0, 0);
+    for (int f = 0; f < 3 * TN; ++f) load_b(Set0{}, f, 0, chunk_lo);
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) stage_piece(0, i);
     __syncthreads();
 
     // chunk c (parity PAR): A fragments from LDS stage PAR; tap t uses B register set and fragment set (PAR + t) & 1 (nine taps:
-    // the next chunk starts on the other set).  Handed out between the 24 MFMAs of a tap: the B loads of the next step, the A
-    // fragment reads of the next tap, and this chunk's share of the patch of chunk c + 1 (loads in taps 0-2, stores in taps 5-8).
+    // the next chunk starts on the other set).  Handed out between the NM = 24 or 12 MFMAs of a tap: the B loads of the next step,
+    // the A fragment reads of the next tap, and this chunk's share of the patch of chunk c + 1 (loads in taps 0-2, stores in 5-8).
     auto body = [&](auto PARITY, int chunk) {
         constexpr int PAR = decltype(PARITY)::value;
 #pragma unroll
@@ -746,6 +754,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restri
                 if (PAR) read_frag(Set1{}, PAR, 0, pl, i); else read_frag(Set0{}, PAR, 0, pl, i);
             }
         constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};
+        constexpr int NM = 6 * TM * TN, BSTEP = NM / 6;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int S = (PAR + tap) & 1;
@@ -759,23 +768,23 @@ __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restri
                     for (int j = 0; j < TN; ++j) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[S][PA[q]][i], __builtin_bit_cast(bf16x8, rbf[S][PB[q]][j]),
                                                                             acc[i][j], 0, 0, 0);
-                        // B fragments of the next step: behind MFMAs 0, 4, .. 20
-                        if ((slot & 3) == 0) {
-                            const int f = slot >> 2, ntap = tap == 8 ? 0 : tap + 1, nchunk = tap == 8 ? chunk + 1 : chunk;
+                        // B fragments of the next step: behind MFMAs 0, 4, .. 20 (NM 12: 0, 2, .. 10)
+                        if (slot % BSTEP == 0) {
+                            const int f = slot / BSTEP, ntap = tap == 8 ? 0 : tap + 1, nchunk = tap == 8 ? chunk + 1 : chunk;
                             if (S) load_b(Set0{}, f, ntap, nchunk); else load_b(Set1{}, f, ntap, nchunk);
                         }
-                        // A fragments of the next tap: behind MFMAs 1, 5, .. 21 (the planes in the order the MFMAs want them)
-                        if ((slot & 3) == 1 && tap < 8) {
+                        // A fragments of the next tap: behind MFMAs 1, 5, .. (the planes in the order the MFMAs want them)
+                        if ((slot & 3) == 1 && tap < 8 && (slot >> 2) < 3 * TM) {
                             const int f = slot >> 2, pl = f / TM, i = f % TM;
                             if (S) read_frag(Set0{}, PAR, tap + 1, pl, i); else read_frag(Set1{}, PAR, tap + 1, pl, i);
                         }
                         // the patch of chunk + 1: three loads per tap in taps 0-2, two stores per tap in taps 5-8
-                        if (tap < 3 && (slot == 2 || slot == 10 || slot == 18)) {
-                            const int i = tap * 3 + (slot - 2) / 8;
+                        if (tap < 3 && slot % (NM / 3) == 2) {
+                            const int i = tap * 3 + slot / (NM / 3);
                             if (i < NPASS) load_a(i, chunk + 1);
                         }
-                        if (tap >= 5 && (slot == 6 || slot == 18)) {
-                            const int i = (tap - 5) * 2 + (slot == 18);
+                        if (tap >= 5 && slot % (NM / 2) == NM / 4) {
+                            const int i = (tap - 5) * 2 + slot / (NM / 2);
                             if (i < NPASS) stage_piece(PAR ^ 1, i);
                         }
                         ++slot;
@@ -784,9 +793,9 @@ __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restri
         }
         __syncthreads();
     };
-    for (int chunk = 0; chunk < n_chunks; chunk += 2) {
+    for (int chunk = chunk_lo; chunk < chunk_hi; chunk += 2) {
         body(Set0{}, chunk);
-        if (chunk + 1 < n_chunks) body(Set1{}, chunk + 1);
+        if (chunk + 1 < chunk_hi) body(Set1{}, chunk + 1);
     }
 
 #pragma unroll
@@ -795,14 +804,15 @@ __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restri
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * 64 + j * 32 + (lane & 31);
             if (n >= p.Co) continue;
-            const float bv = bias ? bias[n] : 0.f;
+            const float bv = (bias && ks == 0) ? bias[n] : 0.f;
             const bool affine = ep.scale != nullptr;     // the output epilogue of igemm_x6b_kernel
             const float es = affine ? ep.scale[n] : 1.f, et = affine ? ep.shift[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (row >= M) continue;
-                if (affine) {
+                if (k_splits > 1) atomicAdd(Y + row * p.Co + n, acc[i][j][r] + bv);
+                else if (affine) {
                     float v = fmaf(acc[i][j][r] + bv, es, et);
                     if (ep.residual) v += ep.residual[row * p.Co + n];
                     Y[row * p.Co + n] = ep.relu ? fmaxf(v, 0.f) : v;
@@ -1155,15 +1165,19 @@ static X6Plan x6_forward_plan(int64_t M, int Ci, int Co, int KH, int KW, int dil
     return X6Plan{bn, n_tiles, bdirect, bmt, m_tiles, k_splits};
 }
 
-// igemm_x6p_kernel's conditions: 3 x 3, stride 1, pad 1 on 64-wide maps, unsplit, tiles of whole image rows inside one image.
-// DSF_X6_PATCH=0 switches it off; read per call (tests/test_gpu_conv.py compares both kernels in one process).
-static bool x6_patch_applies(const X6Plan& plan, int Hi, int Wi, int Ho, int Wo, int KH, int KW, int stride, int dil, int pad_h,
-                             int pad_w) {
+// igemm_x6p_kernel's conditions: 3 x 3, stride 1, pad 1 on 64 / 32 / 16 / 8-wide maps, tiles of whole image rows inside one image,
+// K splits no finer than channel chunks.  DSF_X6_PATCH=0 switches it off, 1 keeps it to the 64-wide maps; read per call
+// (tests/test_gpu_conv.py compares the kernels in one process).
+static bool x6_patch_applies(const X6Plan& plan, int Hi, int Wi, int Ci, int Ho, int Wo, int KH, int KW, int stride, int dil,
+                             int pad_h, int pad_w) {
     const char* e = getenv("DSF_X6_PATCH");
-    if (e && atoi(e) == 0) return false;
-    const bool direct = plan.bdirect && !(plan.bmt == 64 && plan.n_tiles >= 2);
-    return direct && dil == 1 && KH == 3 && KW == 3 && stride == 1 && pad_h == 1 && pad_w == 1 && Ho == Hi && Wo == Wi && Wi == 64 &&
-           plan.k_splits == 1 && (plan.bn == 64 ? plan.bmt == 256 : plan.bmt == 128) && (Hi * Wi) % plan.bmt == 0;
+    const int level = e ? atoi(e) : 2;
+    if (level <= 0 || !plan.bdirect) return false;
+    if (!(dil == 1 && KH == 3 && KW == 3 && stride == 1 && pad_h == 1 && pad_w == 1 && Ho == Hi && Wo == Wi)) return false;
+    if ((Hi * Wi) % plan.bmt != 0 || plan.k_splits > (Ci + XBK - 1) / XBK) return false;
+    if (Wi == 64) return plan.bn == 64 ? plan.bmt == 256 : true;
+    if (level < 2 || plan.bn != 128) return false;
+    return Wi == 32 || (plan.bmt == 64 && (Wi == 16 || Wi == 8));
 }
 
 // Ci / Co are the reduction / output channel counts of the IMAGE (mode 1: those of the backward-data GEMM).
@@ -1187,7 +1201,8 @@ static int x6_forward_impl(const float* X, const void* image, const float* bias,
         dsf_zero_async(Y, sizeof(float) * (size_t)M * Co, (hipStream_t)stream) != hipSuccess) return DSF_ERR_LAUNCH;
     const dim3 grid(m_tiles * n_tiles * k_splits);
     // BatchNorm statistics in the epilogue: only the B-direct kernels, unsplit, without a bias
-    const bool direct_pre = bdirect && !(bmt == 64 && n_tiles >= 2);
+    const bool patch = x6_patch_applies(plan, Hi, Wi, Ci, Ho, Wo, KH, KW, stride, dil, pad_h, pad_w);
+    const bool direct_pre = patch || (bdirect && !(bmt == 64 && n_tiles >= 2));
     float* stats = (bn_stats && bn_rows && direct_pre && k_splits == 1 && !bias) ? bn_stats : nullptr;
     if (bn_rows) *bn_rows = stats ? m_tiles : 0;
     // the affine output epilogue has the same conditions (a split reduction meets in Y by atomics; the staged kernel has none)
@@ -1203,17 +1218,22 @@ static int x6_forward_impl(const float* X, const void* image, const float* bias,
     // 64-row tiles with several n tiles (16x16x256, 8x8x512 maps): every wave of the many small tiles would pull its own copy of
     // the weight block from L2 -- the LDS-staged kernel is faster there (measured 136 / 139 vs 133 / 133 TFLOP/s)
     const bool direct = bdirect && !(bmt == 64 && n_tiles >= 2);
-    if (x6_patch_applies(plan, Hi, Wi, Ho, Wo, KH, KW, stride, dil, pad_h, pad_w)) {
-#define DSF_LAUNCH_X6P(BNv, BMv)                                                                                                  \
+    if (patch) {
+#define DSF_LAUNCH_X6P(BNv, BMv, Wv)                                                                                              \
     do {                                                                                                                          \
-        using PT = X6Patch<BMv, 64>;                                                                                              \
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_x6p_kernel<BNv, BMv, 64>),        \
+        using PT = X6Patch<BMv, Wv>;                                                                                              \
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_x6p_kernel<BNv, BMv, Wv>),        \
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, PT::LDS_BYTES);            \
         if (attr != hipSuccess) return DSF_ERR_LAUNCH;                                                                            \
-        hipLaunchKernelGGL((igemm_x6p_kernel<BNv, BMv, 64>), grid, dim3(256), PT::LDS_BYTES, (hipStream_t)stream, X,              \
-                           (const uint4*)image, bias, Y, p, m_tiles, n_tiles, (uint32_t)x_bytes, (uint32_t)w_bytes, stats, ep);   \
+        hipLaunchKernelGGL((igemm_x6p_kernel<BNv, BMv, Wv>), grid, dim3(256), PT::LDS_BYTES, (hipStream_t)stream, X,              \
+                           (const uint4*)image, bias, Y, p, m_tiles, n_tiles, k_splits, (uint32_t)x_bytes, (uint32_t)w_bytes,     \
+                           stats, ep);                                                                                            \
     } while (0)
-        if (bn == 64) DSF_LAUNCH_X6P(64, 256); else DSF_LAUNCH_X6P(128, 128);
+        if (bn == 64) DSF_LAUNCH_X6P(64, 256, 64);
+        else if (Wi == 64) { if (bmt == 128) DSF_LAUNCH_X6P(128, 128, 64); else DSF_LAUNCH_X6P(128, 64, 64); }
+        else if (Wi == 32) { if (bmt == 128) DSF_LAUNCH_X6P(128, 128, 32); else DSF_LAUNCH_X6P(128, 64, 32); }
+        else if (Wi == 16) DSF_LAUNCH_X6P(128, 64, 16);
+        else DSF_LAUNCH_X6P(128, 64, 8);
 #undef DSF_LAUNCH_X6P
         return dsf_launch_status();
     }
@@ -1264,7 +1284,7 @@ int dsf_conv_x6_forward_variant(int B, int Hi, int Wi, int Ci, int Ho, int Wo, i
                                 int pad_w) {
     if (B <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || Ci <= 0 || Co <= 0 || KH <= 0 || KW <= 0 || (dil != 1 && dil != 2)) return -1;
     const X6Plan plan = x6_forward_plan((int64_t)B * Ho * Wo, Ci, Co, KH, KW, dil, 0);
-    if (x6_patch_applies(plan, Hi, Wi, Ho, Wo, KH, KW, stride, dil, pad_h, pad_w)) return 2;
+    if (x6_patch_applies(plan, Hi, Wi, Ci, Ho, Wo, KH, KW, stride, dil, pad_h, pad_w)) return 2;
     return (plan.bdirect && !(plan.bmt == 64 && plan.n_tiles >= 2)) ? 1 : 0;
 }
 

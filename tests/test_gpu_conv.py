@@ -191,42 +191,56 @@ def test_x6_matches_float64_as_closely_as_the_fp32_mfma(Ci, Co, K, s, p, H, B, m
         assert e6 < 3 * e32 + 1e-7, (i, e6, e32)
 
 
-@pytest.mark.parametrize("Ci,Co,H,B,bias", [
-    (64, 64, 8, 2, False),        # 256-pixel tiles, two per image: top and bottom image borders inside the patch
-    (20, 36, 12, 1, True),        # ragged chunk (20 channels), ragged n tile, three tiles per image
-    (36, 130, 64, 6, False),      # 128-wide n tiles (two, the second ragged), odd chunk count
-    (488, 256, 64, 6, True),      # the stage-2 fusion layer: half-filled last chunk
-    (64, 64, 64, 4, False),
+@pytest.mark.parametrize("Ci,Co,H,W,B,bias", [
+    (64, 64, 8, 64, 2, False),        # 256-pixel tiles, two per image: top and bottom image borders inside the patch
+    (20, 36, 12, 64, 1, True),        # ragged chunk (20 channels), ragged n tile, three tiles per image
+    (36, 130, 64, 64, 6, False),      # 128-wide n tiles (two, the second ragged), odd chunk count
+    (488, 256, 64, 64, 6, True),      # the stage-2 fusion layer: half-filled last chunk
+    (36, 130, 2, 64, 3, False),       # 64-row tiles of one image row each
+    (64, 64, 64, 64, 4, False),
+    (128, 128, 32, 32, 48, False),    # 32-wide maps, 128-row tiles (four image rows)
+    (20, 130, 32, 32, 2, True),       # 32-wide maps, 64-row tiles
+    (36, 130, 16, 16, 3, False),      # 16-wide maps: a fragment block covers two image rows
+    (40, 200, 8, 8, 5, True),         # 8-wide maps: a tile is one image, patch rows padded to 24 granules
+    (256, 256, 12, 16, 2, False),     # non-square: three tiles per image
 ])
-def test_patch_staged_3x3_kernel_is_bit_identical_to_the_per_tap_gather(Ci, Co, H, B, bias, monkeypatch):
-    """igemm_x6p_kernel (input staged once per 16-channel chunk as a patch with halo, read by all nine taps) against
-    igemm_x6b_kernel (one gather per tap, DSF_X6_PATCH=0) on 64-wide maps: same reduction order, so forward, input gradient
-    (the mode-1 image through the same kernel) and the BatchNorm-statistics epilogue are BITWISE equal; the shape really takes the
-    patch kernel (dsf_conv_x6_forward_variant == 2), and both agree with float64."""
+def test_patch_staged_3x3_kernel_is_bit_identical_to_the_per_tap_gather(Ci, Co, H, W, B, bias, monkeypatch):
+    """igemm_x6p_kernel (input staged once per 16-channel chunk as a patch with halo, read by all nine taps) against the per-tap
+    gather kernels (DSF_X6_PATCH=0) on 64 / 32 / 16 / 8-wide maps: same reduction order, so with an unsplit reduction
+    (deterministic mode) forward and input gradient (the mode-1 image through the same kernel) are BITWISE equal; with the K
+    splits the launcher chooses otherwise (float atomics; splits finer than the channel chunks fall back to the gather kernels)
+    the result stays at accumulation-order distance from float64.  Unsplit, the shape really takes the patch kernel
+    (dsf_conv_x6_forward_variant == 2)."""
     import ctypes
     from dsf_amd import nn_conv, _lib as L
     I = ctypes.c_int
     monkeypatch.setattr(nn_conv, "MATH", "x6")
-    W = 64
     g = torch.Generator().manual_seed(Ci + Co + H)
     x = torch.randn(B, Ci, H, W, generator=g).cuda().requires_grad_(True)
     w = (torch.randn(Co, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5).cuda().requires_grad_(True)
     b = torch.randn(Co, generator=g).cuda().requires_grad_(True) if bias else None
     gy = torch.randn(B, Co, H, W, generator=g).cuda()
     variant = lambda ci, co: int(L.lib().dsf_conv_x6_forward_variant(I(B), I(H), I(W), I(ci), I(H), I(W), I(co), I(3), I(3), I(1), I(1), I(1), I(1)))
-    out = {}
-    for patch in ("0", "1"):
-        monkeypatch.setenv("DSF_X6_PATCH", patch)
-        assert variant(Ci, Co) == (2 if patch == "1" else 1)
-        assert variant(Co, Ci) == (2 if patch == "1" else 1)          # the backward-data launch
-        y = nn_conv.Conv2dFunction.apply(x, w, b, 1, (1, 1))
-        gx, gw = torch.autograd.grad((y * gy).sum(), [x, w])
-        out[patch] = (y.detach(), gx, gw)
-    for a, r in zip(out["1"], out["0"]):
-        assert torch.equal(a, r)
-    xd, wd = x.detach().double().cpu(), w.detach().double().cpu()
+    xd, wd = x.detach().double().cpu().requires_grad_(True), w.detach().double().cpu()
     ref = F.conv2d(xd, wd, b.detach().double().cpu() if bias else None, padding=1)
-    assert _rel(out["1"][0].double().cpu(), ref) < 4e-6
+    gxd, = torch.autograd.grad((ref * gy.double().cpu()).sum(), [xd])
+    was = L.set_deterministic(True)
+    try:
+        out = {}
+        for patch in ("0", "2"):
+            monkeypatch.setenv("DSF_X6_PATCH", patch)
+            assert (variant(Ci, Co) == 2) == (patch == "2") and (variant(Co, Ci) == 2) == (patch == "2")
+            y = nn_conv.Conv2dFunction.apply(x, w, b, 1, (1, 1))
+            gx, = torch.autograd.grad((y * gy).sum(), [x])
+            out[patch] = (y.detach(), gx)
+        for a, r in zip(out["2"], out["0"]):
+            assert torch.equal(a, r)
+        L.set_deterministic(False)
+        y = nn_conv.Conv2dFunction.apply(x, w, b, 1, (1, 1))            # the launcher's own K splits
+        gx, = torch.autograd.grad((y * gy).sum(), [x])
+        assert _rel(y.detach().double().cpu(), ref.detach()) < 4e-6 and _rel(gx.double().cpu(), gxd) < 4e-6
+    finally:
+        L.set_deterministic(was)
 
 
 def test_x6_weight_images_follow_the_weights(monkeypatch):
