@@ -649,7 +649,7 @@ template <int BMT, int W> struct X6Patch {
     static constexpr int LDS_BYTES = 2 * STAGE * 16;
 };
 
-template <int BN, int BMT, int W>
+template <int BN, int BMT, int W, int NW = 2, int BD = 2>
 __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restrict__ X, const uint4* __restrict__ Wimg,
                                                           const float* __restrict__ bias, float* __restrict__ Y, X6P p, int m_tiles,
                                                           int n_tiles, int k_splits, uint32_t x_bytes, uint32_t w_bytes,
@@ -657,13 +657,17 @@ __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restri
     static_assert((BN == 128 && (BMT == 128 || BMT == 64)) || (BN == 64 && BMT == 256), "tile shapes");
     static_assert(BMT % W == 0 && (W % 32 == 0 || 32 % W == 0), "fragment blocks are whole image rows or lie in one");
     using PT = X6Patch<BMT, W>;
-    constexpr int WM = (BN == 128) ? BMT / 2 : 64;       // wave sub-tile WM x 64: 2 x 2 waves (BN 128) or 4 x 1 (BN 64)
-    constexpr int TM = WM / 32, TN = 2;
+    // waves: WMW x WN, each WM rows x WNC columns: 2 x 2 of (BMT / 2) x 64 (BN 128), 4 x 1 of 64 x 64 (BN 64), or -- NW = 4, the
+    // 64-row tiles -- 1 x 4 of 64 x 32: every wave then reads its own quarter of the weight block (half the weight traffic of the
+    // 2 x 2 arrangement, whose two wave rows pull the same fragments) and all of the A tile
+    constexpr int WN = (BN == 128) ? NW : 1, WMW = 4 / WN, WNC = BN / WN;
+    constexpr int WM = BMT / WMW, TM = WM / 32, TN = WNC / 32;
+    static_assert(NW == 2 || (NW == 4 && BN == 128 && BMT == 64), "wave arrangements");
     constexpr int NPASS = PT::NPASS;
     constexpr int B_GRANULES = 2 * BN;
     extern __shared__ uint4 x6p_lds[];                   // [stage 2][plane 3][k-group 2][KGS]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = (BN == 128) ? (wave >> 1) : wave, wn = (BN == 128) ? (wave & 1) : 0;
+    const int wm = wave / WN, wn = wave % WN;
     int tile = x6_xcd_contiguous(blockIdx.x, m_tiles * n_tiles * k_splits);
     const int n_tile = tile % n_tiles; tile /= n_tiles;
     const int m_tile = tile % m_tiles; const int ks = tile / m_tiles;
@@ -698,9 +702,9 @@ __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restri
     const int per_split = (n_chunks + k_splits - 1) / k_splits;
     const int chunk_lo = ks * per_split, chunk_hi = min(n_chunks, chunk_lo + per_split);
     u32x4 ra[NPASS];
-    u32x4 rbf[2][3][TN];                                 // [set][plane][n block]: B fragments as loaded
+    u32x4 rbf[BD][3][TN];                                // [set][plane][n block]: B fragments as loaded, BD - 1 steps ahead
     bf16x8 af[2][3][TM];                                 // [set][plane][m block]: A fragments of the current / next tap
-    const uint32_t b_lane = (uint32_t)((lane >> 5) * BN + wn * 64 + (lane & 31)) * 16u;
+    const uint32_t b_lane = (uint32_t)((lane >> 5) * BN + wn * WNC + (lane & 31)) * 16u;
     auto load_a = [&](int i, int chunk) {                // pass i of the patch of `chunk` (past the end: zeros)
         const bool ok = a_off[i] >= 0 && chunk < chunk_hi && chunk * XBK + a_k4 < p.Ci;
         ra[i] = x6_load16(xbuf, ok ? (uint32_t)(a_off[i] + chunk * XBK) * 4u : X_OOB);
@@ -712,8 +716,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restri
         uint2* dst = reinterpret_cast<uint2*>(&x6p_lds[buf * PT::STAGE + (a_q >> 1) * PT::KGS + a_lds[i]]) + (a_q & 1);
         dst[0] = h; dst[2 * PT::PLANE] = m; dst[4 * PT::PLANE] = l;
     };
-    auto load_b = [&](auto SET, int f, int tap, int chunk) {             // fragment f of step (chunk, tap) (past the end: zeros)
-        constexpr int S = decltype(SET)::value;
+    auto load_b = [&](int S, int f, int tap, int chunk) {                // fragment f of step (chunk, tap) (past the end: zeros)
         const int pl = f / TN, j = f % TN;
         const uint32_t dead = chunk < chunk_hi ? 0u : X_OOB;
         const int blk = tap * n_chunks + chunk;
@@ -737,7 +740,11 @@ __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restri
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) load_a(i, chunk_lo);
 #pragma unroll
-    for (int f = 0; f < 3 * TN; ++f) load_b(Set0{}, f, 0, chunk_lo);
+    for (int f = 0; f < 3 * TN; ++f) load_b(0, f, 0, chunk_lo);
+    if (BD == 3) {
+#pragma unroll
+        for (int f = 0; f < 3 * TN; ++f) load_b(1, f, 1, chunk_lo);
+    }
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) stage_piece(0, i);
     __syncthreads();
@@ -754,10 +761,11 @@ __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restri
                 if (PAR) read_frag(Set1{}, PAR, 0, pl, i); else read_frag(Set0{}, PAR, 0, pl, i);
             }
         constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};
-        constexpr int NM = 6 * TM * TN, BSTEP = NM / 6;
+        constexpr int NM = 6 * TM * TN, BSTEP = 2 * TM, ASTEP = 2 * TN;   // NM / (3 TN) B loads, NM / (3 TM) fragment reads
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int S = (PAR + tap) & 1;
+            const int S = (PAR + tap) & 1;                 // fragment set;  B set: the same (BD 2), tap mod 3 (BD 3: nine taps)
+            const int SB = BD == 3 ? tap % 3 : S;
             __builtin_amdgcn_sched_barrier(0);
             int slot = 0;
 #pragma unroll
@@ -766,16 +774,16 @@ __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restri
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[S][PA[q]][i], __builtin_bit_cast(bf16x8, rbf[S][PB[q]][j]),
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[S][PA[q]][i], __builtin_bit_cast(bf16x8, rbf[SB][PB[q]][j]),
                                                                             acc[i][j], 0, 0, 0);
                         // B fragments of the next step: behind MFMAs 0, 4, .. 20 (NM 12: 0, 2, .. 10)
                         if (slot % BSTEP == 0) {
-                            const int f = slot / BSTEP, ntap = tap == 8 ? 0 : tap + 1, nchunk = tap == 8 ? chunk + 1 : chunk;
-                            if (S) load_b(Set0{}, f, ntap, nchunk); else load_b(Set1{}, f, ntap, nchunk);
+                            const int f = slot / BSTEP, ahead = tap + BD - 1;
+                            load_b(BD == 3 ? ahead % 3 : S ^ 1, f, ahead % 9, chunk + ahead / 9);
                         }
                         // A fragments of the next tap: behind MFMAs 1, 5, .. (the planes in the order the MFMAs want them)
-                        if ((slot & 3) == 1 && tap < 8 && (slot >> 2) < 3 * TM) {
-                            const int f = slot >> 2, pl = f / TM, i = f % TM;
+                        if (slot % ASTEP == 1 && tap < 8) {
+                            const int f = slot / ASTEP, pl = f / TM, i = f % TM;
                             if (S) read_frag(Set0{}, PAR, tap + 1, pl, i); else read_frag(Set1{}, PAR, tap + 1, pl, i);
                         }
                         // the patch of chunk + 1: three loads per tap in taps 0-2, two stores per tap in taps 5-8
@@ -802,7 +810,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restri
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+            const int n = n0 + wn * WNC + j * 32 + (lane & 31);
             if (n >= p.Co) continue;
             const float bv = (bias && ks == 0) ? bias[n] : 0.f;
             const bool affine = ep.scale != nullptr;     // the output epilogue of igemm_x6b_kernel
@@ -835,15 +843,14 @@ __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restri
             if (lane < 32) { s_st[wave][0][j * 32 + lane] = su; s_st[wave][1][j * 32 + lane] = sq; }
         }
         __syncthreads();
-        constexpr int WAVES_M = (BN == 128) ? 2 : 4;
         for (int e = t; e < 2 * BN; e += 256) {
             const int which = e / BN, c = e % BN;
             const int n = n0 + c;
             if (n >= p.Co) continue;
-            const int wcol = (BN == 128) ? (c >> 6) : 0, lc = c & 63;
+            const int wcol = c / WNC, lc = c % WNC;
             float tot = 0.f;
 #pragma unroll
-            for (int w = 0; w < WAVES_M; ++w) tot += s_st[(BN == 128) ? (w * 2 + wcol) : w][which][lc];
+            for (int w = 0; w < WMW; ++w) tot += s_st[w * WN + wcol][which][lc];
             if (ep.stats_acc > 0)
                 __hip_atomic_fetch_add(reinterpret_cast<double*>(stats) + ((int64_t)(m_tile % ep.stats_acc) * 2 + which) * p.Co + n, (double)tot,
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1139,7 +1146,16 @@ int dsf_conv_x6_split_weights_multi(const int64_t* jobs, int n_jobs, int64_t tot
 
 // Tiling of one forward launch: tile rows, tile counts and the number of K splits (k_splits < 1: chosen here).
 struct X6Plan { int bn, n_tiles, bdirect, bmt, m_tiles, k_splits; };
-static X6Plan x6_forward_plan(int64_t M, int Ci, int Co, int KH, int KW, int dil, int k_splits) {
+// the geometry igemm_x6p_kernel serves: 3 x 3, stride 1, pad 1 on 64 / 32 / 16 / 8-wide maps (DSF_X6_PATCH=0 switches the kernel
+// off, 1 keeps it to the 64-wide maps; read per call: tests/test_gpu_conv.py compares the kernels in one process)
+static bool x6_patch_geometry(int Hi, int Wi, int Ho, int Wo, int KH, int KW, int stride, int dil, int pad_h, int pad_w) {
+    const char* e = getenv("DSF_X6_PATCH");
+    const int level = e ? atoi(e) : 2;
+    if (level <= 0) return false;
+    if (!(dil == 1 && KH == 3 && KW == 3 && stride == 1 && pad_h == 1 && pad_w == 1 && Ho == Hi && Wo == Wi)) return false;
+    return Wi == 64 || (level >= 2 && (Wi == 32 || Wi == 16 || Wi == 8));
+}
+static X6Plan x6_forward_plan(int64_t M, int Ci, int Co, int KH, int KW, int dil, int k_splits, bool patch_geo = false) {
     const int bn = x6_bn(Co);
     const int n_tiles = (Co + bn - 1) / bn;
     // DSF_X6_BDIRECT=0: the first-generation kernels (both operands through LDS); default: igemm_x6b_kernel (B operand straight
@@ -1151,6 +1167,15 @@ static X6Plan x6_forward_plan(int64_t M, int Ci, int Co, int KH, int KW, int dil
     if (bdirect && bn == 64) bmt = 256;                                  // 4 x 1 waves of 64 x 64
     const int m_tiles = (int)((M + bmt - 1) / bmt);
     const int n_chunks = (KH * KW / (dil * dil)) * ((Ci + XBK - 1) / XBK);          // live chunks of a tile
+    if (k_splits < 1 && patch_geo && bdirect && bmt == 64) {
+        // the patch kernel's 64-row tiles: one workgroup per CU already runs at the rate of two half-length ones (B = 32, 16x16x256:
+        // 256 tiles unsplit 48 us, 2-way 54) and an unsplit launch needs no zero fill, keeps the BatchNorm-statistics epilogue and is
+        // deterministic; 128 tiles: unsplit 67 us, 4-way 54.  Splits are ranges of channel chunks, at least two each.
+        const int tiles = m_tiles * n_tiles, ch = (Ci + XBK - 1) / XBK;
+        k_splits = tiles < 256 ? (512 + tiles - 1) / tiles : 1;
+        if (k_splits > ch / 2) k_splits = ch / 2;
+        if (k_splits < 1) k_splits = 1;
+    }
     if (k_splits < 1) {
         // auto: fewer than ~0.8 tiles per CU -> split K towards 2 workgroups per CU.  Each split adds M x Co float atomics
         // (~1.3 TB/s chip-wide), so 256 tiles run unsplit (69 vs 83 us on the 32x32x128 layers), 128 tiles 4-way, 64 8-way.
@@ -1165,19 +1190,13 @@ static X6Plan x6_forward_plan(int64_t M, int Ci, int Co, int KH, int KW, int dil
     return X6Plan{bn, n_tiles, bdirect, bmt, m_tiles, k_splits};
 }
 
-// igemm_x6p_kernel's conditions: 3 x 3, stride 1, pad 1 on 64 / 32 / 16 / 8-wide maps, tiles of whole image rows inside one image,
-// K splits no finer than channel chunks.  DSF_X6_PATCH=0 switches it off, 1 keeps it to the 64-wide maps; read per call
-// (tests/test_gpu_conv.py compares the kernels in one process).
-static bool x6_patch_applies(const X6Plan& plan, int Hi, int Wi, int Ci, int Ho, int Wo, int KH, int KW, int stride, int dil,
-                             int pad_h, int pad_w) {
-    const char* e = getenv("DSF_X6_PATCH");
-    const int level = e ? atoi(e) : 2;
-    if (level <= 0 || !plan.bdirect) return false;
-    if (!(dil == 1 && KH == 3 && KW == 3 && stride == 1 && pad_h == 1 && pad_w == 1 && Ho == Hi && Wo == Wi)) return false;
+// igemm_x6p_kernel's conditions on top of x6_patch_geometry: tiles of whole image rows inside one image, K splits no finer than
+// channel chunks
+static bool x6_patch_applies(const X6Plan& plan, bool patch_geo, int Hi, int Wi, int Ci) {
+    if (!patch_geo || !plan.bdirect) return false;
     if ((Hi * Wi) % plan.bmt != 0 || plan.k_splits > (Ci + XBK - 1) / XBK) return false;
     if (Wi == 64) return plan.bn == 64 ? plan.bmt == 256 : true;
-    if (level < 2 || plan.bn != 128) return false;
-    return Wi == 32 || (plan.bmt == 64 && (Wi == 16 || Wi == 8));
+    return plan.bn == 128 && (Wi == 32 || plan.bmt == 64);
 }
 
 // Ci / Co are the reduction / output channel counts of the IMAGE (mode 1: those of the backward-data GEMM).
@@ -1193,7 +1212,8 @@ static int x6_forward_impl(const float* X, const void* image, const float* bias,
     const int64_t M = (int64_t)B * Ho * Wo;
     const int64_t x_bytes = (int64_t)B * Hi * Wi * Ci * 4, w_bytes = dsf_conv_x6_image_bytes(KH, KW, Ci, Co);
     DSF_CHECK_ARG(M < (1ll << 31) && x_bytes < 0xFFFFFFF0ll && w_bytes < 0xFFFFFFF0ll);
-    const X6Plan plan = x6_forward_plan(M, Ci, Co, KH, KW, dil, k_splits);
+    const bool patch_geo = x6_patch_geometry(Hi, Wi, Ho, Wo, KH, KW, stride, dil, pad_h, pad_w);
+    const X6Plan plan = x6_forward_plan(M, Ci, Co, KH, KW, dil, k_splits, patch_geo);
     const int bn = plan.bn, n_tiles = plan.n_tiles, bdirect = plan.bdirect, bmt = plan.bmt, m_tiles = plan.m_tiles;
     k_splits = plan.k_splits;
     if (y_ready && k_splits < 2) return DSF_ERR_UNSUPPORTED;             // only the split launches ADD into Y
@@ -1201,7 +1221,7 @@ static int x6_forward_impl(const float* X, const void* image, const float* bias,
         dsf_zero_async(Y, sizeof(float) * (size_t)M * Co, (hipStream_t)stream) != hipSuccess) return DSF_ERR_LAUNCH;
     const dim3 grid(m_tiles * n_tiles * k_splits);
     // BatchNorm statistics in the epilogue: only the B-direct kernels, unsplit, without a bias
-    const bool patch = x6_patch_applies(plan, Hi, Wi, Ci, Ho, Wo, KH, KW, stride, dil, pad_h, pad_w);
+    const bool patch = x6_patch_applies(plan, patch_geo, Hi, Wi, Ci);
     const bool direct_pre = patch || (bdirect && !(bmt == 64 && n_tiles >= 2));
     float* stats = (bn_stats && bn_rows && direct_pre && k_splits == 1 && !bias) ? bn_stats : nullptr;
     if (bn_rows) *bn_rows = stats ? m_tiles : 0;
@@ -1219,21 +1239,24 @@ static int x6_forward_impl(const float* X, const void* image, const float* bias,
     // the weight block from L2 -- the LDS-staged kernel is faster there (measured 136 / 139 vs 133 / 133 TFLOP/s)
     const bool direct = bdirect && !(bmt == 64 && n_tiles >= 2);
     if (patch) {
-#define DSF_LAUNCH_X6P(BNv, BMv, Wv)                                                                                              \
+#define DSF_LAUNCH_X6P(BNv, BMv, Wv, NWv, BDv)                                                                                    \
     do {                                                                                                                          \
         using PT = X6Patch<BMv, Wv>;                                                                                              \
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_x6p_kernel<BNv, BMv, Wv>),        \
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_x6p_kernel<BNv, BMv, Wv, NWv, BDv>), \
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, PT::LDS_BYTES);            \
         if (attr != hipSuccess) return DSF_ERR_LAUNCH;                                                                            \
-        hipLaunchKernelGGL((igemm_x6p_kernel<BNv, BMv, Wv>), grid, dim3(256), PT::LDS_BYTES, (hipStream_t)stream, X,              \
+        hipLaunchKernelGGL((igemm_x6p_kernel<BNv, BMv, Wv, NWv, BDv>), grid, dim3(256), PT::LDS_BYTES, (hipStream_t)stream, X,    \
                            (const uint4*)image, bias, Y, p, m_tiles, n_tiles, k_splits, (uint32_t)x_bytes, (uint32_t)w_bytes,     \
                            stats, ep);                                                                                            \
     } while (0)
-        if (bn == 64) DSF_LAUNCH_X6P(64, 256, 64);
-        else if (Wi == 64) { if (bmt == 128) DSF_LAUNCH_X6P(128, 128, 64); else DSF_LAUNCH_X6P(128, 64, 64); }
-        else if (Wi == 32) { if (bmt == 128) DSF_LAUNCH_X6P(128, 128, 32); else DSF_LAUNCH_X6P(128, 64, 32); }
-        else if (Wi == 16) DSF_LAUNCH_X6P(128, 64, 16);
-        else DSF_LAUNCH_X6P(128, 64, 8);
+        // 64-row tiles: 1 x 4 waves and weight fragments two taps ahead (B = 32, 16x16x256 unsplit: 2 x 2 waves 55 us, 1 x 4 51,
+        // + two taps ahead 48; no gain from either on the taller tiles, which have two workgroups per CU to hide the latency)
+        if (bn == 64) DSF_LAUNCH_X6P(64, 256, 64, 2, 2);
+        else if (bmt == 128) { if (Wi == 64) DSF_LAUNCH_X6P(128, 128, 64, 2, 2); else DSF_LAUNCH_X6P(128, 128, 32, 2, 2); }
+        else if (Wi == 64) DSF_LAUNCH_X6P(128, 64, 64, 4, 3);
+        else if (Wi == 32) DSF_LAUNCH_X6P(128, 64, 32, 4, 3);
+        else if (Wi == 16) DSF_LAUNCH_X6P(128, 64, 16, 4, 3);
+        else DSF_LAUNCH_X6P(128, 64, 8, 4, 3);
 #undef DSF_LAUNCH_X6P
         return dsf_launch_status();
     }
@@ -1278,14 +1301,18 @@ int dsf_conv_x6_forward_splits(int B, int Ho, int Wo, int Ci, int Co, int KH, in
     return x6_forward_plan((int64_t)B * Ho * Wo, Ci, Co, KH, KW, dil, 0).k_splits;
 }
 
-// Which kernel dsf_conv_x6_forward (k_splits <= 0) launches for this shape: 0 igemm_x6_kernel (both operands through LDS),
-// 1 igemm_x6b_kernel (weights straight into the fragment registers), 2 igemm_x6p_kernel (the same with a patch-staged input).
-int dsf_conv_x6_forward_variant(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int dil, int pad_h,
-                                int pad_w) {
-    if (B <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || Ci <= 0 || Co <= 0 || KH <= 0 || KW <= 0 || (dil != 1 && dil != 2)) return -1;
-    const X6Plan plan = x6_forward_plan((int64_t)B * Ho * Wo, Ci, Co, KH, KW, dil, 0);
-    if (x6_patch_applies(plan, Hi, Wi, Ci, Ho, Wo, KH, KW, stride, dil, pad_h, pad_w)) return 2;
-    return (plan.bdirect && !(plan.bmt == 64 && plan.n_tiles >= 2)) ? 1 : 0;
+// What dsf_conv_x6_forward (k_splits <= 0) launches for this layer.  *variant: 0 igemm_x6_kernel (both operands through LDS),
+// 1 igemm_x6b_kernel (weights straight into the fragment registers), 2 igemm_x6p_kernel (the same with a patch-staged input);
+// *k_splits: its K splits (1: an unsplit launch that stores Y).  Either pointer may be null.
+int dsf_conv_x6_forward_plan(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int dil, int pad_h,
+                             int pad_w, int* variant, int* k_splits) {
+    DSF_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && Ci > 0 && Co > 0 && KH > 0 && KW > 0 && (dil == 1 || dil == 2));
+    const bool patch_geo = x6_patch_geometry(Hi, Wi, Ho, Wo, KH, KW, stride, dil, pad_h, pad_w);
+    const X6Plan plan = x6_forward_plan((int64_t)B * Ho * Wo, Ci, Co, KH, KW, dil, 0, patch_geo);
+    if (variant)
+        *variant = x6_patch_applies(plan, patch_geo, Hi, Wi, Ci) ? 2 : (plan.bdirect && !(plan.bmt == 64 && plan.n_tiles >= 2)) ? 1 : 0;
+    if (k_splits) *k_splits = plan.k_splits;
+    return DSF_OK;
 }
 
 // dsf_conv_x6_forward as a split launch that ADDS into a Y the caller has initialised (zeros from one pooled fill instead of a

@@ -189,7 +189,11 @@ def _fwd_x6(x, image, bias, out_hw, Co, KH, KW, stride, pad, dil=1):
     if _ZERO is not None and B > 0 and y.numel() * 4 <= ZERO_POOL_MAX_BYTES:
         # a small layer that the launcher splits along K (partial sums meet in Y by float atomics): Y from the step's pooled zero
         # fill instead of a fill launch of its own in front of every such layer
-        splits = int(L.lib().dsf_conv_x6_forward_splits(I(B), I(Ho), I(Wo), I(Ci), I(Co), I(KH), I(KW), I(dil)))
+        import ctypes
+        k = ctypes.c_int(1)
+        check(L.lib().dsf_conv_x6_forward_plan(I(B), I(Hi), I(Wi), I(Ci), I(Ho), I(Wo), I(Co), I(KH), I(KW), I(stride), I(dil), I(pad[0]),
+                                               I(pad[1]), None, ctypes.byref(k)), "dsf_conv_x6_forward_plan")
+        splits = k.value
         off = _zero_take(B * Ho * Wo * Co, x.device) if splits > 1 else None
         if off is not None:
             # (a tensor of its own on the pool's storage, not a view of the pool: views share ONE version counter, and an

@@ -388,12 +388,14 @@ int dsf_conv_x6_forward_splits(int B, int Ho, int Wo, int Ci, int Co, int KH, in
 int dsf_conv_x6_forward_into(const float* X, const void* image, const float* bias, float* Y, int B, int Hi, int Wi, int Ci, int Ho,
                              int Wo, int Co, int KH, int KW, int stride, int dil, int pad_h, int pad_w, int k_splits,
                              dsf_stream_t stream);
-/* Which kernel dsf_conv_x6_forward (k_splits <= 0) launches for this shape: 0 = both operands staged through LDS, 1 = weight
- * fragments read straight from the image, 2 = the same with the input staged once per 16-channel chunk as a patch with halo and
- * read by all nine taps (3 x 3, stride 1, pad 1, 64-wide maps; bit-identical to variant 1; DSF_X6_PATCH=0 switches it off).
- * -1 on a bad argument.  Additive in round 5 (the ABI version stays 2). */
-int dsf_conv_x6_forward_variant(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int dil, int pad_h,
-                                int pad_w);
+/* What dsf_conv_x6_forward (k_splits <= 0) launches for this layer, with the full geometry (dsf_conv_x6_forward_splits knows only
+ * the output size and answers for the general kernels).  *variant: 0 = both operands staged through LDS, 1 = weight fragments
+ * read straight from the image, 2 = the same with the input staged once per 16-channel chunk as a patch with halo that all nine
+ * taps read (3 x 3, stride 1, pad 1, maps 64 / 32 / 16 / 8 wide; bit-identical to the others when unsplit; DSF_X6_PATCH=0
+ * switches it off).  *k_splits: the K splits of that launch -- what to hand dsf_conv_x6_forward_into.  Either pointer may be
+ * NULL.  Additive in round 5 (the ABI version stays 2). */
+int dsf_conv_x6_forward_plan(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int dil, int pad_h,
+                             int pad_w, int* variant, int* k_splits);
 /* Measurement aid for bench.py: launches a bare v_mfma_f32_32x32x16_bf16 loop (no memory traffic) on `workgroups` x 4 waves,
  * `iters` x 24 MFMAs each, operands = 16 KiB of bf16 pairs; returns the number of MFMAs issued (each 2*32*32*16 flop), -1 on error.
  * Timed by the caller: the matrix-pipe rate the chip sustains at the clock it holds under that load. */
