@@ -59,6 +59,15 @@ __device__ __forceinline__ int x6_xcd_contiguous(int bid, int total) {
     return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
 }
 
+// Dilation-2 gathers (transposed convolutions, backward-data of stride-2 layers) order their rows by output parity class, and the
+// classes differ in live taps (k = 1: one class carries the whole GEMM, three store zeros; k = 3: 4 / 2 / 2 / 1 taps).  In
+// launch order the heavy class would fill two of the eight XCDs and leave six idle (B = 192, 32x32x512 -> 64x64x256 k1: 1090 us):
+// deal the tiles of the four classes round-robin instead (a bijection on [0, m_tiles)).
+__device__ __forceinline__ int x6_dil2_tile(int j, int m_tiles) {
+    const int q = m_tiles >> 2;
+    return j < 4 * q ? (j & 3) * q + (j >> 2) : j;
+}
+
 // two floats -> packed bf16 pair (round to nearest even; v_cvt_pk_bf16_f32), and back
 __device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
     const f32x2 v = {a, b};
@@ -161,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(const float* __restric
     const int wm = (BN == 128) ? (wave >> 1) : wave, wn = (BN == 128) ? (wave & 1) : 0;
     int tile = x6_xcd_contiguous(blockIdx.x, m_tiles * n_tiles * k_splits);
     const int n_tile = tile % n_tiles; tile /= n_tiles;
-    const int m_tile = tile % m_tiles; const int ks = tile / m_tiles;
+    const int m_tile = DIL2 ? x6_dil2_tile(tile % m_tiles, m_tiles) : tile % m_tiles; const int ks = tile / m_tiles;
     const int m0 = m_tile * BMT, n0 = n_tile * BN;
     const bool b_thread = t < B_GRANULES;                // BN 64: waves 0-1 carry the B tile (wave-uniform)
     const int M = p.B * p.Ho * p.Wo;
@@ -389,7 +398,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x6b_kernel(const float* __restri
     const int wm = (BN == 128) ? (wave >> 1) : wave, wn = (BN == 128) ? (wave & 1) : 0;
     int tile = x6_xcd_contiguous(blockIdx.x, m_tiles * n_tiles * k_splits);
     const int n_tile = tile % n_tiles; tile /= n_tiles;
-    const int m_tile = tile % m_tiles; const int ks = tile / m_tiles;
+    const int m_tile = DIL2 ? x6_dil2_tile(tile % m_tiles, m_tiles) : tile % m_tiles; const int ks = tile / m_tiles;
     const int m0 = m_tile * BMT, n0 = n_tile * BN;
     const int M = p.B * p.Ho * p.Wo;
     const __amdgpu_buffer_rsrc_t xbuf = x6_buffer(X, x_bytes), wbuf = x6_buffer(Wimg, w_bytes);
@@ -1155,7 +1164,8 @@ static bool x6_patch_geometry(int Hi, int Wi, int Ho, int Wo, int KH, int KW, in
     if (!(dil == 1 && KH == 3 && KW == 3 && stride == 1 && pad_h == 1 && pad_w == 1 && Ho == Hi && Wo == Wi)) return false;
     return Wi == 64 || (level >= 2 && (Wi == 32 || Wi == 16 || Wi == 8));
 }
-static X6Plan x6_forward_plan(int64_t M, int Ci, int Co, int KH, int KW, int dil, int k_splits, bool patch_geo = false) {
+// patch_w: the map width when the layer has igemm_x6p_kernel's geometry (x6_patch_geometry), else 0
+static X6Plan x6_forward_plan(int64_t M, int Ci, int Co, int KH, int KW, int dil, int k_splits, int patch_w = 0) {
     const int bn = x6_bn(Co);
     const int n_tiles = (Co + bn - 1) / bn;
     // DSF_X6_BDIRECT=0: the first-generation kernels (both operands through LDS); default: igemm_x6b_kernel (B operand straight
@@ -1165,9 +1175,10 @@ static X6Plan x6_forward_plan(int64_t M, int Ci, int Co, int KH, int KW, int dil
     static const int bm_env = [] { const char* e = getenv("DSF_X6_BM"); return e ? atoi(e) : 0; }();             // tuning aid
     int bmt = (bn == 128 && (bm_env == 64 || (bm_env != 128 && ((M + 127) / 128) * n_tiles < 384))) ? 64 : 128;
     if (bdirect && bn == 64) bmt = 256;                                  // 4 x 1 waves of 64 x 64
+    if (bdirect && bn == 128 && patch_w == 8) bmt = 64;                  // the patch kernel's tiles lie inside one (8 x 8) image
     const int m_tiles = (int)((M + bmt - 1) / bmt);
     const int n_chunks = (KH * KW / (dil * dil)) * ((Ci + XBK - 1) / XBK);          // live chunks of a tile
-    if (k_splits < 1 && patch_geo && bdirect && bmt == 64) {
+    if (k_splits < 1 && patch_w && bdirect && bmt == 64) {
         // the patch kernel's 64-row tiles: one workgroup per CU already runs at the rate of two half-length ones (B = 32, 16x16x256:
         // 256 tiles unsplit 48 us, 2-way 54) and an unsplit launch needs no zero fill, keeps the BatchNorm-statistics epilogue and is
         // deterministic; 128 tiles: unsplit 67 us, 4-way 54.  Splits are ranges of channel chunks, at least two each.
@@ -1196,7 +1207,7 @@ static bool x6_patch_applies(const X6Plan& plan, bool patch_geo, int Hi, int Wi,
     if (!patch_geo || !plan.bdirect) return false;
     if ((Hi * Wi) % plan.bmt != 0 || plan.k_splits > (Ci + XBK - 1) / XBK) return false;
     if (Wi == 64) return plan.bn == 64 ? plan.bmt == 256 : true;
-    return plan.bn == 128 && (Wi == 32 || plan.bmt == 64);
+    return plan.bn == 128 && (Wi == 32 || Wi == 16 || plan.bmt == 64);
 }
 
 // Ci / Co are the reduction / output channel counts of the IMAGE (mode 1: those of the backward-data GEMM).
@@ -1213,7 +1224,7 @@ static int x6_forward_impl(const float* X, const void* image, const float* bias,
     const int64_t x_bytes = (int64_t)B * Hi * Wi * Ci * 4, w_bytes = dsf_conv_x6_image_bytes(KH, KW, Ci, Co);
     DSF_CHECK_ARG(M < (1ll << 31) && x_bytes < 0xFFFFFFF0ll && w_bytes < 0xFFFFFFF0ll);
     const bool patch_geo = x6_patch_geometry(Hi, Wi, Ho, Wo, KH, KW, stride, dil, pad_h, pad_w);
-    const X6Plan plan = x6_forward_plan(M, Ci, Co, KH, KW, dil, k_splits, patch_geo);
+    const X6Plan plan = x6_forward_plan(M, Ci, Co, KH, KW, dil, k_splits, patch_geo ? Wi : 0);
     const int bn = plan.bn, n_tiles = plan.n_tiles, bdirect = plan.bdirect, bmt = plan.bmt, m_tiles = plan.m_tiles;
     k_splits = plan.k_splits;
     if (y_ready && k_splits < 2) return DSF_ERR_UNSUPPORTED;             // only the split launches ADD into Y
@@ -1252,7 +1263,10 @@ static int x6_forward_impl(const float* X, const void* image, const float* bias,
         // 64-row tiles: 1 x 4 waves and weight fragments two taps ahead (B = 32, 16x16x256 unsplit: 2 x 2 waves 55 us, 1 x 4 51,
         // + two taps ahead 48; no gain from either on the taller tiles, which have two workgroups per CU to hide the latency)
         if (bn == 64) DSF_LAUNCH_X6P(64, 256, 64, 2, 2);
-        else if (bmt == 128) { if (Wi == 64) DSF_LAUNCH_X6P(128, 128, 64, 2, 2); else DSF_LAUNCH_X6P(128, 128, 32, 2, 2); }
+        else if (bmt == 128) {
+            if (Wi == 64) DSF_LAUNCH_X6P(128, 128, 64, 2, 2); else if (Wi == 32) DSF_LAUNCH_X6P(128, 128, 32, 2, 2);
+            else DSF_LAUNCH_X6P(128, 128, 16, 2, 2);
+        }
         else if (Wi == 64) DSF_LAUNCH_X6P(128, 64, 64, 4, 3);
         else if (Wi == 32) DSF_LAUNCH_X6P(128, 64, 32, 4, 3);
         else if (Wi == 16) DSF_LAUNCH_X6P(128, 64, 16, 4, 3);
@@ -1308,7 +1322,7 @@ int dsf_conv_x6_forward_plan(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int 
                              int pad_w, int* variant, int* k_splits) {
     DSF_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && Ci > 0 && Co > 0 && KH > 0 && KW > 0 && (dil == 1 || dil == 2));
     const bool patch_geo = x6_patch_geometry(Hi, Wi, Ho, Wo, KH, KW, stride, dil, pad_h, pad_w);
-    const X6Plan plan = x6_forward_plan((int64_t)B * Ho * Wo, Ci, Co, KH, KW, dil, 0, patch_geo);
+    const X6Plan plan = x6_forward_plan((int64_t)B * Ho * Wo, Ci, Co, KH, KW, dil, 0, patch_geo ? Wi : 0);
     if (variant)
         *variant = x6_patch_applies(plan, patch_geo, Hi, Wi, Ci) ? 2 : (plan.bdirect && !(plan.bmt == 64 && plan.n_tiles >= 2)) ? 1 : 0;
     if (k_splits) *k_splits = plan.k_splits;

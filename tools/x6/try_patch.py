@@ -71,6 +71,8 @@ if __name__ == "__main__":
                 ok &= run(B, 16, 256, 256, W=16, splits=splits)
                 ok &= run(B, 8, 512, 512, W=8, splits=splits)
         ok &= run(64, 64, 128, 128, W=64)
+        ok &= run(192, 16, 256, 256, W=16)
+        ok &= run(192, 8, 512, 512, W=8)
         ok &= run(64, 4, 128, 128, W=4) if False else True
         sys.exit(0 if ok else 1)
     ok &= run(2, 8, 64, 64)                  # two tiles per image: top and bottom borders
