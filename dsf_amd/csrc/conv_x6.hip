@@ -1061,6 +1061,221 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// igemm_wrw_x6p_kernel: backward-weights of the 3 x 3, stride 1, pad 1 layers with the input staged as ROWS WITH HALO.
+//
+// igemm_wrw_x6_kernel gathers, splits and stores a 16-pixel x 128-(tap, channel) X tile and a 16 x BN dY tile per 24 MFMAs of a
+// wave: ~120 loader VALU per chunk, 5 per MFMA gap -- the kernel is issue-bound at 0.47 MFMA utilisation.  Here a workgroup owns
+// 32 input channels x ALL NINE TAPS x 128 output channels (wave w: output channels 32 w .. 32 w + 31, nine 32 x 32 accumulators)
+// and walks whole output rows of the maps: the three input rows an output row needs live in a ring of four row buffers
+// ([plane][pixel -1 .. W][32 channels] bf16, 64 bytes per pixel and plane), each input row is loaded and split ONCE and read by
+// three output rows x three kw shifts (the fragment of tap (kh, kw) is the transposed read of ring row kh moved by kw pixels = 64 kw
+// bytes; 64-byte pixels make any 4-pixel window of the ds_read_b64_tr_b16 bank-conflict-free without a swizzle), and a dY tile
+// feeds 54 MFMAs per wave instead of 24.  Loader work per MFMA falls ~4x (1.3 VALU per gap).  Rows outside the image (kh = 0
+// above the first row, kh = 2 below the last) read a plane of zeros instead of the ring; the halo pixels are zeroed once.
+// Pixel splits are ranges of whole rows; they meet in dW by float atomics, or in `partial` in deterministic mode, as in
+// igemm_wrw_x6_kernel.
+// ------------------------------------------------------------------------------------------------
+template <int W> struct X6WrwPatch {
+    static constexpr int A_PLANE = (W + 2) * 64, A_SLOT = 3 * A_PLANE;   // bytes: one plane of a row buffer, one row buffer
+    static constexpr int B_PLANE = 16 * 256;                             // dY tile plane: as igemm_wrw_x6_kernel
+    static constexpr int RING = 0, ZERO = 4 * A_SLOT, BS = ZERO + A_PLANE, LDS_BYTES = BS + 2 * 3 * B_PLANE;
+    static constexpr int CPR = W / 16;                                   // 16-pixel chunks per row
+    static constexpr int NXP = (W * 8 + 255) / 256;                      // float4 loads of an input row per thread
+};
+
+template <int W>
+__global__ __launch_bounds__(256, 2) void igemm_wrw_x6p_kernel(const float* __restrict__ X, const float* __restrict__ dY,
+                                                              float* __restrict__ dW, X6P p, int c_tiles, int n_tiles, int n_splits,
+                                                              int rows_per_split, uint32_t x_bytes, uint32_t dy_bytes,
+                                                              float* __restrict__ partial) {
+    using PT = X6WrwPatch<W>;
+    constexpr int CPR = PT::CPR, NXP = PT::NXP, U = CPR > 2 ? CPR : 2;   // chunks per trip of the main loop
+    extern __shared__ __attribute__((aligned(16))) char wrw_lds[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int tile = x6_xcd_contiguous(blockIdx.x, c_tiles * n_tiles * n_splits);
+    const int cb = tile % c_tiles; tile /= c_tiles;
+    const int n_tile = tile % n_tiles; const int split = tile / n_tiles;
+    const int c0 = cb * 32, n0 = n_tile * 128;
+    const int RT = p.B * p.Hi, K = 9 * p.Ci;             // rows of all maps; the stride-1 layer has Ho = Hi, Wo = Wi = W
+    const int r_begin = split * rows_per_split, r_end = min(RT, r_begin + rows_per_split);
+    const __amdgpu_buffer_rsrc_t xbuf = x6_buffer(X, x_bytes), ybuf = x6_buffer(dY, dy_bytes);
+
+    // zero plane and halo pixels (pixel -1 and W of every plane of every ring slot)
+    for (int e = t; e < PT::A_PLANE / 16; e += 256) reinterpret_cast<uint4*>(wrw_lds + PT::ZERO)[e] = make_uint4(0, 0, 0, 0);
+    for (int e = t; e < 4 * 3 * 2 * 4; e += 256) {
+        const int q = e & 3, side = (e >> 2) & 1, pl = (e >> 3) % 3, slot = e / 24;
+        reinterpret_cast<uint4*>(wrw_lds + slot * PT::A_SLOT + pl * PT::A_PLANE + side * (W + 1) * 64)[q] = make_uint4(0, 0, 0, 0);
+    }
+
+    // X loader: thread -> (pixel x_px, channel quad x_q) of an input row, NXP passes of 32 pixels
+    const int x_q = t & 7, x_c = c0 + x_q * 4;
+    const bool x_cok = x_c < p.Ci;
+    // dY loader: thread -> (channel quad b_q, pixels b_p and b_p + 8 of the chunk)
+    const int b_q = t & 31, b_p = t >> 5, b_n = n0 + b_q * 4;
+    const bool b_nok = b_n < p.Co;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    u32x4 rx[NXP], rl[2][2];
+    auto load_x = [&](int pass, int g) {                 // input row g (all maps stacked); outside [0, RT): zeros
+        const int px = (t >> 3) + 32 * pass;
+        const bool ok = x_cok & (px < W) & ((unsigned)g < (unsigned)RT);
+        rx[pass] = x6_load16(xbuf, ok ? (uint32_t)((g * W + px) * p.Ci + x_c) * 4u : X_OOB);
+    };
+    auto stage_x = [&](int pass, int g) {
+        const int px = (t >> 3) + 32 * pass;
+        if (NXP * 32 > W && px >= W) return;
+        uint2 h, m, l;
+        split4(rx[pass], h, m, l);
+        char* base = wrw_lds + (g & 3) * PT::A_SLOT + (px + 1) * 64 + x_q * 8;
+        *reinterpret_cast<uint2*>(base) = h;
+        *reinterpret_cast<uint2*>(base + PT::A_PLANE) = m;
+        *reinterpret_cast<uint2*>(base + 2 * PT::A_PLANE) = l;
+    };
+    auto load_y = [&](auto SET, int j, int q) {          // piece j of chunk q of the split (past the end: zeros)
+        constexpr int S = decltype(SET)::value;
+        const int r = r_begin + q / CPR, x0 = (q % CPR) * 16;
+        const int m = r * W + x0 + b_p + 8 * j;
+        const bool ok = b_nok & (r < r_end);
+        rl[S][j] = x6_load16(ybuf, ok ? (uint32_t)(m * p.Co + b_n) * 4u : X_OOB);
+    };
+    const int st_offb0 = x6_tr_off(b_p, b_q >> 1) + 8 * (b_q & 1), st_offb1 = x6_tr_off(b_p + 8, b_q >> 1) + 8 * (b_q & 1);
+    auto stage_y = [&](auto SET, int buf, int j) {
+        constexpr int S = decltype(SET)::value;
+        uint2 h, m, l;
+        split4(rl[S][j], h, m, l);
+        char* base = wrw_lds + PT::BS + buf * 3 * PT::B_PLANE + (j ? st_offb1 : st_offb0);
+        *reinterpret_cast<uint2*>(base) = h;
+        *reinterpret_cast<uint2*>(base + PT::B_PLANE) = m;
+        *reinterpret_cast<uint2*>(base + 2 * PT::B_PLANE) = l;
+    };
+
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, 1>;
+    // prologue: input rows r_begin - 1 .. r_begin + 1 into the ring, dY chunk 0 staged, chunk 1 in flight
+    if (r_begin < r_end) {
+#pragma unroll
+        for (int d = -1; d <= 1; ++d) {
+#pragma unroll
+            for (int ps = 0; ps < NXP; ++ps) load_x(ps, r_begin + d);
+#pragma unroll
+            for (int ps = 0; ps < NXP; ++ps) stage_x(ps, r_begin + d);
+        }
+        load_y(Set0{}, 0, 0); load_y(Set0{}, 1, 0);
+        load_y(Set1{}, 0, 1); load_y(Set1{}, 1, 1);
+        stage_y(Set0{}, 0, 0); stage_y(Set0{}, 0, 1);
+    }
+    __syncthreads();
+
+    // transposed fragment reads (see igemm_wrw_x6_kernel): lane -> pixel row f_row (+ 4 for the second read), channels f_col ..
+    const int f_row = 8 * (lane >> 5) + ((lane & 15) >> 2);
+    const int f_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    const int la = f_row * 64 + f_col * 2;               // X rows: 64-byte pixels, no swizzle
+    int fb[2];
+    {
+        const int c = wave * 32 + f_col;
+        fb[0] = x6_tr_off(f_row, c >> 3) + 2 * (c & 7);
+        fb[1] = x6_tr_off(f_row + 4, c >> 3) + 2 * (c & 7);
+    }
+    auto tr_read = [&](const char* a0, const char* a1) {
+        struct { s16x4 lo, hi; } v;
+        v.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+        v.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+    // chunk q (dY register set / LDS stage SET = q & 1; CI = its place in the row): nine taps x 6 MFMAs.  Handed out between them:
+    // the fragment reads of the next tap, the dY loads of chunk q + 2 and the LDS stores of chunk q + 1, and this chunk's share
+    // of input row r + 2 (loads in the first chunks of row r, stores in the last ones; W = 16: load first, store last).
+    auto body = [&](auto SET, auto OTHER, auto CI_, int q) {
+        constexpr int buf = decltype(SET)::value, CI = decltype(CI_)::value;
+        const int r = r_begin + q / CPR, x0 = (q % CPR) * 16;
+        const int oy = r % p.Hi;
+        // fragment base of plane pl of ring row kh: the ring slot of input row r + kh - 1, or the zero plane outside the map
+        int abase[3][3];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const bool inside = kh == 1 || (kh == 0 ? oy > 0 : oy < p.Hi - 1);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                abase[kh][pl] = (inside ? ((r + kh - 1) & 3) * PT::A_SLOT + pl * PT::A_PLANE : PT::ZERO) + x0 * 64 + la;
+        }
+        const char* bbase = wrw_lds + PT::BS + buf * 3 * PT::B_PLANE;
+        bf16x8 b[3], a[2][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) b[pl] = tr_read(bbase + pl * PT::B_PLANE + fb[0], bbase + pl * PT::B_PLANE + fb[1]);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) a[0][pl] = tr_read(wrw_lds + abase[0][pl], wrw_lds + abase[0][pl] + 256);
+        constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int S = tap & 1;
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[S][PA[s]], b[PB[s]], acc[tap], 0, 0, 0);
+                // fragments of the next tap: plane 0 first (the first MFMAs of a tap want it)
+                if (tap < 8 && s < 3) {
+                    const int nt = tap + 1, kh = nt / 3, kw = nt % 3;
+                    a[S ^ 1][s] = tr_read(wrw_lds + abase[kh][s] + kw * 64, wrw_lds + abase[kh][s] + kw * 64 + 256);
+                }
+                if (s == 4) {
+                    if (tap == 0) load_y(SET, 0, q + 2);
+                    if (tap == 1) load_y(SET, 1, q + 2);
+                    if (tap == 3) stage_y(OTHER, buf ^ 1, 0);
+                    if (tap == 5) stage_y(OTHER, buf ^ 1, 1);
+                    if (CPR == 4) {
+                        if (tap == 2 && CI < 2) load_x(CI, r + 2);
+                        if (tap == 7 && CI >= 2) stage_x(CI - 2, r + 2);
+                    } else if (CPR == 2) {
+                        if (tap == 2 && CI == 0) load_x(0, r + 2);
+                        if (tap == 7 && CI == 1) stage_x(0, r + 2);
+                    } else {
+                        if (tap == 0) load_x(0, r + 2);
+                        if (tap == 8) stage_x(0, r + 2);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+    };
+    const int n_chunks = (r_end - r_begin) * CPR;
+    for (int q = 0; q < n_chunks; q += U) {              // (W = 16: rows come in pairs; one past the end has an all-zero dY tile)
+        if (CPR == 4) {
+            body(Set0{}, Set1{}, std::integral_constant<int, 0>{}, q);
+            body(Set1{}, Set0{}, std::integral_constant<int, 1>{}, q + 1);
+            body(Set0{}, Set1{}, std::integral_constant<int, 2>{}, q + 2);
+            body(Set1{}, Set0{}, std::integral_constant<int, 3>{}, q + 3);
+        } else if (CPR == 2) {
+            body(Set0{}, Set1{}, std::integral_constant<int, 0>{}, q);
+            body(Set1{}, Set0{}, std::integral_constant<int, 1>{}, q + 1);
+        } else {
+            body(Set0{}, Set1{}, std::integral_constant<int, 0>{}, q);
+            body(Set1{}, Set0{}, std::integral_constant<int, 0>{}, q + 1);
+        }
+    }
+
+    const int n = n0 + wave * 32 + (lane & 31);
+    if (n < p.Co) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = c0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (ci >= p.Ci) continue;
+                const int k = tap * p.Ci + ci;
+                if (partial) partial[((int64_t)split * K + k) * p.Co + n] = acc[tap][r];
+                else atomicAdd(dW + (int64_t)k * p.Co + n, acc[tap][r]);
+            }
+    }
+}
+
 // dW[e] = sum over the pixel splits, ascending (deterministic mode)
 // (n is a multiple of 4: K * Co with Co % 4 == 0; four elements per lane, the splits still added one by one in ascending order)
 // accumulate != 0: the ordered sum starts from what dW holds (the launcher's `accumulate` contract; still one fixed order)
@@ -1382,10 +1597,42 @@ int dsf_conv_x6_forward_affine(const float* X, const void* image, const float* b
                            X6Ep{scale, shift, residual, relu, 0}, applied, stream);
 }
 
+// igemm_wrw_x6p_kernel's tiling: 32-channel blocks x 128-wide n tiles x row splits (whole output rows, at least four each, pairs on
+// 16-wide maps) towards two workgroups per CU
+static int x6_wrw_patch_plan(int B, int H, int W, int Ci, int Co, int& c_tiles, int& n_tiles, int& rows_per_split) {
+    c_tiles = (Ci + 31) / 32; n_tiles = (Co + 127) / 128;
+    const int RT = B * H;
+    int splits = 512 / (c_tiles * n_tiles);
+    if (splits < 1) splits = 1;
+    rows_per_split = (RT + splits - 1) / splits;
+    if (rows_per_split < 4) rows_per_split = 4;
+    if (W == 16) rows_per_split += rows_per_split & 1;
+    return (RT + rows_per_split - 1) / rows_per_split;
+}
+// the layers it serves (DSF_X6_WRW_PATCH=0 switches it off, 2 drops the size rule; read per call): 3 x 3, stride 1, pad 1 on 64 / 32 / 16-wide maps with at
+// least 1024 pixels per split -- every split adds its 288 x 128 tile into dW with float atomics, and on short splits that traffic
+// (B = 32, 32x32x128: 128 splits of 256 pixels, 19 M atomics) costs more than the loader saves (84 us against 66)
+static bool x6_wrw_patch_applies(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int pad_h,
+                                 int pad_w) {
+    const char* e = getenv("DSF_X6_WRW_PATCH");
+    const int level = e ? atoi(e) : 1;                                   // 0: off;  2: wherever the geometry fits (tests)
+    if (level <= 0) return false;
+    if (!(KH == 3 && KW == 3 && stride == 1 && pad_h == 1 && pad_w == 1 && Ho == Hi && Wo == Wi && Co > 64 &&
+          (Wi == 64 || Wi == 32 || Wi == 16))) return false;
+    int c_tiles, n_tiles, rows;
+    x6_wrw_patch_plan(B, Hi, Wi, Ci, Co, c_tiles, n_tiles, rows);
+    return level >= 2 || rows * Wi >= 1024;
+}
+
 int64_t dsf_conv_x6_wrw_workspace_bytes(int B, int Ho, int Wo, int Ci, int Co, int KH, int KW) {
     if (!dsf_deterministic() || B <= 0) return 0;
     int k_tiles, n_tiles; int64_t per;
-    const int splits = x6_wrw_plan(B, Ho, Wo, Ci, Co, KH, KW, k_tiles, n_tiles, per);
+    int splits = x6_wrw_plan(B, Ho, Wo, Ci, Co, KH, KW, k_tiles, n_tiles, per);
+    if (KH == 3 && KW == 3 && Co > 64 && (Wo == 64 || Wo == 32 || Wo == 16)) {     // (stride and padding unknown here: the larger of the two)
+        int c_tiles, rows;
+        const int ps = x6_wrw_patch_plan(B, Ho, Wo, Ci, Co, c_tiles, n_tiles, rows);
+        if (ps > splits) splits = ps;
+    }
     return (int64_t)splits * KH * KW * Ci * Co * 4;
 }
 
@@ -1404,10 +1651,32 @@ int dsf_conv_x6_wrw_ws(const float* X, const float* dY, float* dW, int B, int Hi
     const int64_t x_bytes = (int64_t)B * Hi * Wi * Ci * 4, dy_bytes = M * Co * 4;
     DSF_CHECK_ARG(M < (1ll << 31) && x_bytes < 0xFFFFFFF0ll && dy_bytes < 0xFFFFFFF0ll);
     const int bn = x6_bn(Co);
+    float* partial = det ? workspace : nullptr;
+    if (x6_wrw_patch_applies(B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad_h, pad_w)) {
+        int c_tiles, pn_tiles, rows;
+        const int psplits = x6_wrw_patch_plan(B, Hi, Wi, Ci, Co, c_tiles, pn_tiles, rows);
+#define DSF_LAUNCH_WRWP(Wv)                                                                                                       \
+    do {                                                                                                                          \
+        using PT = X6WrwPatch<Wv>;                                                                                                \
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wrw_x6p_kernel<Wv>),              \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, PT::LDS_BYTES);            \
+        if (attr != hipSuccess) return DSF_ERR_LAUNCH;                                                                            \
+        hipLaunchKernelGGL(igemm_wrw_x6p_kernel<Wv>, dim3(c_tiles * pn_tiles * psplits), dim3(256), PT::LDS_BYTES,               \
+                           (hipStream_t)stream, X, dY, dW, p, c_tiles, pn_tiles, psplits, rows, (uint32_t)x_bytes,               \
+                           (uint32_t)dy_bytes, partial);                                                                          \
+    } while (0)
+        if (Wi == 64) DSF_LAUNCH_WRWP(64); else if (Wi == 32) DSF_LAUNCH_WRWP(32); else DSF_LAUNCH_WRWP(16);
+#undef DSF_LAUNCH_WRWP
+        if (det) {
+            const int64_t n = (int64_t)K * Co;
+            hipLaunchKernelGGL(x6_wrw_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial,
+                               dW, n, psplits, accumulate);
+        }
+        return dsf_launch_status();
+    }
     int k_tiles, n_tiles; int64_t per;
     const int splits = x6_wrw_plan(B, Ho, Wo, Ci, Co, KH, KW, k_tiles, n_tiles, per);
     const uint64_t mwo = ((1ull << 40) + Wo - 1) / Wo, mho = ((1ull << 40) + Ho - 1) / Ho;
-    float* partial = det ? workspace : nullptr;
     if (bn == 128)
         hipLaunchKernelGGL(igemm_wrw_x6_kernel<128>, dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream, X, dY,
                            dW, p, k_tiles, n_tiles, splits, (int)per, mwo, mho, (uint32_t)x_bytes, (uint32_t)dy_bytes, partial);

@@ -247,6 +247,48 @@ def test_patch_staged_3x3_kernel_is_bit_identical_to_the_per_tap_gather(Ci, Co, 
         L.set_deterministic(was)
 
 
+@pytest.mark.parametrize("Ci,Co,H,W,B", [
+    (36, 132, 8, 64, 2),          # ragged 32-channel block (4 of 32), two n tiles (the second 4 wide), splits of four rows
+    (20, 200, 5, 64, 1),          # one map of five rows: the last split is a single row
+    (40, 72, 7, 32, 3),           # 32-wide maps (two chunks per row), maps of odd height
+    (36, 132, 16, 16, 5),         # 16-wide maps: rows in pairs, an odd row count in the last split
+    (32, 128, 3, 16, 3),
+    (200, 520, 64, 64, 4),        # takes the row kernel by the launcher's own rule (splits of 1024+ pixels)
+])
+def test_row_staged_3x3_backward_weights_against_float64(Ci, Co, H, W, B, monkeypatch):
+    """igemm_wrw_x6p_kernel (input rows with halo staged once in a ring, all nine taps per workgroup) against float64 and against
+    igemm_wrw_x6_kernel: both within accumulation-order distance of the float64 weight gradient; in deterministic mode (partial
+    tiles per split, added in order) two runs are bitwise equal.  DSF_X6_WRW_PATCH=2 takes the row kernel wherever its
+    geometry fits, so that the small shapes here exercise it; the last case takes it by the launcher's own rule."""
+    import ctypes
+    from dsf_amd import nn_conv, _lib as L
+    monkeypatch.setattr(nn_conv, "MATH", "x6")
+    g = torch.Generator().manual_seed(Ci + Co + H)
+    x = torch.randn(B, Ci, H, W, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(B, Co, H, W, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    wd = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, device="cuda", requires_grad=True)
+    ref, = torch.autograd.grad((F.conv2d(x.double(), wd, None, padding=1) * gy.double()).sum(), [wd])
+    ref = ref.permute(2, 3, 1, 0).contiguous()                      # the kernel layout [KH][KW][Ci][Co]
+    out = {}
+    for level in ("0", "2" if (Ci, Co) != (200, 520) else "1"):
+        monkeypatch.setenv("DSF_X6_WRW_PATCH", level)
+        nn_conv.RECORD = []
+        try:
+            out[level] = nn_conv._wrw(x, gy, 3, 3, 1, (1, 1))
+            name = nn_conv.kernel_name(nn_conv.RECORD[0])
+        finally:
+            nn_conv.RECORD = None
+        assert name.startswith("igemm_wrw_x6p_kernel" if level != "0" else "igemm_wrw_x6_kernel"), name
+        assert _rel(out[level].double(), ref) < 3e-6, (level, _rel(out[level].double(), ref))
+    was = L.set_deterministic(True)
+    try:
+        a = nn_conv._wrw(x, gy, 3, 3, 1, (1, 1))
+        b = nn_conv._wrw(x, gy, 3, 3, 1, (1, 1))
+        assert torch.equal(a, b) and _rel(a.double(), ref) < 3e-6
+    finally:
+        L.set_deterministic(was)
+
+
 def test_x6_weight_images_follow_the_weights(monkeypatch):
     """The split image of a weight is kept from one use to the next only for MANAGED parameters (FusedAdamW's, EvalStep's):
     in-place torch updates (version counter) and FusedAdamW's raw-pointer updates (nn_conv.weights_changed) both invalidate
