@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(const float* __restric
 // Tiles: BN 128: 128 x 128 (2 x 2 waves of 64 x 64) or 64 x 128 (2 x 2 waves of 32 x 64: the 8x8 .. 32x32 maps);
 //        BN 64:  256 x 64  (4 x 1 waves of 64 x 64): the 64-channel layers get the 64 x 64 wave tile too.
 // ------------------------------------------------------------------------------------------------
-struct X6Ep { const float* scale; const float* shift; const float* residual; int relu; int stats_acc; };   // output epilogue (all null: none); stats_acc: see `stats`
+struct X6Ep { const float* scale; const float* shift; const float* residual; int relu; int stats_acc; int live_cls = -1; };   // output epilogue (all null: none); stats_acc: see `stats`; live_cls: see igemm_x6b_kernel
 
 template <int BN, bool DIL2, int BMT>
 __global__ __launch_bounds__(256, 2) void igemm_x6b_kernel(const float* __restrict__ X, const uint4* __restrict__ Wimg,
@@ -398,15 +398,18 @@ __global__ __launch_bounds__(256, 2) void igemm_x6b_kernel(const float* __restri
     const int wm = (BN == 128) ? (wave >> 1) : wave, wn = (BN == 128) ? (wave & 1) : 0;
     int tile = x6_xcd_contiguous(blockIdx.x, m_tiles * n_tiles * k_splits);
     const int n_tile = tile % n_tiles; tile /= n_tiles;
-    const int m_tile = DIL2 ? x6_dil2_tile(tile % m_tiles, m_tiles) : tile % m_tiles; const int ks = tile / m_tiles;
+    // DIL2, ep.live_cls >= 0 (a 1 x 1 filter: only that parity class of output pixels has a tap): the launch covers the rows of
+    // that class only, and their epilogue also stores the zeros of the three sibling pixels
+    const int live = DIL2 ? ep.live_cls : -1;
+    const int m_tile = (DIL2 && live < 0) ? x6_dil2_tile(tile % m_tiles, m_tiles) : tile % m_tiles; const int ks = tile / m_tiles;
     const int m0 = m_tile * BMT, n0 = n_tile * BN;
-    const int M = p.B * p.Ho * p.Wo;
     const __amdgpu_buffer_rsrc_t xbuf = x6_buffer(X, x_bytes), wbuf = x6_buffer(Wimg, w_bytes);
 
     const int Hq = p.Ho >> 1, Wq = p.Wo >> 1, Mc = p.B * Hq * Wq;           // DIL2: pixels per parity class
+    const int M = live >= 0 ? Mc : p.B * p.Ho * p.Wo;                       // rows of the launch
     auto decode = [&](int m, int& b, int& oy, int& ox) {
         if (DIL2) {
-            const int cls = m / Mc, r = m % Mc;
+            const int cls = live >= 0 ? live : m / Mc, r = live >= 0 ? m : m % Mc;
             const int qx = r % Wq, q = r / Wq;
             ox = qx * 2 + (cls & 1); oy = (q % Hq) * 2 + (cls >> 1); b = q / Hq;
         } else {
@@ -415,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x6b_kernel(const float* __restri
     };
     int tile_py = -1, tile_px = -1;                      // DIL2: the tile's parity class when it has just one
     if (DIL2) {
-        const int c0 = m0 / Mc, c1 = min(m0 + BMT - 1, M - 1) / Mc;
+        const int c0 = live >= 0 ? live : m0 / Mc, c1 = live >= 0 ? live : min(m0 + BMT - 1, M - 1) / Mc;
         if (c0 == c1) { tile_py = c0 >> 1; tile_px = c0 & 1; }
     }
     const int a_q = t & 3, a_k4 = a_q * 4, a_r = t >> 2;
@@ -586,6 +589,12 @@ __global__ __launch_bounds__(256, 2) void igemm_x6b_kernel(const float* __restri
                     int b, oy, ox;
                     decode(m, b, oy, ox);
                     row = ((int64_t)b * p.Ho + oy) * p.Wo + ox;
+                    if (live >= 0) {                     // the siblings (oy ^ 1, ox), (oy, ox ^ 1), (oy ^ 1, ox ^ 1) have no tap
+                        const int64_t rb = (int64_t)b * p.Ho;
+                        Y[((rb + (oy ^ 1)) * p.Wo + ox) * p.Co + n] = 0.f;
+                        Y[((rb + oy) * p.Wo + (ox ^ 1)) * p.Co + n] = 0.f;
+                        Y[((rb + (oy ^ 1)) * p.Wo + (ox ^ 1)) * p.Co + n] = 0.f;
+                    }
                 }
                 if (k_splits > 1) atomicAdd(Y + row * p.Co + n, acc[i][j][r] + bv);
                 else if (affine) {
@@ -1439,7 +1448,20 @@ static int x6_forward_impl(const float* X, const void* image, const float* bias,
     const int64_t x_bytes = (int64_t)B * Hi * Wi * Ci * 4, w_bytes = dsf_conv_x6_image_bytes(KH, KW, Ci, Co);
     DSF_CHECK_ARG(M < (1ll << 31) && x_bytes < 0xFFFFFFF0ll && w_bytes < 0xFFFFFFF0ll);
     const bool patch_geo = x6_patch_geometry(Hi, Wi, Ho, Wo, KH, KW, stride, dil, pad_h, pad_w);
-    const X6Plan plan = x6_forward_plan(M, Ci, Co, KH, KW, dil, k_splits, patch_geo ? Wi : 0);
+    X6Plan plan = x6_forward_plan(M, Ci, Co, KH, KW, dil, k_splits, patch_geo ? Wi : 0);
+    // a 1 x 1 filter under dilation 2 (backward-data of a 1 x 1 stride-2 shortcut): one output pixel in four has a tap.  Launch the
+    // rows of that parity class only -- their epilogue stores the zeros of the three siblings -- instead of 4x the tiles, three
+    // quarters of which only store zeros (B = 192, 32x32x512 -> 64x64x256: 812 -> ... us).  DSF_X6_LIVE=0: off.
+    int live_cls = -1;
+    if (dil == 2 && KH == 1 && KW == 1 && !bias && !ep.scale && !bn_stats && !y_ready && k_splits < 2) {
+        const char* live_e = getenv("DSF_X6_LIVE");                       // read per call: the test compares both launches
+        const int live_env = live_e ? atoi(live_e) : 1;
+        const X6Plan lp = x6_forward_plan(M / 4, Ci, Co, 1, 1, 1, k_splits);
+        if (live_env && lp.k_splits == 1 && lp.bdirect && !(lp.bmt == 64 && lp.n_tiles >= 2)) {
+            plan = lp;
+            live_cls = ((pad_h & 1) << 1) | (pad_w & 1);
+        }
+    }
     const int bn = plan.bn, n_tiles = plan.n_tiles, bdirect = plan.bdirect, bmt = plan.bmt, m_tiles = plan.m_tiles;
     k_splits = plan.k_splits;
     if (y_ready && k_splits < 2) return DSF_ERR_UNSUPPORTED;             // only the split launches ADD into Y
@@ -1454,6 +1476,7 @@ static int x6_forward_impl(const float* X, const void* image, const float* bias,
     // the affine output epilogue has the same conditions (a split reduction meets in Y by atomics; the staged kernel has none)
     const bool ep_on = ep.scale && direct_pre && k_splits == 1;
     if (!ep_on) ep = X6Ep{nullptr, nullptr, nullptr, 0, ep.stats_acc};
+    ep.live_cls = live_cls;
     if (ep_applied) *ep_applied = ep_on ? 1 : 0;
 #define DSF_LAUNCH_X6(KERNEL, BNv, DILv, BMv) hipLaunchKernelGGL((KERNEL<BNv, DILv, BMv>), grid, dim3(256), 0, (hipStream_t)stream, \
                                                        X, (const uint4*)image, bias, Y, p, m_tiles, n_tiles, k_splits,              \

@@ -289,6 +289,38 @@ def test_row_staged_3x3_backward_weights_against_float64(Ci, Co, H, W, B, monkey
         L.set_deterministic(was)
 
 
+@pytest.mark.parametrize("Ci,Co,H,W,B", [
+    (64, 128, 16, 16, 3),         # R18 / R50 shortcut: 1 x 1, stride 2
+    (256, 512, 32, 32, 8),        # enough rows for 128-row tiles
+    (36, 200, 10, 6, 2),          # ragged channels, non-square, a partial last tile
+])
+def test_backward_data_of_1x1_stride_2_launches_the_live_parity_class_only(Ci, Co, H, W, B, monkeypatch):
+    """The input gradient of a 1 x 1 stride-2 convolution is a dilation-2 gather in which one pixel in four has a tap.  The
+    launch over that parity class alone (its epilogue stores the three siblings' zeros) against the launch over all four classes
+    (DSF_X6_LIVE=0): bitwise equal -- every pixel written exactly once, zeros where there is no tap -- and equal to float64."""
+    from dsf_amd import nn_conv, _lib as L
+    monkeypatch.setattr(nn_conv, "MATH", "x6")
+    g = torch.Generator().manual_seed(Ci + Co)
+    x = torch.randn(B, Ci, H, W, generator=g).cuda().requires_grad_(True)
+    w = (torch.randn(Co, Ci, 1, 1, generator=g) / Ci ** 0.5).cuda().requires_grad_(True)
+    gy = torch.randn(B, Co, H // 2, W // 2, generator=g).cuda()
+    was = L.set_deterministic(True)                                      # unsplit launches on these small shapes
+    try:
+        out = {}
+        for live in ("0", "1"):
+            monkeypatch.setenv("DSF_X6_LIVE", live)
+            y = nn_conv.Conv2dFunction.apply(x, w, None, 2, (0, 0))
+            gx, = torch.autograd.grad((y * gy).sum(), [x])
+            out[live] = gx
+    finally:
+        L.set_deterministic(was)
+    assert torch.equal(out["0"], out["1"])
+    assert float(out["1"][:, :, 1::2, :].abs().max()) == 0.0 and float(out["1"][:, :, :, 1::2].abs().max()) == 0.0
+    xd, wd = x.detach().double().cpu().requires_grad_(True), w.detach().double().cpu()
+    gxd, = torch.autograd.grad((F.conv2d(xd, wd, None, stride=2) * gy.double().cpu()).sum(), [xd])
+    assert _rel(out["1"].double().cpu(), gxd) < 3e-6
+
+
 def test_x6_weight_images_follow_the_weights(monkeypatch):
     """The split image of a weight is kept from one use to the next only for MANAGED parameters (FusedAdamW's, EvalStep's):
     in-place torch updates (version counter) and FusedAdamW's raw-pointer updates (nn_conv.weights_changed) both invalidate
