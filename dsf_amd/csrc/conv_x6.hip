@@ -1093,19 +1093,23 @@ template <int W> struct X6WrwPatch {
     static constexpr int NXP = (W * 8 + 255) / 256;                      // float4 loads of an input row per thread
 };
 
-template <int W>
+template <int W, int BN = 128>
 __global__ __launch_bounds__(256, 2) void igemm_wrw_x6p_kernel(const float* __restrict__ X, const float* __restrict__ dY,
                                                               float* __restrict__ dW, X6P p, int c_tiles, int n_tiles, int n_splits,
                                                               int rows_per_split, uint32_t x_bytes, uint32_t dy_bytes,
                                                               float* __restrict__ partial) {
     using PT = X6WrwPatch<W>;
     constexpr int CPR = PT::CPR, NXP = PT::NXP, U = CPR > 2 ? CPR : 2;   // chunks per trip of the main loop
+    // BN 128: wave w = output channels 32 w .., all nine taps.  BN 64 (layers with <= 64 output channels): two channel blocks x two
+    // tap groups (taps 0-4 and 5-8; the second group's fifth accumulator multiplies the zero plane: idle either way)
+    constexpr int WN = BN / 32, TAPS = (BN == 128) ? 9 : 5, NPY = (BN == 128) ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) char wrw_lds[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     int tile = x6_xcd_contiguous(blockIdx.x, c_tiles * n_tiles * n_splits);
     const int cb = tile % c_tiles; tile /= c_tiles;
     const int n_tile = tile % n_tiles; const int split = tile / n_tiles;
-    const int c0 = cb * 32, n0 = n_tile * 128;
+    const int c0 = cb * 32, n0 = n_tile * BN;
+    const int wn = wave % WN, t0 = __builtin_amdgcn_readfirstlane(wave / WN) * TAPS;          // first tap of this wave
     const int RT = p.B * p.Hi, K = 9 * p.Ci;             // rows of all maps; the stride-1 layer has Ho = Hi, Wo = Wi = W
     const int r_begin = split * rows_per_split, r_end = min(RT, r_begin + rows_per_split);
     const __amdgpu_buffer_rsrc_t xbuf = x6_buffer(X, x_bytes), ybuf = x6_buffer(dY, dy_bytes);
@@ -1120,17 +1124,17 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6p_kernel(const float* __re
     // X loader: thread -> (pixel x_px, channel quad x_q) of an input row, NXP passes of 32 pixels
     const int x_q = t & 7, x_c = c0 + x_q * 4;
     const bool x_cok = x_c < p.Ci;
-    // dY loader: thread -> (channel quad b_q, pixels b_p and b_p + 8 of the chunk)
-    const int b_q = t & 31, b_p = t >> 5, b_n = n0 + b_q * 4;
+    // dY loader: thread -> (channel quad b_q, pixels b_p and b_p + 8 of the chunk);  BN 64: one float4 per thread (pixel t >> 4)
+    const int b_q = (BN == 128) ? (t & 31) : (t & 15), b_p = (BN == 128) ? (t >> 5) : (t >> 4), b_n = n0 + b_q * 4;
     const bool b_nok = b_n < p.Co;
 
-    f32x16 acc[9];
+    f32x16 acc[TAPS];
 #pragma unroll
-    for (int i = 0; i < 9; ++i)
+    for (int i = 0; i < TAPS; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    u32x4 rx[NXP], rl[2][2];
+    u32x4 rx[NXP], rl[2][NPY];
     auto load_x = [&](int pass, int g) {                 // input row g (all maps stacked); outside [0, RT): zeros
         const int px = (t >> 3) + 32 * pass;
         const bool ok = x_cok & (px < W) & ((unsigned)g < (unsigned)RT);
@@ -1175,9 +1179,12 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6p_kernel(const float* __re
 #pragma unroll
             for (int ps = 0; ps < NXP; ++ps) stage_x(ps, r_begin + d);
         }
-        load_y(Set0{}, 0, 0); load_y(Set0{}, 1, 0);
-        load_y(Set1{}, 0, 1); load_y(Set1{}, 1, 1);
-        stage_y(Set0{}, 0, 0); stage_y(Set0{}, 0, 1);
+#pragma unroll
+        for (int j = 0; j < NPY; ++j) load_y(Set0{}, j, 0);
+#pragma unroll
+        for (int j = 0; j < NPY; ++j) load_y(Set1{}, j, 1);
+#pragma unroll
+        for (int j = 0; j < NPY; ++j) stage_y(Set0{}, 0, j);
     }
     __syncthreads();
 
@@ -1187,7 +1194,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6p_kernel(const float* __re
     const int la = f_row * 64 + f_col * 2;               // X rows: 64-byte pixels, no swizzle
     int fb[2];
     {
-        const int c = wave * 32 + f_col;
+        const int c = wn * 32 + f_col;
         fb[0] = x6_tr_off(f_row, c >> 3) + 2 * (c & 7);
         fb[1] = x6_tr_off(f_row + 4, c >> 3) + 2 * (c & 7);
     }
@@ -1205,48 +1212,54 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6p_kernel(const float* __re
         constexpr int buf = decltype(SET)::value, CI = decltype(CI_)::value;
         const int r = r_begin + q / CPR, x0 = (q % CPR) * 16;
         const int oy = r % p.Hi;
-        // fragment base of plane pl of ring row kh: the ring slot of input row r + kh - 1, or the zero plane outside the map
-        int abase[3][3];
+        // fragment base of plane pl of tap t0 + tt: the ring slot of input row r + kh - 1 moved by kw pixels, or the zero plane
+        // outside the map (and for the tap past the ninth)
+        // (BN 128: nine taps = three ring rows x three constant kw shifts -- nine base registers, not 27)
+        constexpr int NBASE = (BN == 128) ? 3 : TAPS;
+        int abase[NBASE][3];
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const bool inside = kh == 1 || (kh == 0 ? oy > 0 : oy < p.Hi - 1);
+        for (int tt = 0; tt < NBASE; ++tt) {
+            const int tap = (BN == 128) ? 3 * tt : t0 + tt, kh = tap / 3, kw = tap - 3 * kh;
+            const bool inside = tap < 9 && (kh == 1 || (kh == 0 ? oy > 0 : oy < p.Hi - 1));
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
-                abase[kh][pl] = (inside ? ((r + kh - 1) & 3) * PT::A_SLOT + pl * PT::A_PLANE : PT::ZERO) + x0 * 64 + la;
+                abase[tt][pl] = (inside ? ((r + kh - 1) & 3) * PT::A_SLOT + pl * PT::A_PLANE + kw * 64 : PT::ZERO) + x0 * 64 + la;
         }
+        auto frag = [&](int tt, int pl) {                // byte offset of the fragment of this wave's tap tt
+            return (BN == 128) ? abase[tt / 3][pl] + (tt % 3) * 64 : abase[tt][pl];
+        };
         const char* bbase = wrw_lds + PT::BS + buf * 3 * PT::B_PLANE;
         bf16x8 b[3], a[2][3];
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) b[pl] = tr_read(bbase + pl * PT::B_PLANE + fb[0], bbase + pl * PT::B_PLANE + fb[1]);
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) a[0][pl] = tr_read(wrw_lds + abase[0][pl], wrw_lds + abase[0][pl] + 256);
+        for (int pl = 0; pl < 3; ++pl) a[0][pl] = tr_read(wrw_lds + frag(0, pl), wrw_lds + frag(0, pl) + 256);
         constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
+        for (int tap = 0; tap < TAPS; ++tap) {
             const int S = tap & 1;
 #pragma unroll
             for (int s = 0; s < 6; ++s) {
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[S][PA[s]], b[PB[s]], acc[tap], 0, 0, 0);
                 // fragments of the next tap: plane 0 first (the first MFMAs of a tap want it)
-                if (tap < 8 && s < 3) {
-                    const int nt = tap + 1, kh = nt / 3, kw = nt % 3;
-                    a[S ^ 1][s] = tr_read(wrw_lds + abase[kh][s] + kw * 64, wrw_lds + abase[kh][s] + kw * 64 + 256);
-                }
+                if (tap < TAPS - 1 && s < 3) a[S ^ 1][s] = tr_read(wrw_lds + frag(tap + 1, s), wrw_lds + frag(tap + 1, s) + 256);
                 if (s == 4) {
+                    // (nine taps: pieces behind taps 0, 1, 2, 3, 5, 7 / 8;  five: 0, 1, 2, 3, 4)
                     if (tap == 0) load_y(SET, 0, q + 2);
-                    if (tap == 1) load_y(SET, 1, q + 2);
+                    if (tap == 1 && NPY == 2) load_y(SET, 1, q + 2);
                     if (tap == 3) stage_y(OTHER, buf ^ 1, 0);
-                    if (tap == 5) stage_y(OTHER, buf ^ 1, 1);
+                    if (tap == (TAPS == 9 ? 5 : 4) && NPY == 2) stage_y(OTHER, buf ^ 1, 1);
+                    constexpr int TX = TAPS == 9 ? 7 : 4;                // the tap behind which an X row piece is stored
                     if (CPR == 4) {
                         if (tap == 2 && CI < 2) load_x(CI, r + 2);
-                        if (tap == 7 && CI >= 2) stage_x(CI - 2, r + 2);
+                        if (tap == TX && CI >= 2) stage_x(CI - 2, r + 2);
                     } else if (CPR == 2) {
                         if (tap == 2 && CI == 0) load_x(0, r + 2);
-                        if (tap == 7 && CI == 1) stage_x(0, r + 2);
+                        if (tap == TX && CI == 1) stage_x(0, r + 2);
                     } else {
                         if (tap == 0) load_x(0, r + 2);
-                        if (tap == 8) stage_x(0, r + 2);
+                        if (tap == TAPS - 1) stage_x(0, r + 2);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -1270,18 +1283,20 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6p_kernel(const float* __re
         }
     }
 
-    const int n = n0 + wave * 32 + (lane & 31);
+    const int n = n0 + wn * 32 + (lane & 31);
     if (n < p.Co) {
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
+        for (int tt = 0; tt < TAPS; ++tt) {
+            if (t0 + tt >= 9) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ci = c0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (ci >= p.Ci) continue;
-                const int k = tap * p.Ci + ci;
-                if (partial) partial[((int64_t)split * K + k) * p.Co + n] = acc[tap][r];
-                else atomicAdd(dW + (int64_t)k * p.Co + n, acc[tap][r]);
+                const int k = (t0 + tt) * p.Ci + ci;
+                if (partial) partial[((int64_t)split * K + k) * p.Co + n] = acc[tt][r];
+                else atomicAdd(dW + (int64_t)k * p.Co + n, acc[tt][r]);
             }
+        }
     }
 }
 
@@ -1629,6 +1644,10 @@ static int x6_wrw_patch_plan(int B, int H, int W, int Ci, int Co, int& c_tiles, 
     if (splits < 1) splits = 1;
     rows_per_split = (RT + splits - 1) / splits;
     if (rows_per_split < 4) rows_per_split = 4;
+    // 64-wide maps: longer splits of 1024 pixels where that still leaves a workgroup per CU (the 64 -> 64 layers at B = 32:
+    // 256 x 16 rows, 80.7 -> 73.8 us; on the narrower maps the old kernel wins such cases)
+    const int want = 1024 / W;
+    if (W == 64 && rows_per_split < want && c_tiles * n_tiles * ((RT + want - 1) / want) >= 256) rows_per_split = want;
     if (W == 16) rows_per_split += rows_per_split & 1;
     return (RT + rows_per_split - 1) / rows_per_split;
 }
@@ -1640,7 +1659,7 @@ static bool x6_wrw_patch_applies(int B, int Hi, int Wi, int Ci, int Ho, int Wo, 
     const char* e = getenv("DSF_X6_WRW_PATCH");
     const int level = e ? atoi(e) : 1;                                   // 0: off;  2: wherever the geometry fits (tests)
     if (level <= 0) return false;
-    if (!(KH == 3 && KW == 3 && stride == 1 && pad_h == 1 && pad_w == 1 && Ho == Hi && Wo == Wi && Co > 64 &&
+    if (!(KH == 3 && KW == 3 && stride == 1 && pad_h == 1 && pad_w == 1 && Ho == Hi && Wo == Wi &&
           (Wi == 64 || Wi == 32 || Wi == 16))) return false;
     int c_tiles, n_tiles, rows;
     x6_wrw_patch_plan(B, Hi, Wi, Ci, Co, c_tiles, n_tiles, rows);
@@ -1651,7 +1670,7 @@ int64_t dsf_conv_x6_wrw_workspace_bytes(int B, int Ho, int Wo, int Ci, int Co, i
     if (!dsf_deterministic() || B <= 0) return 0;
     int k_tiles, n_tiles; int64_t per;
     int splits = x6_wrw_plan(B, Ho, Wo, Ci, Co, KH, KW, k_tiles, n_tiles, per);
-    if (KH == 3 && KW == 3 && Co > 64 && (Wo == 64 || Wo == 32 || Wo == 16)) {     // (stride and padding unknown here: the larger of the two)
+    if (KH == 3 && KW == 3 && (Wo == 64 || Wo == 32 || Wo == 16)) {     // (stride and padding unknown here: the larger of the two)
         int c_tiles, rows;
         const int ps = x6_wrw_patch_plan(B, Ho, Wo, Ci, Co, c_tiles, n_tiles, rows);
         if (ps > splits) splits = ps;
@@ -1678,17 +1697,18 @@ int dsf_conv_x6_wrw_ws(const float* X, const float* dY, float* dW, int B, int Hi
     if (x6_wrw_patch_applies(B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad_h, pad_w)) {
         int c_tiles, pn_tiles, rows;
         const int psplits = x6_wrw_patch_plan(B, Hi, Wi, Ci, Co, c_tiles, pn_tiles, rows);
-#define DSF_LAUNCH_WRWP(Wv)                                                                                                       \
+#define DSF_LAUNCH_WRWP(Wv, BNv)                                                                                                  \
     do {                                                                                                                          \
         using PT = X6WrwPatch<Wv>;                                                                                                \
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wrw_x6p_kernel<Wv>),              \
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wrw_x6p_kernel<Wv, BNv>),         \
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, PT::LDS_BYTES);            \
         if (attr != hipSuccess) return DSF_ERR_LAUNCH;                                                                            \
-        hipLaunchKernelGGL(igemm_wrw_x6p_kernel<Wv>, dim3(c_tiles * pn_tiles * psplits), dim3(256), PT::LDS_BYTES,               \
+        hipLaunchKernelGGL((igemm_wrw_x6p_kernel<Wv, BNv>), dim3(c_tiles * pn_tiles * psplits), dim3(256), PT::LDS_BYTES,        \
                            (hipStream_t)stream, X, dY, dW, p, c_tiles, pn_tiles, psplits, rows, (uint32_t)x_bytes,               \
                            (uint32_t)dy_bytes, partial);                                                                          \
     } while (0)
-        if (Wi == 64) DSF_LAUNCH_WRWP(64); else if (Wi == 32) DSF_LAUNCH_WRWP(32); else DSF_LAUNCH_WRWP(16);
+        if (bn == 128) { if (Wi == 64) DSF_LAUNCH_WRWP(64, 128); else if (Wi == 32) DSF_LAUNCH_WRWP(32, 128); else DSF_LAUNCH_WRWP(16, 128); }
+        else { if (Wi == 64) DSF_LAUNCH_WRWP(64, 64); else if (Wi == 32) DSF_LAUNCH_WRWP(32, 64); else DSF_LAUNCH_WRWP(16, 64); }
 #undef DSF_LAUNCH_WRWP
         if (det) {
             const int64_t n = (int64_t)K * Co;

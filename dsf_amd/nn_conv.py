@@ -846,12 +846,16 @@ def kernel_name(rec):
         # the row-staged 3 x 3 kernel (conv_x6.hip: x6_wrw_patch_applies / x6_wrw_patch_plan)
         level = int(os.environ.get("DSF_X6_WRW_PATCH", "1"))
         if (level > 0 and rec[8] == 3 and rec[9] == 3 and rec[10] == 1 and rec[12] == 1 and rec[13] == 1
-                and Ho == Hi and Wo == Wi and Co > 64 and Wi in (64, 32, 16)):
-            splits = max(1, 512 // (((Ci + 31) // 32) * ((Co + 127) // 128)))
+                and Ho == Hi and Wo == Wi and Wi in (64, 32, 16)):
+            tiles = ((Ci + 31) // 32) * ((Co + 127) // 128)
+            splits = max(1, 512 // tiles)
             rows = max(4, (B * Hi + splits - 1) // splits)
+            want = 1024 // Wi
+            if Wi == 64 and rows < want and tiles * ((B * Hi + want - 1) // want) >= 256:
+                rows = want
             rows += rows & 1 if Wi == 16 else 0
             if level >= 2 or rows * Wi >= 1024:
-                return "igemm_wrw_x6p_kernel<%d>" % Wi
+                return "igemm_wrw_x6p_kernel<%d, %d>" % (Wi, 128 if Co > 64 else 64)
         return "igemm_wrw_x6_kernel<%d>" % (128 if Co > 64 else 64)
     if vec:
         return "igemm_wrw_fast_kernel<%d, %d>" % (bn, 16 if M >= 32768 else 32)

@@ -253,6 +253,8 @@ def test_patch_staged_3x3_kernel_is_bit_identical_to_the_per_tap_gather(Ci, Co, 
     (40, 72, 7, 32, 3),           # 32-wide maps (two chunks per row), maps of odd height
     (36, 132, 16, 16, 5),         # 16-wide maps: rows in pairs, an odd row count in the last split
     (32, 128, 3, 16, 3),
+    (36, 60, 8, 64, 2),           # <= 64 output channels: two channel blocks x two tap groups
+    (64, 64, 6, 32, 3),
     (200, 520, 64, 64, 4),        # takes the row kernel by the launcher's own rule (splits of 1024+ pixels)
 ])
 def test_row_staged_3x3_backward_weights_against_float64(Ci, Co, H, W, B, monkeypatch):

@@ -66,6 +66,11 @@ if __name__ == "__main__":
     ok &= run(3, 7, 32, 40, 72, ref=True)
     ok &= run(5, 16, 16, 36, 132, ref=True)
     ok &= run(3, 3, 16, 32, 128, ref=True)
+    ok &= run(2, 8, 64, 36, 60, ref=True)
+    ok &= run(3, 6, 32, 64, 64, ref=True)
+    ok &= run(32, 64, 64, 64, 64)
+    ok &= run(32, 64, 64, 256, 64)
+    ok &= run(64, 64, 64, 64, 64)
     ok &= run(32, 64, 64, 488, 256)
     ok &= run(32, 64, 64, 256, 488)
     ok &= run(32, 64, 64, 256, 256)
