@@ -706,7 +706,11 @@ inline int bn_rows_per_wg(int64_t M, int C, int max_wgs = BN_MAX_WGS) {
 }
 inline int bn_apply_grid(int64_t n4, int C) {
     int64_t g = (n4 + 1023) / 1024;                             // >= 4 float4 per thread
-    if (g > 2048) g = 2048;
+    // at most 1024 workgroups (DSF_BN_APPLY_WGS: tuning aid, read per call): 512 .. 1536 measured alike, 2048 costs 0.3-0.5 % of the
+    // B = 32 and B = 192 steps, 4096 and 8192 1.5 % of the latter
+    const char* cap_e = getenv("DSF_BN_APPLY_WGS");
+    const int64_t cap = cap_e ? atoi(cap_e) : 1024;
+    if (g > cap) g = cap;
     if (g < 1) g = 1;
     const int m = bn_col_blocks(C);                             // the grid stride must be a multiple of the float4 column count
     g = ((g + m - 1) / m) * m;
@@ -859,7 +863,11 @@ extern "C" int dsf_bn_backward_acc(const float* x, const float* grad_y, const fl
     DSF_CHECK_ARG(x && grad_y && save_mean && save_invstd && grad_x && acc && M > 0 && relu >= 0 && relu <= 2 && (relu != 1 || y));
     if (!bn_shape_ok(C) || dsf_deterministic()) return DSF_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    const int rows = bn_rows_per_wg(M, C, BN_ACC_WGS);
+    // 1024 reduction workgroups (DSF_BN_BWD_WGS: tuning aid, read per call): on the B = 192 tensors (800 MB) 512 left the pass at
+    // 2.7-3.4 TB/s -- config 4 165.4 -> 163.5 ms per step with 1024, 2048 and 4096 alike; the B = 32 step does not care.  Eight rows
+    // in flight per lane instead of four: no gain (162.5 vs 163.6 ms)
+    const char* wg_e = getenv("DSF_BN_BWD_WGS");
+    const int rows = bn_rows_per_wg(M, C, wg_e ? atoi(wg_e) : 1024);
     const int wgs = (int)((M + rows - 1) / rows);
     BnFinal fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, grad_gamma, grad_beta};
     if (bn_small_ok(M, C)) {                                         // both sums + apply in one launch (`acc` stays untouched)
