@@ -657,24 +657,27 @@ __global__ __launch_bounds__(256, 2) void igemm_x6b_kernel(const float* __restri
 // CU); the B fragments alternate between two register sets per tap; the A loads of chunk c + 1 are issued during taps 0-2 of
 // chunk c and split / stored during taps 5-8; the fragments of tap t + 1 are read during tap t.
 // ------------------------------------------------------------------------------------------------
-template <int BMT, int W> struct X6Patch {
-    // pixel pitch of a patch row: W + 2; 8-wide maps 24 (a 32-row fragment block spans four image rows: the 16-lane halves of
+template <int BMT, int W, int NT = 9> struct X6Patch {
+    // NT = 9: 3 x 3 taps, halo 2;  NT = 4: the 2 x 2 taps one output-parity class of a 4 x 4 stride-2 transposed convolution has, halo 1.
+    // pixel pitch of a patch row: W + halo; 8-wide maps 24 (a 32-row fragment block spans four image rows: the 16-lane halves of
     // the ds_read_b128 then land on disjoint bank halves)
-    static constexpr int R = BMT / W, PW = (W == 8) ? 24 : W + 2, NPIX = (R + 2) * (W + 2);
-    static constexpr int KGS = (((R + 2) * PW + 11) / 16) * 16 + 4;       // k-group pitch = 4 mod 16 granules: see LdsPlane
+    static constexpr int HALO = (NT == 9) ? 2 : 1, TW = (NT == 9) ? 3 : 2;
+    static constexpr int R = BMT / W, PW = (W == 8) ? 24 : W + HALO, NPIX = (R + HALO) * (W + HALO);
+    static constexpr int KGS = (((R + HALO) * PW + 11) / 16) * 16 + 4;    // k-group pitch = 4 mod 16 granules: see LdsPlane
     static constexpr int PLANE = 2 * KGS, STAGE = 3 * PLANE;             // granules
     static constexpr int NPASS = (NPIX + 63) / 64;                       // float4 loads of the patch per thread
     static constexpr int LDS_BYTES = 2 * STAGE * 16;
 };
 
-template <int BN, int BMT, int W, int NW = 2, int BD = 2>
+template <int BN, int BMT, int W, int NW = 2, int BD = 2, int NT = 9>
 __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restrict__ X, const uint4* __restrict__ Wimg,
                                                           const float* __restrict__ bias, float* __restrict__ Y, X6P p, int m_tiles,
                                                           int n_tiles, int k_splits, uint32_t x_bytes, uint32_t w_bytes,
                                                           float* __restrict__ stats, X6Ep ep) {
     static_assert((BN == 128 && (BMT == 128 || BMT == 64)) || (BN == 64 && BMT == 256), "tile shapes");
     static_assert(BMT % W == 0 && (W % 32 == 0 || 32 % W == 0), "fragment blocks are whole image rows or lie in one");
-    using PT = X6Patch<BMT, W>;
+    static_assert(NT == 9 || (NT == 4 && BD == 2), "taps");
+    using PT = X6Patch<BMT, W, NT>;
     // waves: WMW x WN, each WM rows x WNC columns: 2 x 2 of (BMT / 2) x 64 (BN 128), 4 x 1 of 64 x 64 (BN 64), or -- NW = 4, the
     // 64-row tiles -- 1 x 4 of 64 x 32: every wave then reads its own quarter of the weight block (half the weight traffic of the
     // 2 x 2 arrangement, whose two wave rows pull the same fragments) and all of the A tile
@@ -693,16 +696,24 @@ __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restri
     const int M = p.B * p.Ho * p.Wo;                     // a multiple of BMT (launcher)
     const __amdgpu_buffer_rsrc_t xbuf = x6_buffer(X, x_bytes), wbuf = x6_buffer(Wimg, w_bytes);
 
-    // patch pixel (py, px), LDS granule py PW + px  <->  input pixel (y0 - 1 + py, px - 1) of image `img`
-    const int img = m0 / (p.Hi * W), y0 = (m0 % (p.Hi * W)) / W;
+    // patch pixel (py, px), LDS granule py PW + px  <->  input pixel (y0 + oy0 + py, ox0 + px) of image `img`.
+    // NT = 9: rows are output pixels in order, (oy0, ox0) = (-1, -1).  NT = 4 (dilation-2 gather of a 4 x 4 stride-2 transposed
+    // convolution): rows are ordered by output parity class (cpy, cpx), then as the W-wide class image = the input grid; an output
+    // pixel (2 qy + cpy, 2 qx + cpx) has the taps kh = kh0 + 2 ty, kw = kw0 + 2 tx at input (qy + oy0 + ty, qx + ox0 + tx)
+    const int Mc = p.B * p.Hi * W;                       // NT = 4: rows per parity class
+    const int cls = (NT == 4) ? m0 / Mc : 0, r0 = (NT == 4) ? m0 % Mc : m0;
+    const int cpy = cls >> 1, cpx = cls & 1;
+    const int kh0 = (NT == 4) ? ((p.pad_h - cpy) & 1) : 0, kw0 = (NT == 4) ? ((p.pad_w - cpx) & 1) : 0;
+    const int oy0 = (NT == 4) ? (cpy - p.pad_h + kh0) / 2 : -1, ox0 = (NT == 4) ? (cpx - p.pad_w + kw0) / 2 : -1;
+    const int img = r0 / (p.Hi * W), y0 = (r0 % (p.Hi * W)) / W;
     const int a_q = t & 3, a_k4 = a_q * 4, a_r = t >> 2;
     int a_off[NPASS];                                    // element offset of (pixel, channel quad) at chunk 0; -1: zeros
     int a_lds[NPASS];                                    // granule of the pixel in k-group 0; -1: no such pixel
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
         const int pidx = a_r + 64 * i;
-        const int py = pidx / (W + 2), px = pidx % (W + 2);
-        const int y = y0 - 1 + py, x = px - 1;
+        const int py = pidx / (W + PT::HALO), px = pidx % (W + PT::HALO);
+        const int y = y0 + oy0 + py, x = ox0 + px;
         const bool ok = pidx < PT::NPIX && (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)W;
         a_off[i] = ok ? ((img * p.Hi + y) * W + x) * p.Ci + a_k4 : -1;
         a_lds[i] = pidx < PT::NPIX ? py * PT::PW + px : -1;
@@ -737,7 +748,8 @@ __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restri
     auto load_b = [&](int S, int f, int tap, int chunk) {                // fragment f of step (chunk, tap) (past the end: zeros)
         const int pl = f / TN, j = f % TN;
         const uint32_t dead = chunk < chunk_hi ? 0u : X_OOB;
-        const int blk = tap * n_chunks + chunk;
+        const int wtap = (NT == 4) ? (kh0 + 2 * (tap >> 1)) * p.KW + kw0 + 2 * (tap & 1) : tap;      // tap of the weight image
+        const int blk = wtap * n_chunks + chunk;
         rbf[S][pl][j] = x6_load16(wbuf, ((uint32_t)(blk * n_tiles + n_tile) * (uint32_t)(3 * B_GRANULES * 16) +
                                          (uint32_t)(pl * B_GRANULES * 16 + j * 32 * 16) + b_lane) | dead);
     };
@@ -750,7 +762,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restri
     }
     auto read_frag = [&](auto SET, int buf, int tap, int pl, int i) {
         constexpr int S = decltype(SET)::value;
-        af[S][pl][i] = __builtin_bit_cast(bf16x8, x6p_lds[buf * PT::STAGE + pl * PT::PLANE + a_frag[i] + (tap / 3) * PT::PW + tap % 3]);
+        af[S][pl][i] = __builtin_bit_cast(bf16x8, x6p_lds[buf * PT::STAGE + pl * PT::PLANE + a_frag[i] + (tap / PT::TW) * PT::PW + tap % PT::TW]);
     };
 
     using Set0 = std::integral_constant<int, 0>;
@@ -763,6 +775,9 @@ __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restri
 #pragma unroll
         for (int f = 0; f < 3 * TN; ++f) load_b(1, f, 1, chunk_lo);
     }
+    // the patch loader's schedule inside a chunk: three loads per tap from tap 0, two stores per tap from tap ST
+    constexpr int ST = (NT == 9) ? 5 : 2;
+    static_assert(NPASS <= 2 * (NT - ST) && NPASS <= 3 * ST, "patch passes fit the tap schedule");
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) stage_piece(0, i);
     __syncthreads();
@@ -776,13 +791,15 @@ __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restri
         for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                if (PAR) read_frag(Set1{}, PAR, 0, pl, i); else read_frag(Set0{}, PAR, 0, pl, i);
+                if (PAR && (NT & 1)) read_frag(Set1{}, PAR, 0, pl, i); else read_frag(Set0{}, PAR, 0, pl, i);
             }
         constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};
         constexpr int NM = 6 * TM * TN, BSTEP = 2 * TM, ASTEP = 2 * TN;   // NM / (3 TN) B loads, NM / (3 TM) fragment reads
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int S = (PAR + tap) & 1;                 // fragment set;  B set: the same (BD 2), tap mod 3 (BD 3: nine taps)
+        for (int tap = 0; tap < NT; ++tap) {
+            // fragment set: alternates per step (nine taps: a chunk starts on its parity; four: always on set 0);  B set: the same
+            // (BD 2), tap mod 3 (BD 3: nine taps)
+            const int S = ((NT & 1) ? PAR + tap : tap) & 1;
             const int SB = BD == 3 ? tap % 3 : S;
             __builtin_amdgcn_sched_barrier(0);
             int slot = 0;
@@ -797,20 +814,20 @@ __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restri
                         // B fragments of the next step: behind MFMAs 0, 4, .. 20 (NM 12: 0, 2, .. 10)
                         if (slot % BSTEP == 0) {
                             const int f = slot / BSTEP, ahead = tap + BD - 1;
-                            load_b(BD == 3 ? ahead % 3 : S ^ 1, f, ahead % 9, chunk + ahead / 9);
+                            load_b(BD == 3 ? ahead % 3 : S ^ 1, f, ahead % NT, chunk + ahead / NT);
                         }
                         // A fragments of the next tap: behind MFMAs 1, 5, .. (the planes in the order the MFMAs want them)
-                        if (slot % ASTEP == 1 && tap < 8) {
+                        if (slot % ASTEP == 1 && tap < NT - 1) {
                             const int f = slot / ASTEP, pl = f / TM, i = f % TM;
                             if (S) read_frag(Set0{}, PAR, tap + 1, pl, i); else read_frag(Set1{}, PAR, tap + 1, pl, i);
                         }
                         // the patch of chunk + 1: three loads per tap in taps 0-2, two stores per tap in taps 5-8
-                        if (tap < 3 && slot % (NM / 3) == 2) {
+                        if (tap < ST && slot % (NM / 3) == 2) {
                             const int i = tap * 3 + slot / (NM / 3);
                             if (i < NPASS) load_a(i, chunk + 1);
                         }
-                        if (tap >= 5 && slot % (NM / 2) == NM / 4) {
-                            const int i = (tap - 5) * 2 + slot / (NM / 2);
+                        if (tap >= ST && slot % (NM / 2) == NM / 4) {
+                            const int i = (tap - ST) * 2 + slot / (NM / 2);
                             if (i < NPASS) stage_piece(PAR ^ 1, i);
                         }
                         ++slot;
@@ -835,7 +852,11 @@ __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restri
             const float es = affine ? ep.scale[n] : 1.f, et = affine ? ep.shift[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int64_t row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                int64_t row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (NT == 4) {                           // class row -> output pixel (2 qy + cpy, 2 qx + cpx)
+                    const int rc = (int)row - cls * Mc, qx = rc % W, q = rc / W;
+                    row = ((int64_t)(q / p.Hi) * p.Ho + 2 * (q % p.Hi) + cpy) * p.Wo + 2 * qx + cpx;
+                }
                 if (row >= M) continue;
                 if (k_splits > 1) atomicAdd(Y + row * p.Co + n, acc[i][j][r] + bv);
                 else if (affine) {
@@ -1396,12 +1417,16 @@ int dsf_conv_x6_split_weights_multi(const int64_t* jobs, int n_jobs, int64_t tot
 struct X6Plan { int bn, n_tiles, bdirect, bmt, m_tiles, k_splits; };
 // the geometry igemm_x6p_kernel serves: 3 x 3, stride 1, pad 1 on 64 / 32 / 16 / 8-wide maps (DSF_X6_PATCH=0 switches the kernel
 // off, 1 keeps it to the 64-wide maps; read per call: tests/test_gpu_conv.py compares the kernels in one process)
-static bool x6_patch_geometry(int Hi, int Wi, int Ho, int Wo, int KH, int KW, int stride, int dil, int pad_h, int pad_w) {
+// -> taps of the patch kernel: 9 (that geometry), 4 (a 4 x 4 stride-2 transposed convolution as its dilation-2 gather: each output
+// parity class is a 2 x 2 convolution over the input grid; 32 / 16 / 8-wide inputs; DSF_X6_PATCH=3 keeps these on the gather kernel), 0
+static int x6_patch_geometry(int Hi, int Wi, int Ho, int Wo, int KH, int KW, int stride, int dil, int pad_h, int pad_w) {
     const char* e = getenv("DSF_X6_PATCH");
     const int level = e ? atoi(e) : 2;
-    if (level <= 0) return false;
-    if (!(dil == 1 && KH == 3 && KW == 3 && stride == 1 && pad_h == 1 && pad_w == 1 && Ho == Hi && Wo == Wi)) return false;
-    return Wi == 64 || (level >= 2 && (Wi == 32 || Wi == 16 || Wi == 8));
+    if (level <= 0) return 0;
+    if (dil == 2 && KH == 4 && KW == 4 && stride == 1 && Ho == 2 * Hi && Wo == 2 * Wi && pad_h >= 0 && pad_h <= 3 && pad_w >= 0 &&
+        pad_w <= 3 && level == 2 && (Wi == 32 || Wi == 16 || Wi == 8)) return 4;
+    if (!(dil == 1 && KH == 3 && KW == 3 && stride == 1 && pad_h == 1 && pad_w == 1 && Ho == Hi && Wo == Wi)) return 0;
+    return (Wi == 64 || (level >= 2 && (Wi == 32 || Wi == 16 || Wi == 8))) ? 9 : 0;
 }
 // patch_w: the map width when the layer has igemm_x6p_kernel's geometry (x6_patch_geometry), else 0
 static X6Plan x6_forward_plan(int64_t M, int Ci, int Co, int KH, int KW, int dil, int k_splits, int patch_w = 0) {
@@ -1442,7 +1467,7 @@ static X6Plan x6_forward_plan(int64_t M, int Ci, int Co, int KH, int KW, int dil
 
 // igemm_x6p_kernel's conditions on top of x6_patch_geometry: tiles of whole image rows inside one image, K splits no finer than
 // channel chunks
-static bool x6_patch_applies(const X6Plan& plan, bool patch_geo, int Hi, int Wi, int Ci) {
+static bool x6_patch_applies(const X6Plan& plan, int patch_geo, int Hi, int Wi, int Ci) {
     if (!patch_geo || !plan.bdirect) return false;
     if ((Hi * Wi) % plan.bmt != 0 || plan.k_splits > (Ci + XBK - 1) / XBK) return false;
     if (Wi == 64) return plan.bn == 64 ? plan.bmt == 256 : true;
@@ -1462,7 +1487,7 @@ static int x6_forward_impl(const float* X, const void* image, const float* bias,
     const int64_t M = (int64_t)B * Ho * Wo;
     const int64_t x_bytes = (int64_t)B * Hi * Wi * Ci * 4, w_bytes = dsf_conv_x6_image_bytes(KH, KW, Ci, Co);
     DSF_CHECK_ARG(M < (1ll << 31) && x_bytes < 0xFFFFFFF0ll && w_bytes < 0xFFFFFFF0ll);
-    const bool patch_geo = x6_patch_geometry(Hi, Wi, Ho, Wo, KH, KW, stride, dil, pad_h, pad_w);
+    const int patch_geo = x6_patch_geometry(Hi, Wi, Ho, Wo, KH, KW, stride, dil, pad_h, pad_w);
     X6Plan plan = x6_forward_plan(M, Ci, Co, KH, KW, dil, k_splits, patch_geo ? Wi : 0);
     // a 1 x 1 filter under dilation 2 (backward-data of a 1 x 1 stride-2 shortcut): one output pixel in four has a tap.  Launch the
     // rows of that parity class only -- their epilogue stores the zeros of the three siblings -- instead of 4x the tiles, three
@@ -1503,27 +1528,33 @@ static int x6_forward_impl(const float* X, const void* image, const float* bias,
     // the weight block from L2 -- the LDS-staged kernel is faster there (measured 136 / 139 vs 133 / 133 TFLOP/s)
     const bool direct = bdirect && !(bmt == 64 && n_tiles >= 2);
     if (patch) {
-#define DSF_LAUNCH_X6P(BNv, BMv, Wv, NWv, BDv)                                                                                    \
+#define DSF_LAUNCH_X6P(BNv, BMv, Wv, NWv, BDv, NTv)                                                                               \
     do {                                                                                                                          \
-        using PT = X6Patch<BMv, Wv>;                                                                                              \
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_x6p_kernel<BNv, BMv, Wv, NWv, BDv>), \
+        using PT = X6Patch<BMv, Wv, NTv>;                                                                                         \
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_x6p_kernel<BNv, BMv, Wv, NWv, BDv, NTv>), \
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, PT::LDS_BYTES);            \
         if (attr != hipSuccess) return DSF_ERR_LAUNCH;                                                                            \
-        hipLaunchKernelGGL((igemm_x6p_kernel<BNv, BMv, Wv, NWv, BDv>), grid, dim3(256), PT::LDS_BYTES, (hipStream_t)stream, X,    \
-                           (const uint4*)image, bias, Y, p, m_tiles, n_tiles, k_splits, (uint32_t)x_bytes, (uint32_t)w_bytes,     \
+        hipLaunchKernelGGL((igemm_x6p_kernel<BNv, BMv, Wv, NWv, BDv, NTv>), grid, dim3(256), PT::LDS_BYTES, (hipStream_t)stream,  \
+                           X, (const uint4*)image, bias, Y, p, m_tiles, n_tiles, k_splits, (uint32_t)x_bytes, (uint32_t)w_bytes,  \
                            stats, ep);                                                                                            \
     } while (0)
         // 64-row tiles: 1 x 4 waves and weight fragments two taps ahead (B = 32, 16x16x256 unsplit: 2 x 2 waves 55 us, 1 x 4 51,
         // + two taps ahead 48; no gain from either on the taller tiles, which have two workgroups per CU to hide the latency)
-        if (bn == 64) DSF_LAUNCH_X6P(64, 256, 64, 2, 2);
-        else if (bmt == 128) {
-            if (Wi == 64) DSF_LAUNCH_X6P(128, 128, 64, 2, 2); else if (Wi == 32) DSF_LAUNCH_X6P(128, 128, 32, 2, 2);
-            else DSF_LAUNCH_X6P(128, 128, 16, 2, 2);
+        if (patch_geo == 4) {                                            // transposed 4 x 4 stride 2: Wi = the class image's width
+            if (bmt == 128) { if (Wi == 32) DSF_LAUNCH_X6P(128, 128, 32, 2, 2, 4); else DSF_LAUNCH_X6P(128, 128, 16, 2, 2, 4); }
+            else if (Wi == 32) DSF_LAUNCH_X6P(128, 64, 32, 4, 2, 4);
+            else if (Wi == 16) DSF_LAUNCH_X6P(128, 64, 16, 4, 2, 4);
+            else DSF_LAUNCH_X6P(128, 64, 8, 4, 2, 4);
         }
-        else if (Wi == 64) DSF_LAUNCH_X6P(128, 64, 64, 4, 3);
-        else if (Wi == 32) DSF_LAUNCH_X6P(128, 64, 32, 4, 3);
-        else if (Wi == 16) DSF_LAUNCH_X6P(128, 64, 16, 4, 3);
-        else DSF_LAUNCH_X6P(128, 64, 8, 4, 3);
+        else if (bn == 64) DSF_LAUNCH_X6P(64, 256, 64, 2, 2, 9);
+        else if (bmt == 128) {
+            if (Wi == 64) DSF_LAUNCH_X6P(128, 128, 64, 2, 2, 9); else if (Wi == 32) DSF_LAUNCH_X6P(128, 128, 32, 2, 2, 9);
+            else DSF_LAUNCH_X6P(128, 128, 16, 2, 2, 9);
+        }
+        else if (Wi == 64) DSF_LAUNCH_X6P(128, 64, 64, 4, 3, 9);
+        else if (Wi == 32) DSF_LAUNCH_X6P(128, 64, 32, 4, 3, 9);
+        else if (Wi == 16) DSF_LAUNCH_X6P(128, 64, 16, 4, 3, 9);
+        else DSF_LAUNCH_X6P(128, 64, 8, 4, 3, 9);
 #undef DSF_LAUNCH_X6P
         return dsf_launch_status();
     }
@@ -1574,7 +1605,7 @@ int dsf_conv_x6_forward_splits(int B, int Ho, int Wo, int Ci, int Co, int KH, in
 int dsf_conv_x6_forward_plan(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int dil, int pad_h,
                              int pad_w, int* variant, int* k_splits) {
     DSF_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && Ci > 0 && Co > 0 && KH > 0 && KW > 0 && (dil == 1 || dil == 2));
-    const bool patch_geo = x6_patch_geometry(Hi, Wi, Ho, Wo, KH, KW, stride, dil, pad_h, pad_w);
+    const int patch_geo = x6_patch_geometry(Hi, Wi, Ho, Wo, KH, KW, stride, dil, pad_h, pad_w);
     const X6Plan plan = x6_forward_plan((int64_t)B * Ho * Wo, Ci, Co, KH, KW, dil, 0, patch_geo ? Wi : 0);
     if (variant)
         *variant = x6_patch_applies(plan, patch_geo, Hi, Wi, Ci) ? 2 : (plan.bdirect && !(plan.bmt == 64 && plan.n_tiles >= 2)) ? 1 : 0;

@@ -323,6 +323,55 @@ def test_backward_data_of_1x1_stride_2_launches_the_live_parity_class_only(Ci, C
     assert _rel(out["1"].double().cpu(), gxd) < 3e-6
 
 
+@pytest.mark.parametrize("Ci,Co,H,W,B", [
+    (256, 256, 32, 32, 4),        # 64-row tiles (1 x 4 waves)
+    (64, 128, 32, 32, 8),         # 128-row tiles
+    (36, 132, 16, 16, 3),         # ragged channel chunk and n tile
+    (132, 72, 8, 8, 5),           # 8-wide inputs: a class image is one tile
+    (40, 130, 12, 16, 2),         # non-square input
+])
+def test_patch_staged_transposed_4x4_stride_2_is_bit_identical_to_the_gather(Ci, Co, H, W, B, monkeypatch):
+    """ConvTranspose2d(k = 4, s = 2, p = 1) runs as a dilation-2 gather in which every output parity class is a 2 x 2 convolution
+    over the input grid.  igemm_x6p_kernel with four taps (one input patch per 16-channel chunk, read by the class's four taps)
+    against igemm_x6b / x6_kernel (DSF_X6_PATCH=3): same reduction order, unsplit (deterministic mode) => BITWISE equal, forward
+    and the input gradient of the matching stride-2 convolution (the same gather with the mode-1 image); both against float64."""
+    import ctypes
+    from dsf_amd import nn_conv, _lib as L
+    I = ctypes.c_int
+    monkeypatch.setattr(nn_conv, "MATH", "x6")
+    g = torch.Generator().manual_seed(Ci + Co + H)
+    x = torch.randn(B, Ci, H, W, generator=g).cuda().requires_grad_(True)
+    wt = (torch.randn(Ci, Co, 4, 4, generator=g) / (4 * Ci) ** 0.5).cuda().requires_grad_(True)          # transposed layout
+    xs = torch.randn(B, Co, 2 * H, 2 * W, generator=g).cuda().requires_grad_(True)                      # for the stride-2 convolution
+    ws = (torch.randn(Ci, Co, 4, 4, generator=g) / (16 * Co) ** 0.5).cuda().requires_grad_(True)         # (Co_out = Ci, Ci_in = Co)
+    gys = torch.randn(B, Ci, H, W, generator=g).cuda()
+
+    def variant():
+        v = ctypes.c_int(-1)
+        assert L.lib().dsf_conv_x6_forward_plan(I(B), I(H), I(W), I(Ci), I(2 * H), I(2 * W), I(Co), I(4), I(4), I(1), I(2), I(2), I(2),
+                                                ctypes.byref(v), None) == 0
+        return v.value
+    was = L.set_deterministic(True)
+    try:
+        out = {}
+        for level in ("3", "2"):
+            monkeypatch.setenv("DSF_X6_PATCH", level)
+            assert (variant() == 2) == (level == "2")
+            y = nn_conv.ConvTranspose2dFunction.apply(x, wt, None, 2, (1, 1), (0, 0))
+            ys = nn_conv.Conv2dFunction.apply(xs, ws, None, 2, (1, 1))
+            gxs, = torch.autograd.grad((ys * gys).sum(), [xs])
+            out[level] = (y.detach(), gxs)
+    finally:
+        L.set_deterministic(was)
+    for a, r in zip(out["2"], out["3"]):
+        assert torch.equal(a, r)
+    ref = F.conv_transpose2d(x.detach().double().cpu(), wt.detach().double().cpu(), None, stride=2, padding=1)
+    assert _rel(out["2"][0].double().cpu(), ref) < 4e-6
+    xsd = xs.detach().double().cpu().requires_grad_(True)
+    gxd, = torch.autograd.grad((F.conv2d(xsd, ws.detach().double().cpu(), None, stride=2, padding=1) * gys.double().cpu()).sum(), [xsd])
+    assert _rel(out["2"][1].double().cpu(), gxd) < 4e-6
+
+
 def test_x6_weight_images_follow_the_weights(monkeypatch):
     """The split image of a weight is kept from one use to the next only for MANAGED parameters (FusedAdamW's, EvalStep's):
     in-place torch updates (version counter) and FusedAdamW's raw-pointer updates (nn_conv.weights_changed) both invalidate
