@@ -697,15 +697,17 @@ __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restri
     const __amdgpu_buffer_rsrc_t xbuf = x6_buffer(X, x_bytes), wbuf = x6_buffer(Wimg, w_bytes);
 
     // patch pixel (py, px), LDS granule py PW + px  <->  input pixel (y0 + oy0 + py, ox0 + px) of image `img`.
-    // NT = 9: rows are output pixels in order, (oy0, ox0) = (-1, -1).  NT = 4 (dilation-2 gather of a 4 x 4 stride-2 transposed
+    // NT = 9: rows are output pixels in order, (oy0, ox0) = (-pad, -pad): pad 1 (Hi x W input), or pad 0 over an input that was
+    // padded beforehand (reflection padding: Hi = Ho + 2, Wi = W + 2; every patch pixel is then inside the input).  NT = 4 (dilation-2 gather of a 4 x 4 stride-2 transposed
     // convolution): rows are ordered by output parity class (cpy, cpx), then as the W-wide class image = the input grid; an output
     // pixel (2 qy + cpy, 2 qx + cpx) has the taps kh = kh0 + 2 ty, kw = kw0 + 2 tx at input (qy + oy0 + ty, qx + ox0 + tx)
-    const int Mc = p.B * p.Hi * W;                       // NT = 4: rows per parity class
+    const int OH = (NT == 4) ? p.Hi : p.Ho;              // rows of the (class) image the tile's rows index
+    const int Mc = p.B * OH * W;                         // NT = 4: rows per parity class
     const int cls = (NT == 4) ? m0 / Mc : 0, r0 = (NT == 4) ? m0 % Mc : m0;
     const int cpy = cls >> 1, cpx = cls & 1;
     const int kh0 = (NT == 4) ? ((p.pad_h - cpy) & 1) : 0, kw0 = (NT == 4) ? ((p.pad_w - cpx) & 1) : 0;
-    const int oy0 = (NT == 4) ? (cpy - p.pad_h + kh0) / 2 : -1, ox0 = (NT == 4) ? (cpx - p.pad_w + kw0) / 2 : -1;
-    const int img = r0 / (p.Hi * W), y0 = (r0 % (p.Hi * W)) / W;
+    const int oy0 = (NT == 4) ? (cpy - p.pad_h + kh0) / 2 : -p.pad_h, ox0 = (NT == 4) ? (cpx - p.pad_w + kw0) / 2 : -p.pad_w;
+    const int img = r0 / (OH * W), y0 = (r0 % (OH * W)) / W;
     const int a_q = t & 3, a_k4 = a_q * 4, a_r = t >> 2;
     int a_off[NPASS];                                    // element offset of (pixel, channel quad) at chunk 0; -1: zeros
     int a_lds[NPASS];                                    // granule of the pixel in k-group 0; -1: no such pixel
@@ -714,8 +716,8 @@ __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restri
         const int pidx = a_r + 64 * i;
         const int py = pidx / (W + PT::HALO), px = pidx % (W + PT::HALO);
         const int y = y0 + oy0 + py, x = ox0 + px;
-        const bool ok = pidx < PT::NPIX && (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)W;
-        a_off[i] = ok ? ((img * p.Hi + y) * W + x) * p.Ci + a_k4 : -1;
+        const bool ok = pidx < PT::NPIX && (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi;
+        a_off[i] = ok ? ((img * p.Hi + y) * p.Wi + x) * p.Ci + a_k4 : -1;
         a_lds[i] = pidx < PT::NPIX ? py * PT::PW + px : -1;
     }
 
@@ -855,7 +857,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restri
                 int64_t row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (NT == 4) {                           // class row -> output pixel (2 qy + cpy, 2 qx + cpx)
                     const int rc = (int)row - cls * Mc, qx = rc % W, q = rc / W;
-                    row = ((int64_t)(q / p.Hi) * p.Ho + 2 * (q % p.Hi) + cpy) * p.Wo + 2 * qx + cpx;
+                    row = ((int64_t)(q / OH) * p.Ho + 2 * (q % OH) + cpy) * p.Wo + 2 * qx + cpx;
                 }
                 if (row >= M) continue;
                 if (k_splits > 1) atomicAdd(Y + row * p.Co + n, acc[i][j][r] + bv);
@@ -1425,8 +1427,10 @@ static int x6_patch_geometry(int Hi, int Wi, int Ho, int Wo, int KH, int KW, int
     if (level <= 0) return 0;
     if (dil == 2 && KH == 4 && KW == 4 && stride == 1 && Ho == 2 * Hi && Wo == 2 * Wi && pad_h >= 0 && pad_h <= 3 && pad_w >= 0 &&
         pad_w <= 3 && level == 2 && (Wi == 32 || Wi == 16 || Wi == 8)) return 4;
-    if (!(dil == 1 && KH == 3 && KW == 3 && stride == 1 && pad_h == 1 && pad_w == 1 && Ho == Hi && Wo == Wi)) return 0;
-    return (Wi == 64 || (level >= 2 && (Wi == 32 || Wi == 16 || Wi == 8))) ? 9 : 0;
+    // 3 x 3, stride 1: pad 1, or pad 0 over an input that carries its own (reflection) padding
+    if (!(dil == 1 && KH == 3 && KW == 3 && stride == 1 && pad_h == pad_w && (pad_h == 0 || pad_h == 1) && Hi == Ho + 2 - 2 * pad_h &&
+          Wi == Wo + 2 - 2 * pad_w)) return 0;
+    return (Wo == 64 || (level >= 2 && (Wo == 32 || Wo == 16 || Wo == 8))) ? 9 : 0;
 }
 // patch_w: the map width when the layer has igemm_x6p_kernel's geometry (x6_patch_geometry), else 0
 static X6Plan x6_forward_plan(int64_t M, int Ci, int Co, int KH, int KW, int dil, int k_splits, int patch_w = 0) {
@@ -1467,11 +1471,12 @@ static X6Plan x6_forward_plan(int64_t M, int Ci, int Co, int KH, int KW, int dil
 
 // igemm_x6p_kernel's conditions on top of x6_patch_geometry: tiles of whole image rows inside one image, K splits no finer than
 // channel chunks
-static bool x6_patch_applies(const X6Plan& plan, int patch_geo, int Hi, int Wi, int Ci) {
+// (ph x pw: the image the tile rows index -- the output map, or the input grid = one parity class of a transposed convolution)
+static bool x6_patch_applies(const X6Plan& plan, int patch_geo, int ph, int pw, int Ci) {
     if (!patch_geo || !plan.bdirect) return false;
-    if ((Hi * Wi) % plan.bmt != 0 || plan.k_splits > (Ci + XBK - 1) / XBK) return false;
-    if (Wi == 64) return plan.bn == 64 ? plan.bmt == 256 : true;
-    return plan.bn == 128 && (Wi == 32 || Wi == 16 || plan.bmt == 64);
+    if ((ph * pw) % plan.bmt != 0 || plan.k_splits > (Ci + XBK - 1) / XBK) return false;
+    if (pw == 64) return plan.bn == 64 ? plan.bmt == 256 : true;
+    return plan.bn == 128 && (pw == 32 || pw == 16 || plan.bmt == 64);
 }
 
 // Ci / Co are the reduction / output channel counts of the IMAGE (mode 1: those of the backward-data GEMM).
@@ -1488,7 +1493,8 @@ static int x6_forward_impl(const float* X, const void* image, const float* bias,
     const int64_t x_bytes = (int64_t)B * Hi * Wi * Ci * 4, w_bytes = dsf_conv_x6_image_bytes(KH, KW, Ci, Co);
     DSF_CHECK_ARG(M < (1ll << 31) && x_bytes < 0xFFFFFFF0ll && w_bytes < 0xFFFFFFF0ll);
     const int patch_geo = x6_patch_geometry(Hi, Wi, Ho, Wo, KH, KW, stride, dil, pad_h, pad_w);
-    X6Plan plan = x6_forward_plan(M, Ci, Co, KH, KW, dil, k_splits, patch_geo ? Wi : 0);
+    const int ph = patch_geo == 4 ? Hi : Ho, pw = patch_geo == 4 ? Wi : Wo;       // the image the patch kernel's tile rows index
+    X6Plan plan = x6_forward_plan(M, Ci, Co, KH, KW, dil, k_splits, patch_geo ? pw : 0);
     // a 1 x 1 filter under dilation 2 (backward-data of a 1 x 1 stride-2 shortcut): one output pixel in four has a tap.  Launch the
     // rows of that parity class only -- their epilogue stores the zeros of the three siblings -- instead of 4x the tiles, three
     // quarters of which only store zeros (B = 192, 32x32x512 -> 64x64x256: 812 -> ... us).  DSF_X6_LIVE=0: off.
@@ -1509,7 +1515,7 @@ static int x6_forward_impl(const float* X, const void* image, const float* bias,
         dsf_zero_async(Y, sizeof(float) * (size_t)M * Co, (hipStream_t)stream) != hipSuccess) return DSF_ERR_LAUNCH;
     const dim3 grid(m_tiles * n_tiles * k_splits);
     // BatchNorm statistics in the epilogue: only the B-direct kernels, unsplit, without a bias
-    const bool patch = x6_patch_applies(plan, patch_geo, Hi, Wi, Ci);
+    const bool patch = x6_patch_applies(plan, patch_geo, ph, pw, Ci);
     const bool direct_pre = patch || (bdirect && !(bmt == 64 && n_tiles >= 2));
     float* stats = (bn_stats && bn_rows && direct_pre && k_splits == 1 && !bias) ? bn_stats : nullptr;
     if (bn_rows) *bn_rows = stats ? m_tiles : 0;
@@ -1540,20 +1546,20 @@ static int x6_forward_impl(const float* X, const void* image, const float* bias,
     } while (0)
         // 64-row tiles: 1 x 4 waves and weight fragments two taps ahead (B = 32, 16x16x256 unsplit: 2 x 2 waves 55 us, 1 x 4 51,
         // + two taps ahead 48; no gain from either on the taller tiles, which have two workgroups per CU to hide the latency)
-        if (patch_geo == 4) {                                            // transposed 4 x 4 stride 2: Wi = the class image's width
-            if (bmt == 128) { if (Wi == 32) DSF_LAUNCH_X6P(128, 128, 32, 2, 2, 4); else DSF_LAUNCH_X6P(128, 128, 16, 2, 2, 4); }
-            else if (Wi == 32) DSF_LAUNCH_X6P(128, 64, 32, 4, 2, 4);
-            else if (Wi == 16) DSF_LAUNCH_X6P(128, 64, 16, 4, 2, 4);
+        if (patch_geo == 4) {                                            // transposed 4 x 4 stride 2: pw = the class image's width
+            if (bmt == 128) { if (pw == 32) DSF_LAUNCH_X6P(128, 128, 32, 2, 2, 4); else DSF_LAUNCH_X6P(128, 128, 16, 2, 2, 4); }
+            else if (pw == 32) DSF_LAUNCH_X6P(128, 64, 32, 4, 2, 4);
+            else if (pw == 16) DSF_LAUNCH_X6P(128, 64, 16, 4, 2, 4);
             else DSF_LAUNCH_X6P(128, 64, 8, 4, 2, 4);
         }
         else if (bn == 64) DSF_LAUNCH_X6P(64, 256, 64, 2, 2, 9);
         else if (bmt == 128) {
-            if (Wi == 64) DSF_LAUNCH_X6P(128, 128, 64, 2, 2, 9); else if (Wi == 32) DSF_LAUNCH_X6P(128, 128, 32, 2, 2, 9);
+            if (pw == 64) DSF_LAUNCH_X6P(128, 128, 64, 2, 2, 9); else if (pw == 32) DSF_LAUNCH_X6P(128, 128, 32, 2, 2, 9);
             else DSF_LAUNCH_X6P(128, 128, 16, 2, 2, 9);
         }
-        else if (Wi == 64) DSF_LAUNCH_X6P(128, 64, 64, 4, 3, 9);
-        else if (Wi == 32) DSF_LAUNCH_X6P(128, 64, 32, 4, 3, 9);
-        else if (Wi == 16) DSF_LAUNCH_X6P(128, 64, 16, 4, 3, 9);
+        else if (pw == 64) DSF_LAUNCH_X6P(128, 64, 64, 4, 3, 9);
+        else if (pw == 32) DSF_LAUNCH_X6P(128, 64, 32, 4, 3, 9);
+        else if (pw == 16) DSF_LAUNCH_X6P(128, 64, 16, 4, 3, 9);
         else DSF_LAUNCH_X6P(128, 64, 8, 4, 3, 9);
 #undef DSF_LAUNCH_X6P
         return dsf_launch_status();
@@ -1606,9 +1612,10 @@ int dsf_conv_x6_forward_plan(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int 
                              int pad_w, int* variant, int* k_splits) {
     DSF_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && Ci > 0 && Co > 0 && KH > 0 && KW > 0 && (dil == 1 || dil == 2));
     const int patch_geo = x6_patch_geometry(Hi, Wi, Ho, Wo, KH, KW, stride, dil, pad_h, pad_w);
-    const X6Plan plan = x6_forward_plan((int64_t)B * Ho * Wo, Ci, Co, KH, KW, dil, 0, patch_geo ? Wi : 0);
+    const int ph = patch_geo == 4 ? Hi : Ho, pw = patch_geo == 4 ? Wi : Wo;
+    const X6Plan plan = x6_forward_plan((int64_t)B * Ho * Wo, Ci, Co, KH, KW, dil, 0, patch_geo ? pw : 0);
     if (variant)
-        *variant = x6_patch_applies(plan, patch_geo, Hi, Wi, Ci) ? 2 : (plan.bdirect && !(plan.bmt == 64 && plan.n_tiles >= 2)) ? 1 : 0;
+        *variant = x6_patch_applies(plan, patch_geo, ph, pw, Ci) ? 2 : (plan.bdirect && !(plan.bmt == 64 && plan.n_tiles >= 2)) ? 1 : 0;
     if (k_splits) *k_splits = plan.k_splits;
     return DSF_OK;
 }

@@ -826,10 +826,11 @@ def kernel_name(rec):
         L.lib().dsf_conv_x6_forward_plan(I(B), I(Hi), I(Wi), I(Ci), I(Ho), I(Wo), I(Co), I(rec[8]), I(rec[9]), I(rec[10]), I(dil), I(rec[12]),
                                          I(rec[13]), ctypes.byref(variant), None)
         if variant.value == 2:                                 # the patch-staged kernel: <BN, BMT, W, waves along n, B sets, taps>
-            if bn6 == 128 and Wi == 8:
-                bmt = 64
             nt = 4 if dil == 2 else 9                           # 4: a 4 x 4 stride-2 transposed convolution, class by class
-            return "igemm_x6p_kernel<%d, %d, %d, %d, %d, %d>" % (bn6, bmt, Wi, 4 if bmt == 64 else 2, 3 if (bmt == 64 and nt == 9) else 2, nt)
+            pw = Wi if nt == 4 else Wo                          # width of the image the tile rows index
+            if bn6 == 128 and pw == 8:
+                bmt = 64
+            return "igemm_x6p_kernel<%d, %d, %d, %d, %d, %d>" % (bn6, bmt, pw, 4 if bmt == 64 else 2, 3 if (bmt == 64 and nt == 9) else 2, nt)
         if direct and not (bmt == 64 and n6 >= 2):            # weight operand straight into the MFMA fragments (conv_x6.hip)
             return "igemm_x6b_kernel<%d, %s, %d>" % (bn6, "true" if dil == 2 else "false", bmt)
         return "igemm_x6_kernel<%d, %s, %d>" % (bn6, "true" if dil == 2 else "false", bmt)

@@ -372,6 +372,41 @@ def test_patch_staged_transposed_4x4_stride_2_is_bit_identical_to_the_gather(Ci,
     assert _rel(out["2"][1].double().cpu(), gxd) < 4e-6
 
 
+@pytest.mark.parametrize("Ci,Co,H,W,B", [(256, 256, 32, 32, 6), (36, 132, 16, 16, 3), (64, 64, 8, 64, 2), (40, 200, 8, 8, 5)])
+def test_patch_staged_3x3_over_a_reflection_padded_input(Ci, Co, H, W, B, monkeypatch):
+    """The generator's residual blocks are ReflectionPad2d(1) + Conv2d(3, padding=0): the input carries its own border, every
+    patch pixel is inside it.  igemm_x6p_kernel against the gather kernels (DSF_X6_PATCH=0), unsplit: bitwise equal, forward and
+    input gradient (a pad-2 gather: stays on the gather kernel either way); against float64."""
+    import ctypes
+    from dsf_amd import nn_conv, _lib as L
+    I = ctypes.c_int
+    monkeypatch.setattr(nn_conv, "MATH", "x6")
+    g = torch.Generator().manual_seed(Ci + Co + H)
+    x = torch.randn(B, Ci, H + 2, W + 2, generator=g).cuda().requires_grad_(True)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5).cuda().requires_grad_(True)
+    gy = torch.randn(B, Co, H, W, generator=g).cuda()
+    was = L.set_deterministic(True)
+    try:
+        out = {}
+        for level in ("0", "2"):
+            monkeypatch.setenv("DSF_X6_PATCH", level)
+            v = ctypes.c_int(-1)
+            assert L.lib().dsf_conv_x6_forward_plan(I(B), I(H + 2), I(W + 2), I(Ci), I(H), I(W), I(Co), I(3), I(3), I(1), I(1), I(0), I(0),
+                                                    ctypes.byref(v), None) == 0
+            assert (v.value == 2) == (level == "2")
+            y = nn_conv.Conv2dFunction.apply(x, w, None, 1, (0, 0))
+            gx, = torch.autograd.grad((y * gy).sum(), [x])
+            out[level] = (y.detach(), gx)
+    finally:
+        L.set_deterministic(was)
+    for a, r in zip(out["2"], out["0"]):
+        assert torch.equal(a, r)
+    xd = x.detach().double().cpu().requires_grad_(True)
+    ref = F.conv2d(xd, w.detach().double().cpu(), None)
+    gxd, = torch.autograd.grad((ref * gy.double().cpu()).sum(), [xd])
+    assert _rel(out["2"][0].double().cpu(), ref.detach()) < 4e-6 and _rel(out["2"][1].double().cpu(), gxd) < 4e-6
+
+
 def test_x6_weight_images_follow_the_weights(monkeypatch):
     """The split image of a weight is kept from one use to the next only for MANAGED parameters (FusedAdamW's, EvalStep's):
     in-place torch updates (version counter) and FusedAdamW's raw-pointer updates (nn_conv.weights_changed) both invalidate
@@ -451,7 +486,7 @@ def test_x6_random_geometries_against_float64():
             for name, a, r in (("y", y, yd), ("gx", gx, gxd), ("gw", gw, gwd)):
                 assert _rel(a.detach().double().cpu(), r.detach()) < 3e-6, (case, name, Ci, Co, K, s, p, H, W, B, transposed)
         kinds = [r[0] for r in nn_conv.RECORD]
-        assert kinds.count("x6") >= 30, kinds          # the sweep really exercised the split kernels
+        assert nn_conv.MATH != "x6" or kinds.count("x6") >= 30, kinds          # the sweep really exercised the split kernels
     finally:
         nn_conv.RECORD = saved
 
@@ -471,6 +506,8 @@ def test_bn_statistics_from_the_conv_epilogue_equal_the_reduction_pass(kind, Ci,
     epilogue) against conv -> dsf_bn_forward: same output / saved statistics / running buffers to accumulation-order noise
     and the same gradients; the request is honoured (rows > 0) on these shapes."""
     from dsf_amd import nn_conv, nn_norm
+    if nn_conv.MATH != "x6":
+        pytest.skip("DSF_CONV_MATH=f32: the fp32-MFMA kernels have no statistics epilogue")
     torch.manual_seed(3)
     conv = (nn_conv.Conv2d(Ci, Co, K, s, p, bias=False) if kind == "conv"
             else nn_conv.ConvTranspose2d(Ci, Co, K, stride=s, padding=p, output_padding=0, bias=False)).cuda()
@@ -647,6 +684,8 @@ def test_split_launch_adds_into_a_pooled_zero_output(Ci, Co, K, H, B):
     from dsf_amd import nn_conv, _lib as L
     if nn_conv.MATH != "x6":
         pytest.skip("DSF_CONV_MATH=f32")
+    if L.deterministic():
+        pytest.skip("deterministic mode never splits the reduction")
     I = ctypes.c_int
     assert int(L.lib().dsf_conv_x6_forward_splits(I(B), I(H), I(H), I(Ci), I(Co), I(K), I(K), I(1))) > 1
     bwd_split = int(L.lib().dsf_conv_x6_forward_splits(I(B), I(H), I(H), I(Co), I(Ci), I(K), I(K), I(1))) > 1    # the backward-data launch

@@ -491,7 +491,11 @@ def test_two_stage_resnet50_teacher_forced_blocks(render, orender):
     assert fwd.max() < 5e-6, [(r[0], r[2][0]) for r in rows if r[2][0] >= 5e-6]
     # backward: the typical block is at rounding level (observed medians 3.1e-7 / 4.6e-7; torch-CPU 3.3e-7 / 5.5e-7) ...
     assert _np.median(gx) < 2e-6 and _np.median(gw) < 3e-6, (_np.median(gx), _np.median(gw))
-    assert _np.median(gx) <= 2.0 * _np.median(gx_c) and _np.median(gw) <= 2.0 * _np.median(gw_c)
+    # (deterministic mode runs every reduction unsplit: one fp32 accumulation chain over all of K -- up to 4392 terms -- instead of
+    #  several shorter ones, hence medians of ~1e-6 there against 3-5e-7: still accumulation order, see test_gpu_conv.py)
+    from dsf_amd import _lib as _L
+    slack = 4.0 if _L.deterministic() else 2.0
+    assert _np.median(gx) <= slack * _np.median(gx_c) and _np.median(gw) <= slack * _np.median(gw_c)
     # ... a minority of blocks holds a switch (observed 8 of 44, torch-CPU 9), and a switch is small (observed <= 4.5e-3):
     # a wrong backward formula in any op would put its blocks at >= 1e-1
     assert int((gx > 1e-5).sum()) <= len(gx) // 3, int((gx > 1e-5).sum())
