@@ -56,7 +56,7 @@ SYMBOLS = [
     "dsf_depth_augment_crop", "dsf_conv_x6_bn_stats_rows", "dsf_conv_x6_forward_bn", "dsf_conv_x6_forward_affine", "dsf_bn_forward_from_stats",
     "dsf_instnorm_forward", "dsf_reflect_pad_nhwc", "dsf_bn_local_sums", "dsf_bn_forward_from_sums", "dsf_bn_backward_sums", "dsf_bn_backward_apply",
     "dsf_bn_acc_rows", "dsf_conv_x6_forward_splits", "dsf_conv_x6_forward_into", "dsf_conv_x6_forward_bn_acc", "dsf_bn_forward_acc", "dsf_bn_backward_acc",
-    "dsf_conv_x6_forward_plan",
+    "dsf_conv_x6_forward_plan", "dsf_conv_co1_forward",
 ]
 
 

@@ -133,6 +133,73 @@ constexpr int C1_WRW_WGS = 2048;                      // 8 waves per SIMD: the k
 
 inline bool c1_ok(int Co, int K, int stride) { return Co >= 1 && Co <= 64 && (K == 5 || K == 7) && (stride == 1 || stride == 2); }
 
+
+// ------------------------------------------------------------------------------------------------
+// conv_co1_fwd_kernel: ONE output channel (the generator's last layer: ReflectionPad2d(3) + Conv2d(64, 1, 7), reference
+// render_model/transfer.py; 1 M output pixels x 3136 products at B = 64).  As an implicit GEMM it pads N from 1 to 64 columns
+// (igemm_x6b_kernel<64, false, 256>: 1.79 ms, 3.7 TFLOP/s of useful work).  Here a lane owns output pixels: a workgroup takes a
+// 64 x 8 tile (wave w: rows 2 w and 2 w + 1, lane = column), stages the (8 + K - 1) x (64 + K - 1) input patch of an 8-channel chunk
+// in LDS ([pixel][8 + 4 floats]: the 16-lane groups of a ds_read_b128 hit 64 distinct banks), and every lane accumulates its two
+// pixels' dot products with fp32 FMAs -- an input row is read once for the two output rows it feeds; the weights are wave-uniform
+// (scalar loads).  HBM: the input once (+ halo), 4 bytes out per pixel.
+// ------------------------------------------------------------------------------------------------
+struct Co1P { int B, Hi, Wi, Ci, Ho, Wo, pad; };
+
+template <int K>
+__global__ __launch_bounds__(256) void conv_co1_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                           const float* __restrict__ bias, float* __restrict__ Y, Co1P p,
+                                                           int tiles_x, int tiles_y) {
+    constexpr int TX = 64, TY = 8, CH = 8, PITCH = CH + 4;               // floats per staged pixel
+    constexpr int PW = TX + K - 1, PH = TY + K - 1, NPIX = PW * PH;
+    __shared__ __attribute__((aligned(16))) float s_in[NPIX * PITCH];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int tile = blockIdx.x;
+    const int tx = tile % tiles_x; tile /= tiles_x;
+    const int ty = tile % tiles_y; const int b = tile / tiles_y;
+    const int x0 = tx * TX, y0 = ty * TY;                                // first output pixel of the tile
+    float acc0 = 0.f, acc1 = 0.f;
+    for (int c0 = 0; c0 < p.Ci; c0 += CH) {
+        __syncthreads();                                                 // the previous chunk's readers are done
+        for (int e = t; e < NPIX * 2; e += 256) {                        // (patch pixel, channel quad)
+            const int pix = e >> 1, q = e & 1;
+            const int py = pix / PW, px = pix - py * PW;
+            const int iy = y0 + py - p.pad, ix = x0 + px - p.pad;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
+                v = *reinterpret_cast<const float4*>(X + ((int64_t)(b * p.Hi + iy) * p.Wi + ix) * p.Ci + c0 + q * 4);
+            *reinterpret_cast<float4*>(&s_in[pix * PITCH + q * 4]) = v;
+        }
+        __syncthreads();
+        const float* wc = W + c0;                                        // W [K][K][Ci]: tap (ky, kx) of this chunk at wc[(ky K + kx) Ci ..]
+#pragma unroll
+        for (int ry = 0; ry <= K; ++ry) {                                // input row 2 wave + ry feeds output row 0 (tap ry) and 1 (tap ry - 1)
+            const float* row = &s_in[((2 * wave + ry) * PW + lane) * PITCH];
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const float4 a = *reinterpret_cast<const float4*>(row + kx * PITCH);
+                const float4 c = *reinterpret_cast<const float4*>(row + kx * PITCH + 4);
+                const float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+                if (ry < K) {
+                    const float* w0 = wc + (ry * K + kx) * p.Ci;
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) acc0 = fmaf(v[j], w0[j], acc0);
+                }
+                if (ry >= 1) {
+                    const float* w1 = wc + ((ry - 1) * K + kx) * p.Ci;
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) acc1 = fmaf(v[j], w1[j], acc1);
+                }
+            }
+        }
+    }
+    const float bv = bias ? bias[0] : 0.f;
+    const int ox = x0 + lane, oy = y0 + 2 * wave;
+    if (ox < p.Wo) {
+        if (oy < p.Ho) Y[(int64_t)(b * p.Ho + oy) * p.Wo + ox] = acc0 + bv;
+        if (oy + 1 < p.Ho) Y[(int64_t)(b * p.Ho + oy + 1) * p.Wo + ox] = acc1 + bv;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -177,6 +244,22 @@ int dsf_conv_c1_wrw(const float* X, const float* dY, float* dW, float* workspace
     else { if (stride == 1) DSF_LAUNCH_C1W(7, 1); else DSF_LAUNCH_C1W(7, 2); }
 #undef DSF_LAUNCH_C1W
     hipLaunchKernelGGL(conv_c1_wrw_combine_kernel, dim3(K * K), dim3(256), 0, st, workspace, wgs, K * K, Co, accumulate, dW);
+    return dsf_launch_status();
+}
+
+// One output channel, square K in {3, 5, 7}, stride 1, Ci % 8 == 0: X (B,Hi,Wi,Ci) NHWC, W [K][K][Ci] (= the kernel layout
+// [K][K][Ci][1]), Y (B,Ho,Wo); other shapes DSF_ERR_UNSUPPORTED.
+int dsf_conv_co1_forward(const float* X, const float* W, const float* bias, float* Y, int B, int Hi, int Wi, int Ci, int Ho, int Wo,
+                         int K, int pad, dsf_stream_t stream) {
+    DSF_CHECK_ARG(X && W && Y && B >= 0 && Hi > 0 && Wi > 0 && Ci > 0 && Ho > 0 && Wo > 0 && pad >= 0);
+    if (!(K == 3 || K == 5 || K == 7) || (Ci & 7) || Ho != Hi + 2 * pad - K + 1 || Wo != Wi + 2 * pad - K + 1) return DSF_ERR_UNSUPPORTED;
+    if (B == 0) return DSF_OK;
+    Co1P p = {B, Hi, Wi, Ci, Ho, Wo, pad};
+    const int tiles_x = (Wo + 63) / 64, tiles_y = (Ho + 7) / 8;
+    const dim3 grid((unsigned)(B * tiles_x * tiles_y));
+    if (K == 3) hipLaunchKernelGGL(conv_co1_fwd_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, X, W, bias, Y, p, tiles_x, tiles_y);
+    else if (K == 5) hipLaunchKernelGGL(conv_co1_fwd_kernel<5>, grid, dim3(256), 0, (hipStream_t)stream, X, W, bias, Y, p, tiles_x, tiles_y);
+    else hipLaunchKernelGGL(conv_co1_fwd_kernel<7>, grid, dim3(256), 0, (hipStream_t)stream, X, W, bias, Y, p, tiles_x, tiles_y);
     return dsf_launch_status();
 }
 

@@ -261,6 +261,22 @@ def _c1_ok(Ci, Co, KH, KW, stride, pad):
     return Ci == 1 and pad[0] == pad[1] and bool(L.lib().dsf_conv_c1_supported(I(Co), I(KH), I(KW), I(stride)))
 
 
+def _co1_ok(Ci, Co, KH, KW, stride, pad):
+    """one output channel (conv_c1.hip: conv_co1_fwd_kernel): the generator's last layer"""
+    return Co == 1 and KH == KW and KH in (3, 5, 7) and stride == 1 and Ci % 8 == 0 and pad[0] == pad[1]
+
+
+def _fwd_co1(x, wk, bias, out_hw, K, pad):
+    B, Ci, Hi, Wi = x.shape
+    Ho, Wo = out_hw
+    if RECORD is not None:
+        RECORD.append(("co1_fwd", B, Hi, Wi, Ci, Ho, Wo, 1, K, K, 1, 1, pad, pad))
+    y = torch.empty((B, 1, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=CL)
+    check(L.lib().dsf_conv_co1_forward(ptr_nhwc(x), ptr(wk), ptr(bias), ptr_nhwc(y), I(B), I(Hi), I(Wi), I(Ci), I(Ho), I(Wo), I(K), I(pad),
+                                       stream_ptr()), "dsf_conv_co1_forward")
+    return y
+
+
 def _fwd_c1(x, wk, bias, out_hw, Co, K, stride, pad):
     B, _, Hi, Wi = x.shape
     Ho, Wo = out_hw
@@ -421,6 +437,8 @@ class Conv2dFunction(Function):
         b = bias.detach().float().contiguous() if bias is not None else None
         if _c1_ok(Ci, Co, KH, KW, stride, padding):
             y = _fwd_c1(x, wk, b, (Ho, Wo), Co, KH, stride, padding[0])
+        elif _co1_ok(Ci, Co, KH, KW, stride, padding):
+            y = _fwd_co1(x, wk, b, (Ho, Wo), KH, padding[0])
         elif _x6_ok(Ci, x.numel()):
             y = _fwd_x6(x, _x6_image(weight, wk, 0), b, (Ho, Wo), Co, KH, KW, stride, padding)
         else:
@@ -770,6 +788,9 @@ def replay(rec, iters=3):
     elif kind == "c1_fwd":
         wk = torch.randn(KH, KW, 1, Co, device=dev)
         run = lambda: _fwd_c1(x, wk, None, (Ho, Wo), Co, KH, stride, ph)
+    elif kind == "co1_fwd":
+        wk = torch.randn(KH, KW, Ci, 1, device=dev)
+        run = lambda: _fwd_co1(x, wk, None, (Ho, Wo), KH, ph)
     elif kind == "c1_wrw":
         gy = torch.randn(B, Co, Ho, Wo, device=dev).contiguous(memory_format=CL)
         run = lambda: _wrw_c1(x, gy, KH, stride, ph)
@@ -814,6 +835,8 @@ def kernel_name(rec):
     vec = Ci % 4 == 0 and Co % 4 == 0
     if kind in ("c1_fwd", "c1_wrw"):
         return "conv_c1_%s_kernel<%d, %d>" % (kind[3:], rec[8], rec[10])
+    if kind == "co1_fwd":
+        return "conv_co1_fwd_kernel<%d>" % rec[8]
     if kind == "x6":
         bn6 = 128 if Co > 64 else 64
         n6 = (Co + bn6 - 1) // bn6

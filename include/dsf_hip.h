@@ -347,6 +347,12 @@ int dsf_depth_crop_normalize_u16(const uint16_t* depth, const double* com, const
  * dsf_conv_igemm_wrw), workspace = dsf_conv_c1_workspace_bytes(K, K) bytes of per-workgroup partial sums; deterministic.
  * ---------------------------------------------------------------------------------- */
 int dsf_conv_c1_supported(int Co, int KH, int KW, int stride);
+/* ONE output channel (the generator's last layer, ReflectionPad2d(3) + Conv2d(64, 1, 7): render_model/transfer.py:441-442; as an
+ * implicit GEMM it would pad N from 1 to 64 columns): X (B,Hi,Wi,Ci) NHWC, W [K][K][Ci] (the kernel layout [K][K][Ci][1]),
+ * Y (B,Ho,Wo); square K in {3, 5, 7}, stride 1, Ci % 8 == 0, zero padding `pad`; other shapes DSF_ERR_UNSUPPORTED.  fp32 FMAs,
+ * lane = output pixel.  Additive in round 5 (the ABI version stays 2). */
+int dsf_conv_co1_forward(const float* X, const float* W, const float* bias, float* Y, int B, int Hi, int Wi, int Ci, int Ho, int Wo,
+                         int K, int pad, dsf_stream_t stream);
 int64_t dsf_conv_c1_workspace_bytes(int KH, int KW);
 int dsf_conv_c1_forward(const float* X, const float* W, const float* bias, float* Y, int B, int Hi, int Wi, int Ho, int Wo, int Co,
                         int K, int stride, int pad, dsf_stream_t stream);

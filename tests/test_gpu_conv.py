@@ -407,6 +407,37 @@ def test_patch_staged_3x3_over_a_reflection_padded_input(Ci, Co, H, W, B, monkey
     assert _rel(out["2"][0].double().cpu(), ref.detach()) < 4e-6 and _rel(out["2"][1].double().cpu(), gxd) < 4e-6
 
 
+@pytest.mark.parametrize("Ci,K,p,H,W,B,bias", [
+    (64, 7, 0, 26, 70, 2, True),          # the generator's last layer on a reflection-padded input (tiles with ragged edges)
+    (64, 7, 3, 19, 33, 3, False),         # zero padding instead
+    (16, 5, 2, 9, 130, 1, True),          # three tiles wide, one and a bit high
+    (8, 3, 1, 8, 64, 4, False),
+])
+def test_one_output_channel_convolution_matches_float64(Ci, K, p, H, W, B, bias):
+    """conv_co1_fwd_kernel (lane = output pixel, fp32 FMAs over an LDS-staged patch) against float64, and its gradients (which
+    take the general kernels) through the layer."""
+    from dsf_amd import nn_conv
+    g = torch.Generator().manual_seed(Ci + K + H)
+    x = torch.randn(B, Ci, H, W, generator=g).cuda().requires_grad_(True)
+    w = (torch.randn(1, Ci, K, K, generator=g) / (Ci * K * K) ** 0.5).cuda().requires_grad_(True)
+    b = torch.randn(1, generator=g).cuda().requires_grad_(True) if bias else None
+    nn_conv.RECORD = []
+    try:
+        y = nn_conv.Conv2dFunction.apply(x, w, b, 1, (p, p))
+        kinds = [r[0] for r in nn_conv.RECORD]
+    finally:
+        nn_conv.RECORD = None
+    assert kinds == ["co1_fwd"], kinds
+    gy = torch.randn(y.shape, generator=g).cuda()
+    gx, gw = torch.autograd.grad((y * gy).sum(), [x, w])
+    xd, wd = x.detach().double().cpu().requires_grad_(True), w.detach().double().cpu().requires_grad_(True)
+    yd = F.conv2d(xd, wd, b.detach().double().cpu() if bias else None, padding=p)
+    gxd, gwd = torch.autograd.grad((yd * gy.double().cpu()).sum(), [xd, wd])
+    assert yd.shape == y.shape
+    assert _rel(y.detach().double().cpu(), yd.detach()) < 2e-6
+    assert _rel(gx.double().cpu(), gxd) < 3e-6 and _rel(gw.double().cpu(), gwd) < 3e-6
+
+
 def test_x6_weight_images_follow_the_weights(monkeypatch):
     """The split image of a weight is kept from one use to the next only for MANAGED parameters (FusedAdamW's, EvalStep's):
     in-place torch updates (version counter) and FusedAdamW's raw-pointer updates (nn_conv.weights_changed) both invalidate
