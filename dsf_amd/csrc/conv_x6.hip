@@ -18,9 +18,11 @@
 //    v_mfma_f32_32x32x16_bf16 (lane = row + 32 k-group, 8 consecutive k) is one conflict-free ds_read_b128;
 //  * two LDS stages of one 16-deep chunk each, two register sets for the global loads (chunk c + 2 in flight while
 //    chunk c + 1 waits for its stage), loader pieces handed out between the 24 MFMAs of a chunk.
-// Kernels: igemm_x6_kernel<BN, DIL2> (forward, backward-data, transposed convolution), igemm_wrw_x6_kernel
-// (backward-weights: both operands are activations and are split on the fly; LDS transposes with ds_read_b64_tr_b16),
-// x6_split_weights(_multi)_kernel.  MI355X, B = 32 ResNet-18 two-stage step: 175-200 TFLOP/s fp32-equivalent on the
+// Kernels: igemm_x6_kernel / igemm_x6b_kernel<BN, DIL2, BMT> (forward, backward-data, transposed convolution: one gather per tap),
+// igemm_x6p_kernel (3 x 3 stride-1 layers and the parity classes of 4 x 4 stride-2 transposed ones: the input patch of a chunk is
+// staged ONCE for all taps; bit-identical to the gather kernels), igemm_wrw_x6_kernel (backward-weights: both operands are
+// activations and are split on the fly; LDS transposes with ds_read_b64_tr_b16), igemm_wrw_x6p_kernel (the same for 3 x 3 stride-1
+// layers from a ring of input rows with halo, all nine taps per workgroup), x6_split_weights(_multi)_kernel.  MI355X, B = 32 ResNet-18 two-stage step: 175-200 TFLOP/s fp32-equivalent on the
 // 64x64-map layers against 120-134 for the fp32 MFMA kernels of conv.hip (whose peak is 157.3); 28.0 -> 21.1 ms per step.
 #include "common.h"
 
