@@ -11,6 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdsf_hip.so")
+ERR_UNSUPPORTED = 2         # DSF_ERR_UNSUPPORTED (include/dsf_hip.h): the launcher declined the shape / mode, nothing was launched
 EXPECTED_ABI = 2            # dsf_abi_version() of the library these bindings were written for (csrc/api.hip)
 
 c_float_p = ctypes.c_void_p
@@ -56,7 +57,7 @@ SYMBOLS = [
     "dsf_depth_augment_crop", "dsf_conv_x6_bn_stats_rows", "dsf_conv_x6_forward_bn", "dsf_conv_x6_forward_affine", "dsf_bn_forward_from_stats",
     "dsf_instnorm_forward", "dsf_reflect_pad_nhwc", "dsf_bn_local_sums", "dsf_bn_forward_from_sums", "dsf_bn_backward_sums", "dsf_bn_backward_apply",
     "dsf_bn_acc_rows", "dsf_conv_x6_forward_splits", "dsf_conv_x6_forward_into", "dsf_conv_x6_forward_bn_acc", "dsf_bn_forward_acc", "dsf_bn_backward_acc",
-    "dsf_conv_x6_forward_plan", "dsf_conv_co1_forward",
+    "dsf_conv_x6_forward_plan", "dsf_conv_co1_forward", "dsf_conv_x6_wrw_bias",
 ]
 
 

@@ -302,8 +302,10 @@ def _wrw_c1(x, gy, K, stride, pad):
     return dw
 
 
-def _wrw(x, gy, KH, KW, stride, pad, out=None):
-    """-> dW [KH][KW][Ci][Co] for x (B,Ci,Hi,Wi), gy (B,Co,Ho,Wo), both channels_last; ``out``: add into this dW instead."""
+def _wrw(x, gy, KH, KW, stride, pad, out=None, dbias=None):
+    """-> dW [KH][KW][Ci][Co] for x (B,Ci,Hi,Wi), gy (B,Co,Ho,Wo), both channels_last; ``out``: add into this dW instead.
+    ``dbias``: a one-element list holding None -- when the split kernels run the launch (not in deterministic mode) it receives the
+    bias gradient (Co floats from the zeroed gradient pool or a fresh zero vector), computed by the same launch."""
     B, Ci, Hi, Wi = x.shape
     _, Co, Ho, Wo = gy.shape
     if RECORD is not None:
@@ -315,6 +317,19 @@ def _wrw(x, gy, KH, KW, stride, pad, out=None):
     if _wrw_x6_ok(Ci, Co, x.numel(), gy.numel()):
         nws = int(L.lib().dsf_conv_x6_wrw_workspace_bytes(I(B), I(Ho), I(Wo), I(Ci), I(Co), I(KH), I(KW)))    # > 0: deterministic mode
         ws = torch.empty(nws // 4, device=x.device, dtype=torch.float32) if nws else None
+        if dbias is not None and not nws:
+            save = _POOL[1] if _POOL is not None else None
+            db = _pool_take(Co, x.device)
+            db = db if db is not None else torch.zeros(Co, device=x.device, dtype=torch.float32)
+            rc = L.lib().dsf_conv_x6_wrw_bias(ptr_nhwc(x), ptr_nhwc(gy), ptr(dw), ptr(db), I(B), I(Hi), I(Wi), I(Ci), I(Ho), I(Wo), I(Co),
+                                              I(KH), I(KW), I(stride), I(pad[0]), I(pad[1]), I(1 if pooled else 0), stream_ptr())
+            if rc == 0:
+                dbias[0] = db
+                return dw
+            if rc != L.ERR_UNSUPPORTED:
+                check(rc, "dsf_conv_x6_wrw_bias")
+            if save is not None:                        # declined (a layer with many pixel splits): nothing was launched
+                _POOL[1] = save
         check(L.lib().dsf_conv_x6_wrw_ws(ptr_nhwc(x), ptr_nhwc(gy), ptr(dw), I(B), I(Hi), I(Wi), I(Ci), I(Ho), I(Wo), I(Co), I(KH),
                                          I(KW), I(stride), I(pad[0]), I(pad[1]), I(1 if pooled else 0), ptr(ws), stream_ptr()),
               "dsf_conv_x6_wrw_ws")
@@ -361,7 +376,8 @@ def _pool_take(n, device):
 
 def weight_grad_floats(module):
     """pool size for one backward pass over ``module``: the weights of its dsf_amd convolution layers"""
-    return sum(((m.weight.numel() + 3) & ~3) for m in module.modules() if isinstance(m, (Conv2d, ConvTranspose2d)))
+    return sum(((m.weight.numel() + 3) & ~3) + (((m.bias.numel() + 3) & ~3) if m.bias is not None else 0)      # (+ bias gradients: _wrw)
+               for m in module.modules() if isinstance(m, (Conv2d, ConvTranspose2d)))
 
 
 def _bias_grad(gy):
@@ -496,11 +512,19 @@ class Conv2dFunction(Function):
             if _c1_ok(Ci, Co, KH, KW, stride, padding):  # (the stem kernel overwrites its output: never a shared dW)
                 dw = _wrw_dispatch(weight, lambda: _wrw_c1(x, gy, KH, stride, padding[0]), None, (x, gy))
             else:
-                dw = _wrw_dispatch(weight, lambda: _wrw(x, gy, KH, KW, stride, padding),
+                # the bias gradient rides in the weight-gradient launch when that launch runs on THIS stream (small layers and
+                # everything under DSF_WRW_STREAM=0): on the side stream nothing orders the bias's AccumulateGrad behind it
+                on = BIAS_IN_WRW[0] if BIAS_IN_WRW[0] is not None else os.environ.get("DSF_BIAS_IN_WRW", "1") == "1"
+                want_db = has_bias and ctx.needs_input_grad[2] and on
+                main = torch.cuda.current_stream() if want_db else None
+                cell = [None]
+                dw = _wrw_dispatch(weight, lambda: _wrw(x, gy, KH, KW, stride, padding,
+                                                        dbias=cell if (want_db and torch.cuda.current_stream() == main) else None),
                                    lambda acc: _wrw(x, gy, KH, KW, stride, padding, out=acc), (x, gy),
                                    work=2.0 * gy.numel() * Ci * KH * KW)
+                gb = cell[0]
             gw = None if dw is False else dw.permute(3, 2, 0, 1)
-        if has_bias and ctx.needs_input_grad[2]:
+        if has_bias and ctx.needs_input_grad[2] and gb is None:
             gb = _bias_grad(gy)
         return gx, gw, gb, None, None
 
@@ -542,6 +566,7 @@ def _side_api_ok():
 SIDE_API = _side_api_ok()
 WRW_STREAM = [os.environ.get("DSF_WRW_STREAM", "1") == "1" and SIDE_API]
 WRW_MIN_WORK = [float(os.environ.get("DSF_WRW_MIN_GFLOP", "8")) * 1e9]   # below: the layer's dW stays on the chain's stream
+BIAS_IN_WRW = [None]     # bias gradient from the weight-gradient launch (dsf_conv_x6_wrw_bias): None = DSF_BIAS_IN_WRW (default on), read per call
 WRW_PRIORITY = int(os.environ.get("DSF_WRW_PRIORITY", "0"))          # priority of the side stream (lower number = higher priority)
 _SIDE = {}
 _JOIN_QUEUED = [-1]

@@ -411,6 +411,14 @@ int64_t dsf_mfma_bf16_probe(const void* operands, float* out, int workgroups, in
  * splits that meet in dW by float atomics. */
 int dsf_conv_x6_wrw(const float* X, const float* dY, float* dW, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
                     int KW, int stride, int pad_h, int pad_w, int accumulate, dsf_stream_t stream);
+/* dsf_conv_x6_wrw that also returns the bias gradient from the same launch: dbias[co] += sum over all pixels of dY[.][co] (the
+ * workgroups that stage a dY tile for the first K tile add its column sums; float atomics, so dbias must be zeroed -- or hold
+ * what it accumulates into -- like dW under accumulate != 0).  Replaces the separate column-sum launches behind every biased
+ * convolution (dsf_col_sum: 2-3 launches).  DSF_ERR_UNSUPPORTED -- nothing launched: use dsf_conv_x6_wrw_ws + dsf_col_sum -- in
+ * deterministic mode and for layers whose pixels are cut into more than 64 splits (their atomics on the same Co addresses would
+ * queue up).  Additive in round 5 (the ABI version stays 2). */
+int dsf_conv_x6_wrw_bias(const float* X, const float* dY, float* dW, float* dbias, int B, int Hi, int Wi, int Ci, int Ho, int Wo,
+                         int Co, int KH, int KW, int stride, int pad_h, int pad_w, int accumulate, dsf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Fused training-mode BatchNorm2d (+ residual add) (+ ReLU) on NHWC activations, x viewed as (M, C).

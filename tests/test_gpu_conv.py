@@ -438,6 +438,47 @@ def test_one_output_channel_convolution_matches_float64(Ci, K, p, H, W, B, bias)
     assert _rel(gx.double().cpu(), gxd) < 3e-6 and _rel(gw.double().cpu(), gwd) < 3e-6
 
 
+@pytest.mark.parametrize("Ci,Co,K,s,p,H,W,B,rows", [
+    (36, 132, 3, 1, 1, 8, 64, 2, "2"),        # row-staged kernel (forced), 128-wide tiles: two n tiles, ragged
+    (64, 60, 3, 1, 1, 6, 32, 3, "2"),         # row-staged kernel, <= 64 output channels (two tap groups stage the same dY)
+    (128, 128, 3, 1, 1, 4, 4, 64, "1"),       # old kernel: hourglass-sized maps
+    (256, 128, 1, 1, 0, 8, 8, 64, "1"),       # 1 x 1
+    (40, 72, 3, 2, 1, 9, 11, 5, "1"),         # stride 2, ragged everything
+    (16, 20, 5, 1, 2, 7, 7, 3, "1"),
+])
+def test_bias_gradient_from_the_weight_gradient_launch(Ci, Co, K, s, p, H, W, B, rows, monkeypatch):
+    """dsf_conv_x6_wrw_bias: the workgroups that stage a dY tile for the first K tile (or channel block) add its column sums into
+    dbias -- the bias gradient without the separate column-sum launches.  Through Conv2dFunction's backward (the launch runs on the
+    calling stream for layers below the side-stream threshold): no col_sum launch is recorded, db equals the float64 sum, dW is
+    what the plain launch gives; with the gradient pool the vectors come out of the pooled zeros."""
+    from dsf_amd import nn_conv, _lib as L
+    if nn_conv.MATH != "x6" or L.deterministic():
+        pytest.skip("split kernels in float-atomic mode only")
+    monkeypatch.setenv("DSF_X6_WRW_PATCH", rows)
+    monkeypatch.setattr(nn_conv, "WRW_MIN_WORK", [1e30])              # every layer's dW on the calling stream
+    g = torch.Generator().manual_seed(Ci + Co + K)
+    x = torch.randn(B, Ci, H, W, generator=g).cuda().requires_grad_(True)
+    w = (torch.randn(Co, Ci, K, K, generator=g) / (Ci * K * K) ** 0.5).cuda().requires_grad_(True)
+    b = torch.randn(Co, generator=g).cuda().requires_grad_(True)
+    out = {}
+    for fused in (True, False):
+        monkeypatch.setattr(nn_conv, "BIAS_IN_WRW", [fused])
+        for pooled in (False, True):
+            y = nn_conv.Conv2dFunction.apply(x, w, b, s, (p, p))
+            gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(1)).cuda()
+            if pooled:
+                with nn_conv.grad_pool(w.numel() + Co + 16, x.device):
+                    gw, gb = torch.autograd.grad((y * gy).sum(), [w, b])
+                    gw, gb = gw.clone(), gb.clone()
+            else:
+                gw, gb = torch.autograd.grad((y * gy).sum(), [w, b])
+            out[(fused, pooled)] = (gw, gb)
+    ref_b = gy.double().sum((0, 2, 3))
+    for key, (gw, gb) in out.items():
+        assert _rel(gb.double(), ref_b) < 3e-6, (key, _rel(gb.double(), ref_b))
+        assert _rel(gw.double(), out[(False, False)][0].double()) < 3e-6, key
+
+
 def test_x6_weight_images_follow_the_weights(monkeypatch):
     """The split image of a weight is kept from one use to the next only for MANAGED parameters (FusedAdamW's, EvalStep's):
     in-place torch updates (version counter) and FusedAdamW's raw-pointer updates (nn_conv.weights_changed) both invalidate
