@@ -346,7 +346,7 @@ _POOL = None         # [flat zeroed tensor, next offset]
 class grad_pool:
     """``with grad_pool(n_floats, device):`` around a backward pass: the backward-weights kernels (which accumulate their
     pixel splits with float atomics and therefore need zeroed outputs) take their outputs from ONE pre-zeroed buffer,
-    16-byte aligned slices handed out in call order, instead of zeroing ~50 separate tensors.  The slices stay valid as
+    256-byte aligned slices handed out in call order, instead of zeroing ~50 separate tensors.  The slices stay valid as
     long as the gradients that view them live; a pool that runs out falls back to per-layer buffers."""
 
     def __init__(self, n_floats, device):
@@ -367,7 +367,8 @@ def _pool_take(n, device):
     if _POOL is None or _POOL[0].device != device:
         return None
     off = _POOL[1]
-    end = off + ((n + 3) & ~3)
+    a = int(os.environ.get("DSF_POOL_ALIGN", "64")) - 1  # (tuning aid, floats) 256-byte slices: a 32-lane row of float atomics never straddles a cache line
+    end = off + ((n + a) & ~a)
     if end > _POOL[0].numel():
         return None
     _POOL[1] = end
@@ -376,7 +377,7 @@ def _pool_take(n, device):
 
 def weight_grad_floats(module):
     """pool size for one backward pass over ``module``: the weights of its dsf_amd convolution layers"""
-    return sum(((m.weight.numel() + 3) & ~3) + (((m.bias.numel() + 3) & ~3) if m.bias is not None else 0)      # (+ bias gradients: _wrw)
+    return sum(((m.weight.numel() + 63) & ~63) + (((m.bias.numel() + 63) & ~63) if m.bias is not None else 0)      # (+ bias gradients: _wrw)
                for m in module.modules() if isinstance(m, (Conv2d, ConvTranspose2d)))
 
 

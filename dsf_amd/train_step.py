@@ -145,7 +145,7 @@ class RenderSupervisedStep:
         self.opt.zero_grad(set_to_none=True)
         self.render.mano_layer.clear_cache()                 # results of the previous step must not outlive its graph
         if not hasattr(self, "_pool_floats"):
-            self._pool_floats = nn_conv.weight_grad_floats(self.net) + 64          # fused heads re-lay one merged weight
+            self._pool_floats = nn_conv.weight_grad_floats(self.net) + 256          # fused heads re-lay one merged weight
             self._pool_dev = next(self.net.parameters()).device
         with _stat_pool(self, self.net):
             loss, terms = self.loss(tgt)
@@ -224,7 +224,7 @@ class MeshLossStep:
         self.opt.zero_grad(set_to_none=True)
         self.render.mano_layer.clear_cache()                 # results of the previous step must not outlive its graph
         if not hasattr(self, "_pool_floats"):                # one zero fill per step for the ~90 weight gradients of the
-            self._pool_floats = nn_conv.weight_grad_floats(self.net) + 64          # hourglass instead of one launch each
+            self._pool_floats = nn_conv.weight_grad_floats(self.net) + 256          # hourglass instead of one launch each
             self._pool_dev = next(self.net.parameters()).device
         with _stat_pool(self, self.net):
             loss, terms = self.loss(tgt)
@@ -521,7 +521,7 @@ class _StepBase:
     def _optimise(self, loss):
         from . import nn_conv
         if not hasattr(self, "_pool_floats"):
-            self._pool_floats = nn_conv.weight_grad_floats(self.net) + 64
+            self._pool_floats = nn_conv.weight_grad_floats(self.net) + 256
             self._pool_dev = next(self.net.parameters()).device
         with nn_conv.grad_pool(self._pool_floats if self._pool_dev.type == "cuda" else 0, self._pool_dev):
             loss.backward()
