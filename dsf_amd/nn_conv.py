@@ -242,7 +242,7 @@ class zero_pool:
 
 
 def _zero_take(n, device):
-    n = (n + 3) & ~3
+    n = (n + 63) & ~63                                    # 256-byte slices: rows of float atomics stay inside their cache lines
     _ZERO[2] += n
     buf, off = _ZERO[0], _ZERO[1]
     if buf is None or buf.device != device or off + n > buf.numel():
