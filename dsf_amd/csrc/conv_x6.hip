@@ -925,14 +925,16 @@ __device__ __forceinline__ int x6_tr_off(int row, int ch) { return 256 * row + 1
 // cost").  Measured B = 32: 488->256 at 64x64 1627 -> 1513 us (181 -> 195 TFLOP/s), 256->256 k4 s2 404 -> 366, the 8x8 .. 32x32
 // maps 71-77 -> 66-72 us (profiles/r03_wrw_variants_ab.txt).  The forward-type kernels keep the piece placement: their loaders
 // are lighter (2.6 VALU per gap) and the pipeline hoists their eight loads in front of the first MFMA (197 -> 186 TFLOP/s).
-template <int BN>
+template <int BN, bool BIAS = false>
 __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __restrict__ X, const float* __restrict__ dY,
                                                              float* __restrict__ dW, X6P p, int k_tiles, int n_tiles,
                                                              int n_splits, int m_per_split, uint64_t magic_wo,
                                                              uint64_t magic_ho, uint32_t x_bytes, uint32_t dy_bytes,
                                                              float* __restrict__ partial, float* __restrict__ dbias) {
-    // dbias != nullptr: the workgroups of k tile 0 also add the column sums of their dY tiles into dbias (the bias gradient:
-    // every dY element passes through exactly one of them per n tile) -- float atomics into a zeroed (or accumulating) vector
+    // BIAS: the workgroups of k tile 0 also add the column sums of their dY tiles into dbias (the bias gradient: every dY element
+    // passes through exactly one of them per n tile) -- float atomics into a zeroed (or accumulating) vector.  A template
+    // parameter, not a run-time test: a branch inside the chunk body would cut the basic block the sched_group_barrier pipeline
+    // below interleaves (measured: every backward-weights launch 10 % slower, 144 -> 129 TFLOP/s on the dominant kernel)
     // partial != nullptr (deterministic mode): every pixel split stores its tile to partial[split][K][Co] (plain stores,
     // one writer per element); x6_wrw_reduce_kernel adds the splits in order.  Else: float atomics into dW.
     // BN = 128: 2 x 2 waves of 64 (k rows) x 64 (channels);  BN = 64 (layers with <= 64 output channels): 4 x 1 waves of
@@ -994,15 +996,16 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
     };
     const int st_off0 = x6_tr_off(l_p, l_q >> 1) + 8 * (l_q & 1), st_off1 = x6_tr_off(l_p + 8, l_q >> 1) + 8 * (l_q & 1);
     const int st_offb0 = x6_tr_off(b_p, b_q >> 1) + 8 * (b_q & 1), st_offb1 = x6_tr_off((b_p + 8) & 15, b_q >> 1) + 8 * (b_q & 1);
-    const bool do_bias = dbias != nullptr && k_tile == 0;
+    const float bias_on = (BIAS && k_tile == 0) ? 1.f : 0.f;            // (a factor, not a branch: see above)
     float bsum0 = 0.f, bsum1 = 0.f, bsum2 = 0.f, bsum3 = 0.f;
     auto stage_piece = [&](auto SET, int buf, int j) {
         constexpr int S = decltype(SET)::value;
         uint2 h, m, l;
         split4(rl[S][j], h, m, l);
-        if (j >= 2 && do_bias) {                         // (rows past m_end were loaded as zeros; scalar adds: no packed FP32)
+        if (BIAS && j >= 2) {                            // (compile-time; rows past m_end were loaded as zeros; scalar FMAs: no packed FP32)
             const f32x4 v = __builtin_bit_cast(f32x4, rl[S][j]);
-            bsum0 += v[0]; bsum1 += v[1]; bsum2 += v[2]; bsum3 += v[3];
+            bsum0 = fmaf(v[0], bias_on, bsum0); bsum1 = fmaf(v[1], bias_on, bsum1);
+            bsum2 = fmaf(v[2], bias_on, bsum2); bsum3 = fmaf(v[3], bias_on, bsum3);
         }
         char* base = (j < 2) ? As[buf] + (j ? st_off1 : st_off0) : Bs[buf] + ((j - 2) ? st_offb1 : st_offb0);
         *reinterpret_cast<uint2*>(base) = h;
@@ -1101,7 +1104,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
                 else atomicAdd(dW + (int64_t)k * p.Co + n, acc[i][j][r]);
             }
         }
-    if (do_bias) {                                       // (workgroup-uniform) fold the pixel lanes through LDS, one atomic per channel
+    if (BIAS && k_tile == 0) {                           // (workgroup-uniform) fold the pixel lanes through LDS, one atomic per channel
         float* s_red = reinterpret_cast<float*>(As[0]);  // [pixel lane][BN]: the last chunk's barrier has passed, the tiles are dead
         constexpr int LANES = (BN == 128) ? 8 : 16;
         __syncthreads();
@@ -1144,8 +1147,7 @@ template <int W, int BN = 128>
 __global__ __launch_bounds__(256, 2) void igemm_wrw_x6p_kernel(const float* __restrict__ X, const float* __restrict__ dY,
                                                               float* __restrict__ dW, X6P p, int c_tiles, int n_tiles, int n_splits,
                                                               int rows_per_split, uint32_t x_bytes, uint32_t dy_bytes,
-                                                              float* __restrict__ partial, float* __restrict__ dbias) {
-    // (dbias: as in igemm_wrw_x6_kernel -- the workgroups of channel block 0 add the column sums of their dY tiles)
+                                                              float* __restrict__ partial) {
     using PT = X6WrwPatch<W>;
     constexpr int CPR = PT::CPR, NXP = PT::NXP, U = CPR > 2 ? CPR : 2;   // chunks per trip of the main loop
     // BN 128: wave w = output channels 32 w .., all nine taps.  BN 64 (layers with <= 64 output channels): two channel blocks x two
@@ -1206,16 +1208,10 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6p_kernel(const float* __re
         rl[S][j] = x6_load16(ybuf, ok ? (uint32_t)(m * p.Co + b_n) * 4u : X_OOB);
     };
     const int st_offb0 = x6_tr_off(b_p, b_q >> 1) + 8 * (b_q & 1), st_offb1 = x6_tr_off(b_p + 8, b_q >> 1) + 8 * (b_q & 1);
-    const bool do_bias = dbias != nullptr && cb == 0;
-    float bsum0 = 0.f, bsum1 = 0.f, bsum2 = 0.f, bsum3 = 0.f;
     auto stage_y = [&](auto SET, int buf, int j) {
         constexpr int S = decltype(SET)::value;
         uint2 h, m, l;
         split4(rl[S][j], h, m, l);
-        if (do_bias) {                                   // (scalar adds: no packed FP32 in this library)
-            const f32x4 v = __builtin_bit_cast(f32x4, rl[S][j]);
-            bsum0 += v[0]; bsum1 += v[1]; bsum2 += v[2]; bsum3 += v[3];
-        }
         char* base = wrw_lds + PT::BS + buf * 3 * PT::B_PLANE + (j ? st_offb1 : st_offb0);
         *reinterpret_cast<uint2*>(base) = h;
         *reinterpret_cast<uint2*>(base + PT::B_PLANE) = m;
@@ -1350,20 +1346,6 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6p_kernel(const float* __re
                 if (partial) partial[((int64_t)split * K + k) * p.Co + n] = acc[tt][r];
                 else atomicAdd(dW + (int64_t)k * p.Co + n, acc[tt][r]);
             }
-        }
-    }
-    if (do_bias) {                                       // (workgroup-uniform) fold the pixel lanes through LDS, one atomic per channel
-        float* s_red = reinterpret_cast<float*>(wrw_lds);   // [pixel lane][BN] over the ring: every chunk's barrier has passed
-        constexpr int LANES = (BN == 128) ? 8 : 16;
-        __syncthreads();
-        s_red[b_p * BN + b_q * 4 + 0] = bsum0; s_red[b_p * BN + b_q * 4 + 1] = bsum1;
-        s_red[b_p * BN + b_q * 4 + 2] = bsum2; s_red[b_p * BN + b_q * 4 + 3] = bsum3;
-        __syncthreads();
-        if (t < BN && n0 + t < p.Co) {
-            float tot = 0.f;
-#pragma unroll
-            for (int q = 0; q < LANES; ++q) tot += s_red[q * BN + t];
-            atomicAdd(dbias + n0 + t, tot);
         }
     }
 }
@@ -1788,7 +1770,7 @@ static int x6_wrw_impl(const float* X, const float* dY, float* dW, float* dbias,
         if (attr != hipSuccess) return DSF_ERR_LAUNCH;                                                                            \
         hipLaunchKernelGGL((igemm_wrw_x6p_kernel<Wv, BNv>), dim3(c_tiles * pn_tiles * psplits), dim3(256), PT::LDS_BYTES,        \
                            (hipStream_t)stream, X, dY, dW, p, c_tiles, pn_tiles, psplits, rows, (uint32_t)x_bytes,               \
-                           (uint32_t)dy_bytes, partial, dbias);                                                                   \
+                           (uint32_t)dy_bytes, partial);                                                                          \
     } while (0)
         if (bn == 128) { if (Wi == 64) DSF_LAUNCH_WRWP(64, 128); else if (Wi == 32) DSF_LAUNCH_WRWP(32, 128); else DSF_LAUNCH_WRWP(16, 128); }
         else { if (Wi == 64) DSF_LAUNCH_WRWP(64, 64); else if (Wi == 32) DSF_LAUNCH_WRWP(32, 64); else DSF_LAUNCH_WRWP(16, 64); }
@@ -1803,12 +1785,12 @@ static int x6_wrw_impl(const float* X, const float* dY, float* dW, float* dbias,
     int k_tiles, n_tiles; int64_t per;
     const int splits = x6_wrw_plan(B, Ho, Wo, Ci, Co, KH, KW, k_tiles, n_tiles, per);
     const uint64_t mwo = ((1ull << 40) + Wo - 1) / Wo, mho = ((1ull << 40) + Ho - 1) / Ho;
-    if (bn == 128)
-        hipLaunchKernelGGL(igemm_wrw_x6_kernel<128>, dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream, X, dY,
-                           dW, p, k_tiles, n_tiles, splits, (int)per, mwo, mho, (uint32_t)x_bytes, (uint32_t)dy_bytes, partial, dbias);
-    else
-        hipLaunchKernelGGL(igemm_wrw_x6_kernel<64>, dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream, X, dY,
-                           dW, p, k_tiles, n_tiles, splits, (int)per, mwo, mho, (uint32_t)x_bytes, (uint32_t)dy_bytes, partial, dbias);
+#define DSF_LAUNCH_WRW(BNv, BIASv)                                                                                                \
+    hipLaunchKernelGGL((igemm_wrw_x6_kernel<BNv, BIASv>), dim3(k_tiles * n_tiles * splits), dim3(256), 0, (hipStream_t)stream, X, dY, \
+                       dW, p, k_tiles, n_tiles, splits, (int)per, mwo, mho, (uint32_t)x_bytes, (uint32_t)dy_bytes, partial, dbias)
+    if (bn == 128) { if (dbias) DSF_LAUNCH_WRW(128, true); else DSF_LAUNCH_WRW(128, false); }
+    else { if (dbias) DSF_LAUNCH_WRW(64, true); else DSF_LAUNCH_WRW(64, false); }
+#undef DSF_LAUNCH_WRW
     if (det) {
         const int64_t n = (int64_t)K * Co;
         hipLaunchKernelGGL(x6_wrw_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial, dW,
@@ -1831,10 +1813,11 @@ int dsf_conv_x6_wrw_bias(const float* X, const float* dY, float* dW, float* dbia
     if (dsf_deterministic()) return DSF_ERR_UNSUPPORTED;
     {   // every pixel split adds its column sums into the same Co addresses: with hundreds of splits (the 64x64-map layers: 256) the
         // atomics queue up behind each other (+250 us on the 256 -> 84 head, measured) -- those layers keep dsf_col_sum
-        int k_tiles, n_tiles, c_tiles, rows; int64_t per;
-        const int splits = x6_wrw_patch_applies(B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad_h, pad_w)
-                               ? x6_wrw_patch_plan(B, Hi, Wi, Ci, Co, c_tiles, n_tiles, rows)
-                               : x6_wrw_plan(B, Ho, Wo, Ci, Co, KH, KW, k_tiles, n_tiles, per);
+        // (the layers of the row-staged kernel are large ones: a column-sum pass is noise beside them, and its nine accumulators
+        //  leave no registers for the sums)
+        if (x6_wrw_patch_applies(B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pad_h, pad_w)) return DSF_ERR_UNSUPPORTED;
+        int k_tiles, n_tiles; int64_t per;
+        const int splits = x6_wrw_plan(B, Ho, Wo, Ci, Co, KH, KW, k_tiles, n_tiles, per);
         const char* ms_e = getenv("DSF_WRW_BIAS_MAX_SPLITS");            // tuning aid
         if (splits > (ms_e ? atoi(ms_e) : 64)) return DSF_ERR_UNSUPPORTED;
     }

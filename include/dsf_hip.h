@@ -415,8 +415,8 @@ int dsf_conv_x6_wrw(const float* X, const float* dY, float* dW, int B, int Hi, i
  * workgroups that stage a dY tile for the first K tile add its column sums; float atomics, so dbias must be zeroed -- or hold
  * what it accumulates into -- like dW under accumulate != 0).  Replaces the separate column-sum launches behind every biased
  * convolution (dsf_col_sum: 2-3 launches).  DSF_ERR_UNSUPPORTED -- nothing launched: use dsf_conv_x6_wrw_ws + dsf_col_sum -- in
- * deterministic mode and for layers whose pixels are cut into more than 64 splits (their atomics on the same Co addresses would
- * queue up).  Additive in round 5 (the ABI version stays 2). */
+ * deterministic mode, for layers whose pixels are cut into more than 64 splits (more adders per address bring nothing) and for the
+ * large 3 x 3 layers that take the row-staged kernel.  Additive in round 5 (the ABI version stays 2). */
 int dsf_conv_x6_wrw_bias(const float* X, const float* dY, float* dW, float* dbias, int B, int Hi, int Wi, int Ci, int Ho, int Wo,
                          int Co, int KH, int KW, int stride, int pad_h, int pad_w, int accumulate, dsf_stream_t stream);
 
