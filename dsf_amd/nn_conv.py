@@ -907,7 +907,7 @@ def kernel_name(rec):
             rows += rows & 1 if Wi == 16 else 0
             if level >= 2 or rows * Wi >= 1024:
                 return "igemm_wrw_x6p_kernel<%d, %d>" % (Wi, 128 if Co > 64 else 64)
-        return "igemm_wrw_x6_kernel<%d>" % (128 if Co > 64 else 64)
+        return "igemm_wrw_x6_kernel<%d, false>" % (128 if Co > 64 else 64)      # (<.., true>: with the bias sums, dsf_conv_x6_wrw_bias)
     if vec:
         return "igemm_wrw_fast_kernel<%d, %d>" % (bn, 16 if M >= 32768 else 32)
     return "igemm_wrw_kernel<%d>" % bn
