@@ -97,7 +97,15 @@ def deterministic():
     return bool(lib().dsf_get_deterministic())
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_GET_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream_ptr():
+    """The current HIP stream of the current device as a launcher argument.  Through torch's raw-stream accessor where it exists:
+    torch.cuda.current_stream() builds a Stream object (~9 us; ~280 launches per step call this)"""
+    if _RAW_STREAM is not None and _GET_DEVICE is not None:
+        return ctypes.c_void_p(_RAW_STREAM(_GET_DEVICE()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
