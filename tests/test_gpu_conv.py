@@ -447,10 +447,11 @@ def test_one_output_channel_convolution_matches_float64(Ci, K, p, H, W, B, bias)
     (16, 20, 5, 1, 2, 7, 7, 3, "1"),
 ])
 def test_bias_gradient_from_the_weight_gradient_launch(Ci, Co, K, s, p, H, W, B, rows, monkeypatch):
-    """dsf_conv_x6_wrw_bias: the workgroups that stage a dY tile for the first K tile (or channel block) add its column sums into
-    dbias -- the bias gradient without the separate column-sum launches.  Through Conv2dFunction's backward (the launch runs on the
-    calling stream for layers below the side-stream threshold): no col_sum launch is recorded, db equals the float64 sum, dW is
-    what the plain launch gives; with the gradient pool the vectors come out of the pooled zeros."""
+    """dsf_conv_x6_wrw_bias: the workgroups that stage a dY tile for the first K tile add its column sums into dbias -- the bias
+    gradient without the separate column-sum launches.  Through Conv2dFunction's backward (the launch runs on the calling stream
+    for layers below the side-stream threshold): the column-sum path is NOT taken where the launcher accepts the layer (the old
+    kernel, <= 64 pixel splits) and IS taken where it declines (the row-staged kernel's layers); either way db equals the
+    float64 sum and dW is what the plain launch gives; with the gradient pool the vectors come out of the pooled zeros."""
     from dsf_amd import nn_conv, _lib as L
     if nn_conv.MATH != "x6" or L.deterministic():
         pytest.skip("split kernels in float-atomic mode only")
@@ -461,9 +462,13 @@ def test_bias_gradient_from_the_weight_gradient_launch(Ci, Co, K, s, p, H, W, B,
     w = (torch.randn(Co, Ci, K, K, generator=g) / (Ci * K * K) ** 0.5).cuda().requires_grad_(True)
     b = torch.randn(Co, generator=g).cuda().requires_grad_(True)
     out = {}
+    calls = []
+    plain_bias_grad = nn_conv._bias_grad
+    monkeypatch.setattr(nn_conv, "_bias_grad", lambda gy_: (calls.append(1), plain_bias_grad(gy_))[1])
     for fused in (True, False):
         monkeypatch.setattr(nn_conv, "BIAS_IN_WRW", [fused])
         for pooled in (False, True):
+            del calls[:]
             y = nn_conv.Conv2dFunction.apply(x, w, b, s, (p, p))
             gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(1)).cuda()
             if pooled:
@@ -472,6 +477,7 @@ def test_bias_gradient_from_the_weight_gradient_launch(Ci, Co, K, s, p, H, W, B,
                     gw, gb = gw.clone(), gb.clone()
             else:
                 gw, gb = torch.autograd.grad((y * gy).sum(), [w, b])
+            assert len(calls) == (0 if (fused and rows == "1") else 1), (fused, pooled, rows, len(calls))
             out[(fused, pooled)] = (gw, gb)
     ref_b = gy.double().sum((0, 2, 3))
     for key, (gw, gb) in out.items():
