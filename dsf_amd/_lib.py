@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdsf_hip.so")
 ERR_UNSUPPORTED = 2         # DSF_ERR_UNSUPPORTED (include/dsf_hip.h): the launcher declined the shape / mode, nothing was launched
-EXPECTED_ABI = 2            # dsf_abi_version() of the library these bindings were written for (csrc/api.hip)
+EXPECTED_ABI = 3            # dsf_abi_version() of the library these bindings were written for (csrc/api.hip)
 
 c_float_p = ctypes.c_void_p
 _lib = None
@@ -57,7 +57,7 @@ SYMBOLS = [
     "dsf_depth_augment_crop", "dsf_conv_x6_bn_stats_rows", "dsf_conv_x6_forward_bn", "dsf_conv_x6_forward_affine", "dsf_bn_forward_from_stats",
     "dsf_instnorm_forward", "dsf_reflect_pad_nhwc", "dsf_bn_local_sums", "dsf_bn_forward_from_sums", "dsf_bn_backward_sums", "dsf_bn_backward_apply",
     "dsf_bn_acc_rows", "dsf_conv_x6_forward_splits", "dsf_conv_x6_forward_into", "dsf_conv_x6_forward_bn_acc", "dsf_bn_forward_acc", "dsf_bn_backward_acc",
-    "dsf_conv_x6_forward_plan", "dsf_conv_co1_forward", "dsf_conv_x6_wrw_bias",
+    "dsf_conv_x6_forward_plan", "dsf_conv_co1_forward", "dsf_conv_x6_wrw_bias", "dsf_bn_backward_pair", "dsf_bn_backward_acc_pair",
 ]
 
 
@@ -70,10 +70,17 @@ def lib():
                 "libdsf_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(dsf_amd has no CPU fallback)" % LIB_PATH)
         cand = ctypes.CDLL(LIB_PATH)
-        cand.dsf_abi_version.restype = ctypes.c_int
-        if cand.dsf_abi_version() != EXPECTED_ABI:                  # a stale build: argument lists differ, pointers would shift
-            raise MissingNativeLibrary("%s has ABI version %d, this package needs %d -- rebuild it with "
-                                       "`python -c 'import __graft_entry__ as g; g.build()'`" % (LIB_PATH, cand.dsf_abi_version(), EXPECTED_ABI))
+        rebuild = "rebuild it with `python -c 'import __graft_entry__ as g; g.build()'`"
+        try:
+            cand.dsf_abi_version.restype = ctypes.c_int
+            found = cand.dsf_abi_version()
+        except AttributeError:                                      # a library older than the version export
+            raise MissingNativeLibrary("%s exports no dsf_abi_version -- %s" % (LIB_PATH, rebuild)) from None
+        if found != EXPECTED_ABI:                                   # a stale build: argument lists differ, pointers would shift
+            raise MissingNativeLibrary("%s has ABI version %d, this package needs %d -- %s" % (LIB_PATH, found, EXPECTED_ABI, rebuild))
+        missing = [s for s in SYMBOLS if not hasattr(cand, s)]
+        if missing:                                                 # same version number, fewer exports: still a stale build
+            raise MissingNativeLibrary("%s lacks %s -- %s" % (LIB_PATH, ", ".join(missing[:4]), rebuild))
         _lib = cand
         _lib.dsf_status_string.restype = ctypes.c_char_p
         _lib.dsf_conv_x6_image_bytes.restype = ctypes.c_int64
@@ -82,8 +89,6 @@ def lib():
         _lib.dsf_conv_x6_image_granules.restype = ctypes.c_int64
         _lib.dsf_part_volume_workspace_bytes.restype = ctypes.c_int64
         _lib.dsf_conv_x6_wrw_workspace_bytes.restype = ctypes.c_int64
-        for s in SYMBOLS:
-            getattr(_lib, s)
     return _lib
 
 

@@ -28,12 +28,17 @@ struct BnFinal {
     double* sums; float* dgamma; float* dbeta;
 };
 
-template <int MODE, bool YMASK = false>
+// G2: the incoming gradient is the SUM of two tensors, gy + gy2 (the fan-in of a block output that feeds the next block's first
+//     convolution and its identity path, model/resnet.py:39-55: autograd would add them with a pass of its own, 2R + 1W).
+// WG: the (summed, ReLU-masked) gradient g is also WRITTEN to gout -- it is the residual path's gradient, and the apply pass
+//     that follows then reads x and gout only (no y, no second addend, no mask), writing dx alone.
+template <int MODE, bool YMASK = false, bool G2 = false, bool WG = false>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                         const float* __restrict__ y, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int64_t M, int C, int relu,
-                                                        int rows_per_wg, float* __restrict__ part, int acc_rows) {
+                                                        int rows_per_wg, float* __restrict__ part, int acc_rows,
+                                                        const float* __restrict__ gy2 = nullptr, float* __restrict__ gout = nullptr) {
     // (with acc_rows > 0 `part` is really a double array: the accumulation rows are DOUBLES, see bn_fold_rows)
     // acc_rows == 0: workgroup w stores partial row w (bn_finalize_kernel folds them in a fixed order: deterministic).
     // acc_rows  > 0: the workgroup ADDS its partial row into row (w mod acc_rows) of a zeroed [acc_rows][2][C] block of DOUBLES
@@ -66,13 +71,14 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
             sh[k] = beta ? beta[col * 4 + k] : 0.f;
         }
     }
-    auto accumulate = [&](const float4& xv, const float4& gv, const float4& yv) {
+    auto accumulate = [&](const float4& xv, float4& gv, const float4& yv, const float4& hv) {
         const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
         if (MODE == 0) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) { a0[k] += xe[k]; a1[k] = fmaf(xe[k], xe[k], a1[k]); }
         } else {
             float ge[4] = {gv.x, gv.y, gv.z, gv.w};
+            if (G2) { ge[0] += hv.x; ge[1] += hv.y; ge[2] += hv.z; ge[3] += hv.w; }     // (the add autograd would have done: same fp32 sum)
             if (YMASK) {                     // (YMASK <=> relu == 1: the launchers pick the instantiation)
                 const float ye[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
@@ -83,6 +89,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) { a0[k] += ge[k]; a1[k] = fmaf(ge[k], (xe[k] - mu[k]) * is[k], a1[k]); }
+            if (WG) gv = make_float4(ge[0], ge[1], ge[2], ge[3]);
         }
     };
     // U rows per lane in flight (forward 8 x 16 bytes of x; backward 4 of x, of gy, and of y with a saved-output mask): with one workgroup per CU
@@ -91,7 +98,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
     constexpr int U = (MODE == 0) ? 8 : 4;      // backward: 2-3 tensors per row, and the wave has to fit beside the backward-weights kernels
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int64_t r = r0 + rl; r < r1; r += (int64_t)U * rlanes) {
-        float4 xv[U], gv[U], yv[U];
+        float4 xv[U], gv[U], yv[U], hv[G2 ? U : 1];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t rr = r + (int64_t)u * rlanes;
@@ -100,9 +107,16 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
             xv[u] = ok ? *reinterpret_cast<const float4*>(x + o) : z4;
             gv[u] = (MODE == 1 && ok) ? *reinterpret_cast<const float4*>(gy + o) : z4;
             yv[u] = (YMASK && ok) ? *reinterpret_cast<const float4*>(y + o) : z4;
+            if (G2) hv[u] = ok ? *reinterpret_cast<const float4*>(gy2 + o) : z4;
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) accumulate(xv[u], gv[u], yv[u]);
+        for (int u = 0; u < U; ++u) {
+            accumulate(xv[u], gv[u], yv[u], hv[G2 ? u : 0]);
+            if (WG) {
+                const int64_t rr = r + (int64_t)u * rlanes;
+                if (rr < r1) *reinterpret_cast<float4*>(gout + rr * C + col * 4) = gv[u];
+            }
+        }
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) { s_part[0][t * 4 + k] = a0[k]; s_part[1][t * 4 + k] = a1[k]; }
@@ -223,14 +237,38 @@ __device__ __forceinline__ void bn_share_params(int nq, float (&par)[NP][4], dou
     }
 }
 
+// ---- streaming accessors of the apply passes -----------------------------------------------------------------------------------
+// NT: non-temporal 16-byte accesses (global_load_dwordx4 ... nt): the apply passes touch every byte once.
+typedef float bn_v4f __attribute__((ext_vector_type(4)));
+template <bool NT> __device__ __forceinline__ float4 bn_ld4(const float* __restrict__ p, int64_t j) {
+    if (NT) {
+        const bn_v4f v = __builtin_nontemporal_load(reinterpret_cast<const bn_v4f*>(p) + j);
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    return reinterpret_cast<const float4*>(p)[j];
+}
+template <bool NT> __device__ __forceinline__ void bn_st4(float* __restrict__ p, int64_t j, const float4& v) {
+    if (NT) {
+        bn_v4f w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+        __builtin_nontemporal_store(w, reinterpret_cast<bn_v4f*>(p) + j);
+    } else {
+        reinterpret_cast<float4*>(p)[j] = v;
+    }
+}
+// VAR (tuning aid DSF_BN_VAR, read per call): bit 0 = non-temporal loads, bit 1 = non-temporal stores, bit 2 = the next batch of
+// loads is issued BEFORE the current one is processed and stored (two register sets)
+constexpr int BN_VAR_DEFAULT = 0;
+// DSF_BN_WRITE_G=0 (tuning aid, read per call): the sums pass does not write the masked gradient, the apply pass re-reads gy (+ gy2) and y
+static inline bool bn_write_g() { const char* e = getenv("DSF_BN_WRITE_G"); return !e || atoi(e) != 0; }
+static inline int bn_var() { const char* e = getenv("DSF_BN_VAR"); const int v = e ? atoi(e) : BN_VAR_DEFAULT; return (v < 0 || v > 7) ? BN_VAR_DEFAULT : v; }
+
 // ---- pass 2 forward: y = (x - mean) * invstd * gamma + beta (+ residual) (relu) ---------------------
 // The grid stride is a multiple of the float4 column count, so a thread's channel quad is loop-invariant.
 // FOLD: mean / invstd are not read but COMPUTED in the prologue from the accumulation rows (folded once per workgroup, see
 // above), with bn_finalize_kernel<0>'s arithmetic; the owners of the first workgroup(s) (i0 < C / 4) also store mean / invstd
 // for the backward pass and update the running statistics.
-// Four float4 of x (and of the residual) are in flight per thread, and the first batch is issued BEFORE the prologue (no register
-// double buffer: the passes share the CUs with the backward-weights kernels of the second stream, which leave ~150 VGPRs per SIMD).
-template <bool FOLD>
+// Four float4 of x (and of the residual) are in flight per thread, and the first batch is issued BEFORE the prologue.
+template <bool FOLD, int VAR>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -238,6 +276,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        const double* __restrict__ rows, int n_rows, int64_t M, BnFinal fin) {
     __shared__ double s_buf[BN_FOLD_LDS];
     constexpr int U = 4;
+    constexpr bool NTL = (VAR & 1) != 0, NTS = (VAR & 2) != 0, PF = (VAR & 4) != 0;
     const int c4n = C >> 2, nq = min(c4n, 256);
     const int64_t i0 = blockIdx.x * (int64_t)256 + threadIdx.x;
     const int64_t S = (int64_t)gridDim.x * 256;
@@ -249,17 +288,17 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         rows += (int64_t)blockIdx.y * n_rows * 2 * C;
     }
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 xv[U], rv[U];
-    auto fetch = [&](int64_t i) {
+    float4 xa[U], ra[U], xb[PF ? U : 1], rb[PF ? U : 1];
+    auto fetch = [&](int64_t i, float4* xv, float4* rv) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t j = i + u * S;
             const bool ok = j < n4;
-            xv[u] = ok ? reinterpret_cast<const float4*>(x)[j] : z4;
-            rv[u] = (res && ok) ? reinterpret_cast<const float4*>(res)[j] : z4;
+            xv[u] = ok ? bn_ld4<NTL>(x, j) : z4;
+            rv[u] = (res && ok) ? bn_ld4<NTL>(res, j) : z4;
         }
     };
-    fetch(i0);
+    fetch(i0, xa, ra);
     float par[3][4];                                           // mean, scale = invstd * gamma, shift = beta
     if (FOLD) {
         double s0[4], s1[4];
@@ -294,7 +333,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         }
     }
     if (nq < 256) bn_share_params<3>(nq, par, s_buf);
-    for (int64_t i = i0; i < n4;) {
+    auto process = [&](int64_t i, const float4* xv, const float4* rv) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t j = i + u * S;
@@ -308,47 +347,69 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 #pragma unroll
                 for (int k = 0; k < 4; ++k) o[k] = fmaxf(o[k], 0.f);
             }
-            reinterpret_cast<float4*>(y)[j] = make_float4(o[0], o[1], o[2], o[3]);
+            bn_st4<NTS>(y, j, make_float4(o[0], o[1], o[2], o[3]));
         }
-        i += U * S;
-        if (i < n4) fetch(i);
+    };
+    const int64_t US = (int64_t)U * S;
+    if (PF) {
+        for (int64_t i = i0; i < n4;) {
+            if (i + US < n4) fetch(i + US, xb, rb);
+            process(i, xa, ra);
+            i += US;
+            if (i >= n4) break;
+            if (i + US < n4) fetch(i + US, xa, ra);
+            process(i, xb, rb);
+            i += US;
+        }
+    } else {
+        for (int64_t i = i0; i < n4;) {
+            process(i, xa, ra);
+            i += US;
+            if (i < n4) fetch(i, xa, ra);
+        }
     }
 }
 
 // ---- pass 2 backward: dx = gamma*invstd*(g - sum_g/M - xhat*sum_gx/M); dres = g -----------------------
 // FOLD: the two channel sums come from the accumulation rows (folded once per workgroup, as in bn_apply_kernel<true>) instead of
 // the finalise launch's doubles; the owners of the first workgroup(s) also store dgamma / dbeta.
+// G2: g = gy + gy2 (see bn_reduce_kernel).  A launch behind a reduce pass that wrote the masked gradient (WG) gets that tensor as
+// gy with relu = 0 and dres = nullptr: two reads, one write.
 // (launch bound 5, not 6: the same 80 VGPRs, but bound 6 made the allocator spill three dwords that the main loop reloaded per
 //  iteration; config 4 172.0 -> 170.9 ms, config 2 unchanged)
-template <bool FOLD>
-__global__ __launch_bounds__(256, 5) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+template <bool FOLD, bool G2, int VAR>
+__global__ __launch_bounds__(256, G2 ? 3 : ((VAR & 4) ? 4 : 5)) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                            const float* __restrict__ y, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const double* __restrict__ acc,
                                                            int64_t M, int64_t n4, int C, int relu, float* __restrict__ dx,
                                                            float* __restrict__ dres, const double* __restrict__ rows, int n_rows,
-                                                           BnFinal fin, const double* __restrict__ count) {
+                                                           BnFinal fin, const double* __restrict__ count,
+                                                           const float* __restrict__ gy2) {
     // count != nullptr: the divisor is the element count of the WHOLE (cross-replica) batch, read from device memory
     __shared__ double s_buf[BN_FOLD_LDS];
     constexpr int U = 2;                                      // (the wave has to fit beside the backward-weights kernels: ~150 VGPRs per SIMD)
+    constexpr bool NTL = (VAR & 1) != 0, NTS = (VAR & 2) != 0, PF = (VAR & 4) != 0;
     const int c4n = C >> 2, nq = min(c4n, 256);
     const int64_t i0 = blockIdx.x * (int64_t)256 + threadIdx.x;
     const int64_t S = (int64_t)gridDim.x * 256;
     const int c = (int)(i0 % c4n) * 4;
     const bool owner = (int)threadIdx.x < nq;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 xv[U], gv[U], yv[U];
-    auto fetch = [&](int64_t i) {
+    struct Set { float4 xv[U], gv[U], yv[U], hv[G2 ? U : 1]; };
+    Set A, B;                                                 // (B: the second register set of the prefetching variant)
+    auto fetch = [&](int64_t i, Set& s) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t j = i + u * S;
             const bool ok = j < n4;
-            xv[u] = ok ? reinterpret_cast<const float4*>(x)[j] : z4;
-            gv[u] = ok ? reinterpret_cast<const float4*>(gy)[j] : z4;
-            yv[u] = (relu == 1 && ok) ? reinterpret_cast<const float4*>(y)[j] : z4;
+            s.xv[u] = ok ? bn_ld4<NTL>(x, j) : z4;
+            s.gv[u] = ok ? bn_ld4<NTL>(gy, j) : z4;
+            s.yv[u] = (relu == 1 && ok) ? bn_ld4<NTL>(y, j) : z4;
+            if (G2) s.hv[u] = ok ? bn_ld4<NTL>(gy2, j) : z4;
         }
     };
-    fetch(i0);
+    fetch(i0, A);
     double f0[4] = {0.0, 0.0, 0.0, 0.0}, f1[4] = {0.0, 0.0, 0.0, 0.0};
     if (FOLD) {
         bn_fold_rows_wg(rows, n_rows, C, nq, c, s_buf, f0, f1);
@@ -372,15 +433,16 @@ __global__ __launch_bounds__(256, 5) void bn_bwd_apply_kernel(const float* __res
         }
     }
     if (nq < 256) bn_share_params<6>(nq, par, s_buf);
-    for (int64_t i = i0; i < n4;) {
+    auto process = [&](int64_t i, const Set& s) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t j = i + u * S;
             if (j >= n4) break;
-            const float xe[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
-            float ge[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+            const float xe[4] = {s.xv[u].x, s.xv[u].y, s.xv[u].z, s.xv[u].w};
+            float ge[4] = {s.gv[u].x, s.gv[u].y, s.gv[u].z, s.gv[u].w};
+            if (G2) { ge[0] += s.hv[u].x; ge[1] += s.hv[u].y; ge[2] += s.hv[u].z; ge[3] += s.hv[u].w; }
             if (relu == 1) {
-                const float ye[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};
+                const float ye[4] = {s.yv[u].x, s.yv[u].y, s.yv[u].z, s.yv[u].w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) ge[k] = (ye[k] > 0.f) ? ge[k] : 0.f;
             } else if (relu == 2) {
@@ -393,11 +455,27 @@ __global__ __launch_bounds__(256, 5) void bn_bwd_apply_kernel(const float* __res
                 const float xh = (xe[k] - par[0][k]) * par[1][k];
                 o[k] = par[4][k] * (ge[k] - par[2][k] - xh * par[3][k]);
             }
-            reinterpret_cast<float4*>(dx)[j] = make_float4(o[0], o[1], o[2], o[3]);
-            if (dres) reinterpret_cast<float4*>(dres)[j] = make_float4(ge[0], ge[1], ge[2], ge[3]);
+            bn_st4<NTS>(dx, j, make_float4(o[0], o[1], o[2], o[3]));
+            if (dres) bn_st4<NTS>(dres, j, make_float4(ge[0], ge[1], ge[2], ge[3]));
         }
-        i += U * S;
-        if (i < n4) fetch(i);
+    };
+    const int64_t US = (int64_t)U * S;
+    if (PF) {
+        for (int64_t i = i0; i < n4;) {
+            if (i + US < n4) fetch(i + US, B);
+            process(i, A);
+            i += US;
+            if (i >= n4) break;
+            if (i + US < n4) fetch(i + US, A);
+            process(i, B);
+            i += US;
+        }
+    } else {
+        for (int64_t i = i0; i < n4;) {
+            process(i, A);
+            i += US;
+            if (i < n4) fetch(i, A);
+        }
     }
 }
 
@@ -493,7 +571,8 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
                                                            const float* __restrict__ y, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, int M, int C, int relu,
-                                                           float* __restrict__ dx, float* __restrict__ dres, BnFinal fin) {
+                                                           float* __restrict__ dx, float* __restrict__ dres, BnFinal fin,
+                                                           const float* __restrict__ gy2) {
     __shared__ double s_red[32];
     const int t = threadIdx.x, C4 = C >> 2, c4 = blockIdx.x, c = c4 * 4;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -515,6 +594,10 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
         gv[u] = ok ? reinterpret_cast<const float4*>(gy)[j] : z4;
         const float xe[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
         float ge[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+        if (gy2 && ok) {                                                  // second addend of the incoming gradient (see bn_reduce_kernel)
+            const float4 hv = reinterpret_cast<const float4*>(gy2)[j];
+            ge[0] += hv.x; ge[1] += hv.y; ge[2] += hv.z; ge[3] += hv.w;
+        }
         if (relu == 1) {
             const float4 yv = ok ? reinterpret_cast<const float4*>(y)[j] : z4;
             const float ye[4] = {yv.x, yv.y, yv.z, yv.w};
@@ -728,10 +811,58 @@ inline void bn_small_forward(const float* x, const float* residual, const float*
 }
 inline void bn_small_backward(const float* x, const float* grad_y, const float* y, const float* save_mean, const float* save_invstd,
                               const float* gamma, const float* beta, int64_t M, int C, int relu, float* grad_x, float* grad_residual,
-                              const BnFinal& fin, hipStream_t st) {
+                              const BnFinal& fin, hipStream_t st, const float* grad_y2 = nullptr) {
     const dim3 grid(C >> 2);
-    if (M <= 256) hipLaunchKernelGGL(bn_small_bwd_kernel<1>, grid, dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd, gamma, beta, (int)M, C, relu, grad_x, grad_residual, fin);
-    else hipLaunchKernelGGL(bn_small_bwd_kernel<4>, grid, dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd, gamma, beta, (int)M, C, relu, grad_x, grad_residual, fin);
+    if (M <= 256) hipLaunchKernelGGL(bn_small_bwd_kernel<1>, grid, dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd, gamma, beta, (int)M, C, relu, grad_x, grad_residual, fin, grad_y2);
+    else hipLaunchKernelGGL(bn_small_bwd_kernel<4>, grid, dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd, gamma, beta, (int)M, C, relu, grad_x, grad_residual, fin, grad_y2);
+}
+
+// ---- launch helpers: the VAR / G2 / mask instantiations ---------------------------------------------------------------------
+#define BN_VAR_SWITCH(var, CALL) \
+    switch (var) { case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; \
+                   case 5: CALL(5); break; case 6: CALL(6); break; case 7: CALL(7); break; default: CALL(0); break; }
+
+template <bool FOLD>
+inline void bn_launch_apply(int grid_x, int grid_y, hipStream_t st, const float* x, const float* res, const float* mean, const float* invstd,
+                            const float* gamma, const float* beta, int64_t n4, int C, int relu, float* y, const double* rows, int n_rows,
+                            int64_t M, const BnFinal& fin) {
+#define BN_CALL(V) hipLaunchKernelGGL((bn_apply_kernel<FOLD, V>), dim3(grid_x, grid_y), dim3(256), 0, st, x, res, mean, invstd, gamma, beta, n4, C, relu, y, rows, n_rows, M, fin)
+    BN_VAR_SWITCH(bn_var(), BN_CALL)
+#undef BN_CALL
+}
+
+template <bool FOLD>
+inline void bn_launch_bwd_apply(int grid_x, hipStream_t st, const float* x, const float* gy, const float* gy2, const float* y, const float* mean,
+                                const float* invstd, const float* gamma, const float* beta, const double* acc, int64_t M, int64_t n4, int C,
+                                int relu, float* dx, float* dres, const double* rows, int n_rows, const BnFinal& fin, const double* count) {
+    if (gy2) {
+#define BN_CALL(V) hipLaunchKernelGGL((bn_bwd_apply_kernel<FOLD, true, V>), dim3(grid_x), dim3(256), 0, st, x, gy, y, mean, invstd, gamma, beta, acc, M, n4, C, relu, dx, dres, rows, n_rows, fin, count, gy2)
+        BN_VAR_SWITCH(bn_var(), BN_CALL)
+#undef BN_CALL
+    } else {
+#define BN_CALL(V) hipLaunchKernelGGL((bn_bwd_apply_kernel<FOLD, false, V>), dim3(grid_x), dim3(256), 0, st, x, gy, y, mean, invstd, gamma, beta, acc, M, n4, C, relu, dx, dres, rows, n_rows, fin, count, gy2)
+        BN_VAR_SWITCH(bn_var(), BN_CALL)
+#undef BN_CALL
+    }
+}
+
+// backward sums pass: relu 1 -> mask from y; gy2 -> two addends; gout -> the masked gradient is written (and the apply pass reads it)
+inline void bn_launch_bwd_reduce(dim3 grid, hipStream_t st, const float* x, const float* gy, const float* gy2, const float* y, const float* mean,
+                                 const float* invstd, const float* gamma, const float* beta, int64_t M, int C, int relu, int rows, float* part,
+                                 int acc_rows, float* gout) {
+#define BN_RED(YM, G2, WG) hipLaunchKernelGGL((bn_reduce_kernel<1, YM, G2, WG>), grid, dim3(256), 0, st, x, gy, y, mean, invstd, gamma, beta, M, C, relu, rows, part, acc_rows, gy2, gout)
+    const int sel = (relu == 1 ? 4 : 0) | (gy2 ? 2 : 0) | (gout ? 1 : 0);
+    switch (sel) {
+        case 0: BN_RED(false, false, false); break;
+        case 1: BN_RED(false, false, true); break;
+        case 2: BN_RED(false, true, false); break;
+        case 3: BN_RED(false, true, true); break;
+        case 4: BN_RED(true, false, false); break;
+        case 5: BN_RED(true, false, true); break;
+        case 6: BN_RED(true, true, false); break;
+        default: BN_RED(true, true, true); break;
+    }
+#undef BN_RED
 }
 
 }  // namespace
@@ -758,7 +889,7 @@ extern "C" int dsf_bn_forward(const float* x, const float* residual, const float
                        M, C, 0, rows, bn_ws_part(workspace, C), 0);
     hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3((C + 15) / 16), dim3(256), 0, st, bn_ws_part(workspace, C), wgs, M, C, fin);
     const int64_t n4 = M * (C >> 2);
-    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(bn_apply_grid(n4, C)), dim3(256), 0, st, x, residual, save_mean, save_invstd, gamma,
+    bn_launch_apply<false>(bn_apply_grid(n4, C), 1, st, x, residual, save_mean, save_invstd, gamma,
                        beta, n4, C, relu, y, nullptr, 0, M, fin);
     return dsf_launch_status();
 }
@@ -775,7 +906,7 @@ extern "C" int dsf_bn_forward_from_stats(const float* x, const float* residual, 
     BnFinal fin = {eps, momentum, save_mean, save_invstd, running_mean, running_var, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3((C + 15) / 16), dim3(256), 0, st, part, rows, M, C, fin);
     const int64_t n4 = M * (C >> 2);
-    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(bn_apply_grid(n4, C)), dim3(256), 0, st, x, residual, save_mean, save_invstd, gamma,
+    bn_launch_apply<false>(bn_apply_grid(n4, C), 1, st, x, residual, save_mean, save_invstd, gamma,
                        beta, n4, C, relu, y, nullptr, 0, M, fin);
     return dsf_launch_status();
 }
@@ -788,8 +919,36 @@ extern "C" int dsf_bn_apply(const float* x, const float* residual, const float* 
     if (!bn_shape_ok(C)) return DSF_ERR_UNSUPPORTED;
     const int64_t n4 = M * (C >> 2);
     BnFinal fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(bn_apply_grid(n4, C)), dim3(256), 0, (hipStream_t)stream, x, residual, mean, invstd,
+    bn_launch_apply<false>(bn_apply_grid(n4, C), 1, (hipStream_t)stream, x, residual, mean, invstd,
                        gamma, beta, n4, C, relu, y, nullptr, 0, M, fin);
+    return dsf_launch_status();
+}
+
+// grad_y2 (may be NULL): second addend of the incoming gradient, g = grad_y + grad_y2.  With a residual gradient wanted the sums
+// pass writes the masked g into grad_residual and the apply pass reads it back (x + g in, dx out) instead of re-reading
+// grad_y (+ grad_y2) and y: add + sums + apply were 8R + 3W of the activation, now 6R + 2W (5R + 2W with one addend, was 6R + 2W).
+static int bn_backward_ordered(const float* x, const float* grad_y, const float* grad_y2, const float* y, const float* gamma, const float* beta,
+                               const float* save_mean, const float* save_invstd, int64_t M, int C, int relu,
+                               float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta,
+                               double* workspace, hipStream_t st) {
+    const int rows = bn_rows_per_wg(M, C);
+    const int wgs = (int)((M + rows - 1) / rows);
+    BnFinal fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, workspace, grad_gamma, grad_beta};
+    if (bn_small_ok(M, C)) {
+        bn_small_backward(x, grad_y, y, save_mean, save_invstd, gamma, beta, M, C, relu, grad_x, grad_residual, fin, st, grad_y2);
+        return dsf_launch_status();
+    }
+    float* gout = bn_write_g() ? grad_residual : nullptr;
+    bn_launch_bwd_reduce(dim3(wgs, bn_col_blocks(C)), st, x, grad_y, grad_y2, y, save_mean, save_invstd, gamma, beta, M, C, relu, rows,
+                         bn_ws_part(workspace, C), 0, gout);
+    hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(256), 0, st, bn_ws_part(workspace, C), wgs, M, C, fin);
+    const int64_t n4 = M * (C >> 2);
+    if (gout)
+        bn_launch_bwd_apply<false>(bn_apply_grid(n4, C), st, x, gout, nullptr, nullptr, save_mean, save_invstd, gamma, beta, workspace, M, n4, C, 0,
+                                   grad_x, nullptr, nullptr, 0, fin, nullptr);
+    else
+        bn_launch_bwd_apply<false>(bn_apply_grid(n4, C), st, x, grad_y, grad_y2, y, save_mean, save_invstd, gamma, beta, workspace, M, n4, C, relu,
+                                   grad_x, grad_residual, nullptr, 0, fin, nullptr);
     return dsf_launch_status();
 }
 
@@ -800,26 +959,19 @@ extern "C" int dsf_bn_backward(const float* x, const float* grad_y, const float*
     DSF_CHECK_ARG(x && grad_y && save_mean && save_invstd && grad_x && workspace && M > 0 && relu >= 0 && relu <= 2 &&
                   (relu != 1 || y));
     if (!bn_shape_ok(C)) return DSF_ERR_UNSUPPORTED;
-    hipStream_t st = (hipStream_t)stream;
-    const int rows = bn_rows_per_wg(M, C);
-    const int wgs = (int)((M + rows - 1) / rows);
-    BnFinal fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, workspace, grad_gamma, grad_beta};
-    if (bn_small_ok(M, C)) {
-        bn_small_backward(x, grad_y, y, save_mean, save_invstd, gamma, beta, M, C, relu, grad_x, grad_residual, fin, st);
-        return dsf_launch_status();
-    }
-    if (relu == 1) {
-        hipLaunchKernelGGL((bn_reduce_kernel<1, true>), dim3(wgs, bn_col_blocks(C)), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd, gamma, beta, M, C,
-                           relu, rows, bn_ws_part(workspace, C), 0);
-    } else {
-        hipLaunchKernelGGL((bn_reduce_kernel<1, false>), dim3(wgs, bn_col_blocks(C)), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd, gamma, beta, M, C,
-                           relu, rows, bn_ws_part(workspace, C), 0);
-    }
-    hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(256), 0, st, bn_ws_part(workspace, C), wgs, M, C, fin);
-    const int64_t n4 = M * (C >> 2);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(bn_apply_grid(n4, C)), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd,
-                       gamma, beta, workspace, M, n4, C, relu, grad_x, grad_residual, nullptr, 0, fin, nullptr);
-    return dsf_launch_status();
+    return bn_backward_ordered(x, grad_y, nullptr, y, gamma, beta, save_mean, save_invstd, M, C, relu, grad_x, grad_residual, grad_gamma,
+                               grad_beta, workspace, (hipStream_t)stream);
+}
+
+extern "C" int dsf_bn_backward_pair(const float* x, const float* grad_y, const float* grad_y2, const float* y, const float* gamma,
+                                    const float* beta, const float* save_mean, const float* save_invstd, int64_t M, int C, int relu,
+                                    float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta, double* workspace,
+                                    dsf_stream_t stream) {
+    DSF_CHECK_ARG(x && grad_y && save_mean && save_invstd && grad_x && workspace && M > 0 && relu >= 0 && relu <= 2 &&
+                  (relu != 1 || y));
+    if (!bn_shape_ok(C)) return DSF_ERR_UNSUPPORTED;
+    return bn_backward_ordered(x, grad_y, grad_y2, y, gamma, beta, save_mean, save_invstd, M, C, relu, grad_x, grad_residual, grad_gamma,
+                               grad_beta, workspace, (hipStream_t)stream);
 }
 
 // ---- the same passes WITHOUT the finalise launches (default, float-atomic mode) --------------------------------------
@@ -852,8 +1004,37 @@ extern "C" int dsf_bn_forward_acc(const float* x, const float* residual, const f
                            nullptr, M, C, 0, rows, reinterpret_cast<float*>(acc), BN_ACC_ROWS);
     }
     const int64_t n4 = M * (C >> 2);
-    hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(bn_apply_grid(n4, C)), dim3(256), 0, st, x, residual, nullptr, nullptr, gamma, beta,
+    bn_launch_apply<true>(bn_apply_grid(n4, C), 1, st, x, residual, nullptr, nullptr, gamma, beta,
                        n4, C, relu, y, acc, BN_ACC_ROWS, M, fin);
+    return dsf_launch_status();
+}
+
+static int bn_backward_acc_impl(const float* x, const float* grad_y, const float* grad_y2, const float* y, const float* gamma, const float* beta,
+                                const float* save_mean, const float* save_invstd, int64_t M, int C, int relu, float* grad_x,
+                                float* grad_residual, float* grad_gamma, float* grad_beta, double* acc, hipStream_t st) {
+    // 1024 reduction workgroups (DSF_BN_BWD_WGS: tuning aid, read per call): on the B = 192 tensors (800 MB) 512 left the pass at
+    // 2.7-3.4 TB/s -- config 4 165.4 -> 163.5 ms per step with 1024, 2048 and 4096 alike; the B = 32 step does not care.  Eight rows
+    // in flight per lane instead of four: no gain (162.5 vs 163.6 ms)
+    const char* wg_e = getenv("DSF_BN_BWD_WGS");
+    int max_wgs = wg_e ? atoi(wg_e) : 1024;
+    if (max_wgs < 1) max_wgs = 1024;                                 // (0 / garbage would divide by zero in bn_rows_per_wg)
+    const int rows = bn_rows_per_wg(M, C, max_wgs);
+    const int wgs = (int)((M + rows - 1) / rows);
+    BnFinal fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, grad_gamma, grad_beta};
+    if (bn_small_ok(M, C)) {                                         // both sums + apply in one launch (`acc` stays untouched)
+        bn_small_backward(x, grad_y, y, save_mean, save_invstd, gamma, beta, M, C, relu, grad_x, grad_residual, fin, st, grad_y2);
+        return dsf_launch_status();
+    }
+    float* gout = bn_write_g() ? grad_residual : nullptr;
+    bn_launch_bwd_reduce(dim3(wgs, bn_col_blocks(C)), st, x, grad_y, grad_y2, y, save_mean, save_invstd, gamma, beta, M, C, relu, rows,
+                         reinterpret_cast<float*>(acc), BN_ACC_ROWS, gout);
+    const int64_t n4 = M * (C >> 2);
+    if (gout)
+        bn_launch_bwd_apply<true>(bn_apply_grid(n4, C), st, x, gout, nullptr, nullptr, save_mean, save_invstd, gamma, beta, nullptr, M, n4, C, 0,
+                                  grad_x, nullptr, acc, BN_ACC_ROWS, fin, nullptr);
+    else
+        bn_launch_bwd_apply<true>(bn_apply_grid(n4, C), st, x, grad_y, grad_y2, y, save_mean, save_invstd, gamma, beta, nullptr, M, n4, C, relu,
+                                  grad_x, grad_residual, acc, BN_ACC_ROWS, fin, nullptr);
     return dsf_launch_status();
 }
 
@@ -862,29 +1043,18 @@ extern "C" int dsf_bn_backward_acc(const float* x, const float* grad_y, const fl
                                    float* grad_residual, float* grad_gamma, float* grad_beta, double* acc, dsf_stream_t stream) {
     DSF_CHECK_ARG(x && grad_y && save_mean && save_invstd && grad_x && acc && M > 0 && relu >= 0 && relu <= 2 && (relu != 1 || y));
     if (!bn_shape_ok(C) || dsf_deterministic()) return DSF_ERR_UNSUPPORTED;
-    hipStream_t st = (hipStream_t)stream;
-    // 1024 reduction workgroups (DSF_BN_BWD_WGS: tuning aid, read per call): on the B = 192 tensors (800 MB) 512 left the pass at
-    // 2.7-3.4 TB/s -- config 4 165.4 -> 163.5 ms per step with 1024, 2048 and 4096 alike; the B = 32 step does not care.  Eight rows
-    // in flight per lane instead of four: no gain (162.5 vs 163.6 ms)
-    const char* wg_e = getenv("DSF_BN_BWD_WGS");
-    const int rows = bn_rows_per_wg(M, C, wg_e ? atoi(wg_e) : 1024);
-    const int wgs = (int)((M + rows - 1) / rows);
-    BnFinal fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, grad_gamma, grad_beta};
-    if (bn_small_ok(M, C)) {                                         // both sums + apply in one launch (`acc` stays untouched)
-        bn_small_backward(x, grad_y, y, save_mean, save_invstd, gamma, beta, M, C, relu, grad_x, grad_residual, fin, st);
-        return dsf_launch_status();
-    }
-    if (relu == 1) {
-        hipLaunchKernelGGL((bn_reduce_kernel<1, true>), dim3(wgs, bn_col_blocks(C)), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd, gamma, beta,
-                           M, C, relu, rows, reinterpret_cast<float*>(acc), BN_ACC_ROWS);
-    } else {
-        hipLaunchKernelGGL((bn_reduce_kernel<1, false>), dim3(wgs, bn_col_blocks(C)), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd, gamma, beta,
-                           M, C, relu, rows, reinterpret_cast<float*>(acc), BN_ACC_ROWS);
-    }
-    const int64_t n4 = M * (C >> 2);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(bn_apply_grid(n4, C)), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd,
-                       gamma, beta, nullptr, M, n4, C, relu, grad_x, grad_residual, acc, BN_ACC_ROWS, fin, nullptr);
-    return dsf_launch_status();
+    return bn_backward_acc_impl(x, grad_y, nullptr, y, gamma, beta, save_mean, save_invstd, M, C, relu, grad_x, grad_residual, grad_gamma,
+                                grad_beta, acc, (hipStream_t)stream);
+}
+
+extern "C" int dsf_bn_backward_acc_pair(const float* x, const float* grad_y, const float* grad_y2, const float* y, const float* gamma,
+                                        const float* beta, const float* save_mean, const float* save_invstd, int64_t M, int C, int relu,
+                                        float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta, double* acc,
+                                        dsf_stream_t stream) {
+    DSF_CHECK_ARG(x && grad_y && save_mean && save_invstd && grad_x && acc && M > 0 && relu >= 0 && relu <= 2 && (relu != 1 || y));
+    if (!bn_shape_ok(C) || dsf_deterministic()) return DSF_ERR_UNSUPPORTED;
+    return bn_backward_acc_impl(x, grad_y, grad_y2, y, gamma, beta, save_mean, save_invstd, M, C, relu, grad_x, grad_residual, grad_gamma,
+                                grad_beta, acc, (hipStream_t)stream);
 }
 
 // ---- cross-replica BatchNorm (SyncBatchNorm): ONE exchange of 2C + 1 doubles per layer and pass -------------
@@ -933,7 +1103,7 @@ extern "C" int dsf_bn_forward_from_sums(const float* x, const float* residual, c
     BnFinal fin = {eps, momentum, save_mean, save_invstd, running_mean, running_var, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(bn_stats_from_sums_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, C, fin);
     const int64_t n4 = M * (C >> 2);
-    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(bn_apply_grid(n4, C)), dim3(256), 0, st, x, residual, save_mean, save_invstd, gamma,
+    bn_launch_apply<false>(bn_apply_grid(n4, C), 1, st, x, residual, save_mean, save_invstd, gamma,
                        beta, n4, C, relu, y, nullptr, 0, M, fin);
     return dsf_launch_status();
 }
@@ -947,13 +1117,8 @@ extern "C" int dsf_bn_backward_sums(const float* x, const float* grad_y, const f
     const int rows = bn_rows_per_wg(M, C);
     const int wgs = (int)((M + rows - 1) / rows);
     BnFinal fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, sums, grad_gamma, grad_beta};      // dgamma / dbeta: this replica's share
-    if (relu == 1) {
-        hipLaunchKernelGGL((bn_reduce_kernel<1, true>), dim3(wgs, bn_col_blocks(C)), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd, gamma, beta,
-                           M, C, relu, rows, bn_ws_part(workspace, C), 0);
-    } else {
-        hipLaunchKernelGGL((bn_reduce_kernel<1, false>), dim3(wgs, bn_col_blocks(C)), dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd, gamma, beta,
-                           M, C, relu, rows, bn_ws_part(workspace, C), 0);
-    }
+    bn_launch_bwd_reduce(dim3(wgs, bn_col_blocks(C)), st, x, grad_y, nullptr, y, save_mean, save_invstd, gamma, beta, M, C, relu, rows,
+                         bn_ws_part(workspace, C), 0, nullptr);
     hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(256), 0, st, bn_ws_part(workspace, C), wgs, M, C, fin);
     return dsf_launch_status();
 }
@@ -965,8 +1130,8 @@ extern "C" int dsf_bn_backward_apply(const float* x, const float* grad_y, const 
     if (!bn_shape_ok(C)) return DSF_ERR_UNSUPPORTED;
     BnFinal fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     const int64_t n4 = M * (C >> 2);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(bn_apply_grid(n4, C)), dim3(256), 0, (hipStream_t)stream, x, grad_y, y, save_mean,
-                       save_invstd, gamma, beta, sums, M, n4, C, relu, grad_x, grad_residual, nullptr, 0, fin, count);
+    bn_launch_bwd_apply<false>(bn_apply_grid(n4, C), (hipStream_t)stream, x, grad_y, nullptr, y, save_mean, save_invstd, gamma, beta, sums, M, n4, C,
+                               relu, grad_x, grad_residual, nullptr, 0, fin, count);
     return dsf_launch_status();
 }
 
@@ -987,7 +1152,7 @@ extern "C" int dsf_instnorm_forward(const float* x, const float* residual, int B
                        nullptr, HW, C, 0, rows, reinterpret_cast<float*>(acc), 1);
     BnFinal fin = {eps, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     const int64_t n4 = HW * (C >> 2);
-    hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(bn_apply_grid(n4, C), B), dim3(256), 0, st, x, residual, nullptr, nullptr, nullptr,
+    bn_launch_apply<true>(bn_apply_grid(n4, C), B, st, x, residual, nullptr, nullptr, nullptr,
                        nullptr, n4, C, relu, y, acc, 1, HW, fin);
     return dsf_launch_status();
 }

@@ -15,7 +15,7 @@ import torch.nn as nn
 from . import resnet as _resnet
 from .resnet import BasicBlock, Bottleneck
 from .. import nn_conv
-from ..nn_norm import FusedBatchNorm2d, ConvBN
+from ..nn_norm import FusedBatchNorm2d, ConvBN, take_twin
 from ..util.generateFeature import joint2offset, offset2joint_softmax
 from ..streams import fork
 
@@ -99,8 +99,8 @@ class _TwoBranchNet(nn.Module):
 
     def _run_trunk(self, x, suffix):
         g = lambda n: getattr(self, n + suffix)
-        c4 = g('layer4')(g('layer3')(g('layer2')(g('layer1')(x))))
-        mano = g('mano_regress')(c4)
+        c4, c4b = take_twin(g('layer4')(g('layer3')(g('layer2')(g('layer1')(x)))))    # c4 is read twice: a handle each (nn_norm.take_twin)
+        mano = g('mano_regress')(c4b)
         feat = g('deconv_layer2')(g('deconv_layer3')(g('deconv_layer4')(c4)))
         heads = g('finals')
         pix = nn_conv.fused_heads(feat, heads)
@@ -175,10 +175,10 @@ class MANO_OCR_stage(_TwoBranchNet):
             # the stage-2 bridge (MANO head -> MANO layer -> rasteriser -> offset map: a chain of short, latency-bound launches,
             # forward and backward) needs only c4; the decoder (three transposed convolutions + heads: large launches) needs
             # nothing of it until the stage-2 `cat` -- beside each other on forked streams (streams.py)
-            c4 = self.layer4(self.layer3(self.layer2(self.layer1(c0))))
+            c4, c4b = take_twin(self.layer4(self.layer3(self.layer2(self.layer1(c0)))))
             f = fork(c4.device, params=self)
-            with f.branch(0, c4):
-                mano = self.mano_regress(c4)
+            with f.branch(0, c4b):
+                mano = self.mano_regress(c4b)
                 mano_img, mano_uvd, _, _ = render.render(mano, center, cube)
                 remap = joint2offset(mano_uvd, mano_img, 0.8, 64)
             feat = self.deconv_layer2(self.deconv_layer3(self.deconv_layer4(c4)))

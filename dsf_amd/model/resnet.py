@@ -4,7 +4,7 @@ keys) load unchanged."""
 import torch.nn as nn
 
 from ..nn_conv import Conv2d as _HipConv2d
-from ..nn_norm import FusedBatchNorm2d, conv_bn_act
+from ..nn_norm import FusedBatchNorm2d, conv_bn_act, take_twin
 from ..streams import fork
 import os
 _DS_FORK = [os.environ.get("DSF_DS_FORK", "1") == "1"]
@@ -35,16 +35,20 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        # x is read twice (conv1, identity / downsample): one handle of the producing BatchNorm's twin output each, so that its
+        # backward gets the two gradients separately and adds them in its own sums pass (nn_norm.take_twin); this block's output is
+        # handed out the same way
+        x, x2 = take_twin(x)
         if self.downsample is not None and _DS_FORK[0]:
             f = fork(x.device, params=self)
-            with f.branch(0, x):
-                identity = self.downsample(x)
+            with f.branch(0, x2):
+                identity = self.downsample(x2)
             y = conv_bn_act(self.conv1, self.bn1, x, relu=True)
             f.join()
-            return conv_bn_act(self.conv2, self.bn2, y, residual=identity, relu=True)
+            return conv_bn_act(self.conv2, self.bn2, y, residual=identity, relu=True, twin=True)
         y = conv_bn_act(self.conv1, self.bn1, x, relu=True)                       # (BN statistics from the conv epilogue)
-        identity = x if self.downsample is None else self.downsample(x)
-        return conv_bn_act(self.conv2, self.bn2, y, residual=identity, relu=True)    # bn + skip + relu in one pass
+        identity = x2 if self.downsample is None else self.downsample(x2)
+        return conv_bn_act(self.conv2, self.bn2, y, residual=identity, relu=True, twin=True)    # bn + skip + relu in one pass
 
 
 class Bottleneck(nn.Module):
@@ -63,15 +67,16 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        x, x2 = take_twin(x)                                 # (see BasicBlock.forward)
         if self.downsample is not None and _DS_FORK[0]:
             f = fork(x.device, params=self)
-            with f.branch(0, x):
-                identity = self.downsample(x)
+            with f.branch(0, x2):
+                identity = self.downsample(x2)
             y = conv_bn_act(self.conv1, self.bn1, x, relu=True)
             y = conv_bn_act(self.conv2, self.bn2, y, relu=True)
             f.join()
-            return conv_bn_act(self.conv3, self.bn3, y, residual=identity, relu=True)
+            return conv_bn_act(self.conv3, self.bn3, y, residual=identity, relu=True, twin=True)
         y = conv_bn_act(self.conv1, self.bn1, x, relu=True)
         y = conv_bn_act(self.conv2, self.bn2, y, relu=True)
-        identity = x if self.downsample is None else self.downsample(x)
-        return conv_bn_act(self.conv3, self.bn3, y, residual=identity, relu=True)
+        identity = x2 if self.downsample is None else self.downsample(x2)
+        return conv_bn_act(self.conv3, self.bn3, y, residual=identity, relu=True, twin=True)

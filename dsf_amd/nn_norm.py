@@ -93,9 +93,32 @@ def stat_floats(module, applications=1):
                               if isinstance(m, FusedBatchNorm2d) and supported(m.num_features))
 
 
+# ---- twin outputs: the fan-in sum of a block output's two gradients inside the BatchNorm backward --------------------------------
+# The output of a residual block feeds the next block's first convolution AND its identity / downsample path (reference
+# model/resnet.py:39-55, 78-98); autograd sums the two gradients with an elementwise pass (2R + 1W of the activation) before
+# the BatchNorm backward that produced the output can run.  With ``twin=True`` the fused BatchNorm hands out its output TWICE (two
+# tensors on one storage: ``y`` and ``y._dsf_twin``); a consumer that reads the output twice takes one each (``take_twin``),
+# and the backward receives the two gradients separately: its sums pass adds them on the fly (dsf_bn_backward_acc_pair).
+# DSF_BN_TWIN=0: one output, autograd adds.
+TWIN = [os.environ.get("DSF_BN_TWIN", "1") == "1"]
+
+
+def _alias(y):
+    """a second tensor on y's storage (not a view: no ``_base`` reference back to y, so hanging it on y makes no cycle)"""
+    return torch.empty(0, device=y.device, dtype=y.dtype).set_(y.untyped_storage(), y.storage_offset(), y.shape, y.stride())
+
+
+def take_twin(x):
+    """-> (x, x2): the two handles of a twin output (x2 is x itself when x has none).  The twin is handed out once."""
+    t = x.__dict__.pop("_dsf_twin", None) if torch.is_tensor(x) else None
+    return (x, t) if t is not None else (x, x)
+
+
 class _BNFunction(Function):
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, eps, momentum, relu, part=None, rows=0, acc=None, acc_filled=0):
+    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, eps, momentum, relu, part=None, rows=0, acc=None, acc_filled=0,
+                twin=False):
+        ctx.set_materialize_grads(False)
         x = x.contiguous(memory_format=CL)
         if residual is not None:
             residual = residual.contiguous(memory_format=CL)
@@ -123,30 +146,42 @@ class _BNFunction(Function):
         # ReLU mask in the backward: recomputed from x when no residual was added (y is then not kept alive for it)
         ctx.save_for_backward(x, y if (relu and residual is not None) else None, gamma, beta, mean, invstd)
         ctx.cfg = (relu, residual is not None, gamma is not None, beta is not None)
+        if twin:
+            return y, _alias(y)
         return y
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, gy):
+    def backward(ctx, gy, gy2=None):
+        n_in = 14
+        if gy is None:
+            gy, gy2 = gy2, None
+        if gy is None:                                        # neither handle of the output reached the loss
+            return (None,) * n_in
         x, y, gamma, beta, mean, invstd = ctx.saved_tensors
         relu, has_res, has_g, has_b = ctx.cfg
         relu_mode = 0 if not relu else (1 if has_res else 2)
         gy = gy.contiguous(memory_format=CL)
+        if gy2 is not None:
+            gy2 = gy2.contiguous(memory_format=CL)
         B, C, H, W = x.shape
         M = B * H * W
         gx = torch.empty_like(x, memory_format=CL)
-        gres = torch.empty_like(x, memory_format=CL) if has_res else None
+        # the residual's gradient is the (summed, masked) incoming gradient; unmasked and alone it IS gy: nothing to write
+        gres = None if not has_res else (gy if (relu_mode == 0 and gy2 is None) else torch.empty_like(x, memory_format=CL))
+        gres_out = gres if gres is not gy else None
         gg = torch.empty(C, device=x.device, dtype=torch.float32) if has_g else None
         gb = torch.empty(C, device=x.device, dtype=torch.float32) if has_b else None
         acc = _acc_take(C, x.device)
         if acc is not None:
-            check(L.lib().dsf_bn_backward_acc(_p(x), _p(gy), _p(y), _p(gamma), _p(beta), _p(mean), _p(invstd), I64(M), I(C), I(relu_mode),
-                                              _p(gx), _p(gres), _p(gg), _p(gb), _p(acc), stream_ptr()), "dsf_bn_backward_acc")
+            check(L.lib().dsf_bn_backward_acc_pair(_p(x), _p(gy), _p(gy2), _p(y), _p(gamma), _p(beta), _p(mean), _p(invstd), I64(M), I(C),
+                                                   I(relu_mode), _p(gx), _p(gres_out), _p(gg), _p(gb), _p(acc), stream_ptr()),
+                  "dsf_bn_backward_acc_pair")
         else:
             ws = _workspace(x.device, C)
-            check(L.lib().dsf_bn_backward(_p(x), _p(gy), _p(y), _p(gamma), _p(beta), _p(mean), _p(invstd), I64(M), I(C), I(relu_mode), _p(gx),
-                                          _p(gres), _p(gg), _p(gb), _p(ws), stream_ptr()), "dsf_bn_backward")
-        return gx, gres, gg, gb, None, None, None, None, None, None, None, None, None
+            check(L.lib().dsf_bn_backward_pair(_p(x), _p(gy), _p(gy2), _p(y), _p(gamma), _p(beta), _p(mean), _p(invstd), I64(M), I(C),
+                                               I(relu_mode), _p(gx), _p(gres_out), _p(gg), _p(gb), _p(ws), stream_ptr()), "dsf_bn_backward_pair")
+        return (gx, gres, gg, gb) + (None,) * (n_in - 4)
 
 
 class FusedBatchNorm2d(nn.BatchNorm2d):
@@ -186,6 +221,13 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
             hit = self.__dict__["_folded"] = (key, scale.contiguous(), shift.contiguous())
         return hit[1], hit[2]
 
+    @staticmethod
+    def _out(res):
+        if isinstance(res, tuple):                           # (y, second handle): see take_twin
+            res[0].__dict__["_dsf_twin"] = res[1]
+            return res[0]
+        return res
+
     def __getattr__(self, name):
         if name == "num_batches_tracked" and self.__dict__.get("_pending_batches"):
             self.flush_batch_counter()
@@ -199,7 +241,9 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
         self._pending_batches = 0
         super()._load_from_state_dict(*args, **kwargs)
 
-    def forward(self, x, residual=None, relu=None, stats=None):
+    def forward(self, x, residual=None, relu=None, stats=None, twin=False):
+        """``twin=True`` (training path only): the output also carries a second handle ``y._dsf_twin`` for a consumer that reads it
+        twice (take_twin); every other path ignores the flag."""
         relu = self.fuse_relu if relu is None else relu
         if not x.is_cuda:
             raise RuntimeError("dsf_amd FusedBatchNorm2d runs on the GPU only (got %s)" % x.device)
@@ -219,14 +263,15 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
                 mom = self.momentum
                 rm = self.running_mean if (self.training and self.track_running_stats) else None
                 rv = self.running_var if (self.training and self.track_running_stats) else None
+                twin = bool(twin and TWIN[0] and torch.is_grad_enabled())
                 if stats is not None and isinstance(stats[0], str):            # ("acc", rows block, filled)
-                    return _BNFunction.apply(x, residual, self.weight, self.bias, rm, rv, self.eps, mom, relu, None, 0, stats[1], stats[2])
+                    return self._out(_BNFunction.apply(x, residual, self.weight, self.bias, rm, rv, self.eps, mom, relu, None, 0, stats[1], stats[2], twin))
                 part, rows = stats if stats is not None else (None, 0)
                 if part is None:
                     acc = _acc_take(C, x.device)
                     if acc is not None:
-                        return _BNFunction.apply(x, residual, self.weight, self.bias, rm, rv, self.eps, mom, relu, None, 0, acc, 0)
-                return _BNFunction.apply(x, residual, self.weight, self.bias, rm, rv, self.eps, mom, relu, part, rows)
+                        return self._out(_BNFunction.apply(x, residual, self.weight, self.bias, rm, rv, self.eps, mom, relu, None, 0, acc, 0, twin))
+                return self._out(_BNFunction.apply(x, residual, self.weight, self.bias, rm, rv, self.eps, mom, relu, part, rows, None, 0, twin))
             if torch.is_grad_enabled() and (x.requires_grad or (residual is not None and residual.requires_grad) or
                                             (self.weight is not None and self.weight.requires_grad) or
                                             (self.bias is not None and self.bias.requires_grad)):
@@ -312,12 +357,13 @@ class FusedSyncBatchNorm2d(FusedBatchNorm2d):
     class in place).  Single-rank groups and evaluation mode fall through to FusedBatchNorm2d."""
     process_group = None
 
-    def forward(self, x, residual=None, relu=None, stats=None):
+    def forward(self, x, residual=None, relu=None, stats=None, twin=False):
         import torch.distributed as dist
         world = dist.get_world_size(self.process_group) if (dist.is_available() and dist.is_initialized()) else 1
         if not (self.training and self.track_running_stats and world > 1 and x.is_cuda and x.dtype == torch.float32 and
                 supported(x.shape[1]) and x.numel() > 0 and self.momentum is not None):
-            return super().forward(x, residual, relu, stats)
+            return super().forward(x, residual, relu, stats, twin)
+        # (the cross-replica passes hand out one output: autograd sums a two-consumer gradient itself)
         relu = self.fuse_relu if relu is None else relu
         if self._buffers.get("num_batches_tracked") is not None:
             self._pending_batches += 1
@@ -351,10 +397,10 @@ def reflect_pad(x, pad):
     return y
 
 
-def bn_act(bn, x, residual=None, relu=False):
+def bn_act(bn, x, residual=None, relu=False, twin=False):
     """bn(x) (+ residual) (relu) for either the fused module or a plain nn.BatchNorm2d (CPU twin)."""
     if isinstance(bn, FusedBatchNorm2d):
-        return bn(x, residual, relu)
+        return bn(x, residual, relu, twin=twin)
     y = bn(x)
     if residual is not None:
         y = y + residual
@@ -366,7 +412,7 @@ EPILOGUE_STATS = [os.environ.get("DSF_BN_EPILOGUE", "1") == "1"]
 EPILOGUE_AFFINE = [os.environ.get("DSF_BN_EPILOGUE", "1") == "1"]
 
 
-def conv_bn_act(conv, bn, x, residual=None, relu=None):
+def conv_bn_act(conv, bn, x, residual=None, relu=None, twin=False):
     """``bn(conv(x))`` (+ residual) (relu).  Both this package's HIP layers, training mode: the BatchNorm batch statistics
     come from the convolution's epilogue (one pass over the convolution output less, two launches instead of three).
     Evaluation mode without autograd: the whole frozen-statistics BatchNorm (+ residual)(+ ReLU) rides in the convolution's
@@ -388,7 +434,7 @@ def conv_bn_act(conv, bn, x, residual=None, relu=None):
     fusable = (EPILOGUE_STATS[0] and isinstance(bn, FusedBatchNorm2d) and isinstance(conv, (nn_conv.Conv2d, nn_conv.ConvTranspose2d)) and bn.training and
                bn.track_running_stats and conv.bias is None and x.is_cuda and supported(bn.num_features) and nn_conv.STATS is None)
     if not fusable:
-        return bn_act(bn, conv(x), residual, relu if relu is not None else getattr(bn, "fuse_relu", False))
+        return bn_act(bn, conv(x), residual, relu if relu is not None else getattr(bn, "fuse_relu", False), twin)
     req = nn_conv.StatsRequest()
     # finalise-free path: the epilogue adds into these zeroed rows (a cross-replica BatchNorm exchanges ordered partial rows instead)
     req.acc = None if isinstance(bn, FusedSyncBatchNorm2d) else _acc_take(bn.num_features, x.device)
@@ -398,8 +444,8 @@ def conv_bn_act(conv, bn, x, residual=None, relu=None):
     finally:
         nn_conv.STATS = None
     if req.acc is not None:
-        return bn(y, residual, relu, stats=("acc", req.acc, req.filled))
-    return bn(y, residual, relu, stats=(req.part, req.rows) if req.rows else None)
+        return bn(y, residual, relu, stats=("acc", req.acc, req.filled), twin=twin)
+    return bn(y, residual, relu, stats=(req.part, req.rows) if req.rows else None, twin=twin)
 
 
 class ConvBN(nn.Sequential):

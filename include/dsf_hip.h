@@ -350,7 +350,7 @@ int dsf_conv_c1_supported(int Co, int KH, int KW, int stride);
 /* ONE output channel (the generator's last layer, ReflectionPad2d(3) + Conv2d(64, 1, 7): render_model/transfer.py:441-442; as an
  * implicit GEMM it would pad N from 1 to 64 columns): X (B,Hi,Wi,Ci) NHWC, W [K][K][Ci] (the kernel layout [K][K][Ci][1]),
  * Y (B,Ho,Wo); square K in {3, 5, 7}, stride 1, Ci % 8 == 0, zero padding `pad`; other shapes DSF_ERR_UNSUPPORTED.  fp32 FMAs,
- * lane = output pixel.  Additive in round 5 (the ABI version stays 2). */
+ * lane = output pixel.  Added in round 5 (ABI version 3 since round 6). */
 int dsf_conv_co1_forward(const float* X, const float* W, const float* bias, float* Y, int B, int Hi, int Wi, int Ci, int Ho, int Wo,
                          int K, int pad, dsf_stream_t stream);
 int64_t dsf_conv_c1_workspace_bytes(int KH, int KW);
@@ -399,7 +399,7 @@ int dsf_conv_x6_forward_into(const float* X, const void* image, const float* bia
  * read straight from the image, 2 = the same with the input staged once per 16-channel chunk as a patch with halo that all nine
  * taps read (3 x 3, stride 1, pad 1, maps 64 / 32 / 16 / 8 wide; bit-identical to the others when unsplit; DSF_X6_PATCH=0
  * switches it off).  *k_splits: the K splits of that launch -- what to hand dsf_conv_x6_forward_into.  Either pointer may be
- * NULL.  Additive in round 5 (the ABI version stays 2). */
+ * NULL.  Added in round 5 (ABI version 3 since round 6). */
 int dsf_conv_x6_forward_plan(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride, int dil, int pad_h,
                              int pad_w, int* variant, int* k_splits);
 /* Measurement aid for bench.py: launches a bare v_mfma_f32_32x32x16_bf16 loop (no memory traffic) on `workgroups` x 4 waves,
@@ -416,7 +416,7 @@ int dsf_conv_x6_wrw(const float* X, const float* dY, float* dW, int B, int Hi, i
  * what it accumulates into -- like dW under accumulate != 0).  Replaces the separate column-sum launches behind every biased
  * convolution (dsf_col_sum: 2-3 launches).  DSF_ERR_UNSUPPORTED -- nothing launched: use dsf_conv_x6_wrw_ws + dsf_col_sum -- in
  * deterministic mode, for layers whose pixels are cut into more than 64 splits (more adders per address bring nothing) and for the
- * large 3 x 3 layers that take the row-staged kernel.  Additive in round 5 (the ABI version stays 2). */
+ * large 3 x 3 layers that take the row-staged kernel.  Added in round 5 (ABI version 3 since round 6). */
 int dsf_conv_x6_wrw_bias(const float* X, const float* dY, float* dW, float* dbias, int B, int Hi, int Wi, int Ci, int Ho, int Wo,
                          int Co, int KH, int KW, int stride, int pad_h, int pad_w, int accumulate, dsf_stream_t stream);
 
@@ -446,6 +446,15 @@ int dsf_bn_backward(const float* x, const float* grad_y, const float* y, const f
                     const float* save_mean, const float* save_invstd, int64_t M, int C, int relu,
                     float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta,
                     double* workspace, dsf_stream_t stream);
+/* The same pass for a gradient that arrives as TWO tensors, g = grad_y + grad_y2 (grad_y2 may be NULL): the output of a residual
+ * block feeds the next block's first convolution AND its identity path (model/resnet.py:39-55, 78-98: `out += identity`), so
+ * autograd would sum the two gradients with an elementwise pass of its own (2 reads + 1 write of the activation) before this
+ * backward could run.  Here the sums pass adds them on the fly; when grad_residual is wanted it also WRITES the (masked) g
+ * there and the apply pass reads x and that tensor only.  Same arithmetic as torch's add followed by dsf_bn_backward. */
+int dsf_bn_backward_pair(const float* x, const float* grad_y, const float* grad_y2, const float* y, const float* gamma,
+                         const float* beta, const float* save_mean, const float* save_invstd, int64_t M, int C, int relu,
+                         float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta, double* workspace,
+                         dsf_stream_t stream);
 
 /* out[c] = sum_m x[m][c] of a row-major (M, C) matrix (bias gradient of an NHWC convolution output:
  * the `gy.sum((0,2,3))` of nn.Conv2d's backward).  workspace: dsf_col_sum_workspace_bytes(C) bytes of 16-byte
@@ -542,6 +551,11 @@ int dsf_bn_forward_acc(const float* x, const float* residual, const float* gamma
 int dsf_bn_backward_acc(const float* x, const float* grad_y, const float* y, const float* gamma, const float* beta,
                         const float* save_mean, const float* save_invstd, int64_t M, int C, int relu, float* grad_x,
                         float* grad_residual, float* grad_gamma, float* grad_beta, double* acc, dsf_stream_t stream);
+/* dsf_bn_backward_pair on the accumulation rows (no finalise launch) */
+int dsf_bn_backward_acc_pair(const float* x, const float* grad_y, const float* grad_y2, const float* y, const float* gamma,
+                             const float* beta, const float* save_mean, const float* save_invstd, int64_t M, int C, int relu,
+                             float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta, double* acc,
+                             dsf_stream_t stream);
 
 /* ----------------------------------------------------------------------------------
  * Training-phase augmentation of cropped frames: `loader.augmentCrop`
