@@ -1404,6 +1404,18 @@ __global__ __launch_bounds__(256) void mfma_bf16_probe_kernel(const u32x4* __res
 
 }  // namespace
 
+// More than 64 KB of dynamic LDS needs hipFuncAttributeMaxDynamicSharedMemorySize, and the attribute is set for the device that is
+// current at the call: once per (kernel instantiation, device), a failure is not remembered (the next launch tries again).
+constexpr int X6_MAX_DEVICES = 16;
+static inline bool x6_arm_dynamic_lds(const void* fn, int bytes, bool* armed) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (dev >= 0 && dev < X6_MAX_DEVICES && armed[dev]) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (dev >= 0 && dev < X6_MAX_DEVICES) armed[dev] = true;
+    return true;
+}
+
 extern "C" {
 
 // operands: 1024 x 16 bytes of bf16 pairs; out: workgroups * 256 floats (ignored values); returns the MFMA count issued
@@ -1564,9 +1576,9 @@ static int x6_forward_impl(const float* X, const void* image, const float* bias,
 #define DSF_LAUNCH_X6P(BNv, BMv, Wv, NWv, BDv, NTv)                                                                               \
     do {                                                                                                                          \
         using PT = X6Patch<BMv, Wv, NTv>;                                                                                         \
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_x6p_kernel<BNv, BMv, Wv, NWv, BDv, NTv>), \
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, PT::LDS_BYTES);            \
-        if (attr != hipSuccess) return DSF_ERR_LAUNCH;                                                                            \
+        static bool armed[X6_MAX_DEVICES];                   /* per device: the attribute belongs to the device that was current */ \
+        if (!x6_arm_dynamic_lds(reinterpret_cast<const void*>(&igemm_x6p_kernel<BNv, BMv, Wv, NWv, BDv, NTv>), PT::LDS_BYTES, armed)) \
+            return DSF_ERR_LAUNCH;                                                                                                 \
         hipLaunchKernelGGL((igemm_x6p_kernel<BNv, BMv, Wv, NWv, BDv, NTv>), grid, dim3(256), PT::LDS_BYTES, (hipStream_t)stream,  \
                            X, (const uint4*)image, bias, Y, p, m_tiles, n_tiles, k_splits, (uint32_t)x_bytes, (uint32_t)w_bytes,  \
                            stats, ep);                                                                                            \
@@ -1765,9 +1777,9 @@ static int x6_wrw_impl(const float* X, const float* dY, float* dW, float* dbias,
 #define DSF_LAUNCH_WRWP(Wv, BNv)                                                                                                  \
     do {                                                                                                                          \
         using PT = X6WrwPatch<Wv>;                                                                                                \
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wrw_x6p_kernel<Wv, BNv>),         \
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, PT::LDS_BYTES);            \
-        if (attr != hipSuccess) return DSF_ERR_LAUNCH;                                                                            \
+        static bool armed[X6_MAX_DEVICES];                                                                                        \
+        if (!x6_arm_dynamic_lds(reinterpret_cast<const void*>(&igemm_wrw_x6p_kernel<Wv, BNv>), PT::LDS_BYTES, armed))             \
+            return DSF_ERR_LAUNCH;                                                                                                 \
         hipLaunchKernelGGL((igemm_wrw_x6p_kernel<Wv, BNv>), dim3(c_tiles * pn_tiles * psplits), dim3(256), PT::LDS_BYTES,        \
                            (hipStream_t)stream, X, dY, dW, p, c_tiles, pn_tiles, psplits, rows, (uint32_t)x_bytes,               \
                            (uint32_t)dy_bytes, partial);                                                                          \

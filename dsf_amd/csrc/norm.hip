@@ -257,7 +257,7 @@ template <bool NT> __device__ __forceinline__ void bn_st4(float* __restrict__ p,
 }
 // VAR (tuning aid DSF_BN_VAR, read per call): bit 0 = non-temporal loads, bit 1 = non-temporal stores, bit 2 = the next batch of
 // loads is issued BEFORE the current one is processed and stored (two register sets)
-constexpr int BN_VAR_DEFAULT = 0;
+constexpr int BN_VAR_DEFAULT = 3;     // non-temporal loads and stores (in-step A/B, one box: config 4 157.6 -> 155.9 ms, config 5 78.5 -> 77.7, config 2 unchanged; the prefetching variants 4 / 7 bring nothing more)
 // DSF_BN_WRITE_G=0 (tuning aid, read per call): the sums pass does not write the masked gradient, the apply pass re-reads gy (+ gy2) and y
 static inline bool bn_write_g() { const char* e = getenv("DSF_BN_WRITE_G"); return !e || atoi(e) != 0; }
 static inline int bn_var() { const char* e = getenv("DSF_BN_VAR"); const int v = e ? atoi(e) : BN_VAR_DEFAULT; return (v < 0 || v > 7) ? BN_VAR_DEFAULT : v; }

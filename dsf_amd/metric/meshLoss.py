@@ -28,13 +28,16 @@ _PART_CACHE = {}
 
 
 def _cached_parts(faces_list, device):
-    key = (tuple((f.data_ptr(), int(f.shape[0])) for f in faces_list), str(device))
+    """the int32 table of a list of face tensors, cached per list.  The entry HOLDS the face tensors it was built from (so
+    their addresses cannot be handed to other tensors while it lives) and the key carries their version counters (an in-place
+    edit of a face list makes a new entry): a table is never served for other faces than those it was built from."""
+    key = (tuple((f.data_ptr(), int(f.shape[0]), f._version) for f in faces_list), str(device))
     hit = _PART_CACHE.get(key)
     if hit is None:
         if len(_PART_CACHE) > 64:
             _PART_CACHE.clear()
-        hit = _PART_CACHE[key] = _as_parts(faces_list, device)
-    return hit
+        hit = _PART_CACHE[key] = _as_parts(faces_list, device) + (tuple(faces_list),)
+    return hit[0], hit[1]
 
 
 def _masked_part_mean(dis, pcl_seg, n_parts):

@@ -363,11 +363,21 @@ class grad_pool:
         _POOL = self.saved
 
 
+def _pow2_at_least(v, floor):
+    v = max(int(v), floor)
+    return 1 << (v - 1).bit_length()
+
+
+# slice alignment of the gradient pool in floats (DSF_POOL_ALIGN: tuning aid, read once; rounded up to a power of two >= 4 -- it
+# is used as a mask, and any other value would make slices overlap)
+_POOL_ALIGN = _pow2_at_least(os.environ.get("DSF_POOL_ALIGN", "64") or 64, 4)
+
+
 def _pool_take(n, device):
     if _POOL is None or _POOL[0].device != device:
         return None
     off = _POOL[1]
-    a = int(os.environ.get("DSF_POOL_ALIGN", "64")) - 1  # (tuning aid, floats) 256-byte slices: a 32-lane row of float atomics never straddles a cache line
+    a = _POOL_ALIGN - 1                                  # 256-byte slices: a 32-lane row of float atomics never straddles a cache line
     end = off + ((n + a) & ~a)
     if end > _POOL[0].numel():
         return None
@@ -517,10 +527,10 @@ class Conv2dFunction(Function):
                 # everything under DSF_WRW_STREAM=0): on the side stream nothing orders the bias's AccumulateGrad behind it
                 on = BIAS_IN_WRW[0] if BIAS_IN_WRW[0] is not None else os.environ.get("DSF_BIAS_IN_WRW", "1") == "1"
                 want_db = has_bias and ctx.needs_input_grad[2] and on
-                main = torch.cuda.current_stream() if want_db else None
+                main = stream_ptr().value if want_db else None      # (raw handles: a torch Stream object costs ~9 us to build)
                 cell = [None]
                 dw = _wrw_dispatch(weight, lambda: _wrw(x, gy, KH, KW, stride, padding,
-                                                        dbias=cell if (want_db and torch.cuda.current_stream() == main) else None),
+                                                        dbias=cell if (want_db and stream_ptr().value == main) else None),
                                    lambda acc: _wrw(x, gy, KH, KW, stride, padding, out=acc), (x, gy),
                                    work=2.0 * gy.numel() * Ci * KH * KW)
                 gb = cell[0]

@@ -271,3 +271,23 @@ def test_lanes_tool_accounts_for_every_nanosecond(tmp_path, capsys):
     assert "alone in flight, by workgroup count: 1+: 2.00 ms, 16+: 0.00 ms, 64+: 0.00 ms, 256+: 6.00 ms, 1024+: 0.00 ms" in out
     assert "alone    6.00 ms in    2 intervals  big_kernel<4>" in out
     assert "2 idle gaps, 7.00 ms in total, median 4000.0 us, 2 above 10 us" in out
+
+
+def test_part_table_cache_never_serves_a_stale_table():
+    """dsf_amd/metric/meshLoss.py::_cached_parts (round-5 verdict): the cache entry holds the face tensors it was built from (their
+    addresses cannot be reused while it lives) and follows in-place edits through the version counters."""
+    from dsf_amd.metric import meshLoss
+    meshLoss._PART_CACHE.clear()
+    a = [torch.tensor([[0, 1, 2], [2, 3, 0]]), torch.tensor([[4, 5, 6]])]
+    cat, first = meshLoss._cached_parts(a, "cpu")
+    assert cat.tolist() == [[0, 1, 2], [2, 3, 0], [4, 5, 6]] and first.tolist() == [0, 2, 3]
+    assert meshLoss._cached_parts(a, "cpu")[0] is cat                      # served from the cache
+    a[1][0, 0] = 7                                                        # in-place edit: a new entry
+    assert meshLoss._cached_parts(a, "cpu")[0].tolist()[2] == [7, 5, 6]
+    held = [t for e in meshLoss._PART_CACHE.values() for t in e[2]]
+    assert any(t is a[0] for t in held)                                   # the entry keeps its sources alive
+    addr = a[0].data_ptr()
+    del a, held
+    b = [torch.tensor([[9, 9, 9], [8, 8, 8]]), torch.tensor([[1, 1, 1]])]
+    assert b[0].data_ptr() != addr or meshLoss._cached_parts(b, "cpu")[0].tolist()[0] == [9, 9, 9]
+    assert meshLoss._cached_parts(b, "cpu")[0].tolist() == [[9, 9, 9], [8, 8, 8], [1, 1, 1]]

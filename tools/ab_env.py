@@ -17,6 +17,14 @@ ap.add_argument("--block", type=int, default=10)
 ap.add_argument("--rounds", type=int, default=6)
 ap.add_argument("--init", default="fresh")
 a = ap.parse_args()
+def sync_python_switches():
+    """switches that the Python side reads once at import (module-level lists): follow the environment"""
+    from dsf_amd import nn_norm
+    for name, cell in (("DSF_BN_TWIN", nn_norm.TWIN), ("DSF_BN_EPILOGUE", nn_norm.EPILOGUE_STATS)):
+        if name in os.environ:
+            cell[0] = os.environ[name] == "1"
+
+
 args = types.SimpleNamespace(config=a.config, batch=0, backbone="", graph=False, no_graph=False, cpu_steps=0, init=a.init)
 dev = torch.device("cuda", 0)
 os.environ[a.var] = a.values[0]
@@ -24,6 +32,7 @@ w = bench.build_workload(args, dev, 0, 1)
 runs = {}
 for v in a.values:
     os.environ[a.var] = v
+    sync_python_switches()
     if a.config == 3:
         from dsf_amd.train_step import GraphedStep
         g = GraphedStep(w["step"], w["tgt"])
@@ -37,6 +46,7 @@ tot = {v: [] for v in a.values}
 for r in range(a.rounds):
     for v in (a.values if r % 2 == 0 else a.values[::-1]):
         os.environ[a.var] = v
+        sync_python_switches()
         runs[v]()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
