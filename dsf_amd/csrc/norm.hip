@@ -26,6 +26,7 @@ struct BnFinal {
     float* mean; float* invstd; float* running_mean; float* running_var;
     // MODE 1
     double* sums; float* dgamma; float* dbeta;
+    int accum = 0;          // dgamma / dbeta are ADDED to what the buffers hold (a second application of the layer in one backward pass)
 };
 
 // G2: the incoming gradient is the SUM of two tensors, gy + gy2 (the fan-in of a block output that feeds the next block's first
@@ -175,8 +176,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
         } else {
             fin.sums[c] = s0;
             fin.sums[C + c] = s1;
-            if (fin.dbeta) fin.dbeta[c] = (float)s0;
-            if (fin.dgamma) fin.dgamma[c] = (float)s1;
+            if (fin.dbeta) fin.dbeta[c] = (fin.accum ? fin.dbeta[c] : 0.f) + (float)s0;
+            if (fin.dgamma) fin.dgamma[c] = (fin.accum ? fin.dgamma[c] : 0.f) + (float)s1;
         }
     }
 }
@@ -416,8 +417,8 @@ __global__ __launch_bounds__(256, G2 ? 3 : ((VAR & 4) ? 4 : 5)) void bn_bwd_appl
         if (owner && i0 < c4n) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                if (fin.dbeta) fin.dbeta[c + k] = (float)f0[k];
-                if (fin.dgamma) fin.dgamma[c + k] = (float)f1[k];
+                if (fin.dbeta) fin.dbeta[c + k] = (fin.accum ? fin.dbeta[c + k] : 0.f) + (float)f0[k];
+                if (fin.dgamma) fin.dgamma[c + k] = (fin.accum ? fin.dgamma[c + k] : 0.f) + (float)f1[k];
             }
         }
     }
@@ -620,8 +621,8 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (t == 0) {
-            if (fin.dbeta) fin.dbeta[c + k] = (float)v[k];
-            if (fin.dgamma) fin.dgamma[c + k] = (float)v[4 + k];
+            if (fin.dbeta) fin.dbeta[c + k] = (fin.accum ? fin.dbeta[c + k] : 0.f) + (float)v[k];
+            if (fin.dgamma) fin.dgamma[c + k] = (fin.accum ? fin.dgamma[c + k] : 0.f) + (float)v[4 + k];
         }
         m0[k] = (float)v[k] * invM; m1[k] = (float)v[4 + k] * invM;
     }
@@ -930,10 +931,10 @@ extern "C" int dsf_bn_apply(const float* x, const float* residual, const float* 
 static int bn_backward_ordered(const float* x, const float* grad_y, const float* grad_y2, const float* y, const float* gamma, const float* beta,
                                const float* save_mean, const float* save_invstd, int64_t M, int C, int relu,
                                float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta,
-                               double* workspace, hipStream_t st) {
+                               double* workspace, hipStream_t st, int accumulate_affine = 0) {
     const int rows = bn_rows_per_wg(M, C);
     const int wgs = (int)((M + rows - 1) / rows);
-    BnFinal fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, workspace, grad_gamma, grad_beta};
+    BnFinal fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, workspace, grad_gamma, grad_beta, accumulate_affine};
     if (bn_small_ok(M, C)) {
         bn_small_backward(x, grad_y, y, save_mean, save_invstd, gamma, beta, M, C, relu, grad_x, grad_residual, fin, st, grad_y2);
         return dsf_launch_status();
@@ -965,13 +966,13 @@ extern "C" int dsf_bn_backward(const float* x, const float* grad_y, const float*
 
 extern "C" int dsf_bn_backward_pair(const float* x, const float* grad_y, const float* grad_y2, const float* y, const float* gamma,
                                     const float* beta, const float* save_mean, const float* save_invstd, int64_t M, int C, int relu,
-                                    float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta, double* workspace,
-                                    dsf_stream_t stream) {
+                                    float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta, int accumulate_affine,
+                                    double* workspace, dsf_stream_t stream) {
     DSF_CHECK_ARG(x && grad_y && save_mean && save_invstd && grad_x && workspace && M > 0 && relu >= 0 && relu <= 2 &&
                   (relu != 1 || y));
     if (!bn_shape_ok(C)) return DSF_ERR_UNSUPPORTED;
     return bn_backward_ordered(x, grad_y, grad_y2, y, gamma, beta, save_mean, save_invstd, M, C, relu, grad_x, grad_residual, grad_gamma,
-                               grad_beta, workspace, (hipStream_t)stream);
+                               grad_beta, workspace, (hipStream_t)stream, accumulate_affine);
 }
 
 // ---- the same passes WITHOUT the finalise launches (default, float-atomic mode) --------------------------------------
@@ -1011,7 +1012,8 @@ extern "C" int dsf_bn_forward_acc(const float* x, const float* residual, const f
 
 static int bn_backward_acc_impl(const float* x, const float* grad_y, const float* grad_y2, const float* y, const float* gamma, const float* beta,
                                 const float* save_mean, const float* save_invstd, int64_t M, int C, int relu, float* grad_x,
-                                float* grad_residual, float* grad_gamma, float* grad_beta, double* acc, hipStream_t st) {
+                                float* grad_residual, float* grad_gamma, float* grad_beta, double* acc, hipStream_t st,
+                                int accumulate_affine = 0) {
     // 1024 reduction workgroups (DSF_BN_BWD_WGS: tuning aid, read per call): on the B = 192 tensors (800 MB) 512 left the pass at
     // 2.7-3.4 TB/s -- config 4 165.4 -> 163.5 ms per step with 1024, 2048 and 4096 alike; the B = 32 step does not care.  Eight rows
     // in flight per lane instead of four: no gain (162.5 vs 163.6 ms)
@@ -1020,7 +1022,7 @@ static int bn_backward_acc_impl(const float* x, const float* grad_y, const float
     if (max_wgs < 1) max_wgs = 1024;                                 // (0 / garbage would divide by zero in bn_rows_per_wg)
     const int rows = bn_rows_per_wg(M, C, max_wgs);
     const int wgs = (int)((M + rows - 1) / rows);
-    BnFinal fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, grad_gamma, grad_beta};
+    BnFinal fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, grad_gamma, grad_beta, accumulate_affine};
     if (bn_small_ok(M, C)) {                                         // both sums + apply in one launch (`acc` stays untouched)
         bn_small_backward(x, grad_y, y, save_mean, save_invstd, gamma, beta, M, C, relu, grad_x, grad_residual, fin, st, grad_y2);
         return dsf_launch_status();
@@ -1049,12 +1051,12 @@ extern "C" int dsf_bn_backward_acc(const float* x, const float* grad_y, const fl
 
 extern "C" int dsf_bn_backward_acc_pair(const float* x, const float* grad_y, const float* grad_y2, const float* y, const float* gamma,
                                         const float* beta, const float* save_mean, const float* save_invstd, int64_t M, int C, int relu,
-                                        float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta, double* acc,
-                                        dsf_stream_t stream) {
+                                        float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta, int accumulate_affine,
+                                        double* acc, dsf_stream_t stream) {
     DSF_CHECK_ARG(x && grad_y && save_mean && save_invstd && grad_x && acc && M > 0 && relu >= 0 && relu <= 2 && (relu != 1 || y));
     if (!bn_shape_ok(C) || dsf_deterministic()) return DSF_ERR_UNSUPPORTED;
     return bn_backward_acc_impl(x, grad_y, grad_y2, y, gamma, beta, save_mean, save_invstd, M, C, relu, grad_x, grad_residual, grad_gamma,
-                                grad_beta, acc, (hipStream_t)stream);
+                                grad_beta, acc, (hipStream_t)stream, accumulate_affine);
 }
 
 // ---- cross-replica BatchNorm (SyncBatchNorm): ONE exchange of 2C + 1 doubles per layer and pass -------------

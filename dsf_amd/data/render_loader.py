@@ -49,7 +49,7 @@ class loader:
 
     @staticmethod
     def _inv(M):
-        return torch.linalg.inv_ex(M.reshape(-1, 3, 3).float())[0]
+        return ops.inverse3x3(M)                 # once per M tensor (ops._memo)
 
     def uvd_nl2xyznl_tensor(self, uvd, center, m, cube):
         B = uvd.size(0)

@@ -43,13 +43,20 @@ MATH = os.environ.get("DSF_CONV_MATH", "x6")
 _EPOCH = 0
 
 
-def weights_changed():
+def weights_changed(params=None):
     """Called by whoever rewrites parameters behind torch's version counters (optim.FusedAdamW's raw-pointer kernel, the
     model builders' init_weights, user code that writes through ``.data``): bumps the global write epoch that every cache
-    keyed on parameter contents includes (the split weight images of conv_x6 here, the MANO layer's result memo)."""
+    keyed on parameter contents includes (the MANO layer's result memo, BatchNorm's folded affine) and invalidates the split
+    weight images of conv_x6 -- all of them, or with ``params`` (the writer knows exactly what it wrote: an optimizer) only
+    theirs, so that the images of parameters nobody touched (a frozen transfer generator beside the network being trained: 43
+    re-split launches per config-5 step until round 6) survive the step."""
     global _EPOCH
-    _EPOCH += 1
-    L.WRITE_EPOCH[0] = _EPOCH
+    L.WRITE_EPOCH[0] += 1
+    if params is None:
+        _EPOCH += 1
+    else:
+        for p in params:
+            p.__dict__["_dsf_wepoch"] = p.__dict__.get("_dsf_wepoch", 0) + 1
 
 
 def manage_weights(params, managed=True):
@@ -78,7 +85,7 @@ def _x6_image(weight, wk, mode):
     """bf16x3 image of ``wk`` = [KH][KW][Ci][Co] (a view of ``weight``'s memory): mode 0 the forward operand, mode 1
     the stride-1 backward-data operand.  Cached on the parameter until it changes; temporaries are split per call."""
     KH, KW, Ci, Co = wk.shape
-    key = (weight._version, _EPOCH, wk.data_ptr())
+    key = (weight._version, _EPOCH, weight.__dict__.get("_dsf_wepoch", 0), wk.data_ptr())
     cache = weight.__dict__.get("_dsf_x6")
     if cache is not None and mode in cache and cache[mode][0] == key and weight.__dict__.get("_dsf_managed", False):
         return cache[mode][1]
@@ -106,7 +113,7 @@ def refresh_images(params, owner=None):
         if not cache or not p.is_cuda:
             continue
         for mode, (key, img, (KH, KW, Ci, Co)) in cache.items():
-            if key[2] != p.data_ptr():                  # the parameter moved (re-laid out): its next use splits it lazily
+            if key[-1] != p.data_ptr():                 # the parameter moved (re-laid out): its next use splits it lazily
                 continue
             Ck, Cn = (Co, Ci) if mode else (Ci, Co)
             rows.append((p.data_ptr(), img.data_ptr(), KH, KW, Ci, Co, mode, total))
@@ -125,7 +132,7 @@ def refresh_images(params, owner=None):
     for p, mode in entries:
         cache = p.__dict__["_dsf_x6"]
         _, img, geom = cache[mode]
-        cache[mode] = ((p._version, _EPOCH, p.data_ptr()), img, geom)
+        cache[mode] = ((p._version, _EPOCH, p.__dict__.get("_dsf_wepoch", 0), p.data_ptr()), img, geom)
 
 
 class StatsRequest:
@@ -302,15 +309,17 @@ def _wrw_c1(x, gy, K, stride, pad):
     return dw
 
 
-def _wrw(x, gy, KH, KW, stride, pad, out=None, dbias=None):
+def _wrw(x, gy, KH, KW, stride, pad, out=None, dbias=None, param=None):
     """-> dW [KH][KW][Ci][Co] for x (B,Ci,Hi,Wi), gy (B,Co,Ho,Wo), both channels_last; ``out``: add into this dW instead.
+    ``param``: the weight this dW is the gradient of (kernel layout): under data parallelism dW is written into the weight's slot
+    of its all-reduce bucket (parallel.GradAllReducer.grad_slot) instead of the step's gradient pool.
     ``dbias``: a one-element list holding None -- when the split kernels run the launch (not in deterministic mode) it receives the
     bias gradient (Co floats from the zeroed gradient pool or a fresh zero vector), computed by the same launch."""
     B, Ci, Hi, Wi = x.shape
     _, Co, Ho, Wo = gy.shape
     if RECORD is not None:
         RECORD.append(("wrw", B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, 1, pad[0], pad[1]))
-    dw = _pool_take(KH * KW * Ci * Co, x.device) if out is None else out
+    dw = _grad_out(KH * KW * Ci * Co, x.device, param) if out is None else out
     pooled = dw is not None
     dw = dw.view(KH, KW, Ci, Co) if pooled else torch.empty((KH, KW, Ci, Co), device=x.device, dtype=torch.float32)
     # both operands are activations: conv_x6 splits them on the fly (Ci % 4 == 0 and Co % 4 == 0), else the fp32 MFMA kernel
@@ -356,6 +365,9 @@ class grad_pool:
         global _POOL
         self.saved = _POOL
         _POOL = [torch.zeros(self.n, device=self.device, dtype=torch.float32), 0] if self.n > 0 else None
+        from . import parallel
+        if parallel._ACTIVE:                             # data parallel: the reducers' bucket stores are zeroed for this pass
+            parallel.begin_backward()
         return self
 
     def __exit__(self, *a):
@@ -371,6 +383,19 @@ def _pow2_at_least(v, floor):
 # slice alignment of the gradient pool in floats (DSF_POOL_ALIGN: tuning aid, read once; rounded up to a power of two >= 4 -- it
 # is used as a mask, and any other value would make slices overlap)
 _POOL_ALIGN = _pow2_at_least(os.environ.get("DSF_POOL_ALIGN", "64") or 64, 4)
+
+
+def _grad_out(n, device, param=None):
+    """zeroed output (n floats) of a weight-gradient launch: the parameter's slot in its data-parallel bucket -- the gradient is
+    then written where the all-reduce reads it, and autograd adopts that view as ``.grad`` --, else a slice of the step's gradient
+    pool, else None (the caller allocates and the kernel overwrites)"""
+    if param is not None:
+        owner = param.__dict__.get("_dsf_grad_slot")
+        if owner is not None and param.dim() == 4 and param.permute(2, 3, 1, 0).is_contiguous():    # memory order [KH][KW][.][.]
+            v = owner.grad_slot(param)
+            if v is not None and v.device == device and v.numel() == n:
+                return v
+    return _pool_take(n, device)
 
 
 def _pool_take(n, device):
@@ -530,7 +555,7 @@ class Conv2dFunction(Function):
                 main = stream_ptr().value if want_db else None      # (raw handles: a torch Stream object costs ~9 us to build)
                 cell = [None]
                 dw = _wrw_dispatch(weight, lambda: _wrw(x, gy, KH, KW, stride, padding,
-                                                        dbias=cell if (want_db and stream_ptr().value == main) else None),
+                                                        dbias=cell if (want_db and stream_ptr().value == main) else None, param=weight),
                                    lambda acc: _wrw(x, gy, KH, KW, stride, padding, out=acc), (x, gy),
                                    work=2.0 * gy.numel() * Ci * KH * KW)
                 gb = cell[0]
@@ -750,7 +775,7 @@ class ConvTranspose2dFunction(Function):
             else:
                 gx = _fwd(gy, wd, None, (x.shape[2], x.shape[3]), Cin, KH, KW, stride, 1, padding)
         if ctx.needs_input_grad[1]:
-            dw = _wrw_dispatch(weight, lambda: _wrw(gy, x, KH, KW, stride, padding),
+            dw = _wrw_dispatch(weight, lambda: _wrw(gy, x, KH, KW, stride, padding, param=weight),
                                lambda acc: _wrw(gy, x, KH, KW, stride, padding, out=acc), (x, gy),
                                work=2.0 * x.numel() * Cout * KH * KW)
             gw = None if dw is False else dw.permute(3, 2, 0, 1)                               # [kh][kw][Cout][Cin] -> (Cin,Cout,kh,kw)

@@ -101,6 +101,9 @@ def stat_floats(module, applications=1):
 # and the backward receives the two gradients separately: its sums pass adds them on the fly (dsf_bn_backward_acc_pair).
 # DSF_BN_TWIN=0: one output, autograd adds.
 TWIN = [os.environ.get("DSF_BN_TWIN", "1") == "1"]
+# second application of a layer in one backward pass adds its dgamma / dbeta into the first one's buffers (DSF_BN_AFFINE_ACC=0: off)
+AFFINE_ACCUMULATE = [os.environ.get("DSF_BN_AFFINE_ACC", "1") == "1"]
+_TASK_ID = getattr(torch._C, "_current_graph_task_id", None)         # (private: the id of the running backward pass, -1 outside one)
 
 
 def _alias(y):
@@ -172,15 +175,33 @@ class _BNFunction(Function):
         gres_out = gres if gres is not gy else None
         gg = torch.empty(C, device=x.device, dtype=torch.float32) if has_g else None
         gb = torch.empty(C, device=x.device, dtype=torch.float32) if has_b else None
+        # A layer applied TWICE before one backward() (the network on the synthetic and on the real batch, train_render.py:628-703):
+        # the pass's first contribution to dgamma / dbeta is recorded on the parameter, the second ADDS into those buffers
+        # (accumulate_affine) and hands autograd nothing -- else the engine sums the two with a launch per parameter (~90 per
+        # config-5 step).  Same stream only (the engine holds the first buffer until every contribution has arrived).
+        accumulate, rec_key = 0, None
+        if has_g and has_b and _TASK_ID is not None and gamma.is_leaf and beta.is_leaf and AFFINE_ACCUMULATE[0]:
+            task, st_now = _TASK_ID(), stream_ptr().value
+            rec = gamma.__dict__.get("_dsf_bnpass")
+            if task >= 0 and rec is not None and rec[0] == task and rec[1] == st_now and rec[2].shape == gg.shape:
+                accumulate, gg_k, gb_k = 1, rec[2], rec[3]
+            elif task >= 0:
+                rec_key = (task, st_now)
         acc = _acc_take(C, x.device)
+        gg_w, gb_w = (gg_k, gb_k) if accumulate else (gg, gb)
         if acc is not None:
             check(L.lib().dsf_bn_backward_acc_pair(_p(x), _p(gy), _p(gy2), _p(y), _p(gamma), _p(beta), _p(mean), _p(invstd), I64(M), I(C),
-                                                   I(relu_mode), _p(gx), _p(gres_out), _p(gg), _p(gb), _p(acc), stream_ptr()),
+                                                   I(relu_mode), _p(gx), _p(gres_out), _p(gg_w), _p(gb_w), I(accumulate), _p(acc), stream_ptr()),
                   "dsf_bn_backward_acc_pair")
         else:
             ws = _workspace(x.device, C)
             check(L.lib().dsf_bn_backward_pair(_p(x), _p(gy), _p(gy2), _p(y), _p(gamma), _p(beta), _p(mean), _p(invstd), I64(M), I(C),
-                                               I(relu_mode), _p(gx), _p(gres_out), _p(gg), _p(gb), _p(ws), stream_ptr()), "dsf_bn_backward_pair")
+                                               I(relu_mode), _p(gx), _p(gres_out), _p(gg_w), _p(gb_w), I(accumulate), _p(ws), stream_ptr()),
+                  "dsf_bn_backward_pair")
+        if accumulate:
+            gg = gb = None                                    # added into the buffers the first contribution handed to autograd
+        elif rec_key is not None:
+            gamma.__dict__["_dsf_bnpass"] = rec_key + (gg, gb)
         return (gx, gres, gg, gb) + (None,) * (n_in - 4)
 
 
@@ -356,10 +377,13 @@ class FusedSyncBatchNorm2d(FusedBatchNorm2d):
     ``forward(x, residual=None, relu=None, stats=None)`` as the module it replaces (parallel.convert_sync_batchnorm swaps the
     class in place).  Single-rank groups and evaluation mode fall through to FusedBatchNorm2d."""
     process_group = None
+    force_sync = False            # True: the cross-replica passes (and their collectives) also run in a ONE-rank group (tests/test_gpu_rccl.py)
 
     def forward(self, x, residual=None, relu=None, stats=None, twin=False):
         import torch.distributed as dist
         world = dist.get_world_size(self.process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        if self.force_sync and dist.is_available() and dist.is_initialized():
+            world = max(world, 2)
         if not (self.training and self.track_running_stats and world > 1 and x.is_cuda and x.dtype == torch.float32 and
                 supported(x.shape[1]) and x.numel() > 0 and self.momentum is not None):
             return super().forward(x, residual, relu, stats, twin)

@@ -130,6 +130,7 @@ class FusedAdamW(torch.optim.Optimizer):
                                               D(group["weight_decay"]), D(1.0 - math.pow(b1, step)), D(1.0 - math.pow(b2, step)),
                                               stream_ptr()), "dsf_adamw_multi")
         from . import nn_conv
-        nn_conv.weights_changed()            # the kernel wrote the parameters behind torch's version counters
-        nn_conv.refresh_images([p for g in self.param_groups for p in g["params"]], owner=self)     # one launch
+        mine = [p for g in self.param_groups for p in g["params"]]
+        nn_conv.weights_changed(mine)        # the kernel wrote THESE parameters behind torch's version counters
+        nn_conv.refresh_images(mine, owner=self)     # one launch
         return loss

@@ -391,7 +391,7 @@ class Render(nn.Module):
     def _inverse(self, M, minv_closed):
         if self.inverse == 'closed' and minv_closed is not None:
             return minv_closed
-        return torch.linalg.inv_ex(M)[0]         # same LAPACK-style routine as torch.inverse, no host sync
+        return ops.inverse3x3(M)                 # same LAPACK-style routine as torch.inverse, no host sync; once per M tensor
 
     def _depth_crop(self, hand_verts, center3d, cube_size, M=None, normalise=True):
         center2d, M_auto, _, minv_c = ops.crop_setup(center3d, cube_size, self.cam, self.crop_size[0],
@@ -400,7 +400,7 @@ class Render(nn.Module):
             M = M_auto
             minv = self._inverse(M, minv_c)
         else:
-            minv = torch.linalg.inv_ex(M.float())[0]
+            minv = ops.inverse3x3(M)
         cz = center2d[:, 2].contiguous() if normalise else None
         cbz = cube_size[:, 2].contiguous() if normalise else None
         img, p2f = ops.RenderCropFunction.apply(hand_verts, self.mano_layer.faces_i32, minv, self.resize_rowmap, cz, cbz,

@@ -450,11 +450,14 @@ int dsf_bn_backward(const float* x, const float* grad_y, const float* y, const f
  * block feeds the next block's first convolution AND its identity path (model/resnet.py:39-55, 78-98: `out += identity`), so
  * autograd would sum the two gradients with an elementwise pass of its own (2 reads + 1 write of the activation) before this
  * backward could run.  Here the sums pass adds them on the fly; when grad_residual is wanted it also WRITES the (masked) g
- * there and the apply pass reads x and that tensor only.  Same arithmetic as torch's add followed by dsf_bn_backward. */
+ * there and the apply pass reads x and that tensor only.  Same arithmetic as torch's add followed by dsf_bn_backward.
+ * accumulate_affine != 0: grad_gamma / grad_beta are ADDED to what the buffers hold -- the second application of one layer in a
+ * backward pass (train_render.py:628-703 runs the network on the synthetic and on the real batch before one `backward()`), whose
+ * contribution autograd would otherwise add with a launch per parameter. */
 int dsf_bn_backward_pair(const float* x, const float* grad_y, const float* grad_y2, const float* y, const float* gamma,
                          const float* beta, const float* save_mean, const float* save_invstd, int64_t M, int C, int relu,
-                         float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta, double* workspace,
-                         dsf_stream_t stream);
+                         float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta, int accumulate_affine,
+                         double* workspace, dsf_stream_t stream);
 
 /* out[c] = sum_m x[m][c] of a row-major (M, C) matrix (bias gradient of an NHWC convolution output:
  * the `gy.sum((0,2,3))` of nn.Conv2d's backward).  workspace: dsf_col_sum_workspace_bytes(C) bytes of 16-byte
@@ -554,8 +557,8 @@ int dsf_bn_backward_acc(const float* x, const float* grad_y, const float* y, con
 /* dsf_bn_backward_pair on the accumulation rows (no finalise launch) */
 int dsf_bn_backward_acc_pair(const float* x, const float* grad_y, const float* grad_y2, const float* y, const float* gamma,
                              const float* beta, const float* save_mean, const float* save_invstd, int64_t M, int C, int relu,
-                             float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta, double* acc,
-                             dsf_stream_t stream);
+                             float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta, int accumulate_affine,
+                             double* acc, dsf_stream_t stream);
 
 /* ----------------------------------------------------------------------------------
  * Training-phase augmentation of cropped frames: `loader.augmentCrop`

@@ -100,7 +100,7 @@ def test_pair_entry_point_equals_the_presummed_gradient_bitwise(M, C, relu, res,
         gg, gbt = torch.empty(C, device=dev), torch.empty(C, device=dev)
         if fn_pair:
             L.check(L.lib().dsf_bn_backward_pair(_p(x), _p(ga), _p(gb), _p(y), _p(gamma), _p(beta), _p(mean), _p(invstd), I64(M), I(C), I(relu),
-                                                 _p(gx), _p(gr), _p(gg), _p(gbt), _p(ws), st()), "dsf_bn_backward_pair")
+                                                 _p(gx), _p(gr), _p(gg), _p(gbt), I(0), _p(ws), st()), "dsf_bn_backward_pair")
         else:
             gs = ga + gb
             L.check(L.lib().dsf_bn_backward(_p(x), _p(gs), _p(y), _p(gamma), _p(beta), _p(mean), _p(invstd), I64(M), I(C), I(relu),

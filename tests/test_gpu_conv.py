@@ -524,6 +524,19 @@ def test_x6_weight_images_follow_the_weights(monkeypatch):
     conv.weight.data.mul_(0.5)
     nn_conv.weights_changed()                               # the documented way to announce a .data write on managed weights
     assert _rel(conv(x).double(), ref()) < 2e-6
+    # a frozen, managed layer beside the optimizer's (the transfer generator of FinetuneStageStep): the optimizer announces ITS
+    # parameters only, so the bystander's image survives the step (round 5 re-split all 43 generator layers every step) ...
+    frozen = nn_conv.Conv2d(32, 32, 3, padding=1, bias=False).cuda().requires_grad_(False)
+    nn_conv.manage_weights(frozen.parameters())
+    yf = frozen(x)
+    entry = frozen.weight.__dict__["_dsf_x6"][0]
+    conv(x).square().mean().backward()
+    opt.step()
+    assert torch.equal(frozen(x), yf) and frozen.weight.__dict__["_dsf_x6"][0] is entry
+    # ... and an unannounced write somewhere (weights_changed() without arguments) still invalidates it
+    frozen.weight.data.mul_(3.0)
+    nn_conv.weights_changed()
+    assert _rel(frozen(x).double(), F.conv2d(x.double(), frozen.weight.detach().double(), padding=1)) < 2e-6
 
 
 def test_x6_random_geometries_against_float64():

@@ -85,6 +85,59 @@ out["eager_r18_gradients_bitwise"] = ok_g
 out["eager_r18_parameters_bitwise_after_3_steps"] = ok_w
 out["eager_r18_collectives_launched_from_hooks"] = launched
 out["eager_r18_buckets"] = len(sync.buckets)
+sync.detach()
+
+# ---- 1b. the default 32 MiB buckets: weight gradients are written INTO the persistent bucket store (no pack) ---------------------
+net_c, net_d = build18(), build18()
+step_c = RenderSupervisedStep(net_c, render, Config)
+sync32 = GradAllReducer(net_d.parameters(), force=True)                       # bucket_bytes = 32 MiB
+step_d = RenderSupervisedStep(net_d, render, Config, grad_sync=sync32)
+ok32, in_place, same_addr = True, 0, True
+addr = None
+for it in range(3):
+    lc_, _ = step_c.forward_backward(tgt)
+    gc_ = grads_of(net_c)
+    step_c.opt.step()
+    ld_, _ = step_d.forward_backward(tgt)
+    # gradients that autograd adopted straight from their bucket slot (written there by the backward-weights kernels)
+    in_place = sum(1 for q in sync32.params if q.grad is not None and q.grad.data_ptr() == sync32._view(q).data_ptr())
+    sync32.finish()
+    gd_ = grads_of(net_d)
+    now = [q.grad.data_ptr() for q in sync32.params if q.grad is not None]
+    same_addr &= addr is None or addr == now                                   # persistent slots: the optimizer's pointer table never changes
+    addr = now
+    step_d.opt.step()
+    torch.cuda.synchronize()
+    ok32 &= same(gc_, gd_) and bool(torch.equal(lc_, ld_)) and all(torch.equal(x, y) for x, y in zip(net_c.parameters(), net_d.parameters()))
+out["default_buckets"] = len(sync32.buckets)
+out["default_buckets_bitwise_3_steps"] = ok32
+out["default_buckets_gradients_written_in_place_before_finish"] = in_place
+out["default_buckets_gradient_addresses_persistent"] = same_addr
+out["default_buckets_all_gradients_in_store"] = all(q.grad.data_ptr() == sync32._view(q).data_ptr() for q in sync32.params if q.grad is not None)
+sync32.detach()
+
+# ---- 1c. FusedSyncBatchNorm2d's collectives on RCCL (forced at world size 1): = the per-replica fused BatchNorm ---------------------
+from dsf_amd.parallel import convert_sync_batchnorm
+from dsf_amd.nn_norm import FusedSyncBatchNorm2d
+net_e, net_f = build18(), build18()
+convert_sync_batchnorm(net_f)
+FusedSyncBatchNorm2d.force_sync = True
+n_sync = sum(isinstance(m, FusedSyncBatchNorm2d) for m in net_f.modules())
+step_e = RenderSupervisedStep(net_e, render, Config)
+step_f = RenderSupervisedStep(net_f, render, Config, grad_sync=GradAllReducer(net_f.parameters(), force=True))
+le_, _ = step_e.forward_backward(tgt)
+lf_, _ = step_f.forward_backward(tgt)
+step_f.grad_sync.finish()
+torch.cuda.synchronize()
+num = sum(((a_.grad - b_.grad).double() ** 2).sum() for a_, b_ in zip(net_e.parameters(), net_f.parameters()))
+den = sum((a_.grad.double() ** 2).sum() for a_ in net_e.parameters())
+out["syncbn_modules"] = n_sync
+out["syncbn_loss_rel"] = abs(float(le_) - float(lf_)) / abs(float(le_))
+out["syncbn_grad_rel"] = float((num / den) ** 0.5)
+out["syncbn_running_stats_rel"] = max(float((a_ - b_).abs().max() / a_.abs().max().clamp_min(1e-12)) for (k_, a_), (_, b_) in
+                                      zip(net_e.state_dict().items(), net_f.state_dict().items()) if "running" in k_)
+FusedSyncBatchNorm2d.force_sync = False
+step_f.grad_sync.detach()
 
 # ---- 2. forked streams (hourglass arms run backward nodes on branch streams) under the reducer, eager --------------------------
 def build_hg():
@@ -183,3 +236,11 @@ def test_gradient_all_reduce_on_rccl_at_world_size_one(tmp_path):
     assert res["forked_hourglass_arrival_streams"] >= 2, res          # gradients really arrived on more than one stream
     assert res["graphed_step_loss_bitwise"] and res["graphed_step_parameters_bitwise_after_3_steps"] and res["hooks_left_enabled"], res
     assert res["detach_removed_marks"], res
+    # round 6: the in-place buckets at their default size, and the cross-replica BatchNorm's collectives on RCCL
+    assert res["default_buckets"] <= 6 and res["default_buckets_bitwise_3_steps"], res
+    assert res["default_buckets_gradients_written_in_place_before_finish"] >= 30, res       # the convolution weights' dW
+    assert res["default_buckets_gradient_addresses_persistent"] and res["default_buckets_all_gradients_in_store"], res
+    assert res["syncbn_modules"] >= 40 and res["syncbn_loss_rel"] < 1e-5 and res["syncbn_running_stats_rel"] < 1e-5, res
+    # (same forward to the bit; the backward sums are folded in another order -- fp32 rounding through ~40 BatchNorm layers at B = 4: the
+    #  bar of tests/test_gpu_determinism.py's cross-path comparisons)
+    assert res["syncbn_grad_rel"] < 2e-2, res

@@ -566,6 +566,34 @@ def test_finetune_single_stage_step_vs_oracle(render, orender, fitted):
 # ------------------------------------------------------------------------------------------------
 # full-size property runs (per-GPU share of each config)
 # ------------------------------------------------------------------------------------------------
+def test_config2_full_size_properties(render):
+    """The headline configuration at its full size (bench.py's default workload: B = 32, ResNet-18 two-stage + MANO + rasteriser,
+    the whole optimizer step): every loss term finite, the loss falls within 60 steps, gradients reach every trunk (both
+    stages, the decoder, the heads and the MANO heads), and the residual blocks run with their twin outputs."""
+    from dsf_amd.model.backbone import MANO_OCR_stage
+    from dsf_amd.train_step import RenderSupervisedStep, synthetic_batch, Config
+    from dsf_amd import nn_norm
+    torch.manual_seed(0)
+    net = MANO_OCR_stage("ResNet_stage_18", 21, True).cuda()
+    step = RenderSupervisedStep(net, render, Config)
+    p, c, cube = synthetic_batch(32, "cuda", seed=0)
+    tgt = step.make_targets(p, c, cube, seed=1)
+    assert tgt["img"].shape == (32, 1, 128, 128) and float((tgt["img"] < 0.99).float().mean()) > 0.02
+    l0, terms = step(tgt)
+    assert len(terms) == 13 and all(torch.isfinite(v) for v in terms.values()) and torch.isfinite(l0)
+    grads = {n: q.grad for n, q in net.named_parameters()}
+    assert all(g is not None and torch.isfinite(g).all() for g in grads.values())
+    for n in ("pre.0.weight", "layer1.0.conv1.weight", "layer4.1.conv2.weight", "deconv_layer2.0.weight", "finals.0.weight", "mano_regress.2.weight",
+              "fusion.0.weight", "layer1_s2.0.conv1.weight", "layer2_s2.0.downsample.0.weight", "layer4_s2.1.bn2.weight", "deconv_layer4_s2.0.weight",
+              "finals_s2.1.bias", "mano_regress_s2.2.bias"):
+        assert float(grads[n].abs().sum()) > 0, n
+    hist = [float(step(tgt)[0]) for _ in range(60)]          # (AdamW at lr 1e-3 from random init: the first steps overshoot, then it falls)
+    assert all(np.isfinite(hist)) and min(hist[-20:]) < float(l0)
+    if nn_norm.TWIN[0]:                                       # the block outputs are handed out twice (nn_norm.take_twin)
+        x = torch.randn(2, 64, 16, 16, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        assert "_dsf_twin" in net.layer1[0](x).__dict__
+
+
 def test_config3_full_size_properties(render):
     from dsf_amd.model.hourglass import PoseNetMANO
     from dsf_amd.train_step import MeshLossStep, synthetic_batch, Config

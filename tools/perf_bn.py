@@ -82,7 +82,7 @@ def main():
 
         def bwd(relu, res, pair):
             return lambda: lib.dsf_bn_backward_acc_pair(_p(x), _p(ga), _p(gb if pair else None), _p(y), _p(gamma), _p(beta), _p(mean), _p(invstd), I64(M), I(C),
-                                                        I(relu), _p(gx), _p(gr if res else None), _p(gg), _p(gbt), _p(acc), st())
+                                                        I(relu), _p(gx), _p(gr if res else None), _p(gg), _p(gbt), I(0), _p(acc), st())
 
         def add_then_bwd():
             def f():
