@@ -18,7 +18,7 @@ mkdir -p $OUT
 # isa_lint.py below disassembles the linked library and fails the build on any packed-FP32 or scratch instruction.
 # Cost: none measurable (round 4: non-convolution sources +0.03 ms of a 19.5 ms step, the convolution sources -0.1 ... -0.2 ms).
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fno-vectorize -Wall -Wno-unused-function"
-SRCS="api mano raster pfd hand_geom image_ops data_ops conv conv_x6 conv_c1 norm loss optim pool volume"
+SRCS="api mano raster pfd hand_geom image_ops data_ops conv conv_x6 conv_c1 norm loss optim pool volume step_ops"
 if [ "$(cat $OUT/.flags 2>/dev/null)" != "$FLAGS" ]; then
   rm -f $OUT/*.o
   echo "$FLAGS" > $OUT/.flags

@@ -42,6 +42,8 @@ def _cached_parts(faces_list, device):
 
 def _masked_part_mean(dis, pcl_seg, n_parts):
     """mean over the points of part j with dis > 0, 0 when there are none (reference :389-394)."""
+    if dis.is_cuda and dis.dtype == torch.float32 and pcl_seg.dtype == torch.int64 and n_parts <= 16 and dis.dim() == 2:
+        return ops.PartMean.apply(dis, pcl_seg, n_parts)     # one launch each way (csrc/step_ops.hip)
     labels = torch.arange(1, n_parts + 1, device=dis.device).view(1, n_parts, 1)
     sel = pcl_seg.unsqueeze(1).eq(labels)
     per = torch.where(sel, dis.unsqueeze(1), torch.zeros_like(dis).unsqueeze(1))

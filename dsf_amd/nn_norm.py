@@ -202,6 +202,8 @@ class _BNFunction(Function):
             gg = gb = None                                    # added into the buffers the first contribution handed to autograd
         elif rec_key is not None:
             gamma.__dict__["_dsf_bnpass"] = rec_key + (gg, gb)
+            # (autograd adopts a gradient as ``.grad`` without a copy only when nobody else holds the tensor OBJECT: hand it views)
+            gg, gb = gg.view(C), gb.view(C)
         return (gx, gres, gg, gb) + (None,) * (n_in - 4)
 
 

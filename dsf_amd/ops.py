@@ -624,3 +624,135 @@ class Offset2Joint(Function):
                                                 I(C // 4), I(depth.shape[-1]), I(S), F(ks), F(scale), ptr(gm),
                                                 stream_ptr()), "dsf_offset2joint_backward")
         return gm, None, None, None
+
+
+# --------------------------------------------------------------------------------------------
+# Loss-side glue of the trainer steps as fused launches (csrc/step_ops.hip; include/dsf_hip.h "Loss-side glue")
+# --------------------------------------------------------------------------------------------
+class M2dLoss(Function):
+    """``m2d_loss`` (train_render.py:728-732) -> (loss, sums (B,4), per (B,)); gradient w.r.t. ``synth`` only."""
+
+    @staticmethod
+    def forward(ctx, real, synth, thresh, scale):
+        B = real.shape[0]
+        P = real.numel() // max(B, 1)
+        sums = _empty((B, 4), real)
+        per = _empty((B,), real)
+        loss = torch.zeros((), device=real.device, dtype=torch.float32) if B == 0 else _empty((), real)
+        check(L.lib().dsf_m2d_forward(ptr(real), ptr(synth), I(B), I(P), F(thresh), F(scale), ptr(sums), ptr(per), ptr(loss), stream_ptr()),
+              "dsf_m2d_forward")
+        ctx.save_for_backward(real, synth, sums)
+        ctx.args = (thresh, scale)
+        ctx.mark_non_differentiable(sums, per)
+        return loss, sums, per
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g, _gs, _gp):
+        real, synth, sums = ctx.saved_tensors
+        thresh, scale = ctx.args
+        B = real.shape[0]
+        gs = torch.empty_like(synth)
+        check(L.lib().dsf_m2d_backward(ptr(real), ptr(synth), ptr(sums), ptr(f32(g)), I(B), I(real.numel() // max(B, 1)), F(thresh), F(scale),
+                                       ptr(gs), stream_ptr()), "dsf_m2d_backward")
+        return None, gs, None, None
+
+
+def m2d(real, synth, thresh=0.99, scale=0.1):
+    """-> (loss, sums, per) of the fused model-to-data term, or None when the fused path does not apply (``real`` needs a
+    gradient, layouts differ, not fp32)."""
+    if not (real.is_cuda and real.dtype == torch.float32 and synth.dtype == torch.float32 and real.shape == synth.shape and
+            real.is_contiguous() and synth.is_contiguous() and not real.requires_grad and real.dim() >= 2):
+        return None
+    return M2dLoss.apply(real, synth, float(thresh), float(scale))
+
+
+class CubePoints(Function):
+    """(verts_n, joints_n, center, cube) -> (verts_world, joints_world, verts_norm, joints_norm): Render.render's
+    ``p * cube / 2 + center`` and ``(p - center) / cube * 2`` (mano_layer.py:1078-1092); gradients w.r.t. the points only."""
+
+    @staticmethod
+    def forward(ctx, verts, joints, center, cube):
+        verts, joints, center, cube = f32(verts), f32(joints), f32(center), f32(cube)
+        B, NV, NJ = verts.shape[0], verts.shape[1], joints.shape[1]
+        vw, vn = torch.empty_like(verts), torch.empty_like(verts)
+        jw, jn = torch.empty_like(joints), torch.empty_like(joints)
+        check(L.lib().dsf_cube_points_forward(ptr(verts), ptr(joints), ptr(center), ptr(cube), I(B), I(NV), I(NJ), ptr(vw), ptr(jw), ptr(vn), ptr(jn),
+                                              stream_ptr()), "dsf_cube_points_forward")
+        ctx.save_for_backward(cube)
+        ctx.dims = (B, NV, NJ)
+        ctx.set_materialize_grads(False)
+        return vw, jw, vn, jn
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gvw, gjw, gvn, gjn):
+        cube, = ctx.saved_tensors
+        B, NV, NJ = ctx.dims
+        c = lambda t: None if t is None else f32(t)
+        gvw, gjw, gvn, gjn = c(gvw), c(gjw), c(gvn), c(gjn)
+        gv = _empty((B, NV, 3), cube)
+        gj = _empty((B, NJ, 3), cube)
+        check(L.lib().dsf_cube_points_backward(ptr(gvw), ptr(gjw), ptr(gvn), ptr(gjn), ptr(cube), I(B), I(NV), I(NJ), ptr(gv), ptr(gj), stream_ptr()),
+              "dsf_cube_points_backward")
+        return gv, gj, None, None
+
+
+def view_rotate(verts, joints, center, rot):
+    """RotationPoints (mano_layer.py:874-884) in one launch, inference only -> (verts, joints) rotated about ``center``."""
+    verts, joints, center, rot = f32(verts), f32(joints), f32(center), f32(rot)
+    ov, oj = torch.empty_like(verts), torch.empty_like(joints)
+    check(L.lib().dsf_view_rotate(ptr(verts), ptr(joints), ptr(center), ptr(rot), I(rot.shape[-1]), I(verts.shape[0]), I(verts.shape[1]),
+                                  I(joints.shape[1]), ptr(ov), ptr(oj), stream_ptr()), "dsf_view_rotate")
+    return ov, oj
+
+
+class PartMean(Function):
+    """per-part masked mean of point distances (metric/meshLoss.py:389-394): dis (B,P), seg (B,P) int64 labels -> (B,n_parts)"""
+
+    @staticmethod
+    def forward(ctx, dis, seg, n_parts):
+        dis = f32(dis)
+        seg = seg.contiguous()
+        B, P = dis.shape
+        out = _empty((B, n_parts), dis)
+        valid = _empty((B, n_parts), dis)
+        check(L.lib().dsf_part_mean_forward(ptr(dis), ptr(seg), I(B), I(P), I(n_parts), ptr(out), ptr(valid), stream_ptr()), "dsf_part_mean_forward")
+        ctx.save_for_backward(seg, valid)
+        ctx.n = n_parts
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        seg, valid = ctx.saved_tensors
+        B, P = seg.shape
+        gd = _empty((B, P), valid)
+        check(L.lib().dsf_part_mean_backward(ptr(f32(g)), ptr(seg), ptr(valid), I(B), I(P), I(ctx.n), ptr(gd), stream_ptr()), "dsf_part_mean_backward")
+        return gd, None, None
+
+
+class ManoReg(Function):
+    """the two MANO regularisers of Pretrain (train_render.py:463-464) on the packed rows (B,W) -> (2,) [beta term, scale term]"""
+
+    @staticmethod
+    def forward(ctx, paras, beta_col, scale_col, w_beta, w_scale):
+        paras = f32(paras)
+        B, W = paras.shape
+        out = _empty((2,), paras)
+        check(L.lib().dsf_mano_reg_forward(ptr(paras), I(B), I(W), I(beta_col), I(scale_col), F(w_beta), F(w_scale), ptr(out), stream_ptr()),
+              "dsf_mano_reg_forward")
+        ctx.save_for_backward(paras)
+        ctx.args = (beta_col, scale_col, w_beta, w_scale)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        paras, = ctx.saved_tensors
+        B, W = paras.shape
+        bc, sc, wb, ws_ = ctx.args
+        gp = torch.empty_like(paras)
+        check(L.lib().dsf_mano_reg_backward(ptr(paras), ptr(f32(g)), I(B), I(W), I(bc), I(sc), F(wb), F(ws_), ptr(gp), stream_ptr()),
+              "dsf_mano_reg_backward")
+        return gp, None, None, None, None

@@ -53,6 +53,9 @@ def RotationPoints(verts, joints, center3d, rot):
     """Rotate about ``center3d`` (reference :874-884)."""
     # (B, V, 3) x (B, 3, 3)^T as ONE batched product per tensor: the reference's broadcast form, matmul((B,1,3,3), (B,V,3,1)), is a
     # bmm over B*V 3x3 matrices -- 149,568 of them at config 4's 192 meshes, 1.07 ms per call in hipBLASLt (round-2 profile)
+    if verts.is_cuda and not (torch.is_grad_enabled() and (verts.requires_grad or joints.requires_grad or rot.requires_grad)) \
+            and verts.dim() == 3 and joints.dim() == 3 and rot.dim() == 2:
+        return ops.view_rotate(verts, joints, center3d, rot)  # one launch (csrc/step_ops.hip): the synthetic branch renders without gradients
     Rt = _rotmat(rot).transpose(1, 2)
     c = center3d.unsqueeze(1)
     return torch.bmm(verts - c, Rt) + c, torch.bmm(joints - c, Rt) + c
@@ -440,6 +443,11 @@ class Render(nn.Module):
     def render(self, model_paras, center3d, cube_size, M=None):
         """MANO params (cube-normalised) -> (img (B,1,128,128), joint_uvd, joint_xyz, mesh_xyz) (reference :1071-1097)."""
         hand_verts, hand_joints = self.mano_layer.get_mano_vertices_packed(model_paras[:, :62], global_scale=1 / 125)
+        if hand_verts.is_cuda and not center3d.requires_grad and not cube_size.requires_grad:
+            # the four point transforms below in one launch each way (csrc/step_ops.hip; same operations per element)
+            hand_verts, hand_joints, mesh_xyz, joint_xyz = ops.CubePoints.apply(hand_verts, hand_joints, center3d, cube_size)
+            img, center2d, M, _ = self._depth_crop(hand_verts, center3d, cube_size)
+            return img, self.JointTrans(hand_joints, M, center2d, cube_size), joint_xyz, mesh_xyz
         hand_verts = hand_verts * cube_size.unsqueeze(1) / 2 + center3d.unsqueeze(1)
         hand_joints = hand_joints * cube_size.unsqueeze(1) / 2 + center3d.unsqueeze(1)
         img, center2d, M, _ = self._depth_crop(hand_verts, center3d, cube_size)

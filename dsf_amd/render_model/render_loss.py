@@ -26,6 +26,11 @@ class depth_loss(torch.nn.Module):
 def m2d_loss(real_crop, synth_crop):
     """Model-to-data depth term written inline in the trainer (train_render.py:728-732): L1 over the
     UNION of the two foreground masks, normalised per sample, batch mean, x0.1."""
+    if real_crop.is_cuda:
+        from .. import ops
+        fused = ops.m2d(real_crop, synth_crop)               # one reduction launch pair + one backward launch (csrc/step_ops.hip)
+        if fused is not None:
+            return fused[0]
     union = (real_crop.lt(0.99) | synth_crop.lt(0.99)).to(real_crop.dtype)
     per = ((real_crop - synth_crop).abs() * union).sum(-1).sum(-1) / (union.sum(-1).sum(-1) + 1e-8)
     return per.mean() * 0.1

@@ -56,6 +56,15 @@ def synthetic_batch(B, device, seed=0, dtype=torch.float32):
     return p.to(device, dtype), center.to(device, dtype), cube.to(device, dtype)
 
 
+def _mano_regularisers(mano_pd, w_beta, w_scale):
+    """(mean(beta^2) * w_beta, mean(|min(scale, 0)|) * w_scale) of the packed MANO rows (train_render.py:463-464): one launch each
+    way on the GPU (csrc/step_ops.hip: the backward writes the whole gradient row), the reference's expression elsewhere."""
+    if mano_pd.is_cuda and mano_pd.dtype == torch.float32 and mano_pd.dim() == 2 and mano_pd.size(1) >= 59:
+        both = ops.ManoReg.apply(mano_pd, 48, 58, float(w_beta), float(w_scale))
+        return both[0], both[1]
+    return (torch.mean(torch.pow(mano_pd[:, 48:58], 2)) * w_beta, torch.mean(torch.abs(torch.clamp(mano_pd[:, 58], max=0.0))) * w_scale)
+
+
 def _stat_pool(step, net, applications=1):
     """The per-step pools around one forward + backward: zeroed BatchNorm accumulation rows (nn_norm.stat_pool: one zero fill
     per step lets every fused BatchNorm of ``net`` run without finalise launches; sized once per step object) and the zeroed
@@ -121,8 +130,7 @@ class RenderSupervisedStep:
                 jxyz_pd, mesh_pd = self.render.get_mesh_xyz(mano_pd)
                 terms["joint%d" % s] = self.L1(jxyz_pd, tgt["joint_xyz"], weight=cfg.coord_weight)
                 terms["vert%d" % s] = self.L1(mesh_pd, tgt["mesh_xyz"], weight=cfg.coord_weight)
-                terms["beta%d" % s] = torch.mean(torch.pow(mano_pd[:, 48:58], 2)) * (cfg.coord_weight * 10)
-                terms["scale%d" % s] = torch.mean(torch.abs(torch.clamp(mano_pd[:, 58], max=0.0))) * 0.1
+                terms["beta%d" % s], terms["scale%d" % s] = _mano_regularisers(mano_pd, cfg.coord_weight * 10, 0.1)
             # render loss on the final estimate (:719, :728-732, :745)
             img_pd, _, _, _ = self.render.render(outputs[-1][1], center, cube)
             terms["m2d"] = m2d_loss(img, img_pd) * cfg.model_weight
@@ -566,8 +574,7 @@ class PretrainStep(_StepBase):
                 jxyz_pd, mesh_pd = R.get_mesh_xyz(mano_pd)
                 terms["joint%d" % i] = L1(jxyz_pd, s["joint_xyz"], weight=cfg.coord_weight)
                 terms["vert%d" % i] = L1(mesh_pd, s["mesh_xyz"], weight=cfg.coord_weight)
-                terms["beta%d" % i] = torch.mean(torch.pow(mano_pd[:, 48:58], 2)) * (cfg.coord_weight * 10)
-                terms["scale%d" % i] = torch.mean(torch.abs(torch.clamp(mano_pd[:, 58], max=0.0))) * 0.1
+                terms["beta%d" % i], terms["scale%d" % i] = _mano_regularisers(mano_pd, cfg.coord_weight * 10, 0.1)
         for i, (pixel_pd, _) in enumerate(outputs):
             S = pixel_pd.size(-1)
             pixel_gt = gfm.joint2feature(s["joint_uvd"], img, cfg.feature_para, S, cfg.feature_type)
@@ -667,15 +674,18 @@ class FinetuneStageStep(_StepBase):
         s = self.synth(model_para, cube, d)
         img, juvd_gt, jxyz_gt, mesh_gt = s["img"], s["joint_uvd"], s["joint_xyz"], s["mesh_xyz"]
         outputs = self.net(s["img_t"], R, center=s["center"], cube=s["cube"])
-        total = 0
+        # every loss term with its weight folded in (a weight of 1 multiplies nothing); ONE stack + sum at the end instead of a
+        # chain of ~35 scalar multiplies and adds, each with a backward launch of its own
+        acc = []
+        w = lambda t, k: t if k == 1 else t * k
         for pixel_pd, mano_pd in outputs:
             S = pixel_pd.size(-1)
             pixel_gt = gfm.joint2feature(juvd_gt, img, cfg.feature_para, S, cfg.feature_type)
             juvd = gfm.feature2joint(img, pixel_pd, cfg.feature_type, cfg.feature_para)
-            total = total + L1(pixel_pd, pixel_gt) * cfg.deconv_weight + L1(juvd, juvd_gt) * cfg.coord_weight
+            acc += [L1(pixel_pd, pixel_gt, weight=cfg.deconv_weight), L1(juvd, juvd_gt, weight=cfg.coord_weight)]
             jx, mx = R.get_mesh_xyz(mano_pd)
-            total = total + L1(jx, jxyz_gt) * cfg.coord_weight + L1(mx, mesh_gt) * cfg.coord_weight \
-                + mano_layer.calculate_coll(jx, mx.detach()) * cfg.coll_weight
+            acc += [L1(jx, jxyz_gt, weight=cfg.coord_weight), L1(mx, mesh_gt, weight=cfg.coord_weight),
+                    w(mano_layer.calculate_coll(jx, mx.detach()), cfg.coll_weight)]
         # ---- real branch: teacher from the detached stage-2 outputs (:671-703) ----
         outputs = self.net(img_r, R, center=center_r, cube=cube_r)
         pix_t, mano_t = outputs[1][0].detach(), outputs[1][1].detach()
@@ -688,32 +698,40 @@ class FinetuneStageStep(_StepBase):
         # ---- stage 1 student (:706-749) ----
         pix1, mano1 = outputs[0]
         juvd1 = gfm.feature2joint(img_r, pix1, cfg.feature_type, cfg.feature_para)
-        total = total + L1(pix1, pix_t) * cfg.deconv_weight + L1(juvd1, juvd_t) * cfg.coord_weight
+        acc += [L1(pix1, pix_t, weight=cfg.deconv_weight), L1(juvd1, juvd_t, weight=cfg.coord_weight)]
         img1, mjuvd1, mjxyz1, mesh1 = R.render(mano1, center_r, cube_r)
-        total = total + L1(mjxyz1, jxyz_t) * cfg.coord_weight + L1(mesh1, mm_t) * cfg.coord_weight
-        total = total + mano_layer.calculate_coll(mjxyz1, mesh1.detach()) * cfg.coll_weight
+        acc += [L1(mjxyz1, jxyz_t, weight=cfg.coord_weight), L1(mesh1, mm_t, weight=cfg.coord_weight),
+                w(mano_layer.calculate_coll(mjxyz1, mesh1.detach()), cfg.coll_weight)]
         crop1 = u.crop_hand(img1, mj_t, center_r, M_r, cube_r)
-        total = total + m2d_loss(crop_r, crop1) * cfg.model_weight
-        total = total + ICPLoss(mesh1, pcl, mano_layer.faces).mean(-1) * cfg.model_weight
-        total = total + JointICPLoss(mesh1, joint_pcl, mano_layer.joint_faces, segment).mean(-1).mean(-1) * cfg.partICP_weight
+        acc += [w(m2d_loss(crop_r, crop1), cfg.model_weight), w(ICPLoss(mesh1, pcl, mano_layer.faces).mean(-1), cfg.model_weight),
+                w(JointICPLoss(mesh1, joint_pcl, mano_layer.joint_faces, segment).mean(-1).mean(-1), cfg.partICP_weight)]
         # ---- stage 2 (:752-808) ----
         pix2, mano2 = outputs[1]
         juvd2 = gfm.feature2joint(img_r, pix2, cfg.feature_type, cfg.feature_para)
         img2, mjuvd2, mjxyz2, mesh2 = R.render(mano2, center_r, cube_r)
-        p2m = L1(mjuvd2, juvd_t) * cfg.coord_weight
+        p2m = L1(mjuvd2, juvd_t, weight=cfg.coord_weight)
         coll2 = mano_layer.calculate_coll(mjxyz2, mesh2.detach())
         crop2 = u.crop_hand(img2, mj_t, center_r, M_r, cube_r)
-        union = (crop_r.lt(0.99) | crop2.lt(0.99)).float()
-        m2d2 = m2d_loss(crop_r, crop2)
         pd2m_j = JointICPLoss(mesh2, joint_pcl, mano_layer.joint_faces, segment)
         d2m_b = ICPLoss(mesh2, pcl, mano_layer.faces)
-        both = (crop_r.lt(0.99) & crop2.lt(0.99)).float()
-        depth_b = ((crop_r - crop2).abs() * both).sum(-1).sum(-1) / (union.sum(-1).sum(-1) + 1e-8)
-        mano_ok = depth_b.lt(0.04).squeeze(-1) & d2m_b.lt(1e-3)                              # (:787-789)
+        fused = ops.m2d(crop_r, crop2) if crop_r.is_cuda else None
+        if fused is not None:
+            # the model-to-data term and the agreement sums of the M2P gate from ONE reduction (csrc/step_ops.hip): sums =
+            # {sum |d| union, sum union, sum |d| both, sum both} per sample
+            m2d2, sums, _ = fused
+            depth_b = sums[:, 2] / (sums[:, 1] + 1e-8)
+        else:
+            union = (crop_r.lt(0.99) | crop2.lt(0.99)).float()
+            m2d2 = m2d_loss(crop_r, crop2)
+            both = (crop_r.lt(0.99) & crop2.lt(0.99)).float()
+            depth_b = (((crop_r - crop2).abs() * both).sum(-1).sum(-1) / (union.sum(-1).sum(-1) + 1e-8)).squeeze(-1)
+        mano_ok = depth_b.lt(0.04) & d2m_b.lt(1e-3)                                          # (:787-789)
         m2p = self._m2p(juvd2, mjuvd2, mano_ok, pd2m_j)
-        total = total + p2m + coll2 * cfg.coll_weight + m2d2 * cfg.model_weight + d2m_b.mean(-1) * cfg.model_weight \
-            + pd2m_j.mean(-1).mean(-1) * cfg.partICP_weight + m2p * cfg.M2P_weight
-        terms = {"P2M": p2m, "m2d": m2d2, "d2m": d2m_b.mean(-1), "pd2m": pd2m_j.mean(-1).mean(-1), "M2P": m2p, "coll": coll2}
+        d2m, pd2m = d2m_b.mean(-1), pd2m_j.mean(-1).mean(-1)
+        acc += [p2m, w(coll2, cfg.coll_weight), w(m2d2, cfg.model_weight), w(d2m, cfg.model_weight), w(pd2m, cfg.partICP_weight),
+                w(m2p, cfg.M2P_weight)]
+        total = torch.stack([t.reshape(()) for t in acc]).sum()
+        terms = {"P2M": p2m, "m2d": m2d2, "d2m": d2m, "pd2m": pd2m, "M2P": m2p, "coll": coll2}
         return total, terms
 
     def __call__(self, model_para, cube, img_r, center_r, cube_r, M_r, generator=None, draws=None):

@@ -560,6 +560,47 @@ int dsf_bn_backward_acc_pair(const float* x, const float* grad_y, const float* g
                              float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta, int accumulate_affine,
                              double* acc, dsf_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Loss-side glue of the trainer steps, one launch (pair) per term (round 6; csrc/step_ops.hip).  The reference writes each of
+ * these as a chain of 10-25 elementwise / reduce torch operators (forward and backward); on one stream that is launch latency.
+ *
+ * dsf_m2d_*: model-to-data depth term, /root/reference/train_render.py:728-732 (also :556-558): per sample over the P pixels of a
+ *   crop, u = (real < thresh) | (synth < thresh); per[b] = sum |real - synth| u / (sum u + 1e-8); loss[0] = mean_b per[b] * scale.
+ *   sums (B,4) = {sum |d| u, sum u, sum |d| a, sum a} with a = the AND of the two masks: the agreement test of the M2P gate
+ *   (:786-789) reads them.  Gradient w.r.t. synth only.
+ * dsf_cube_points_*: Render.render's point transforms, /root/reference/render_model/mano_layer.py:1078-1092: world = p * cube / 2 +
+ *   center and norm = (world - center) / cube * 2 for the vertex (B,NV,3) and the joint (B,NJ,3) tensor in one launch each way
+ *   (any of the four incoming gradients may be NULL).
+ * dsf_view_rotate: RotationPoints (mano_layer.py:874-884) through batch_rodrigues / quat2mat (:773-805): rot (B,3) axis-angle or
+ *   (B,4) quaternion, points rotated about center (B,3).  Forward only (the synthetic branch renders without gradients).
+ * dsf_part_mean_*: the per-part masked means of JointICPLoss / FingerICPLoss, /root/reference/metric/meshLoss.py:389-394: out[b][k] =
+ *   sum of dis over the points labelled k + 1, divided by (the number of those with dis > 0) + 1e-8, 0 when there are none;
+ *   valid (B,n_parts) = those counts (kept for the backward pass).  n_parts <= 16.
+ * dsf_mano_reg_*: the two regularisers of Pretrain, /root/reference/train_render.py:463-464, on the packed parameter rows (B,W):
+ *   out[0] = mean(p[:, beta_col:beta_col+10]^2) * w_beta, out[1] = mean(|min(p[:, scale_col], 0)|) * w_scale; the backward
+ *   writes EVERY column of grad_paras (zeros outside the eleven).
+ * All reductions run in a fixed order (deterministic).
+ * ---------------------------------------------------------------------------------- */
+int dsf_m2d_forward(const float* real, const float* synth, int B, int P, float thresh, float scale, float* sums, float* per,
+                    float* loss, dsf_stream_t stream);
+int dsf_m2d_backward(const float* real, const float* synth, const float* sums, const float* grad_loss, int B, int P, float thresh,
+                     float scale, float* grad_synth, dsf_stream_t stream);
+int dsf_cube_points_forward(const float* verts, const float* joints, const float* center, const float* cube, int B, int NV, int NJ,
+                            float* verts_world, float* joints_world, float* verts_norm, float* joints_norm, dsf_stream_t stream);
+int dsf_cube_points_backward(const float* g_verts_world, const float* g_joints_world, const float* g_verts_norm,
+                             const float* g_joints_norm, const float* cube, int B, int NV, int NJ, float* g_verts, float* g_joints,
+                             dsf_stream_t stream);
+int dsf_view_rotate(const float* verts, const float* joints, const float* center, const float* rot, int rot_dim, int B, int NV, int NJ,
+                    float* verts_out, float* joints_out, dsf_stream_t stream);
+int dsf_part_mean_forward(const float* dis, const int64_t* seg, int B, int P, int n_parts, float* out, float* valid,
+                          dsf_stream_t stream);
+int dsf_part_mean_backward(const float* grad_out, const int64_t* seg, const float* valid, int B, int P, int n_parts, float* grad_dis,
+                           dsf_stream_t stream);
+int dsf_mano_reg_forward(const float* paras, int B, int W, int beta_col, int scale_col, float w_beta, float w_scale, float* out,
+                         dsf_stream_t stream);
+int dsf_mano_reg_backward(const float* paras, const float* grad_out, int B, int W, int beta_col, int scale_col, float w_beta,
+                          float w_scale, float* grad_paras, dsf_stream_t stream);
+
 /* ----------------------------------------------------------------------------------
  * Training-phase augmentation of cropped frames: `loader.augmentCrop`
  * (/root/reference/data/render_loader.py:653-695 = rotateHand :458-497 / moveCoM :427-456 / scaleHand :499-527 through

@@ -26,7 +26,7 @@ def _lib_path():
 
 def test_every_code_object_is_free_of_scratch_and_packed_fp32():
     bad, summary = isa_lint.lint(_lib_path())
-    assert summary["code_objects"] == 15, summary                  # one per .hip source of build.sh
+    assert summary["code_objects"] == 16, summary                  # one per .hip source of build.sh
     assert summary["kernels"] >= 100 and summary["instructions"] > 100000, summary
     assert not bad, "\n".join(bad)
 

@@ -30,7 +30,8 @@ class Rec(TorchDispatchMode):
         if not any(v in name for v in VIEW_OPS):
             where = "<backward>"
             for fr in reversed(traceback.extract_stack(limit=40)):
-                if (fr.filename.startswith(os.path.join(ROOT, "dsf_amd")) or fr.filename.endswith("bench.py")) and "op_sources" not in fr.filename:
+                if (fr.filename.startswith(os.path.join(ROOT, "dsf_amd")) or fr.filename.endswith("bench.py")) and "op_sources" not in fr.filename \
+                        and not fr.filename.endswith("_lib.py"):
                     where = "%s:%d %s" % (os.path.relpath(fr.filename, ROOT), fr.lineno, (fr.line or "").strip()[:90])
                     break
             self.n[(name.replace("aten.", ""), where)] += 1
