@@ -98,6 +98,26 @@ __global__ __launch_bounds__(256) void sphere_set_kernel(dsf_sphere_model sm, co
     }
 }
 
+// seg_pcl's sphere set (mano_layer.py:404-413): CENTRES from one skeleton (the pixel branch's joints), RADII from another (the MANO
+// branch's joints, whose distances to the mesh define them).  The reference evaluates get_sphere_radius twice and keeps half of
+// each result; centres need no radii, so one top-10 selection serves: one launch instead of two.
+__global__ __launch_bounds__(256) void sphere_mixed_kernel(dsf_sphere_model sm, const float* __restrict__ joints_c,
+                                                           const float* __restrict__ joints_r, const float* __restrict__ mesh, int V,
+                                                           float* __restrict__ centres, float* __restrict__ radii) {
+    __shared__ float s_J[63], s_jr[21], s_Jc[63];
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (t >= 64 && t < 127) s_Jc[t - 64] = joints_c[b * 63 + t - 64];
+    joint_radii(sm, joints_r + b * 63, mesh + (int64_t)b * V * 3, s_J, s_jr, nullptr);       // (ends with a barrier)
+    if (t < NS) {
+        const float r_root = fminf(fmaxf(s_jr[0] - 0.05f, 0.01f), 0.4f);
+        float c[3], cr[3], r, r_unused;
+        sphere_from_joints(sm, s_J, s_jr, r_root, t, cr, r);                 // radius: the MANO skeleton's
+        sphere_from_joints(sm, s_Jc, s_jr, r_root, t, c, r_unused);          // centre: the other skeleton's
+        radii[b * NS + t] = r;
+        centres[(b * NS + t) * 3] = c[0]; centres[(b * NS + t) * 3 + 1] = c[1]; centres[(b * NS + t) * 3 + 2] = c[2];
+    }
+}
+
 __global__ __launch_bounds__(256) void collision_fwd_kernel(dsf_sphere_model sm, const float* __restrict__ joints,
                                                             const float* __restrict__ mesh, int V,
                                                             float* __restrict__ loss_rows, float* __restrict__ centres,
@@ -288,6 +308,15 @@ extern "C" int dsf_sphere_set(const dsf_sphere_model* sm, const float* joints, c
     if (B == 0) return DSF_OK;
     hipLaunchKernelGGL(sphere_set_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, *sm, joints, mesh, V, centres,
                        radii, topk_idx);
+    return dsf_launch_status();
+}
+
+extern "C" int dsf_sphere_mixed(const dsf_sphere_model* sm, const float* joints_centres, const float* joints_radii, const float* mesh, int B,
+                                int V, float* centres, float* radii, dsf_stream_t stream) {
+    DSF_CHECK_ARG(sm && joints_centres && joints_radii && mesh && centres && radii && B >= 0 && V >= 778);
+    if (B == 0) return DSF_OK;
+    hipLaunchKernelGGL(sphere_mixed_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, *sm, joints_centres, joints_radii, mesh, V, centres,
+                       radii);
     return dsf_launch_status();
 }
 

@@ -1005,6 +1005,14 @@ extern "C" int dsf_bn_forward_acc(const float* x, const float* residual, const f
                            nullptr, M, C, 0, rows, reinterpret_cast<float*>(acc), BN_ACC_ROWS);
     }
     const int64_t n4 = M * (C >> 2);
+    // TIMING PROBE (DSF_BN_PROBE=skip_single_apply, read per call; results are WRONG): the apply pass of a BatchNorm whose statistics
+    // came from the convolution's epilogue and whose output has no residual -- the passes that a BatchNorm(+ReLU) in the consuming
+    // convolution's loader would remove -- is not launched: the whole-step time without them bounds that fusion from above
+    // (profiles/r06_bn_loader_bound.txt).
+    if (acc_filled && !residual) {
+        const char* pr = getenv("DSF_BN_PROBE");
+        if (pr && pr[0] == 's') return DSF_OK;
+    }
     bn_launch_apply<true>(bn_apply_grid(n4, C), 1, st, x, residual, nullptr, nullptr, gamma, beta,
                        n4, C, relu, y, acc, BN_ACC_ROWS, M, fin);
     return dsf_launch_status();

@@ -8,6 +8,7 @@
 //   S3 view rotation  RotationPoints (mano_layer.py:874-884) with batch_rodrigues / quat2mat (:773-805): inference only
 //   S4 masked part mean  the per-part masked means of JointICPLoss / FingerICPLoss (metric/meshLoss.py:389-394)
 //   S5 MANO regularisers  mean(beta^2) and mean(|min(scale, 0)|) of the Pretrain losses (train_render.py:463-464)
+//   S6 M2P        the masked Huber term that lets a trusted MANO fit teach the pixel branch (train_render.py:590-603, 787-801)
 // Arithmetic per element is the reference's, operation for operation (-ffp-contract=off); reductions run in a fixed order
 // (deterministic), which differs from torch's reduction order in the last bits only.
 #include "common.h"
@@ -106,21 +107,23 @@ __global__ __launch_bounds__(256) void cube_points_bwd_kernel(const float* __res
     if (is_v) gv[o] = r; else gj[o] = r;
 }
 
-// ---- S3: rotation about `center` by an axis-angle (rot_dim 3) or a quaternion (rot_dim 4) per sample
+// ---- S3: rotation about `center` by an axis-angle (rot_dim 3) or a quaternion (rot_dim 4) per sample.  recentre: the points are first
+//      moved so that the mean of the joints sits at `center` (Render.forward, mano_layer.py:995-1003: p - mean(joints) + center);
+//      rot == nullptr: no rotation
 __global__ __launch_bounds__(256) void view_rotate_kernel(const float* __restrict__ v, const float* __restrict__ j, const float* __restrict__ center,
-                                                          const float* __restrict__ rot, int rot_dim, int NV, int NJ, float* __restrict__ ov,
-                                                          float* __restrict__ oj) {
-    __shared__ float R[9];
+                                                          const float* __restrict__ rot, int rot_dim, int recentre, int NV, int NJ,
+                                                          float* __restrict__ ov, float* __restrict__ oj) {
+    __shared__ float R[9], SC[3];
     const int b = blockIdx.x;
     if (threadIdx.x == 0) {
-        float q[4];
-        if (rot_dim == 3) {                                               // batch_rodrigues: angle = |theta + 1e-8|, quat = [cos(a/2), sin(a/2) theta / a]
+        float q[4] = {1.f, 0.f, 0.f, 0.f};
+        if (rot && rot_dim == 3) {                                        // batch_rodrigues: angle = |theta + 1e-8|, quat = [cos(a/2), sin(a/2) theta / a]
             const float t0 = rot[b * 3 + 0], t1 = rot[b * 3 + 1], t2 = rot[b * 3 + 2];
             const float a0 = t0 + 1e-8f, a1 = t1 + 1e-8f, a2 = t2 + 1e-8f;
             const float angle = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
             const float half = angle * 0.5f, sn = sinf(half);
             q[0] = cosf(half); q[1] = sn * (t0 / angle); q[2] = sn * (t1 / angle); q[3] = sn * (t2 / angle);
-        } else {
+        } else if (rot) {
             q[0] = rot[b * 4 + 0]; q[1] = rot[b * 4 + 1]; q[2] = rot[b * 4 + 2]; q[3] = rot[b * 4 + 3];
         }
         const float nrm = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
@@ -129,6 +132,13 @@ __global__ __launch_bounds__(256) void view_rotate_kernel(const float* __restric
         R[3] = 2 * w * z + 2 * x * y;         R[4] = w * w - x * x + y * y - z * z; R[5] = 2 * y * z - 2 * w * x;
         R[6] = 2 * x * z - 2 * w * y;         R[7] = 2 * w * x + 2 * y * z;         R[8] = w * w - x * x - y * y + z * z;
     }
+    if (threadIdx.x >= 64 && threadIdx.x < 67) {                          // mean of the joints (another wave than the matrix)
+        const int a = threadIdx.x - 64;
+        float sum = 0.f;
+        if (recentre)
+            for (int k = 0; k < NJ; ++k) sum += j[((int64_t)b * NJ + k) * 3 + a];
+        SC[a] = recentre ? sum / (float)NJ : 0.f;
+    }
     __syncthreads();
     const float c0 = center[b * 3 + 0], c1 = center[b * 3 + 1], c2 = center[b * 3 + 2];
     for (int p = threadIdx.x; p < NV + NJ; p += 256) {
@@ -136,11 +146,78 @@ __global__ __launch_bounds__(256) void view_rotate_kernel(const float* __restric
         const int64_t o = is_v ? ((int64_t)b * NV + p) * 3 : ((int64_t)b * NJ + (p - NV)) * 3;
         const float* src = is_v ? v : j;
         float* dst = is_v ? ov : oj;
-        const float d0 = src[o] - c0, d1 = src[o + 1] - c1, d2 = src[o + 2] - c2;
-        dst[o + 0] = (d0 * R[0] + d1 * R[1] + d2 * R[2]) + c0;              // row i of (p - c) R^T = sum_k (p - c)_k R[i][k]
-        dst[o + 1] = (d0 * R[3] + d1 * R[4] + d2 * R[5]) + c1;
-        dst[o + 2] = (d0 * R[6] + d1 * R[7] + d2 * R[8]) + c2;
+        float p0 = src[o], p1 = src[o + 1], p2 = src[o + 2];
+        if (recentre) { p0 = (p0 - SC[0]) + c0; p1 = (p1 - SC[1]) + c1; p2 = (p2 - SC[2]) + c2; }
+        if (rot) {
+            const float d0 = p0 - c0, d1 = p1 - c1, d2 = p2 - c2;
+            p0 = (d0 * R[0] + d1 * R[1] + d2 * R[2]) + c0;                // row i of (p - c) R^T = sum_k (p - c)_k R[i][k]
+            p1 = (d0 * R[3] + d1 * R[4] + d2 * R[5]) + c1;
+            p2 = (d0 * R[6] + d1 * R[7] + d2 * R[8]) + c2;
+        }
+        dst[o] = p0; dst[o + 1] = p1; dst[o + 2] = p2;
     }
+}
+
+// n = (p - center) / cube * 2 for the vertex and the joint tensor (Render.forward, mano_layer.py:1033-1034)
+__global__ __launch_bounds__(256) void cube_normalise_kernel(const float* __restrict__ v, const float* __restrict__ j, const float* __restrict__ center,
+                                                             const float* __restrict__ cube, int B, int NV, int NJ, float* __restrict__ vn,
+                                                             float* __restrict__ jn) {
+    const int per = (NV + NJ) * 3;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)B * per) return;
+    const int b = (int)(i / per), e = (int)(i % per);
+    const bool is_v = e < NV * 3;
+    const int64_t o = is_v ? (int64_t)b * NV * 3 + e : (int64_t)b * NJ * 3 + (e - NV * 3);
+    const int c = (is_v ? e : e - NV * 3) % 3;
+    const float p = is_v ? v[o] : j[o];
+    const float n = (p - center[b * 3 + c]) / cube[b * 3 + c] * 2.f;
+    if (is_v) vn[o] = n; else jn[o] = n;
+}
+
+// ---- S6: the M2P term (train_render.py:590-603 / 787-801): rows (b, joint) with ok[b] && jm[b][joint], jm = [1, pd2m < t (15), pd2m[2,5,8,11,14] < t];
+//      val = sum_rows mean_k h(a - b) / max(#rows, 1) * weight, 0 when no row with index > 0 is selected (the reference tests the SUM OF THE
+//      SELECTED INDICES == 0 on the host); aux = {#rows, 1 if any selected row has index > 0}.  One workgroup; fixed-order sums.
+__device__ __forceinline__ bool m2p_row(const unsigned char* ok, const float* pd2m, float t, int b, int jn) {
+    if (!ok[b]) return false;
+    if (jn == 0) return true;
+    const int col = jn <= 15 ? jn - 1 : (jn - 16) * 3 + 2;               // 16..20 -> parts 2, 5, 8, 11, 14
+    return pd2m[b * 15 + col] < t;
+}
+__global__ __launch_bounds__(256) void m2p_fwd_kernel(const float* __restrict__ a, const float* __restrict__ bb, const unsigned char* __restrict__ ok,
+                                                      const float* __restrict__ pd2m, int B, float t, float delta, float weight,
+                                                      float* __restrict__ out, float* __restrict__ aux) {
+    __shared__ float s[4];
+    float acc = 0.f, cnt = 0.f, hi = 0.f;
+    for (int r = threadIdx.x; r < B * 21; r += 256) {
+        if (!m2p_row(ok, pd2m, t, r / 21, r % 21)) continue;
+        float h = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float z = a[r * 3 + k] - bb[r * 3 + k], az = fabsf(z);
+            h += az < delta ? (0.5f * z) * z : delta * (az - 0.5f * delta);
+        }
+        acc += h / 3.f; cnt += 1.f; if (r > 0) hi = 1.f;
+    }
+    acc = block_sum(acc, s); cnt = block_sum(cnt, s); hi = block_sum(hi, s);
+    if (threadIdx.x == 0) {
+        const float val = acc / fmaxf(cnt, 1.f);
+        out[0] = hi == 0.f ? 0.f : val * weight;
+        aux[0] = cnt; aux[1] = hi == 0.f ? 0.f : 1.f;
+    }
+}
+__global__ __launch_bounds__(256) void m2p_bwd_kernel(const float* __restrict__ a, const float* __restrict__ bb, const unsigned char* __restrict__ ok,
+                                                      const float* __restrict__ pd2m, const float* __restrict__ aux, const float* __restrict__ g, int B,
+                                                      float t, float delta, float weight, float* __restrict__ ga) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * 63) return;
+    const int r = i / 3;
+    float res = 0.f;
+    if (aux[1] != 0.f && m2p_row(ok, pd2m, t, r / 21, r % 21)) {
+        const float z = a[i] - bb[i];
+        const float hg = fabsf(z) < delta ? z : copysignf(delta, z);
+        res = g[0] * weight / fmaxf(aux[0], 1.f) / 3.f * hg;
+    }
+    ga[i] = res;
 }
 
 // ---- S4: out[b][k] = sum_{p: seg = k + 1} dis[b][p] / (#{p: seg = k + 1, dis > 0} + 1e-8), 0 when that count is 0;  valid[b][k] = the count
@@ -248,12 +325,39 @@ extern "C" int dsf_cube_points_backward(const float* g_verts_world, const float*
     return dsf_launch_status();
 }
 
-extern "C" int dsf_view_rotate(const float* verts, const float* joints, const float* center, const float* rot, int rot_dim, int B, int NV, int NJ,
-                               float* verts_out, float* joints_out, dsf_stream_t stream) {
-    DSF_CHECK_ARG(verts && joints && center && rot && verts_out && joints_out && (rot_dim == 3 || rot_dim == 4) && B >= 0);
+extern "C" int dsf_view_rotate(const float* verts, const float* joints, const float* center, const float* rot, int rot_dim, int recentre, int B,
+                               int NV, int NJ, float* verts_out, float* joints_out, dsf_stream_t stream) {
+    DSF_CHECK_ARG(verts && joints && center && verts_out && joints_out && (!rot || rot_dim == 3 || rot_dim == 4) && B >= 0 && NJ > 0);
     if (B == 0) return DSF_OK;
-    hipLaunchKernelGGL(view_rotate_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, verts, joints, center, rot, rot_dim, NV, NJ, verts_out,
-                       joints_out);
+    hipLaunchKernelGGL(view_rotate_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, verts, joints, center, rot, rot_dim, recentre, NV, NJ,
+                       verts_out, joints_out);
+    return dsf_launch_status();
+}
+
+extern "C" int dsf_cube_normalise(const float* verts, const float* joints, const float* center, const float* cube, int B, int NV, int NJ,
+                                  float* verts_norm, float* joints_norm, dsf_stream_t stream) {
+    DSF_CHECK_ARG(verts && joints && center && cube && verts_norm && joints_norm && B >= 0 && NV >= 0 && NJ >= 0);
+    const int64_t n = (int64_t)B * (NV + NJ) * 3;
+    if (n == 0) return DSF_OK;
+    hipLaunchKernelGGL(cube_normalise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, verts, joints, center, cube, B, NV,
+                       NJ, verts_norm, joints_norm);
+    return dsf_launch_status();
+}
+
+extern "C" int dsf_m2p_forward(const float* juvd_pix, const float* juvd_mano, const unsigned char* sample_ok, const float* part_dist, int B,
+                               float part_thresh, float delta, float weight, float* out, float* aux, dsf_stream_t stream) {
+    DSF_CHECK_ARG(juvd_pix && juvd_mano && sample_ok && part_dist && out && aux && B > 0);
+    hipLaunchKernelGGL(m2p_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, juvd_pix, juvd_mano, sample_ok, part_dist, B, part_thresh, delta,
+                       weight, out, aux);
+    return dsf_launch_status();
+}
+
+extern "C" int dsf_m2p_backward(const float* juvd_pix, const float* juvd_mano, const unsigned char* sample_ok, const float* part_dist,
+                                const float* aux, const float* grad_out, int B, float part_thresh, float delta, float weight, float* grad_pix,
+                                dsf_stream_t stream) {
+    DSF_CHECK_ARG(juvd_pix && juvd_mano && sample_ok && part_dist && aux && grad_out && grad_pix && B > 0);
+    hipLaunchKernelGGL(m2p_bwd_kernel, dim3((B * 63 + 255) / 256), dim3(256), 0, (hipStream_t)stream, juvd_pix, juvd_mano, sample_ok, part_dist, aux,
+                       grad_out, B, part_thresh, delta, weight, grad_pix);
     return dsf_launch_status();
 }
 

@@ -190,7 +190,12 @@ def inverse3x3(M):
     """``torch.inverse(M)`` of a batch's (B,3,3) crop transforms (the reference's own routine: its LAPACK-style rounding decides
     exact-.5 ties of the nearest-neighbour crop), once per M tensor.  No host synchronisation."""
     M = M.reshape(-1, 3, 3).float()
-    return _memo("inv", (M,), lambda: torch.linalg.inv_ex(M)[0])
+    return _memo("inv", (M,), lambda: torch.linalg.inv_ex(M)[0].contiguous())     # (LAPACK-style output is column-major: one copy here, not one per consumer)
+
+
+def column(t, c):
+    """``t[:, c].contiguous()`` once per tensor (the depth column of a batch's centres / cubes, read by every crop launch)"""
+    return _memo("col%d" % c, (t,), lambda: t[:, c].contiguous())
 
 
 def crop_setup(center3d, cube, cam, crop=128, want_closed_inverse=False):
@@ -319,6 +324,21 @@ def sphere_set(sphere_model, joints, mesh):
     check(L.lib().dsf_sphere_set(ctypes.byref(sphere_model), ptr(joints), ptr(mesh), I(B), I(V), ptr(c), ptr(r),
                                  ptr(None), stream_ptr()), "dsf_sphere_set")
     return c, r
+
+
+def sphere_mixed(sphere_model, joints_centres, joints_radii, mesh):
+    """seg_pcl's sphere set (mano_layer.py:404-413): centres from one skeleton, radii from the other, one launch; once per
+    (joints, joints, mesh) triple (the trainer labels two clouds against the same spheres, train_render.py:695-700)."""
+    jc, jr, mesh = f32(joints_centres), f32(joints_radii), f32(mesh)
+
+    def run():
+        B, V = jc.shape[0], mesh.shape[1]
+        c = _empty((B, 66, 3), jc)
+        r = _empty((B, 66), jc)
+        check(L.lib().dsf_sphere_mixed(ctypes.byref(sphere_model), ptr(jc), ptr(jr), ptr(mesh), I(B), I(V), ptr(c), ptr(r), stream_ptr()),
+              "dsf_sphere_mixed")
+        return c, r
+    return _memo("sphere_mixed", (jc, jr, mesh), run)
 
 
 class CollisionRows(Function):
@@ -698,13 +718,52 @@ class CubePoints(Function):
         return gv, gj, None, None
 
 
-def view_rotate(verts, joints, center, rot):
-    """RotationPoints (mano_layer.py:874-884) in one launch, inference only -> (verts, joints) rotated about ``center``."""
-    verts, joints, center, rot = f32(verts), f32(joints), f32(center), f32(rot)
+def view_rotate(verts, joints, center, rot=None, recentre=False):
+    """RotationPoints (mano_layer.py:874-884) in one launch, inference only -> (verts, joints) rotated about ``center`` by ``rot``
+    ((B,3) axis-angle or (B,4) quaternion; None: no rotation); ``recentre``: the points are first moved so that the mean of the
+    joints sits at ``center`` (Render.forward :995-1003)."""
+    verts, joints, center = f32(verts), f32(joints), f32(center)
+    rot = f32(rot) if rot is not None else None
     ov, oj = torch.empty_like(verts), torch.empty_like(joints)
-    check(L.lib().dsf_view_rotate(ptr(verts), ptr(joints), ptr(center), ptr(rot), I(rot.shape[-1]), I(verts.shape[0]), I(verts.shape[1]),
-                                  I(joints.shape[1]), ptr(ov), ptr(oj), stream_ptr()), "dsf_view_rotate")
+    check(L.lib().dsf_view_rotate(ptr(verts), ptr(joints), ptr(center), ptr(rot), I(rot.shape[-1] if rot is not None else 0), I(int(recentre)),
+                                  I(verts.shape[0]), I(verts.shape[1]), I(joints.shape[1]), ptr(ov), ptr(oj), stream_ptr()), "dsf_view_rotate")
     return ov, oj
+
+
+def cube_normalise(verts, joints, center, cube):
+    """((verts - center) / cube * 2, the same for the joints) in one launch, inference only (Render.forward :1033-1034)"""
+    verts, joints, center, cube = f32(verts), f32(joints), f32(center), f32(cube)
+    vn, jn = torch.empty_like(verts), torch.empty_like(joints)
+    check(L.lib().dsf_cube_normalise(ptr(verts), ptr(joints), ptr(center), ptr(cube), I(verts.shape[0]), I(verts.shape[1]), I(joints.shape[1]),
+                                     ptr(vn), ptr(jn), stream_ptr()), "dsf_cube_normalise")
+    return vn, jn
+
+
+class M2P(Function):
+    """the M2P term (train_render.py:590-603 / 787-801) in one launch each way: juvd_pix, juvd_mano (B,21,3), sample_ok (B) bool,
+    part_dist (B,15) -> scalar (weight folded in); gradient w.r.t. juvd_pix only."""
+
+    @staticmethod
+    def forward(ctx, juvd_pix, juvd_mano, sample_ok, part_dist, weight):
+        a, b = f32(juvd_pix), f32(juvd_mano)
+        ok = sample_ok.to(torch.uint8).contiguous()
+        pd = f32(part_dist)
+        B = a.shape[0]
+        out, aux = _empty((), a), _empty((2,), a)
+        check(L.lib().dsf_m2p_forward(ptr(a), ptr(b), ptr(ok), ptr(pd), I(B), F(1e-3), F(0.01), F(weight), ptr(out), ptr(aux), stream_ptr()),
+              "dsf_m2p_forward")
+        ctx.save_for_backward(a, b, ok, pd, aux)
+        ctx.weight = weight
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        a, b, ok, pd, aux = ctx.saved_tensors
+        ga = torch.empty_like(a)
+        check(L.lib().dsf_m2p_backward(ptr(a), ptr(b), ptr(ok), ptr(pd), ptr(aux), ptr(f32(g)), I(a.shape[0]), F(1e-3), F(0.01), F(ctx.weight),
+                                       ptr(ga), stream_ptr()), "dsf_m2p_backward")
+        return ga, None, None, None, None
 
 
 class PartMean(Function):

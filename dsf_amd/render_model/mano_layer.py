@@ -300,8 +300,7 @@ class MANO_SMPL(nn.Module):
         """Part label 0..15 per point: centres from ``joints`` (pixel branch), radii from
         ``joints_mano`` (reference :404-426)."""
         sm = self._native().sphere_struct
-        c, _ = ops.sphere_set(sm, joints.detach(), mesh.detach())
-        _, r = ops.sphere_set(sm, joints_mano.detach(), mesh.detach())
+        c, r = ops.sphere_mixed(sm, joints.detach(), joints_mano.detach(), mesh.detach())     # one launch, once per (joints, joints, mesh)
         return ops.seg_pcl(c, r, pcl.detach())
 
 
@@ -404,8 +403,8 @@ class Render(nn.Module):
             minv = self._inverse(M, minv_c)
         else:
             minv = ops.inverse3x3(M)
-        cz = center2d[:, 2].contiguous() if normalise else None
-        cbz = cube_size[:, 2].contiguous() if normalise else None
+        cz = ops.column(center2d, 2) if normalise else None
+        cbz = ops.column(cube_size, 2) if normalise else None
         img, p2f = ops.RenderCropFunction.apply(hand_verts, self.mano_layer.faces_i32, minv, self.resize_rowmap, cz, cbz,
                                                 self.cam, max(self.img_size), self.crop_size[0])
         return img, center2d, M, minv
@@ -417,16 +416,23 @@ class Render(nn.Module):
         device = model_paras.device
         quat, theta, beta, cam = self._split(model_paras, augmentShape)
         hand_verts, hand_joints = self.mano_layer.get_mano_vertices(quat, theta, beta, cam)
-        synth_center = hand_joints.mean(dim=1, keepdim=True)
-        hand_verts = hand_verts - synth_center
-        hand_joints = hand_joints - synth_center
         if center3d is None:
             depth = torch.rand([batch_size, 1]) * (self.depth_range[1] - self.depth_range[0]) + self.depth_range[0]
             center3d = torch.cat((torch.zeros([batch_size, 2]), depth), dim=-1).to(device)
-        hand_verts = hand_verts + center3d.unsqueeze(1)
-        hand_joints = hand_joints + center3d.unsqueeze(1)
-        if augmentView is not None:
-            hand_verts, hand_joints = RotationPoints(hand_verts, hand_joints, center3d, augmentView)
+        fused = hand_verts.is_cuda and not (torch.is_grad_enabled() and (hand_verts.requires_grad or center3d.requires_grad or
+                                                                         cube_size.requires_grad))
+        if fused:
+            # the placement (p - mean(joints) + centre), the view rotation and -- below -- the cube normalisation of both point
+            # tensors as one launch each (csrc/step_ops.hip; this branch renders without gradients): 20 elementwise launches less
+            hand_verts, hand_joints = ops.view_rotate(hand_verts, hand_joints, center3d, augmentView, recentre=True)
+        else:
+            synth_center = hand_joints.mean(dim=1, keepdim=True)
+            hand_verts = hand_verts - synth_center
+            hand_joints = hand_joints - synth_center
+            hand_verts = hand_verts + center3d.unsqueeze(1)
+            hand_joints = hand_joints + center3d.unsqueeze(1)
+            if augmentView is not None:
+                hand_verts, hand_joints = RotationPoints(hand_verts, hand_joints, center3d, augmentView)
         if augmentCenter is not None:
             center3d = center3d + augmentCenter
         if augmentSize is not None:
@@ -434,8 +440,11 @@ class Render(nn.Module):
         img, center2d, M, _ = self._depth_crop(hand_verts, center3d, cube_size)
         joint_uvd = self.JointTrans(hand_joints, M, center2d, cube_size)
         verts_uvd = self.JointTrans(hand_verts, M, center2d, cube_size)
-        joint_xyz = (hand_joints - center3d.unsqueeze(1)) / cube_size.unsqueeze(1) * 2
-        verts_xyz = (hand_verts - center3d.unsqueeze(1)) / cube_size.unsqueeze(1) * 2
+        if fused:
+            verts_xyz, joint_xyz = ops.cube_normalise(hand_verts, hand_joints, center3d, cube_size)
+        else:
+            joint_xyz = (hand_joints - center3d.unsqueeze(1)) / cube_size.unsqueeze(1) * 2
+            verts_xyz = (hand_verts - center3d.unsqueeze(1)) / cube_size.unsqueeze(1) * 2
         if mask:
             img = self.mask_img(img, joint_uvd, 0.15, 0.3)
         return img, joint_uvd, verts_uvd, joint_xyz, verts_xyz, center3d, cube_size, M

@@ -521,6 +521,9 @@ class _StepBase:
         """M2P selection (:590-603 / :787-801): samples whose render and ICP agree with the data teach the pixel branch,
         joint by joint (part distance < 1e-3; wrist always; the five tips follow joints 2,5,8,11,14)."""
         B = juvd_pix.size(0)
+        if juvd_pix.is_cuda and B > 0 and juvd_pix.shape[1:] == (21, 3) and pd2m_j.shape == (B, 15) and juvd_pix.dtype == torch.float32:
+            # selection + masked Huber + the reference's empty rule in one launch each way (csrc/step_ops.hip)
+            return ops.M2P.apply(juvd_pix, juvd_mano.detach(), mano_ok.detach(), pd2m_j.detach(), float(self.cfg.coord_weight))
         jm = pd2m_j.lt(1e-3)
         jm = torch.cat((torch.ones(B, 1, device=jm.device, dtype=torch.bool), jm, jm[:, [2, 5, 8, 11, 14]]), dim=-1)
         rows = (mano_ok.unsqueeze(-1) & jm).detach().reshape(-1)

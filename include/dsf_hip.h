@@ -200,6 +200,11 @@ typedef struct dsf_sphere_model {
  * (the 10 nearest owned vertices per joint, needed by the backward; may be NULL). */
 int dsf_sphere_set(const dsf_sphere_model* sm, const float* joints, const float* mesh, int B, int V,
                    float* centres, float* radii, int32_t* topk_idx, dsf_stream_t stream);
+/* seg_pcl's sphere set, /root/reference/render_model/mano_layer.py:404-413: centres from `joints_centres` (the pixel branch's
+ * skeleton), radii from `joints_radii` + mesh (the MANO skeleton) -- the reference calls get_sphere_radius twice and keeps half of
+ * each result; here one launch (one top-10 selection per joint). */
+int dsf_sphere_mixed(const dsf_sphere_model* sm, const float* joints_centres, const float* joints_radii, const float* mesh, int B,
+                     int V, float* centres, float* radii, dsf_stream_t stream);
 
 /* loss_rows (B,66): gated row sums sum_j err_ij (the caller takes the mean, = calculate_coll).
  * Also writes centres/radii/topk_idx for the backward. */
@@ -572,7 +577,13 @@ int dsf_bn_backward_acc_pair(const float* x, const float* grad_y, const float* g
  *   center and norm = (world - center) / cube * 2 for the vertex (B,NV,3) and the joint (B,NJ,3) tensor in one launch each way
  *   (any of the four incoming gradients may be NULL).
  * dsf_view_rotate: RotationPoints (mano_layer.py:874-884) through batch_rodrigues / quat2mat (:773-805): rot (B,3) axis-angle or
- *   (B,4) quaternion, points rotated about center (B,3).  Forward only (the synthetic branch renders without gradients).
+ *   (B,4) quaternion (NULL: none), points rotated about center (B,3); recentre != 0 first moves the points so that the mean of the
+ *   joints sits at center (Render.forward :995-1003).  dsf_cube_normalise: (p - center) / cube * 2 for both tensors (:1033-1034).
+ *   Forward only (the synthetic branch renders without gradients).
+ * dsf_m2p_*: the M2P term, /root/reference/train_render.py:590-603 / 787-801: Huber (delta) between the pixel branch's and the MANO
+ *   branch's joints (B,21,3) over the rows (b, j) with sample_ok[b] (uint8) and part_dist[b][part(j)] < part_thresh (joint 0 always,
+ *   joints 16..20 follow parts 2, 5, 8, 11, 14), mean over the selected rows x weight, 0 when no row with a positive index is
+ *   selected (the reference's host test); aux = {rows selected, that flag}.  Gradient w.r.t. juvd_pix only.
  * dsf_part_mean_*: the per-part masked means of JointICPLoss / FingerICPLoss, /root/reference/metric/meshLoss.py:389-394: out[b][k] =
  *   sum of dis over the points labelled k + 1, divided by (the number of those with dis > 0) + 1e-8, 0 when there are none;
  *   valid (B,n_parts) = those counts (kept for the backward pass).  n_parts <= 16.
@@ -590,8 +601,15 @@ int dsf_cube_points_forward(const float* verts, const float* joints, const float
 int dsf_cube_points_backward(const float* g_verts_world, const float* g_joints_world, const float* g_verts_norm,
                              const float* g_joints_norm, const float* cube, int B, int NV, int NJ, float* g_verts, float* g_joints,
                              dsf_stream_t stream);
-int dsf_view_rotate(const float* verts, const float* joints, const float* center, const float* rot, int rot_dim, int B, int NV, int NJ,
-                    float* verts_out, float* joints_out, dsf_stream_t stream);
+int dsf_view_rotate(const float* verts, const float* joints, const float* center, const float* rot, int rot_dim, int recentre, int B,
+                    int NV, int NJ, float* verts_out, float* joints_out, dsf_stream_t stream);
+int dsf_cube_normalise(const float* verts, const float* joints, const float* center, const float* cube, int B, int NV, int NJ,
+                       float* verts_norm, float* joints_norm, dsf_stream_t stream);
+int dsf_m2p_forward(const float* juvd_pix, const float* juvd_mano, const unsigned char* sample_ok, const float* part_dist, int B,
+                    float part_thresh, float delta, float weight, float* out, float* aux, dsf_stream_t stream);
+int dsf_m2p_backward(const float* juvd_pix, const float* juvd_mano, const unsigned char* sample_ok, const float* part_dist,
+                     const float* aux, const float* grad_out, int B, float part_thresh, float delta, float weight, float* grad_pix,
+                     dsf_stream_t stream);
 int dsf_part_mean_forward(const float* dis, const int64_t* seg, int B, int P, int n_parts, float* out, float* valid,
                           dsf_stream_t stream);
 int dsf_part_mean_backward(const float* grad_out, const int64_t* seg, const float* valid, int B, int P, int n_parts, float* grad_dis,

@@ -186,3 +186,66 @@ def test_a_layer_applied_twice_adds_its_affine_gradients_in_the_kernel(acc, monk
         out[on] = [bn.weight.grad.clone(), bn.bias.grad.clone()] + [x.grad.clone() for x in xs]
     for a, b_ in zip(out[True], out[False]):
         assert _rel(a, b_) < 1e-6
+
+
+@pytest.mark.parametrize("case", ["mixed", "none", "only_row0"])
+def test_m2p_term_in_one_launch(case):
+    """selection + masked Huber + the reference's "sum of the selected indices == 0" rule (train_render.py:590-603 / 787-801)"""
+    from dsf_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(len(case))
+    B = 16
+    pix = (torch.randn(B, 21, 3, device="cuda", generator=g) * 0.02).requires_grad_(True)
+    mano = torch.randn(B, 21, 3, device="cuda", generator=g) * 0.02
+    pd = torch.rand(B, 15, device="cuda", generator=g) * 2e-3
+    pd[3, 4] = float("nan")                                                         # lt() is False for NaN
+    ok = torch.rand(B, device="cuda", generator=g) < 0.6
+    if case == "none":
+        ok[:] = False
+    if case == "only_row0":
+        ok[:] = False; ok[0] = True; pd[0] = 1.0                                    # only (sample 0, wrist) = flat row index 0 is selected
+    jm = pd.lt(1e-3)
+    jm = torch.cat((torch.ones(B, 1, device="cuda", dtype=torch.bool), jm, jm[:, [2, 5, 8, 11, 14]]), dim=-1)
+    rows = (ok.unsqueeze(-1) & jm).reshape(-1)
+    z = (pix.reshape(-1, 3) - mano.reshape(-1, 3)).float()
+    az = z.abs()
+    per_row = torch.where(az < 0.01, 0.5 * z * z, 0.01 * (az - 0.005)).mean(-1)
+    m = rows.to(per_row.dtype)
+    idx_sum = (torch.arange(m.numel(), device="cuda", dtype=per_row.dtype) * m).sum()
+    val = (per_row * m).sum() / torch.clamp(m.sum(), min=1.0)
+    ref = torch.where(idx_sum == 0, torch.zeros_like(val), val) * 100.0
+    gref, = torch.autograd.grad(ref, pix)
+    out = ops.M2P.apply(pix, mano, ok, pd, 100.0)
+    assert _rel(out.detach().double(), ref.detach().double()) < 2e-6 or (float(ref) == 0.0 and float(out) == 0.0)
+    gg, = torch.autograd.grad(out, pix)
+    assert (float(gref.abs().max()) == 0.0 and float(gg.abs().max()) == 0.0) or _rel(gg, gref) < 2e-6
+    if case != "mixed":
+        assert float(out) == 0.0
+
+
+def test_synthetic_render_with_the_fused_point_kernels_equals_the_elementwise_chain(render):
+    """Render.forward (mano_layer.py:983-1039): the no-gradient path (placement + view rotation + cube normalisation as one launch
+    each) against the differentiable path (the reference's chain of elementwise operators)."""
+    from dsf_amd.train_step import synthetic_batch
+    g = torch.Generator(device="cuda").manual_seed(11)
+    B = 6
+    p, _, cube = synthetic_batch(B, "cuda", seed=6)
+    c0 = torch.cat((torch.zeros(B, 2, device="cuda"), torch.rand(B, 1, device="cuda", generator=g) * 700 + 500), -1)
+    kw = dict(augmentView=torch.rand(B, 3, device="cuda", generator=g) * 6.28, augmentShape=torch.randn(B, 10, device="cuda", generator=g),
+              augmentCenter=(torch.rand(B, 3, device="cuda", generator=g) - 0.5) * 40, augmentSize=1 + (torch.rand(B, 1, device="cuda", generator=g) - 0.5) * 0.4,
+              mask=False)
+    with torch.no_grad():
+        a = render(p, c0, cube, **kw)
+    b = render(p.clone().requires_grad_(True), c0, cube, **kw)                        # gradients wanted: the elementwise chain
+    assert b[3].requires_grad and not a[3].requires_grad
+    names = ("img", "joint_uvd", "verts_uvd", "joint_xyz", "verts_xyz", "center3d", "cube", "M")
+    for n, x, y in zip(names, a, b):
+        if n == "img":
+            assert float(((x - y.detach()).abs() > 1e-4).float().mean()) < 2e-3    # (depths agree to rounding; a vertex moved by an ulp can flip a boundary pixel)
+        else:
+            assert _rel(x.double(), y.detach().double()) < 5e-6, n
+    # without a view rotation as well
+    kw["augmentView"] = None
+    with torch.no_grad():
+        a = render(p, c0, cube, **kw)
+    b = render(p.clone().requires_grad_(True), c0, cube, **kw)
+    assert _rel(a[4].double(), b[4].detach().double()) < 5e-6 and _rel(a[1].double(), b[1].detach().double()) < 5e-6
