@@ -45,6 +45,12 @@ def batch_rodrigues(theta):
     return quat2mat(torch.cat([torch.cos(half), torch.sin(half) * (theta / angle)], dim=1))
 
 
+def _rows62(model_paras):
+    """``model_paras[:, :62]`` (reference :1078, :1103), without the slice when the rows ARE 62 wide: autograd's backward of a slice is a
+    zero fill + a copy, twice per render"""
+    return model_paras if model_paras.size(-1) == 62 else model_paras[:, :62]
+
+
 def _rotmat(rot):
     return batch_rodrigues(rot) if rot.size(-1) == 3 else quat2mat(rot)
 
@@ -451,7 +457,7 @@ class Render(nn.Module):
 
     def render(self, model_paras, center3d, cube_size, M=None):
         """MANO params (cube-normalised) -> (img (B,1,128,128), joint_uvd, joint_xyz, mesh_xyz) (reference :1071-1097)."""
-        hand_verts, hand_joints = self.mano_layer.get_mano_vertices_packed(model_paras[:, :62], global_scale=1 / 125)
+        hand_verts, hand_joints = self.mano_layer.get_mano_vertices_packed(_rows62(model_paras), global_scale=1 / 125)
         if hand_verts.is_cuda and not center3d.requires_grad and not cube_size.requires_grad:
             # the four point transforms below in one launch each way (csrc/step_ops.hip; same operations per element)
             hand_verts, hand_joints, mesh_xyz, joint_xyz = ops.CubePoints.apply(hand_verts, hand_joints, center3d, cube_size)
@@ -466,7 +472,7 @@ class Render(nn.Module):
         return img, joint_uvd, joint_xyz, mesh_xyz
 
     def normal_render(self, model_paras, center3d, cube_size):
-        hand_verts, hand_joints = self.mano_layer.get_mano_vertices_packed(model_paras[:, :62], global_scale=1 / 125)
+        hand_verts, hand_joints = self.mano_layer.get_mano_vertices_packed(_rows62(model_paras), global_scale=1 / 125)
         hand_verts = (hand_verts + 1) / 2 * cube_size.unsqueeze(1) + center3d.unsqueeze(1)
         hand_joints = (hand_joints + 1) / 2 * cube_size.unsqueeze(1) + center3d.unsqueeze(1)
         img, center2d, M, _ = self._depth_crop(hand_verts, center3d, cube_size)
@@ -484,7 +490,7 @@ class Render(nn.Module):
         return img
 
     def get_mesh_xyz(self, model_paras):
-        hand_mesh, hand_joints = self.mano_layer.get_mano_vertices_packed(model_paras[:, :62], global_scale=1 / 125)
+        hand_mesh, hand_joints = self.mano_layer.get_mano_vertices_packed(_rows62(model_paras), global_scale=1 / 125)
         return hand_joints, hand_mesh
 
     def mesh2img(self, hand_mesh, center3d, cube_size):
