@@ -59,7 +59,7 @@ SYMBOLS = [
     "dsf_bn_acc_rows", "dsf_conv_x6_forward_splits", "dsf_conv_x6_forward_into", "dsf_conv_x6_forward_bn_acc", "dsf_bn_forward_acc", "dsf_bn_backward_acc",
     "dsf_conv_x6_forward_plan", "dsf_conv_co1_forward", "dsf_conv_x6_wrw_bias", "dsf_bn_backward_pair", "dsf_bn_backward_acc_pair",
     "dsf_m2d_forward", "dsf_m2d_backward", "dsf_cube_points_forward", "dsf_cube_points_backward", "dsf_view_rotate", "dsf_part_mean_forward",
-    "dsf_part_mean_backward", "dsf_mano_reg_forward", "dsf_mano_reg_backward", "dsf_cube_normalise", "dsf_m2p_forward", "dsf_m2p_backward", "dsf_sphere_mixed",
+    "dsf_part_mean_backward", "dsf_mano_reg_forward", "dsf_mano_reg_backward", "dsf_cube_normalise", "dsf_m2p_forward", "dsf_m2p_backward", "dsf_sphere_mixed", "dsf_offset2joint_forward_strided", "dsf_offset2joint_backward_strided", "dsf_pool_linear_forward", "dsf_pool_linear_backward",
 ]
 
 

@@ -356,20 +356,22 @@ __device__ __forceinline__ float block_sum(float v, float* s) {
     return v;
 }
 
+// (sb, sc, sq): batch / channel / pixel strides of the maps in floats -- NCHW (4 J S S, S S, 1) or channels-last (4 J S S, 1, 4 J):
+// the network's maps are channels-last, and reading them in place saves the layout copy in front of every decode (and behind
+// every backward: the gradient is written in the maps' own layout)
 __global__ __launch_bounds__(256) void offset2joint_fwd_kernel(const float* __restrict__ maps,
                                                                const float* __restrict__ depth, int J, int H, int S,
                                                                float ks, float scale, float* __restrict__ joints,
-                                                               float* __restrict__ stats) {
+                                                               float* __restrict__ stats, int64_t sb, int64_t sc, int64_t sq) {
     __shared__ float s_red[4];
     const int j = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
-    const int64_t plane = (int64_t)S * S;
-    const float* mb = maps + (int64_t)b * 4 * J * plane;
+    const float* mb = maps + (int64_t)b * sb;
     const int step = H / S;
     float mx = -INFINITY;
     for (int q = t; q < S * S; q += 256) {
         const int y = q / S, x = q % S;
         const float dep = depth[((int64_t)b * H + y * step) * H + x * step];
-        const float hm = (dep < 0.99f) ? mb[(3 * J + j) * plane + q] : 0.f;
+        const float hm = (dep < 0.99f) ? mb[(3 * J + j) * sc + q * sq] : 0.f;
         mx = fmaxf(mx, hm * scale);
     }
     mx = block_max(mx, s_red);
@@ -378,13 +380,13 @@ __global__ __launch_bounds__(256) void offset2joint_fwd_kernel(const float* __re
         const int y = q / S, x = q % S;
         const float dep = depth[((int64_t)b * H + y * step) * H + x * step];
         const float m = (dep < 0.99f) ? 1.f : 0.f;
-        const float hm = mb[(3 * J + j) * plane + q] * m;
+        const float hm = mb[(3 * J + j) * sc + q * sq] * m;
         const float e = expf(hm * scale - mx);
         const float dist = ks - hm * ks;
         den += e;
-        a0 += (mb[(j * 3) * plane + q] * m * dist + grid_centre(x, S)) * e;
-        a1 += (mb[(j * 3 + 1) * plane + q] * m * dist + grid_centre(y, S)) * e;
-        a2 += (mb[(j * 3 + 2) * plane + q] * m * dist + dep) * e;
+        a0 += (mb[(j * 3) * sc + q * sq] * m * dist + grid_centre(x, S)) * e;
+        a1 += (mb[(j * 3 + 1) * sc + q * sq] * m * dist + grid_centre(y, S)) * e;
+        a2 += (mb[(j * 3 + 2) * sc + q * sq] * m * dist + dep) * e;
     }
     den = block_sum(den, s_red); a0 = block_sum(a0, s_red); a1 = block_sum(a1, s_red); a2 = block_sum(a2, s_red);
     if (t == 0) {
@@ -399,11 +401,11 @@ __global__ __launch_bounds__(256) void offset2joint_bwd_kernel(const float* __re
                                                                const float* __restrict__ joints,
                                                                const float* __restrict__ stats,
                                                                const float* __restrict__ gj, int J, int H, int S,
-                                                               float ks, float scale, float* __restrict__ gmaps) {
+                                                               float ks, float scale, float* __restrict__ gmaps, int64_t sb, int64_t sc,
+                                                               int64_t sq) {
     const int j = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
-    const int64_t plane = (int64_t)S * S;
-    const float* mb = maps + (int64_t)b * 4 * J * plane;
-    float* gb = gmaps + (int64_t)b * 4 * J * plane;
+    const float* mb = maps + (int64_t)b * sb;
+    float* gb = gmaps + (int64_t)b * sb;
     const int step = H / S;
     const float mx = stats[(b * J + j) * 2], den = stats[(b * J + j) * 2 + 1];
     const float g0 = gj[(b * J + j) * 3], g1 = gj[(b * J + j) * 3 + 1], g2 = gj[(b * J + j) * 3 + 2];
@@ -413,18 +415,18 @@ __global__ __launch_bounds__(256) void offset2joint_bwd_kernel(const float* __re
         const int y = q / S, x = q % S;
         const float dep = depth[((int64_t)b * H + y * step) * H + x * step];
         const float m = (dep < 0.99f) ? 1.f : 0.f;
-        const float hm = mb[(3 * J + j) * plane + q] * m;
+        const float hm = mb[(3 * J + j) * sc + q * sq] * m;
         const float w = expf(hm * scale - mx) / den;
         const float dist = ks - hm * ks;
-        const float u0 = mb[(j * 3) * plane + q] * m, u1 = mb[(j * 3 + 1) * plane + q] * m, u2 = mb[(j * 3 + 2) * plane + q] * m;
+        const float u0 = mb[(j * 3) * sc + q * sq] * m, u1 = mb[(j * 3 + 1) * sc + q * sq] * m, u2 = mb[(j * 3 + 2) * sc + q * sq] * m;
         const float v0 = u0 * dist + grid_centre(x, S), v1 = u1 * dist + grid_centre(y, S), v2 = u2 * dist + dep;
         const float gw = g0 * v0 + g1 * v1 + g2 * v2;
         const float ga = w * (gw - gdotj);                      // softmax backward
         const float gdist = w * (g0 * u0 + g1 * u1 + g2 * u2);
-        gb[(j * 3) * plane + q] = w * g0 * dist * m;
-        gb[(j * 3 + 1) * plane + q] = w * g1 * dist * m;
-        gb[(j * 3 + 2) * plane + q] = w * g2 * dist * m;
-        gb[(3 * J + j) * plane + q] = (ga * scale - gdist * ks) * m;
+        gb[(j * 3) * sc + q * sq] = w * g0 * dist * m;
+        gb[(j * 3 + 1) * sc + q * sq] = w * g1 * dist * m;
+        gb[(j * 3 + 2) * sc + q * sq] = w * g2 * dist * m;
+        gb[(3 * J + j) * sc + q * sq] = (ga * scale - gdist * ks) * m;
     }
 }
 
@@ -534,7 +536,16 @@ extern "C" int dsf_offset2joint_forward(const float* maps, const float* depth, i
     DSF_CHECK_ARG(maps && depth && joints && stats && B >= 0 && J > 0 && S > 0 && H >= S && H % S == 0);
     if (B == 0) return DSF_OK;
     hipLaunchKernelGGL(offset2joint_fwd_kernel, dim3(J, B), dim3(256), 0, (hipStream_t)stream, maps, depth, J, H, S,
-                       kernel_size, scale, joints, stats);
+                       kernel_size, scale, joints, stats, (int64_t)4 * J * S * S, (int64_t)S * S, (int64_t)1);
+    return dsf_launch_status();
+}
+
+extern "C" int dsf_offset2joint_forward_strided(const float* maps, const int64_t* map_strides, const float* depth, int B, int J, int H, int S,
+                                                float kernel_size, float scale, float* joints, float* stats, dsf_stream_t stream) {
+    DSF_CHECK_ARG(maps && map_strides && depth && joints && stats && B >= 0 && J > 0 && S > 0 && H >= S && H % S == 0);
+    if (B == 0) return DSF_OK;
+    hipLaunchKernelGGL(offset2joint_fwd_kernel, dim3(J, B), dim3(256), 0, (hipStream_t)stream, maps, depth, J, H, S,
+                       kernel_size, scale, joints, stats, map_strides[0], map_strides[1], map_strides[2]);
     return dsf_launch_status();
 }
 
@@ -545,6 +556,17 @@ extern "C" int dsf_offset2joint_backward(const float* maps, const float* depth, 
                   H % S == 0);
     if (B == 0) return DSF_OK;
     hipLaunchKernelGGL(offset2joint_bwd_kernel, dim3(J, B), dim3(256), 0, (hipStream_t)stream, maps, depth, joints,
-                       stats, grad_joints, J, H, S, kernel_size, scale, grad_maps);
+                       stats, grad_joints, J, H, S, kernel_size, scale, grad_maps, (int64_t)4 * J * S * S, (int64_t)S * S, (int64_t)1);
+    return dsf_launch_status();
+}
+
+extern "C" int dsf_offset2joint_backward_strided(const float* maps, const int64_t* map_strides, const float* depth, const float* joints,
+                                                 const float* stats, const float* grad_joints, int B, int J, int H, int S, float kernel_size,
+                                                 float scale, float* grad_maps, dsf_stream_t stream) {
+    DSF_CHECK_ARG(maps && map_strides && depth && joints && stats && grad_joints && grad_maps && B >= 0 && J > 0 && S > 0 && H >= S &&
+                  H % S == 0);
+    if (B == 0) return DSF_OK;
+    hipLaunchKernelGGL(offset2joint_bwd_kernel, dim3(J, B), dim3(256), 0, (hipStream_t)stream, maps, depth, joints,
+                       stats, grad_joints, J, H, S, kernel_size, scale, grad_maps, map_strides[0], map_strides[1], map_strides[2]);
     return dsf_launch_status();
 }

@@ -8,6 +8,7 @@
 //   S3 view rotation  RotationPoints (mano_layer.py:874-884) with batch_rodrigues / quat2mat (:773-805): inference only
 //   S4 masked part mean  the per-part masked means of JointICPLoss / FingerICPLoss (metric/meshLoss.py:389-394)
 //   S5 MANO regularisers  mean(beta^2) and mean(|min(scale, 0)|) of the Pretrain losses (train_render.py:463-464)
+//   S7 pooled head  AdaptiveAvgPool2d(1) + Linear of the MANO regression head (model/backbone.py:225-226), forward and backward
 //   S6 M2P        the masked Huber term that lets a trusted MANO fit teach the pixel branch (train_render.py:590-603, 787-801)
 // Arithmetic per element is the reference's, operation for operation (-ffp-contract=off); reductions run in a fixed order
 // (deterministic), which differs from torch's reduction order in the last bits only.
@@ -282,6 +283,63 @@ __global__ __launch_bounds__(256) void mano_reg_bwd_kernel(const float* __restri
     gp[i] = r;
 }
 
+// ---- S7: the MANO regression head (model/backbone.py:225-226: AdaptiveAvgPool2d(1) -> Flatten -> Linear(C, 62)) on a channels-last
+//      feature map x (B, HW, C): pooled[b][c] = mean_p x[b][p][c];  out[b][o] = bias[o] + sum_c pooled[b][c] W[o][c].  One workgroup
+//      per sample.  torch runs it as a mean reduction + a hipBLASLt GEMM (a 46 us launch for a 32 x 512 x 62 product) + their
+//      five backward launches; fixed-order sums here.
+constexpr int PL_MAX_C = 2048;
+__global__ __launch_bounds__(256) void pool_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
+                                                              int HW, int C, int O, float* __restrict__ pooled, float* __restrict__ out) {
+    __shared__ float s_p[PL_MAX_C];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float* xb = x + (int64_t)b * HW * C;
+    for (int c = t; c < C; c += 256) {
+        float acc = 0.f;
+        for (int p = 0; p < HW; ++p) acc += xb[(int64_t)p * C + c];
+        const float m = acc / (float)HW;
+        s_p[c] = m;
+        pooled[(int64_t)b * C + c] = m;
+    }
+    __syncthreads();
+    for (int o = wave; o < O; o += 4) {
+        float acc = 0.f;
+        for (int c = lane; c < C; c += 64) acc += s_p[c] * W[(int64_t)o * C + c];
+        acc = wave_sum(acc);
+        if (lane == 0) out[(int64_t)b * O + o] = acc + (bias ? bias[o] : 0.f);
+    }
+}
+
+// gx[b][p][c] = (sum_o g[b][o] W[o][c]) / HW   (one workgroup per sample)
+__global__ __launch_bounds__(256) void pool_linear_bwd_x_kernel(const float* __restrict__ g, const float* __restrict__ W, int HW, int C, int O,
+                                                                float* __restrict__ gx) {
+    __shared__ float s_g[64];
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (t < O) s_g[t] = g[(int64_t)b * O + t];
+    __syncthreads();
+    for (int c = t; c < C; c += 256) {
+        float acc = 0.f;
+        for (int o = 0; o < O; ++o) acc += s_g[o] * W[(int64_t)o * C + c];
+        const float v = acc / (float)HW;
+        for (int p = 0; p < HW; ++p) gx[((int64_t)b * HW + p) * C + c] = v;
+    }
+}
+
+// gW[o][c] = sum_b g[b][o] pooled[b][c];  gb[o] = sum_b g[b][o]   (one workgroup per output row o)
+__global__ __launch_bounds__(256) void pool_linear_bwd_w_kernel(const float* __restrict__ g, const float* __restrict__ pooled, int B, int C, int O,
+                                                                float* __restrict__ gW, float* __restrict__ gb) {
+    const int o = blockIdx.x, t = threadIdx.x;
+    for (int c = t; c < C; c += 256) {
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) acc += g[(int64_t)b * O + o] * pooled[(int64_t)b * C + c];
+        gW[(int64_t)o * C + c] = acc;
+    }
+    if (t == 0 && gb) {
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) acc += g[(int64_t)b * O + o];
+        gb[o] = acc;
+    }
+}
+
 }  // namespace
 
 extern "C" int dsf_m2d_forward(const float* real, const float* synth, int B, int P, float thresh, float scale, float* sums, float* per,
@@ -393,5 +451,24 @@ extern "C" int dsf_mano_reg_backward(const float* paras, const float* grad_out, 
     const int64_t n = (int64_t)B * W;
     hipLaunchKernelGGL(mano_reg_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, paras, grad_out, B, W, beta_col,
                        scale_col, w_beta, w_scale, grad_paras);
+    return dsf_launch_status();
+}
+
+extern "C" int dsf_pool_linear_forward(const float* x, const float* weight, const float* bias, int B, int HW, int C, int O, float* pooled,
+                                       float* out, dsf_stream_t stream) {
+    DSF_CHECK_ARG(x && weight && pooled && out && B >= 0 && HW > 0 && C > 0 && O > 0);
+    if (C > PL_MAX_C) return DSF_ERR_UNSUPPORTED;
+    if (B == 0) return DSF_OK;
+    hipLaunchKernelGGL(pool_linear_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, weight, bias, HW, C, O, pooled, out);
+    return dsf_launch_status();
+}
+
+extern "C" int dsf_pool_linear_backward(const float* grad_out, const float* pooled, const float* weight, int B, int HW, int C, int O,
+                                        float* grad_x, float* grad_weight, float* grad_bias, dsf_stream_t stream) {
+    DSF_CHECK_ARG(grad_out && pooled && weight && B >= 0 && HW > 0 && C > 0 && O > 0 && O <= 64);
+    if (B == 0) return DSF_OK;
+    if (grad_x) hipLaunchKernelGGL(pool_linear_bwd_x_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, grad_out, weight, HW, C, O, grad_x);
+    if (grad_weight) hipLaunchKernelGGL(pool_linear_bwd_w_kernel, dim3(O), dim3(256), 0, (hipStream_t)stream, grad_out, pooled, B, C, O, grad_weight,
+                                        grad_bias);
     return dsf_launch_status();
 }

@@ -17,6 +17,7 @@ from .resnet import BasicBlock, Bottleneck
 from .. import nn_conv
 from ..nn_norm import FusedBatchNorm2d, ConvBN, take_twin
 from ..util.generateFeature import joint2offset, offset2joint_softmax
+from .. import ops as _ops
 from ..streams import fork
 
 _BRIDGE_FORK = [os.environ.get("DSF_BRIDGE_FORK", "1") == "1"]
@@ -57,6 +58,13 @@ class _Layers:
 
     def __exit__(self, *a):
         _resnet._CONV[0], _resnet._FUSED_BN[0] = self._saved
+
+
+def _head(seq, x):
+    """``mano_regress`` = Sequential(AdaptiveAvgPool2d(1), Flatten, Linear): pooling + product as one launch on the GPU (ops.PoolLinear:
+    torch runs a mean reduction, a hipBLASLt GEMM and five backward launches for a 32 x 512 x 62 product), the modules themselves elsewhere"""
+    out = _ops.pool_linear(x, seq[2]) if (len(seq) == 3 and isinstance(seq[2], nn.Linear) and isinstance(seq[0], nn.AdaptiveAvgPool2d)) else None
+    return out if out is not None else seq(x)
 
 
 def convtranspose_bn_relu(cin, cout, kernel, L):
@@ -100,7 +108,7 @@ class _TwoBranchNet(nn.Module):
     def _run_trunk(self, x, suffix):
         g = lambda n: getattr(self, n + suffix)
         c4, c4b = take_twin(g('layer4')(g('layer3')(g('layer2')(g('layer1')(x)))))    # c4 is read twice: a handle each (nn_norm.take_twin)
-        mano = g('mano_regress')(c4b)
+        mano = _head(g('mano_regress'), c4b)
         feat = g('deconv_layer2')(g('deconv_layer3')(g('deconv_layer4')(c4)))
         heads = g('finals')
         pix = nn_conv.fused_heads(feat, heads)
@@ -178,7 +186,7 @@ class MANO_OCR_stage(_TwoBranchNet):
             c4, c4b = take_twin(self.layer4(self.layer3(self.layer2(self.layer1(c0)))))
             f = fork(c4.device, params=self)
             with f.branch(0, c4b):
-                mano = self.mano_regress(c4b)
+                mano = _head(self.mano_regress, c4b)
                 mano_img, mano_uvd, _, _ = render.render(mano, center, cube)
                 remap = joint2offset(mano_uvd, mano_img, 0.8, 64)
             feat = self.deconv_layer2(self.deconv_layer3(self.deconv_layer4(c4)))

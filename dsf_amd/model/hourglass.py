@@ -189,4 +189,6 @@ class PoseNetMANO(nn.Module):
 
     def forward(self, img):
         preds, hg = self.body(img)
-        return preds, self.mano_regress(hg)
+        from .. import ops
+        head = ops.pool_linear(hg, self.mano_regress[2])          # pooling + Linear in one launch (ops.PoolLinear)
+        return preds, (head if head is not None else self.mano_regress(hg))

@@ -618,17 +618,22 @@ def huber_mean(x, y, delta=0.01, size_average=True, weight=1.0):
 
 
 class Offset2Joint(Function):
-    """GFM.offset2joint_softmax (util/generateFeature.py:39-59)."""
+    """GFM.offset2joint_softmax (util/generateFeature.py:39-59).  The maps are read in the layout they come in (NCHW or the
+    network's channels-last) and their gradient is written in that layout: no layout copy either way."""
 
     @staticmethod
     def forward(ctx, maps, depth, kernel_size, scale):
-        maps, depth = f32(maps), f32(depth)
+        maps, depth = (maps if maps.dtype == torch.float32 else maps.float()), f32(depth)
+        st = _map_strides(maps)
+        if st is None or st[0] != maps[0].numel():      # an exotic layout: settle on plain contiguous
+            maps = maps.contiguous()
+            st = _map_strides(maps)
         B, C, S, _ = maps.shape
         J, H = C // 4, depth.shape[-1]
         joints = _empty((B, J, 3), maps)
         stats = _empty((B, J, 2), maps)
-        check(L.lib().dsf_offset2joint_forward(ptr(maps), ptr(depth), I(B), I(J), I(H), I(S), F(kernel_size), F(scale),
-                                               ptr(joints), ptr(stats), stream_ptr()), "dsf_offset2joint_forward")
+        check(L.lib().dsf_offset2joint_forward_strided(L.addr(maps), st, ptr(depth), I(B), I(J), I(H), I(S), F(kernel_size), F(scale),
+                                                       ptr(joints), ptr(stats), stream_ptr()), "dsf_offset2joint_forward_strided")
         ctx.save_for_backward(maps, depth, joints, stats)
         ctx.args = (kernel_size, scale)
         return joints
@@ -639,10 +644,11 @@ class Offset2Joint(Function):
         maps, depth, joints, stats = ctx.saved_tensors
         ks, scale = ctx.args
         B, C, S, _ = maps.shape
-        gm = _empty(maps.shape, maps)
-        check(L.lib().dsf_offset2joint_backward(ptr(maps), ptr(depth), ptr(joints), ptr(stats), ptr(f32(g)), I(B),
-                                                I(C // 4), I(depth.shape[-1]), I(S), F(ks), F(scale), ptr(gm),
-                                                stream_ptr()), "dsf_offset2joint_backward")
+        gm = torch.empty_like(maps)                       # preserve_format: the maps' own dense layout
+        assert gm.stride() == maps.stride()
+        check(L.lib().dsf_offset2joint_backward_strided(L.addr(maps), _map_strides(maps), ptr(depth), ptr(joints), ptr(stats), ptr(f32(g)), I(B),
+                                                        I(C // 4), I(depth.shape[-1]), I(S), F(ks), F(scale), L.addr(gm),
+                                                        stream_ptr()), "dsf_offset2joint_backward_strided")
         return gm, None, None, None
 
 
@@ -815,3 +821,47 @@ class ManoReg(Function):
         check(L.lib().dsf_mano_reg_backward(ptr(paras), ptr(f32(g)), I(B), I(W), I(bc), I(sc), F(wb), F(ws_), ptr(gp), stream_ptr()),
               "dsf_mano_reg_backward")
         return gp, None, None, None, None
+
+
+class PoolLinear(Function):
+    """``Linear(AdaptiveAvgPool2d(1)(x).flatten(1))`` (model/backbone.py:225-226: the MANO regression head) on a channels-last feature
+    map: one launch forward, two backward (csrc/step_ops.hip); the input gradient comes back channels-last."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = x.contiguous(memory_format=torch.channels_last)
+        w = f32(weight)
+        b = f32(bias) if bias is not None else None
+        B, C, H, W_ = x.shape
+        O = w.shape[0]
+        pooled = _empty((B, C), x)
+        out = _empty((B, O), x)
+        check(L.lib().dsf_pool_linear_forward(L.addr(x), ptr(w), ptr(b), I(B), I(H * W_), I(C), I(O), ptr(pooled), ptr(out), stream_ptr()),
+              "dsf_pool_linear_forward")
+        ctx.save_for_backward(pooled, w)
+        ctx.dims = (B, C, H, W_, bias is not None)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        pooled, w = ctx.saved_tensors
+        B, C, H, W_, has_bias = ctx.dims
+        O = w.shape[0]
+        g = f32(g)
+        gx = torch.empty((B, C, H, W_), device=g.device, dtype=torch.float32, memory_format=torch.channels_last) if ctx.needs_input_grad[0] else None
+        gw = _empty((O, C), g) if ctx.needs_input_grad[1] else None
+        gb = _empty((O,), g) if (has_bias and ctx.needs_input_grad[2] and gw is not None) else None
+        check(L.lib().dsf_pool_linear_backward(ptr(g), ptr(pooled), ptr(w), I(B), I(H * W_), I(C), I(O), L.addr(gx) if gx is not None else None,
+                                               ptr(gw), ptr(gb), stream_ptr()), "dsf_pool_linear_backward")
+        if has_bias and ctx.needs_input_grad[2] and gb is None:
+            gb = g.sum(0)
+        return gx, gw, gb
+
+
+def pool_linear(x, linear):
+    """the fused head when it applies (GPU, fp32, C <= 2048, <= 64 outputs), else None"""
+    if x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.shape[1] <= 2048 and linear.out_features <= 64 and x.shape[0] > 0 \
+            and linear.weight.dtype == torch.float32:
+        return PoolLinear.apply(x, linear.weight, linear.bias)
+    return None

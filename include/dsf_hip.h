@@ -292,6 +292,14 @@ int dsf_offset2joint_forward(const float* maps, const float* depth, int B, int J
 int dsf_offset2joint_backward(const float* maps, const float* depth, const float* joints,
                               const float* stats, const float* grad_joints, int B, int J, int H, int S,
                               float kernel_size, float scale, float* grad_maps, dsf_stream_t stream);
+/* The same pair on maps of ANY uniformly strided layout: map_strides = {batch, channel, pixel} strides in floats (NCHW:
+ * {4 J S S, S S, 1}; channels-last, the layout the network produces: {4 J S S, 1, 4 J}); grad_maps is written in the maps' own
+ * layout.  Round 6: the decode of a channels-last map needs no layout copy in front of it and none behind its backward. */
+int dsf_offset2joint_forward_strided(const float* maps, const int64_t* map_strides, const float* depth, int B, int J, int H, int S,
+                                     float kernel_size, float scale, float* joints, float* stats, dsf_stream_t stream);
+int dsf_offset2joint_backward_strided(const float* maps, const int64_t* map_strides, const float* depth, const float* joints,
+                                      const float* stats, const float* grad_joints, int B, int J, int H, int S, float kernel_size,
+                                      float scale, float* grad_maps, dsf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * K11  fp32 implicit-GEMM convolution on the matrix cores (v_mfma_f32_32x32x2_f32).
@@ -610,6 +618,14 @@ int dsf_m2p_forward(const float* juvd_pix, const float* juvd_mano, const unsigne
 int dsf_m2p_backward(const float* juvd_pix, const float* juvd_mano, const unsigned char* sample_ok, const float* part_dist,
                      const float* aux, const float* grad_out, int B, float part_thresh, float delta, float weight, float* grad_pix,
                      dsf_stream_t stream);
+/* The MANO regression head, /root/reference/model/backbone.py:225-226 (`nn.AdaptiveAvgPool2d(1)`, flatten, `nn.Linear(C, 62)`) on a
+ * channels-last feature map x (B, HW, C): pooled (B,C) = mean over the pixels (kept for the backward pass), out (B,O) = pooled W^T +
+ * bias.  Backward: grad_x (B,HW,C) = (grad_out W) / HW broadcast over the pixels, grad_weight (O,C), grad_bias (O) (any of the
+ * three may be NULL; grad_bias rides with grad_weight).  C <= 2048, O <= 64.  Fixed-order sums. */
+int dsf_pool_linear_forward(const float* x, const float* weight, const float* bias, int B, int HW, int C, int O, float* pooled,
+                            float* out, dsf_stream_t stream);
+int dsf_pool_linear_backward(const float* grad_out, const float* pooled, const float* weight, int B, int HW, int C, int O,
+                             float* grad_x, float* grad_weight, float* grad_bias, dsf_stream_t stream);
 int dsf_part_mean_forward(const float* dis, const int64_t* seg, int B, int P, int n_parts, float* out, float* valid,
                           dsf_stream_t stream);
 int dsf_part_mean_backward(const float* grad_out, const int64_t* seg, const float* valid, int B, int P, int n_parts, float* grad_dis,

@@ -213,7 +213,7 @@ def test_forked_streams_are_invisible(render, det_mode, kind):
         assert all(torch.equal(a, b) for a, b in zip(first, g))
 
 
-def test_graphed_step_refuses_a_graph_with_memset_nodes(render):
+def test_graphed_step_refuses_a_graph_with_memset_nodes(render, monkeypatch):
     """A step holding a torch multi-block reduction (here: a one-shot global mean over a channels-last map) captures a
     hipMemsetAsync node; GraphedStep must refuse it rather than replay wrong numbers at some later step."""
     from dsf_amd.model.hourglass import PoseNetMANO
@@ -221,6 +221,8 @@ def test_graphed_step_refuses_a_graph_with_memset_nodes(render):
     torch.manual_seed(0)
     net = PoseNetMANO(1, 21).cuda()
     net.mano_regress[0] = torch.nn.AdaptiveAvgPool2d(1)
+    from dsf_amd import ops
+    monkeypatch.setattr(ops, "pool_linear", lambda *a, **k: None)       # (round 6 fuses pooling + Linear: here torch's own pooling must run)
     step = MeshLossStep(net, render, Config, n_points=512)
     p, c, cube = synthetic_batch(4, "cuda", seed=2)
     tgt = step.make_targets(p, c, cube)

@@ -249,3 +249,44 @@ def test_synthetic_render_with_the_fused_point_kernels_equals_the_elementwise_ch
         a = render(p, c0, cube, **kw)
     b = render(p.clone().requires_grad_(True), c0, cube, **kw)
     assert _rel(a[4].double(), b[4].detach().double()) < 5e-6 and _rel(a[1].double(), b[1].detach().double()) < 5e-6
+
+
+def test_soft_argmax_decode_reads_channels_last_maps_in_place():
+    """GFM.offset2joint_softmax (util/generateFeature.py:39-59) on a channels-last map (what the network produces): same bits as on the
+    NCHW copy, forward and backward, and the gradient comes back channels-last (no layout copy either way)."""
+    from dsf_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(21)
+    B, J, S = 5, 21, 64
+    maps = torch.randn(B, 4 * J, S, S, device="cuda", generator=g) * 0.3
+    depth = torch.where(torch.rand(B, 1, 128, 128, device="cuda", generator=g) < 0.4, torch.rand(B, 1, 128, 128, device="cuda", generator=g) * 1.6 - 0.8,
+                        torch.ones(B, 1, 128, 128, device="cuda"))
+    gj = torch.randn(B, J, 3, device="cuda", generator=g)
+    a = maps.clone().requires_grad_(True)                                            # NCHW
+    b = maps.clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    ja, jb = ops.Offset2Joint.apply(a, depth, 0.8, 30.0), ops.Offset2Joint.apply(b, depth, 0.8, 30.0)
+    assert torch.equal(ja, jb)
+    ga, = torch.autograd.grad((ja * gj).sum(), a)
+    gb, = torch.autograd.grad((jb * gj).sum(), b)
+    assert gb.is_contiguous(memory_format=torch.channels_last) and ga.is_contiguous() and torch.equal(ga, gb)
+    # a channel slice (not a dense layout) still works through a copy
+    wide = torch.randn(B, 4 * J + 8, S, S, device="cuda", generator=g)
+    assert torch.equal(ops.Offset2Joint.apply(wide[:, :4 * J], depth, 0.8, 30.0), ops.Offset2Joint.apply(wide[:, :4 * J].contiguous(), depth, 0.8, 30.0))
+
+
+@pytest.mark.parametrize("B,C,H", [(32, 512, 8), (6, 2048, 4), (3, 256, 32)])
+def test_pooled_linear_head_in_one_launch(B, C, H):
+    """AdaptiveAvgPool2d(1) -> Flatten -> Linear(C, 62) (model/backbone.py:225-226) as ops.PoolLinear against the torch modules"""
+    from dsf_amd import ops
+    torch.manual_seed(C)
+    seq = torch.nn.Sequential(torch.nn.AdaptiveAvgPool2d(1), torch.nn.Flatten(), torch.nn.Linear(C, 62)).cuda()
+    x = torch.randn(B, C, H, H, device="cuda").contiguous(memory_format=torch.channels_last)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    g = torch.randn(B, 62, device="cuda")
+    ref = seq(xa)
+    rg = torch.autograd.grad((ref * g).sum(), [xa, seq[2].weight, seq[2].bias])
+    out = ops.pool_linear(xb, seq[2])
+    assert out is not None and _rel(out.detach().double(), ref.detach().double()) < 2e-6
+    og = torch.autograd.grad((out * g).sum(), [xb, seq[2].weight, seq[2].bias])
+    assert og[0].is_contiguous(memory_format=torch.channels_last)
+    for a, b_ in zip(og, rg):
+        assert _rel(a.double(), b_.double()) < 5e-6
