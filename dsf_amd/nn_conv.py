@@ -356,18 +356,20 @@ class grad_pool:
     """``with grad_pool(n_floats, device):`` around a backward pass: the backward-weights kernels (which accumulate their
     pixel splits with float atomics and therefore need zeroed outputs) take their outputs from ONE pre-zeroed buffer,
     256-byte aligned slices handed out in call order, instead of zeroing ~50 separate tensors.  The slices stay valid as
-    long as the gradients that view them live; a pool that runs out falls back to per-layer buffers."""
+    long as the gradients that view them live; a pool that runs out falls back to per-layer buffers.
+    ``reducer``: the parallel.GradAllReducer of the parameters this pass differentiates -- its bucket store is zeroed here, on the
+    stream the pass starts on, and the weight gradients are then written straight into their bucket slots (only THIS reducer: the
+    gradients another network's reducer still holds for its optimizer are not touched)."""
 
-    def __init__(self, n_floats, device):
-        self.n, self.device = int(n_floats), device
+    def __init__(self, n_floats, device, reducer=None):
+        self.n, self.device, self.reducer = int(n_floats), device, reducer
 
     def __enter__(self):
         global _POOL
         self.saved = _POOL
         _POOL = [torch.zeros(self.n, device=self.device, dtype=torch.float32), 0] if self.n > 0 else None
-        from . import parallel
-        if parallel._ACTIVE:                             # data parallel: the reducers' bucket stores are zeroed for this pass
-            parallel.begin_backward()
+        if self.reducer is not None and hasattr(self.reducer, "begin_backward"):
+            self.reducer.begin_backward()
         return self
 
     def __exit__(self, *a):

@@ -62,7 +62,7 @@ class GradAllReducer:
     Parameters are grouped (reverse registration order ~ the order backward produces their grads) into ~32 MiB buckets, and
     every bucket is a slice of ONE persistent flat buffer in which each parameter owns a 256-byte aligned slot (its gradient
     in the parameter's own memory order) followed by the bucket's presence row.  The buffer is zeroed once per backward pass
-    (``begin_backward``: one fill launch, issued by ``nn_conv.grad_pool`` when the pass starts); the backward-weights kernels of
+    (``begin_backward``: one fill launch, issued by ``nn_conv.grad_pool(..., reducer=self)`` when the pass starts, else by the first hook); the backward-weights kernels of
     this package write a convolution's dW straight into the weight's slot (``grad_slot``: the slot takes the place of the
     per-step gradient pool), autograd adopts that view as ``p.grad``, and the few gradients produced elsewhere (BatchNorm
     affine parameters, linear layers, biases) are copied into their slots by one multi-tensor copy per bucket.  The
@@ -132,7 +132,6 @@ class GradAllReducer:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
                 p.__dict__["_dsf_hooks_join"] = True     # (nn_conv._side_ok: this hook joins the side stream before it reads)
                 p.__dict__["_dsf_grad_slot"] = self      # (nn_conv._grad_out: the weight gradient is written into its slot)
-            _ACTIVE.append(self)
         from . import streams
         streams.DP_EPOCH[0] += 1     # every module's cached "may this level fork under data parallelism" answer is stale now
 
@@ -166,9 +165,10 @@ class GradAllReducer:
         return self._buf[b][off:off + p.numel()]
 
     def begin_backward(self):
-        """Zeroes the store for the backward pass that starts now: ONE fill per (device, dtype).  Called by nn_conv.grad_pool on
-        the stream the pass starts on (everything that writes a slot is ordered behind it); a pass that never announced itself
-        is caught by the first hook."""
+        """Zeroes the store for the backward pass that starts now: ONE fill per (device, dtype).  Called by
+        ``nn_conv.grad_pool(.., reducer=self)`` on the stream the pass starts on (everything that writes a slot is ordered behind
+        it); a pass that never announced itself is caught by the first hook (the weight gradients launched before that hook went
+        to the ordinary pool and are copied into their slots with the bucket's other stragglers)."""
         if not (self.active and self.enabled) or self._begun:
             return
         for b, w in enumerate(self._work):               # a pass that was abandoned before finish(): its collectives first
@@ -188,8 +188,6 @@ class GradAllReducer:
             p.__dict__.pop("_dsf_hooks_join", None)
             p.__dict__.pop("_dsf_grad_slot", None)
         self.active = False
-        if self in _ACTIVE:
-            _ACTIVE.remove(self)
         from . import streams
         streams.DP_EPOCH[0] += 1
 
@@ -303,14 +301,6 @@ class GradAllReducer:
                         p.grad = None if anywhere[i] == 0.0 else self._view(p)
         self._reset()
         self._begun = False
-
-
-_ACTIVE = []                         # reducers whose stores the next backward pass writes (nn_conv.grad_pool announces the pass)
-
-
-def begin_backward():
-    for r in _ACTIVE:
-        r.begin_backward()
 
 
 def _dense(t):

@@ -157,7 +157,7 @@ class RenderSupervisedStep:
             self._pool_dev = next(self.net.parameters()).device
         with _stat_pool(self, self.net):
             loss, terms = self.loss(tgt)
-            with nn_conv.grad_pool(self._pool_floats if self._pool_dev.type == "cuda" else 0, self._pool_dev):
+            with nn_conv.grad_pool(self._pool_floats if self._pool_dev.type == "cuda" else 0, self._pool_dev, reducer=self.grad_sync):
                 loss.backward()
         return loss.detach(), terms
 
@@ -236,7 +236,7 @@ class MeshLossStep:
             self._pool_dev = next(self.net.parameters()).device
         with _stat_pool(self, self.net):
             loss, terms = self.loss(tgt)
-            with nn_conv.grad_pool(self._pool_floats if self._pool_dev.type == "cuda" else 0, self._pool_dev):
+            with nn_conv.grad_pool(self._pool_floats if self._pool_dev.type == "cuda" else 0, self._pool_dev, reducer=self.grad_sync):
                 loss.backward()
         return loss.detach(), terms
 
@@ -534,7 +534,7 @@ class _StepBase:
         if not hasattr(self, "_pool_floats"):
             self._pool_floats = nn_conv.weight_grad_floats(self.net) + 256
             self._pool_dev = next(self.net.parameters()).device
-        with nn_conv.grad_pool(self._pool_floats if self._pool_dev.type == "cuda" else 0, self._pool_dev):
+        with nn_conv.grad_pool(self._pool_floats if self._pool_dev.type == "cuda" else 0, self._pool_dev, reducer=self.grad_sync):
             loss.backward()
         if self.grad_sync is not None:
             self.grad_sync.finish()

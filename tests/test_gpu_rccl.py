@@ -139,6 +139,18 @@ out["syncbn_running_stats_rel"] = max(float((a_ - b_).abs().max() / a_.abs().max
 FusedSyncBatchNorm2d.force_sync = False
 step_f.grad_sync.detach()
 
+# ---- 1d. two networks, two reducers: a backward pass zeroes ITS reducer's store only (the other's reduced gradients may still be
+#          waiting for their optimizer: GAN-style training) ----------------------------------------------------------------------
+net_g, net_h = build18(), build18()
+sync_gg, sync_hh = GradAllReducer(net_g.parameters(), force=True), GradAllReducer(net_h.parameters(), force=True)
+step_g = RenderSupervisedStep(net_g, render, Config, grad_sync=sync_gg)
+step_h = RenderSupervisedStep(net_h, render, Config, grad_sync=sync_hh)
+step_g.forward_backward(tgt); sync_gg.finish()
+held = grads_of(net_g)                                          # reduced, not yet consumed by an optimizer
+step_h.forward_backward(tgt); sync_hh.finish()                  # another network's pass in between
+out["other_reducers_gradients_survive_a_foreign_pass"] = same(held, grads_of(net_g)) and same(grads_of(net_g), grads_of(net_h))
+sync_gg.detach(); sync_hh.detach()
+
 # ---- 2. forked streams (hourglass arms run backward nodes on branch streams) under the reducer, eager --------------------------
 def build_hg():
     torch.manual_seed(1)
@@ -244,3 +256,4 @@ def test_gradient_all_reduce_on_rccl_at_world_size_one(tmp_path):
     # (same forward to the bit; the backward sums are folded in another order -- fp32 rounding through ~40 BatchNorm layers at B = 4: the
     #  bar of tests/test_gpu_determinism.py's cross-path comparisons)
     assert res["syncbn_grad_rel"] < 2e-2, res
+    assert res["other_reducers_gradients_survive_a_foreign_pass"], res

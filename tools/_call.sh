@@ -1,3 +1,3 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/c14
-timeout 900 python3 tools/x6/try_wrw_splits.py > gpurun_out/c14/wrw_splits.txt 2>&1
-cat gpurun_out/c14/wrw_splits.txt
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/c18; mkdir -p $O; cd $R
+timeout 1500 python3 -m pytest tests/test_gpu_rccl.py tests/test_gpu_dp.py -q -m gpu > $O/pytest_dp.log 2>&1; echo "rc=$?" >> $O/pytest_dp.log
+tail -n 5 $O/pytest_dp.log; cp gpurun_out/rccl_world1.log $O/
