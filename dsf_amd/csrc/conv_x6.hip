@@ -61,6 +61,19 @@ __device__ __forceinline__ int x6_xcd_contiguous(int bid, int total) {
     return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
 }
 
+#ifdef X6_STAMP      // diagnostic build only (tools/x6/wrw_stamps.py): per-workgroup wall-clock stamps; the shipped library has none of this
+__device__ unsigned long long* x6_stamp_buf = nullptr;
+__device__ __forceinline__ void x6_stamp(int slot) {
+    if (x6_stamp_buf && threadIdx.x == 0) {
+        unsigned long long* row = x6_stamp_buf + (size_t)blockIdx.x * 8;
+        row[slot] = wall_clock64();                                     // s_memrealtime: 100 MHz, chip-wide
+        if (slot == 0) { row[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4); row[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20); }   // HW_ID, XCC_ID
+    }
+}
+#else
+__device__ __forceinline__ void x6_stamp(int) {}
+#endif
+
 // Dilation-2 gathers (transposed convolutions, backward-data of stride-2 layers) order their rows by output parity class, and the
 // classes differ in live taps (k = 1: one class carries the whole GEMM, three store zeros; k = 3: 4 / 2 / 2 / 1 taps).  In
 // launch order the heavy class would fill two of the eight XCDs and leave six idle (B = 192, 32x32x512 -> 64x64x256 k1: 1090 us):
@@ -690,6 +703,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restri
     constexpr int B_GRANULES = 2 * BN;
     extern __shared__ uint4 x6p_lds[];                   // [stage 2][plane 3][k-group 2][KGS]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    x6_stamp(0);
     const int wm = wave / WN, wn = wave % WN;
     int tile = x6_xcd_contiguous(blockIdx.x, m_tiles * n_tiles * k_splits);
     const int n_tile = tile % n_tiles; tile /= n_tiles;
@@ -840,10 +854,12 @@ __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restri
         }
         __syncthreads();
     };
+    x6_stamp(1);
     for (int chunk = chunk_lo; chunk < chunk_hi; chunk += 2) {
         body(Set0{}, chunk);
         if (chunk + 1 < chunk_hi) body(Set1{}, chunk + 1);
     }
+    x6_stamp(2);
 
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -871,6 +887,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restri
             }
         }
 
+    x6_stamp(3);
     // BatchNorm batch statistics of this tile: as in igemm_x6b_kernel (the partial sums meet in the first 2 KB of the stage)
     if (stats) {
         float (*s_st)[2][64] = reinterpret_cast<float (*)[2][64]>(x6p_lds);
@@ -944,6 +961,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
     __shared__ __attribute__((aligned(16))) char As[2][3 * PLANE];
     __shared__ __attribute__((aligned(16))) char Bs[2][3 * PLANE];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    x6_stamp(0);
     const int wm = (BN == 128) ? (wave >> 1) : wave, wn = (BN == 128) ? (wave & 1) : 0;
     int tile = x6_xcd_contiguous(blockIdx.x, k_tiles * n_tiles * n_splits);
     const int k_tile = tile % k_tiles; tile /= k_tiles;
@@ -974,10 +992,14 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    u32x4 rl[2][4];                                      // [set][A px 0, A px 8, B px 0, B px 8]
-    auto load_piece = [&](auto SET, int j, int mc) {     // rows past m_end get the out-of-range offset (zeros)
+    u32x4 rl[3][4];                                      // [set][A px 0, A px 8, B px 0, B px 8]: chunk c lives in set c % 3
+    auto load_piece = [&](auto SET, int j, int mc, auto INLOOP) __attribute__((always_inline)) {     // rows past m_end get the out-of-range offset (zeros)
+        constexpr bool in_loop = decltype(INLOOP)::value; (void)in_loop;
         constexpr int S = decltype(SET)::value;
         const int m = (j < 2) ? mc + l_p + 8 * j : mc + b_p + 8 * (j - 2);
+#if defined(X6_STAMP) && defined(X6_KO_ADDR)               // knock-out: neither the address arithmetic nor the load after the prologue
+        if (in_loop) return;
+#endif
         if (j < 2) {
             const uint32_t mm = (uint32_t)min(m, M - 1);
             const uint32_t q = x6_fast_div(mm, magic_wo);
@@ -988,9 +1010,15 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
             // bitwise & (no short-circuit): straight-line code, one select
             const bool ok = a_kok & (m < m_end) & ((unsigned)iy < (unsigned)p.Hi) & ((unsigned)ix < (unsigned)p.Wi);
             const uint32_t off = (uint32_t)((((int)b * p.Hi + iy) * p.Wi + ix) * p.Ci + a_c) * 4u;
+#if defined(X6_STAMP) && defined(X6_KO_LOAD)              // knock-out (diagnostic build): the address is computed, the load is not issued after the prologue
+            if (in_loop) { asm volatile("" ::"v"(ok ? off : X_OOB)); return; }
+#endif
             rl[S][j] = x6_load16(xbuf, ok ? off : X_OOB);
         } else {
             const bool ok = b_nok & (m < m_end);
+#if defined(X6_STAMP) && defined(X6_KO_LOAD)
+            if (in_loop) { asm volatile("" ::"v"(ok ? (uint32_t)(m * p.Co + b_n) * 4u : X_OOB)); return; }
+#endif
             rl[S][j] = x6_load16(ybuf, ok ? (uint32_t)(m * p.Co + b_n) * 4u : X_OOB);
         }
     };
@@ -998,10 +1026,14 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
     const int st_offb0 = x6_tr_off(b_p, b_q >> 1) + 8 * (b_q & 1), st_offb1 = x6_tr_off((b_p + 8) & 15, b_q >> 1) + 8 * (b_q & 1);
     const float bias_on = (BIAS && k_tile == 0) ? 1.f : 0.f;            // (a factor, not a branch: see above)
     float bsum0 = 0.f, bsum1 = 0.f, bsum2 = 0.f, bsum3 = 0.f;
-    auto stage_piece = [&](auto SET, int buf, int j) {
+    auto stage_piece = [&](auto SET, int buf, int j) __attribute__((always_inline)) {
         constexpr int S = decltype(SET)::value;
         uint2 h, m, l;
+#if defined(X6_STAMP) && defined(X6_KO_SPLIT)              // knock-out: the tile is stored unsplit (wrong values, same LDS traffic)
+        h = make_uint2(rl[S][j][0], rl[S][j][1]); m = make_uint2(rl[S][j][2], rl[S][j][3]); l = h;
+#else
         split4(rl[S][j], h, m, l);
+#endif
         if (BIAS && j >= 2) {                            // (compile-time; rows past m_end were loaded as zeros; scalar FMAs: no packed FP32)
             const f32x4 v = __builtin_bit_cast(f32x4, rl[S][j]);
             bsum0 = fmaf(v[0], bias_on, bsum0); bsum1 = fmaf(v[1], bias_on, bsum1);
@@ -1015,11 +1047,14 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
 
     using Set0 = std::integral_constant<int, 0>;
     using Set1 = std::integral_constant<int, 1>;
+    using Set2 = std::integral_constant<int, 2>;
     if (m_begin < m_end) {
 #pragma unroll
-        for (int j = 0; j < NPC; ++j) load_piece(Set0{}, j, m_begin);
+        for (int j = 0; j < NPC; ++j) load_piece(Set0{}, j, m_begin, std::false_type{});
 #pragma unroll
-        for (int j = 0; j < NPC; ++j) load_piece(Set1{}, j, m_begin + XBK);
+        for (int j = 0; j < NPC; ++j) load_piece(Set1{}, j, m_begin + XBK, std::false_type{});
+#pragma unroll
+        for (int j = 0; j < NPC; ++j) load_piece(Set2{}, j, m_begin + 2 * XBK, std::false_type{});
 #pragma unroll
         for (int j = 0; j < NPC; ++j) stage_piece(Set0{}, 0, j);
     }
@@ -1029,7 +1064,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
     // the group addresses pixel row q, channels 4 c .. 4 c + 3 of the block and receives channel (lane & 15) of 4 pixels
     const int f_row = 8 * (lane >> 5) + ((lane & 15) >> 2);                    // + 4 for the second read
     const int f_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);                 // first channel addressed, within the MFMA tile
-    auto frag_off = [&](int cbase, int r) {                                     // cbase: first channel of the MFMA tile
+    auto frag_off = [&](int cbase, int r) __attribute__((always_inline)) {                                     // cbase: first channel of the MFMA tile
         const int c = cbase + f_col;
         return x6_tr_off(f_row + 4 * r, c >> 3) + 2 * (c & 7);
     };
@@ -1038,15 +1073,20 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
     for (int i = 0; i < TM; ++i) { fa[i][0] = frag_off(wm * WM + i * 32, 0); fa[i][1] = frag_off(wm * WM + i * 32, 1); }
 #pragma unroll
     for (int j = 0; j < TN; ++j) { fb[j][0] = frag_off(wn * 64 + j * 32, 0); fb[j][1] = frag_off(wn * 64 + j * 32, 1); }
-    auto tr_read = [&](const char* base, int off0, int off1) {
+    auto tr_read = [&](const char* base, int off0, int off1) __attribute__((always_inline)) {
         struct { s16x4 lo, hi; } v;
         v.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off0));
         v.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off1));
         return __builtin_bit_cast(bf16x8, v);
     };
 
-    auto body = [&](auto SET, auto OTHER, int mc) {
-        constexpr int buf = decltype(SET)::value;
+    // chunk c: fragments from LDS stage c % 2; loads chunk c + 3 into register set c % 3 (free since chunk c was staged during chunk
+    // c - 1); splits and stores chunk c + 1 (register set (c + 1) % 3, loaded during chunk c - 2) into the other stage.  Round 6: the
+    // loads used to run TWO chunks ahead of their split (two register sets) -- ~1.2 chunk times = 1.1-1.4 us at these kernels' pace,
+    // less than a load that misses L2 needs under load: with the loop's buffer loads knocked out (tools/x6/wrw_stamps.py --variant
+    // ko_load, profiles/r06_wrw_knockouts.txt) the main loop of the small-map layers ran 27 % shorter.
+    auto body = [&](auto SET, auto OTHER, auto BUF, int mc) __attribute__((always_inline)) {
+        constexpr int buf = decltype(BUF)::value;
         bf16x8 a[3][TM], b[3][TN];
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
@@ -1059,7 +1099,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
         {
             // program order: fragment reads, the whole loader, the MFMAs; the pipeline below interleaves them
 #pragma unroll
-            for (int pc = 0; pc < NPC; ++pc) load_piece(SET, pc, mc + 2 * XBK);
+            for (int pc = 0; pc < NPC; ++pc) load_piece(SET, pc, mc + 3 * XBK, std::true_type{});
 #pragma unroll
             for (int pc = 0; pc < NPC; ++pc) stage_piece(OTHER, buf ^ 1, pc);
 #pragma unroll
@@ -1085,10 +1125,33 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
         }
         __syncthreads();
     };
-    for (int mc = m_begin; mc < m_end; mc += 2 * XBK) {         // chunks come in pairs: one past m_end is all zeros
-        body(Set0{}, Set1{}, mc);
-        body(Set1{}, Set0{}, mc + XBK);
+    x6_stamp(1);
+    // three register sets x two LDS stages: the pattern repeats after six chunks.  The main loop is straight-line code (the compiler's
+    // s_waitcnt vmcnt(N) are then exact: with a condition in front of every chunk it assumed the fewest loads in flight at each join
+    // and waited for ALL of them at the top of two chunks in six); the last 0-5 chunks of a split run from a nest of conditions
+    int mc = m_begin;
+    for (; mc + 6 * XBK <= m_end; mc += 6 * XBK) {
+        body(Set0{}, Set1{}, Set0{}, mc);
+        body(Set1{}, Set2{}, Set1{}, mc + XBK);
+        body(Set2{}, Set0{}, Set0{}, mc + 2 * XBK);
+        body(Set0{}, Set1{}, Set1{}, mc + 3 * XBK);
+        body(Set1{}, Set2{}, Set0{}, mc + 4 * XBK);
+        body(Set2{}, Set0{}, Set1{}, mc + 5 * XBK);
     }
+    if (mc < m_end) {
+        body(Set0{}, Set1{}, Set0{}, mc);
+        if (mc + XBK < m_end) {
+            body(Set1{}, Set2{}, Set1{}, mc + XBK);
+            if (mc + 2 * XBK < m_end) {
+                body(Set2{}, Set0{}, Set0{}, mc + 2 * XBK);
+                if (mc + 3 * XBK < m_end) {
+                    body(Set0{}, Set1{}, Set1{}, mc + 3 * XBK);
+                    if (mc + 4 * XBK < m_end) body(Set1{}, Set2{}, Set0{}, mc + 4 * XBK);
+                }
+            }
+        }
+    }
+    x6_stamp(2);
 
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -1104,6 +1167,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wrw_x6_kernel(const float* __res
                 else atomicAdd(dW + (int64_t)k * p.Co + n, acc[i][j][r]);
             }
         }
+    x6_stamp(3);
     if (BIAS && k_tile == 0) {                           // (workgroup-uniform) fold the pixel lanes through LDS, one atomic per channel
         float* s_red = reinterpret_cast<float*>(As[0]);  // [pixel lane][BN]: the last chunk's barrier has passed, the tiles are dead
         constexpr int LANES = (BN == 128) ? 8 : 16;
@@ -1418,6 +1482,10 @@ static inline bool x6_arm_dynamic_lds(const void* fn, int bytes, bool* armed) {
 
 extern "C" {
 
+#ifdef X6_STAMP
+int dsf_x6_stamp_buffer(unsigned long long* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(x6_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : 1; }
+#endif
+
 // operands: 1024 x 16 bytes of bf16 pairs; out: workgroups * 256 floats (ignored values); returns the MFMA count issued
 int64_t dsf_mfma_bf16_probe(const void* operands, float* out, int workgroups, int iters, dsf_stream_t stream) {
     if (!operands || !out || workgroups <= 0 || iters <= 0) return -1;
@@ -1485,12 +1553,14 @@ static X6Plan x6_forward_plan(int64_t M, int Ci, int Co, int KH, int KW, int dil
     if (bdirect && bn == 128 && patch_w == 8) bmt = 64;                  // the patch kernel's tiles lie inside one (8 x 8) image
     const int m_tiles = (int)((M + bmt - 1) / bmt);
     const int n_chunks = (KH * KW / (dil * dil)) * ((Ci + XBK - 1) / XBK);          // live chunks of a tile
+    const char* ks_e = getenv("DSF_X6_KSPLIT_WGS");                      // tuning aid, read per call: workgroup target of the K splits
+    const int ks_target = (ks_e && atoi(ks_e) > 0) ? atoi(ks_e) : 512;
     if (k_splits < 1 && patch_w && bdirect && bmt == 64) {
         // the patch kernel's 64-row tiles: one workgroup per CU already runs at the rate of two half-length ones (B = 32, 16x16x256:
         // 256 tiles unsplit 48 us, 2-way 54) and an unsplit launch needs no zero fill, keeps the BatchNorm-statistics epilogue and is
         // deterministic; 128 tiles: unsplit 67 us, 4-way 54.  Splits are ranges of channel chunks, at least two each.
         const int tiles = m_tiles * n_tiles, ch = (Ci + XBK - 1) / XBK;
-        k_splits = tiles < 256 ? (512 + tiles - 1) / tiles : 1;
+        k_splits = tiles < 256 ? (ks_target + tiles - 1) / tiles : 1;
         if (k_splits > ch / 2) k_splits = ch / 2;
         if (k_splits < 1) k_splits = 1;
     }
@@ -1499,7 +1569,7 @@ static X6Plan x6_forward_plan(int64_t M, int Ci, int Co, int KH, int KW, int dil
         // (~1.3 TB/s chip-wide), so 256 tiles run unsplit (69 vs 83 us on the 32x32x128 layers), 128 tiles 4-way, 64 8-way.
         // 64-row tiles (measured, B = 32): 512 tiles unsplit 63 us (128-row: 68), 256 tiles 2-way 70 (75), 128 tiles 4-way 68 (74).
         const int tiles = m_tiles * n_tiles;
-        k_splits = bmt == 64 ? (tiles < 512 ? (512 + tiles - 1) / tiles : 1) : (tiles < 200 ? (512 + tiles / 2) / tiles : 1);
+        k_splits = bmt == 64 ? (tiles < 512 ? (ks_target + tiles - 1) / tiles : 1) : (tiles < 200 ? (ks_target + tiles / 2) / tiles : 1);
         if (k_splits > n_chunks / 8) k_splits = n_chunks / 8;
         if (k_splits < 1) k_splits = 1;
     }
@@ -1620,9 +1690,21 @@ static int x6_wrw_plan(int B, int Ho, int Wo, int Ci, int Co, int KH, int KW, in
     const int K = KH * KW * Ci;
     const int bn = x6_bn(Co);
     k_tiles = (K + 127) / 128; n_tiles = (Co + bn - 1) / bn;
-    // split the pixel reduction so that one round of resident workgroups (2 per CU) covers the chip; >= 4 chunks per split
-    static const int wg_env = [] { const char* e = getenv("DSF_X6_WRW_WGS"); return e ? atoi(e) : 0; }();          // tuning aid
-    int splits = (wg_env > 0 ? wg_env : 512) / (k_tiles * n_tiles);
+    // split the pixel reduction towards ONE workgroup per CU (256), >= 4 chunks per split -- towards two per CU (512) only where
+    // that still leaves a workgroup 1024 chunks or more (the large-batch layers of config 4).  Inside a step these launches run BESIDE
+    // the main queue's kernels: (probably) two of these workgroups hold 96 KB of a CU's LDS and a patch-staged forward workgroup cannot
+    // join them, one leaves it room; and every workgroup ends with 64 KB of float atomics (~13 us of its CU's atomic path:
+    // tools/x6/wrw_stamps.py), half as many at half the workgroups.  Whole steps, one box, alternating blocks
+    // (profiles/r06_wrw_split_target.txt): config 2 17.07 -> 16.62 ms, config 3 15.94 -> 15.34; config 4 159.2 vs 159.7 the other way.
+    // ALONE, a small-map launch is ~10 % slower at 256 (one wave per SIMD): the isolated optimum was the wrong target for rounds 3-5.
+    const char* wg_e = getenv("DSF_X6_WRW_WGS");                         // tuning aid, read per call (tools/ab_env.py alternates it in one process)
+    const int wg_env = wg_e ? atoi(wg_e) : 0;
+    int target = wg_env > 0 ? wg_env : 512;
+    if (wg_env <= 0) {
+        const int s512 = 512 / (k_tiles * n_tiles) > 0 ? 512 / (k_tiles * n_tiles) : 1;
+        if (M / s512 < 1024 * XBK) target = 256;
+    }
+    int splits = target / (k_tiles * n_tiles);
     if (splits < 1) splits = 1;
     per = (M + splits - 1) / splits;
     per = ((per + 2 * XBK - 1) / (2 * XBK)) * (2 * XBK);
@@ -1713,11 +1795,13 @@ int dsf_conv_x6_forward_affine(const float* X, const void* image, const float* b
 }
 
 // igemm_wrw_x6p_kernel's tiling: 32-channel blocks x 128-wide n tiles x row splits (whole output rows, at least four each, pairs on
-// 16-wide maps) towards two workgroups per CU
+// 16-wide maps) towards one workgroup per CU (rounds 4-5: two)
 static int x6_wrw_patch_plan(int B, int H, int W, int Ci, int Co, int& c_tiles, int& n_tiles, int& rows_per_split) {
     c_tiles = (Ci + 31) / 32; n_tiles = (Co + 127) / 128;
     const int RT = B * H;
-    int splits = 512 / (c_tiles * n_tiles);
+    const char* wg_e = getenv("DSF_X6_WRWP_WGS");                        // tuning aid, read per call
+    const int wg_target = (wg_e && atoi(wg_e) > 0) ? atoi(wg_e) : 256;   // one workgroup per CU: see x6_wrw_plan (config 2, alternating blocks: 16.28 -> 16.20 ms)
+    int splits = wg_target / (c_tiles * n_tiles);
     if (splits < 1) splits = 1;
     rows_per_split = (RT + splits - 1) / splits;
     if (rows_per_split < 4) rows_per_split = 4;
