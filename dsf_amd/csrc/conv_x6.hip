@@ -753,19 +753,31 @@ __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restri
     bf16x8 af[2][3][TM];                                 // [set][plane][m block]: A fragments of the current / next tap
     const uint32_t b_lane = (uint32_t)((lane >> 5) * BN + wn * WNC + (lane & 31)) * 16u;
     auto load_a = [&](int i, int chunk) {                // pass i of the patch of `chunk` (past the end: zeros)
+#if defined(X6_STAMP) && defined(X6P_KO_A)                 // knock-out (diagnostic build): patch loads after the first chunk are issued out of range (no memory access)
+        const bool ok = a_off[i] >= 0 && chunk <= chunk_lo && chunk * XBK + a_k4 < p.Ci;
+#else
         const bool ok = a_off[i] >= 0 && chunk < chunk_hi && chunk * XBK + a_k4 < p.Ci;
+#endif
         ra[i] = x6_load16(xbuf, ok ? (uint32_t)(a_off[i] + chunk * XBK) * 4u : X_OOB);
     };
     auto stage_piece = [&](int buf, int i) {
         if (NPASS * 64 > PT::NPIX && a_lds[i] < 0) return;               // the tail of the last pass
         uint2 h, m, l;
+#if defined(X6_STAMP) && defined(X6P_KO_SPLIT)             // knock-out: the patch is stored unsplit
+        h = make_uint2(ra[i][0], ra[i][1]); m = make_uint2(ra[i][2], ra[i][3]); l = h;
+#else
         split4(ra[i], h, m, l);
+#endif
         uint2* dst = reinterpret_cast<uint2*>(&x6p_lds[buf * PT::STAGE + (a_q >> 1) * PT::KGS + a_lds[i]]) + (a_q & 1);
         dst[0] = h; dst[2 * PT::PLANE] = m; dst[4 * PT::PLANE] = l;
     };
     auto load_b = [&](int S, int f, int tap, int chunk) {                // fragment f of step (chunk, tap) (past the end: zeros)
         const int pl = f / TN, j = f % TN;
+#if defined(X6_STAMP) && defined(X6P_KO_B)                 // knock-out: weight-fragment loads after the first chunk are issued out of range
+        const uint32_t dead = chunk <= chunk_lo ? 0u : X_OOB;
+#else
         const uint32_t dead = chunk < chunk_hi ? 0u : X_OOB;
+#endif
         const int wtap = (NT == 4) ? (kh0 + 2 * (tap >> 1)) * p.KW + kw0 + 2 * (tap & 1) : tap;      // tap of the weight image
         const int blk = wtap * n_chunks + chunk;
         rbf[S][pl][j] = x6_load16(wbuf, ((uint32_t)(blk * n_tiles + n_tile) * (uint32_t)(3 * B_GRANULES * 16) +

@@ -16,9 +16,13 @@ ap.add_argument("--variant", default="stamp", help="stamp | ko_load | ko_addr | 
                 "X6_KO_LOAD no buffer loads, X6_KO_ADDR neither loads nor their address arithmetic, X6_KO_SPLIT tiles stored unsplit)")
 ap.add_argument("--wgs", default=None, help="DSF_X6_WRW_WGS: workgroup target of the pixel split")
 ap.add_argument("--wrw-only", action="store_true")
+ap.add_argument("--fwd-only", action="store_true")
 args = ap.parse_args()
 VARIANTS = {"stamp": [], "ko_load": ["-DX6_KO_LOAD=1"], "ko_addr": ["-DX6_KO_ADDR=1"], "ko_split": ["-DX6_KO_SPLIT=1"],
-            "ko_addr_split": ["-DX6_KO_ADDR=1", "-DX6_KO_SPLIT=1"]}
+            "ko_addr_split": ["-DX6_KO_ADDR=1", "-DX6_KO_SPLIT=1"],
+            # knock-outs of igemm_x6p_kernel's loop: patch loads / weight-fragment loads issued out of range after the first chunk (the
+            # instruction stays, the memory access does not), the patch stored unsplit
+            "kop_a": ["-DX6P_KO_A=1"], "kop_b": ["-DX6P_KO_B=1"], "kop_ab": ["-DX6P_KO_A=1", "-DX6P_KO_B=1"], "kop_split": ["-DX6P_KO_SPLIT=1"]}
 so = os.path.join(ROOT, "tools", "x6", "_stamp", "libx6_%s.so" % args.variant)
 cs = os.path.join(ROOT, "dsf_amd", "csrc")
 if not os.path.isfile(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(cs, "conv_x6.hip")):
@@ -87,7 +91,7 @@ def run(tag, fn, flops):
 
 B = 32
 print("backward-weights, igemm_wrw_x6_kernel (variant %s, DSF_X6_WRW_WGS=%s)" % (args.variant, os.environ.get("DSF_X6_WRW_WGS", "512")))
-for (Ci, Co, H, K, s, p) in [(128, 128, 32, 3, 1, 1), (256, 256, 16, 3, 1, 1), (512, 512, 8, 3, 1, 1), (256, 256, 64, 4, 2, 1)]:
+for (Ci, Co, H, K, s, p) in ([] if args.fwd_only else [(128, 128, 32, 3, 1, 1), (256, 256, 16, 3, 1, 1), (512, 512, 8, 3, 1, 1), (256, 256, 64, 4, 2, 1)]):
     Ho = (H + 2 * p - K) // s + 1
     x, gy = nhwc(B, Ci, H), nhwc(B, Co, Ho)
     dw = torch.zeros(K, K, Ci, Co, device="cuda")
@@ -97,7 +101,7 @@ for (Ci, Co, H, K, s, p) in [(128, 128, 32, 3, 1, 1), (256, 256, 16, 3, 1, 1), (
     os.environ["DSF_X6_WRW_PATCH"] = "0"                   # the gather kernel, as the small maps run
     run("wrw %dx%dx%d->%d k%d s%d" % (H, H, Ci, Co, K, s), f, 2.0 * B * Ho * Ho * Co * Ci * K * K)
 
-print("forward, igemm_x6p_kernel")
+print("forward, igemm_x6p_kernel (variant %s)" % args.variant)
 for (Ci, Co, H) in ([] if args.wrw_only else [(128, 128, 32), (256, 256, 16), (512, 512, 8), (64, 64, 64), (488, 256, 64)]):
     x, y = nhwc(B, Ci, H), torch.empty(B, H, H, Co, device="cuda")
     w = torch.randn(3, 3, Ci, Co, device="cuda")
