@@ -20,7 +20,7 @@
 //    chunk c + 1 waits for its stage), loader pieces handed out between the 24 MFMAs of a chunk.
 // Kernels: igemm_x6_kernel / igemm_x6b_kernel<BN, DIL2, BMT> (forward, backward-data, transposed convolution: one gather per tap),
 // igemm_x6p_kernel (3 x 3 stride-1 layers and the parity classes of 4 x 4 stride-2 transposed ones: the input patch of a chunk is
-// staged ONCE for all taps; bit-identical to the gather kernels), igemm_wrw_x6_kernel (backward-weights: both operands are
+// staged ONCE for all taps; bit-identical to the gather kernels; round 6: 4 x 4 stride-2 convolutions by INPUT parity classes), igemm_wrw_x6_kernel (backward-weights: both operands are
 // activations and are split on the fly; LDS transposes with ds_read_b64_tr_b16), igemm_wrw_x6p_kernel (the same for 3 x 3 stride-1
 // layers from a ring of input rows with halo, all nine taps per workgroup), x6_split_weights(_multi)_kernel.  MI355X, B = 32 ResNet-18 two-stage step: 175-200 TFLOP/s fp32-equivalent on the
 // 64x64-map layers against 120-134 for the fp32 MFMA kernels of conv.hip (whose peak is 157.3); 28.0 -> 21.1 ms per step.
@@ -684,7 +684,7 @@ template <int BMT, int W, int NT = 9> struct X6Patch {
     static constexpr int LDS_BYTES = 2 * STAGE * 16;
 };
 
-template <int BN, int BMT, int W, int NW = 2, int BD = 2, int NT = 9>
+template <int BN, int BMT, int W, int NW = 2, int BD = 2, int NT = 9, bool IP = false>
 __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restrict__ X, const uint4* __restrict__ Wimg,
                                                           const float* __restrict__ bias, float* __restrict__ Y, X6P p, int m_tiles,
                                                           int n_tiles, int k_splits, uint32_t x_bytes, uint32_t w_bytes,
@@ -692,6 +692,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restri
     static_assert((BN == 128 && (BMT == 128 || BMT == 64)) || (BN == 64 && BMT == 256), "tile shapes");
     static_assert(BMT % W == 0 && (W % 32 == 0 || 32 % W == 0), "fragment blocks are whole image rows or lie in one");
     static_assert(NT == 9 || (NT == 4 && BD == 2), "taps");
+    static_assert(!IP || NT == 4, "input-parity classes are 2 x 2 convolutions");
     using PT = X6Patch<BMT, W, NT>;
     // waves: WMW x WN, each WM rows x WNC columns: 2 x 2 of (BMT / 2) x 64 (BN 128), 4 x 1 of 64 x 64 (BN 64), or -- NW = 4, the
     // 64-row tiles -- 1 x 4 of 64 x 32: every wave then reads its own quarter of the weight block (half the weight traffic of the
@@ -717,23 +718,37 @@ __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restri
     // padded beforehand (reflection padding: Hi = Ho + 2, Wi = W + 2; every patch pixel is then inside the input).  NT = 4 (dilation-2 gather of a 4 x 4 stride-2 transposed
     // convolution): rows are ordered by output parity class (cpy, cpx), then as the W-wide class image = the input grid; an output
     // pixel (2 qy + cpy, 2 qx + cpx) has the taps kh = kh0 + 2 ty, kw = kw0 + 2 tx at input (qy + oy0 + ty, qx + ox0 + tx)
-    const int OH = (NT == 4) ? p.Hi : p.Ho;              // rows of the (class) image the tile's rows index
+    // IP (round 6; a 4 x 4, stride 2, pad 1 convolution = the input gradient of ConvTranspose2d(4, 2, 1)): rows are output pixels in
+    // order; the INPUT is taken apart into its four parity classes (iy & 1, ix & 1), each a (Ho + 1) x (W + 1)-reachable image on which
+    // the layer is a 2 x 2 stride-1 convolution: class (cy, cx), patch pixel (py, px) <-> input pixel (2 (y0 + py) - cy, 2 px - cx),
+    // tap (ty, tx) <-> filter tap (2 ty + 1 - cy, 2 tx + 1 - cx).  The chunk loop runs over (class, channel chunk) pairs -- "virtual
+    // chunks" -- and all four classes accumulate into the same output tile.
+    const int OH = (NT == 4 && !IP) ? p.Hi : p.Ho;       // rows of the (class) image the tile's rows index
     const int Mc = p.B * OH * W;                         // NT = 4: rows per parity class
-    const int cls = (NT == 4) ? m0 / Mc : 0, r0 = (NT == 4) ? m0 % Mc : m0;
+    const int cls = (NT == 4 && !IP) ? m0 / Mc : 0, r0 = (NT == 4 && !IP) ? m0 % Mc : m0;
     const int cpy = cls >> 1, cpx = cls & 1;
     const int kh0 = (NT == 4) ? ((p.pad_h - cpy) & 1) : 0, kw0 = (NT == 4) ? ((p.pad_w - cpx) & 1) : 0;
-    const int oy0 = (NT == 4) ? (cpy - p.pad_h + kh0) / 2 : -p.pad_h, ox0 = (NT == 4) ? (cpx - p.pad_w + kw0) / 2 : -p.pad_w;
+    const int oy0 = IP ? 0 : (NT == 4) ? (cpy - p.pad_h + kh0) / 2 : -p.pad_h, ox0 = IP ? 0 : (NT == 4) ? (cpx - p.pad_w + kw0) / 2 : -p.pad_w;
     const int img = r0 / (OH * W), y0 = (r0 % (OH * W)) / W;
     const int a_q = t & 3, a_k4 = a_q * 4, a_r = t >> 2;
     int a_off[NPASS];                                    // element offset of (pixel, channel quad) at chunk 0; -1: zeros
     int a_lds[NPASS];                                    // granule of the pixel in k-group 0; -1: no such pixel
+    int a_cok[IP ? NPASS : 1];                           // IP: bit (2 cy + cx) = the pixel exists in class (cy, cx); a_off is that of class (0, 0)
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
         const int pidx = a_r + 64 * i;
         const int py = pidx / (W + PT::HALO), px = pidx % (W + PT::HALO);
-        const int y = y0 + oy0 + py, x = ox0 + px;
-        const bool ok = pidx < PT::NPIX && (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi;
-        a_off[i] = ok ? ((img * p.Hi + y) * p.Wi + x) * p.Ci + a_k4 : -1;
+        if (IP) {
+            const int y2 = 2 * (y0 + py), x2 = 2 * px;   // class (cy, cx): input pixel (y2 - cy, x2 - cx)
+            const bool in = pidx < PT::NPIX;
+            const int vy0 = y2 < p.Hi, vy1 = y2 >= 1 && y2 - 1 < p.Hi, vx0 = x2 < p.Wi, vx1 = x2 >= 1 && x2 - 1 < p.Wi;
+            a_cok[i] = in ? ((vy0 & vx0) | (vy0 & vx1) << 1 | (vy1 & vx0) << 2 | (vy1 & vx1) << 3) : 0;
+            a_off[i] = ((img * p.Hi + y2) * p.Wi + x2) * p.Ci + a_k4;
+        } else {
+            const int y = y0 + oy0 + py, x = ox0 + px;
+            const bool ok = pidx < PT::NPIX && (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi;
+            a_off[i] = ok ? ((img * p.Hi + y) * p.Wi + x) * p.Ci + a_k4 : -1;
+        }
         a_lds[i] = pidx < PT::NPIX ? py * PT::PW + px : -1;
     }
 
@@ -746,13 +761,25 @@ __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restri
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int n_chunks = (p.Ci + XBK - 1) / XBK;       // K splits are ranges of channel chunks (all nine taps of each)
-    const int per_split = (n_chunks + k_splits - 1) / k_splits;
-    const int chunk_lo = ks * per_split, chunk_hi = min(n_chunks, chunk_lo + per_split);
+    const int v_chunks = IP ? 4 * n_chunks : n_chunks;   // IP: virtual chunk v = class * n_chunks + channel chunk
+    const int per_split = (v_chunks + k_splits - 1) / k_splits;
+    const int chunk_lo = ks * per_split, chunk_hi = min(v_chunks, chunk_lo + per_split);
+    // IP: (class, channel chunk) of the virtual chunk the body works on and of the next one (uniform; stepped, not divided)
+    int ip_cls = IP ? chunk_lo / n_chunks : 0, ip_ch = IP ? chunk_lo % n_chunks : 0, ip_cls1 = 0, ip_ch1 = 0, ip_v = chunk_lo;
+    auto ip_next = [&]() { ip_ch1 = ip_ch + 1; ip_cls1 = ip_cls; if (ip_ch1 == n_chunks) { ip_ch1 = 0; ip_cls1 = ip_cls + 1; } };
+    if (IP) ip_next();
     u32x4 ra[NPASS];
     u32x4 rbf[BD][3][TN];                                // [set][plane][n block]: B fragments as loaded, BD - 1 steps ahead
     bf16x8 af[2][3][TM];                                 // [set][plane][m block]: A fragments of the current / next tap
     const uint32_t b_lane = (uint32_t)((lane >> 5) * BN + wn * WNC + (lane & 31)) * 16u;
     auto load_a = [&](int i, int chunk) {                // pass i of the patch of `chunk` (past the end: zeros)
+        if (IP) {                                        // `chunk` is the virtual chunk: the current one (prologue) or the next
+            const bool cur = chunk == ip_v;
+            const int c = cur ? ip_cls : ip_cls1, ch = cur ? ip_ch : ip_ch1;
+            const bool ok = ((a_cok[i] >> c) & 1) && chunk < chunk_hi && ch * XBK + a_k4 < p.Ci;
+            ra[i] = x6_load16(xbuf, ok ? (uint32_t)(a_off[i] - ((c >> 1) * p.Wi + (c & 1)) * p.Ci + ch * XBK) * 4u : X_OOB);
+            return;
+        }
 #if defined(X6_STAMP) && defined(X6P_KO_A)                 // knock-out (diagnostic build): patch loads after the first chunk are issued out of range (no memory access)
         const bool ok = a_off[i] >= 0 && chunk <= chunk_lo && chunk * XBK + a_k4 < p.Ci;
 #else
@@ -778,8 +805,15 @@ __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restri
 #else
         const uint32_t dead = chunk < chunk_hi ? 0u : X_OOB;
 #endif
-        const int wtap = (NT == 4) ? (kh0 + 2 * (tap >> 1)) * p.KW + kw0 + 2 * (tap & 1) : tap;      // tap of the weight image
-        const int blk = wtap * n_chunks + chunk;
+        int wtap = (NT == 4) ? (kh0 + 2 * (tap >> 1)) * p.KW + kw0 + 2 * (tap & 1) : tap;      // tap of the weight image
+        int wch = chunk;
+        if (IP) {                                        // `chunk`: the virtual chunk of the body, or the one after it
+            const bool cur = chunk == ip_v;
+            const int c = cur ? ip_cls : ip_cls1;
+            wch = cur ? ip_ch : ip_ch1;
+            wtap = (2 * (tap >> 1) + 1 - (c >> 1)) * p.KW + 2 * (tap & 1) + 1 - (c & 1);
+        }
+        const int blk = wtap * n_chunks + wch;
         rbf[S][pl][j] = x6_load16(wbuf, ((uint32_t)(blk * n_tiles + n_tile) * (uint32_t)(3 * B_GRANULES * 16) +
                                          (uint32_t)(pl * B_GRANULES * 16 + j * 32 * 16) + b_lane) | dead);
     };
@@ -817,6 +851,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restri
     // the A fragment reads of the next tap, and this chunk's share of the patch of chunk c + 1 (loads in taps 0-2, stores in 5-8).
     auto body = [&](auto PARITY, int chunk) {
         constexpr int PAR = decltype(PARITY)::value;
+        if (IP && chunk != ip_v) { ip_cls = ip_cls1; ip_ch = ip_ch1; ip_v = chunk; ip_next(); }      // (uniform: scalar registers)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
@@ -885,7 +920,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x6p_kernel(const float* __restri
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int64_t row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (NT == 4) {                           // class row -> output pixel (2 qy + cpy, 2 qx + cpx)
+                if (NT == 4 && !IP) {                    // class row -> output pixel (2 qy + cpy, 2 qx + cpx)
                     const int rc = (int)row - cls * Mc, qx = rc % W, q = rc / W;
                     row = ((int64_t)(q / OH) * p.Ho + 2 * (q % OH) + cpy) * p.Wo + 2 * qx + cpx;
                 }
@@ -1542,10 +1577,16 @@ struct X6Plan { int bn, n_tiles, bdirect, bmt, m_tiles, k_splits; };
 // parity class is a 2 x 2 convolution over the input grid; 32 / 16 / 8-wide inputs; DSF_X6_PATCH=3 keeps these on the gather kernel), 0
 static int x6_patch_geometry(int Hi, int Wi, int Ho, int Wo, int KH, int KW, int stride, int dil, int pad_h, int pad_w) {
     const char* e = getenv("DSF_X6_PATCH");
-    const int level = e ? atoi(e) : 2;
+    int level = e ? atoi(e) : 2;
     if (level <= 0) return 0;
+    const bool no_ip = level == 4;                       // 4: everything of level 2 but the input-parity launch
+    if (no_ip) level = 2;
     if (dil == 2 && KH == 4 && KW == 4 && stride == 1 && Ho == 2 * Hi && Wo == 2 * Wi && pad_h >= 0 && pad_h <= 3 && pad_w >= 0 &&
         pad_w <= 3 && level == 2 && (Wi == 32 || Wi == 16 || Wi == 8)) return 4;
+    // 5: a 4 x 4, stride 2, pad 1 convolution (the input gradient of that transposed convolution) by input parity classes (round 6;
+    // DSF_X6_PATCH=4 keeps it on the gather kernel)
+    if (dil == 1 && KH == 4 && KW == 4 && stride == 2 && pad_h == 1 && pad_w == 1 && Hi == 2 * Ho && Wi == 2 * Wo && level == 2 && !no_ip &&
+        (Wo == 32 || Wo == 16 || Wo == 8)) return 5;
     // 3 x 3, stride 1: pad 1, or pad 0 over an input that carries its own (reflection) padding
     if (!(dil == 1 && KH == 3 && KW == 3 && stride == 1 && pad_h == pad_w && (pad_h == 0 || pad_h == 1) && Hi == Ho + 2 - 2 * pad_h &&
           Wi == Wo + 2 - 2 * pad_w)) return 0;
@@ -1655,19 +1696,26 @@ static int x6_forward_impl(const float* X, const void* image, const float* bias,
     // the weight block from L2 -- the LDS-staged kernel is faster there (measured 136 / 139 vs 133 / 133 TFLOP/s)
     const bool direct = bdirect && !(bmt == 64 && n_tiles >= 2);
     if (patch) {
-#define DSF_LAUNCH_X6P(BNv, BMv, Wv, NWv, BDv, NTv)                                                                               \
+#define DSF_LAUNCH_X6P_(BNv, BMv, Wv, NWv, BDv, NTv, IPv)                                                                         \
     do {                                                                                                                          \
         using PT = X6Patch<BMv, Wv, NTv>;                                                                                         \
         static bool armed[X6_MAX_DEVICES];                   /* per device: the attribute belongs to the device that was current */ \
-        if (!x6_arm_dynamic_lds(reinterpret_cast<const void*>(&igemm_x6p_kernel<BNv, BMv, Wv, NWv, BDv, NTv>), PT::LDS_BYTES, armed)) \
+        if (!x6_arm_dynamic_lds(reinterpret_cast<const void*>(&igemm_x6p_kernel<BNv, BMv, Wv, NWv, BDv, NTv, IPv>), PT::LDS_BYTES, armed)) \
             return DSF_ERR_LAUNCH;                                                                                                 \
-        hipLaunchKernelGGL((igemm_x6p_kernel<BNv, BMv, Wv, NWv, BDv, NTv>), grid, dim3(256), PT::LDS_BYTES, (hipStream_t)stream,  \
+        hipLaunchKernelGGL((igemm_x6p_kernel<BNv, BMv, Wv, NWv, BDv, NTv, IPv>), grid, dim3(256), PT::LDS_BYTES, (hipStream_t)stream,  \
                            X, (const uint4*)image, bias, Y, p, m_tiles, n_tiles, k_splits, (uint32_t)x_bytes, (uint32_t)w_bytes,  \
                            stats, ep);                                                                                            \
     } while (0)
+#define DSF_LAUNCH_X6P(BNv, BMv, Wv, NWv, BDv, NTv) DSF_LAUNCH_X6P_(BNv, BMv, Wv, NWv, BDv, NTv, false)
         // 64-row tiles: 1 x 4 waves and weight fragments two taps ahead (B = 32, 16x16x256 unsplit: 2 x 2 waves 55 us, 1 x 4 51,
         // + two taps ahead 48; no gain from either on the taller tiles, which have two workgroups per CU to hide the latency)
-        if (patch_geo == 4) {                                            // transposed 4 x 4 stride 2: pw = the class image's width
+        if (patch_geo == 5) {                                            // 4 x 4 stride 2 by input parity classes: pw = the output map's width
+            if (bmt == 128) { if (pw == 32) DSF_LAUNCH_X6P_(128, 128, 32, 2, 2, 4, true); else DSF_LAUNCH_X6P_(128, 128, 16, 2, 2, 4, true); }
+            else if (pw == 32) DSF_LAUNCH_X6P_(128, 64, 32, 4, 2, 4, true);
+            else if (pw == 16) DSF_LAUNCH_X6P_(128, 64, 16, 4, 2, 4, true);
+            else DSF_LAUNCH_X6P_(128, 64, 8, 4, 2, 4, true);
+        }
+        else if (patch_geo == 4) {                                       // transposed 4 x 4 stride 2: pw = the class image's width
             if (bmt == 128) { if (pw == 32) DSF_LAUNCH_X6P(128, 128, 32, 2, 2, 4); else DSF_LAUNCH_X6P(128, 128, 16, 2, 2, 4); }
             else if (pw == 32) DSF_LAUNCH_X6P(128, 64, 32, 4, 2, 4);
             else if (pw == 16) DSF_LAUNCH_X6P(128, 64, 16, 4, 2, 4);
@@ -1683,6 +1731,7 @@ static int x6_forward_impl(const float* X, const void* image, const float* bias,
         else if (pw == 16) DSF_LAUNCH_X6P(128, 64, 16, 4, 3, 9);
         else DSF_LAUNCH_X6P(128, 64, 8, 4, 3, 9);
 #undef DSF_LAUNCH_X6P
+#undef DSF_LAUNCH_X6P_
         return dsf_launch_status();
     }
     if (direct) {

@@ -911,12 +911,14 @@ def kernel_name(rec):
         variant = ctypes.c_int(-1)
         L.lib().dsf_conv_x6_forward_plan(I(B), I(Hi), I(Wi), I(Ci), I(Ho), I(Wo), I(Co), I(rec[8]), I(rec[9]), I(rec[10]), I(dil), I(rec[12]),
                                          I(rec[13]), ctypes.byref(variant), None)
-        if variant.value == 2:                                 # the patch-staged kernel: <BN, BMT, W, waves along n, B sets, taps>
-            nt = 4 if dil == 2 else 9                           # 4: a 4 x 4 stride-2 transposed convolution, class by class
-            pw = Wi if nt == 4 else Wo                          # width of the image the tile rows index
+        if variant.value == 2:                                 # the patch-staged kernel: <BN, BMT, W, waves along n, B sets, taps, input parity>
+            ip = dil == 1 and rec[8] == 4 and rec[10] == 2     # a 4 x 4 stride-2 convolution by input parity classes (round 6)
+            nt = 4 if (dil == 2 or ip) else 9                   # 4: a 4 x 4 stride-2 transposed convolution, class by class
+            pw = Wi if dil == 2 else Wo                         # width of the image the tile rows index
             if bn6 == 128 and pw == 8:
                 bmt = 64
-            return "igemm_x6p_kernel<%d, %d, %d, %d, %d, %d>" % (bn6, bmt, pw, 4 if bmt == 64 else 2, 3 if (bmt == 64 and nt == 9) else 2, nt)
+            return "igemm_x6p_kernel<%d, %d, %d, %d, %d, %d, %s>" % (bn6, bmt, pw, 4 if bmt == 64 else 2, 3 if (bmt == 64 and nt == 9) else 2, nt,
+                                                                     "true" if ip else "false")
         if direct and not (bmt == 64 and n6 >= 2):            # weight operand straight into the MFMA fragments (conv_x6.hip)
             return "igemm_x6b_kernel<%d, %s, %d>" % (bn6, "true" if dil == 2 else "false", bmt)
         return "igemm_x6_kernel<%d, %s, %d>" % (bn6, "true" if dil == 2 else "false", bmt)
@@ -936,7 +938,7 @@ def kernel_name(rec):
         if (level > 0 and rec[8] == 3 and rec[9] == 3 and rec[10] == 1 and rec[12] == 1 and rec[13] == 1
                 and Ho == Hi and Wo == Wi and Wi in (64, 32, 16)):
             tiles = ((Ci + 31) // 32) * ((Co + 127) // 128)
-            splits = max(1, 512 // tiles)
+            splits = max(1, (int(os.environ.get("DSF_X6_WRWP_WGS", "0")) or 256) // tiles)
             rows = max(4, (B * Hi + splits - 1) // splits)
             want = 1024 // Wi
             if Wi == 64 and rows < want and tiles * ((B * Hi + want - 1) // want) >= 256:

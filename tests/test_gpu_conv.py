@@ -293,6 +293,71 @@ def test_row_staged_3x3_backward_weights_against_float64(Ci, Co, H, W, B, monkey
         L.set_deterministic(was)
 
 
+@pytest.mark.parametrize("B,Ci,Co,Ho,bias", [
+    (2, 256, 256, 32, False),     # the decoder's largest input gradient (64 x 64 x 256 -> 32 x 32 x 256), 128-row tiles of four output rows
+    (5, 64, 128, 16, True),       # 16-wide output, bias
+    (4, 512, 256, 8, False),      # 8-wide output: 64-row tiles (1 x 4 waves), several channel chunks
+    (3, 36, 130, 16, False),      # ragged: a partial last chunk (36 channels), a partial second n tile
+    (32, 256, 256, 8, False),     # few tiles: the launcher splits K -- ranges of (class, chunk) pairs that cut through a class
+])
+def test_4x4_stride_2_convolution_by_input_parity_classes_against_the_gather_kernel_and_float64(B, Ci, Co, Ho, bias, monkeypatch):
+    """igemm_x6p_kernel<.., 4, true> (round 6): a 4 x 4, stride 2, pad 1 convolution -- the input gradient of ConvTranspose2d(4, 2, 1) --
+    with the input taken apart into its four parity classes, each a 2 x 2 stride-1 convolution through the patch-staged kernel,
+    all four accumulating into one output tile.  Against the per-tap gather kernel (DSF_X6_PATCH=4) and float64: the classes change
+    the ORDER of the fp32 accumulation (class-major instead of tap-major), so the two kernels agree to accumulation-order distance,
+    not bitwise; the unsplit launch is deterministic run to run."""
+    from dsf_amd import nn_conv, _lib as L
+    monkeypatch.setattr(nn_conv, "MATH", "x6")
+    g = torch.Generator().manual_seed(B + Ci + Co + Ho)
+    x = torch.randn(B, Ci, 2 * Ho, 2 * Ho, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Co, Ci, 4, 4, generator=g) / (Ci * 16) ** 0.5).cuda()
+    b = torch.randn(Co, generator=g).cuda() if bias else None
+    ref = F.conv2d(x.double(), w.double(), b.double() if bias else None, stride=2, padding=1)
+    out = {}
+    for level in ("2", "4"):
+        monkeypatch.setenv("DSF_X6_PATCH", level)
+        nn_conv.RECORD = []
+        try:
+            out[level] = nn_conv.Conv2dFunction.apply(x, w, b, 2, (1, 1))
+            name = nn_conv.kernel_name(nn_conv.RECORD[0])
+        finally:
+            nn_conv.RECORD = None
+        assert (name.startswith("igemm_x6p_kernel") and name.endswith("4, true>")) == (level == "2"), (level, name)
+        assert _rel(out[level].double(), ref) < 2e-6, (level, _rel(out[level].double(), ref))
+    assert _rel(out["2"].double(), out["4"].double()) < 2e-6
+    monkeypatch.setenv("DSF_X6_PATCH", "2")
+    was = L.set_deterministic(True)                                # (no K split: plain stores)
+    try:
+        a = nn_conv.Conv2dFunction.apply(x, w, b, 2, (1, 1))
+        c = nn_conv.Conv2dFunction.apply(x, w, b, 2, (1, 1))
+        assert torch.equal(a, c) and _rel(a.double(), ref) < 4e-6
+    finally:
+        L.set_deterministic(was)
+
+
+def test_transposed_convolution_input_gradient_takes_the_input_parity_launch(monkeypatch):
+    """ConvTranspose2d(256, 256, 4, 2, 1) of the decoder (reference model/backbone.py:30-43): its backward-data pass is the 4 x 4
+    stride-2 convolution above; gradients against torch's float64 transposed convolution."""
+    from dsf_amd import nn_conv
+    monkeypatch.setattr(nn_conv, "MATH", "x6")
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(3, 256, 16, 16, generator=g).cuda().requires_grad_(True)
+    w = (torch.randn(256, 256, 4, 4, generator=g) / 64).cuda().requires_grad_(True)
+    nn_conv.RECORD = []
+    try:
+        y = nn_conv.ConvTranspose2dFunction.apply(x, w, None, 2, (1, 1), (0, 0))
+        gy = torch.randn(y.shape, generator=g).cuda()
+        gx, gw = torch.autograd.grad((y * gy).sum(), [x, w])
+        names = [nn_conv.kernel_name(r) for r in nn_conv.RECORD]
+    finally:
+        nn_conv.RECORD = None
+    assert any(n.startswith("igemm_x6p_kernel") and n.endswith("4, true>") for n in names), names
+    xd, wd = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    yd = F.conv_transpose2d(xd, wd, None, stride=2, padding=1)
+    gxd, gwd = torch.autograd.grad((yd * gy.double()).sum(), [xd, wd])
+    assert _rel(y.detach().double(), yd.detach()) < 2e-6 and _rel(gx.double(), gxd) < 2e-6 and _rel(gw.double(), gwd) < 3e-6
+
+
 @pytest.mark.parametrize("Ci,Co,H,W,B,K,stride,pad", [
     (128, 128, 32, 32, 4, 3, 1, 1),     # small-map 3 x 3: the layers with the largest share of a config-2 step
     (64, 256, 16, 16, 5, 3, 2, 1),      # stride 2: input and output maps differ
