@@ -136,7 +136,27 @@ def conv_kernel_roofline(step, run_once):
                            "run beside it on a second stream")
     critical["main_queue_conv_ms_per_step"] = round(sum(per_kernel[k][1] for k in main_q) / 1e3, 2)
     critical["weight_gradient_queue_ms_per_step"] = round(sum(v[1] for k, v in per_kernel.items() if "wrw" in k) / 1e3, 2)
-    return entry(dom), table, critical
+    dom_entry = entry(dom)
+    if "igemm_wrw_x6_kernel" in dom and "DSF_X6_WRW_WGS" not in os.environ:
+        # Round 6: the launcher splits these launches' pixels towards ONE workgroup per CU, which is the better choice INSIDE a step (they
+        # run beside the main queue's kernels: config 2 -2.7 %, config 3 -3.7 % per step, profiles/r06_wrw_split_target.txt) and the slower
+        # one for the launch ALONE, which is what this entry times.  The same launches at the isolated optimum (two per CU), for reference:
+        os.environ["DSF_X6_WRW_WGS"] = "512"
+        try:
+            us2 = fl2 = 0.0
+            for r in recs:
+                if nn_conv.kernel_name(r) == dom:
+                    u, f, _ = nn_conv.replay(r)
+                    us2 += u; fl2 += f
+        finally:
+            del os.environ["DSF_X6_WRW_WGS"]
+        if us2 > 0:
+            tf2 = fl2 / (us2 * 1e-6) / 1e12
+            dom_entry["alone_at_two_workgroups_per_cu"] = {
+                "avg_launch_us": round(us2 / per_kernel[dom][0], 1), "achieved": round(tf2, 2), "frac": round(tf2 / dom_entry["peak"], 4),
+                "note": "the same launches with DSF_X6_WRW_WGS=512 (the split of rounds 3-5, the optimum of the launch alone); the step "
+                        "runs them at one workgroup per CU because the STEP is faster that way (profiles/r06_wrw_split_target.txt)"}
+    return dom_entry, table, critical
 
 
 def measured_mfma_ceiling():
@@ -375,7 +395,8 @@ def geometry_rooflines(render, B, launches=50):
         maps = gfm.joint2offset(juvd, img, 0.8, 64)
         us = timed(lambda: gfm.offset2joint_softmax(maps, img, 0.8))
         hbm_row("K10d", "offset2joint_* (soft-argmax decode)", us, B * (84 * 64 * 64 * 4 + 128 * 128 * 4 + 21 * 12),
-                "one read of the 84-channel map; (sample, joint) workgroups")
+                "the 84-channel channels-last map: per-chunk maxima over the 21 heat channels, then one read of the map; pixel-chunk "
+                "workgroups (round 6), three small launches")
     return rows
 
 

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdsf_hip.so")
 ERR_UNSUPPORTED = 2         # DSF_ERR_UNSUPPORTED (include/dsf_hip.h): the launcher declined the shape / mode, nothing was launched
-EXPECTED_ABI = 3            # dsf_abi_version() of the library these bindings were written for (csrc/api.hip)
+EXPECTED_ABI = 4            # dsf_abi_version() of the library these bindings were written for (csrc/api.hip)
 
 c_float_p = ctypes.c_void_p
 _lib = None
@@ -60,6 +60,7 @@ SYMBOLS = [
     "dsf_conv_x6_forward_plan", "dsf_conv_co1_forward", "dsf_conv_x6_wrw_bias", "dsf_bn_backward_pair", "dsf_bn_backward_acc_pair",
     "dsf_m2d_forward", "dsf_m2d_backward", "dsf_cube_points_forward", "dsf_cube_points_backward", "dsf_view_rotate", "dsf_part_mean_forward",
     "dsf_part_mean_backward", "dsf_mano_reg_forward", "dsf_mano_reg_backward", "dsf_cube_normalise", "dsf_m2p_forward", "dsf_m2p_backward", "dsf_sphere_mixed", "dsf_offset2joint_forward_strided", "dsf_offset2joint_backward_strided", "dsf_pool_linear_forward", "dsf_pool_linear_backward",
+    "dsf_offset2joint_cl_workspace_floats", "dsf_offset2joint_forward_cl", "dsf_offset2joint_backward_cl",
 ]
 
 
@@ -91,6 +92,7 @@ def lib():
         _lib.dsf_conv_x6_image_granules.restype = ctypes.c_int64
         _lib.dsf_part_volume_workspace_bytes.restype = ctypes.c_int64
         _lib.dsf_conv_x6_wrw_workspace_bytes.restype = ctypes.c_int64
+        _lib.dsf_offset2joint_cl_workspace_floats.restype = ctypes.c_int64
     return _lib
 
 

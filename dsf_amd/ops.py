@@ -4,6 +4,7 @@ PyTorch is plumbing here (device memory, streams, autograd graph); all
 arithmetic happens in the HIP kernels.  No CPU path exists: CPU tensors raise.
 """
 import ctypes
+import os
 
 import torch
 from torch.autograd import Function
@@ -617,6 +618,9 @@ def huber_mean(x, y, delta=0.01, size_average=True, weight=1.0):
     return HuberMean.apply(x, y, float(delta), float(scale))
 
 
+DECODE_CL = [os.environ.get("DSF_DECODE_CL", "1") == "1"]      # 0: channels-last maps through the (sample, joint) kernels too (A/B aid)
+
+
 class Offset2Joint(Function):
     """GFM.offset2joint_softmax (util/generateFeature.py:39-59).  The maps are read in the layout they come in (NCHW or the
     network's channels-last) and their gradient is written in that layout: no layout copy either way."""
@@ -632,8 +636,16 @@ class Offset2Joint(Function):
         J, H = C // 4, depth.shape[-1]
         joints = _empty((B, J, 3), maps)
         stats = _empty((B, J, 2), maps)
-        check(L.lib().dsf_offset2joint_forward_strided(L.addr(maps), st, ptr(depth), I(B), I(J), I(H), I(S), F(kernel_size), F(scale),
-                                                       ptr(joints), ptr(stats), stream_ptr()), "dsf_offset2joint_forward_strided")
+        # a dense channels-last map (what the heads write): pixel-chunk workgroups that read a pixel's record contiguously
+        # (dsf_offset2joint_*_cl); any other uniformly strided layout: the (sample, joint) kernels
+        ctx.cl = bool(DECODE_CL[0] and B > 0 and J <= 32 and C == 4 * J and tuple(st) == (C * S * S, 1, C))
+        if ctx.cl:
+            ws = _empty((int(L.lib().dsf_offset2joint_cl_workspace_floats(I(B), I(S))),), maps)
+            check(L.lib().dsf_offset2joint_forward_cl(L.addr(maps), ptr(depth), I(B), I(J), I(H), I(S), F(kernel_size), F(scale), ptr(joints),
+                                                      ptr(stats), ptr(ws), stream_ptr()), "dsf_offset2joint_forward_cl")
+        else:
+            check(L.lib().dsf_offset2joint_forward_strided(L.addr(maps), st, ptr(depth), I(B), I(J), I(H), I(S), F(kernel_size), F(scale),
+                                                           ptr(joints), ptr(stats), stream_ptr()), "dsf_offset2joint_forward_strided")
         ctx.save_for_backward(maps, depth, joints, stats)
         ctx.args = (kernel_size, scale)
         return joints
@@ -646,6 +658,11 @@ class Offset2Joint(Function):
         B, C, S, _ = maps.shape
         gm = torch.empty_like(maps)                       # preserve_format: the maps' own dense layout
         assert gm.stride() == maps.stride()
+        if ctx.cl:
+            check(L.lib().dsf_offset2joint_backward_cl(L.addr(maps), ptr(depth), ptr(joints), ptr(stats), ptr(f32(g)), I(B), I(C // 4),
+                                                       I(depth.shape[-1]), I(S), F(ks), F(scale), L.addr(gm), stream_ptr()),
+                  "dsf_offset2joint_backward_cl")
+            return gm, None, None, None
         check(L.lib().dsf_offset2joint_backward_strided(L.addr(maps), _map_strides(maps), ptr(depth), ptr(joints), ptr(stats), ptr(f32(g)), I(B),
                                                         I(C // 4), I(depth.shape[-1]), I(S), F(ks), F(scale), L.addr(gm),
                                                         stream_ptr()), "dsf_offset2joint_backward_strided")

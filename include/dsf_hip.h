@@ -300,6 +300,19 @@ int dsf_offset2joint_forward_strided(const float* maps, const int64_t* map_strid
 int dsf_offset2joint_backward_strided(const float* maps, const int64_t* map_strides, const float* depth, const float* joints,
                                       const float* stats, const float* grad_joints, int B, int J, int H, int S, float kernel_size,
                                       float scale, float* grad_maps, dsf_stream_t stream);
+/* The same decode for a DENSE CHANNELS-LAST map (B, S*S, 4J) -- the layout the network's heads write -- with J <= 32 (else
+ * DSF_ERR_UNSUPPORTED: use the strided entry points): workgroups own 128 consecutive pixels of a sample and all joints, so that a
+ * pixel's 4J-float record is read contiguously (the (sample, joint) kernels behind the strided entry points touch a cache line per
+ * lane on this layout: 84 / 125 us forward / backward at B = 32 against 21 / 23 us on NCHW).  Forward = three small launches
+ * (per-chunk maxima, per-chunk sums with the global maximum, an ordered fold: deterministic); backward = one elementwise launch.
+ * `workspace`: dsf_offset2joint_cl_workspace_floats(B, S) floats, uninitialised.  Per element the arithmetic is that of
+ * dsf_offset2joint_forward / _backward; the forward differs from it by the order of the fp32 sums only.  Added in round 6 (ABI 4). */
+int64_t dsf_offset2joint_cl_workspace_floats(int B, int S);
+int dsf_offset2joint_forward_cl(const float* maps, const float* depth, int B, int J, int H, int S, float kernel_size, float scale,
+                                float* joints, float* stats, float* workspace, dsf_stream_t stream);
+int dsf_offset2joint_backward_cl(const float* maps, const float* depth, const float* joints, const float* stats,
+                                 const float* grad_joints, int B, int J, int H, int S, float kernel_size, float scale,
+                                 float* grad_maps, dsf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * K11  fp32 implicit-GEMM convolution on the matrix cores (v_mfma_f32_32x32x2_f32).

@@ -251,23 +251,36 @@ def test_synthetic_render_with_the_fused_point_kernels_equals_the_elementwise_ch
     assert _rel(a[4].double(), b[4].detach().double()) < 5e-6 and _rel(a[1].double(), b[1].detach().double()) < 5e-6
 
 
-def test_soft_argmax_decode_reads_channels_last_maps_in_place():
-    """GFM.offset2joint_softmax (util/generateFeature.py:39-59) on a channels-last map (what the network produces): same bits as on the
-    NCHW copy, forward and backward, and the gradient comes back channels-last (no layout copy either way)."""
+@pytest.mark.parametrize("B,J,S", [(5, 21, 64), (3, 21, 36), (2, 14, 8), (32, 21, 64)])
+def test_soft_argmax_decode_reads_channels_last_maps_in_place(B, J, S, monkeypatch):
+    """GFM.offset2joint_softmax (util/generateFeature.py:39-59) on a channels-last map (what the network produces), forward and backward,
+    with the gradient coming back channels-last (no layout copy either way).  The pixel-chunk kernels (dsf_offset2joint_*_cl, round 6:
+    contiguous reads of a pixel's record) evaluate the same expressions per element as the (sample, joint) kernels and fold their sums
+    in another order: equal to the NCHW decode to fp32 summation distance, run-to-run bitwise; through the (sample, joint) kernels
+    (DSF_DECODE_CL=0) the two layouts agree to the bit."""
     from dsf_amd import ops
-    g = torch.Generator(device="cuda").manual_seed(21)
-    B, J, S = 5, 21, 64
+    g = torch.Generator(device="cuda").manual_seed(21 + S)
+    H = 2 * S
     maps = torch.randn(B, 4 * J, S, S, device="cuda", generator=g) * 0.3
-    depth = torch.where(torch.rand(B, 1, 128, 128, device="cuda", generator=g) < 0.4, torch.rand(B, 1, 128, 128, device="cuda", generator=g) * 1.6 - 0.8,
-                        torch.ones(B, 1, 128, 128, device="cuda"))
+    depth = torch.where(torch.rand(B, 1, H, H, device="cuda", generator=g) < 0.4, torch.rand(B, 1, H, H, device="cuda", generator=g) * 1.6 - 0.8,
+                        torch.ones(B, 1, H, H, device="cuda"))
     gj = torch.randn(B, J, 3, device="cuda", generator=g)
     a = maps.clone().requires_grad_(True)                                            # NCHW
     b = maps.clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
-    ja, jb = ops.Offset2Joint.apply(a, depth, 0.8, 30.0), ops.Offset2Joint.apply(b, depth, 0.8, 30.0)
-    assert torch.equal(ja, jb)
+    ja = ops.Offset2Joint.apply(a, depth, 0.8, 30.0)
     ga, = torch.autograd.grad((ja * gj).sum(), a)
-    gb, = torch.autograd.grad((jb * gj).sum(), b)
-    assert gb.is_contiguous(memory_format=torch.channels_last) and ga.is_contiguous() and torch.equal(ga, gb)
+    for cl in (True, False):
+        monkeypatch.setattr(ops, "DECODE_CL", [cl])
+        jb = ops.Offset2Joint.apply(b, depth, 0.8, 30.0)
+        gb, = torch.autograd.grad((jb * gj).sum(), b)
+        assert gb.is_contiguous(memory_format=torch.channels_last) and ga.is_contiguous()
+        if cl:
+            assert _rel(jb.detach().double(), ja.detach().double()) < 2e-6 and _rel(gb.double(), ga.double()) < 5e-6
+            jb2 = ops.Offset2Joint.apply(b, depth, 0.8, 30.0)
+            gb2, = torch.autograd.grad((jb2 * gj).sum(), b)
+            assert torch.equal(jb, jb2) and torch.equal(gb, gb2)                     # ordered folds: deterministic
+        else:
+            assert torch.equal(ja, jb) and torch.equal(ga, gb)
     # a channel slice (not a dense layout) still works through a copy
     wide = torch.randn(B, 4 * J + 8, S, S, device="cuda", generator=g)
     assert torch.equal(ops.Offset2Joint.apply(wide[:, :4 * J], depth, 0.8, 30.0), ops.Offset2Joint.apply(wide[:, :4 * J].contiguous(), depth, 0.8, 30.0))
