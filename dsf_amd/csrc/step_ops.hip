@@ -288,17 +288,52 @@ __global__ __launch_bounds__(256) void mano_reg_bwd_kernel(const float* __restri
 //      per sample.  torch runs it as a mean reduction + a hipBLASLt GEMM (a 46 us launch for a 32 x 512 x 62 product) + their
 //      five backward launches; fixed-order sums here.
 constexpr int PL_MAX_C = 2048;
+// The pooling walks HW pixels of C channels: thread = (float4 column, pixel lane), four pixels in flight per thread (round 6: one
+// thread per channel walking all pixels one dependent load after the other took 97 us at B = 32, 8 x 8 x 512 -- at the END of the
+// forward pass, where nothing hides it), pixel lanes folded through LDS in a fixed order.
 __global__ __launch_bounds__(256) void pool_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
                                                               int HW, int C, int O, float* __restrict__ pooled, float* __restrict__ out) {
     __shared__ float s_p[PL_MAX_C];
+    __shared__ __attribute__((aligned(16))) float s_part[4][PL_MAX_C];
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const float* xb = x + (int64_t)b * HW * C;
-    for (int c = t; c < C; c += 256) {
-        float acc = 0.f;
-        for (int p = 0; p < HW; ++p) acc += xb[(int64_t)p * C + c];
-        const float m = acc / (float)HW;
-        s_p[c] = m;
-        pooled[(int64_t)b * C + c] = m;
+    if ((C & 3) == 0) {
+        const int C4 = C >> 2;
+        const int cols = C4 < 256 ? C4 : 256;                  // float4 columns a pass covers
+        const int npl = (256 / cols) < 4 ? (256 / cols) : 4;   // pixel lanes (threads beyond cols * npl idle in the pooling)
+        const int cq = t % cols, pl = t / cols;
+        for (int c0 = 0; c0 < C4; c0 += cols) {
+            const int col = c0 + cq;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (col < C4 && pl < npl) {
+                const float4* xq = reinterpret_cast<const float4*>(xb) + col;
+                int p = pl;
+                for (; p + 3 * npl < HW; p += 4 * npl) {
+                    const float4 v0 = xq[(int64_t)p * C4], v1 = xq[(int64_t)(p + npl) * C4], v2 = xq[(int64_t)(p + 2 * npl) * C4],
+                                 v3 = xq[(int64_t)(p + 3 * npl) * C4];
+                    a.x += (v0.x + v1.x) + (v2.x + v3.x); a.y += (v0.y + v1.y) + (v2.y + v3.y);
+                    a.z += (v0.z + v1.z) + (v2.z + v3.z); a.w += (v0.w + v1.w) + (v2.w + v3.w);
+                }
+                for (; p < HW; p += npl) { const float4 v = xq[(int64_t)p * C4]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+                *reinterpret_cast<float4*>(&s_part[pl][col * 4]) = a;
+            }
+        }
+        __syncthreads();
+        for (int c = t; c < C; c += 256) {
+            float acc = s_part[0][c];
+            for (int k = 1; k < npl; ++k) acc += s_part[k][c];
+            const float m = acc / (float)HW;
+            s_p[c] = m;
+            pooled[(int64_t)b * C + c] = m;
+        }
+    } else {
+        for (int c = t; c < C; c += 256) {
+            float acc = 0.f;
+            for (int p = 0; p < HW; ++p) acc += xb[(int64_t)p * C + c];
+            const float m = acc / (float)HW;
+            s_p[c] = m;
+            pooled[(int64_t)b * C + c] = m;
+        }
     }
     __syncthreads();
     for (int o = wave; o < O; o += 4) {

@@ -1,22 +1,15 @@
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/c41; mkdir -p $O; cd $R
-timeout 900 python3 -m pytest tests/test_gpu_step_ops.py tests/test_gpu_parity.py tests/test_library_abi.py -q -m gpu -x > $O/pytest.log 2>&1; echo "rc=$?" >> $O/pytest.log; tail -n 4 $O/pytest.log
-python3 - <<'PY' > $O/decode_times.txt 2>&1
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/c42; mkdir -p $O; cd $R
+timeout 900 python3 -m pytest tests/test_gpu_step_ops.py -q -m gpu -x > $O/pytest.log 2>&1; echo "rc=$?" >> $O/pytest.log; tail -n 3 $O/pytest.log
+python3 - <<'PY' 2>&1 | grep -v amdgpu > $O/pool_linear.txt
 import torch, sys
 sys.path.insert(0, ".")
 from dsf_amd import ops
 import bench
-B, J, S = 32, 21, 64
-maps = (torch.randn(B, 4 * J, S, S, device="cuda") * 0.3)
-depth = torch.rand(B, 1, 128, 128, device="cuda") * 2 - 1
-gj = torch.randn(B, J, 3, device="cuda")
-for name, m in (("NCHW", maps.clone()), ("channels-last", maps.clone().contiguous(memory_format=torch.channels_last))):
-    for cl in (True, False):
-        ops.DECODE_CL[0] = cl
-        us_f = bench.gpu_time_per_call_us(lambda: ops.Offset2Joint.apply(m, depth, 0.8, 30.0), 50)[0]
-        mr = m.clone().requires_grad_(True)
-        j = ops.Offset2Joint.apply(mr, depth, 0.8, 30.0)
-        us_b = bench.gpu_time_per_call_us(lambda: torch.autograd.grad((j * gj).sum(), mr, retain_graph=True), 50, capture=False)[0]
-        print("%-14s DECODE_CL=%d: forward %.1f us, backward (eager, incl. the sum) %.1f us" % (name, cl, us_f, us_b))
+for (B, C, H) in ((32, 512, 8), (64, 512, 8), (192, 2048, 4)):
+    lin = torch.nn.Linear(C, 62).cuda()
+    x = torch.randn(B, C, H, H, device="cuda").contiguous(memory_format=torch.channels_last)
+    us = bench.gpu_time_per_call_us(lambda: ops.pool_linear(x, lin), 50)[0]
+    print("pool_linear forward B=%d %dx%dx%d: %.1f us" % (B, H, H, C, us))
 PY
-grep -v amdgpu $O/decode_times.txt
-timeout 900 python3 tools/ab_env.py --config 2 --var DSF_DECODE_CL --values 0 1 --rounds 8 > $O/ab_cl_c2.txt 2>&1; tail -n 2 $O/ab_cl_c2.txt
+cat $O/pool_linear.txt
+for i in 1 2 3; do timeout 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"; done
