@@ -1,1 +1,3 @@
-cd $GRAFT_REPO_ROOT; bash tools/run_profiles.sh r06; tail -n 2 gpurun_out/profile_round_r06.log
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/c44; mkdir -p $O; cd $R
+timeout 2400 python3 -m pytest tests -q -m gpu > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log; tail -n 4 $O/pytest_gpu.log
+timeout 300 python3 -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -n 1 $O/smoke.log
