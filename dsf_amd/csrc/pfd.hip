@@ -32,7 +32,7 @@ struct TriRec {                 // 80 B
     float d00, d01, d11, denom; // Gram invariants of (v1-v0, v2-v0)
     float l12;                  // |v2-v1|^2
     int id;
-    int pad;
+    float m1;                   // max |v_k|_1 over the three vertices: scales the rounding margin of plane_skip()
 };
 
 __device__ __forceinline__ TriRec make_tri(f3 v0, f3 v1, f3 v2, int id) {
@@ -48,7 +48,8 @@ __device__ __forceinline__ TriRec make_tri(f3 v0, f3 v1, f3 v2, int id) {
     r.denom = r.d00 * r.d11 - r.d01 * r.d01 + kEps;
     const f3 e12 = v2 - v1;
     r.l12 = dot(e12, e12);
-    r.id = id; r.pad = 0;
+    r.id = id;
+    r.m1 = fmaxf(fabsf(v0.x) + fabsf(v0.y) + fabsf(v0.z), fmaxf(fabsf(v1.x) + fabsf(v1.y) + fabsf(v1.z), fabsf(v2.x) + fabsf(v2.y) + fabsf(v2.z)));
     return r;
 }
 
@@ -81,6 +82,22 @@ __device__ __forceinline__ float point_tri_dist2(f3 p, const TriRec& r) {
     float d = (e01 > e02) ? e02 : e01;
     d = (d > e12) ? e12 : d;
     return d;
+}
+
+// A lower bound of point_tri_dist2(p, r) for the price of the plane term (round 6).  Both branches of the reference are bounded by
+// it: the plane branch returns t^2 with exactly this t; the three segment distances are distances to points OF the triangle, hence
+// >= the true distance to its plane >= |t| (t is computed with the normal divided by |n| + 1e-8: shorter than the unit normal).
+// E covers the fp32 rounding of t and of the segment distances (a few ulps of the coordinates' magnitudes): the pair is skipped only
+// when (|t| - E)^2 > best STRICTLY, so a skipped pair's value is larger than the current minimum and ties are still decided among
+// all minimisers; NaNs compare false and are never skipped.  What it buys: on a mesh the sphere cull cannot work on -- collapsed to
+// a blob, as a freshly initialised network predicts it: every triangle is tiny, its `inside` test (barycentrics over denom + 1e-8)
+// holds far away and its reported distance is the PLANE distance, so each sphere is unbounded -- most triangles' planes still pass
+// far from a given point, and the points of a wave (Morton-ordered) agree on which do not.
+__device__ __forceinline__ bool plane_skip(f3 p, float p1, const TriRec& r, float best) {
+    const f3 v0 = mk3(r.v0x, r.v0y, r.v0z), n = mk3(r.nx, r.ny, r.nz);
+    const float t = dot(v0 - p, n);
+    const float a = fabsf(t) - 4e-6f * (p1 + r.m1);
+    return a > 0.0f && a * a > best;
 }
 
 __device__ __forceinline__ f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
@@ -442,6 +459,7 @@ __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __rest
         if (listed) { live = g * GP + lane < n_mine; p = live ? pbeg + s_list[g * GP + lane] : 0; }
         else { p = split * GP + lane; live = p < P; p = live ? p : 0; }
         const f3 pt = live ? ld3(pb + p * 3) : mk3(0.f, 0.f, 0.f);
+        const float pt1 = fabsf(pt.x) + fabsf(pt.y) + fabsf(pt.z);         // (plane_skip's rounding margin)
         float best = INFINITY, thr = INFINITY;          // thr = sqrt(best) * (1 + m) * 1.0011 / (1 - m), refreshed with best
         int bi = -1;
         // ---- seed: the nearest centroid among every 2nd triangle of this wave's blocks; the four waves' candidates meet in LDS
@@ -513,6 +531,9 @@ __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __rest
                 if (live) {
                     const float was = best;
                     for (int q = 0; q < cnt; ++q) {
+                        const bool sk = bi >= 0 && plane_skip(pt, pt1, w_tri[q], best);
+                        if (!__ballot(!sk)) continue;                                      // (the live lanes agree: its plane passes far from all of them)
+                        if (sk) continue;
                         const float d = point_tri_dist2(pt, w_tri[q]);
                         const int id = f0 + k * bs + q;
                         if (bi < 0 || d < best || (d == best && id < bi)) { best = d; bi = id; }
@@ -530,7 +551,8 @@ __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __rest
                 const float4 s = w_sph[q];
                 const float dx = pt.x - s.x, dy = pt.y - s.y, dz = pt.z - s.z;
                 const float lim = s.w + thr;
-                const bool need = live && !(dx * dx + dy * dy + dz * dz > lim * lim);      // (NaN distances are never skipped)
+                bool need = live && !(dx * dx + dy * dy + dz * dz > lim * lim);            // (NaN distances are never skipped)
+                if (need && bi >= 0 && plane_skip(pt, pt1, w_tri[q], best)) need = false;
                 const unsigned long long who = __ballot(need);
                 if (!who) continue;                                                        // nobody needs this triangle
                 evals += __popcll(who);
