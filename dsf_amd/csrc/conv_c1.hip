@@ -112,20 +112,23 @@ __global__ __launch_bounds__(256) void conv_c1_wrw_kernel(const float* __restric
     }
 }
 
-// one workgroup per tap: lane = channel, the four waves take every fourth partial; fixed order, double accumulation
-__global__ __launch_bounds__(256) void conv_c1_wrw_combine_kernel(const float* __restrict__ part, int n_part, int taps, int Co,
-                                                                  int accumulate, float* __restrict__ dW) {
-    __shared__ double red[4][64];
+// one workgroup per tap: lane = channel, the SIXTEEN waves take every sixteenth partial (round 6: four waves walked 512 partials each,
+// four loads in flight -- 44 us at the very end of the backward pass); fixed order, double accumulation
+__global__ __launch_bounds__(1024) void conv_c1_wrw_combine_kernel(const float* __restrict__ part, int n_part, int taps, int Co,
+                                                                   int accumulate, float* __restrict__ dW) {
+    __shared__ double red[16][64];
     const int t = blockIdx.x, c = threadIdx.x & 63, g = threadIdx.x >> 6;
     double s = 0.0;
-#pragma unroll 4
-    for (int b = g; b < n_part; b += 4) s += (double)part[((int64_t)b * taps + t) * 64 + c];
+#pragma unroll 8
+    for (int b = g; b < n_part; b += 16) s += (double)part[((int64_t)b * taps + t) * 64 + c];
     red[g][c] = s;
     __syncthreads();
     if (g == 0 && c < Co) {
-        const float v = (float)((red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += red[k][c];
         float* dst = dW + t * Co + c;
-        *dst = accumulate ? *dst + v : v;
+        *dst = accumulate ? *dst + (float)v : (float)v;
     }
 }
 
@@ -243,7 +246,7 @@ int dsf_conv_c1_wrw(const float* X, const float* dY, float* dW, float* workspace
     if (K == 5) { if (stride == 1) DSF_LAUNCH_C1W(5, 1); else DSF_LAUNCH_C1W(5, 2); }
     else { if (stride == 1) DSF_LAUNCH_C1W(7, 1); else DSF_LAUNCH_C1W(7, 2); }
 #undef DSF_LAUNCH_C1W
-    hipLaunchKernelGGL(conv_c1_wrw_combine_kernel, dim3(K * K), dim3(256), 0, st, workspace, wgs, K * K, Co, accumulate, dW);
+    hipLaunchKernelGGL(conv_c1_wrw_combine_kernel, dim3(K * K), dim3(1024), 0, st, workspace, wgs, K * K, Co, accumulate, dW);
     return dsf_launch_status();
 }
 
