@@ -258,7 +258,7 @@ template <bool NT> __device__ __forceinline__ void bn_st4(float* __restrict__ p,
 }
 // VAR (tuning aid DSF_BN_VAR, read per call): bit 0 = non-temporal loads, bit 1 = non-temporal stores, bit 2 = the next batch of
 // loads is issued BEFORE the current one is processed and stored (two register sets)
-constexpr int BN_VAR_DEFAULT = 3;     // non-temporal loads and stores (in-step A/B, one box: config 4 157.6 -> 155.9 ms, config 5 78.5 -> 77.7, config 2 unchanged; the prefetching variants 4 / 7 bring nothing more)
+constexpr int BN_VAR_DEFAULT = 1;     // non-temporal LOADS, ordinary stores: what an apply pass writes is read by the next kernel (in-step A/B on the final round-6 code, one box: config 2 15.95 -> 15.77 ms, config 5 72.4 -> 71.6, config 3 15.31 -> 15.06, config 4 153.2 = 153.3; mid-round, before the other changes, 3 = loads and stores had measured better on configs 4 / 5: profiles/r06_bn_nontemporal.txt); the prefetching variants 4 / 7 bring nothing more
 // DSF_BN_WRITE_G=0 (tuning aid, read per call): the sums pass does not write the masked gradient, the apply pass re-reads gy (+ gy2) and y
 static inline bool bn_write_g() { const char* e = getenv("DSF_BN_WRITE_G"); return !e || atoi(e) != 0; }
 static inline int bn_var() { const char* e = getenv("DSF_BN_VAR"); const int v = e ? atoi(e) : BN_VAR_DEFAULT; return (v < 0 || v > 7) ? BN_VAR_DEFAULT : v; }
