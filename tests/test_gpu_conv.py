@@ -293,6 +293,37 @@ def test_row_staged_3x3_backward_weights_against_float64(Ci, Co, H, W, B, monkey
         L.set_deterministic(was)
 
 
+def test_whole_network_weight_split_launch_writes_the_per_layer_images_bit_for_bit():
+    """dsf_conv_x6_split_weights_multi (one launch after an optimizer step; round 6: four granules per thread, 16-byte loads along n
+    (forward images) / along k (backward-data images)) against dsf_conv_x6_split_weights layer by layer: the same bytes, for full,
+    ragged (partial chunk, partial n tile) and 1 x 1 layers in both modes."""
+    import ctypes
+    from dsf_amd import _lib as L
+    lib = L.lib()
+    I, I64, P = ctypes.c_int, ctypes.c_int64, lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator().manual_seed(3)
+    layers = [(3, 3, 64, 64), (3, 3, 488, 256), (1, 1, 256, 84), (4, 4, 256, 256), (3, 3, 36, 132), (5, 5, 20, 36), (1, 1, 2048, 512)]
+    rows, ref, outs, total = [], [], [], 0
+    for (KH, KW, Ci, Co) in layers:
+        w = torch.randn(KH, KW, Ci, Co, generator=g).cuda()
+        for mode in (0, 1):
+            Ck, Cn = (Co, Ci) if mode else (Ci, Co)
+            n = lib.dsf_conv_x6_image_bytes(I(KH), I(KW), I(Ck), I(Cn))
+            a = torch.zeros(n, dtype=torch.uint8, device="cuda")
+            b = torch.full((n,), 0xAB, dtype=torch.uint8, device="cuda")
+            assert lib.dsf_conv_x6_split_weights(P(w), P(a), I(KH), I(KW), I(Ci), I(Co), I(mode), st) == 0
+            rows.append((w.data_ptr(), b.data_ptr(), KH, KW, Ci, Co, mode, total))
+            total += lib.dsf_conv_x6_image_granules(I(KH), I(KW), I(Ck), I(Cn))
+            ref.append(a); outs.append(b); layers_keep = w
+            rows[-1] = rows[-1] + (w,)
+    table = torch.tensor([r[:8] for r in rows] + [(0, 0, 0, 0, 0, 0, 0, total)], dtype=torch.int64).cuda()
+    assert lib.dsf_conv_x6_split_weights_multi(P(table), I(len(rows)), I64(total), st) == 0
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(ref, outs)):
+        assert torch.equal(a, b), (i, rows[i][2:7])
+
+
 @pytest.mark.parametrize("B,Ci,Co,Ho,bias", [
     (2, 256, 256, 32, False),     # the decoder's largest input gradient (64 x 64 x 256 -> 32 x 32 x 256), 128-row tiles of four output rows
     (5, 64, 128, 16, True),       # 16-wide output, bias
