@@ -227,6 +227,12 @@ constexpr int GP = 64;              // points per group: one per lane, the same 
 constexpr int SEG_RANGE = LIST_CAP;  // labelled clouds: points one (sample, part) workgroup compacts its part's members from (512-point
                                      // ranges = 4 x the workgroups, each staging the part's triangles again: 223 us against 171)
 constexpr float CULL_M = 1e-4f;
+#ifdef PFD_STATS     // diagnostic build only (tools/pfd_pairs.py): pairs a lane needed / lane slots the wave spent on evaluations
+__device__ unsigned long long pfd_stat[4];
+#define PFD_COUNT(i, v) do { if (lane == (int)__builtin_ctzll(__ballot(true))) atomicAdd(&pfd_stat[i], (unsigned long long)(v)); } while (0)
+#else
+#define PFD_COUNT(i, v) do { } while (0)
+#endif
 
 __device__ __forceinline__ float4 tri_sphere(const TriRec& r) {
     const f3 v0 = mk3(r.v0x, r.v0y, r.v0z), q0 = mk3(r.v1x, r.v1y, r.v1z) - v0, q1 = mk3(r.v2x, r.v2y, r.v2z) - v0;
@@ -532,7 +538,9 @@ __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __rest
                     const float was = best;
                     for (int q = 0; q < cnt; ++q) {
                         const bool sk = bi >= 0 && plane_skip(pt, pt1, w_tri[q], best);
-                        if (!__ballot(!sk)) continue;                                      // (the live lanes agree: its plane passes far from all of them)
+                        const unsigned long long nsk = __ballot(!sk);
+                        if (!nsk) continue;                                                // (the live lanes agree: its plane passes far from all of them)
+                        PFD_COUNT(0, __popcll(nsk)); PFD_COUNT(1, __popcll(__ballot(true))); PFD_COUNT(2, 1);
                         if (sk) continue;
                         const float d = point_tri_dist2(pt, w_tri[q]);
                         const int id = f0 + k * bs + q;
@@ -555,6 +563,7 @@ __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __rest
                 if (need && bi >= 0 && plane_skip(pt, pt1, w_tri[q], best)) need = false;
                 const unsigned long long who = __ballot(need);
                 if (!who) continue;                                                        // nobody needs this triangle
+                PFD_COUNT(0, __popcll(who)); PFD_COUNT(1, n_live); PFD_COUNT(3, 1);
                 evals += __popcll(who);
                 if (need) {
                     const float d = point_tri_dist2(pt, w_tri[q]);
@@ -688,3 +697,11 @@ extern "C" int dsf_mesh_point_dist_backward(const float* verts, const float* poi
                        faces, idxs, grad_dists, V, P, per_wg, grad_verts, grad_points);
     return dsf_launch_status();
 }
+
+#ifdef PFD_STATS
+extern "C" int dsf_pfd_stats(unsigned long long* out) {
+    unsigned long long z[4] = {0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pfd_stat), sizeof(z)) != hipSuccess) return 1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(pfd_stat), z, sizeof(z)) == hipSuccess ? 0 : 1;
+}
+#endif

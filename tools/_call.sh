@@ -1,4 +1,3 @@
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/c54; mkdir -p $O; cd $R
-timeout 2400 python3 -m pytest tests -q -m gpu > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log; tail -n 3 $O/pytest_gpu.log
-timeout 300 python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -n 1
-timeout 300 python3 bench.py 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline_critical']['frac'], d['cpu_baseline']['value'])"
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/c55; mkdir -p $O; cd $R
+timeout 600 python3 tools/pfd_pairs.py 5 6 2>&1 | grep -v amdgpu > $O/pfd_pairs_c5.txt; cat $O/pfd_pairs_c5.txt
+timeout 600 python3 tools/pfd_pairs.py 3 6 2>&1 | grep -v amdgpu > $O/pfd_pairs_c3.txt; cat $O/pfd_pairs_c3.txt
