@@ -102,6 +102,31 @@ __device__ __forceinline__ bool plane_skip(f3 p, float p1, const TriRec& r, floa
 
 __device__ __forceinline__ f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
 
+// A second bound for triangles whose cull sphere is inflated (round 6).  The reference's `inside` test divides by denom + 1e-8, so
+// it holds on the triangle scaled about v0 by k = denom / (denom - 1e-8) (tri_sphere): 3-4x for the triangles of a SMALL mesh -- the
+// estimate of a freshly initialised network, Gram determinants ~1e-9 -- and the sphere that bounds the scaled triangle then reaches a
+// quarter of the mesh for every point (profiles/r06_pfd_pairs.txt).  But the plane branch needs the point's PROJECTION inside that
+// scaled triangle.  With d2 = |p - c|^2 to the inflated sphere's centre (a point of the plane) and t the plane term, the projection
+// lies rho^2 = d2 - t_true^2 from c, t_true^2 <= 1.0021 t^2 (bounded spheres have |n| / (|n| + 1e-8) >= 1 / 1.001); if rho exceeds
+// the inflated radius, `inside` fails and the value is a distance to the TRUE triangle's edges, >= |p - centroid| - circumradius-like
+// bound of the unscaled triangle.  Margins as in tri_sphere / plane_skip; strict comparison; NaN / inf never skip.
+__device__ __forceinline__ bool tight_skip(f3 p, float p1, const TriRec& r, float4 sph, float d2, float best) {
+    // only where the sphere is inflated by more than half (k = denom / (denom - 1e-8) > 1.5 <=> denom < 3e-8): on an ordinary mesh the
+    // test is pure cost (+6 .. +17 % per launch, measured)
+    if (!(sph.w < INFINITY) || !(r.denom < 3e-8f)) return false;
+    const f3 v0 = mk3(r.v0x, r.v0y, r.v0z), v1 = mk3(r.v1x, r.v1y, r.v1z), v2 = mk3(r.v2x, r.v2y, r.v2z), n = mk3(r.nx, r.ny, r.nz);
+    const float E = 4e-6f * (p1 + r.m1);
+    const float ta = fabsf(dot(v0 - p, n)) + E;
+    const float rho2 = d2 * (1.0f - 4.0f * 1e-4f) - 1.0021f * ta * ta;
+    const float Rf = sph.w * (1.0f + 1e-4f);
+    if (!(rho2 > Rf * Rf)) return false;                // the projection may lie inside the scaled triangle: the plane branch is possible
+    const f3 ct = (1.0f / 3.0f) * ((v0 + v1) + v2);
+    const f3 e0 = v0 - ct, e1 = v1 - ct, e2 = v2 - ct, dp = p - ct;
+    const float Rt = sqrtf(fmaxf(dot(e0, e0), fmaxf(dot(e1, e1), dot(e2, e2))));
+    const float a = sqrtf(dot(dp, dp)) * (1.0f - 1e-4f) - Rt * (1.0f + 1e-4f) - E;
+    return a > 0.0f && a * a > best;
+}
+
 // ---- packed (pytorch3d._C) form ---------------------------------------------------------------
 __global__ __launch_bounds__(256) void pfd_packed_fwd_kernel(const float* __restrict__ points,
                                                              const int64_t* __restrict__ pfirst,
@@ -560,7 +585,7 @@ __global__ __launch_bounds__(256) void mesh_point_fwd_kernel(const float* __rest
                 const float dx = pt.x - s.x, dy = pt.y - s.y, dz = pt.z - s.z;
                 const float lim = s.w + thr;
                 bool need = live && !(dx * dx + dy * dy + dz * dz > lim * lim);            // (NaN distances are never skipped)
-                if (need && bi >= 0 && plane_skip(pt, pt1, w_tri[q], best)) need = false;
+                if (need && bi >= 0 && (plane_skip(pt, pt1, w_tri[q], best) || tight_skip(pt, pt1, w_tri[q], s, dx * dx + dy * dy + dz * dz, best))) need = false;
                 const unsigned long long who = __ballot(need);
                 if (!who) continue;                                                        // nobody needs this triangle
                 PFD_COUNT(0, __popcll(who)); PFD_COUNT(1, n_live); PFD_COUNT(3, 1);

@@ -1,3 +1,4 @@
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/c55; mkdir -p $O; cd $R
-timeout 600 python3 tools/pfd_pairs.py 5 6 2>&1 | grep -v amdgpu > $O/pfd_pairs_c5.txt; cat $O/pfd_pairs_c5.txt
-timeout 600 python3 tools/pfd_pairs.py 3 6 2>&1 | grep -v amdgpu > $O/pfd_pairs_c3.txt; cat $O/pfd_pairs_c3.txt
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/c57; mkdir -p $O; cd $R
+timeout 1800 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_properties.py tests/test_gpu_edge.py tests/test_gpu_stress.py -q -m gpu > $O/pytest_geo.log 2>&1; echo "rc=$?" >> $O/pytest_geo.log; tail -n 2 $O/pytest_geo.log
+timeout 300 python3 tools/perf_pfd.py 2>&1 | grep -v amdgpu | grep "B 64\|labelled" > $O/perf_pfd.txt; cat $O/perf_pfd.txt
+timeout 600 python3 tools/pfd_in_step.py 5 3 2>&1 | grep -v amdgpu > $O/pfd_in_step.txt; cat $O/pfd_in_step.txt
