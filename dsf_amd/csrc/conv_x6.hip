@@ -1849,6 +1849,18 @@ int dsf_conv_x6_forward_plan(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int 
     if (variant)
         *variant = x6_patch_applies(plan, patch_geo, ph, pw, Ci) ? 2 : (plan.bdirect && !(plan.bmt == 64 && plan.n_tiles >= 2)) ? 1 : 0;
     if (k_splits) *k_splits = plan.k_splits;
+    // a 1 x 1 filter under dilation 2 that x6_forward_impl would launch over its live parity class only (unsplit, no zero fill): report
+    // THAT launch (variant 3, one split), so that a caller holding pooled zeros does not route the layer into the split gather
+    // (dsf_conv_x6_forward_into disables the live launch) -- the advisor's round-5 finding; bias / epilogue users get the general plan
+    // from the launcher itself either way
+    if (dil == 2 && KH == 1 && KW == 1 && !((Ho | Wo) & 1)) {
+        const char* live_e = getenv("DSF_X6_LIVE");
+        const X6Plan lp = x6_forward_plan((int64_t)B * Ho * Wo / 4, Ci, Co, 1, 1, 1, 0);
+        if (!(live_e && atoi(live_e) == 0) && lp.k_splits == 1 && lp.bdirect && !(lp.bmt == 64 && lp.n_tiles >= 2)) {
+            if (variant) *variant = 3;
+            if (k_splits) *k_splits = 1;
+        }
+    }
     return DSF_OK;
 }
 

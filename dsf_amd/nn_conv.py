@@ -919,6 +919,9 @@ def kernel_name(rec):
                 bmt = 64
             return "igemm_x6p_kernel<%d, %d, %d, %d, %d, %d, %s>" % (bn6, bmt, pw, 4 if bmt == 64 else 2, 3 if (bmt == 64 and nt == 9) else 2, nt,
                                                                      "true" if ip else "false")
+        if variant.value == 3:                                 # a 1 x 1 filter under dilation 2: the live parity class only (a quarter of the rows)
+            bmt = 256 if bn6 == 64 else (64 if ((B * Ho * Wo // 4 + 127) // 128) * n6 < 384 else 128)
+            return "igemm_x6b_kernel<%d, true, %d>" % (bn6, bmt)
         if direct and not (bmt == 64 and n6 >= 2):            # weight operand straight into the MFMA fragments (conv_x6.hip)
             return "igemm_x6b_kernel<%d, %s, %d>" % (bn6, "true" if dil == 2 else "false", bmt)
         return "igemm_x6_kernel<%d, %s, %d>" % (bn6, "true" if dil == 2 else "false", bmt)
