@@ -1,4 +1,3 @@
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/c62; mkdir -p $O; cd $R
-timeout 900 python3 -m pytest tests/test_gpu_conv.py -q -m gpu -x > $O/pytest.log 2>&1; echo "rc=$?" >> $O/pytest.log; tail -n 3 $O/pytest.log
-timeout 900 python3 tools/ab_env.py --config 2 --var DSF_X6_LIVE --values 0 1 --rounds 6 > $O/ab_live_c2.txt 2>&1; tail -n 2 $O/ab_live_c2.txt
-timeout 900 python3 tools/ab_env.py --config 4 --var DSF_X6_LIVE --values 0 1 --rounds 3 --block 4 > $O/ab_live_c4.txt 2>&1; tail -n 2 $O/ab_live_c4.txt
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/c63; mkdir -p $O; cd $R
+timeout 2400 python3 -m pytest tests -q -m gpu > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log; tail -n 3 $O/pytest_gpu.log
+timeout 300 python3 bench.py --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"
