@@ -22,10 +22,14 @@ __device__ __forceinline__ float c1_row(const float* __restrict__ X, const C1P& 
     return ok ? X[((int64_t)b * p.Hi + iy) * p.Wi + ix] : 0.f;
 }
 
-template <int K, int S>
-__global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W,
-                                                          const float* __restrict__ bias, float* __restrict__ Y, C1P p,
-                                                          int segs_per_row, int64_t n_segs) {
+// STATS: the per-channel sum and sum of squares of the output (the batch statistics of the BatchNorm behind the stem) are taken
+// from the accumulators -- lane = channel: two more registers -- and ADDED as doubles into row (workgroup mod acc_rows) of a zeroed
+// [acc_rows][2][Co] block, the layout norm.hip's apply kernels fold in their prologue (dsf_bn_forward_acc with acc_filled): the
+// BatchNorm's own statistics pass over the 134 MB output is not run.
+template <int K, int S, bool STATS>
+__device__ __forceinline__ void c1_fwd_body(const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
+                                            float* __restrict__ Y, const C1P& p, int segs_per_row, int64_t n_segs, double* __restrict__ stat,
+                                            int acc_rows) {
     constexpr int NIN = (PX - 1) * S + K;
     static_assert(NIN <= 64, "one wave-wide load per input row");
     const int lane = threadIdx.x & 63;
@@ -36,6 +40,7 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restric
 #pragma unroll
     for (int i = 0; i < K * K; ++i) w[i] = c_ok ? W[i * p.Co + lane] : 0.f;
     const float bv = (bias && c_ok) ? bias[lane] : 0.f;
+    float s0 = 0.f, s1 = 0.f;
     for (int64_t seg = wave; seg < n_segs; seg += n_waves) {
         const int sx = (int)(seg % segs_per_row);
         const int64_t row = seg / segs_per_row;
@@ -62,9 +67,39 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restric
             float* dst = Y + (((int64_t)b * p.Ho + oy) * p.Wo + ox0) * p.Co + lane;
 #pragma unroll
             for (int q = 0; q < PX; ++q, dst += p.Co)
-                if (ox0 + q < p.Wo) *dst = acc[q];
+                if (ox0 + q < p.Wo) {
+                    *dst = acc[q];
+                    if (STATS) { s0 += acc[q]; s1 = fmaf(acc[q], acc[q], s1); }
+                }
         }
     }
+    if (STATS) {
+        __shared__ float red[2][4][64];
+        const int wv = threadIdx.x >> 6;
+        red[0][wv][lane] = s0; red[1][wv][lane] = s1;
+        __syncthreads();
+        if (wv == 0 && c_ok) {
+            double* row = stat + (int64_t)(blockIdx.x % acc_rows) * 2 * p.Co;
+            __hip_atomic_fetch_add(row + lane, (double)((red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane])),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(row + p.Co + lane, (double)((red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane])),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+template <int K, int S>
+__global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                          const float* __restrict__ bias, float* __restrict__ Y, C1P p,
+                                                          int segs_per_row, int64_t n_segs) {
+    c1_fwd_body<K, S, false>(X, W, bias, Y, p, segs_per_row, n_segs, nullptr, 1);
+}
+
+template <int K, int S>
+__global__ __launch_bounds__(256) void conv_c1_fwd_stats_kernel(const float* __restrict__ X, const float* __restrict__ W, float* __restrict__ Y,
+                                                                C1P p, int segs_per_row, int64_t n_segs, double* __restrict__ stat,
+                                                                int acc_rows) {
+    c1_fwd_body<K, S, true>(X, W, nullptr, Y, p, segs_per_row, n_segs, stat, acc_rows);
 }
 
 // dW[kh][kw][co] = sum over pixels of x[iy][ix] * gy[pixel][co]: per-lane accumulators, workgroup partials, then a combine
@@ -132,6 +167,7 @@ __global__ __launch_bounds__(1024) void conv_c1_wrw_combine_kernel(const float* 
     }
 }
 
+constexpr int C1_STATS_WGS = 1024;                    // the statistics variant: 128 double atomics per workgroup onto acc_rows x 2 Co addresses
 constexpr int C1_WRW_WGS = 2048;                      // 8 waves per SIMD: the kernel lives on loads in flight
 
 inline bool c1_ok(int Co, int K, int stride) { return Co >= 1 && Co <= 64 && (K == 5 || K == 7) && (stride == 1 || stride == 2); }
@@ -223,6 +259,23 @@ int dsf_conv_c1_forward(const float* X, const float* W, const float* bias, float
     if (wgs > 4096) wgs = 4096;
 #define DSF_LAUNCH_C1(Kv, Sv) hipLaunchKernelGGL((conv_c1_fwd_kernel<Kv, Sv>), dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, \
                                                  X, W, bias, Y, p, spr, n_segs)
+    if (K == 5) { if (stride == 1) DSF_LAUNCH_C1(5, 1); else DSF_LAUNCH_C1(5, 2); }
+    else { if (stride == 1) DSF_LAUNCH_C1(7, 1); else DSF_LAUNCH_C1(7, 2); }
+#undef DSF_LAUNCH_C1
+    return dsf_launch_status();
+}
+
+int dsf_conv_c1_forward_bn_acc(const float* X, const float* W, float* Y, int B, int Hi, int Wi, int Ho, int Wo, int Co, int K, int stride,
+                               int pad, double* acc, int acc_rows, dsf_stream_t stream) {
+    DSF_CHECK_ARG(X && W && Y && acc && acc_rows >= 1 && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && pad >= 0);
+    if (!c1_ok(Co, K, stride) || dsf_deterministic()) return DSF_ERR_UNSUPPORTED;
+    C1P p = {B, Hi, Wi, Ho, Wo, Co, pad};
+    const int spr = (Wo + PX - 1) / PX;
+    const int64_t n_segs = (int64_t)B * Ho * spr;
+    int64_t wgs = (n_segs + 3) / 4;
+    if (wgs > C1_STATS_WGS) wgs = C1_STATS_WGS;
+#define DSF_LAUNCH_C1(Kv, Sv) hipLaunchKernelGGL((conv_c1_fwd_stats_kernel<Kv, Sv>), dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, \
+                                                 X, W, Y, p, spr, n_segs, acc, acc_rows)
     if (K == 5) { if (stride == 1) DSF_LAUNCH_C1(5, 1); else DSF_LAUNCH_C1(5, 2); }
     else { if (stride == 1) DSF_LAUNCH_C1(7, 1); else DSF_LAUNCH_C1(7, 2); }
 #undef DSF_LAUNCH_C1

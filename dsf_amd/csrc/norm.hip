@@ -818,6 +818,245 @@ inline void bn_small_backward(const float* x, const float* grad_y, const float* 
     else hipLaunchKernelGGL(bn_small_bwd_kernel<4>, grid, dim3(256), 0, st, x, grad_y, y, save_mean, save_invstd, gamma, beta, (int)M, C, relu, grad_x, grad_residual, fin, grad_y2);
 }
 
+// ---- stem: BatchNorm + ReLU + MaxPool2d as ONE apply pass, and the pooling's backward inside the BatchNorm backward ------------
+// The backbone stem is conv5x5 -> BatchNorm -> ReLU -> MaxPool2d(3, 2, 1) (reference model/backbone.py:200-204) on the largest map of
+// the step (B x 128 x 128 x 64: 134 MB).  Unfused, the normalised map is written (134 MB), read by the pooling (134 MB), and in the
+// backward the pooling's gather writes a 134 MB gradient that both BatchNorm backward passes read.  Here
+//  * forward: the apply pass computes the normalised, rectified values of a K x K window from x and writes only the pooled output and
+//    the 1-byte argmax (pool.hip's rule: first maximum in (kh, kw) order, NaN wins) -- the full-resolution output never exists;
+//  * backward: both passes take the gradient of a full-resolution element from the pooled gradient (bn_pool_gather: the terms of
+//    pool.hip's maxpool_bwd_kernel in its order, so the value is bit-for-bit the unfused one), and the ReLU mask is recomputed from
+//    x as in the unpooled layer (relu mode 2).
+// Traffic: forward 134 R + 42 W instead of 402; backward 2 x (134 + 42) R + 134 W instead of 845.
+struct BnPoolP { int Hi, Wi, Ho, Wo, k, stride, pad; };
+
+// the <= 2 x 2 output windows (k <= 2 stride) that contain input pixel `pix`: pooled gradient, argmax bytes, and the window position
+// this pixel has in each (255: no such window -- never an argmax byte, k <= 15); addresses of absent windows are clamped onto present ones
+struct BnPoolTap { float4 g[4]; uchar4 a[4]; int me[4]; };
+__device__ __forceinline__ void bn_pool_fetch(const float* __restrict__ g, const uint8_t* __restrict__ arg, const BnPoolP& p, int C, uint32_t pix,
+                                              int c, BnPoolTap& t) {
+    const uint32_t row = pix / (uint32_t)p.Wi, b = row / (uint32_t)p.Hi;
+    const int ix = (int)(pix - row * (uint32_t)p.Wi), iy = (int)(row - b * (uint32_t)p.Hi);
+    const int oy_hi = min((iy + p.pad) / p.stride, p.Ho - 1), ox_hi = min((ix + p.pad) / p.stride, p.Wo - 1);
+    const int oy_lo = max(0, (iy + p.pad - p.k + p.stride) / p.stride), ox_lo = max(0, (ix + p.pad - p.k + p.stride) / p.stride);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int oy = oy_lo + (w >> 1), ox = ox_lo + (w & 1);
+        const bool v = oy <= oy_hi && ox <= ox_hi;
+        const int64_t o = (((int64_t)b * p.Ho + min(oy, p.Ho - 1)) * p.Wo + min(ox, p.Wo - 1)) * C + c;
+        t.me[w] = v ? (iy - (oy * p.stride - p.pad)) * p.k + (ix - (ox * p.stride - p.pad)) : 255;
+        t.a[w] = *reinterpret_cast<const uchar4*>(arg + o);
+        t.g[w] = *reinterpret_cast<const float4*>(g + o);
+    }
+}
+__device__ __forceinline__ float4 bn_pool_gather(const BnPoolTap& t) {
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        a[0] += (t.a[w].x == t.me[w]) ? t.g[w].x : 0.f; a[1] += (t.a[w].y == t.me[w]) ? t.g[w].y : 0.f;
+        a[2] += (t.a[w].z == t.me[w]) ? t.g[w].z : 0.f; a[3] += (t.a[w].w == t.me[w]) ? t.g[w].w : 0.f;
+    }
+    return make_float4(a[0], a[1], a[2], a[3]);
+}
+
+// forward apply: FOLD prologue of bn_apply_kernel (statistics from the accumulation rows; the first workgroup stores mean / invstd and
+// updates the running statistics), then a thread per (output pixel, channel quad)
+template <int K>
+__global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, int64_t n4o, int C, float* __restrict__ y,
+                                                               uint8_t* __restrict__ arg, const double* __restrict__ rows, int n_rows,
+                                                               int64_t M, BnFinal fin, BnPoolP p) {
+    __shared__ double s_buf[BN_FOLD_LDS];
+    const int c4n = C >> 2, nq = min(c4n, 256);
+    const int64_t i0 = blockIdx.x * (int64_t)256 + threadIdx.x;
+    const int64_t S = (int64_t)gridDim.x * 256;
+    const int c = (int)(i0 % c4n) * 4;
+    const bool owner = (int)threadIdx.x < nq;
+    float par[3][4];                                           // mean, scale = invstd * gamma, shift = beta
+    double s0[4], s1[4];
+    bn_fold_rows_wg(rows, n_rows, C, nq, c, s_buf, s0, s1);
+    if (owner) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double m = s0[k] / (double)M;
+            double var = s1[k] / (double)M - m * m;
+            if (var < 0.0) var = 0.0;
+            const float is = (float)(1.0 / sqrt(var + (double)fin.eps));
+            par[0][k] = (float)m;
+            par[1][k] = is * (gamma ? gamma[c + k] : 1.f);
+            par[2][k] = beta ? beta[c + k] : 0.f;
+            if (i0 < c4n && fin.mean) {
+                fin.mean[c + k] = (float)m;
+                fin.invstd[c + k] = is;
+                if (fin.running_mean) {
+                    const double unbiased = (M > 1) ? var * (double)M / (double)(M - 1) : var;
+                    fin.running_mean[c + k] = (1.f - fin.momentum) * fin.running_mean[c + k] + fin.momentum * (float)m;
+                    fin.running_var[c + k] = (1.f - fin.momentum) * fin.running_var[c + k] + fin.momentum * (float)unbiased;
+                }
+            }
+        }
+    }
+    if (nq < 256) bn_share_params<3>(nq, par, s_buf);
+    for (int64_t j = i0; j < n4o; j += S) {
+        const uint32_t q = (uint32_t)j / (uint32_t)c4n;                   // (the launcher checked n4o < 2^31)
+        const uint32_t row = q / (uint32_t)p.Wo, b = row / (uint32_t)p.Ho;
+        const int ox = (int)(q - row * (uint32_t)p.Wo), oy = (int)(row - b * (uint32_t)p.Ho);
+        float4 xv[K * K];
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {                    // (absent taps load a present pixel: clamped address, value unused)
+                const int iy = min(max(oy * p.stride - p.pad + kh, 0), p.Hi - 1), ix = min(max(ox * p.stride - p.pad + kw, 0), p.Wi - 1);
+                xv[kh * K + kw] = *reinterpret_cast<const float4*>(x + (((int64_t)b * p.Hi + iy) * p.Wi + ix) * C + c);
+            }
+        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int where[4] = {-1, -1, -1, -1};
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+                const int iy = oy * p.stride - p.pad + kh, ix = ox * p.stride - p.pad + kw;
+                if ((unsigned)iy >= (unsigned)p.Hi || (unsigned)ix >= (unsigned)p.Wi) continue;
+                const float4 v = xv[kh * K + kw];
+                const float xe[4] = {v.x, v.y, v.z, v.w};
+                const int pos = kh * K + kw;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float o = fmaxf((xe[e] - par[0][e]) * par[1][e] + par[2][e], 0.f);      // bn_apply_kernel's expression
+                    if (where[e] < 0) where[e] = pos;
+                    if (o > best[e] || o != o) { best[e] = o; where[e] = pos; }
+                }
+            }
+        *reinterpret_cast<float4*>(y + j * 4) = make_float4(best[0], best[1], best[2], best[3]);
+        if (arg) *reinterpret_cast<uchar4*>(arg + j * 4) = make_uchar4((uint8_t)where[0], (uint8_t)where[1], (uint8_t)where[2], (uint8_t)where[3]);
+    }
+}
+
+// backward sums: bn_reduce_kernel<1> with relu mode 2, the gradient gathered from the pooled gradient; adds into the accumulation rows
+__global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                                 const uint8_t* __restrict__ arg, const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, int64_t M, int C, int rows_per_wg,
+                                                                 double* __restrict__ acc, int acc_rows, BnPoolP p) {
+    __shared__ float s_part[2][256 * 4];
+    const int t = threadIdx.x;
+    const int c4b = min(C >> 2, 256);
+    const int lcol = t % c4b, rl = t / c4b;
+    const int col = blockIdx.y * c4b + lcol;
+    const int rlanes = 256 / c4b;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+    const int64_t r1 = (r0 + rows_per_wg < M) ? r0 + rows_per_wg : M;
+    float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f}, mu[4], is[4], sc[4], sh[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        mu[k] = mean[col * 4 + k]; is[k] = invstd[col * 4 + k];
+        sc[k] = is[k] * (gamma ? gamma[col * 4 + k] : 1.f);
+        sh[k] = beta ? beta[col * 4 + k] : 0.f;
+    }
+    constexpr int U = 2;
+    for (int64_t r = r0 + rl; r < r1; r += (int64_t)U * rlanes) {
+        float4 xv[U]; BnPoolTap tap[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t rr = r + (int64_t)u * rlanes;
+            const int64_t rc = (rr < r1) ? rr : r;
+            xv[u] = *reinterpret_cast<const float4*>(x + rc * C + col * 4);
+            bn_pool_fetch(g, arg, p, C, (uint32_t)rc, col * 4, tap[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (r + (int64_t)u * rlanes >= r1) break;
+            const float4 gv = bn_pool_gather(tap[u]);
+            const float xe[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+            float ge[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ge[k] = ((xe[k] - mu[k]) * sc[k] + sh[k] > 0.f) ? ge[k] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a0[k] += ge[k]; a1[k] = fmaf(ge[k], (xe[k] - mu[k]) * is[k], a1[k]); }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s_part[0][t * 4 + k] = a0[k]; s_part[1][t * 4 + k] = a1[k]; }
+    __syncthreads();
+    double* out = acc + (int64_t)(blockIdx.x % acc_rows) * 2 * C + blockIdx.y * c4b * 4;
+    for (int ch = t; ch < c4b * 4; ch += 256) {
+        const int cc = ch >> 2, kk = ch & 3;
+        float d0 = 0.f, d1 = 0.f;
+        for (int q = 0; q < rlanes; ++q) { d0 += s_part[0][(q * c4b + cc) * 4 + kk]; d1 += s_part[1][(q * c4b + cc) * 4 + kk]; }
+        __hip_atomic_fetch_add(out + ch, (double)d0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(out + C + ch, (double)d1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// backward apply: bn_bwd_apply_kernel<FOLD> with relu mode 2 and the gathered gradient; x is read once (non-temporal), dx written
+__global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                                const uint8_t* __restrict__ arg, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, int64_t M, int64_t n4, int C,
+                                                                float* __restrict__ dx, const double* __restrict__ rows, int n_rows,
+                                                                BnFinal fin, BnPoolP p) {
+    __shared__ double s_buf[BN_FOLD_LDS];
+    constexpr int U = 2;
+    const int c4n = C >> 2, nq = min(c4n, 256);
+    const int64_t i0 = blockIdx.x * (int64_t)256 + threadIdx.x;
+    const int64_t S = (int64_t)gridDim.x * 256;
+    const int c = (int)(i0 % c4n) * 4;
+    const bool owner = (int)threadIdx.x < nq;
+    float4 xv[U]; BnPoolTap tap[U];
+    auto fetch = [&](int64_t i) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t j = (i + u * S < n4) ? i + u * S : i0;
+            xv[u] = bn_ld4<true>(x, j);
+            bn_pool_fetch(g, arg, p, C, (uint32_t)j / (uint32_t)c4n, c, tap[u]);      // (n4 < 2^31: checked by the launcher)
+        }
+    };
+    fetch(i0);
+    double f0[4], f1[4];
+    bn_fold_rows_wg(rows, n_rows, C, nq, c, s_buf, f0, f1);
+    if (owner && i0 < c4n) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (fin.dbeta) fin.dbeta[c + k] = (fin.accum ? fin.dbeta[c + k] : 0.f) + (float)f0[k];
+            if (fin.dgamma) fin.dgamma[c + k] = (fin.accum ? fin.dgamma[c + k] : 0.f) + (float)f1[k];
+        }
+    }
+    float par[6][4];                                           // mean, invstd, sum_g / M, sum_gx / M, invstd * gamma, beta
+    if (owner) {
+        const float invM = 1.0f / (float)M;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            par[0][k] = mean[c + k]; par[1][k] = invstd[c + k];
+            par[2][k] = (float)f0[k] * invM; par[3][k] = (float)f1[k] * invM;
+            par[4][k] = (gamma ? gamma[c + k] : 1.f) * par[1][k];
+            par[5][k] = beta ? beta[c + k] : 0.f;
+        }
+    }
+    if (nq < 256) bn_share_params<6>(nq, par, s_buf);
+    const int64_t US = (int64_t)U * S;
+    for (int64_t i = i0; i < n4;) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t j = i + u * S;
+            if (j >= n4) break;
+            const float4 gv = bn_pool_gather(tap[u]);
+            const float xe[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+            float ge[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ge[k] = ((xe[k] - par[0][k]) * par[4][k] + par[5][k] > 0.f) ? ge[k] : 0.f;
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float xh = (xe[k] - par[0][k]) * par[1][k];
+                o[k] = par[4][k] * (ge[k] - par[2][k] - xh * par[3][k]);
+            }
+            bn_st4<false>(dx, j, make_float4(o[0], o[1], o[2], o[3]));
+        }
+        i += US;
+        if (i < n4) fetch(i);
+    }
+}
+
 // ---- launch helpers: the VAR / G2 / mask instantiations ---------------------------------------------------------------------
 #define BN_VAR_SWITCH(var, CALL) \
     switch (var) { case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; \
@@ -1065,6 +1304,60 @@ extern "C" int dsf_bn_backward_acc_pair(const float* x, const float* grad_y, con
     if (!bn_shape_ok(C) || dsf_deterministic()) return DSF_ERR_UNSUPPORTED;
     return bn_backward_acc_impl(x, grad_y, grad_y2, y, gamma, beta, save_mean, save_invstd, M, C, relu, grad_x, grad_residual, grad_gamma,
                                 grad_beta, acc, (hipStream_t)stream, accumulate_affine);
+}
+
+// ---- stem: BatchNorm + ReLU + MaxPool2d (see bn_relu_pool_fwd_kernel) ----------------------------------------------------------
+static bool bn_pool_ok(int B, int Hi, int Wi, int C, int k, int stride, int pad, int* Ho, int* Wo) {
+    if (!(B > 0 && Hi > 0 && Wi > 0 && bn_shape_ok(C) && (k == 2 || k == 3) && stride >= 1 && pad >= 0 && 2 * pad <= k && k <= 2 * stride)) return false;
+    *Ho = (Hi + 2 * pad - k) / stride + 1; *Wo = (Wi + 2 * pad - k) / stride + 1;
+    return *Ho > 0 && *Wo > 0 && (int64_t)B * Hi * Wi * (C >> 2) < ((int64_t)1 << 31);
+}
+
+extern "C" int dsf_bn_relu_pool_forward(const float* x, const float* gamma, const float* beta, int B, int Hi, int Wi, int C, int k, int stride,
+                                        int pad, float eps, float momentum, float* running_mean, float* running_var, float* y,
+                                        uint8_t* argmax, float* save_mean, float* save_invstd, double* acc, int acc_filled,
+                                        dsf_stream_t stream) {
+    DSF_CHECK_ARG(x && y && save_mean && save_invstd && acc);
+    int Ho, Wo;
+    if (!bn_pool_ok(B, Hi, Wi, C, k, stride, pad, &Ho, &Wo) || dsf_deterministic()) return DSF_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t M = (int64_t)B * Hi * Wi;
+    BnFinal fin = {eps, momentum, save_mean, save_invstd, running_mean, running_var, nullptr, nullptr, nullptr};
+    if (!acc_filled) {                                                // (else: the producing convolution's epilogue left the sums in `acc`)
+        const int rows = bn_rows_per_wg(M, C, BN_ACC_WGS);
+        const int wgs = (int)((M + rows - 1) / rows);
+        hipLaunchKernelGGL((bn_reduce_kernel<0, false>), dim3(wgs, bn_col_blocks(C)), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr,
+                           nullptr, nullptr, M, C, 0, rows, reinterpret_cast<float*>(acc), BN_ACC_ROWS);
+    }
+    const BnPoolP p = {Hi, Wi, Ho, Wo, k, stride, pad};
+    const int64_t n4o = (int64_t)B * Ho * Wo * (C >> 2);
+    const int grid = bn_apply_grid(n4o * 4, C);                       // (a thread's unit of work is a K x K window, not one float4)
+    if (k == 3) hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<3>, dim3(grid), dim3(256), 0, st, x, gamma, beta, n4o, C, y, argmax, acc, BN_ACC_ROWS, M, fin, p);
+    else hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<2>, dim3(grid), dim3(256), 0, st, x, gamma, beta, n4o, C, y, argmax, acc, BN_ACC_ROWS, M, fin, p);
+    return dsf_launch_status();
+}
+
+extern "C" int dsf_bn_relu_pool_backward(const float* x, const float* grad_y, const uint8_t* argmax, const float* gamma, const float* beta,
+                                         const float* save_mean, const float* save_invstd, int B, int Hi, int Wi, int C, int k, int stride,
+                                         int pad, float* grad_x, float* grad_gamma, float* grad_beta, int accumulate_affine, double* acc,
+                                         dsf_stream_t stream) {
+    DSF_CHECK_ARG(x && grad_y && argmax && save_mean && save_invstd && grad_x && acc);
+    int Ho, Wo;
+    if (!bn_pool_ok(B, Hi, Wi, C, k, stride, pad, &Ho, &Wo) || dsf_deterministic()) return DSF_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t M = (int64_t)B * Hi * Wi, n4 = M * (C >> 2);
+    const BnPoolP p = {Hi, Wi, Ho, Wo, k, stride, pad};
+    const char* wg_e = getenv("DSF_BN_BWD_WGS");
+    int max_wgs = wg_e ? atoi(wg_e) : 1024;
+    if (max_wgs < 1) max_wgs = 1024;
+    const int rows = bn_rows_per_wg(M, C, max_wgs);
+    const int wgs = (int)((M + rows - 1) / rows);
+    BnFinal fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, grad_gamma, grad_beta, accumulate_affine};
+    hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(wgs, bn_col_blocks(C)), dim3(256), 0, st, x, grad_y, argmax, save_mean, save_invstd, gamma,
+                       beta, M, C, rows, acc, BN_ACC_ROWS, p);
+    hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(bn_apply_grid(n4, C)), dim3(256), 0, st, x, grad_y, argmax, save_mean, save_invstd, gamma,
+                       beta, M, n4, C, grad_x, acc, BN_ACC_ROWS, fin, p);
+    return dsf_launch_status();
 }
 
 // ---- cross-replica BatchNorm (SyncBatchNorm): ONE exchange of 2C + 1 doubles per layer and pass -------------

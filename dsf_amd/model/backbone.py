@@ -15,7 +15,7 @@ import torch.nn as nn
 from . import resnet as _resnet
 from .resnet import BasicBlock, Bottleneck
 from .. import nn_conv
-from ..nn_norm import FusedBatchNorm2d, ConvBN, take_twin
+from ..nn_norm import FusedBatchNorm2d, ConvBN, conv_bn_act, take_twin
 from ..util.generateFeature import joint2offset, offset2joint_softmax
 from .. import ops as _ops
 from ..streams import fork
@@ -65,6 +65,20 @@ def _head(seq, x):
     torch runs a mean reduction, a hipBLASLt GEMM and five backward launches for a 32 x 512 x 62 product), the modules themselves elsewhere"""
     out = _ops.pool_linear(x, seq[2]) if (len(seq) == 3 and isinstance(seq[2], nn.Linear) and isinstance(seq[0], nn.AdaptiveAvgPool2d)) else None
     return out if out is not None else seq(x)
+
+
+def _stem(seq, x):
+    """``pre`` = Sequential(Conv2d, BatchNorm, ReLU slot, MaxPool2d) (reference model/backbone.py:200-204): in training the BatchNorm's
+    apply pass writes the POOLED map only and the pooling's backward runs inside the BatchNorm backward
+    (FusedBatchNorm2d.forward_pooled; the 134 MB full-resolution output and its gradient never exist); the modules themselves elsewhere"""
+    if len(seq) == 4 and isinstance(seq[1], FusedBatchNorm2d) and seq[1].fuse_relu and isinstance(seq[2], nn.Identity) \
+            and isinstance(seq[3], nn.MaxPool2d) and seq[1].training:
+        mp = seq[3]
+        geom = [v if isinstance(v, int) else (v[0] if v[0] == v[1] else None)
+                for v in (mp.kernel_size, mp.stride if mp.stride is not None else mp.kernel_size, mp.padding, mp.dilation)]
+        if None not in geom and geom[3] == 1 and not mp.ceil_mode and not mp.return_indices:
+            return conv_bn_act(seq[0], seq[1], x, pool=(geom[0], geom[1], geom[2], mp))
+    return seq(x)
 
 
 def convtranspose_bn_relu(cin, cout, kernel, L):
@@ -150,7 +164,7 @@ class MANO_OCR(_TwoBranchNet):
         self.init_weights()
 
     def forward(self, img):
-        _, _, pix, mano = self._run_trunk(self.pre(img), '')
+        _, _, pix, mano = self._run_trunk(_stem(self.pre, img), '')
         return [[pix, mano]]
 
 
@@ -175,7 +189,7 @@ class MANO_OCR_stage(_TwoBranchNet):
         self.init_weights()
 
     def forward(self, img, render=None, center=None, cube=None, M=None):
-        c0 = self.pre(img)
+        c0 = _stem(self.pre, img)
         if not self.refine:
             _, feat, pix, mano = self._run_trunk(c0, '')
             return [[pix, mano]]
@@ -201,6 +215,6 @@ class MANO_OCR_stage(_TwoBranchNet):
         return [[pix, mano], [pix2, mano2]]
 
     def encoder(self, img):
-        c0 = self.pre(img)
+        c0 = _stem(self.pre, img)
         c4, _, pix, _ = self._run_trunk(c0, '')
         return self.pool(c4).squeeze(), offset2joint_softmax(pix, img, 0.8)

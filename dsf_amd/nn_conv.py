@@ -152,6 +152,7 @@ class AffineRequest:
 
 
 STATS = None
+C1_STATS = [os.environ.get("DSF_C1_STATS", "1") == "1"]     # the 1-channel stem kernels serve a StatsRequest too (0: the BatchNorm reduces itself)
 
 
 def _fwd_x6(x, image, bias, out_hw, Co, KH, KW, stride, pad, dil=1):
@@ -290,6 +291,14 @@ def _fwd_c1(x, wk, bias, out_hw, Co, K, stride, pad):
     if RECORD is not None:
         RECORD.append(("c1_fwd", B, Hi, Wi, 1, Ho, Wo, Co, K, K, stride, 1, pad, pad))
     y = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=CL)
+    req = STATS
+    if isinstance(req, StatsRequest) and req.acc is not None and bias is None and B > 0 and C1_STATS[0] and not L.deterministic():
+        # the BatchNorm behind the stem asked for its batch statistics: lane = channel, the sums ride in two registers
+        check(L.lib().dsf_conv_c1_forward_bn_acc(ptr_nhwc(x), ptr(wk), ptr_nhwc(y), I(B), I(Hi), I(Wi), I(Ho), I(Wo), I(Co), I(K), I(stride),
+                                                 I(pad), ptr(req.acc), I(int(L.lib().dsf_bn_acc_rows())), stream_ptr()),
+              "dsf_conv_c1_forward_bn_acc")
+        req.filled = 1
+        return y
     check(L.lib().dsf_conv_c1_forward(ptr_nhwc(x), ptr(wk), ptr(bias), ptr_nhwc(y), I(B), I(Hi), I(Wi), I(Ho), I(Wo), I(Co), I(K),
                                       I(stride), I(pad), stream_ptr()), "dsf_conv_c1_forward")
     return y

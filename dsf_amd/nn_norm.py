@@ -101,6 +101,8 @@ def stat_floats(module, applications=1):
 # and the backward receives the two gradients separately: its sums pass adds them on the fly (dsf_bn_backward_acc_pair).
 # DSF_BN_TWIN=0: one output, autograd adds.
 TWIN = [os.environ.get("DSF_BN_TWIN", "1") == "1"]
+# DSF_BN_POOL=0: the stem's BatchNorm + ReLU and MaxPool2d run as separate layers (see FusedBatchNorm2d.forward_pooled)
+POOL_FUSED = [os.environ.get("DSF_BN_POOL", "1") == "1"]
 # second application of a layer in one backward pass adds its dgamma / dbeta into the first one's buffers (DSF_BN_AFFINE_ACC=0: off)
 AFFINE_ACCUMULATE = [os.environ.get("DSF_BN_AFFINE_ACC", "1") == "1"]
 _TASK_ID = getattr(torch._C, "_current_graph_task_id", None)         # (private: the id of the running backward pass, -1 outside one)
@@ -120,9 +122,26 @@ def take_twin(x):
 class _BNFunction(Function):
     @staticmethod
     def forward(ctx, x, residual, gamma, beta, running_mean, running_var, eps, momentum, relu, part=None, rows=0, acc=None, acc_filled=0,
-                twin=False):
+                twin=False, pool=None):
         ctx.set_materialize_grads(False)
         x = x.contiguous(memory_format=CL)
+        ctx.pool = pool
+        if pool is not None:
+            # (k, stride, pad) of a MaxPool2d behind BatchNorm + ReLU (the backbone stem, reference model/backbone.py:200-204): the
+            # apply pass writes the POOLED output and the argmax bytes only (forward_pooled checked the preconditions)
+            k, s, p = pool
+            B, C, H, W = x.shape
+            Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+            y = torch.empty((B, C, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=CL)
+            arg = torch.empty((B, Ho, Wo, C), device=x.device, dtype=torch.uint8)
+            mean = torch.empty(C, device=x.device, dtype=torch.float32)
+            invstd = torch.empty(C, device=x.device, dtype=torch.float32)
+            check(L.lib().dsf_bn_relu_pool_forward(_p(x), _p(gamma), _p(beta), I(B), I(H), I(W), I(C), I(k), I(s), I(p), CF(eps), CF(momentum),
+                                                   _p(running_mean), _p(running_var), _p(y), _p(arg), _p(mean), _p(invstd), _p(acc),
+                                                   I(int(acc_filled)), stream_ptr()), "dsf_bn_relu_pool_forward")
+            ctx.save_for_backward(x, None, gamma, beta, mean, invstd, arg)
+            ctx.cfg = (True, False, gamma is not None, beta is not None)
+            return y
         if residual is not None:
             residual = residual.contiguous(memory_format=CL)
         B, C, H, W = x.shape
@@ -147,7 +166,7 @@ class _BNFunction(Function):
                                          I(int(relu)), _p(running_mean), _p(running_var), _p(y), _p(mean), _p(invstd), _p(ws),
                                          stream_ptr()), "dsf_bn_forward")
         # ReLU mask in the backward: recomputed from x when no residual was added (y is then not kept alive for it)
-        ctx.save_for_backward(x, y if (relu and residual is not None) else None, gamma, beta, mean, invstd)
+        ctx.save_for_backward(x, y if (relu and residual is not None) else None, gamma, beta, mean, invstd, None)
         ctx.cfg = (relu, residual is not None, gamma is not None, beta is not None)
         if twin:
             return y, _alias(y)
@@ -156,12 +175,12 @@ class _BNFunction(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, gy, gy2=None):
-        n_in = 14
+        n_in = 15
         if gy is None:
             gy, gy2 = gy2, None
         if gy is None:                                        # neither handle of the output reached the loss
             return (None,) * n_in
-        x, y, gamma, beta, mean, invstd = ctx.saved_tensors
+        x, y, gamma, beta, mean, invstd, arg = ctx.saved_tensors
         relu, has_res, has_g, has_b = ctx.cfg
         relu_mode = 0 if not relu else (1 if has_res else 2)
         gy = gy.contiguous(memory_format=CL)
@@ -189,7 +208,21 @@ class _BNFunction(Function):
                 rec_key = (task, st_now)
         acc = _acc_take(C, x.device)
         gg_w, gb_w = (gg_k, gb_k) if accumulate else (gg, gb)
-        if acc is not None:
+        pooled = ctx.pool is not None and acc is not None
+        if ctx.pool is not None:
+            k, s, p = ctx.pool
+            if pooled:                                        # both passes gather the pooling's backward from the pooled gradient
+                check(L.lib().dsf_bn_relu_pool_backward(_p(x), _p(gy), _p(arg), _p(gamma), _p(beta), _p(mean), _p(invstd), I(B), I(H), I(W),
+                                                        I(C), I(k), I(s), I(p), _p(gx), _p(gg_w), _p(gb_w), I(accumulate), _p(acc),
+                                                        stream_ptr()), "dsf_bn_relu_pool_backward")
+            else:                                             # (the statistics pool ran out between the passes): the two layers' own kernels
+                g_full = torch.empty_like(x, memory_format=CL)
+                check(L.lib().dsf_maxpool_backward(_p(gy), _p(arg), _p(g_full), I(B), I(H), I(W), I(C), I(gy.shape[2]), I(gy.shape[3]), I(k),
+                                                   I(s), I(p), stream_ptr()), "dsf_maxpool_backward")
+                gy = g_full
+        if pooled:
+            pass
+        elif acc is not None:
             check(L.lib().dsf_bn_backward_acc_pair(_p(x), _p(gy), _p(gy2), _p(y), _p(gamma), _p(beta), _p(mean), _p(invstd), I64(M), I(C),
                                                    I(relu_mode), _p(gx), _p(gres_out), _p(gg_w), _p(gb_w), I(accumulate), _p(acc), stream_ptr()),
                   "dsf_bn_backward_acc_pair")
@@ -263,6 +296,25 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
     def _load_from_state_dict(self, *args, **kwargs):
         self._pending_batches = 0
         super()._load_from_state_dict(*args, **kwargs)
+
+    def forward_pooled(self, x, k, stride, pad, stats=None):
+        """MaxPool2d(k, stride, pad)(relu(bn(x))) of a training-mode layer as ONE apply pass that writes the pooled map only, with the
+        pooling's backward inside the BatchNorm backward (dsf_bn_relu_pool_forward / _backward; the backbone stem, reference
+        model/backbone.py:200-204).  None when this call cannot take that path -- the caller then runs the separate layers."""
+        if not (POOL_FUSED[0] and type(self) is FusedBatchNorm2d and self.training and self.track_running_stats and self.momentum is not None
+                and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.numel() and supported(x.shape[1])
+                and k in (2, 3) and k <= 2 * stride and 0 <= 2 * pad <= k and x.numel() // 4 < 2 ** 31
+                and min(x.shape[2], x.shape[3]) + 2 * pad >= k):
+            return None
+        # stats = ("acc", rows block, filled): the block a producing convolution was handed for its epilogue (conv_bn_act's protocol)
+        acc, filled = (stats[1], stats[2]) if stats is not None else (_acc_take(x.shape[1], x.device), 0)
+        if acc is None:                                      # no open statistics pool / deterministic mode
+            return None
+        if self._buffers.get("num_batches_tracked") is not None:
+            self._pending_batches += 1
+        self.__dict__["_stats_epoch"] = self.__dict__.get("_stats_epoch", 0) + 1
+        return _BNFunction.apply(x, None, self.weight, self.bias, self.running_mean, self.running_var, self.eps, self.momentum, True, None, 0,
+                                 acc, filled, False, (k, stride, pad))
 
     def forward(self, x, residual=None, relu=None, stats=None, twin=False):
         """``twin=True`` (training path only): the output also carries a second handle ``y._dsf_twin`` for a consumer that reads it
@@ -438,7 +490,15 @@ EPILOGUE_STATS = [os.environ.get("DSF_BN_EPILOGUE", "1") == "1"]
 EPILOGUE_AFFINE = [os.environ.get("DSF_BN_EPILOGUE", "1") == "1"]
 
 
-def conv_bn_act(conv, bn, x, residual=None, relu=None, twin=False):
+def _pooled(bn, y, pool, stats=None):
+    """MaxPool2d(relu(bn(y))) for conv_bn_act's ``pool`` = (k, stride, pad, the MaxPool2d module): the pooled apply pass when the
+    layer takes it (forward_pooled), the BatchNorm and the pooling module one after the other otherwise"""
+    out = bn.forward_pooled(y, pool[0], pool[1], pool[2], stats=stats) if isinstance(bn, FusedBatchNorm2d) and bn.fuse_relu else None
+    return out if out is not None else pool[3](bn_act(bn, y, None, getattr(bn, "fuse_relu", False), False) if stats is None
+                                               else bn(y, None, None, stats=stats))
+
+
+def conv_bn_act(conv, bn, x, residual=None, relu=None, twin=False, pool=None):
     """``bn(conv(x))`` (+ residual) (relu).  Both this package's HIP layers, training mode: the BatchNorm batch statistics
     come from the convolution's epilogue (one pass over the convolution output less, two launches instead of three).
     Evaluation mode without autograd: the whole frozen-statistics BatchNorm (+ residual)(+ ReLU) rides in the convolution's
@@ -446,7 +506,7 @@ def conv_bn_act(conv, bn, x, residual=None, relu=None, twin=False):
     from . import nn_conv
     ours = isinstance(bn, FusedBatchNorm2d) and isinstance(conv, (nn_conv.Conv2d, nn_conv.ConvTranspose2d)) and x.is_cuda
     if (ours and EPILOGUE_AFFINE[0] and not bn.training and bn.track_running_stats and supported(bn.num_features) and
-            x.dtype == torch.float32 and nn_conv.STATS is None and not torch.is_grad_enabled()):
+            x.dtype == torch.float32 and nn_conv.STATS is None and not torch.is_grad_enabled() and pool is None):
         r = bn.fuse_relu if relu is None else relu
         scale, shift = bn.folded_affine()
         res = residual.contiguous(memory_format=CL) if residual is not None else None
@@ -460,6 +520,8 @@ def conv_bn_act(conv, bn, x, residual=None, relu=None, twin=False):
     fusable = (EPILOGUE_STATS[0] and isinstance(bn, FusedBatchNorm2d) and isinstance(conv, (nn_conv.Conv2d, nn_conv.ConvTranspose2d)) and bn.training and
                bn.track_running_stats and conv.bias is None and x.is_cuda and supported(bn.num_features) and nn_conv.STATS is None)
     if not fusable:
+        if pool is not None:
+            return _pooled(bn, conv(x), pool)
         return bn_act(bn, conv(x), residual, relu if relu is not None else getattr(bn, "fuse_relu", False), twin)
     req = nn_conv.StatsRequest()
     # finalise-free path: the epilogue adds into these zeroed rows (a cross-replica BatchNorm exchanges ordered partial rows instead)
@@ -469,6 +531,8 @@ def conv_bn_act(conv, bn, x, residual=None, relu=None, twin=False):
         y = conv(x)
     finally:
         nn_conv.STATS = None
+    if pool is not None:                                     # (the stem: no residual, the layer's own ReLU; see model/backbone.py _stem)
+        return _pooled(bn, y, pool, ("acc", req.acc, req.filled) if req.acc is not None else None)
     if req.acc is not None:
         return bn(y, residual, relu, stats=("acc", req.acc, req.filled), twin=twin)
     return bn(y, residual, relu, stats=(req.part, req.rows) if req.rows else None, twin=twin)

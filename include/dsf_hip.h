@@ -382,6 +382,11 @@ int dsf_conv_co1_forward(const float* X, const float* W, const float* bias, floa
 int64_t dsf_conv_c1_workspace_bytes(int KH, int KW);
 int dsf_conv_c1_forward(const float* X, const float* W, const float* bias, float* Y, int B, int Hi, int Wi, int Ho, int Wo, int Co,
                         int K, int stride, int pad, dsf_stream_t stream);
+/* dsf_conv_c1_forward (no bias) that also ADDS the per-channel sum and sum of squares of Y, as doubles, into the zeroed block
+ * acc [acc_rows][2][Co] (dsf_bn_acc_rows() rows): the batch statistics of the BatchNorm behind the stem convolution, consumed by
+ * dsf_bn_forward_acc / dsf_bn_relu_pool_forward with acc_filled = 1 (ABI 5).  Deterministic mode: DSF_ERR_UNSUPPORTED. */
+int dsf_conv_c1_forward_bn_acc(const float* X, const float* W, float* Y, int B, int Hi, int Wi, int Ho, int Wo, int Co, int K, int stride,
+                               int pad, double* acc, int acc_rows, dsf_stream_t stream);
 int dsf_conv_c1_wrw(const float* X, const float* dY, float* dW, float* workspace, int B, int Hi, int Wi, int Ho, int Wo, int Co,
                     int K, int stride, int pad, int accumulate, dsf_stream_t stream);
 
@@ -585,6 +590,27 @@ int dsf_bn_backward_acc_pair(const float* x, const float* grad_y, const float* g
                              const float* beta, const float* save_mean, const float* save_invstd, int64_t M, int C, int relu,
                              float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta, int accumulate_affine,
                              double* acc, dsf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * The backbone stem's BatchNorm -> ReLU -> MaxPool2d(k, stride, pad) (reference model/backbone.py:200-204: nn.BatchNorm2d(64),
+ * nn.ReLU, nn.MaxPool2d(3, 2, 1) on the B x 64 x 128 x 128 map) as one training-mode layer (ABI 5; csrc/norm.hip).
+ * Forward: batch statistics of x [B, Hi, Wi, C] into the zeroed accumulation block `acc` (acc_filled = 1: they are there already,
+ * left by dsf_conv_c1_forward_bn_acc / dsf_conv_x6_forward_bn_acc -- no statistics pass), then ONE apply pass that writes the pooled
+ * output y [B, Ho, Wo, C], the 1-byte window position of each maximum (dsf_maxpool_forward's rule) and save_mean / save_invstd, and
+ * updates the running statistics; the full-resolution normalised map is never written.  Backward: both BatchNorm backward passes
+ * gather the gradient of a full-resolution element from the pooled gradient grad_y (dsf_maxpool_backward's terms in its order: the
+ * same bits) and recompute the ReLU mask from x; `acc` is a second zeroed block.  Results equal dsf_bn_forward_acc(relu = 1) +
+ * dsf_maxpool_forward resp. dsf_maxpool_backward + dsf_bn_backward_acc(relu = 2) bit for bit (grad_x, grad_gamma, grad_beta up to the
+ * order of the double-precision atomic sums, as for those entries).  k in {2, 3}, k <= 2 stride, 2 pad <= k, C % 4 == 0 with C / 4 dividing 256 or a multiple of it,
+ * B Hi Wi C / 4 < 2^31; anything else (and the deterministic mode) DSF_ERR_UNSUPPORTED: run the separate layers.
+ * ------------------------------------------------------------------------------------ */
+int dsf_bn_relu_pool_forward(const float* x, const float* gamma, const float* beta, int B, int Hi, int Wi, int C, int k, int stride,
+                             int pad, float eps, float momentum, float* running_mean, float* running_var, float* y, uint8_t* argmax,
+                             float* save_mean, float* save_invstd, double* acc, int acc_filled, dsf_stream_t stream);
+int dsf_bn_relu_pool_backward(const float* x, const float* grad_y, const uint8_t* argmax, const float* gamma, const float* beta,
+                              const float* save_mean, const float* save_invstd, int B, int Hi, int Wi, int C, int k, int stride, int pad,
+                              float* grad_x, float* grad_gamma, float* grad_beta, int accumulate_affine, double* acc,
+                              dsf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Loss-side glue of the trainer steps, one launch (pair) per term (round 6; csrc/step_ops.hip).  The reference writes each of

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), "libdsf_hip.so lacks %s" % s
     assert sorted(_lib.SYMBOLS) == declared
     lib.dsf_abi_version.restype = ctypes.c_int
-    assert lib.dsf_abi_version() == _lib.EXPECTED_ABI == 4
+    assert lib.dsf_abi_version() == _lib.EXPECTED_ABI == 5
     lib.dsf_status_string.restype = ctypes.c_char_p
     assert lib.dsf_status_string(2) == b"unsupported configuration"
 
