@@ -147,6 +147,119 @@ __global__ __launch_bounds__(256) void conv_c1_wrw_kernel(const float* __restric
     }
 }
 
+// ---- backward of the stem: BatchNorm(+ReLU)(+MaxPool2d) backward apply AND the convolution's dW in one launch ----------------------
+// Behind a 1-channel convolution nobody needs the gradient of the convolution's OUTPUT except the dW sum above: the BatchNorm
+// backward's apply pass writes 134 MB (B = 32) that conv_c1_wrw_kernel reads back once.  Here conv_c1_wrw_kernel's wave -- lane =
+// channel, row segments of 8 pixels -- computes that gradient in registers instead of loading it: per pixel the saved convolution
+// output y, the incoming gradient (POOL 0: the BatchNorm output's gradient, one coalesced load; POOL 1 / 2: gathered from the POOLED
+// gradient through the argmax bytes of MaxPool2d(3, 2, 1) / (2, 2, 0), norm.hip's bn_pool_gather terms in their order), the ReLU
+// mask recomputed from y, and norm.hip's bn_bwd_apply_kernel expression, operation for operation: dW is bit for bit what the two
+// launches produce.  The channel sums come from the accumulation rows a sums-only pass left (folded per wave: 16 doubles per lane);
+// workgroup 0 stores dgamma / dbeta.  A segment's pooled neighbourhood is 2 rows x 5 columns: 10 (byte, float) loads per lane, all
+// issued before the first use; the window position a pixel has in a pooled column is a compile-time function of (pixel, column).
+struct C1Bn { const float* gamma; const float* beta; const float* mean; const float* invstd; const double* rows; int n_rows; int relu;
+              float* dgamma; float* dbeta; int accum; int PHo, PWo; };
+
+template <int K, int S, int POOL>
+__global__ __launch_bounds__(256) void conv_c1_wrw_bn_kernel(const float* __restrict__ X, const float* __restrict__ Yc, const float* __restrict__ G,
+                                                             const uint8_t* __restrict__ arg, float* __restrict__ part, C1P p, C1Bn n,
+                                                             int segs_per_row, int64_t n_segs) {
+    constexpr int NIN = (PX - 1) * S + K;
+    constexpr int PK = (POOL == 1) ? 3 : 2, PP = (POOL == 1) ? 1 : 0;                         // pooling window, padding
+    constexpr int NPR = (POOL == 1) ? 2 : 1, NPC = (POOL == 1) ? PX / 2 + 1 : PX / 2;         // pooled rows / columns a segment's pixels sit in
+    __shared__ float red[4][K * K][64];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wv, n_waves = (int64_t)gridDim.x * 4;
+    const bool c_ok = lane < p.Co;
+    const int ch = c_ok ? lane : 0;
+    double f0 = 0.0, f1 = 0.0;
+    for (int r = 0; r < n.n_rows; ++r) { f0 += n.rows[(int64_t)r * 2 * p.Co + ch]; f1 += n.rows[(int64_t)r * 2 * p.Co + p.Co + ch]; }
+    if (blockIdx.x == 0 && wv == 0 && c_ok) {
+        if (n.dbeta) n.dbeta[lane] = (n.accum ? n.dbeta[lane] : 0.f) + (float)f0;
+        if (n.dgamma) n.dgamma[lane] = (n.accum ? n.dgamma[lane] : 0.f) + (float)f1;
+    }
+    const float invM = 1.0f / (float)((int64_t)p.B * p.Ho * p.Wo);
+    const float mu = n.mean[ch], is = n.invstd[ch], m0 = (float)f0 * invM, m1 = (float)f1 * invM;
+    const float sc = (n.gamma ? n.gamma[ch] : 1.f) * is, sh = n.beta ? n.beta[ch] : 0.f;
+    float acc[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) acc[i] = 0.f;
+    for (int64_t seg = wave; seg < n_segs; seg += n_waves) {
+        const int sx = (int)(seg % segs_per_row);
+        const int64_t row = seg / segs_per_row;
+        const int oy = (int)(row % p.Ho), b = (int)(row / p.Ho);
+        const int ox0 = sx * PX, ix0 = ox0 * S - p.pad;
+        float yv[PX], g[PX];
+        const int64_t o0 = (((int64_t)b * p.Ho + oy) * p.Wo + ox0) * p.Co + lane;
+#pragma unroll
+        for (int q = 0; q < PX; ++q) yv[q] = (c_ok && ox0 + q < p.Wo) ? Yc[o0 + (int64_t)q * p.Co] : 0.f;
+        if (POOL == 0) {
+#pragma unroll
+            for (int q = 0; q < PX; ++q) g[q] = (c_ok && ox0 + q < p.Wo) ? G[o0 + (int64_t)q * p.Co] : 0.f;
+        } else {
+            // pooled rows pr0 (, pr0 + 1) and columns pc0 .. pc0 + NPC - 1 (ox0 is a multiple of 8): pixel (oy, ox0 + q) sits at window
+            // position (oy - (2 pr - PP), q - 2 j + PP) of pooled pixel (pr, pc0 + j) when that position lies inside the window
+            const int pr0 = (oy + PP - PK + 2) >> 1, pc0 = ox0 >> 1;
+            float gp[NPR][NPC]; int ap[NPR][NPC]; int kh[NPR];
+#pragma unroll
+            for (int i = 0; i < NPR; ++i) {
+                const int pr = pr0 + i;
+                const int k = oy - (2 * pr - PP);
+                kh[i] = (k >= 0 && k < PK && pr >= 0 && pr < n.PHo) ? k : -1;
+                const int prc = min(max(pr, 0), n.PHo - 1);
+#pragma unroll
+                for (int j = 0; j < NPC; ++j) {
+                    const int64_t o = (((int64_t)b * n.PHo + prc) * n.PWo + min(pc0 + j, n.PWo - 1)) * p.Co + ch;
+                    gp[i][j] = G[o]; ap[i][j] = arg[o];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < PX; ++q) {
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < NPR; ++i)                   // (rows, then columns: maxpool_bwd_kernel's order)
+#pragma unroll
+                    for (int j = 0; j < NPC; ++j) {
+                        const int kw = q - 2 * j + PP;          // compile-time
+                        if (kw < 0 || kw >= PK) continue;
+                        const int me = (kh[i] >= 0 && pc0 + j < n.PWo) ? kh[i] * PK + kw : 255;
+                        s += (ap[i][j] == me) ? gp[i][j] : 0.f;
+                    }
+                g[q] = (c_ok && ox0 + q < p.Wo) ? s : 0.f;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PX; ++q) {                          // bn_bwd_apply_kernel's arithmetic (relu mode 2)
+            float ge = g[q];
+            if (n.relu) ge = ((yv[q] - mu) * sc + sh > 0.f) ? ge : 0.f;
+            const float xh = (yv[q] - mu) * is;
+            const float d = sc * (ge - m0 - xh * m1);
+            g[q] = (c_ok && ox0 + q < p.Wo) ? d : 0.f;
+        }
+        float v[K];
+#pragma unroll
+        for (int kh2 = 0; kh2 < K; ++kh2) v[kh2] = c1_row<K, S>(X, p, b, oy * S + kh2 - p.pad, ix0, lane);
+#pragma unroll
+        for (int kh2 = 0; kh2 < K; ++kh2) {
+            float xs[NIN];
+#pragma unroll
+            for (int j = 0; j < NIN; ++j) xs[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[kh2]), j));
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+                for (int q = 0; q < PX; ++q) acc[kh2 * K + kw] = fmaf(xs[q * S + kw], g[q], acc[kh2 * K + kw]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) red[wv][i][lane] = acc[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * K * 64; i += 256) {
+        const int t = i >> 6, c = i & 63;
+        part[(int64_t)blockIdx.x * (K * K * 64) + i] = (red[0][t][c] + red[1][t][c]) + (red[2][t][c] + red[3][t][c]);
+    }
+}
+
 // one workgroup per tap: lane = channel, the SIXTEEN waves take every sixteenth partial (round 6: four waves walked 512 partials each,
 // four loads in flight -- 44 us at the very end of the backward pass); fixed order, double accumulation
 __global__ __launch_bounds__(1024) void conv_c1_wrw_combine_kernel(const float* __restrict__ part, int n_part, int taps, int Co,
@@ -279,6 +392,33 @@ int dsf_conv_c1_forward_bn_acc(const float* X, const float* W, float* Y, int B, 
     if (K == 5) { if (stride == 1) DSF_LAUNCH_C1(5, 1); else DSF_LAUNCH_C1(5, 2); }
     else { if (stride == 1) DSF_LAUNCH_C1(7, 1); else DSF_LAUNCH_C1(7, 2); }
 #undef DSF_LAUNCH_C1
+    return dsf_launch_status();
+}
+
+int dsf_conv_c1_wrw_bn(const float* X, const float* Y, const float* grad, const uint8_t* argmax, const float* gamma, const float* beta,
+                       const float* save_mean, const float* save_invstd, const double* acc, int acc_rows, int relu, int pool_k, int pool_stride,
+                       int pool_pad, float* dW, float* grad_gamma, float* grad_beta, int accumulate_affine, float* workspace, int B, int Hi,
+                       int Wi, int Ho, int Wo, int Co, int K, int stride, int pad, dsf_stream_t stream) {
+    DSF_CHECK_ARG(X && Y && grad && save_mean && save_invstd && acc && acc_rows >= 1 && dW && workspace && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 &&
+                  Wo > 0 && pad >= 0 && (pool_k == 0 || argmax));
+    if (!c1_ok(Co, K, stride)) return DSF_ERR_UNSUPPORTED;
+    const int pool = pool_k == 0 ? 0 : ((pool_k == 3 && pool_stride == 2 && pool_pad == 1) ? 1 : ((pool_k == 2 && pool_stride == 2 && pool_pad == 0) ? 2 : -1));
+    if (pool < 0) return DSF_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    C1P p = {B, Hi, Wi, Ho, Wo, Co, pad};
+    C1Bn n = {gamma, beta, save_mean, save_invstd, acc, acc_rows, relu, grad_gamma, grad_beta, accumulate_affine,
+              pool ? (Ho + 2 * pool_pad - pool_k) / pool_stride + 1 : 0, pool ? (Wo + 2 * pool_pad - pool_k) / pool_stride + 1 : 0};
+    if (pool && (n.PHo <= 0 || n.PWo <= 0)) return DSF_ERR_UNSUPPORTED;
+    const int spr = (Wo + PX - 1) / PX;
+    const int64_t n_segs = (int64_t)B * Ho * spr;
+    int wgs = (int)((n_segs + 3) / 4 < C1_WRW_WGS ? (n_segs + 3) / 4 : C1_WRW_WGS);
+#define DSF_LAUNCH_C1B(Kv, Sv, Pv) hipLaunchKernelGGL((conv_c1_wrw_bn_kernel<Kv, Sv, Pv>), dim3(wgs), dim3(256), 0, st, X, Y, grad, argmax, workspace, p, n, spr, n_segs)
+#define DSF_LAUNCH_C1B_P(Kv, Sv) do { if (pool == 0) DSF_LAUNCH_C1B(Kv, Sv, 0); else if (pool == 1) DSF_LAUNCH_C1B(Kv, Sv, 1); else DSF_LAUNCH_C1B(Kv, Sv, 2); } while (0)
+    if (K == 5) { if (stride == 1) DSF_LAUNCH_C1B_P(5, 1); else DSF_LAUNCH_C1B_P(5, 2); }
+    else { if (stride == 1) DSF_LAUNCH_C1B_P(7, 1); else DSF_LAUNCH_C1B_P(7, 2); }
+#undef DSF_LAUNCH_C1B_P
+#undef DSF_LAUNCH_C1B
+    hipLaunchKernelGGL(conv_c1_wrw_combine_kernel, dim3(K * K), dim3(1024), 0, st, workspace, wgs, K * K, Co, 0, dW);
     return dsf_launch_status();
 }
 

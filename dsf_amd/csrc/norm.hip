@@ -1290,8 +1290,18 @@ static int bn_backward_acc_impl(const float* x, const float* grad_y, const float
 extern "C" int dsf_bn_backward_acc(const float* x, const float* grad_y, const float* y, const float* gamma, const float* beta,
                                    const float* save_mean, const float* save_invstd, int64_t M, int C, int relu, float* grad_x,
                                    float* grad_residual, float* grad_gamma, float* grad_beta, double* acc, dsf_stream_t stream) {
-    DSF_CHECK_ARG(x && grad_y && save_mean && save_invstd && grad_x && acc && M > 0 && relu >= 0 && relu <= 2 && (relu != 1 || y));
+    DSF_CHECK_ARG(x && grad_y && save_mean && save_invstd && acc && M > 0 && relu >= 0 && relu <= 2 && (relu != 1 || y));
     if (!bn_shape_ok(C) || dsf_deterministic()) return DSF_ERR_UNSUPPORTED;
+    if (!grad_x) {                                                    // sums only (dsf_conv_c1_wrw_bn applies them); not on the one-launch small maps
+        if (bn_small_ok(M, C) || grad_residual) return DSF_ERR_UNSUPPORTED;
+        const char* wg_e = getenv("DSF_BN_BWD_WGS");
+        int max_wgs = wg_e ? atoi(wg_e) : 1024;
+        if (max_wgs < 1) max_wgs = 1024;
+        const int rows = bn_rows_per_wg(M, C, max_wgs);
+        bn_launch_bwd_reduce(dim3((unsigned)((M + rows - 1) / rows), bn_col_blocks(C)), (hipStream_t)stream, x, grad_y, nullptr, y, save_mean, save_invstd,
+                             gamma, beta, M, C, relu, rows, reinterpret_cast<float*>(acc), BN_ACC_ROWS, nullptr);
+        return dsf_launch_status();
+    }
     return bn_backward_acc_impl(x, grad_y, nullptr, y, gamma, beta, save_mean, save_invstd, M, C, relu, grad_x, grad_residual, grad_gamma,
                                 grad_beta, acc, (hipStream_t)stream);
 }
@@ -1341,7 +1351,7 @@ extern "C" int dsf_bn_relu_pool_backward(const float* x, const float* grad_y, co
                                          const float* save_mean, const float* save_invstd, int B, int Hi, int Wi, int C, int k, int stride,
                                          int pad, float* grad_x, float* grad_gamma, float* grad_beta, int accumulate_affine, double* acc,
                                          dsf_stream_t stream) {
-    DSF_CHECK_ARG(x && grad_y && argmax && save_mean && save_invstd && grad_x && acc);
+    DSF_CHECK_ARG(x && grad_y && argmax && save_mean && save_invstd && acc);
     int Ho, Wo;
     if (!bn_pool_ok(B, Hi, Wi, C, k, stride, pad, &Ho, &Wo) || dsf_deterministic()) return DSF_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
@@ -1355,6 +1365,7 @@ extern "C" int dsf_bn_relu_pool_backward(const float* x, const float* grad_y, co
     BnFinal fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, grad_gamma, grad_beta, accumulate_affine};
     hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(wgs, bn_col_blocks(C)), dim3(256), 0, st, x, grad_y, argmax, save_mean, save_invstd, gamma,
                        beta, M, C, rows, acc, BN_ACC_ROWS, p);
+    if (!grad_x) return dsf_launch_status();                          // sums only: dsf_conv_c1_wrw_bn takes it from here
     hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(bn_apply_grid(n4, C)), dim3(256), 0, st, x, grad_y, argmax, save_mean, save_invstd, gamma,
                        beta, M, n4, C, grad_x, acc, BN_ACC_ROWS, fin, p);
     return dsf_launch_status();

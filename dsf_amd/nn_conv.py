@@ -657,6 +657,18 @@ def _wrw_dispatch(weight, fn_new, fn_add, held, work=None):
     return fn_new()
 
 
+def main_stream_weight_grad(weight):
+    """Bookkeeping of a contribution to ``weight``'s gradient that the CALLER launches on the current stream (nn_norm._StemFunction):
+    _wrw_dispatch's main-stream branch without the launch -- a later contribution of this backward pass stays on the main stream too,
+    and one that is still running on the side stream is joined first."""
+    task = torch._C._current_graph_task_id() if SIDE_API else -1
+    rec = weight.__dict__.get("_dsf_pass")
+    if task >= 0:
+        if rec is not None and rec[0] == task:
+            join_side_streams()
+        weight.__dict__["_dsf_pass"] = (task, None)
+
+
 def _side_ok(weight):
     if not (WRW_STREAM[0] and weight.is_leaf and weight.grad is None and not weight._backward_hooks):
         return False
@@ -866,6 +878,28 @@ def replay(rec, iters=3):
     elif kind == "c1_wrw":
         gy = torch.randn(B, Co, Ho, Wo, device=dev).contiguous(memory_format=CL)
         run = lambda: _wrw_c1(x, gy, KH, stride, ph)
+    elif kind == "c1_fwd_bn":                                # nn_norm._StemFunction's forward convolution (statistics in the epilogue)
+        wk = torch.randn(KH, KW, 1, Co, device=dev)
+        y = torch.empty((B, Co, Ho, Wo), device=dev, dtype=torch.float32, memory_format=CL)
+        rows = int(L.lib().dsf_bn_acc_rows())
+        acc = torch.zeros(rows * 2 * Co, device=dev, dtype=torch.float64)
+        run = lambda: check(L.lib().dsf_conv_c1_forward_bn_acc(ptr_nhwc(x), ptr(wk), ptr_nhwc(y), I(B), I(Hi), I(Wi), I(Ho), I(Wo), I(Co), I(KH),
+                                                               I(stride), I(ph), ptr(acc), I(rows), stream_ptr()), "dsf_conv_c1_forward_bn_acc")
+    elif kind.startswith("c1_wrw_bn"):                       # ... and its backward launch (BatchNorm apply arithmetic + dW), pooling mode in the name
+        k, s, p = {"0": (0, 0, 0), "1": (3, 2, 1), "2": (2, 2, 0)}[kind[-1]]
+        y = torch.randn(B, Co, Ho, Wo, device=dev).contiguous(memory_format=CL)
+        Po, Qo = ((Ho + 2 * p - k) // s + 1, (Wo + 2 * p - k) // s + 1) if k else (Ho, Wo)
+        g = torch.randn(B, Co, Po, Qo, device=dev).contiguous(memory_format=CL)
+        arg = torch.randint(0, max(k * k, 1), (B, Po, Qo, Co), device=dev, dtype=torch.uint8)
+        vec = [torch.rand(Co, device=dev) + 0.5 for _ in range(4)]
+        rows = int(L.lib().dsf_bn_acc_rows())
+        acc = torch.randn(rows * 2 * Co, device=dev, dtype=torch.float64)
+        dw, gg, gb = torch.empty(KH * KW * Co, device=dev), torch.empty(Co, device=dev), torch.empty(Co, device=dev)
+        ws = torch.empty(L.lib().dsf_conv_c1_workspace_bytes(I(KH), I(KW)) // 4, device=dev, dtype=torch.float32)
+        run = lambda: check(L.lib().dsf_conv_c1_wrw_bn(ptr_nhwc(x), ptr_nhwc(y), ptr_nhwc(g), ptr(arg) if k else None, ptr(vec[0]), ptr(vec[1]),
+                                                       ptr(vec[2]), ptr(vec[3]), ptr(acc), I(rows), I(1), I(k), I(s), I(p), ptr(dw), ptr(gg), ptr(gb),
+                                                       I(0), ptr(ws), I(B), I(Hi), I(Wi), I(Ho), I(Wo), I(Co), I(KH), I(stride), I(ph), stream_ptr()),
+                            "dsf_conv_c1_wrw_bn")
     elif kind == "x6":
         wk = torch.randn(KH, KW, Ci, Co, device=dev)
         img = _x6_image(wk, wk, 0)
@@ -907,6 +941,10 @@ def kernel_name(rec):
     vec = Ci % 4 == 0 and Co % 4 == 0
     if kind in ("c1_fwd", "c1_wrw"):
         return "conv_c1_%s_kernel<%d, %d>" % (kind[3:], rec[8], rec[10])
+    if kind == "c1_fwd_bn":
+        return "conv_c1_fwd_stats_kernel<%d, %d>" % (rec[8], rec[10])
+    if kind.startswith("c1_wrw_bn"):
+        return "conv_c1_wrw_bn_kernel<%d, %d, %s>" % (rec[8], rec[10], kind[-1])
     if kind == "co1_fwd":
         return "conv_co1_fwd_kernel<%d>" % rec[8]
     if kind == "x6":

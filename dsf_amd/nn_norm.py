@@ -297,6 +297,12 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
         self._pending_batches = 0
         super()._load_from_state_dict(*args, **kwargs)
 
+    def _count_training_batch(self):
+        """bookkeeping of a training-mode pass whose kernels rewrite the running statistics through raw pointers (see forward)"""
+        if self._buffers.get("num_batches_tracked") is not None:
+            self._pending_batches += 1
+        self.__dict__["_stats_epoch"] = self.__dict__.get("_stats_epoch", 0) + 1
+
     def forward_pooled(self, x, k, stride, pad, stats=None):
         """MaxPool2d(k, stride, pad)(relu(bn(x))) of a training-mode layer as ONE apply pass that writes the pooled map only, with the
         pooling's backward inside the BatchNorm backward (dsf_bn_relu_pool_forward / _backward; the backbone stem, reference
@@ -310,9 +316,7 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
         acc, filled = (stats[1], stats[2]) if stats is not None else (_acc_take(x.shape[1], x.device), 0)
         if acc is None:                                      # no open statistics pool / deterministic mode
             return None
-        if self._buffers.get("num_batches_tracked") is not None:
-            self._pending_batches += 1
-        self.__dict__["_stats_epoch"] = self.__dict__.get("_stats_epoch", 0) + 1
+        self._count_training_batch()
         return _BNFunction.apply(x, None, self.weight, self.bias, self.running_mean, self.running_var, self.eps, self.momentum, True, None, 0,
                                  acc, filled, False, (k, stride, pad))
 
@@ -490,6 +494,136 @@ EPILOGUE_STATS = [os.environ.get("DSF_BN_EPILOGUE", "1") == "1"]
 EPILOGUE_AFFINE = [os.environ.get("DSF_BN_EPILOGUE", "1") == "1"]
 
 
+# DSF_C1_BN=0: the stem convolution and its BatchNorm stay two autograd nodes (see _StemFunction)
+C1_BN = [os.environ.get("DSF_C1_BN", "1") == "1"]
+
+
+class _StemFunction(Function):
+    """[1-channel convolution -> BatchNorm (-> ReLU) (-> MaxPool2d)] of a network stem as ONE autograd node (reference
+    model/backbone.py:196-204).  Forward: the convolution's epilogue leaves the batch statistics (dsf_conv_c1_forward_bn_acc), the
+    apply pass normalises (and pools).  Backward: nobody needs the gradient of the convolution OUTPUT except the dW sum, so after the
+    sums pass ONE launch does the BatchNorm backward's apply arithmetic and the dW accumulation (dsf_conv_c1_wrw_bn): the 134 MB
+    gradient is neither written nor read back.  The input must not require a gradient (conv_bn_act checks)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, eps, momentum, relu, stride, pad, pool, acc):
+        from . import nn_conv
+        ctx.set_materialize_grads(False)
+        x = nn_conv._nhwc(x)
+        Co, _, K, _ = weight.shape
+        B, _, Hi, Wi = x.shape
+        Ho, Wo = (Hi + 2 * pad - K) // stride + 1, (Wi + 2 * pad - K) // stride + 1
+        wk = weight.detach().permute(2, 3, 1, 0).contiguous()                  # (a free view: the weight has kernel layout)
+        if nn_conv.RECORD is not None:
+            nn_conv.RECORD.append(("c1_fwd_bn", B, Hi, Wi, 1, Ho, Wo, Co, K, K, stride, 1, pad, pad))
+        y = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=CL)
+        lib = L.lib()
+        check(lib.dsf_conv_c1_forward_bn_acc(_p(x), _p(wk), _p(y), I(B), I(Hi), I(Wi), I(Ho), I(Wo), I(Co), I(K), I(stride), I(pad), _p(acc),
+                                             I(int(lib.dsf_bn_acc_rows())), stream_ptr()), "dsf_conv_c1_forward_bn_acc")
+        mean = torch.empty(Co, device=x.device, dtype=torch.float32)
+        invstd = torch.empty(Co, device=x.device, dtype=torch.float32)
+        arg = None
+        if pool is not None:
+            k, s, p = pool
+            Po, Qo = (Ho + 2 * p - k) // s + 1, (Wo + 2 * p - k) // s + 1
+            out = torch.empty((B, Co, Po, Qo), device=x.device, dtype=torch.float32, memory_format=CL)
+            arg = torch.empty((B, Po, Qo, Co), device=x.device, dtype=torch.uint8)
+            check(lib.dsf_bn_relu_pool_forward(_p(y), _p(gamma), _p(beta), I(B), I(Ho), I(Wo), I(Co), I(k), I(s), I(p), CF(eps), CF(momentum),
+                                               _p(running_mean), _p(running_var), _p(out), _p(arg), _p(mean), _p(invstd), _p(acc), I(1),
+                                               stream_ptr()), "dsf_bn_relu_pool_forward")
+        else:
+            out = torch.empty_like(y, memory_format=CL)
+            check(lib.dsf_bn_forward_acc(_p(y), _p(None), _p(gamma), _p(beta), I64(B * Ho * Wo), I(Co), CF(eps), CF(momentum), I(int(relu)),
+                                         _p(running_mean), _p(running_var), _p(out), _p(mean), _p(invstd), _p(acc), I(1), stream_ptr()),
+                  "dsf_bn_forward_acc")
+        ctx.save_for_backward(x, y, weight, gamma, beta, mean, invstd, arg)
+        ctx.cfg = (bool(relu), stride, pad, pool)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        from . import nn_conv
+        n_in = 13
+        if g is None:
+            return (None,) * n_in
+        x, y, weight, gamma, beta, mean, invstd, arg = ctx.saved_tensors
+        relu, stride, pad, pool = ctx.cfg
+        g = g.contiguous(memory_format=CL)
+        B, Co, Ho, Wo = y.shape
+        _, _, Hi, Wi = x.shape
+        K = weight.shape[2]
+        lib = L.lib()
+        acc = _acc_take(Co, x.device)
+        if acc is None:                                       # (the statistics pool ran out between the passes)
+            acc = torch.zeros(acc_rows() * 2 * Co, device=x.device, dtype=torch.float64)
+        has_g, has_b = gamma is not None, beta is not None
+        gg = torch.empty(Co, device=x.device, dtype=torch.float32) if has_g else None
+        gb = torch.empty(Co, device=x.device, dtype=torch.float32) if has_b else None
+        accumulate, rec_key = 0, None                         # (a second application in one backward pass: see _BNFunction.backward)
+        if has_g and has_b and _TASK_ID is not None and gamma.is_leaf and beta.is_leaf and AFFINE_ACCUMULATE[0]:
+            task, st_now = _TASK_ID(), stream_ptr().value
+            rec = gamma.__dict__.get("_dsf_bnpass")
+            if task >= 0 and rec is not None and rec[0] == task and rec[1] == st_now and rec[2].shape == gg.shape:
+                accumulate, gg_k, gb_k = 1, rec[2], rec[3]
+            elif task >= 0:
+                rec_key = (task, st_now)
+        gg_w, gb_w = (gg_k, gb_k) if accumulate else (gg, gb)
+        # sums pass (no gradient written), then apply + dW in one launch
+        if pool is not None:
+            k, s, p = pool
+            check(lib.dsf_bn_relu_pool_backward(_p(y), _p(g), _p(arg), _p(gamma), _p(beta), _p(mean), _p(invstd), I(B), I(Ho), I(Wo), I(Co),
+                                                I(k), I(s), I(p), _p(None), _p(None), _p(None), I(0), _p(acc), stream_ptr()),
+                  "dsf_bn_relu_pool_backward")
+        else:
+            k = s = p = 0
+            check(lib.dsf_bn_backward_acc(_p(y), _p(g), _p(None), _p(gamma), _p(beta), _p(mean), _p(invstd), I64(B * Ho * Wo), I(Co),
+                                          I(2 if relu else 0), _p(None), _p(None), _p(None), _p(None), _p(acc), stream_ptr()),
+                  "dsf_bn_backward_acc")
+        if nn_conv.RECORD is not None:
+            nn_conv.RECORD.append(("c1_wrw_bn%d" % {0: 0, 3: 1, 2: 2}[k], B, Hi, Wi, 1, Ho, Wo, Co, K, K, stride, 1, pad, pad))
+        nn_conv.main_stream_weight_grad(weight)
+        dw = nn_conv._pool_take(K * K * Co, x.device)
+        dw = dw.view(K, K, 1, Co) if dw is not None else torch.empty((K, K, 1, Co), device=x.device, dtype=torch.float32)
+        ws = torch.empty(lib.dsf_conv_c1_workspace_bytes(I(K), I(K)) // 4, device=x.device, dtype=torch.float32)
+        check(lib.dsf_conv_c1_wrw_bn(_p(x), _p(y), _p(g), _p(arg), _p(gamma), _p(beta), _p(mean), _p(invstd), _p(acc), I(acc_rows()),
+                                     I(int(relu)), I(k), I(s), I(p), _p(dw), _p(gg_w), _p(gb_w), I(accumulate), _p(ws), I(B), I(Hi), I(Wi),
+                                     I(Ho), I(Wo), I(Co), I(K), I(stride), I(pad), stream_ptr()), "dsf_conv_c1_wrw_bn")
+        if accumulate:
+            gg = gb = None
+        elif rec_key is not None:
+            gamma.__dict__["_dsf_bnpass"] = rec_key + (gg, gb)
+            gg, gb = gg.view(Co), gb.view(Co)
+        return (None, dw.permute(3, 2, 0, 1) if ctx.needs_input_grad[1] else None, gg, gb) + (None,) * (n_in - 4)
+
+
+def _stem_node(conv, bn, x, relu, pool):
+    """conv_bn_act's route into _StemFunction, or None: a bias-free 1-channel convolution of this package whose input needs no gradient, a
+    training-mode FusedBatchNorm2d, more than 1024 output pixels, an open statistics pool; pooling (3, 2, 1) or (2, 2, 0) behind a ReLU"""
+    from . import nn_conv
+    if not (C1_BN[0] and nn_conv.C1_STATS[0] and type(bn) is FusedBatchNorm2d and type(conv) is nn_conv.Conv2d and conv.bias is None and
+            not x.requires_grad and x.dim() == 4 and x.dtype == torch.float32 and x.shape[0] > 0 and bn.momentum is not None and
+            conv.weight.dtype == torch.float32 and conv.groups == 1 and tuple(conv.dilation) == (1, 1) and conv.padding_mode == "zeros"):
+        return None
+    s, pd = tuple(conv.stride), tuple(conv.padding)
+    Co, Ci, KH, KW = conv.weight.shape
+    if s[0] != s[1] or pd[0] != pd[1] or Co != bn.num_features or not nn_conv._c1_ok(Ci, Co, KH, KW, s[0], pd):
+        return None
+    Ho, Wo = (x.shape[2] + 2 * pd[0] - KH) // s[0] + 1, (x.shape[3] + 2 * pd[0] - KW) // s[0] + 1
+    if x.shape[0] * Ho * Wo <= 1024 or x.shape[0] * Ho * Wo * (Co // 4) >= 2 ** 31:
+        return None
+    if pool is not None and not (relu and POOL_FUSED[0] and tuple(pool[:3]) in ((3, 2, 1), (2, 2, 0)) and min(Ho, Wo) + 2 * pool[2] >= pool[0]):
+        return None
+    if not conv.weight.permute(2, 3, 1, 0).is_contiguous():
+        nn_conv.kernel_layout_(conv.weight, (2, 3, 1, 0))
+    acc = _acc_take(Co, x.device)
+    if acc is None:
+        return None
+    bn._count_training_batch()
+    return _StemFunction.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, bool(relu), s[0], pd[0],
+                               tuple(pool[:3]) if pool is not None else None, acc)
+
+
 def _pooled(bn, y, pool, stats=None):
     """MaxPool2d(relu(bn(y))) for conv_bn_act's ``pool`` = (k, stride, pad, the MaxPool2d module): the pooled apply pass when the
     layer takes it (forward_pooled), the BatchNorm and the pooling module one after the other otherwise"""
@@ -523,6 +657,10 @@ def conv_bn_act(conv, bn, x, residual=None, relu=None, twin=False, pool=None):
         if pool is not None:
             return _pooled(bn, conv(x), pool)
         return bn_act(bn, conv(x), residual, relu if relu is not None else getattr(bn, "fuse_relu", False), twin)
+    if residual is None and not twin:
+        out = _stem_node(conv, bn, x, bn.fuse_relu if relu is None else relu, pool)
+        if out is not None:
+            return out
     req = nn_conv.StatsRequest()
     # finalise-free path: the epilogue adds into these zeroed rows (a cross-replica BatchNorm exchanges ordered partial rows instead)
     req.acc = None if isinstance(bn, FusedSyncBatchNorm2d) else _acc_take(bn.num_features, x.device)

@@ -387,6 +387,18 @@ int dsf_conv_c1_forward(const float* X, const float* W, const float* bias, float
  * dsf_bn_forward_acc / dsf_bn_relu_pool_forward with acc_filled = 1 (ABI 5).  Deterministic mode: DSF_ERR_UNSUPPORTED. */
 int dsf_conv_c1_forward_bn_acc(const float* X, const float* W, float* Y, int B, int Hi, int Wi, int Ho, int Wo, int Co, int K, int stride,
                                int pad, double* acc, int acc_rows, dsf_stream_t stream);
+/* Backward of [1-channel convolution -> BatchNorm (-> ReLU) (-> MaxPool2d)] behind the sums pass (ABI 5): the BatchNorm backward's apply
+ * arithmetic and the convolution's dW in ONE launch -- the gradient of the convolution output (134 MB at B = 32) is never written.
+ * X (B,Hi,Wi) the convolution input, Y (B,Ho,Wo,Co) its saved output (the BatchNorm input); grad = the gradient of the BatchNorm
+ * output (pool_k = 0, argmax NULL) or of the POOLED output with the argmax bytes of dsf_bn_relu_pool_forward / dsf_maxpool_forward
+ * (pool (3, 2, 1) or (2, 2, 0); others DSF_ERR_UNSUPPORTED); relu: the mask is recomputed from Y (dsf_bn_backward's mode 2).
+ * acc: the accumulation rows a sums-only pass filled (dsf_bn_backward_acc / dsf_bn_relu_pool_backward with grad_x = NULL).  dW
+ * [K*K][Co] is overwritten; grad_gamma / grad_beta as dsf_bn_backward_acc_pair (accumulate_affine).  dW equals dsf_conv_c1_wrw on the
+ * gradient dsf_bn_backward_acc / dsf_bn_relu_pool_backward would have written, bit for bit.  workspace as dsf_conv_c1_wrw. */
+int dsf_conv_c1_wrw_bn(const float* X, const float* Y, const float* grad, const uint8_t* argmax, const float* gamma, const float* beta,
+                       const float* save_mean, const float* save_invstd, const double* acc, int acc_rows, int relu, int pool_k, int pool_stride,
+                       int pool_pad, float* dW, float* grad_gamma, float* grad_beta, int accumulate_affine, float* workspace, int B, int Hi,
+                       int Wi, int Ho, int Wo, int Co, int K, int stride, int pad, dsf_stream_t stream);
 int dsf_conv_c1_wrw(const float* X, const float* dY, float* dW, float* workspace, int B, int Hi, int Wi, int Ho, int Wo, int Co,
                     int K, int stride, int pad, int accumulate, dsf_stream_t stream);
 
@@ -582,6 +594,7 @@ int dsf_conv_x6_forward_bn_acc(const float* X, const void* image, float* Y, int 
 int dsf_bn_forward_acc(const float* x, const float* residual, const float* gamma, const float* beta, int64_t M, int C, float eps,
                        float momentum, int relu, float* running_mean, float* running_var, float* y, float* save_mean,
                        float* save_invstd, double* acc, int acc_filled, dsf_stream_t stream);
+/* (dsf_bn_backward_acc with grad_x = NULL, ABI 5: the sums pass only -- the rows in `acc` then feed dsf_conv_c1_wrw_bn; M > 1024 rows) */
 int dsf_bn_backward_acc(const float* x, const float* grad_y, const float* y, const float* gamma, const float* beta,
                         const float* save_mean, const float* save_invstd, int64_t M, int C, int relu, float* grad_x,
                         float* grad_residual, float* grad_gamma, float* grad_beta, double* acc, dsf_stream_t stream);
@@ -599,7 +612,8 @@ int dsf_bn_backward_acc_pair(const float* x, const float* grad_y, const float* g
  * output y [B, Ho, Wo, C], the 1-byte window position of each maximum (dsf_maxpool_forward's rule) and save_mean / save_invstd, and
  * updates the running statistics; the full-resolution normalised map is never written.  Backward: both BatchNorm backward passes
  * gather the gradient of a full-resolution element from the pooled gradient grad_y (dsf_maxpool_backward's terms in its order: the
- * same bits) and recompute the ReLU mask from x; `acc` is a second zeroed block.  Results equal dsf_bn_forward_acc(relu = 1) +
+ * same bits) and recompute the ReLU mask from x; `acc` is a second zeroed block; grad_x = NULL: the sums pass only (the rows in `acc`
+ * then feed dsf_conv_c1_wrw_bn).  Results equal dsf_bn_forward_acc(relu = 1) +
  * dsf_maxpool_forward resp. dsf_maxpool_backward + dsf_bn_backward_acc(relu = 2) bit for bit (grad_x, grad_gamma, grad_beta up to the
  * order of the double-precision atomic sums, as for those entries).  k in {2, 3}, k <= 2 stride, 2 pad <= k, C % 4 == 0 with C / 4 dividing 256 or a multiple of it,
  * B Hi Wi C / 4 < 2^31; anything else (and the deterministic mode) DSF_ERR_UNSUPPORTED: run the separate layers.

@@ -228,3 +228,120 @@ def test_stem_convolution_epilogue_statistics(B, H, W, Co, K, stride, pad):
     s = acc.sum(0)
     assert _rel(s[0], yd.sum(0)) <= 1e-6 * max(1.0, (yd.abs().sum(0).max() / yd.sum(0).abs().max()).item())
     assert _rel(s[1], (yd * yd).sum(0)) <= 1e-6
+
+
+@pytest.mark.parametrize("B,H,W,Co,K,stride,pad,pool,relu", [(4, 32, 32, 64, 5, 1, 2, (3, 2, 1), 1), (3, 37, 29, 64, 7, 2, 3, (2, 2, 0), 1),
+                                                             (5, 20, 24, 32, 5, 1, 2, None, 1), (5, 40, 44, 64, 7, 2, 3, None, 0),
+                                                             (2, 33, 47, 64, 5, 1, 2, (3, 2, 1), 1), (9, 16, 16, 16, 5, 1, 2, (2, 2, 0), 1)])
+def test_apply_and_weight_gradient_in_one_launch_bit_for_bit(B, H, W, Co, K, stride, pad, pool, relu):
+    """dsf_conv_c1_wrw_bn on the accumulation rows of a sums pass == the BatchNorm backward's apply pass (dsf_bn_relu_pool_backward /
+    dsf_bn_backward_acc) followed by dsf_conv_c1_wrw on the gradient it wrote: dW, dgamma, dbeta bit for bit"""
+    import ctypes
+    from dsf_amd import _lib as L
+    if L.deterministic():
+        pytest.skip("accumulation rows are not used in deterministic mode")
+    lib = L.lib()
+    g = torch.Generator().manual_seed(B * H + K)
+    dev = "cuda"
+    x = torch.randn(B, H, W, 1, generator=g).to(dev)
+    w = torch.randn(K, K, 1, Co, generator=g).to(dev)
+    gamma, beta = (torch.rand(Co, generator=g) + 0.5).to(dev), (torch.randn(Co, generator=g) * 0.3).to(dev)
+    Ho, Wo = (H + 2 * pad - K) // stride + 1, (W + 2 * pad - K) // stride + 1
+    P = lambda t: ctypes.c_void_p(t.data_ptr() if t is not None else 0)
+    I, F, I64 = ctypes.c_int, ctypes.c_float, ctypes.c_int64
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rows = int(lib.dsf_bn_acc_rows())
+    zeros = lambda: torch.zeros(rows * 2 * Co, device=dev, dtype=torch.float64)
+    y = torch.empty(B, Ho, Wo, Co, device=dev)
+    acc_f = zeros()
+    assert lib.dsf_conv_c1_forward_bn_acc(P(x), P(w), P(y), I(B), I(H), I(W), I(Ho), I(Wo), I(Co), I(K), I(stride), I(pad), P(acc_f), I(rows), st) == 0
+    mean, invstd = torch.empty(Co, device=dev), torch.empty(Co, device=dev)
+    if pool:
+        k, s, p = pool
+        Po, Qo = (Ho + 2 * p - k) // s + 1, (Wo + 2 * p - k) // s + 1
+        out, arg = torch.empty(B, Po, Qo, Co, device=dev), torch.empty(B, Po, Qo, Co, device=dev, dtype=torch.uint8)
+        assert lib.dsf_bn_relu_pool_forward(P(y), P(gamma), P(beta), I(B), I(Ho), I(Wo), I(Co), I(k), I(s), I(p), F(1e-5), F(0.1), P(None), P(None),
+                                            P(out), P(arg), P(mean), P(invstd), P(acc_f), I(1), st) == 0
+    else:
+        k = s = p = 0
+        Po, Qo, arg = Ho, Wo, None
+        out = torch.empty_like(y)
+        assert lib.dsf_bn_forward_acc(P(y), P(None), P(gamma), P(beta), I64(B * Ho * Wo), I(Co), F(1e-5), F(0.1), I(relu), P(None), P(None), P(out),
+                                      P(mean), P(invstd), P(acc_f), I(1), st) == 0
+    gy = torch.randn(B, Po, Qo, Co, generator=g).to(dev)
+    # two launches: apply pass writes dx, the stem's dW kernel reads it
+    acc1, dx = zeros(), torch.empty_like(y)
+    gg1, gb1 = torch.empty(Co, device=dev), torch.empty(Co, device=dev)
+    if pool:
+        assert lib.dsf_bn_relu_pool_backward(P(y), P(gy), P(arg), P(gamma), P(beta), P(mean), P(invstd), I(B), I(Ho), I(Wo), I(Co), I(k), I(s), I(p),
+                                             P(dx), P(gg1), P(gb1), I(0), P(acc1), st) == 0
+    else:
+        assert lib.dsf_bn_backward_acc(P(y), P(gy), P(None), P(gamma), P(beta), P(mean), P(invstd), I64(B * Ho * Wo), I(Co), I(2 if relu else 0),
+                                       P(dx), P(None), P(gg1), P(gb1), P(acc1), st) == 0
+    ws = torch.empty(lib.dsf_conv_c1_workspace_bytes(I(K), I(K)) // 4, device=dev)
+    dw1 = torch.empty(K * K, Co, device=dev)
+    assert lib.dsf_conv_c1_wrw(P(x), P(dx), P(dw1), P(ws), I(B), I(H), I(W), I(Ho), I(Wo), I(Co), I(K), I(stride), I(pad), I(0), st) == 0
+    # one launch on the same rows; and the sums-only pass leaves the same kind of rows
+    dw2, gg2, gb2 = torch.empty(K * K, Co, device=dev), torch.empty(Co, device=dev), torch.empty(Co, device=dev)
+    ws2 = torch.empty_like(ws)
+    assert lib.dsf_conv_c1_wrw_bn(P(x), P(y), P(gy), P(arg), P(gamma), P(beta), P(mean), P(invstd), P(acc1), I(rows), I(relu), I(k), I(s), I(p), P(dw2),
+                                  P(gg2), P(gb2), I(0), P(ws2), I(B), I(H), I(W), I(Ho), I(Wo), I(Co), I(K), I(stride), I(pad), st) == 0
+    acc3 = zeros()
+    if pool:
+        assert lib.dsf_bn_relu_pool_backward(P(y), P(gy), P(arg), P(gamma), P(beta), P(mean), P(invstd), I(B), I(Ho), I(Wo), I(Co), I(k), I(s), I(p),
+                                             P(None), P(None), P(None), I(0), P(acc3), st) == 0
+    else:
+        assert lib.dsf_bn_backward_acc(P(y), P(gy), P(None), P(gamma), P(beta), P(mean), P(invstd), I64(B * Ho * Wo), I(Co), I(2 if relu else 0),
+                                       P(None), P(None), P(None), P(None), P(acc3), st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(dw1, dw2) and torch.equal(gg1, gg2) and torch.equal(gb1, gb2)
+    assert _rel(acc3.view(rows, -1).sum(0), acc1.view(rows, -1).sum(0)) <= 1e-12
+    # against float64 on the CPU: dW of conv(x, w) -> BatchNorm(train) -> (ReLU) -> (MaxPool2d)
+    xc = x.cpu().double().permute(0, 3, 1, 2)
+    wc = w.cpu().double().permute(3, 2, 0, 1).clone().requires_grad_(True)
+    gc, bc = gamma.cpu().double().requires_grad_(True), beta.cpu().double().requires_grad_(True)
+    t = torch.nn.functional.batch_norm(torch.nn.functional.conv2d(xc, wc, None, stride, pad), None, None, gc, bc, True, 0.1, 1e-5)
+    if relu:
+        t = torch.relu(t)
+    if pool:
+        t = torch.nn.functional.max_pool2d(t, k, s, p)
+    t.backward(gy.cpu().double().permute(0, 3, 1, 2))
+    assert _rel(dw2.cpu().double(), wc.grad.permute(2, 3, 1, 0).reshape(K * K, Co)) <= 2e-4
+    assert _rel(gg2.cpu().double(), gc.grad) <= 1e-4 and _rel(gb2.cpu().double(), bc.grad) <= 1e-4
+
+
+@pytest.mark.parametrize("pool", [True, False])
+def test_stem_as_one_autograd_node_equals_two(pool):
+    """conv_bn_act on a 1-channel convolution: nn_norm._StemFunction (DSF_C1_BN) against the convolution and the BatchNorm as separate
+    nodes -- outputs and running statistics bit for bit, gradients to the order of the double atomics; applied twice in one pass"""
+    from dsf_amd import nn_norm, nn_conv, _lib as L
+    from dsf_amd.model import backbone
+    if L.deterministic():
+        pytest.skip("deterministic mode keeps the separate layers")
+    Ls = backbone._Layers()
+    torch.manual_seed(8)
+    pre = nn.Sequential(Ls.Conv2d(1, 64, kernel_size=5, stride=1, padding=2, bias=False), *Ls.bn_relu(64, momentum=0.1),
+                        Ls.MaxPool2d(kernel_size=3, stride=2, padding=1)).cuda().train()
+    ref = copy.deepcopy(pre)
+    imgs = [torch.randn(4, 1, 32, 32, device="cuda"), torch.randn(4, 1, 32, 32, device="cuda")]
+    floats = 2 * nn_norm.stat_floats(pre)
+    run = (lambda m, t: backbone._stem(m, t)) if pool else (lambda m, t: nn_norm.conv_bn_act(m[0], m[1], t))
+    res = []
+    for m, on in ((pre, True), (ref, False)):
+        saved = nn_norm.C1_BN[0]
+        nn_norm.C1_BN[0] = on
+        nn_conv.RECORD = []
+        try:
+            with nn_norm.stat_pool(floats, "cuda"):
+                ya, yb = run(m, imgs[0]), run(m, imgs[1])
+                grads = torch.autograd.grad((ya * ya).sum() + yb.sum(), [q for q in m.parameters()])
+            kinds = [r[0] for r in nn_conv.RECORD]
+        finally:
+            nn_norm.C1_BN[0] = saved
+            nn_conv.RECORD = None
+        assert ("c1_fwd_bn" in kinds) == on and (("c1_wrw_bn1" if pool else "c1_wrw_bn0") in kinds) == on and ("c1_wrw" in kinds) == (not on)
+        res.append((ya, yb, grads, m[1].running_mean.clone(), m[1].running_var.clone()))
+    a, b = res
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+    for u, v in zip(a[2], b[2]):
+        assert u.shape == v.shape and _rel(u, v) <= 5e-6
