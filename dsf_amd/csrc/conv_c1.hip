@@ -96,10 +96,10 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restric
 }
 
 template <int K, int S>
-__global__ __launch_bounds__(256) void conv_c1_fwd_stats_kernel(const float* __restrict__ X, const float* __restrict__ W, float* __restrict__ Y,
-                                                                C1P p, int segs_per_row, int64_t n_segs, double* __restrict__ stat,
-                                                                int acc_rows) {
-    c1_fwd_body<K, S, true>(X, W, nullptr, Y, p, segs_per_row, n_segs, stat, acc_rows);
+__global__ __launch_bounds__(256) void conv_c1_fwd_stats_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                                const float* __restrict__ bias, float* __restrict__ Y, C1P p,
+                                                                int segs_per_row, int64_t n_segs, double* __restrict__ stat, int acc_rows) {
+    c1_fwd_body<K, S, true>(X, W, bias, Y, p, segs_per_row, n_segs, stat, acc_rows);
 }
 
 // dW[kh][kw][co] = sum over pixels of x[iy][ix] * gy[pixel][co]: per-lane accumulators, workgroup partials, then a combine
@@ -167,11 +167,12 @@ __global__ __launch_bounds__(256) void conv_c1_wrw_bn_kernel(const float* __rest
     constexpr int NIN = (PX - 1) * S + K;
     constexpr int PK = (POOL == 1) ? 3 : 2, PP = (POOL == 1) ? 1 : 0;                         // pooling window, padding
     constexpr int NPR = (POOL == 1) ? 2 : 1, NPC = (POOL == 1) ? PX / 2 + 1 : PX / 2;         // pooled rows / columns a segment's pixels sit in
-    __shared__ float red[4][K * K][64];
+    __shared__ float red[4][K * K + 1][64];                     // (slot K*K: the bias gradient, the per-channel sum of the gradient)
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t wave = (int64_t)blockIdx.x * 4 + wv, n_waves = (int64_t)gridDim.x * 4;
     const bool c_ok = lane < p.Co;
     const int ch = c_ok ? lane : 0;
+    float sb = 0.f;
     double f0 = 0.0, f1 = 0.0;
     for (int r = 0; r < n.n_rows; ++r) { f0 += n.rows[(int64_t)r * 2 * p.Co + ch]; f1 += n.rows[(int64_t)r * 2 * p.Co + p.Co + ch]; }
     if (blockIdx.x == 0 && wv == 0 && c_ok) {
@@ -235,6 +236,7 @@ __global__ __launch_bounds__(256) void conv_c1_wrw_bn_kernel(const float* __rest
             const float xh = (yv[q] - mu) * is;
             const float d = sc * (ge - m0 - xh * m1);
             g[q] = (c_ok && ox0 + q < p.Wo) ? d : 0.f;
+            sb += g[q];
         }
         float v[K];
 #pragma unroll
@@ -253,10 +255,11 @@ __global__ __launch_bounds__(256) void conv_c1_wrw_bn_kernel(const float* __rest
     }
 #pragma unroll
     for (int i = 0; i < K * K; ++i) red[wv][i][lane] = acc[i];
+    red[wv][K * K][lane] = sb;
     __syncthreads();
-    for (int i = threadIdx.x; i < K * K * 64; i += 256) {
+    for (int i = threadIdx.x; i < (K * K + 1) * 64; i += 256) {
         const int t = i >> 6, c = i & 63;
-        part[(int64_t)blockIdx.x * (K * K * 64) + i] = (red[0][t][c] + red[1][t][c]) + (red[2][t][c] + red[3][t][c]);
+        part[(int64_t)blockIdx.x * ((K * K + 1) * 64) + i] = (red[0][t][c] + red[1][t][c]) + (red[2][t][c] + red[3][t][c]);
     }
 }
 
@@ -358,7 +361,7 @@ extern "C" {
 
 int dsf_conv_c1_supported(int Co, int KH, int KW, int stride) { return (KH == KW && c1_ok(Co, KH, stride)) ? 1 : 0; }
 
-int64_t dsf_conv_c1_workspace_bytes(int KH, int KW) { return (int64_t)C1_WRW_WGS * KH * KW * 64 * 4; }
+int64_t dsf_conv_c1_workspace_bytes(int KH, int KW) { return (int64_t)C1_WRW_WGS * (KH * KW + 1) * 64 * 4; }     // (+ 1: dsf_conv_c1_wrw_bn's bias slot)
 
 int dsf_conv_c1_forward(const float* X, const float* W, const float* bias, float* Y, int B, int Hi, int Wi, int Ho, int Wo, int Co,
                         int K, int stride, int pad, dsf_stream_t stream) {
@@ -378,7 +381,7 @@ int dsf_conv_c1_forward(const float* X, const float* W, const float* bias, float
     return dsf_launch_status();
 }
 
-int dsf_conv_c1_forward_bn_acc(const float* X, const float* W, float* Y, int B, int Hi, int Wi, int Ho, int Wo, int Co, int K, int stride,
+int dsf_conv_c1_forward_bn_acc(const float* X, const float* W, const float* bias, float* Y, int B, int Hi, int Wi, int Ho, int Wo, int Co, int K, int stride,
                                int pad, double* acc, int acc_rows, dsf_stream_t stream) {
     DSF_CHECK_ARG(X && W && Y && acc && acc_rows >= 1 && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && pad >= 0);
     if (!c1_ok(Co, K, stride) || dsf_deterministic()) return DSF_ERR_UNSUPPORTED;
@@ -388,7 +391,7 @@ int dsf_conv_c1_forward_bn_acc(const float* X, const float* W, float* Y, int B, 
     int64_t wgs = (n_segs + 3) / 4;
     if (wgs > C1_STATS_WGS) wgs = C1_STATS_WGS;
 #define DSF_LAUNCH_C1(Kv, Sv) hipLaunchKernelGGL((conv_c1_fwd_stats_kernel<Kv, Sv>), dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, \
-                                                 X, W, Y, p, spr, n_segs, acc, acc_rows)
+                                                 X, W, bias, Y, p, spr, n_segs, acc, acc_rows)
     if (K == 5) { if (stride == 1) DSF_LAUNCH_C1(5, 1); else DSF_LAUNCH_C1(5, 2); }
     else { if (stride == 1) DSF_LAUNCH_C1(7, 1); else DSF_LAUNCH_C1(7, 2); }
 #undef DSF_LAUNCH_C1
@@ -418,7 +421,7 @@ int dsf_conv_c1_wrw_bn(const float* X, const float* Y, const float* grad, const 
     else { if (stride == 1) DSF_LAUNCH_C1B_P(7, 1); else DSF_LAUNCH_C1B_P(7, 2); }
 #undef DSF_LAUNCH_C1B_P
 #undef DSF_LAUNCH_C1B
-    hipLaunchKernelGGL(conv_c1_wrw_combine_kernel, dim3(K * K), dim3(1024), 0, st, workspace, wgs, K * K, Co, 0, dW);
+    hipLaunchKernelGGL(conv_c1_wrw_combine_kernel, dim3(K * K + 1), dim3(1024), 0, st, workspace, wgs, K * K + 1, Co, 0, dW);
     return dsf_launch_status();
 }
 

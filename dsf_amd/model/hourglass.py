@@ -8,7 +8,7 @@ import torch
 from torch import nn
 
 from .. import nn_conv
-from ..nn_norm import FusedBatchNorm2d
+from ..nn_norm import FusedBatchNorm2d, conv_bn_act
 from ..streams import fork
 
 
@@ -32,6 +32,8 @@ class Conv(nn.Module):
             self.bn, self.relu = None, (nn.ReLU() if relu else None)
 
     def forward(self, x):
+        if isinstance(self.bn, FusedBatchNorm2d):            # (the 1-channel stem: one autograd node, see nn_norm._StemFunction)
+            return conv_bn_act(self.conv, self.bn, x)
         x = self.conv(x)
         if self.bn is not None:
             x = self.bn(x)

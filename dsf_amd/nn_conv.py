@@ -294,7 +294,7 @@ def _fwd_c1(x, wk, bias, out_hw, Co, K, stride, pad):
     req = STATS
     if isinstance(req, StatsRequest) and req.acc is not None and bias is None and B > 0 and C1_STATS[0] and not L.deterministic():
         # the BatchNorm behind the stem asked for its batch statistics: lane = channel, the sums ride in two registers
-        check(L.lib().dsf_conv_c1_forward_bn_acc(ptr_nhwc(x), ptr(wk), ptr_nhwc(y), I(B), I(Hi), I(Wi), I(Ho), I(Wo), I(Co), I(K), I(stride),
+        check(L.lib().dsf_conv_c1_forward_bn_acc(ptr_nhwc(x), ptr(wk), None, ptr_nhwc(y), I(B), I(Hi), I(Wi), I(Ho), I(Wo), I(Co), I(K), I(stride),
                                                  I(pad), ptr(req.acc), I(int(L.lib().dsf_bn_acc_rows())), stream_ptr()),
               "dsf_conv_c1_forward_bn_acc")
         req.filled = 1
@@ -883,7 +883,7 @@ def replay(rec, iters=3):
         y = torch.empty((B, Co, Ho, Wo), device=dev, dtype=torch.float32, memory_format=CL)
         rows = int(L.lib().dsf_bn_acc_rows())
         acc = torch.zeros(rows * 2 * Co, device=dev, dtype=torch.float64)
-        run = lambda: check(L.lib().dsf_conv_c1_forward_bn_acc(ptr_nhwc(x), ptr(wk), ptr_nhwc(y), I(B), I(Hi), I(Wi), I(Ho), I(Wo), I(Co), I(KH),
+        run = lambda: check(L.lib().dsf_conv_c1_forward_bn_acc(ptr_nhwc(x), ptr(wk), None, ptr_nhwc(y), I(B), I(Hi), I(Wi), I(Ho), I(Wo), I(Co), I(KH),
                                                                I(stride), I(ph), ptr(acc), I(rows), stream_ptr()), "dsf_conv_c1_forward_bn_acc")
     elif kind.startswith("c1_wrw_bn"):                       # ... and its backward launch (BatchNorm apply arithmetic + dW), pooling mode in the name
         k, s, p = {"0": (0, 0, 0), "1": (3, 2, 1), "2": (2, 2, 0)}[kind[-1]]
@@ -894,7 +894,7 @@ def replay(rec, iters=3):
         vec = [torch.rand(Co, device=dev) + 0.5 for _ in range(4)]
         rows = int(L.lib().dsf_bn_acc_rows())
         acc = torch.randn(rows * 2 * Co, device=dev, dtype=torch.float64)
-        dw, gg, gb = torch.empty(KH * KW * Co, device=dev), torch.empty(Co, device=dev), torch.empty(Co, device=dev)
+        dw, gg, gb = torch.empty((KH * KW + 1) * Co, device=dev), torch.empty(Co, device=dev), torch.empty(Co, device=dev)
         ws = torch.empty(L.lib().dsf_conv_c1_workspace_bytes(I(KH), I(KW)) // 4, device=dev, dtype=torch.float32)
         run = lambda: check(L.lib().dsf_conv_c1_wrw_bn(ptr_nhwc(x), ptr_nhwc(y), ptr_nhwc(g), ptr(arg) if k else None, ptr(vec[0]), ptr(vec[1]),
                                                        ptr(vec[2]), ptr(vec[3]), ptr(acc), I(rows), I(1), I(k), I(s), I(p), ptr(dw), ptr(gg), ptr(gb),

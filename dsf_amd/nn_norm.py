@@ -506,7 +506,7 @@ class _StemFunction(Function):
     gradient is neither written nor read back.  The input must not require a gradient (conv_bn_act checks)."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, eps, momentum, relu, stride, pad, pool, acc):
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, eps, momentum, relu, stride, pad, pool, acc):
         from . import nn_conv
         ctx.set_materialize_grads(False)
         x = nn_conv._nhwc(x)
@@ -518,7 +518,7 @@ class _StemFunction(Function):
             nn_conv.RECORD.append(("c1_fwd_bn", B, Hi, Wi, 1, Ho, Wo, Co, K, K, stride, 1, pad, pad))
         y = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=CL)
         lib = L.lib()
-        check(lib.dsf_conv_c1_forward_bn_acc(_p(x), _p(wk), _p(y), I(B), I(Hi), I(Wi), I(Ho), I(Wo), I(Co), I(K), I(stride), I(pad), _p(acc),
+        check(lib.dsf_conv_c1_forward_bn_acc(_p(x), _p(wk), _p(bias.detach() if bias is not None else None), _p(y), I(B), I(Hi), I(Wi), I(Ho), I(Wo), I(Co), I(K), I(stride), I(pad), _p(acc),
                                              I(int(lib.dsf_bn_acc_rows())), stream_ptr()), "dsf_conv_c1_forward_bn_acc")
         mean = torch.empty(Co, device=x.device, dtype=torch.float32)
         invstd = torch.empty(Co, device=x.device, dtype=torch.float32)
@@ -537,18 +537,18 @@ class _StemFunction(Function):
                                          _p(running_mean), _p(running_var), _p(out), _p(mean), _p(invstd), _p(acc), I(1), stream_ptr()),
                   "dsf_bn_forward_acc")
         ctx.save_for_backward(x, y, weight, gamma, beta, mean, invstd, arg)
-        ctx.cfg = (bool(relu), stride, pad, pool)
+        ctx.cfg = (bool(relu), stride, pad, pool, bias is not None)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
         from . import nn_conv
-        n_in = 13
+        n_in = 14
         if g is None:
             return (None,) * n_in
         x, y, weight, gamma, beta, mean, invstd, arg = ctx.saved_tensors
-        relu, stride, pad, pool = ctx.cfg
+        relu, stride, pad, pool, has_bias = ctx.cfg
         g = g.contiguous(memory_format=CL)
         B, Co, Ho, Wo = y.shape
         _, _, Hi, Wi = x.shape
@@ -583,8 +583,9 @@ class _StemFunction(Function):
         if nn_conv.RECORD is not None:
             nn_conv.RECORD.append(("c1_wrw_bn%d" % {0: 0, 3: 1, 2: 2}[k], B, Hi, Wi, 1, Ho, Wo, Co, K, K, stride, 1, pad, pad))
         nn_conv.main_stream_weight_grad(weight)
-        dw = nn_conv._pool_take(K * K * Co, x.device)
-        dw = dw.view(K, K, 1, Co) if dw is not None else torch.empty((K, K, 1, Co), device=x.device, dtype=torch.float32)
+        dw = nn_conv._pool_take((K * K + 1) * Co, x.device)                   # rows 0 .. K*K - 1: dW; row K*K: the bias gradient
+        if dw is None:
+            dw = torch.empty((K * K + 1) * Co, device=x.device, dtype=torch.float32)
         ws = torch.empty(lib.dsf_conv_c1_workspace_bytes(I(K), I(K)) // 4, device=x.device, dtype=torch.float32)
         check(lib.dsf_conv_c1_wrw_bn(_p(x), _p(y), _p(g), _p(arg), _p(gamma), _p(beta), _p(mean), _p(invstd), _p(acc), I(acc_rows()),
                                      I(int(relu)), I(k), I(s), I(p), _p(dw), _p(gg_w), _p(gb_w), I(accumulate), _p(ws), I(B), I(Hi), I(Wi),
@@ -594,15 +595,18 @@ class _StemFunction(Function):
         elif rec_key is not None:
             gamma.__dict__["_dsf_bnpass"] = rec_key + (gg, gb)
             gg, gb = gg.view(Co), gb.view(Co)
-        return (None, dw.permute(3, 2, 0, 1) if ctx.needs_input_grad[1] else None, gg, gb) + (None,) * (n_in - 4)
+        gw = dw[:K * K * Co].view(K, K, 1, Co).permute(3, 2, 0, 1) if ctx.needs_input_grad[1] else None
+        gbias = dw[K * K * Co:] if (has_bias and ctx.needs_input_grad[2]) else None
+        return (None, gw, gbias, gg, gb) + (None,) * (n_in - 5)
 
 
 def _stem_node(conv, bn, x, relu, pool):
     """conv_bn_act's route into _StemFunction, or None: a bias-free 1-channel convolution of this package whose input needs no gradient, a
     training-mode FusedBatchNorm2d, more than 1024 output pixels, an open statistics pool; pooling (3, 2, 1) or (2, 2, 0) behind a ReLU"""
     from . import nn_conv
-    if not (C1_BN[0] and nn_conv.C1_STATS[0] and type(bn) is FusedBatchNorm2d and type(conv) is nn_conv.Conv2d and conv.bias is None and
-            not x.requires_grad and x.dim() == 4 and x.dtype == torch.float32 and x.shape[0] > 0 and bn.momentum is not None and
+    if not (C1_BN[0] and nn_conv.C1_STATS[0] and EPILOGUE_STATS[0] and type(bn) is FusedBatchNorm2d and type(conv) is nn_conv.Conv2d and
+            bn.training and bn.track_running_stats and x.is_cuda and supported(bn.num_features) and nn_conv.STATS is None and
+            (conv.bias is None or conv.bias.dtype == torch.float32) and not x.requires_grad and x.dim() == 4 and x.dtype == torch.float32 and x.shape[0] > 0 and bn.momentum is not None and
             conv.weight.dtype == torch.float32 and conv.groups == 1 and tuple(conv.dilation) == (1, 1) and conv.padding_mode == "zeros"):
         return None
     s, pd = tuple(conv.stride), tuple(conv.padding)
@@ -620,7 +624,7 @@ def _stem_node(conv, bn, x, relu, pool):
     if acc is None:
         return None
     bn._count_training_batch()
-    return _StemFunction.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, bool(relu), s[0], pd[0],
+    return _StemFunction.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, bool(relu), s[0], pd[0],
                                tuple(pool[:3]) if pool is not None else None, acc)
 
 
@@ -653,14 +657,14 @@ def conv_bn_act(conv, bn, x, residual=None, relu=None, twin=False, pool=None):
         return y if req.applied else bn(y, residual, r)
     fusable = (EPILOGUE_STATS[0] and isinstance(bn, FusedBatchNorm2d) and isinstance(conv, (nn_conv.Conv2d, nn_conv.ConvTranspose2d)) and bn.training and
                bn.track_running_stats and conv.bias is None and x.is_cuda and supported(bn.num_features) and nn_conv.STATS is None)
+    if residual is None and not twin and isinstance(bn, FusedBatchNorm2d):
+        out = _stem_node(conv, bn, x, bn.fuse_relu if relu is None else relu, pool)
+        if out is not None:
+            return out
     if not fusable:
         if pool is not None:
             return _pooled(bn, conv(x), pool)
         return bn_act(bn, conv(x), residual, relu if relu is not None else getattr(bn, "fuse_relu", False), twin)
-    if residual is None and not twin:
-        out = _stem_node(conv, bn, x, bn.fuse_relu if relu is None else relu, pool)
-        if out is not None:
-            return out
     req = nn_conv.StatsRequest()
     # finalise-free path: the epilogue adds into these zeroed rows (a cross-replica BatchNorm exchanges ordered partial rows instead)
     req.acc = None if isinstance(bn, FusedSyncBatchNorm2d) else _acc_take(bn.num_features, x.device)

@@ -382,10 +382,10 @@ int dsf_conv_co1_forward(const float* X, const float* W, const float* bias, floa
 int64_t dsf_conv_c1_workspace_bytes(int KH, int KW);
 int dsf_conv_c1_forward(const float* X, const float* W, const float* bias, float* Y, int B, int Hi, int Wi, int Ho, int Wo, int Co,
                         int K, int stride, int pad, dsf_stream_t stream);
-/* dsf_conv_c1_forward (no bias) that also ADDS the per-channel sum and sum of squares of Y, as doubles, into the zeroed block
+/* dsf_conv_c1_forward (bias may be NULL) that also ADDS the per-channel sum and sum of squares of Y, as doubles, into the zeroed block
  * acc [acc_rows][2][Co] (dsf_bn_acc_rows() rows): the batch statistics of the BatchNorm behind the stem convolution, consumed by
  * dsf_bn_forward_acc / dsf_bn_relu_pool_forward with acc_filled = 1 (ABI 5).  Deterministic mode: DSF_ERR_UNSUPPORTED. */
-int dsf_conv_c1_forward_bn_acc(const float* X, const float* W, float* Y, int B, int Hi, int Wi, int Ho, int Wo, int Co, int K, int stride,
+int dsf_conv_c1_forward_bn_acc(const float* X, const float* W, const float* bias, float* Y, int B, int Hi, int Wi, int Ho, int Wo, int Co, int K, int stride,
                                int pad, double* acc, int acc_rows, dsf_stream_t stream);
 /* Backward of [1-channel convolution -> BatchNorm (-> ReLU) (-> MaxPool2d)] behind the sums pass (ABI 5): the BatchNorm backward's apply
  * arithmetic and the convolution's dW in ONE launch -- the gradient of the convolution output (134 MB at B = 32) is never written.
@@ -393,8 +393,10 @@ int dsf_conv_c1_forward_bn_acc(const float* X, const float* W, float* Y, int B, 
  * output (pool_k = 0, argmax NULL) or of the POOLED output with the argmax bytes of dsf_bn_relu_pool_forward / dsf_maxpool_forward
  * (pool (3, 2, 1) or (2, 2, 0); others DSF_ERR_UNSUPPORTED); relu: the mask is recomputed from Y (dsf_bn_backward's mode 2).
  * acc: the accumulation rows a sums-only pass filled (dsf_bn_backward_acc / dsf_bn_relu_pool_backward with grad_x = NULL).  dW
- * [K*K][Co] is overwritten; grad_gamma / grad_beta as dsf_bn_backward_acc_pair (accumulate_affine).  dW equals dsf_conv_c1_wrw on the
- * gradient dsf_bn_backward_acc / dsf_bn_relu_pool_backward would have written, bit for bit.  workspace as dsf_conv_c1_wrw. */
+ * [K*K + 1][Co] is overwritten -- row K*K is the convolution's BIAS gradient (the per-channel sum of the output gradient);
+ * grad_gamma / grad_beta as dsf_bn_backward_acc_pair (accumulate_affine).  dW equals dsf_conv_c1_wrw on the
+ * gradient dsf_bn_backward_acc / dsf_bn_relu_pool_backward would have written, bit for bit (rows 0 .. K*K - 1).  workspace as
+ * dsf_conv_c1_wrw. */
 int dsf_conv_c1_wrw_bn(const float* X, const float* Y, const float* grad, const uint8_t* argmax, const float* gamma, const float* beta,
                        const float* save_mean, const float* save_invstd, const double* acc, int acc_rows, int relu, int pool_k, int pool_stride,
                        int pool_pad, float* dW, float* grad_gamma, float* grad_beta, int accumulate_affine, float* workspace, int B, int Hi,

@@ -221,7 +221,7 @@ def test_stem_convolution_epilogue_statistics(B, H, W, Co, K, stride, pad):
     I = ctypes.c_int
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     assert L.lib().dsf_conv_c1_forward(P(x), P(w), ctypes.c_void_p(0), P(y0), I(B), I(H), I(W), I(Ho), I(Wo), I(Co), I(K), I(stride), I(pad), st) == 0
-    assert L.lib().dsf_conv_c1_forward_bn_acc(P(x), P(w), P(y1), I(B), I(H), I(W), I(Ho), I(Wo), I(Co), I(K), I(stride), I(pad), P(acc), I(rows), st) == 0
+    assert L.lib().dsf_conv_c1_forward_bn_acc(P(x), P(w), ctypes.c_void_p(0), P(y1), I(B), I(H), I(W), I(Ho), I(Wo), I(Co), I(K), I(stride), I(pad), P(acc), I(rows), st) == 0
     torch.cuda.synchronize()
     assert torch.equal(y0, y1)
     yd = y0.double().reshape(-1, Co)
@@ -254,7 +254,8 @@ def test_apply_and_weight_gradient_in_one_launch_bit_for_bit(B, H, W, Co, K, str
     zeros = lambda: torch.zeros(rows * 2 * Co, device=dev, dtype=torch.float64)
     y = torch.empty(B, Ho, Wo, Co, device=dev)
     acc_f = zeros()
-    assert lib.dsf_conv_c1_forward_bn_acc(P(x), P(w), P(y), I(B), I(H), I(W), I(Ho), I(Wo), I(Co), I(K), I(stride), I(pad), P(acc_f), I(rows), st) == 0
+    bias = (torch.randn(Co, generator=g) * 0.2).to(dev) if K == 7 else None
+    assert lib.dsf_conv_c1_forward_bn_acc(P(x), P(w), P(bias), P(y), I(B), I(H), I(W), I(Ho), I(Wo), I(Co), I(K), I(stride), I(pad), P(acc_f), I(rows), st) == 0
     mean, invstd = torch.empty(Co, device=dev), torch.empty(Co, device=dev)
     if pool:
         k, s, p = pool
@@ -282,7 +283,7 @@ def test_apply_and_weight_gradient_in_one_launch_bit_for_bit(B, H, W, Co, K, str
     dw1 = torch.empty(K * K, Co, device=dev)
     assert lib.dsf_conv_c1_wrw(P(x), P(dx), P(dw1), P(ws), I(B), I(H), I(W), I(Ho), I(Wo), I(Co), I(K), I(stride), I(pad), I(0), st) == 0
     # one launch on the same rows; and the sums-only pass leaves the same kind of rows
-    dw2, gg2, gb2 = torch.empty(K * K, Co, device=dev), torch.empty(Co, device=dev), torch.empty(Co, device=dev)
+    dw2, gg2, gb2 = torch.empty(K * K + 1, Co, device=dev), torch.empty(Co, device=dev), torch.empty(Co, device=dev)
     ws2 = torch.empty_like(ws)
     assert lib.dsf_conv_c1_wrw_bn(P(x), P(y), P(gy), P(arg), P(gamma), P(beta), P(mean), P(invstd), P(acc1), I(rows), I(relu), I(k), I(s), I(p), P(dw2),
                                   P(gg2), P(gb2), I(0), P(ws2), I(B), I(H), I(W), I(Ho), I(Wo), I(Co), I(K), I(stride), I(pad), st) == 0
@@ -294,19 +295,23 @@ def test_apply_and_weight_gradient_in_one_launch_bit_for_bit(B, H, W, Co, K, str
         assert lib.dsf_bn_backward_acc(P(y), P(gy), P(None), P(gamma), P(beta), P(mean), P(invstd), I64(B * Ho * Wo), I(Co), I(2 if relu else 0),
                                        P(None), P(None), P(None), P(None), P(acc3), st) == 0
     torch.cuda.synchronize()
-    assert torch.equal(dw1, dw2) and torch.equal(gg1, gg2) and torch.equal(gb1, gb2)
+    assert torch.equal(dw1, dw2[:K * K]) and torch.equal(gg1, gg2) and torch.equal(gb1, gb2)
+    # row K*K: the convolution's bias gradient = the per-channel sum of dx (zero in exact arithmetic behind a BatchNorm: rounding noise)
+    dxd = dx.double().reshape(-1, Co)
+    assert (dw2[K * K].double() - dxd.sum(0)).abs().max().item() <= 1e-6 * dxd.abs().sum(0).max().item()
     assert _rel(acc3.view(rows, -1).sum(0), acc1.view(rows, -1).sum(0)) <= 1e-12
     # against float64 on the CPU: dW of conv(x, w) -> BatchNorm(train) -> (ReLU) -> (MaxPool2d)
     xc = x.cpu().double().permute(0, 3, 1, 2)
     wc = w.cpu().double().permute(3, 2, 0, 1).clone().requires_grad_(True)
     gc, bc = gamma.cpu().double().requires_grad_(True), beta.cpu().double().requires_grad_(True)
-    t = torch.nn.functional.batch_norm(torch.nn.functional.conv2d(xc, wc, None, stride, pad), None, None, gc, bc, True, 0.1, 1e-5)
+    t = torch.nn.functional.batch_norm(torch.nn.functional.conv2d(xc, wc, bias.cpu().double() if bias is not None else None, stride, pad),
+                                       None, None, gc, bc, True, 0.1, 1e-5)
     if relu:
         t = torch.relu(t)
     if pool:
         t = torch.nn.functional.max_pool2d(t, k, s, p)
     t.backward(gy.cpu().double().permute(0, 3, 1, 2))
-    assert _rel(dw2.cpu().double(), wc.grad.permute(2, 3, 1, 0).reshape(K * K, Co)) <= 2e-4
+    assert _rel(dw2[:K * K].cpu().double(), wc.grad.permute(2, 3, 1, 0).reshape(K * K, Co)) <= 2e-4
     assert _rel(gg2.cpu().double(), gc.grad) <= 1e-4 and _rel(gb2.cpu().double(), bc.grad) <= 1e-4
 
 

@@ -1,5 +1,4 @@
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/c69; mkdir -p $O; cd $R
-timeout 900 python3 tools/ab_env.py --config 2 --var DSF_C1_BN --values 0 1 --block 10 --rounds 12 2>&1 | tail -2 | tee $O/ab_c1bn_c2.txt
-timeout 900 python3 tools/ab_env.py --config 5 --var DSF_C1_BN --values 0 1 --block 5 --rounds 8 2>&1 | tail -2 | tee $O/ab_c1bn_c5.txt
-timeout 2400 python3 -m pytest tests -q -m gpu > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log; tail -n 6 $O/pytest_gpu.log
-timeout 300 python3 bench.py --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-400
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/c70; mkdir -p $O; cd $R
+timeout 1800 python3 -m pytest tests/test_gpu_bn_pool.py tests/test_gpu_steps.py tests/test_gpu_parity.py tests/test_gpu_fused.py tests/test_gpu_determinism.py -q -x -m gpu > $O/pytest_sel.log 2>&1; echo "rc=$?" >> $O/pytest_sel.log; tail -n 12 $O/pytest_sel.log
+timeout 900 python3 tools/ab_env.py --config 3 --var DSF_C1_BN --values 0 1 --block 10 --rounds 10 2>&1 | tail -2 | tee $O/ab_c1bn_c3.txt
+timeout 900 python3 tools/ab_env.py --config 4 --var DSF_C1_BN --values 0 1 --block 3 --rounds 6 2>&1 | tail -2 | tee $O/ab_c1bn_c4.txt
