@@ -283,7 +283,7 @@ __global__ __launch_bounds__(1024) void conv_c1_wrw_combine_kernel(const float* 
     }
 }
 
-constexpr int C1_STATS_WGS = 1024;                    // the statistics variant: 128 double atomics per workgroup onto acc_rows x 2 Co addresses
+constexpr int C1_STATS_WGS = 4096;                    // the statistics variant: 128 double atomics per workgroup onto acc_rows x 2 Co addresses; B = 32 stem alone: 68.7 / 56.0 / 52.1 / 50.1 us at 512 / 1024 / 2048 / 4096 workgroups, 50.1 without the statistics
 constexpr int C1_WRW_WGS = 2048;                      // 8 waves per SIMD: the kernel lives on loads in flight
 
 inline bool c1_ok(int Co, int K, int stride) { return Co >= 1 && Co <= 64 && (K == 5 || K == 7) && (stride == 1 || stride == 2); }
@@ -389,7 +389,9 @@ int dsf_conv_c1_forward_bn_acc(const float* X, const float* W, const float* bias
     const int spr = (Wo + PX - 1) / PX;
     const int64_t n_segs = (int64_t)B * Ho * spr;
     int64_t wgs = (n_segs + 3) / 4;
-    if (wgs > C1_STATS_WGS) wgs = C1_STATS_WGS;
+    const char* cap_e = getenv("DSF_C1_STATS_WGS");                    // tuning aid, read per call
+    const int64_t cap = (cap_e && atoi(cap_e) > 0) ? atoi(cap_e) : C1_STATS_WGS;
+    if (wgs > cap) wgs = cap;
 #define DSF_LAUNCH_C1(Kv, Sv) hipLaunchKernelGGL((conv_c1_fwd_stats_kernel<Kv, Sv>), dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, \
                                                  X, W, bias, Y, p, spr, n_segs, acc, acc_rows)
     if (K == 5) { if (stride == 1) DSF_LAUNCH_C1(5, 1); else DSF_LAUNCH_C1(5, 2); }
