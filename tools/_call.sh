@@ -1,6 +1,4 @@
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/c72; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
-timeout 400 rocprofv3 --kernel-trace --output-format csv -d $O/ks -o k -- python3 $R/tools/step_only.py --config 2 --steps 12 --warmup 4 > $O/step_only.log 2>&1
-grep STEP_ONLY $O/step_only.log
-python3 $R/tools/gaps.py $O/ks/k_kernel_trace.csv 25 | tee $O/gaps_c2.txt
-python3 $R/tools/busy.py $O/ks/k_kernel_trace.csv | tail -3
-rm -rf $O/ks
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/c73; mkdir -p $O; cd $R
+timeout 2400 python3 -m pytest tests -q -m gpu > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log; tail -n 3 $O/pytest_gpu.log
+timeout 300 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 400 python3 bench.py 2>/dev/null | tail -1 > $O/bench.json; python3 -c "import json; d=json.loads(open('$O/bench.json').read()); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['cpu_baseline'])"
