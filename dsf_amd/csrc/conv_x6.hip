@@ -145,8 +145,12 @@ __global__ __launch_bounds__(256) void x6_split_weights_kernel(const float* __re
 // per-granule form above issues eight 4-byte loads per granule: the whole-network launch ran at 2.7 TB/s).  mode 0: eight float4
 // along n, one per k; mode 1: two float4 along k per granule.  The channel counts are multiples of 4 (the convolution's own
 // requirement), so a float4 is inside the matrix or outside it as a whole.  Same values, same split: bit-identical images.
-__device__ __forceinline__ void x6_split_granules4(const float* __restrict__ W, uint4* __restrict__ img, int KH, int KW, int Ci, int Co,
-                                                   int mode, int chunks, int n_tiles, int bn, int64_t g) {
+// wave-local exchange through LDS: the LDS unit serves one wave's instructions in order, so a ds_read issued after a ds_write of the same
+// wave sees it; only the COMPILER must keep the order (a wavefront-scope fence would also wait for the global stores in flight)
+#define X6_WAVE_LDS_ORDER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); } while (0)
+// (out[plane][q]: the high / middle / low granule q; the image index of out[plane][q] is base + q + 2 bn plane)
+__device__ __forceinline__ int64_t x6_split_granules4(const float* __restrict__ W, int KH, int KW, int Ci, int Co,
+                                                      int mode, int chunks, int n_tiles, int bn, int64_t g, uint4 (&out)[3][4]) {
     const int nl = (int)(g % bn), kg = (int)((g / bn) & 1);
     int64_t blk = g / (2 * bn);
     const int n_tile = (int)(blk % n_tiles); blk /= n_tiles;
@@ -178,18 +182,32 @@ __device__ __forceinline__ void x6_split_granules4(const float* __restrict__ W, 
         uint2 h0, m0, l0, h1, m1, l1;
         split4(__builtin_bit_cast(u32x4, lo[q]), h0, m0, l0);
         split4(__builtin_bit_cast(u32x4, hi[q]), h1, m1, l1);
-        img[base + q] = make_uint4(h0.x, h0.y, h1.x, h1.y);
-        img[base + q + 2 * bn] = make_uint4(m0.x, m0.y, m1.x, m1.y);
-        img[base + q + 4 * bn] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        out[0][q] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        out[1][q] = make_uint4(m0.x, m0.y, m1.x, m1.y);
+        out[2][q] = make_uint4(l0.x, l0.y, l1.x, l1.y);
     }
+    return base;
 }
 
 // every image of a network in ONE launch (after an optimizer step): jobs[j] = {W, image, KH, KW, Ci, Co, mode, first granule
 // of the job in the launch-wide numbering}, jobs[n_jobs][7] = the total; a thread takes FOUR consecutive granules (every job's
 // granule count is a multiple of 4) and finds its job by bisection.
-__global__ __launch_bounds__(256) void x6_split_weights_multi_kernel(const int64_t* __restrict__ jobs, int n_jobs) {
-    const int64_t g = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (g >= jobs[(int64_t)n_jobs * 8 + 7]) return;
+// Stores: a thread's four granules are 64 consecutive bytes per plane, so a store instruction written per thread touches 64
+// separate segments per wave (the launch ran at 3.9 TB/s: 154 us for config 2's 30 M weights in both directions).  When a wave's
+// 256 granules belong to one job -- job starts are multiples of 128 granules, a wave straddles two jobs at most once per job --
+// they go through LDS ([plane][q][lane], rows 68 granules apart: both sides conflict-free) and every store instruction writes 64
+// consecutive granules = 1 KB (a 64-granule run never crosses an image block: blocks are 2 bn >= 128 granules): 119 us (a
+// probe with lane-contiguous stores and no exchange: 107; tools/x6/split_probe.py).  Same values, same places: bit-identical images.
+#ifndef X6_SPLIT_OCC                                     // waves per SIMD the register allocation is held to (tools/x6/split_probe.py, config 2's 30 M weights:
+#define X6_SPLIT_OCC 5                                   //  2: 137.5 us, 3: 136.0, 4: 124-128, 5: 119.3, 6: 174.8 (spills); unbounded the kernel took 134 VGPRs)
+#endif
+__global__ __launch_bounds__(256, X6_SPLIT_OCC) void x6_split_weights_multi_kernel(const int64_t* __restrict__ jobs, int n_jobs) {
+    __shared__ uint4 s_x[4][4 * 68];                     // per wave, one plane at a time (the exchange is wave-local: no workgroup barrier)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t total = jobs[(int64_t)n_jobs * 8 + 7];
+    int64_t g = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const bool live = g < total;
+    if (!live) g = total - 4;                            // (keeps the wave's control flow uniform up to the stores; stores nothing)
     int lo = 0, hi = n_jobs - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -200,12 +218,40 @@ __global__ __launch_bounds__(256) void x6_split_weights_multi_kernel(const int64
     const int Ck = mode ? Co : Ci, Cn = mode ? Ci : Co, bn = x6_bn(Cn);
     const float* W = reinterpret_cast<const float*>(j[0]);
     uint4* img = reinterpret_cast<uint4*>(j[1]);
-    if (((Ci | Co) & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0)
-        x6_split_granules4(W, img, KH, KW, Ci, Co, mode, (Ck + XBK - 1) / XBK, (Cn + bn - 1) / bn, bn, g - j[7]);
-    else
+    const bool vec = ((Ci | Co) & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0;
+    const int64_t gl = g - j[7];                         // granule within the job
+    // the wave's 256 granules: one job, all there, a vectorisable matrix, and 64-granule runs aligned in the job
+    const bool uni = __all(live && vec && lo == __builtin_amdgcn_readfirstlane(lo) && ((gl - 4 * lane) & 63) == 0);
+    uint4 out[3][4];
+    int64_t base = 0;
+    if (vec) base = x6_split_granules4(W, KH, KW, Ci, Co, mode, (Ck + XBK - 1) / XBK, (Cn + bn - 1) / bn, bn, gl, out);
+    if (uni) {
+        const int64_t g0 = gl - 4 * lane;                // the wave's first granule
+        int64_t at[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                    // run r: granules g0 + 64 r + lane, held by thread (64 r + lane) / 4 as its granule (lane & 3)
+            const int64_t gi = g0 + 64 * r + lane;
+            at[r] = (gi / (2 * bn)) * (6 * bn) + gi % (2 * bn);
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s_x[wave][q * 68 + lane] = out[pl][q];
+            X6_WAVE_LDS_ORDER();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) img[at[r] + 2 * bn * pl] = s_x[wave][(lane & 3) * 68 + 16 * r + (lane >> 2)];
+            X6_WAVE_LDS_ORDER();
+        }
+    } else if (live && vec) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            img[base + q] = out[0][q]; img[base + q + 2 * bn] = out[1][q]; img[base + q + 4 * bn] = out[2][q];
+        }
+    } else if (live) {
 #pragma unroll 1
         for (int q = 0; q < 4; ++q)
-            x6_split_granule(W, img, KH, KW, Ci, Co, mode, (Ck + XBK - 1) / XBK, (Cn + bn - 1) / bn, bn, g - j[7] + q);
+            x6_split_granule(W, img, KH, KW, Ci, Co, mode, (Ck + XBK - 1) / XBK, (Cn + bn - 1) / bn, bn, gl + q);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
