@@ -196,11 +196,11 @@ __device__ __forceinline__ int64_t x6_split_granules4(const float* __restrict__ 
 // separate segments per wave (the launch ran at 3.9 TB/s: 154 us for config 2's 30 M weights in both directions).  When a wave's
 // 256 granules belong to one job -- job starts are multiples of 128 granules, a wave straddles two jobs at most once per job --
 // they go through LDS ([plane][q][lane], rows 68 granules apart: both sides conflict-free) and every store instruction writes 64
-// consecutive granules = 1 KB (a 64-granule run never crosses an image block: blocks are 2 bn >= 128 granules): 119 us (a
+// consecutive granules = 1 KB (a 64-granule run never crosses an image block: blocks are 2 bn >= 128 granules): 124-128 us (a
 // probe with lane-contiguous stores and no exchange: 107; tools/x6/split_probe.py).  Same values, same places: bit-identical images.
 #ifndef X6_SPLIT_OCC                                     // waves per SIMD the register allocation is held to (tools/x6/split_probe.py, config 2's 30 M weights:
-#define X6_SPLIT_OCC 5                                   //  2: 137.5 us, 3: 136.0, 4: 124-128, 5: 119.3, 6: 174.8 (spills); unbounded the kernel took 134 VGPRs)
-#endif
+#define X6_SPLIT_OCC 4                                   //  2: 137.5 us, 3: 136.0, 4: 124-128, 5: 119.3 but 80 bytes of scratch (the ISA lint refuses it), 6: 174.8;
+#endif                                                   //  unbounded the kernel took 134 VGPRs = 3 waves)
 __global__ __launch_bounds__(256, X6_SPLIT_OCC) void x6_split_weights_multi_kernel(const int64_t* __restrict__ jobs, int n_jobs) {
     __shared__ uint4 s_x[4][4 * 68];                     // per wave, one plane at a time (the exchange is wave-local: no workgroup barrier)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

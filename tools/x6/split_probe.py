@@ -1,8 +1,8 @@
 """The whole-network weight split (x6_split_weights_multi_kernel, once per optimizer step) alone, on a job list of config 2's shape (30 M
 weights, both directions).  History: a thread wrote its four consecutive 16-byte granules per plane directly -- one store instruction of
 a wave touched 64 separate 64-byte segments -- 154.3 us = 3.9 TB/s; a probe build with lane-contiguous stores (wrong placement, same bytes)
-ran 106.9 us; the shipped kernel now exchanges the granules through LDS so that every store instruction writes 1 KB: 132 us, and 119.3 us
-with its registers held to five waves per SIMD (-DX6_SPLIT_OCC: 2 137.5, 3 136.0, 4 124-128, 5 119.3, 6 174.8 us).
+ran 106.9 us; the shipped kernel now exchanges the granules through LDS so that every store instruction writes 1 KB: 132 us, and 124-128 us
+with its registers held to four waves per SIMD (-DX6_SPLIT_OCC: 2 137.5, 3 136.0, 4 124-128, 5 119.3 with scratch spills, 6 174.8 us).
     python tools/x6/split_probe.py"""
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
