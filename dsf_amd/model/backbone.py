@@ -21,6 +21,11 @@ from .. import ops as _ops
 from ..streams import fork
 
 _BRIDGE_FORK = [os.environ.get("DSF_BRIDGE_FORK", "1") == "1"]
+# which of the two forked chains of the stage-2 forward the HOST issues first: "bridge" (MANO head -> MANO layer -> rasteriser -> offset
+# map, ~0.5 ms of host time for short launches) or "decoder" (three transposed convolutions + heads; the default: the main queue has its
+# long launches before the host turns to the short ones -- config 2 16.141 -> 16.107 ms in a same-box A/B, 12 blocks of 10, config 4
+# equal); see streams.fork.mark
+_BRIDGE_ORDER = [os.environ.get("DSF_BRIDGE_ORDER", "decoder")]
 
 BN_MOMENTUM = 0.1
 resnet = {18: (BasicBlock, [2, 2, 2, 2]), 50: (Bottleneck, [3, 4, 6, 3]), 101: (Bottleneck, [3, 4, 23, 3]),
@@ -199,12 +204,18 @@ class MANO_OCR_stage(_TwoBranchNet):
             # nothing of it until the stage-2 `cat` -- beside each other on forked streams (streams.py)
             c4, c4b = take_twin(self.layer4(self.layer3(self.layer2(self.layer1(c0)))))
             f = fork(c4.device, params=self)
+            first = _BRIDGE_ORDER[0] == "decoder"           # the decoder's launches are ISSUED first; both chains start at the fork point
+            if first:
+                f.mark()
+                feat = self.deconv_layer2(self.deconv_layer3(self.deconv_layer4(c4)))
+                pix = nn_conv.fused_heads(feat, self.finals)
             with f.branch(0, c4b):
                 mano = _head(self.mano_regress, c4b)
                 mano_img, mano_uvd, _, _ = render.render(mano, center, cube)
                 remap = joint2offset(mano_uvd, mano_img, 0.8, 64)
-            feat = self.deconv_layer2(self.deconv_layer3(self.deconv_layer4(c4)))
-            pix = nn_conv.fused_heads(feat, self.finals)
+            if not first:
+                feat = self.deconv_layer2(self.deconv_layer3(self.deconv_layer4(c4)))
+                pix = nn_conv.fused_heads(feat, self.finals)
             f.join()
         else:
             _, feat, pix, mano = self._run_trunk(c0, '')

@@ -72,13 +72,27 @@ class fork:
             self.on = cached[1]
         self.device, self.used = device, []
         self.cur = torch.cuda.current_stream(device) if self.on else None
+        self.ev = None
+
+    def mark(self):
+        """Fixes the fork POINT here: branches entered later start behind what the current stream holds NOW, not behind what the host
+        has queued on it by then -- the caller can issue the current stream's (long) chain first and the branch's afterwards, and the
+        two still run beside each other (the host needs ~0.5 ms to enqueue config 2's stage-2 bridge; issued first, the decoder's
+        launches waited for the host that long)."""
+        if self.on:
+            self.ev = torch.cuda.Event()
+            self.ev.record(self.cur)
+        return self
 
     def branch(self, slot, *reads):
         if not self.on:
             return contextlib.nullcontext()
         s = _stream(self.device, slot)
         if s not in self.used:
-            s.wait_stream(self.cur)
+            if self.ev is not None:
+                s.wait_event(self.ev)
+            else:
+                s.wait_stream(self.cur)
             self.used.append(s)
         for t in reads:
             if torch.is_tensor(t) and t.is_cuda:

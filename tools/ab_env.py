@@ -24,6 +24,9 @@ def sync_python_switches():
                        ("DSF_C1_STATS", nn_conv.C1_STATS), ("DSF_C1_BN", nn_norm.C1_BN)):
         if name in os.environ:
             cell[0] = os.environ[name] == "1"
+    from dsf_amd.model import backbone
+    if "DSF_BRIDGE_ORDER" in os.environ:
+        backbone._BRIDGE_ORDER[0] = os.environ["DSF_BRIDGE_ORDER"]
 
 
 args = types.SimpleNamespace(config=a.config, batch=0, backbone="", graph=False, no_graph=False, cpu_steps=0, init=a.init)
