@@ -80,3 +80,24 @@ def test_bad_arguments_are_refused():
     assert rc != 0
     rc = L.lib().dsf_conv_x6_forward_plan(I(1), I(8), I(8), I(16), I(8), I(8), I(16), I(3), I(3), I(1), I(3), I(1), I(1), ctypes.byref(v), None)
     assert rc != 0
+
+
+def test_stem_node_launches_have_names_and_unsupported_geometries_are_refused():
+    """the record kinds of nn_norm._StemFunction map onto the kernels rocprofv3 prints (bench.py's per-kernel table), and the stem entry
+    points refuse what they do not implement before touching any pointer (status codes only: no GPU here)"""
+    from dsf_amd import nn_conv
+    rec = lambda kind: (kind, 32, 128, 128, 1, 128, 128, 64, 5, 5, 1, 1, 2, 2)
+    assert nn_conv.kernel_name(rec("c1_fwd_bn")) == "conv_c1_fwd_stats_kernel<5, 1>"
+    assert nn_conv.kernel_name(rec("c1_wrw_bn1")) == "conv_c1_wrw_bn_kernel<5, 1, 1>"
+    assert nn_conv.kernel_name(("c1_wrw_bn0", 64, 256, 256, 1, 128, 128, 64, 7, 7, 2, 1, 3, 3)) == "conv_c1_wrw_bn_kernel<7, 2, 0>"
+    lib = L.lib()
+    one = ctypes.c_void_p(16)                                # a non-NULL address that is never dereferenced: the geometry is refused first
+    UNSUPPORTED, BAD = lib.dsf_conv_c1_wrw_bn(one, one, one, one, one, one, one, one, one, I(8), I(1), I(3), I(1), I(1), one, one, one, I(0), one, I(2),
+                                              I(16), I(16), I(16), I(16), I(64), I(5), I(1), I(2), ctypes.c_void_p(0)), \
+        lib.dsf_conv_c1_wrw_bn(one, one, one, None, one, one, one, one, one, I(8), I(1), I(3), I(2), I(1), one, one, one, I(0), one, I(2),
+                               I(16), I(16), I(16), I(16), I(64), I(5), I(1), I(2), ctypes.c_void_p(0))
+    assert UNSUPPORTED != 0 and BAD != 0 and UNSUPPORTED != BAD          # pooling (3, 1, 1): not implemented; a pooled call without argmax: bad argument
+    # 5 x 5 windows, more than 2 x 2 windows per pixel, a channel count the kernels do not cover
+    for k, s, p, C in ((5, 2, 2, 64), (3, 1, 1, 64), (3, 2, 1, 6)):
+        assert lib.dsf_bn_relu_pool_forward(one, one, one, I(2), I(16), I(16), I(C), I(k), I(s), I(p), ctypes.c_float(1e-5), ctypes.c_float(0.1), None, None,
+                                            one, one, one, one, one, I(0), ctypes.c_void_p(0)) == UNSUPPORTED
