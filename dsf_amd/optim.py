@@ -15,6 +15,8 @@ from ._lib import I, check, stream_ptr
 D = ctypes.c_double
 
 
+RING = 8          # pinned staging buffers of a pointer table: one is reused eight refreshes later
+
 class FusedAdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
@@ -43,8 +45,8 @@ class FusedAdamW(torch.optim.Optimizer):
               "rows": None, "ptrs": torch.empty((len(plist), 4), dtype=torch.int64, device=dev),
               # ring of pinned staging buffers for pointer-table refreshes: the copy is asynchronous (the host may run a
               # whole step ahead of the GPU), a buffer is reused only after the copy that read it has completed
-              "ring": [torch.empty((len(plist), 4), dtype=torch.int64).pin_memory() for _ in range(4)],
-              "ring_ev": [None] * 4, "ring_i": 0}
+              "ring": [torch.empty((len(plist), 4), dtype=torch.int64).pin_memory() for _ in range(RING)],
+              "ring_ev": [None] * RING, "ring_i": 0}
         self._tables[slot] = tb
         return tb
 
@@ -117,13 +119,16 @@ class FusedAdamW(torch.optim.Optimizer):
                     # addresses changed (first step, a different gradient block from the allocator, or the per-step flat
                     # buckets of data-parallel runs): refresh the device table without draining the stream
                     i = tb["ring_i"]
-                    if tb["ring_ev"][i] is not None:
+                    # (query first: hipEventSynchronize on an event that completed long ago still waited until the GPU had nearly
+                    #  caught up with the host -- 2 ms per step in which the host could have been enqueuing the next forward pass,
+                    #  tools/opt_block.py; the query does not)
+                    if tb["ring_ev"][i] is not None and not tb["ring_ev"][i].query():
                         tb["ring_ev"][i].synchronize()
                     tb["ring"][i].copy_(torch.tensor(rows, dtype=torch.int64))
                     tb["ptrs"].copy_(tb["ring"][i], non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record()
-                    tb["ring_ev"][i], tb["ring_i"], tb["rows"] = ev, (i + 1) % 4, rows
+                    tb["ring_ev"][i], tb["ring_i"], tb["rows"] = ev, (i + 1) % RING, rows
                 vp = lambda t: ctypes.c_void_p(t.data_ptr())
                 check(L.lib().dsf_adamw_multi(vp(tb["ptrs"]), vp(tb["sizes"]), vp(tb["chunk_tensor"]), vp(tb["chunk_index"]),
                                               I(tb["n_chunks"]), D(group["lr"]), D(b1), D(b2), D(group["eps"]),
