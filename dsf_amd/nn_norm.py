@@ -657,7 +657,7 @@ def conv_bn_act(conv, bn, x, residual=None, relu=None, twin=False, pool=None):
         return y if req.applied else bn(y, residual, r)
     fusable = (EPILOGUE_STATS[0] and isinstance(bn, FusedBatchNorm2d) and isinstance(conv, (nn_conv.Conv2d, nn_conv.ConvTranspose2d)) and bn.training and
                bn.track_running_stats and conv.bias is None and x.is_cuda and supported(bn.num_features) and nn_conv.STATS is None)
-    if residual is None and not twin and isinstance(bn, FusedBatchNorm2d):
+    if residual is None and not twin and getattr(conv, "in_channels", 0) == 1 and isinstance(bn, FusedBatchNorm2d):     # (a network's stem)
         out = _stem_node(conv, bn, x, bn.fuse_relu if relu is None else relu, pool)
         if out is not None:
             return out
