@@ -61,7 +61,7 @@ SYMBOLS = [
     "dsf_m2d_forward", "dsf_m2d_backward", "dsf_cube_points_forward", "dsf_cube_points_backward", "dsf_view_rotate", "dsf_part_mean_forward",
     "dsf_part_mean_backward", "dsf_mano_reg_forward", "dsf_mano_reg_backward", "dsf_cube_normalise", "dsf_m2p_forward", "dsf_m2p_backward", "dsf_sphere_mixed", "dsf_offset2joint_forward_strided", "dsf_offset2joint_backward_strided", "dsf_pool_linear_forward", "dsf_pool_linear_backward",
     "dsf_offset2joint_cl_workspace_floats", "dsf_offset2joint_forward_cl", "dsf_offset2joint_backward_cl",
-    "dsf_bn_relu_pool_forward", "dsf_bn_relu_pool_backward", "dsf_conv_c1_forward_bn_acc", "dsf_conv_c1_wrw_bn",
+    "dsf_bn_relu_pool_forward", "dsf_bn_relu_pool_backward", "dsf_conv_c1_forward_bn_acc", "dsf_conv_c1_wrw_bn", "dsf_cat_channels_nhwc",
 ]
 
 

@@ -1,6 +1,6 @@
 #include "common.h"
 
-extern "C" int dsf_abi_version(void) { return 5; }      // 2: dsf_mano_forward needs `save`, dsf_mano_backward takes `scratch`; 3: the exports of rounds 5-6 (.._plan, .._wrw_bias, .._pair, ..); 4: dsf_offset2joint_*_cl; 5: dsf_bn_relu_pool_*, dsf_conv_c1_forward_bn_acc, dsf_conv_c1_wrw_bn
+extern "C" int dsf_abi_version(void) { return 5; }      // 2: dsf_mano_forward needs `save`, dsf_mano_backward takes `scratch`; 3: the exports of rounds 5-6 (.._plan, .._wrw_bias, .._pair, ..); 4: dsf_offset2joint_*_cl; 5: dsf_bn_relu_pool_*, dsf_conv_c1_forward_bn_acc, dsf_conv_c1_wrw_bn, dsf_cat_channels_nhwc
 
 extern "C" const char* dsf_status_string(int s) {
     switch (s) {

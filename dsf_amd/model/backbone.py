@@ -222,7 +222,7 @@ class MANO_OCR_stage(_TwoBranchNet):
             # stage-2 bridge: render the stage-1 MANO estimate, re-encode it as an offset map (HIP kernels)
             mano_img, mano_uvd, _, _ = render.render(mano, center, cube)
             remap = joint2offset(mano_uvd, mano_img, 0.8, 64)
-        _, _, pix2, mano2 = self._run_trunk(self.fusion(torch.cat((c0, feat, pix, remap), dim=1)), '_s2')
+        _, _, pix2, mano2 = self._run_trunk(self.fusion(_ops.cat_channels((c0, feat, pix, remap))), '_s2')
         return [[pix, mano], [pix2, mano2]]
 
     def encoder(self, img):

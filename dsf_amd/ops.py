@@ -876,6 +876,45 @@ class PoolLinear(Function):
         return gx, gw, gb
 
 
+class CatChannels(Function):
+    """``torch.cat(maps, dim=1)`` of up to four channels-last fp32 maps in one launch (csrc/step_ops.hip: dsf_cat_channels_nhwc; the
+    stage-2 input of reference model/backbone.py:256); the gradients are the channel slices of the incoming one, as torch's"""
+
+    @staticmethod
+    def forward(ctx, *maps):
+        maps = [m.contiguous(memory_format=torch.channels_last) for m in maps]
+        B, _, H, W_ = maps[0].shape
+        cs = [m.shape[1] for m in maps]
+        out = torch.empty((B, sum(cs), H, W_), device=maps[0].device, dtype=torch.float32, memory_format=torch.channels_last)
+        a = [(L.addr(m), I(c)) for m, c in zip(maps, cs)] + [(None, I(0))] * (4 - len(maps))
+        check(L.lib().dsf_cat_channels_nhwc(a[0][0], a[0][1], a[1][0], a[1][1], a[2][0], a[2][1], a[3][0], a[3][1], L.addr(out),
+                                            ctypes.c_int64(B * H * W_), stream_ptr()), "dsf_cat_channels_nhwc")
+        ctx.cs = cs
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        outs, o = [], 0
+        for i, c in enumerate(ctx.cs):
+            outs.append(g.narrow(1, o, c) if ctx.needs_input_grad[i] else None)
+            o += c
+        return tuple(outs)
+
+
+CAT_FUSED = [os.environ.get("DSF_CAT", "1") == "1"]
+
+
+def cat_channels(maps):
+    """torch.cat(maps, dim=1); one launch for 2-4 channels-last fp32 GPU maps whose channel counts are multiples of 4 (DSF_CAT=0: torch's)"""
+    m0 = maps[0]
+    if (CAT_FUSED[0] and 2 <= len(maps) <= 4 and all(m.is_cuda and m.dim() == 4 and m.dtype == torch.float32 and m.shape[1] % 4 == 0 and
+                                                      m.shape[0] == m0.shape[0] and m.shape[2:] == m0.shape[2:] for m in maps)
+            and m0.numel() and sum(m.numel() for m in maps) // 4 < 2 ** 32):
+        return CatChannels.apply(*maps)
+    return torch.cat(tuple(maps), dim=1)
+
+
 def pool_linear(x, linear):
     """the fused head when it applies (GPU, fp32, C <= 2048, <= 64 outputs), else None"""
     if x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.shape[1] <= 2048 and linear.out_features <= 64 and x.shape[0] > 0 \

@@ -681,6 +681,11 @@ int dsf_pool_linear_forward(const float* x, const float* weight, const float* bi
                             float* out, dsf_stream_t stream);
 int dsf_pool_linear_backward(const float* grad_out, const float* pooled, const float* weight, int B, int HW, int C, int O,
                              float* grad_x, float* grad_weight, float* grad_bias, dsf_stream_t stream);
+/* torch.cat((a, b, c, d), dim = 1) of channels-last maps as one launch (the stage-2 input of reference model/backbone.py:256; ABI 5):
+ * out (pixels, ca + cb + cc + cd) from a (pixels, ca) ... d (pixels, cd); trailing sources may be absent (count 0, pointer NULL);
+ * channel counts are multiples of 4, pixels x total / 4 < 2^32, else DSF_ERR_UNSUPPORTED.  A copy: bit-exact. */
+int dsf_cat_channels_nhwc(const float* a, int ca, const float* b, int cb, const float* c, int cc, const float* d, int cd, float* out,
+                          int64_t pixels, dsf_stream_t stream);
 int dsf_part_mean_forward(const float* dis, const int64_t* seg, int B, int P, int n_parts, float* out, float* valid,
                           dsf_stream_t stream);
 int dsf_part_mean_backward(const float* grad_out, const int64_t* seg, const float* valid, int B, int P, int n_parts, float* grad_dis,

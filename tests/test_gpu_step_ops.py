@@ -303,3 +303,24 @@ def test_pooled_linear_head_in_one_launch(B, C, H):
     assert og[0].is_contiguous(memory_format=torch.channels_last)
     for a, b_ in zip(og, rg):
         assert _rel(a.double(), b_.double()) < 5e-6
+
+
+@pytest.mark.parametrize("B,H,W,cs", [(4, 16, 16, (64, 256, 84, 84)), (3, 7, 5, (8, 4)), (2, 9, 11, (4, 12, 8)), (1, 1, 1, (4, 4, 4, 4)), (5, 6, 6, (128, 128))])
+def test_channel_concatenation_in_one_launch_equals_torch_cat(B, H, W, cs):
+    """ops.cat_channels (dsf_cat_channels_nhwc): the output of torch.cat(dim=1) bit for bit, channels-last; the gradients are the slices"""
+    from dsf_amd import ops
+    g = torch.Generator().manual_seed(B + H + sum(cs))
+    maps = [torch.randn(B, c, H, W, generator=g).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(i != 1) for i, c in enumerate(cs)]
+    ref = [m.detach().clone().requires_grad_(m.requires_grad) for m in maps]
+    out = ops.cat_channels(maps)
+    want = torch.cat(ref, dim=1)
+    assert out.is_contiguous(memory_format=torch.channels_last) and torch.equal(out, want)
+    gy = torch.randn(out.shape, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    out.backward(gy); want.backward(gy)
+    for a, b in zip(maps, ref):
+        assert (a.grad is None) == (b.grad is None)
+        if a.grad is not None:
+            assert torch.equal(a.grad, b.grad)
+    # what the fused launch does not cover goes to torch.cat
+    odd = [torch.randn(2, 3, 4, 4, device="cuda"), torch.randn(2, 5, 4, 4, device="cuda")]
+    assert torch.equal(ops.cat_channels(odd), torch.cat(odd, dim=1))

@@ -20,7 +20,7 @@ a = ap.parse_args()
 def sync_python_switches():
     """switches that the Python side reads once at import (module-level lists): follow the environment"""
     from dsf_amd import nn_conv, nn_norm, ops
-    for name, cell in (("DSF_BN_TWIN", nn_norm.TWIN), ("DSF_BN_EPILOGUE", nn_norm.EPILOGUE_STATS), ("DSF_DECODE_CL", ops.DECODE_CL), ("DSF_BN_POOL", nn_norm.POOL_FUSED),
+    for name, cell in (("DSF_BN_TWIN", nn_norm.TWIN), ("DSF_BN_EPILOGUE", nn_norm.EPILOGUE_STATS), ("DSF_DECODE_CL", ops.DECODE_CL), ("DSF_CAT", ops.CAT_FUSED), ("DSF_BN_POOL", nn_norm.POOL_FUSED),
                        ("DSF_C1_STATS", nn_conv.C1_STATS), ("DSF_C1_BN", nn_norm.C1_BN)):
         if name in os.environ:
             cell[0] = os.environ[name] == "1"
