@@ -1,3 +1,5 @@
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/c83; mkdir -p $O; cd $R
-timeout 900 python3 -m pytest tests/test_gpu_step_ops.py -q -m gpu -k "concatenation" 2>&1 | tail -3
-timeout 900 python3 tools/ab_env.py --config 2 --var DSF_CAT --values 0 1 --block 10 --rounds 12 2>&1 | grep "^AB" | tee $O/ab_cat.txt
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/c84; mkdir -p $O; cd $R
+timeout 2400 python3 -m pytest tests -q -m gpu > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log; tail -n 3 $O/pytest_gpu.log
+bash tools/run_profiles.sh r06
+timeout 300 python3 tools/bn_pool_probe.py 2>&1 | grep -v amdgpu.ids > gpurun_out/prof_r06/r06_stem_probe.txt
+python3 -c "import json; d=json.loads(open('gpurun_out/prof_r06/r06_bench_default.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"
