@@ -21,6 +21,7 @@ from .. import ops as _ops
 from ..streams import fork
 
 _BRIDGE_FORK = [os.environ.get("DSF_BRIDGE_FORK", "1") == "1"]
+_HEAD_FORK = [os.environ.get("DSF_HEAD_FORK", "1") == "1"]     # _run_trunk: the MANO head beside the decoder (0: in front of it)
 # which of the two forked chains of the stage-2 forward the HOST issues first: "bridge" (MANO head -> MANO layer -> rasteriser -> offset
 # map, ~0.5 ms of host time for short launches) or "decoder" (three transposed convolutions + heads; the default: the main queue has its
 # long launches before the host turns to the short ones -- config 2 16.141 -> 16.107 ms in a same-box A/B, 12 blocks of 10, config 4
@@ -127,9 +128,19 @@ class _TwoBranchNet(nn.Module):
     def _run_trunk(self, x, suffix):
         g = lambda n: getattr(self, n + suffix)
         c4, c4b = take_twin(g('layer4')(g('layer3')(g('layer2')(g('layer1')(x)))))    # c4 is read twice: a handle each (nn_norm.take_twin)
+        heads = g('finals')
+        if _HEAD_FORK[0] and c4.is_cuda:
+            # the pooled MANO head is ONE workgroup per sample (65 us at B = 32 with an eighth of the chip busy, 2 x 29 us backward):
+            # beside the decoder on the branch stream instead of in front of it; the decoder's launches are issued first
+            f = fork(c4.device, params=self).mark()
+            feat = g('deconv_layer2')(g('deconv_layer3')(g('deconv_layer4')(c4)))
+            pix = nn_conv.fused_heads(feat, heads)
+            with f.branch(0, c4b):
+                mano = _head(g('mano_regress'), c4b)
+            f.join()
+            return c4, feat, pix, mano
         mano = _head(g('mano_regress'), c4b)
         feat = g('deconv_layer2')(g('deconv_layer3')(g('deconv_layer4')(c4)))
-        heads = g('finals')
         pix = nn_conv.fused_heads(feat, heads)
         return c4, feat, pix, mano
 

@@ -25,6 +25,8 @@ def sync_python_switches():
         if name in os.environ:
             cell[0] = os.environ[name] == "1"
     from dsf_amd.model import backbone
+    if "DSF_HEAD_FORK" in os.environ:
+        backbone._HEAD_FORK[0] = os.environ["DSF_HEAD_FORK"] == "1"
     if "DSF_BRIDGE_ORDER" in os.environ:
         backbone._BRIDGE_ORDER[0] = os.environ["DSF_BRIDGE_ORDER"]
 
