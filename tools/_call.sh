@@ -1,3 +1,3 @@
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/c86; mkdir -p $O; cd $R
-timeout 2400 python3 -m pytest tests -q -m gpu > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log; tail -n 3 $O/pytest_gpu.log
-timeout 300 python3 bench.py --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/c87; mkdir -p $O; cd $R
+timeout 900 python3 -m pytest tests/test_gpu_steps.py tests/test_gpu_determinism.py -q -x -m gpu 2>&1 | tail -3
+timeout 900 python3 tools/ab_env.py --config 2 --var DSF_EARLY_MODEL_TERMS --values 0 1 --block 10 --rounds 12 2>&1 | grep "^AB" | tee $O/ab_early.txt
