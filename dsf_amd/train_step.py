@@ -8,6 +8,7 @@ lines.  TensorBoard / cv2 drawing / ``xyz2error`` host metrics are out of scope 
 """
 import contextlib
 import math
+import os
 
 import numpy as np
 import torch
@@ -88,6 +89,9 @@ def _default_adamw(params, lr, weight_decay):
         from .optim import FusedAdamW
         return FusedAdamW(params, lr=lr, weight_decay=weight_decay)
     return torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay)
+
+
+FT_STREAMS = [os.environ.get("DSF_FT_STREAMS", "1") == "1"]      # FinetuneStageStep: forked chains on (see its __call__)
 
 
 class RenderSupervisedStep:
@@ -739,9 +743,12 @@ class FinetuneStageStep(_StepBase):
 
     def __call__(self, model_para, cube, img_r, center_r, cube_r, M_r, generator=None, draws=None):
         self._begin()
-        # (the forked chains of the network -- downsample arms, stage-2 bridge -- do not pay in this step, whose network runs twice per
-        #  pass beside the frozen generator: 87.3 ms with them off, 88.0 on, three alternating runs each)
-        with _stat_pool(self, self.net, applications=2), streams.disabled():     # the network sees the synthetic and the real batch
+        # (the forked chains of the network -- stage-2 bridge, MANO heads beside the decoders -- did not pay in this step through round 5
+        #  and most of round 6, whose network runs twice per pass beside the frozen generator: 87.3 ms with them off, 88.0 on; with the
+        #  MANO head of _run_trunk on the branch stream they do: 70.89 -> 70.16 ms, same box, 8 alternating blocks of 5.  DSF_FT_STREAMS=0:
+        #  one stream)
+        one_stream = streams.disabled() if not FT_STREAMS[0] else contextlib.nullcontext()
+        with _stat_pool(self, self.net, applications=2), one_stream:     # the network sees the synthetic and the real batch
             loss, terms = self.loss(model_para, cube, img_r, center_r, cube_r, M_r, generator, draws)
             self._optimise(loss)
         return loss.detach(), terms
