@@ -91,6 +91,7 @@ def _default_adamw(params, lr, weight_decay):
     return torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay)
 
 
+SYN_FORK = [os.environ.get("DSF_FT_SYN_FORK", "1") == "1"]      # FinetuneStageStep.loss: the synthetic batch's loss chains beside the real batch's forward
 FT_STREAMS = [os.environ.get("DSF_FT_STREAMS", "1") == "1"]      # FinetuneStageStep: forked chains on (see its __call__)
 
 
@@ -685,16 +686,22 @@ class FinetuneStageStep(_StepBase):
         # chain of ~35 scalar multiplies and adds, each with a backward launch of its own
         acc = []
         w = lambda t, k: t if k == 1 else t * k
-        for pixel_pd, mano_pd in outputs:
-            S = pixel_pd.size(-1)
-            pixel_gt = gfm.joint2feature(juvd_gt, img, cfg.feature_para, S, cfg.feature_type)
-            juvd = gfm.feature2joint(img, pixel_pd, cfg.feature_type, cfg.feature_para)
-            acc += [L1(pixel_pd, pixel_gt, weight=cfg.deconv_weight), L1(juvd, juvd_gt, weight=cfg.coord_weight)]
-            jx, mx = R.get_mesh_xyz(mano_pd)
-            acc += [L1(jx, jxyz_gt, weight=cfg.coord_weight), L1(mx, mesh_gt, weight=cfg.coord_weight),
-                    w(mano_layer.calculate_coll(jx, mx.detach()), cfg.coll_weight)]
+        # the synthetic batch's loss chains (encode / decode / Huber / MANO layer / collision: ~20 short launches, 64 workgroups each)
+        # on the branch stream, beside the network's pass over the REAL batch that the host issues next (DSF_FT_SYN_FORK=0: in front of it)
+        f_syn = fork(dev) if SYN_FORK[0] else None
+        with (f_syn.branch(0, *[t for o in outputs for t in o]) if f_syn is not None else contextlib.nullcontext()):
+            for pixel_pd, mano_pd in outputs:
+                S = pixel_pd.size(-1)
+                pixel_gt = gfm.joint2feature(juvd_gt, img, cfg.feature_para, S, cfg.feature_type)
+                juvd = gfm.feature2joint(img, pixel_pd, cfg.feature_type, cfg.feature_para)
+                acc += [L1(pixel_pd, pixel_gt, weight=cfg.deconv_weight), L1(juvd, juvd_gt, weight=cfg.coord_weight)]
+                jx, mx = R.get_mesh_xyz(mano_pd)
+                acc += [L1(jx, jxyz_gt, weight=cfg.coord_weight), L1(mx, mesh_gt, weight=cfg.coord_weight),
+                        w(mano_layer.calculate_coll(jx, mx.detach()), cfg.coll_weight)]
         # ---- real branch: teacher from the detached stage-2 outputs (:671-703) ----
         outputs = self.net(img_r, R, center=center_r, cube=cube_r)
+        if f_syn is not None:
+            f_syn.join()
         pix_t, mano_t = outputs[1][0].detach(), outputs[1][1].detach()
         with torch.no_grad():
             juvd_t = gfm.feature2joint(img_r, pix_t, cfg.feature_type, cfg.feature_para)
