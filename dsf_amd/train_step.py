@@ -91,6 +91,7 @@ def _default_adamw(params, lr, weight_decay):
     return torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay)
 
 
+S1_FORK = [os.environ.get("DSF_FT_S1_FORK", "1") == "1"]        # FinetuneStageStep.loss: the stage-1 student's loss chain beside stage 2's
 SYN_FORK = [os.environ.get("DSF_FT_SYN_FORK", "1") == "1"]      # FinetuneStageStep.loss: the synthetic batch's loss chains beside the real batch's forward
 FT_STREAMS = [os.environ.get("DSF_FT_STREAMS", "1") == "1"]      # FinetuneStageStep: forked chains on (see its __call__)
 
@@ -709,16 +710,20 @@ class FinetuneStageStep(_StepBase):
             mj_t, mm_t = R.get_mesh_xyz(mano_t)
             crop_r = u.crop_hand(img_r, mj_t, center_r, M_r, cube_r)
             joint_pcl, segment, pcl, _ = self._real_targets(crop_r, crop_r, jxyz_t, mj_t, mm_t, center_r, M_r, cube_r, d)
-        # ---- stage 1 student (:706-749) ----
+        # ---- stage 1 student (:706-749) ----  (its chain of short launches on the branch stream, beside stage 2's on this one:
+        # DSF_FT_S1_FORK=0 keeps them one after the other)
         pix1, mano1 = outputs[0]
-        juvd1 = gfm.feature2joint(img_r, pix1, cfg.feature_type, cfg.feature_para)
-        acc += [L1(pix1, pix_t, weight=cfg.deconv_weight), L1(juvd1, juvd_t, weight=cfg.coord_weight)]
-        img1, mjuvd1, mjxyz1, mesh1 = R.render(mano1, center_r, cube_r)
-        acc += [L1(mjxyz1, jxyz_t, weight=cfg.coord_weight), L1(mesh1, mm_t, weight=cfg.coord_weight),
-                w(mano_layer.calculate_coll(mjxyz1, mesh1.detach()), cfg.coll_weight)]
-        crop1 = u.crop_hand(img1, mj_t, center_r, M_r, cube_r)
-        acc += [w(m2d_loss(crop_r, crop1), cfg.model_weight), w(ICPLoss(mesh1, pcl, mano_layer.faces).mean(-1), cfg.model_weight),
-                w(JointICPLoss(mesh1, joint_pcl, mano_layer.joint_faces, segment).mean(-1).mean(-1), cfg.partICP_weight)]
+        f_s1 = fork(dev) if S1_FORK[0] else None
+        with (f_s1.branch(0, pix1, mano1, pix_t, juvd_t, jxyz_t, mj_t, mm_t, crop_r, joint_pcl, segment, pcl) if f_s1 is not None
+              else contextlib.nullcontext()):
+            juvd1 = gfm.feature2joint(img_r, pix1, cfg.feature_type, cfg.feature_para)
+            acc += [L1(pix1, pix_t, weight=cfg.deconv_weight), L1(juvd1, juvd_t, weight=cfg.coord_weight)]
+            img1, mjuvd1, mjxyz1, mesh1 = R.render(mano1, center_r, cube_r)
+            acc += [L1(mjxyz1, jxyz_t, weight=cfg.coord_weight), L1(mesh1, mm_t, weight=cfg.coord_weight),
+                    w(mano_layer.calculate_coll(mjxyz1, mesh1.detach()), cfg.coll_weight)]
+            crop1 = u.crop_hand(img1, mj_t, center_r, M_r, cube_r)
+            acc += [w(m2d_loss(crop_r, crop1), cfg.model_weight), w(ICPLoss(mesh1, pcl, mano_layer.faces).mean(-1), cfg.model_weight),
+                    w(JointICPLoss(mesh1, joint_pcl, mano_layer.joint_faces, segment).mean(-1).mean(-1), cfg.partICP_weight)]
         # ---- stage 2 (:752-808) ----
         pix2, mano2 = outputs[1]
         juvd2 = gfm.feature2joint(img_r, pix2, cfg.feature_type, cfg.feature_para)
@@ -744,6 +749,8 @@ class FinetuneStageStep(_StepBase):
         d2m, pd2m = d2m_b.mean(-1), pd2m_j.mean(-1).mean(-1)
         acc += [p2m, w(coll2, cfg.coll_weight), w(m2d2, cfg.model_weight), w(d2m, cfg.model_weight), w(pd2m, cfg.partICP_weight),
                 w(m2p, cfg.M2P_weight)]
+        if f_s1 is not None:
+            f_s1.join()
         total = torch.stack([t.reshape(()) for t in acc]).sum()
         terms = {"P2M": p2m, "m2d": m2d2, "d2m": d2m, "pd2m": pd2m, "M2P": m2p, "coll": coll2}
         return total, terms

@@ -25,6 +25,9 @@ def sync_python_switches():
         if name in os.environ:
             cell[0] = os.environ[name] == "1"
     from dsf_amd.model import backbone
+    if "DSF_FT_S1_FORK" in os.environ:
+        from dsf_amd import train_step
+        train_step.S1_FORK[0] = os.environ["DSF_FT_S1_FORK"] == "1"
     if "DSF_FT_SYN_FORK" in os.environ:
         from dsf_amd import train_step
         train_step.SYN_FORK[0] = os.environ["DSF_FT_SYN_FORK"] == "1"
