@@ -220,13 +220,11 @@ class _BNFunction(Function):
                 check(L.lib().dsf_maxpool_backward(_p(gy), _p(arg), _p(g_full), I(B), I(H), I(W), I(C), I(gy.shape[2]), I(gy.shape[3]), I(k),
                                                    I(s), I(p), stream_ptr()), "dsf_maxpool_backward")
                 gy = g_full
-        if pooled:
-            pass
-        elif acc is not None:
+        if not pooled and acc is not None:
             check(L.lib().dsf_bn_backward_acc_pair(_p(x), _p(gy), _p(gy2), _p(y), _p(gamma), _p(beta), _p(mean), _p(invstd), I64(M), I(C),
                                                    I(relu_mode), _p(gx), _p(gres_out), _p(gg_w), _p(gb_w), I(accumulate), _p(acc), stream_ptr()),
                   "dsf_bn_backward_acc_pair")
-        else:
+        elif not pooled:
             ws = _workspace(x.device, C)
             check(L.lib().dsf_bn_backward_pair(_p(x), _p(gy), _p(gy2), _p(y), _p(gamma), _p(beta), _p(mean), _p(invstd), I64(M), I(C),
                                                I(relu_mode), _p(gx), _p(gres_out), _p(gg_w), _p(gb_w), I(accumulate), _p(ws), stream_ptr()),
